@@ -1,0 +1,332 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by importing the *reference* (IceLab-X/FidelityFusion,
+read-only at /root/reference) in THIS container.  The reference has no tests of its own
+(SURVEY.md section 4), so parity is pinned by outputs of the reference itself run here.
+
+Only data (inputs, hyper-parameters, expected outputs) is written to tests/golden/*.npz;
+no reference source travels.  Run:
+
+    PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python tests/golden/gen_goldens.py
+
+The GPU box has no /root/reference: tests there read only the committed .npz files.
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+os.environ.setdefault("MPLBACKEND", "Agg")
+
+import numpy as np
+import torch
+
+REF = os.environ.get("FFGP_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _install_tensorly_stub():
+    """tensorly is not installed here; the Cholesky hot path never calls it, but several reference
+    modules import it at module top.  Provide mode_dot & friends with real mode-n-product semantics."""
+    tl = types.ModuleType("tensorly")
+    tenalg = types.ModuleType("tensorly.tenalg")
+
+    def mode_dot(tensor, matrix, mode):
+        # mode-n product: contracts tensor's axis `mode` with matrix's axis 1
+        t = torch.movedim(tensor, mode, -1)
+        r = t @ matrix.transpose(-1, -2) if matrix.dim() == 2 else t @ matrix
+        return torch.movedim(r, -1, mode)
+
+    def multi_mode_dot(tensor, matrices, modes=None, transpose=False):
+        modes = list(range(len(matrices))) if modes is None else modes
+        for m, mode in zip(matrices, modes):
+            tensor = mode_dot(tensor, m.T if transpose else m, mode)
+        return tensor
+
+    def tucker_to_tensor(tucker, **kw):
+        core, factors = tucker
+        return multi_mode_dot(core, factors)
+
+    tl.set_backend = lambda name: None
+    tl.tenalg = tenalg
+    tl.ones = lambda shape, **kw: torch.ones(shape)
+    tl.tensor_to_vec = lambda t: t.reshape(-1)
+    tl.tucker_to_tensor = tucker_to_tensor
+    tenalg.mode_dot = mode_dot
+    tenalg.multi_mode_dot = multi_mode_dot
+    tl.tucker_tensor = types.ModuleType("tensorly.tucker_tensor")
+    tl.tucker_tensor.tucker_to_tensor = tucker_to_tensor
+    sys.modules["tensorly"] = tl
+    sys.modules["tensorly.tenalg"] = tenalg
+    sys.modules["tensorly.tucker_tensor"] = tl.tucker_tensor
+
+
+def npy(t):
+    if isinstance(t, torch.Tensor):
+        return t.detach().cpu().numpy().astype(np.float64)
+    return np.asarray(t, dtype=np.float64)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: npy(v) for k, v in arrays.items()})
+    print("wrote", path, {k: np.shape(v) for k, v in arrays.items()})
+
+
+def make_xy(g, n, D, d, scale=1.0):
+    X = torch.rand(n, D, generator=g, dtype=torch.float64) * scale
+    W = torch.rand(D, d, generator=g, dtype=torch.float64)
+    Y = torch.sin(2 * np.pi * X @ W) + 0.1 * torch.randn(n, d, generator=g, dtype=torch.float64)
+    return X, Y
+
+
+def main():
+    _install_tensorly_stub()
+    sys.path.insert(0, REF)
+    cwd = os.getcwd()
+    os.chdir("/tmp")  # keep any stray relative output away from the reference and the repo
+    torch.set_default_dtype(torch.float64)
+
+    import GaussianProcess.kernel as rk
+    import GaussianProcess.gp_computation_pack as rpack
+    from GaussianProcess.cigp_v10 import cigp as RCIGP
+    from GaussianProcess.gp_basic import GP_basic as RGPB
+    from MFGP_ver2023May.base_gp.cigp import CIGP as RCIGP23
+    from MFGP_ver2023May.kernel.SE_kernel import SE_kernel as RSE23
+
+    g = torch.Generator().manual_seed(20260103)
+
+    # ------------------------------------------------------------------ kernels K1-K3
+    for D in (1, 5, 16):
+        x1 = torch.rand(65, D, generator=g) * 3 - 1
+        x2 = torch.rand(33, D, generator=g) * 3 - 1
+        xs = torch.rand(17, D, generator=g)  # <=25 rows: cdist takes the direct (non-matmul) path
+        ls = (torch.rand(D, generator=g) * 1.5 + 0.5) * torch.where(torch.rand(D, generator=g) > 0.5, 1.0, -1.0)
+        sv = torch.tensor([-1.7])
+        k = rk.ARDKernel(D)
+        with torch.no_grad():
+            k.length_scales.copy_(ls)
+            k.signal_variance.copy_(sv)
+            save(f"k_ard_D{D}", x1=x1, x2=x2, xs=xs, length_scales=ls, signal_variance=sv,
+                 K12=k(x1, x2), K11=k(x1, x1), Kss=k(xs, xs), K1s=k(x1, xs))
+        k = rk.SquaredExponentialKernel(length_scale=0.3, signal_variance=-0.2)
+        with torch.no_grad():
+            save(f"k_se_D{D}", x1=x1, x2=x2, length_scale=k.length_scale, signal_variance=k.signal_variance,
+                 K12=k(x1, x2), K11=k(x1, x1))
+        for fmt, lsv, scv in ((False, 1.3, 0.7), (True, 1.3, 0.7)):
+            k = RSE23(fmt, lsv, scv)
+            with torch.no_grad():
+                save(f"k_se2023_D{D}_{'exp' if fmt else 'lin'}", x1=x1, x2=x2, length_scale=k.length_scale,
+                     scale=k.scale, exp_format=float(fmt), K12=k(x1, x2), K11=k(x1, x1))
+
+    # ------------------------------------------------------------------ NLML V1 (cigp_v10), grads
+    for tag, n, D, d, use_yvar, kern in (
+        ("ard_d1", 257, 5, 1, False, "ard"),
+        ("ard_d7", 257, 5, 7, False, "ard"),
+        ("ard_d7_yvar", 257, 5, 7, True, "ard"),
+        ("se_d3", 130, 3, 3, False, "se"),
+        ("se_d3_yvar", 130, 3, 3, True, "se"),
+        ("ard_n64", 64, 2, 2, False, "ard"),
+        ("ard_n1", 1, 2, 1, False, "ard"),
+    ):
+        X, Y = make_xy(g, n, D, d)
+        Y = Y.clone().requires_grad_(True)
+        if kern == "ard":
+            k = rk.ARDKernel(D)
+            with torch.no_grad():
+                k.length_scales.copy_((torch.rand(D, generator=g) + 0.5) *
+                                      torch.where(torch.rand(D, generator=g) > 0.3, 1.0, -1.0))
+                k.signal_variance.copy_(torch.tensor([-0.9 if n > 1 else 1.2]))
+        else:
+            k = rk.SquaredExponentialKernel(length_scale=-0.4, signal_variance=0.25)
+        m = RCIGP(k, log_beta=0.7)
+        yv = None
+        if use_yvar:
+            B = torch.rand(n, n, generator=g)
+            yv = (B @ B.T) / n * 0.05 + torch.diag(torch.rand(n, generator=g) * 0.3)
+        ll = m.negative_log_likelihood(X, [Y, yv] if use_yvar else Y)
+        ll.backward()
+        arrs = dict(X=X, Y=Y, log_beta=m.log_beta, ll=ll, g_log_beta=m.log_beta.grad, g_Y=Y.grad,
+                    g_signal_variance=k.signal_variance.grad, signal_variance=k.signal_variance)
+        if kern == "ard":
+            arrs.update(length_scales=k.length_scales, g_length_scales=k.length_scales.grad)
+        else:
+            arrs.update(length_scale=k.length_scale, g_length_scale=k.length_scale.grad)
+        if use_yvar:
+            arrs["y_var"] = yv
+        # prediction P1 (y_var ignored, noise on all entries)
+        Xs = torch.rand(19, D, generator=g)
+        with torch.no_grad():
+            mean, var = m(X, [Y.detach(), yv] if use_yvar else Y.detach(), Xs)
+        arrs.update(Xs=Xs, mean=mean, var=var)
+        save(f"nlml_v1_cigp_{tag}", **arrs)
+
+    # ------------------------------------------------------------------ NLML V1 pack variant (mean-K jitter)
+    for tag, n, D, d in (("d1", 200, 4, 1), ("d5", 129, 6, 5)):
+        X, Y = make_xy(g, n, D, d)
+        Y = Y.clone().requires_grad_(True)
+        k = rk.ARDKernel(D)
+        with torch.no_grad():
+            k.length_scales.copy_(torch.rand(D, generator=g) + 0.4)
+            k.signal_variance.copy_(torch.tensor([1.9]))
+        log_beta = torch.tensor([0.3], requires_grad=True)
+        ll = rpack.negative_log_likelihood(k, log_beta, X, Y)
+        ll.backward()
+        save(f"nlml_v1_pack_{tag}", X=X, Y=Y, log_beta=log_beta, ll=ll, g_log_beta=log_beta.grad, g_Y=Y.grad,
+             length_scales=k.length_scales, g_length_scales=k.length_scales.grad,
+             signal_variance=k.signal_variance, g_signal_variance=k.signal_variance.grad)
+
+    # ------------------------------------------------------------------ 2023 CIGP (S4/L1/P3)
+    for tag, n, D, d, y_var in (("d1", 150, 3, 1, 0.0), ("d4_yvar", 128, 5, 4, 0.01)):
+        X, Y = make_xy(g, n, D, d)
+        Y = Y.clone().requires_grad_(True)
+        m = RCIGP23({"noise": {"init_value": 20.0, "format": "exp"},
+                     "kernel": {"SE": {"noise_exp_format": True, "length_scale": 1.0, "scale": 1.0}}})
+        with torch.no_grad():
+            m.kernel.length_scale.copy_(torch.tensor(0.8))
+            m.kernel.scale.copy_(torch.tensor(1.4))
+        nll = m.compute_loss(X, Y, y_var=y_var)
+        nll.backward()
+        Xs = torch.rand(21, D, generator=g)
+        u, vd = m.forward(Xs)
+        save(f"nlml_v1_cigp2023_{tag}", X=X, Y=Y, y_var=y_var, noise_value=m.noise_box.value,
+             exp_format=float(m.kernel.noise_exp_format is True),
+             length_scale=m.kernel.length_scale, scale=m.kernel.scale, nll=nll,
+             g_noise_value=m.noise_box.value.grad, g_length_scale=m.kernel.length_scale.grad,
+             g_scale=m.kernel.scale.grad, g_Y=Y.grad, Xs=Xs, u=u, var_diag=vd)
+
+    # ------------------------------------------------------------------ V2 (Sigma^-2 quirk), cond. Gaussian, GP_basic
+    for tag, n, D, d in (("d1", 120, 3, 1), ("d6", 140, 4, 6)):
+        X, Y = make_xy(g, n, D, d)
+        k = rk.ARDKernel(D)
+        with torch.no_grad():
+            k.length_scales.copy_(torch.rand(D, generator=g) + 0.5)
+            cov = k(X, X) + 0.2 * torch.eye(n)
+        cov = cov.clone().requires_grad_(True)
+        Yg = Y.clone().requires_grad_(True)
+        ll = rpack.Gaussian_log_likelihood(Yg, cov, Kinv_method="cholesky3")
+        ll.sum().backward()
+        Xs = torch.rand(23, D, generator=g)
+        with torch.no_grad():
+            Ks, Kss = k(X, Xs), k(Xs, Xs)
+            mu, c = rpack.conditional_Gaussian(Y, cov.detach(), Ks, Kss, Kinv_method="cholesky3")
+        save(f"nlml_v2_{tag}", Y=Y, cov=cov, ll=ll, ll_shape=np.array(ll.shape, dtype=np.float64),
+             g_cov=cov.grad, g_Y=Yg.grad, Ks=Ks, Kss=Kss, mu=mu, cond_cov=c)
+        # GP_basic end-to-end ('cholesky3')
+        gp = RGPB(k, noise_variance=0.45)
+        Yb = Y.clone().requires_grad_(True)
+        llb = gp.log_likelihood(X, Yb)
+        llb.sum().backward()
+        with torch.no_grad():
+            mub, varb = gp.forward(X, Y, Xs)
+        B = torch.rand(n, n, generator=g)
+        yv = (B @ B.T) / n * 0.02
+        with torch.no_grad():
+            llv = gp.log_likelihood(X, [Y, yv])
+            muv, varv = gp.forward(X, [Y, yv], Xs)
+        save(f"gp_basic_{tag}", X=X, Y=Y, Xs=Xs, length_scales=k.length_scales, signal_variance=k.signal_variance,
+             noise_variance=gp.noise_variance, ll=llb, g_noise_variance=gp.noise_variance.grad,
+             g_length_scales=k.length_scales.grad, g_signal_variance=k.signal_variance.grad, g_Y=Yb.grad,
+             mu=mub, var=varb, y_var=yv, ll_yvar=llv, mu_yvar=muv, var_yvar=varv)
+
+    # ------------------------------------------------------------------ ResGP chain, 2024 API, 5 Adam steps/fidelity
+    from FidelityFusion_Models.ResGP import ResGP as RResGP, train_ResGP
+    from FidelityFusion_Models.MF_data import MultiFidelityDataManager
+    torch.manual_seed(7)
+    x_all = torch.rand(120, 2) * 4
+    il = torch.sort(torch.randperm(120)[:80]).values
+    ih = torch.sort(torch.randperm(120)[:50]).values
+    xl, xh = x_all[il], x_all[ih]
+    f = lambda x: torch.sin(x.sum(1, keepdim=True))
+    yl = f(xl) - 0.4 * torch.sin(2 * xl[:, :1]) + 0.05 * torch.rand(80, 1)
+    yh = f(xh) + 0.05 * torch.rand(50, 1)
+    xt = torch.rand(15, 2) * 4
+    data = [{"raw_fidelity_name": "0", "fidelity_indicator": 0, "X": xl, "Y": yl},
+            {"raw_fidelity_name": "1", "fidelity_indicator": 1, "X": xh, "Y": yh}]
+    mgr = MultiFidelityDataManager(data)
+    model = RResGP(2, [rk.SquaredExponentialKernel() for _ in range(2)], if_nonsubset=True)
+    losses = []
+    _orig = RCIGP.negative_log_likelihood
+
+    def _spy(self, x, y):
+        r = _orig(self, x, y)
+        losses.append(float(r))
+        return r
+
+    RCIGP.negative_log_likelihood = _spy
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        train_ResGP(model, mgr, max_iter=5, lr_init=1e-2, debugger=None)
+    RCIGP.negative_log_likelihood = _orig
+    with torch.no_grad():
+        xtn = mgr.normalizelayer[1].normalize_x(xt)
+        yp, vp = model(mgr, xtn)
+    sd = {k.replace(".", "__"): v for k, v in model.state_dict().items()}
+    x0n, y0n = mgr.get_data(0, normal=True)
+    xr, yr = mgr.get_data_by_name("res-1")
+    save("resgp_chain", xl=xl, yl=yl, xh=xh, yh=yh, xt=xt, xtn=xtn, x0n=x0n, y0n=y0n,
+         x_res=xr, y_res_mean=yr[0], y_res_var=yr[1], ll_trace=np.array(losses), ypred=yp, var_pred=vp, **sd)
+
+    # ------------------------------------------------------------------ CIGAR-style per-fidelity blocks (sharded sum)
+    F, n, D, d = 4, 256, 4, 32
+    blocks = {}
+    total = 0.0
+    for fi in range(F):
+        X, Y = make_xy(g, n, D, d)
+        k = rk.ARDKernel(D)
+        with torch.no_grad():
+            k.length_scales.copy_(torch.rand(D, generator=g) + 0.5)
+        m = RCIGP(k, log_beta=1.0)
+        ll = m.negative_log_likelihood(X, Y)
+        total += float(ll)
+        blocks.update({f"X{fi}": X, f"Y{fi}": Y, f"length_scales{fi}": k.length_scales,
+                       f"signal_variance{fi}": k.signal_variance, f"log_beta{fi}": m.log_beta, f"ll{fi}": ll})
+    save("cigar_blocks", F=float(F), ll_sum=total, **blocks)
+
+    # ------------------------------------------------------------------ 2023 ResGP joint loss (config-1 plumbing)
+    try:
+        from MFGP_ver2023May.ResGP import ResGP as RResGP23
+        xin = np.load(os.path.join(REF, "assets/MF_data/Poisson_data/input.npy"))
+        xtr = torch.tensor(xin[:128], dtype=torch.float64)
+        xev = torch.tensor(xin[128:160], dtype=torch.float64)
+        gg = torch.Generator().manual_seed(5)
+        W = torch.rand(xtr.shape[1], 8, generator=gg)
+        f0 = lambda x: torch.sin(x @ W)
+        ys = [f0(xtr) * 0.8 + 0.1, f0(xtr)]
+        m23 = RResGP23({"fidelity_shapes": [(8,), (8,)]}) if False else None
+        cfg = {"fidelity_shapes": [ys[0].shape[1:], ys[1].shape[1:]]}
+        m23 = RResGP23(cfg)
+        m23 = m23.double()
+        opt = torch.optim.Adam(m23.parameters(), lr=0.01)
+        tr = []
+        for _ in range(10):
+            opt.zero_grad()
+            nll = m23.compute_loss(xtr, ys)
+            tr.append(float(nll))
+            nll.backward()
+            opt.step()
+        with torch.no_grad():
+            pm, pv = m23(xev)
+        sd = {k.replace(".", "__"): v for k, v in m23.state_dict().items()}
+        save("resgp2023_demo", x_train=xtr, y0=ys[0], y1=ys[1], x_eval=xev, nll_trace=np.array(tr),
+             pred_mean=pm, pred_var=pv, **sd)
+    except Exception as e:  # noqa
+        print("resgp2023_demo skipped:", repr(e))
+
+    # ------------------------------------------------------------------ loose known answers from the reference's own log
+    rows = {}
+    try:
+        with open(os.path.join(REF, "FidelityFusion_Models/log/ResGP/train.log")) as fh:
+            lines = fh.readlines()
+        import re
+        for ln in (201, 401, 601):
+            nums = [float(v) for v in re.findall(r"tensor\(\[?(-?\d+\.\d+)", lines[ln - 1])]
+            rows[f"line{ln}"] = np.array(nums)
+        save("train_log_resgp", **rows)
+    except Exception as e:  # noqa
+        print("train_log_resgp skipped:", repr(e))
+
+    os.chdir(cwd)
+
+
+if __name__ == "__main__":
+    main()

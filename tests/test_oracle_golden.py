@@ -1,0 +1,156 @@
+"""CPU: pin the oracle (oracle/gp_oracle.py) against vectors captured from the imported reference
+(tests/golden/gen_goldens.py).  fp64 tolerance 1e-10 relative unless a fixture documents otherwise."""
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as O
+
+RTOL = 1e-10
+
+
+def close(a, b, rtol=RTOL, atol=None):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = max(np.abs(b).max(), 1e-300) if b.size else 1.0
+    atol = rtol * scale if atol is None else atol
+    np.testing.assert_allclose(a, b.reshape(a.shape), rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("D", [1, 5, 16])
+def test_k_ard(golden, D):
+    g = golden(f"k_ard_D{D}")
+    for a, b, key in (("x1", "x2", "K12"), ("x1", "x1", "K11"), ("xs", "xs", "Kss"), ("x1", "xs", "K1s")):
+        close(O.ard_kernel(g[a], g[b], g["length_scales"], g["signal_variance"]), g[key], 1e-12)
+
+
+@pytest.mark.parametrize("D", [1, 5, 16])
+def test_k_se(golden, D):
+    g = golden(f"k_se_D{D}")
+    close(O.se_kernel(g["x1"], g["x2"], g["length_scale"], g["signal_variance"]), g["K12"], 1e-12)
+    close(O.se_kernel(g["x1"], g["x1"], g["length_scale"], g["signal_variance"]), g["K11"], 1e-12)
+
+
+@pytest.mark.parametrize("D", [1, 5, 16])
+@pytest.mark.parametrize("fmt", ["lin", "exp"])
+def test_k_se2023(golden, D, fmt):
+    g = golden(f"k_se2023_D{D}_{fmt}")
+    close(O.se_kernel_2023(g["x1"], g["x2"], g["length_scale"], g["scale"], bool(g["exp_format"])), g["K12"], 1e-12)
+    close(O.se_kernel_2023(g["x1"], g["x1"], g["length_scale"], g["scale"], bool(g["exp_format"])), g["K11"], 1e-12)
+
+
+CIGP_CASES = ["ard_d1", "ard_d7", "ard_d7_yvar", "se_d3", "se_d3_yvar", "ard_n64", "ard_n1"]
+
+
+@pytest.mark.parametrize("tag", CIGP_CASES)
+def test_nlml_v1_cigp(golden, tag):
+    g = golden("nlml_v1_cigp_" + tag)
+    kind = "ard" if "length_scales" in g else "se"
+    ls = g["length_scales"] if kind == "ard" else g["length_scale"]
+    ll, gr = O.cigp_ll_and_grads(g["X"], g["Y"], ls, g["signal_variance"], g["log_beta"], g.get("y_var"), kind)
+    close(ll, g["ll"])
+    close(gr["log_beta"], g["g_log_beta"], 1e-9)
+    close(gr["Y"], g["g_Y"], 1e-9)
+    close(gr["signal_variance"], g["g_signal_variance"], 1e-9)
+    close(gr["length_scales" if kind == "ard" else "length_scale"],
+          g["g_length_scales" if kind == "ard" else "g_length_scale"], 1e-9)
+    # posterior P1
+    if kind == "ard":
+        kf = lambda a, b: O.ard_kernel(a, b, ls, g["signal_variance"])
+    else:
+        kf = lambda a, b: O.se_kernel(a, b, ls, g["signal_variance"])
+    mean, var = O.cigp_forward(g["X"], g["Y"], g["Xs"], kf, g["log_beta"])
+    close(mean, g["mean"], 1e-9)
+    close(var, g["var"], 1e-9)
+
+
+@pytest.mark.parametrize("tag", ["d1", "d5"])
+def test_nlml_v1_pack(golden, tag):
+    g = golden("nlml_v1_pack_" + tag)
+    ll, gr = O.pack_ll_and_grads(g["X"], g["Y"], g["length_scales"], g["signal_variance"], g["log_beta"])
+    close(ll, g["ll"])
+    for k in ("log_beta", "Y", "signal_variance", "length_scales"):
+        close(gr[k], g["g_" + k], 1e-9)
+
+
+@pytest.mark.parametrize("tag", ["d1", "d4_yvar"])
+def test_cigp2023(golden, tag):
+    g = golden("nlml_v1_cigp2023_" + tag)
+    fmt = bool(g["exp_format"])
+    nll, gr = O.cigp2023_nll_and_grads(g["X"], g["Y"], g["length_scale"], g["scale"], fmt, g["noise_value"],
+                                       float(g["y_var"]))
+    # the noise box is hard-wired float32 in the reference (utils/gp_noise.py:17,19): exp() and pow(-1) run
+    # in fp32 (torch's fp32 exp and numpy's may differ by 1 ulp = 6e-8 in the noise), hence the looser bars
+    close(nll, g["nll"], 1e-6)
+    # d nll/d noise = -tr(G)/noise is a difference of two O(N) terms; fp32 rounding of the noise moves it by ~1e-5
+    close(gr["noise_value"], g["g_noise_value"], 1e-6, atol=5e-5)
+    close(gr["length_scale"], g["g_length_scale"], 1e-6)
+    close(gr["scale"], g["g_scale"], 1e-6)
+    close(gr["Y"], g["g_Y"], 1e-6)
+    u, vd = O.cigp2023_forward(g["X"], g["Y"], g["Xs"], g["length_scale"], g["scale"], fmt, g["noise_value"])
+    close(u, g["u"], 1e-6)
+    close(vd, g["var_diag"], 1e-6)
+
+
+@pytest.mark.parametrize("tag", ["d1", "d6"])
+def test_v2_and_conditional(golden, tag):
+    g = golden("nlml_v2_" + tag)
+    ll, g_cov, g_Y = O.ll_v2_grads(g["Y"], g["cov"])
+    close(ll, g["ll"])
+    assert tuple(int(v) for v in g["ll_shape"]) == ((1, 1) if g["Y"].shape[1] == 1 else ())
+    close(g_cov, g["g_cov"], 1e-8)
+    close(g_Y, g["g_Y"], 1e-9)
+    mu, cov = O.conditional_gaussian(g["Y"], g["cov"], g["Ks"], g["Kss"])
+    close(mu, g["mu"], 1e-9)
+    close(cov, g["cond_cov"], 1e-9)
+
+
+@pytest.mark.parametrize("tag", ["d1", "d6"])
+def test_gp_basic(golden, tag):
+    g = golden("gp_basic_" + tag)
+    kf = lambda a, b: O.ard_kernel(a, b, g["length_scales"], g["signal_variance"])
+    S = O.sigma_basic(kf(g["X"], g["X"]), g["noise_variance"])
+    ll, _, _ = O.ll_v2(g["Y"], S)
+    close(ll, g["ll"])
+    mu, var = O.gp_basic_forward(g["X"], g["Y"], g["Xs"], kf, g["noise_variance"])
+    close(mu, g["mu"], 1e-9)
+    close(var, g["var"], 1e-9)
+    S = O.sigma_basic(kf(g["X"], g["X"]), g["noise_variance"], g["y_var"])
+    ll, _, _ = O.ll_v2(g["Y"], S)
+    close(ll, g["ll_yvar"])
+    mu, var = O.gp_basic_forward(g["X"], g["Y"], g["Xs"], kf, g["noise_variance"], g["y_var"])
+    close(mu, g["mu_yvar"], 1e-9)
+    close(var, g["var_yvar"], 1e-9)
+
+
+def test_cigar_blocks_sum(golden):
+    g = golden("cigar_blocks")
+    tot = 0.0
+    for f in range(int(g["F"])):
+        ll, _ = O.cigp_ll_and_grads(g[f"X{f}"], g[f"Y{f}"], g[f"length_scales{f}"], g[f"signal_variance{f}"],
+                                    g[f"log_beta{f}"])
+        close(ll, g[f"ll{f}"])
+        tot += ll
+    close(tot, g["ll_sum"])
+
+
+def test_unblocked_restatements_agree_with_lapack():
+    rng = np.random.default_rng(3)
+    B = rng.standard_normal((40, 40))
+    S = B @ B.T + 40 * np.eye(40)
+    close(O.cholesky_unblocked(S), O.cholesky_lower(S), 1e-12)
+    Y = rng.standard_normal((40, 3))
+    L = O.cholesky_lower(S)
+    close(O.solve_lower_loops(L, Y), O.solve_lower(L, Y), 1e-12)
+    with pytest.raises(np.linalg.LinAlgError):
+        O.cholesky_unblocked(-S)
+    with pytest.raises(np.linalg.LinAlgError):
+        O.cholesky_lower(-S)
+
+
+def test_pi_quirk_constant():
+    # L1 uses 3.1415, not pi: the constant term differs by 0.5*N*d*log(pi/3.1415)
+    X, Y = O.synthetic_xy(50, 3, 2, seed=1)
+    K = O.ard_kernel(X, X, np.ones(3), 1.0)
+    a, _, _ = O.nll_v1_from_sigma(O.sigma_cigp(K, 1.0), Y)
+    b, _, _ = O.nll_v1_from_sigma(O.sigma_cigp(K, 1.0), Y, pi_const=np.pi)
+    close(b - a, 0.5 * 50 * 2 * np.log(np.pi / 3.1415), 1e-9)
