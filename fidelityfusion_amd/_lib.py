@@ -1,0 +1,148 @@
+"""ctypes binding of libffgp.so (include/ffgp.h) -- the reference-side stub of the C ABI.
+
+The library is built in-tree by `python __graft_entry__.py` (hipcc, gfx950) and loaded from the package
+directory.  There is no CPU or torch fallback: if the shared object is missing the import fails, and if no
+MI355X is visible `handle()` raises.
+"""
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libffgp.so")
+
+FFGP_LL_V1, FFGP_LL_V2 = 1, 2
+FFGP_VAR_FULL, FFGP_VAR_DIAG = 0, 1
+PI_TRUNC = 3.1415  # GaussianProcess/cigp_v10.py:15 ; gp_computation_pack.py:17 ; MFGP_ver2023May/base_gp/cigp.py:6
+
+ERRORS = {-1: "FFGP_ERR_ARG", -2: "FFGP_ERR_HIP", -3: "FFGP_ERR_ALLOC", -4: "FFGP_ERR_NODEVICE"}
+
+_dp = C.c_void_p  # device pointers travel as void*
+
+
+class Problem(C.Structure):
+    _fields_ = [
+        ("n", C.c_int), ("D", C.c_int), ("d", C.c_int),
+        ("X_dev", _dp), ("Y_dev", _dp), ("w_dev", _dp), ("amp_dev", _dp),
+        ("clamp_min", C.c_double),
+        ("diag_add_dev", _dp), ("diag_vec_dev", _dp), ("diag_stride", C.c_long),
+        ("add_mat_dev", _dp), ("ld_add", C.c_int),
+        ("add_all", C.c_double), ("mean_jitter", C.c_double),
+        ("ll_variant", C.c_int), ("pi_const", C.c_double),
+    ]
+
+
+class Grads(C.Structure):
+    _fields_ = [("g_w_dev", _dp), ("g_amp_dev", _dp), ("g_diag_add_dev", _dp), ("g_Y_dev", _dp),
+                ("g_diag_vec_dev", _dp)]
+
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "ffgp_version": (C.c_char_p, []),
+    "ffgp_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "ffgp_destroy": (C.c_int, [C.c_void_p]),
+    "ffgp_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ffgp_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
+    "ffgp_assemble": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, C.c_double, _dp, _dp,
+                                C.c_long, _dp, C.c_int, C.c_double, C.c_double, _dp, C.c_int, C.c_int]),
+    "ffgp_potrf": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int]),
+    "ffgp_potrf_rows": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, C.c_int]),
+    "ffgp_trsm_lower": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int]),
+    "ffgp_trsm_lower_t": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int]),
+    "ffgp_potrs": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int]),
+    "ffgp_nll_reduce": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int, C.c_double, _dp]),
+    "ffgp_potri": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int]),
+    "ffgp_nlml_fused": (C.c_int, [C.c_void_p, C.POINTER(Problem), _dp, C.POINTER(Grads)]),
+    "ffgp_predict": (C.c_int, [C.c_void_p, C.POINTER(Problem), _dp, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int]),
+    "ffgp_last_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.c_int,
+                                    C.POINTER(C.c_int)]),
+    "ffgp_syrk_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long),
+                                  C.c_int]),
+    "ffgp_mfma_f64_peak": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "ffgp_gemm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, C.c_int,
+                            C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]),
+}
+
+
+class FFGPError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(_SO):
+        raise ImportError(
+            "fidelityfusion_amd: %s is missing -- build it with `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback." % _SO)
+    lib = C.CDLL(_SO)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)  # AttributeError here = the .so does not export what include/ffgp.h declares
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+_handles = {}
+_lock = threading.Lock()
+
+
+def check(rc, what):
+    """Negative status -> FFGPError; positive (pivot index) is returned to the caller."""
+    if rc < 0:
+        raise FFGPError("%s failed: %s (%d)" % (what, ERRORS.get(rc, "?"), rc))
+    return rc
+
+
+def handle(device_index=None):
+    """One ffgp handle per GPU of this process (one process per GPU is the deployment model)."""
+    import torch
+
+    if not torch.cuda.is_available():
+        raise FFGPError("fidelityfusion_amd needs an MI355X (gfx950) GPU: torch.cuda.is_available() is False "
+                        "and the package has no CPU path")
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    with _lock:
+        h = _handles.get(device_index)
+        if h is None:
+            out = C.c_void_p()
+            check(lib.ffgp_create(int(device_index), C.byref(out)), "ffgp_create")
+            h = out
+            _handles[device_index] = h
+    return h
+
+
+def set_option(key, value, device_index=None):
+    check(lib.ffgp_set_option(handle(device_index), key.encode(), float(value)), "ffgp_set_option(%s)" % key)
+
+
+def bind_stream(h, device_index):
+    import torch
+
+    s = torch.cuda.current_stream(device_index).cuda_stream
+    check(lib.ffgp_set_stream(h, C.c_void_p(s)), "ffgp_set_stream")
+
+
+def last_timings(device_index=None):
+    h = handle(device_index)
+    ms = (C.c_float * 16)()
+    names = (C.c_char_p * 16)()
+    n = C.c_int(0)
+    check(lib.ffgp_last_timings(h, ms, names, 16, C.byref(n)), "ffgp_last_timings")
+    return {names[i].decode(): float(ms[i]) for i in range(n.value)}
+
+
+def syrk_stats(reset=False, device_index=None):
+    h = handle(device_index)
+    fl, ms, ln = C.c_double(0), C.c_double(0), C.c_long(0)
+    check(lib.ffgp_syrk_stats(h, C.byref(fl), C.byref(ms), C.byref(ln), 1 if reset else 0), "ffgp_syrk_stats")
+    return {"flops": fl.value, "ms": ms.value, "launches": ln.value}
+
+
+def mfma_f64_peak(device_index=None):
+    h = handle(device_index)
+    out = C.c_double(0)
+    check(lib.ffgp_mfma_f64_peak(h, C.byref(out)), "ffgp_mfma_f64_peak")
+    return out.value

@@ -1,0 +1,381 @@
+// libffgp C ABI: handle lifetime, workspace, fused NLML (+ gradients) and posterior paths.  See include/ffgp.h.
+#include <cmath>
+
+#include "ffgp_internal.h"
+
+int ffgp_assemble_impl(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const double* w,
+                       const double* amp, double clamp_min, const double* diag_add, const double* diag_vec,
+                       long diag_stride, const double* add_mat, int ld_add, double add_all, double mean_jitter, double* K,
+                       int ldk, int lower_only);
+int ffgp_transpose(ffgp_handle* h, const double* src, int rows, int cols, int ld_src, double* dst, int ld_dst, double scale);
+int ffgp_trtri_impl(ffgp_handle* h, const double* L, int n, int ldl, double* X, int ldx, double* T);
+int ffgp_lauum_impl(ffgp_handle* h, const double* X, int n, int ldx, double* S, int lds_);
+int ffgp_nll_reduce_impl(ffgp_handle* h, int variant, const double* L, int n, int ldl, const double* M, int rows, int cols,
+                         int ldm, int d, double pi_const, double* out_dev);
+int ffgp_grad_impl(ffgp_handle* h, const double* X, int n, int D, const double* w, const double* amp, double clamp,
+                   const double* G, int ldg, double mean_jitter, double* g_w, double* g_amp, double* g_diag_add,
+                   double* g_diag_vec, double* partial_ws);
+size_t ffgp_grad_partial_doubles(int n, int D);
+
+#define SCAL_DOUBLES 2048
+
+static const char* k_stage_names[FFGP_MAX_STAGES] = {"assemble", "potrf", "reduce", "trtri", "lauum", "grad",
+                                                     "predict_gemm", "", "", "", "", "", "", "", "", ""};
+
+int ffgp_ensure_ws(ffgp_handle* h, size_t bytes) {
+  if (bytes <= h->ws_bytes) return FFGP_OK;
+  if (h->ws) {
+    hipStreamSynchronize(h->stream);
+    hipFree(h->ws);
+    h->ws = nullptr;
+    h->ws_bytes = 0;
+  }
+  // round up to 64 MiB so a slowly growing problem does not reallocate on every call
+  const size_t gran = (size_t)64 << 20;
+  const size_t want = (bytes + gran - 1) / gran * gran;
+  if (hipMalloc(&h->ws, want) != hipSuccess) {
+    fprintf(stderr, "[ffgp] workspace allocation of %zu bytes failed\n", want);
+    return FFGP_ERR_ALLOC;
+  }
+  h->ws_bytes = want;
+  return FFGP_OK;
+}
+
+static void stage_mark(ffgp_handle* h, int idx) {
+  if (h->timing >= 1 && idx <= FFGP_MAX_STAGES) {
+    hipEventRecord(h->ev[idx], h->stream);
+    if (idx > h->n_stages) h->n_stages = idx;
+  }
+}
+
+static void stage_collect(ffgp_handle* h) {
+  if (h->timing < 1) return;
+  for (int i = 0; i < FFGP_MAX_STAGES; ++i) h->stage_ms[i] = 0.f;
+  for (int i = 0; i < h->n_stages; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) == hipSuccess) h->stage_ms[i] = ms;
+  }
+}
+
+extern "C" {
+
+const char* ffgp_version(void) { return "ffgp 0.1 (gfx950, fp64 MFMA)"; }
+
+int ffgp_create(int device, ffgp_handle** out) {
+  if (!out) return FFGP_ERR_ARG;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) {
+    fprintf(stderr, "[ffgp] no usable HIP device (requested %d of %d); libffgp has no CPU fallback\n", device, count);
+    return FFGP_ERR_NODEVICE;
+  }
+  FFGP_HIP(hipSetDevice(device));
+  ffgp_handle* h = new ffgp_handle();  // value-initialised: every POD member is zero
+  h->device = device;
+  FFGP_HIP(hipStreamCreate(&h->stream));
+  h->own_stream = true;
+  h->own = h->stream;
+  FFGP_HIP(hipMalloc(&h->d_info, 16 * sizeof(int)));
+  FFGP_HIP(hipMalloc(&h->d_scal, SCAL_DOUBLES * sizeof(double)));
+  FFGP_HIP(hipHostMalloc(&h->h_info, 16 * sizeof(int)));
+  FFGP_HIP(hipHostMalloc(&h->h_scal, 64 * sizeof(double)));
+  for (int i = 0; i <= FFGP_MAX_STAGES; ++i) FFGP_HIP(hipEventCreate(&h->ev[i]));
+  FFGP_HIP(hipEventCreate(&h->syrk_ev[0]));
+  FFGP_HIP(hipEventCreate(&h->syrk_ev[1]));
+  h->nb_outer = 512;
+  *out = h;
+  return FFGP_OK;
+}
+
+int ffgp_destroy(ffgp_handle* h) {
+  if (!h) return FFGP_OK;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  if (h->ws) hipFree(h->ws);
+  if (h->dinv) hipFree(h->dinv);
+  hipFree(h->d_info);
+  hipFree(h->d_scal);
+  hipHostFree(h->h_info);
+  hipHostFree(h->h_scal);
+  for (int i = 0; i <= FFGP_MAX_STAGES; ++i) hipEventDestroy(h->ev[i]);
+  hipEventDestroy(h->syrk_ev[0]);
+  hipEventDestroy(h->syrk_ev[1]);
+  for (hipEvent_t e : h->syrk_pool) hipEventDestroy(e);
+  hipStreamDestroy(h->own);
+  delete h;
+  return FFGP_OK;
+}
+
+int ffgp_set_stream(ffgp_handle* h, void* s) {
+  if (!h) return FFGP_ERR_ARG;
+  h->stream = s ? reinterpret_cast<hipStream_t>(s) : h->own;
+  return FFGP_OK;
+}
+
+int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
+  if (!h || !key) return FFGP_ERR_ARG;
+  if (!strcmp(key, "timing")) {
+    h->timing = (int)value;
+  } else if (!strcmp(key, "nb_outer")) {
+    const int v = (int)value;
+    if (v < FFGP_NB || v % FFGP_NB) return FFGP_ERR_ARG;
+    h->nb_outer = v;
+  } else if (!strcmp(key, "naive")) {
+    h->use_naive = (int)value;
+  } else {
+    return FFGP_ERR_ARG;
+  }
+  return FFGP_OK;
+}
+
+int ffgp_assemble(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const double* w,
+                  const double* amp, double clamp_min, const double* diag_add, const double* diag_vec, long diag_stride,
+                  const double* add_mat, int ld_add, double add_all, double mean_jitter, double* K, int ldk,
+                  int lower_only) {
+  if (!h) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  return ffgp_assemble_impl(h, X1, n1, X2, n2, D, w, amp, clamp_min, diag_add, diag_vec, diag_stride, add_mat, ld_add,
+                            add_all, mean_jitter, K, ldk, lower_only);
+}
+
+int ffgp_potrf(ffgp_handle* h, double* A, int n, int lda) {
+  if (!h) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  return ffgp_potrf_impl(h, A, n, n, lda, 1);
+}
+
+int ffgp_potrf_rows(ffgp_handle* h, double* A, int n, int mtot, int lda) {
+  if (!h) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  return ffgp_potrf_impl(h, A, n, mtot, lda, 1);
+}
+
+int ffgp_trsm_lower(ffgp_handle* h, const double* L, int n, int ldl, double* B, int nrhs, int ldb) {
+  if (!h) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  return ffgp_trsm_lower_impl(h, L, n, ldl, B, nrhs, ldb);
+}
+
+int ffgp_trsm_lower_t(ffgp_handle* h, const double* L, int n, int ldl, double* B, int nrhs, int ldb) {
+  if (!h) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  return ffgp_trsm_lower_t_impl(h, L, n, ldl, B, nrhs, ldb);
+}
+
+int ffgp_potrs(ffgp_handle* h, const double* L, int n, int ldl, double* B, int nrhs, int ldb) {
+  if (!h) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  FFGP_CHECK(ffgp_trsm_lower_impl(h, L, n, ldl, B, nrhs, ldb));
+  return ffgp_trsm_lower_t_impl(h, L, n, ldl, B, nrhs, ldb);
+}
+
+int ffgp_nll_reduce(ffgp_handle* h, int variant, const double* L, int n, int ldl, const double* M, int d, int ldm,
+                    double pi_const, double* out_dev) {
+  if (!h) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  return ffgp_nll_reduce_impl(h, variant, L, n, ldl, M, n, d, ldm, d, pi_const, out_dev);
+}
+
+int ffgp_gemm(ffgp_handle* h, int opa, int opb, int lower_tiles, int tri, const double* A, int lda, const double* B, int ldb,
+              double* C, int ldc, int m, int n, int k, double alpha, double beta) {
+  if (!h) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  return ffgp_gemm_launch(h, opa ? OP_MNMAJOR : OP_KMAJOR, opb ? OP_MNMAJOR : OP_KMAJOR, lower_tiles ? TILES_LOWER : TILES_FULL,
+                          0, A, lda, B, ldb, C, ldc, m, n, k, alpha, beta, tri);
+}
+
+int ffgp_potri(ffgp_handle* h, double* L, int n, int ldl) {
+  if (!h || !L || n <= 0) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  const size_t ld = ffgp_round_up(n, 16);
+  const size_t n1 = ffgp_round_up((n + 1) / 2, FFGP_NB);
+  const size_t xd = (size_t)n * ld, td = n1 * n1 + 16;
+  FFGP_CHECK(ffgp_ensure_ws(h, (xd + td) * sizeof(double)));
+  double* X = h->ws;
+  double* T = h->ws + xd;
+  FFGP_CHECK(ffgp_trtri_impl(h, L, n, ldl, X, (int)ld, T));
+  FFGP_CHECK(ffgp_lauum_impl(h, X, n, (int)ld, L, ldl));
+  h->dinv_L = nullptr;  // the buffer no longer holds the factor
+  return FFGP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// fused NLML (+ gradients)
+// ------------------------------------------------------------------------------------------------------------
+int ffgp_nlml_fused(ffgp_handle* h, const ffgp_problem* p, double* nll_dev, const ffgp_grads* g) {
+  if (!h || !p || !nll_dev) return FFGP_ERR_ARG;
+  if (p->n <= 0 || p->D <= 0 || p->d <= 0 || !p->X_dev || !p->Y_dev || !p->w_dev || !p->amp_dev) return FFGP_ERR_ARG;
+  if (p->ll_variant != FFGP_LL_V1 && p->ll_variant != FFGP_LL_V2) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  const int n = p->n, D = p->D, d = p->d;
+  const bool want_grad = g && (g->g_w_dev || g->g_amp_dev || g->g_diag_add_dev || g->g_Y_dev || g->g_diag_vec_dev);
+  const bool v2 = (p->ll_variant == FFGP_LL_V2);
+  if (v2 && want_grad) {
+    fprintf(stderr, "[ffgp] gradients of the V2 (Sigma^-2) likelihood are not implemented in this build\n");
+    return FFGP_ERR_ARG;
+  }
+  const size_t ld = ffgp_round_up(n, 16);
+  const size_t w0 = (size_t)(n + d) * ld;          // Sigma | Y^T  ->  L | Gamma^T
+  const size_t n1 = ffgp_round_up((n + 1) / 2, FFGP_NB);
+  size_t total = w0;
+  size_t o_X = 0, o_S = 0, o_T = 0, o_At = 0, o_P = 0, o_A = 0;
+  if (want_grad) {
+    o_X = total; total += (size_t)n * ld;          // L^-1
+    o_S = total; total += (size_t)n * ld;          // Sigma^-1 -> G
+    o_T = total; total += n1 * n1 + 16;            // TRTRI scratch
+    o_At = total; total += (size_t)d * ld;         // A^T = (Sigma^-1 Y)^T
+    o_P = total; total += ffgp_grad_partial_doubles(n, D) + 16;
+  }
+  if (v2) {
+    o_A = total; total += (size_t)n * ffgp_round_up(d, 2) + 16;
+  }
+  FFGP_CHECK(ffgp_ensure_ws(h, total * sizeof(double)));
+  double* W0 = h->ws;
+  double* Gt = W0 + (size_t)n * ld;  // passenger rows: Gamma^T (d x n)
+
+  h->n_stages = 0;
+  stage_mark(h, 0);
+  FFGP_CHECK(ffgp_assemble_impl(h, p->X_dev, n, p->X_dev, n, D, p->w_dev, p->amp_dev, p->clamp_min, p->diag_add_dev,
+                                p->diag_vec_dev, p->diag_stride, p->add_mat_dev, p->ld_add, p->add_all, p->mean_jitter,
+                                W0, (int)ld, 1));
+  FFGP_CHECK(ffgp_transpose(h, p->Y_dev, n, d, d, Gt, (int)ld, 1.0));
+  stage_mark(h, 1);
+  FFGP_CHECK(ffgp_potrf_impl(h, W0, n, n + d, (int)ld, 0));
+  stage_mark(h, 2);
+  if (!v2) {
+    FFGP_CHECK(ffgp_nll_reduce_impl(h, FFGP_LL_V1, W0, n, (int)ld, Gt, d, n, (int)ld, d, p->pi_const, nll_dev));
+  } else {
+    // A = L^-T Gamma  (n x d), then ||A||^2
+    double* A = h->ws + o_A;
+    const int lda2 = ffgp_round_up(d, 2);
+    FFGP_CHECK(ffgp_transpose(h, Gt, d, n, (int)ld, A, lda2, 1.0));
+    FFGP_CHECK(ffgp_trsm_lower_t_impl(h, W0, n, (int)ld, A, d, lda2));
+    FFGP_CHECK(ffgp_nll_reduce_impl(h, FFGP_LL_V2, W0, n, (int)ld, A, n, d, lda2, d, p->pi_const, nll_dev));
+  }
+  stage_mark(h, 3);
+  if (want_grad) {
+    double* X = h->ws + o_X;
+    double* S = h->ws + o_S;
+    double* T = h->ws + o_T;
+    double* At = h->ws + o_At;
+    double* P = h->ws + o_P;
+    FFGP_CHECK(ffgp_trtri_impl(h, W0, n, (int)ld, X, (int)ld, T));
+    stage_mark(h, 4);
+    FFGP_CHECK(ffgp_lauum_impl(h, X, n, (int)ld, S, (int)ld));
+    stage_mark(h, 5);
+    // A^T = Gamma^T L^-1   (d x n)
+    FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Gt, (int)ld, X, (int)ld, At, (int)ld, d, n, n, 1.0, 0.0,
+                                TRI_LO_J));
+    // G = d/2 Sigma^-1 - 1/2 A A^T   (lower, in place of Sigma^-1)
+    FFGP_CHECK(ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_LOWER, 0, At, (int)ld, At, (int)ld, S, (int)ld, n, n, d, -0.5,
+                                0.5 * (double)d));
+    FFGP_CHECK(ffgp_grad_impl(h, p->X_dev, n, D, p->w_dev, p->amp_dev, p->clamp_min, S, (int)ld, p->mean_jitter, g->g_w_dev,
+                              g->g_amp_dev, g->g_diag_add_dev, g->g_diag_vec_dev, P));
+    if (g->g_Y_dev) FFGP_CHECK(ffgp_transpose(h, At, d, n, (int)ld, g->g_Y_dev, d, 1.0));
+    stage_mark(h, 6);
+  }
+  FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  FFGP_HIP(hipStreamSynchronize(h->stream));
+  stage_collect(h);
+  return h->h_info[0];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// posterior
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ffgp_var_diag_kernel(const double* __restrict__ Vt, int nt, int n, int ld,
+                                                            const double* __restrict__ amp, double clamp, double add,
+                                                            double* __restrict__ var) {
+  // one wave per test point: var[t] = k(x*,x*) - sum_i Vt[t][i]^2 + add
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= nt) return;
+  const int lane = threadIdx.x & 63;
+  double s = 0.0;
+  for (int i = lane; i < n; i += 64) {
+    const double v = Vt[(size_t)t * ld + i];
+    s = __builtin_fma(v, v, s);
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if (lane == 0) var[t] = amp[0] * exp(-0.5 * fmax(0.0, clamp)) - s + add;
+}
+
+int ffgp_predict(ffgp_handle* h, const ffgp_problem* p, const double* Xs, int nt, int var_mode, double var_add_all,
+                 double* mean_dev, double* var_dev, int ldv) {
+  if (!h || !p || !Xs || nt <= 0 || !mean_dev) return FFGP_ERR_ARG;
+  if (p->n <= 0 || p->D <= 0 || p->d <= 0 || !p->X_dev || !p->Y_dev || !p->w_dev || !p->amp_dev) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  const int n = p->n, D = p->D, d = p->d;
+  const size_t ld = ffgp_round_up(n, 16);
+  const size_t total = (size_t)(n + d + nt) * ld;
+  FFGP_CHECK(ffgp_ensure_ws(h, total * sizeof(double)));
+  double* W0 = h->ws;
+  double* Gt = W0 + (size_t)n * ld;        // Gamma^T (d x n)
+  double* Vt = Gt + (size_t)d * ld;        // V^T = K_*^T L^-T (nt x n)
+  h->n_stages = 0;
+  stage_mark(h, 0);
+  FFGP_CHECK(ffgp_assemble_impl(h, p->X_dev, n, p->X_dev, n, D, p->w_dev, p->amp_dev, p->clamp_min, p->diag_add_dev,
+                                p->diag_vec_dev, p->diag_stride, p->add_mat_dev, p->ld_add, p->add_all, p->mean_jitter,
+                                W0, (int)ld, 1));
+  FFGP_CHECK(ffgp_transpose(h, p->Y_dev, n, d, d, Gt, (int)ld, 1.0));
+  FFGP_CHECK(ffgp_assemble_impl(h, Xs, nt, p->X_dev, n, D, p->w_dev, p->amp_dev, p->clamp_min, nullptr, nullptr, 0, nullptr, 0,
+                                0.0, 0.0, Vt, (int)ld, 0));
+  stage_mark(h, 1);
+  FFGP_CHECK(ffgp_potrf_impl(h, W0, n, n + d + nt, (int)ld, 0));
+  stage_mark(h, 2);
+  // mean = V^T Gamma   ([nt, n] x [n, d])
+  FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, Vt, (int)ld, Gt, (int)ld, mean_dev, d, nt, d, n, 1.0, 0.0));
+  if (var_dev) {
+    if (var_mode == FFGP_VAR_FULL) {
+      if (ldv < nt) return FFGP_ERR_ARG;
+      FFGP_CHECK(ffgp_assemble_impl(h, Xs, nt, Xs, nt, D, p->w_dev, p->amp_dev, p->clamp_min, nullptr, nullptr, 0, nullptr, 0,
+                                    var_add_all, 0.0, var_dev, ldv, 0));
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, Vt, (int)ld, Vt, (int)ld, var_dev, ldv, nt, nt, n, -1.0,
+                                  1.0));
+    } else {
+      hipLaunchKernelGGL(ffgp_var_diag_kernel, dim3((nt + 3) / 4), dim3(256), 0, h->stream, Vt, nt, n, (int)ld, p->amp_dev,
+                         p->clamp_min, var_add_all, var_dev);
+    }
+  }
+  stage_mark(h, 3);
+  FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  FFGP_HIP(hipStreamSynchronize(h->stream));
+  stage_collect(h);
+  return h->h_info[0];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// instrumentation
+// ------------------------------------------------------------------------------------------------------------
+int ffgp_last_timings(ffgp_handle* h, float* ms_out, const char** names_out, int max_stages, int* n_stages) {
+  if (!h || !ms_out || !n_stages) return FFGP_ERR_ARG;
+  const int ns = h->n_stages < max_stages ? h->n_stages : max_stages;
+  for (int i = 0; i < ns; ++i) {
+    ms_out[i] = h->stage_ms[i];
+    if (names_out) names_out[i] = k_stage_names[i];
+  }
+  *n_stages = ns;
+  return FFGP_OK;
+}
+
+int ffgp_syrk_stats(ffgp_handle* h, double* flops, double* ms, long* launches, int reset) {
+  if (!h) return FFGP_ERR_ARG;
+  if (h->syrk_pool_used > 0) {
+    hipSetDevice(h->device);
+    hipEventSynchronize(h->syrk_pool[h->syrk_pool_used - 1]);
+    for (int i = 0; i + 1 < h->syrk_pool_used; i += 2) {
+      float ms_i = 0.f;
+      if (hipEventElapsedTime(&ms_i, h->syrk_pool[i], h->syrk_pool[i + 1]) == hipSuccess) h->syrk_ms += ms_i;
+    }
+    h->syrk_pool_used = 0;
+  }
+  if (flops) *flops = h->syrk_flops;
+  if (ms) *ms = h->syrk_ms;
+  if (launches) *launches = h->syrk_launches;
+  if (reset) {
+    h->syrk_flops = 0.0;
+    h->syrk_ms = 0.0;
+    h->syrk_launches = 0;
+  }
+  return FFGP_OK;
+}
+
+}  // extern "C"

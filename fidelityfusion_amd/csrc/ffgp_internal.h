@@ -1,0 +1,100 @@
+// Internal declarations shared by the libffgp translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/ffgp.h"
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+#define FFGP_NB 128        // diagonal-block size of the blocked factorisation (one LDS-resident panel)
+#define FFGP_MAX_STAGES 16 // hipEvent stage timers exposed through ffgp_last_timings
+
+#define FFGP_HIP(call)                                                                        \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      fprintf(stderr, "[ffgp] HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      return FFGP_ERR_HIP;                                                                    \
+    }                                                                                         \
+  } while (0)
+
+#define FFGP_CHECK(call)            \
+  do {                              \
+    int s_ = (call);                \
+    if (s_ != 0) return s_;         \
+  } while (0)
+
+static inline int ffgp_round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// GEMM operand layouts.  "K-major": element (row, k) at P[row*ld + k]; "MN-major": at P[k*ld + row].
+enum { OP_KMAJOR = 0, OP_MNMAJOR = 1 };
+// tile scheduling modes: full rectangle / lower-triangular tiles of a symmetric update
+enum { TILES_FULL = 0, TILES_LOWER = 1 };
+
+struct GemmArgs {
+  const double* A;  // op(A) is m x k
+  const double* B;  // op(B) is k x n   (K-major B stores B^T as n x k)
+  double* C;        // m x n row-major
+  int m, n, k;
+  int lda, ldb, ldc;
+  double alpha, beta;  // C = alpha*op(A)op(B) + beta*C   (beta == 0 -> C not read)
+  int tiles_m, tiles_n;
+  int total_tiles;
+  int avec, bvec;      // 16-byte vector loads allowed for A / B
+  // triangular operands: restrict the k range of tile (ti, tj) to [max(lo_i*ti, lo_j*tj)*128, min(K, hi_i*(ti+1)*128, ...))
+  int lo_i, lo_j, hi_i, hi_j;
+};
+
+struct ffgp_handle {
+  int device;
+  hipStream_t stream;   // stream work is enqueued on (caller's, or `own`)
+  hipStream_t own;      // the handle's own stream
+  bool own_stream;
+  // workspace (grown on demand, never shrunk)
+  double* ws;        // generic workspace
+  size_t ws_bytes;
+  double* dinv;      // inverses of the NB x NB diagonal blocks of the last factor: nblk * NB*NB
+  size_t dinv_bytes;
+  const double* dinv_L;  // factor the Dinv store currently belongs to (pointer, n, ld); nullptr = stale
+  int dinv_n, dinv_ld;
+  int* d_info;       // device status word(s)
+  double* d_scal;    // small device scalar scratch (64 doubles)
+  int* h_info;       // pinned host mirror
+  double* h_scal;    // pinned host mirror
+  // timing
+  int timing;        // 0 = off
+  hipEvent_t ev[FFGP_MAX_STAGES + 1];
+  float stage_ms[FFGP_MAX_STAGES];
+  int n_stages;
+  // roofline bookkeeping for the dominant kernel (trailing-update SYRK)
+  double syrk_flops;
+  double syrk_ms;
+  long syrk_launches;
+  hipEvent_t syrk_ev[2];
+  std::vector<hipEvent_t> syrk_pool;  // (start, stop) pairs recorded around trailing-update launches (timing == 2)
+  int syrk_pool_used;
+  // tuning knobs
+  int nb_outer;      // outer (trailing-update) block size, multiple of FFGP_NB
+  int use_naive;     // debug: route potrf through the naive kernels
+};
+
+// ---- gemm.hip
+// tri: OR of TRI_* -- the k range of output tile (ti,tj) is clipped to the structurally non-zero part
+enum { TRI_LO_I = 1, TRI_LO_J = 2, TRI_HI_I = 4, TRI_HI_J = 8 };
+int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, const double* A, int lda, const double* B,
+                     int ldb, double* C, int ldc, int m, int n, int k, double alpha, double beta, int tri = 0);
+// ---- potrf.hip
+int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int sync_info);
+int ffgp_ensure_dinv(ffgp_handle* h, int n);
+int ffgp_refresh_dinv(ffgp_handle* h, const double* L, int n, int ldl);
+// ---- solve.hip
+int ffgp_trsm_lower_impl(ffgp_handle* h, const double* L, int n, int ldl, double* B, int nrhs, int ldb);
+int ffgp_trsm_lower_t_impl(ffgp_handle* h, const double* L, int n, int ldl, double* B, int nrhs, int ldb);
+// ---- workspace
+int ffgp_ensure_ws(ffgp_handle* h, size_t bytes);

@@ -1,0 +1,366 @@
+// fp64 MFMA GEMM for gfx950: C = alpha * op(A) op(B) + beta * C on v_mfma_f64_16x16x4_f64.
+//
+// This one kernel carries every O(N^3) stage of the GP hot path: the trailing SYRK update of the blocked
+// Cholesky (the roofline kernel), panel updates, TRSM-as-GEMM with pre-inverted diagonal blocks, TRTRI, LAUUM
+// and the dense products of the gradient / prediction paths.
+//
+// Geometry: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each wave 64x64 = 4x4 MFMA tiles,
+// 16 accumulators x 4 fp64 = 128 VGPRs), BK = 16 (4 MFMA k-steps), double-buffered LDS, one barrier per
+// k-tile, global->register->LDS staging issued a full compute phase ahead (the 64-cycle fp64 MFMA leaves
+// the load/LDS pipes almost idle, so a deeper pipeline buys nothing).  2 workgroups per CU (2 x 72 KiB LDS,
+// <= 256 VGPRs) so one workgroup's C epilogue overlaps the other's MFMA stream.
+//
+// LDS images (both bank-conflict-free for the ds_read_b64 operand fetch, see MI355X guide "LDS"):
+//   K-major operand (global rows have k contiguous):  [row][16] doubles, 16-byte chunks XOR-swizzled with
+//       (row>>1)&7, so the 16 rows x 2 k-values a 32-lane half reads cover all 64 banks exactly once;
+//   MN-major operand (global rows have m/n contiguous): [k][128+16] doubles; the 16-double pad shifts
+//       consecutive k rows by 128 B = half the bank row.
+// Workgroup -> tile map: XCD-aware (blocks b, b+8, ... share an XCD/L2, so each XCD gets a contiguous chunk
+// of the tile order) over 8-tile-row bands walked column-major, so the ~64 tiles resident on one XCD share
+// 8 A panels and ~8 B panels through its L2.
+#include "ffgp_internal.h"
+
+#define BM 128
+#define BN 128
+#define BK 16
+#define MNLD 144
+#define OPBUF 2304  // doubles per operand buffer = max(128*16, 16*144)
+
+__device__ __forceinline__ d2_t ld2_guard(const double* p, int rem, bool vec) {
+  d2_t v = {0.0, 0.0};
+  if (rem >= 2) {
+    if (vec) {
+      v = *reinterpret_cast<const d2_t*>(p);
+    } else {  // odd leading dimension / unaligned base: two 8-byte loads
+      v.x = p[0];
+      v.y = p[1];
+    }
+  } else if (rem == 1) {
+    v.x = p[0];
+  }
+  return v;
+}
+
+template <int OP>
+__device__ __forceinline__ void gload(const double* __restrict__ P, int ld, int r0, int R, int k0, int K, int tid,
+                                      bool vec, d2_t (&v)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i;
+    d2_t z = {0.0, 0.0};
+    if (OP == OP_KMAJOR) {
+      const int row = idx >> 3, ch = idx & 7;
+      const int gr = r0 + row, gk = k0 + ch * 2;
+      v[i] = (gr < R) ? ld2_guard(P + (size_t)gr * ld + gk, K - gk, vec) : z;
+    } else {
+      const int kk = idx >> 6, c2 = idx & 63;
+      const int gk = k0 + kk, gr = r0 + c2 * 2;
+      v[i] = (gk < K) ? ld2_guard(P + (size_t)gk * ld + gr, R - gr, vec) : z;
+    }
+  }
+}
+
+template <int OP>
+__device__ __forceinline__ void sstore(double* s, int tid, const d2_t (&v)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i;
+    if (OP == OP_KMAJOR) {
+      const int row = idx >> 3, ch = idx & 7;
+      *reinterpret_cast<d2_t*>(s + row * 16 + ((ch ^ ((row >> 1) & 7)) << 1)) = v[i];
+    } else {
+      const int kk = idx >> 6, c2 = idx & 63;
+      *reinterpret_cast<d2_t*>(s + kk * MNLD + c2 * 2) = v[i];
+    }
+  }
+}
+
+// offset (doubles) of this lane's operand element for MFMA k-step kq, sub-tile 0 of the wave's 64 rows
+template <int OP>
+__device__ __forceinline__ void frag_offsets(int lane, int wbase, int (&off)[4]) {
+#pragma unroll
+  for (int kq = 0; kq < 4; ++kq) {
+    if (OP == OP_KMAJOR) {
+      const int row = wbase + (lane & 15);
+      const int c0 = (lane >> 5) ^ ((lane & 15) >> 1);
+      off[kq] = row * 16 + ((((kq << 1) ^ c0)) << 1) + ((lane >> 4) & 1);
+    } else {
+      off[kq] = (kq * 4 + (lane >> 4)) * MNLD + wbase + (lane & 15);
+    }
+  }
+}
+
+__device__ __forceinline__ void decode_tile(int t, int mode, int tiles_m, int tiles_n, int& ti, int& tj) {
+  const int G = 8;
+  if (mode == TILES_FULL) {
+    const int band_sz = G * tiles_n;
+    const int b = t / band_sz;
+    const int r0 = b * G;
+    const int hgt = min(G, tiles_m - r0);
+    const int tt = t - b * band_sz;
+    tj = tt / hgt;
+    ti = r0 + tt % hgt;
+  } else {
+    // lower trapezoid (m >= n, origin on the diagonal): tile row ti owns columns 0..min(ti, tiles_n-1)
+    int r0 = 0, hgt = 0, fc = 0;
+    while (true) {
+      hgt = min(G, tiles_m - r0);
+      fc = min(r0, tiles_n);  // columns every row of the band owns
+      int tri = 0;
+      for (int c = 0; c < hgt; ++c)
+        if (r0 + c < tiles_n) tri += hgt - c;
+      const int cnt = hgt * fc + tri;
+      if (t < cnt) break;
+      t -= cnt;
+      r0 += hgt;
+    }
+    if (t < hgt * fc) {
+      tj = t / hgt;
+      ti = r0 + t % hgt;
+    } else {
+      t -= hgt * fc;
+      int c = 0;
+      while (t >= hgt - c) {
+        t -= hgt - c;
+        ++c;
+      }
+      tj = r0 + c;
+      ti = r0 + c + t;
+    }
+  }
+}
+
+template <int OPA, int OPB, int MODE, int TAG>
+__global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) double smem[4 * OPBUF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware bijective remap of the block id, then banded tile order
+  int t;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  int ti, tj;
+  decode_tile(t, MODE, p.tiles_m, p.tiles_n, ti, tj);
+  const int m0 = ti * BM, n0 = tj * BN;
+
+  d4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+
+  int offA[4], offB[4];
+  frag_offsets<OPA>(lane, wm * 64, offA);
+  frag_offsets<OPB>(lane, wn * 64, offB);
+  constexpr int subA = (OPA == OP_KMAJOR) ? 256 : 16;
+  constexpr int subB = (OPB == OP_KMAJOR) ? 256 : 16;
+
+  // k range of this tile (triangular operands skip the k-tiles that are structurally zero)
+  int kbeg = 0, kend = p.k;
+  if (p.lo_i) kbeg = max(kbeg, ti * BM);
+  if (p.lo_j) kbeg = max(kbeg, tj * BN);
+  if (p.hi_i) kend = min(kend, (ti + 1) * BM);
+  if (p.hi_j) kend = min(kend, (tj + 1) * BN);
+  const int kt0 = kbeg / BK;
+  const int kt1 = (kend + BK - 1) / BK;
+
+  if (kt0 < kt1) {
+    d2_t ra[4], rb[4];
+    gload<OPA>(p.A, p.lda, m0, p.m, kt0 * BK, p.k, tid, p.avec != 0, ra);
+    gload<OPB>(p.B, p.ldb, n0, p.n, kt0 * BK, p.k, tid, p.bvec != 0, rb);
+    sstore<OPA>(smem, tid, ra);
+    sstore<OPB>(smem + OPBUF, tid, rb);
+    __syncthreads();
+
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int par = (kt - kt0) & 1;
+      const double* sA = smem + par * (2 * OPBUF);
+      const double* sB = sA + OPBUF;
+      const bool more = (kt + 1 < kt1);
+      if (more) {
+        gload<OPA>(p.A, p.lda, m0, p.m, (kt + 1) * BK, p.k, tid, p.avec != 0, ra);
+        gload<OPB>(p.B, p.ldb, n0, p.n, (kt + 1) * BK, p.k, tid, p.bvec != 0, rb);
+      }
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) {
+        double a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = sA[offA[kq] + i * subA];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = sB[offB[kq] + j * subB];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      if (more) {
+        double* dA = smem + (par ^ 1) * (2 * OPBUF);
+        sstore<OPA>(dA, tid, ra);
+        sstore<OPB>(dA + OPBUF, tid, rb);
+      }
+      __syncthreads();
+    }
+  }
+
+  // epilogue: lane holds rows (lane>>4)+4r, column lane&15 of each 16x16 accumulator tile
+  // (16 loads in flight per 16-row group: addresses are clamped in-bounds so the loads are unconditional and
+  //  the compiler batches them instead of one vmcnt(0) round trip per element)
+  const double alpha = p.alpha, beta = p.beta;
+  const bool use_c = (beta != 0.0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    double cv[4][4];
+    const int rbase = m0 + wm * 64 + i * 16 + (lane >> 4);
+    const int cbase = n0 + wn * 64 + (lane & 15);
+    if (use_c) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rowc = min(rbase + 4 * r, p.m - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int colc = min(cbase + j * 16, p.n - 1);
+          cv[r][j] = p.C[(size_t)rowc * p.ldc + colc];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cv[r][j] = 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rbase + 4 * r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = cbase + j * 16;
+        if (row < p.m && col < p.n && (MODE != TILES_LOWER || col <= row)) {
+          p.C[(size_t)row * p.ldc + col] = alpha * acc[i][j][r] + beta * cv[r][j];
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host launcher
+// ------------------------------------------------------------------------------------------------------------
+template <int OPA, int OPB, int MODE, int TAG>
+static int launch_t(ffgp_handle* h, const GemmArgs& a) {
+  hipLaunchKernelGGL((ffgp_gemm_f64<OPA, OPB, MODE, TAG>), dim3(a.total_tiles), dim3(256), 0, h->stream, a);
+  return FFGP_OK;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, const double* A, int lda, const double* B,
+                     int ldb, double* C, int ldc, int m, int n, int k, double alpha, double beta, int tri) {
+  if (m <= 0 || n <= 0) return FFGP_OK;
+  if (k <= 0) {
+    // degenerate: C = beta*C handled by callers (never used on the hot path)
+    return FFGP_ERR_ARG;
+  }
+  if (!A || !B || !C) return FFGP_ERR_ARG;
+  GemmArgs a;
+  // vector (16-byte) operand loads need even leading dimensions and 16-byte aligned bases
+  a.avec = (!(lda & 1) && aligned16(A)) ? 1 : 0;
+  a.bvec = (!(ldb & 1) && aligned16(B)) ? 1 : 0;
+  a.A = A; a.B = B; a.C = C;
+  a.m = m; a.n = n; a.k = k;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.alpha = alpha; a.beta = beta;
+  a.lo_i = (tri & TRI_LO_I) ? 1 : 0;
+  a.lo_j = (tri & TRI_LO_J) ? 1 : 0;
+  a.hi_i = (tri & TRI_HI_I) ? 1 : 0;
+  a.hi_j = (tri & TRI_HI_J) ? 1 : 0;
+  a.tiles_m = (m + BM - 1) / BM;
+  a.tiles_n = (n + BN - 1) / BN;
+  if (mode == TILES_LOWER) {
+    if (m < n) return FFGP_ERR_ARG;
+    a.total_tiles = 0;
+    for (int ti = 0; ti < a.tiles_m; ++ti) a.total_tiles += (ti + 1 < a.tiles_n) ? ti + 1 : a.tiles_n;
+  } else {
+    a.total_tiles = a.tiles_m * a.tiles_n;
+  }
+  // timing == 2: bracket every trailing-update launch with its own event pair (no host sync inside the timed
+  // region; ffgp_syrk_stats drains the pool afterwards)
+  const bool timed = (syrk_tag && h->timing == 2);
+  hipEvent_t ev_stop = nullptr;
+  if (timed) {
+    if (h->syrk_pool_used + 2 > (int)h->syrk_pool.size()) {
+      hipEvent_t e0, e1;
+      hipEventCreate(&e0);
+      hipEventCreate(&e1);
+      h->syrk_pool.push_back(e0);
+      h->syrk_pool.push_back(e1);
+    }
+    hipEventRecord(h->syrk_pool[h->syrk_pool_used], h->stream);
+    ev_stop = h->syrk_pool[h->syrk_pool_used + 1];
+    h->syrk_pool_used += 2;
+  }
+  int rc = FFGP_ERR_ARG;
+  if (syrk_tag) {
+    // the trailing update of the blocked Cholesky gets its own instantiation so rocprofv3 --stats separates it
+    if (opa == OP_KMAJOR && opb == OP_KMAJOR && mode == TILES_LOWER) rc = launch_t<OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1>(h, a);
+  } else if (mode == TILES_LOWER) {
+    if (opa == OP_KMAJOR && opb == OP_KMAJOR) rc = launch_t<OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 0>(h, a);
+    else if (opa == OP_MNMAJOR && opb == OP_MNMAJOR) rc = launch_t<OP_MNMAJOR, OP_MNMAJOR, TILES_LOWER, 0>(h, a);
+  } else {
+    if (opa == OP_KMAJOR && opb == OP_KMAJOR) rc = launch_t<OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0>(h, a);
+    else if (opa == OP_KMAJOR && opb == OP_MNMAJOR) rc = launch_t<OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0>(h, a);
+    else if (opa == OP_MNMAJOR && opb == OP_MNMAJOR) rc = launch_t<OP_MNMAJOR, OP_MNMAJOR, TILES_FULL, 0>(h, a);
+    else if (opa == OP_MNMAJOR && opb == OP_KMAJOR) rc = launch_t<OP_MNMAJOR, OP_KMAJOR, TILES_FULL, 0>(h, a);
+  }
+  if (rc != FFGP_OK) return rc;
+  if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
+  if (syrk_tag) {
+    h->syrk_launches += 1;
+    // algorithmic flops: 2k per element of the lower trapezoid (n(n+1)/2 + (m-n)n elements)
+    h->syrk_flops += 2.0 * (double)k * ((double)n * ((double)n + 1.0) * 0.5 + ((double)m - (double)n) * (double)n);
+    if (timed) hipEventRecord(ev_stop, h->stream);
+  }
+  return FFGP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// fp64 MFMA peak probe: register-resident v_mfma_f64_16x16x4_f64 stream, 4 waves per CU x 2 workgroups
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void ffgp_mfma_peak_kernel(double* out, int iters, double seed) {
+  d4_t acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = (d4_t){0.0, 0.0, 0.0, 0.0};
+  double a = seed + threadIdx.x * 1e-3, b = 1.0 - threadIdx.x * 1e-3;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+extern "C" int ffgp_mfma_f64_peak(ffgp_handle* h, double* tflops_out) {
+  if (!h || !tflops_out) return FFGP_ERR_ARG;
+  const int blocks = 512, iters = 4096;
+  FFGP_CHECK(ffgp_ensure_ws(h, (size_t)blocks * 256 * sizeof(double)));
+  hipEvent_t e0, e1;
+  FFGP_HIP(hipEventCreate(&e0));
+  FFGP_HIP(hipEventCreate(&e1));
+  hipLaunchKernelGGL(ffgp_mfma_peak_kernel, dim3(blocks), dim3(256), 0, h->stream, h->ws, 64, 0.5);  // warm-up
+  FFGP_HIP(hipEventRecord(e0, h->stream));
+  hipLaunchKernelGGL(ffgp_mfma_peak_kernel, dim3(blocks), dim3(256), 0, h->stream, h->ws, iters, 0.5);
+  FFGP_HIP(hipEventRecord(e1, h->stream));
+  FFGP_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  FFGP_HIP(hipEventElapsedTime(&ms, e0, e1));
+  const double flops = (double)blocks * 4.0 * iters * 8.0 * 2048.0;
+  *tflops_out = flops / (ms * 1e-3) / 1e12;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return FFGP_OK;
+}

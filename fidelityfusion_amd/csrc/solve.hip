@@ -1,0 +1,177 @@
+// Triangular solves, inverse (TRTRI + LAUUM) and likelihood reductions, all built on the fp64 MFMA GEMM with
+// the pre-inverted 128x128 diagonal blocks the factorisation leaves in the handle (Dinv store).
+#include "ffgp_internal.h"
+
+#define NB FFGP_NB
+
+// make sure h->dinv matches the factor L (it does right after ffgp_potrf on the same buffer)
+static int ensure_dinv_for(ffgp_handle* h, const double* L, int n, int ldl) {
+  if (h->dinv_L == L && h->dinv_n == n && h->dinv_ld == ldl) return FFGP_OK;
+  return ffgp_refresh_dinv(h, L, n, ldl);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// B <- L^-1 B   (forward, blocked by 128):  B_b <- Dinv_b B_b ;  B[below] -= L[below, b] B_b
+// ------------------------------------------------------------------------------------------------------------
+int ffgp_trsm_lower_impl(ffgp_handle* h, const double* L, int n, int ldl, double* B, int nrhs, int ldb) {
+  if (n <= 0 || nrhs <= 0) return FFGP_OK;
+  if (!L || !B || ldl < n || ldb < nrhs) return FFGP_ERR_ARG;
+  FFGP_CHECK(ensure_dinv_for(h, L, n, ldl));
+  for (int r0 = 0; r0 < n; r0 += NB) {
+    const int rb = min(NB, n - r0);
+    double* Bb = B + (size_t)r0 * ldb;
+    const double* Db = h->dinv + (size_t)(r0 / NB) * NB * NB;
+    // in place: a single tile row (m = rb <= 128); every workgroup reads/writes only its own column tile
+    FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Db, NB, Bb, ldb, Bb, ldb, rb, nrhs, rb, 1.0, 0.0));
+    const int below = n - (r0 + rb);
+    if (below > 0)
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, L + (size_t)(r0 + rb) * ldl + r0, ldl, Bb, ldb,
+                                  B + (size_t)(r0 + rb) * ldb, ldb, below, nrhs, rb, -1.0, 1.0));
+  }
+  return FFGP_OK;
+}
+
+// B <- L^-T B  (backward):  B_b <- Dinv_b^T B_b ;  B[above] -= L[b, above]^T B_b
+int ffgp_trsm_lower_t_impl(ffgp_handle* h, const double* L, int n, int ldl, double* B, int nrhs, int ldb) {
+  if (n <= 0 || nrhs <= 0) return FFGP_OK;
+  if (!L || !B || ldl < n || ldb < nrhs) return FFGP_ERR_ARG;
+  FFGP_CHECK(ensure_dinv_for(h, L, n, ldl));
+  const int nblk = (n + NB - 1) / NB;
+  for (int b = nblk - 1; b >= 0; --b) {
+    const int r0 = b * NB;
+    const int rb = min(NB, n - r0);
+    double* Bb = B + (size_t)r0 * ldb;
+    const double* Db = h->dinv + (size_t)b * NB * NB;
+    // op(A) = Dinv_b^T: stored k x m with m contiguous = MN-major
+    FFGP_CHECK(ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_FULL, 0, Db, NB, Bb, ldb, Bb, ldb, rb, nrhs, rb, 1.0, 0.0));
+    if (r0 > 0)  // op(A) = L[b-rows, 0:r0]^T : stored k(=rb) x m(=r0), MN-major
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_FULL, 0, L + (size_t)r0 * ldl, ldl, Bb, ldb, B, ldb, r0,
+                                  nrhs, rb, -1.0, 1.0));
+  }
+  return FFGP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// X = L^-1 (lower, zeros above the diagonal), recursive:  inv([[L11,0],[L21,L22]]) = [[X11,0],[-X22 L21 X11, X22]]
+// ------------------------------------------------------------------------------------------------------------
+__global__ void ffgp_copy_block_kernel(const double* __restrict__ src, int lds_, double* __restrict__ dst, int ldd,
+                                       int rows, int cols) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < rows * cols) {
+    const int r = idx / cols, c = idx % cols;
+    dst[(size_t)r * ldd + c] = src[(size_t)r * lds_ + c];
+  }
+}
+
+static int trtri_rec(ffgp_handle* h, const double* L, int ldl, double* X, int ldx, int r0, int n, double* T) {
+  if (n <= NB) {
+    const double* Db = h->dinv + (size_t)(r0 / NB) * NB * NB;
+    hipLaunchKernelGGL(ffgp_copy_block_kernel, dim3((n * n + 255) / 256), dim3(256), 0, h->stream, Db, NB,
+                       X + (size_t)r0 * ldx + r0, ldx, n, n);
+    return FFGP_OK;
+  }
+  const int n1 = ffgp_round_up((n + 1) / 2, NB);
+  const int n2 = n - n1;
+  FFGP_CHECK(trtri_rec(h, L, ldl, X, ldx, r0, n1, T));
+  FFGP_CHECK(trtri_rec(h, L, ldl, X, ldx, r0 + n1, n2, T));
+  const double* L21 = L + (size_t)(r0 + n1) * ldl + r0;
+  double* X11 = X + (size_t)r0 * ldx + r0;
+  double* X22 = X + (size_t)(r0 + n1) * ldx + (r0 + n1);
+  double* X21 = X + (size_t)(r0 + n1) * ldx + r0;
+  // T = L21 * X11       (n2 x n1; X11 lower: B[k][j] = 0 for k < j  -> k starts at the tile column)
+  FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, L21, ldl, X11, ldx, T, n1, n2, n1, n1, 1.0, 0.0, TRI_LO_J));
+  // X21 = -X22 * T      (X22 lower: A[i][k] = 0 for k > i -> k ends at the tile row)
+  FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, X22, ldx, T, n1, X21, ldx, n2, n1, n2, -1.0, 0.0, TRI_HI_I));
+  return FFGP_OK;
+}
+
+// X (n x n, ldx) <- L^-1; the strictly-upper triangle of X is zeroed.  Workspace T: (n/2 rounded) ^2 doubles.
+int ffgp_trtri_impl(ffgp_handle* h, const double* L, int n, int ldl, double* X, int ldx, double* T) {
+  FFGP_CHECK(ensure_dinv_for(h, L, n, ldl));
+  FFGP_HIP(hipMemsetAsync(X, 0, (size_t)n * ldx * sizeof(double), h->stream));
+  return trtri_rec(h, L, ldl, X, ldx, 0, n, T);
+}
+
+// S (lower triangle, n x n, lds) <- X^T X  for lower-triangular X  (= Sigma^-1 when X = L^-1)
+int ffgp_lauum_impl(ffgp_handle* h, const double* X, int n, int ldx, double* S, int lds_) {
+  // op(A) = X^T, op(B) = X: both stored k x (m|n) = MN-major; X[k][i] = 0 for k < i -> k starts at the tile row
+  return ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_LOWER, 0, X, ldx, X, ldx, S, lds_, n, n, n, 1.0, 0.0, TRI_LO_I);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// reductions:  ss = sum over the (rows x cols, ld) region of M^2 ; ld = sum_i log L_ii ; then the NLL formula
+// ------------------------------------------------------------------------------------------------------------
+#define RED_BLOCKS 512
+
+__global__ __launch_bounds__(256) void ffgp_reduce_stage1(const double* __restrict__ M, int rows, int cols, int ldm,
+                                                          const double* __restrict__ L, int n, int ldl,
+                                                          double* __restrict__ partial) {
+  __shared__ double r1[4], r2[4];
+  double ss = 0.0, lg = 0.0;
+  const long total = (long)rows * cols;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long r = e / cols, c = e - r * cols;
+    const double v = M[r * ldm + c];
+    ss = __builtin_fma(v, v, ss);
+  }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) lg += log(L[(size_t)i * ldl + i]);
+  for (int o = 32; o > 0; o >>= 1) {
+    ss += __shfl_down(ss, o);
+    lg += __shfl_down(lg, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    r1[threadIdx.x >> 6] = ss;
+    r2[threadIdx.x >> 6] = lg;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = r1[0] + r1[1] + r1[2] + r1[3];
+    partial[RED_BLOCKS + blockIdx.x] = r2[0] + r2[1] + r2[2] + r2[3];
+  }
+}
+
+__global__ __launch_bounds__(256) void ffgp_reduce_stage2(const double* __restrict__ partial, int nblocks, int variant,
+                                                          int n, int d, double pi_const, double* __restrict__ out,
+                                                          double* __restrict__ aux) {
+  __shared__ double r1[4], r2[4];
+  double ss = 0.0, lg = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) {
+    ss += partial[i];
+    lg += partial[RED_BLOCKS + i];
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    ss += __shfl_down(ss, o);
+    lg += __shfl_down(lg, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    r1[threadIdx.x >> 6] = ss;
+    r2[threadIdx.x >> 6] = lg;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ss = r1[0] + r1[1] + r1[2] + r1[3];
+    lg = r2[0] + r2[1] + r2[2] + r2[3];
+    // V1: 1/2 ss + d*lg + 1/2 n d log(2 pi~)      V2 (-LL): 1/2 (ss + 2 d lg + n d log(2 pi))  -- same expression
+    out[0] = 0.5 * ss + (double)d * lg + 0.5 * (double)n * (double)d * log(2.0 * pi_const);
+    if (aux) {
+      aux[0] = ss;
+      aux[1] = lg;
+    }
+    (void)variant;
+  }
+}
+
+int ffgp_nll_reduce_impl(ffgp_handle* h, int variant, const double* L, int n, int ldl, const double* M, int rows, int cols,
+                         int ldm, int d, double pi_const, double* out_dev) {
+  if (!L || !M || !out_dev) return FFGP_ERR_ARG;
+  double* partial = h->d_scal + 64;  // 2*RED_BLOCKS doubles reserved behind the scalar scratch
+  long total = (long)rows * cols;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > RED_BLOCKS) blocks = RED_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(ffgp_reduce_stage1, dim3(blocks), dim3(256), 0, h->stream, M, rows, cols, ldm, L, n, ldl, partial);
+  hipLaunchKernelGGL(ffgp_reduce_stage2, dim3(1), dim3(256), 0, h->stream, partial, blocks, variant, n, d, pi_const, out_dev,
+                     h->d_scal + 8);
+  if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
+  return FFGP_OK;
+}

@@ -1,0 +1,254 @@
+"""Torch-facing operators over the libffgp C ABI (device memory, streams and autograd glue only).
+
+Everything numerical happens in the HIP library; this module moves pointers.  Inputs may live on the CPU (the
+reference's 2024 API is CPU-only, `torch.eye` without a device at GaussianProcess/cigp_v10.py:31,57): they are
+copied to the MI355X, results come back on the input's device and dtype.  Arithmetic is fp64 on the device
+whatever the input dtype.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import FFGP_LL_V1, FFGP_LL_V2, FFGP_VAR_DIAG, FFGP_VAR_FULL, PI_TRUNC, Grads, Problem, check, lib
+
+NEG_INF = float("-inf")
+
+
+def _device_of(*tensors):
+    for t in tensors:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            return t.device
+    if not torch.cuda.is_available():
+        raise _lib.FFGPError("fidelityfusion_amd needs an MI355X (gfx950) GPU; there is no CPU path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _dev(t, dev):
+    """fp64 contiguous copy/view of t on the compute device (detached)."""
+    return t.detach().to(device=dev, dtype=torch.float64).contiguous()
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _raise_not_pd(rc, what):
+    raise torch.linalg.LinAlgError(
+        "%s: The factorization could not be completed because the input is not positive-definite "
+        "(the leading minor of order %d is not positive-definite)." % (what, rc))
+
+
+def _problem(dev, X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, variant, pi_const, keep):
+    Xd, Yd = _dev(X, dev), _dev(Y, dev)
+    n, D = Xd.shape
+    d = Yd.shape[1]
+    wd = _dev(w.reshape(-1), dev)
+    if wd.numel() == 1 and D > 1:
+        wd = wd.expand(D).contiguous()
+    ad = _dev(amp.reshape(-1)[:1], dev)
+    p = Problem()
+    p.n, p.D, p.d = n, D, d
+    p.X_dev, p.Y_dev, p.w_dev, p.amp_dev = _ptr(Xd), _ptr(Yd), _ptr(wd), _ptr(ad)
+    p.clamp_min = clamp
+    keep += [Xd, Yd, wd, ad]
+    if diag_add is not None:
+        dd = _dev(diag_add.reshape(-1)[:1], dev)
+        p.diag_add_dev = _ptr(dd)
+        keep.append(dd)
+    if diag_vec is not None:
+        dv = _dev(diag_vec, dev)
+        if dv.dim() == 2:  # an N x N matrix whose diagonal is wanted (cigp_v10.py:59-60): read in place, stride N+1
+            p.diag_stride = dv.shape[1] + 1
+        else:
+            p.diag_stride = 1
+        p.diag_vec_dev = _ptr(dv)
+        keep.append(dv)
+    if add_mat is not None:
+        am = _dev(add_mat, dev)
+        p.add_mat_dev = _ptr(am)
+        p.ld_add = am.shape[1]
+        keep.append(am)
+    p.add_all = float(add_all)
+    p.mean_jitter = float(mean_jitter)
+    p.ll_variant = variant
+    p.pi_const = pi_const
+    return p, (n, D, d)
+
+
+class _NLML(torch.autograd.Function):
+    """nll(X, Y; w, amp, diag_add, diag_vec, add_mat) -> 0-dim tensor.  V1: +nll; V2: -LL.
+    Gradients (closed form, computed by the same fused call): Y, w, amp, diag_add, diag_vec."""
+
+    @staticmethod
+    def forward(ctx, X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, variant, pi_const):
+        dev = _device_of(X, Y, w, amp)
+        h = _lib.handle(dev.index)
+        _lib.bind_stream(h, dev.index)
+        keep = []
+        p, (n, D, d) = _problem(dev, X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, variant,
+                                pi_const, keep)
+        needs = [isinstance(t, torch.Tensor) and t.requires_grad for t in (Y, w, amp, diag_add, diag_vec)]
+        out = torch.empty((), dtype=torch.float64, device=dev)
+        g = None
+        grads = {}
+        if any(needs):
+            g = Grads()
+            if needs[0]:
+                grads["Y"] = torch.empty((n, d), dtype=torch.float64, device=dev)
+                g.g_Y_dev = _ptr(grads["Y"])
+            if needs[1]:
+                grads["w"] = torch.empty((D,), dtype=torch.float64, device=dev)
+                g.g_w_dev = _ptr(grads["w"])
+            if needs[2]:
+                grads["amp"] = torch.empty((1,), dtype=torch.float64, device=dev)
+                g.g_amp_dev = _ptr(grads["amp"])
+            if needs[3]:
+                grads["diag_add"] = torch.empty((1,), dtype=torch.float64, device=dev)
+                g.g_diag_add_dev = _ptr(grads["diag_add"])
+            if needs[4]:
+                grads["diag_vec"] = torch.empty((n,), dtype=torch.float64, device=dev)
+                g.g_diag_vec_dev = _ptr(grads["diag_vec"])
+        rc = check(lib.ffgp_nlml_fused(h, C.byref(p), _ptr(out), C.byref(g) if g is not None else None),
+                   "ffgp_nlml_fused")
+        if rc > 0:
+            _raise_not_pd(rc, "linalg.cholesky")
+        ctx.grads = grads
+        ctx.meta = [(t.shape, t.dtype, t.device) if isinstance(t, torch.Tensor) else None
+                    for t in (Y, w, amp, diag_add, diag_vec)]
+        return out.to(device=Y.device, dtype=Y.dtype if Y.dtype.is_floating_point else torch.float64)
+
+    @staticmethod
+    def backward(ctx, gout):
+        gr = ctx.grads
+
+        def fin(key, idx):
+            if key not in gr or ctx.meta[idx] is None:
+                return None
+            shape, dtype, device = ctx.meta[idx]
+            t = gr[key] * gout.to(device=gr[key].device, dtype=torch.float64)
+            if key == "w" and math.prod(shape) == 1 and t.numel() > 1:
+                t = t.sum().reshape(1)  # a scalar length scale was broadcast over the D input dimensions
+            if key == "diag_vec" and len(shape) == 2:
+                t = torch.diag_embed(t)
+            return t.reshape(shape).to(device=device, dtype=dtype)
+
+        return (None, fin("Y", 0), fin("w", 1), fin("amp", 2), fin("diag_add", 3), fin("diag_vec", 4), None, None, None,
+                None, None, None)
+
+
+def nlml(X, Y, w, amp, diag_add=None, diag_vec=None, add_mat=None, add_all=0.0, mean_jitter=0.0, clamp=NEG_INF,
+         variant=FFGP_LL_V1, pi_const=PI_TRUNC):
+    """Negative log marginal likelihood of one GP block through the fused HIP path (assemble -> blocked Cholesky
+    with Y^T riding as passenger rows -> reductions -> closed-form gradients)."""
+    return _NLML.apply(X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, variant, pi_const)
+
+
+@torch.no_grad()
+def predict(X, Y, Xs, w, amp, diag_add=None, diag_vec=None, add_mat=None, add_all=0.0, mean_jitter=0.0, clamp=NEG_INF,
+            full_cov=True, var_add_all=0.0):
+    """Posterior mean [Nt, d] and covariance [Nt, Nt] (or variance [Nt]) at Xs."""
+    dev = _device_of(X, Y, Xs, w, amp)
+    h = _lib.handle(dev.index)
+    _lib.bind_stream(h, dev.index)
+    keep = []
+    p, (n, D, d) = _problem(dev, X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, FFGP_LL_V1,
+                            PI_TRUNC, keep)
+    Xsd = _dev(Xs, dev)
+    nt = Xsd.shape[0]
+    mean = torch.empty((nt, d), dtype=torch.float64, device=dev)
+    var = torch.empty((nt, nt) if full_cov else (nt,), dtype=torch.float64, device=dev)
+    rc = check(lib.ffgp_predict(h, C.byref(p), _ptr(Xsd), nt, FFGP_VAR_FULL if full_cov else FFGP_VAR_DIAG,
+                                float(var_add_all), _ptr(mean), _ptr(var), nt), "ffgp_predict")
+    if rc > 0:
+        _raise_not_pd(rc, "linalg.cholesky")
+    odt = Y.dtype if Y.dtype.is_floating_point else torch.float64
+    return mean.to(device=Y.device, dtype=odt), var.to(device=Y.device, dtype=odt)
+
+
+@torch.no_grad()
+def kernel_matrix(x1, x2, w, amp, clamp=NEG_INF):
+    """K(x1, x2) [n1, n2] on the device (no Sigma extras)."""
+    dev = _device_of(x1, x2, w, amp)
+    h = _lib.handle(dev.index)
+    _lib.bind_stream(h, dev.index)
+    a, b = _dev(x1, dev), _dev(x2, dev)
+    if a.dim() > 2:  # SE_kernel.py:29-32 flattens >2-D inputs
+        a, b = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+    D = a.shape[1]
+    wd = _dev(w.reshape(-1), dev)
+    if wd.numel() == 1 and D > 1:
+        wd = wd.expand(D).contiguous()
+    ad = _dev(amp.reshape(-1)[:1], dev)
+    K = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float64, device=dev)
+    check(lib.ffgp_assemble(h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], D, _ptr(wd), _ptr(ad), clamp, None, None, 0, None,
+                            0, 0.0, 0.0, _ptr(K), b.shape[0], 0), "ffgp_assemble")
+    odt = x1.dtype if x1.dtype.is_floating_point else torch.float64
+    return K.to(device=x1.device, dtype=odt)
+
+
+def _pad_ld(n):
+    return (n + 1) // 2 * 2
+
+
+@torch.no_grad()
+def cholesky_with_rows(Sigma, rows=None):
+    """Lower factor of Sigma [n, n]; if `rows` [m, n] is given also returns rows @ L^-T (= (L^-1 rows^T)^T),
+    computed inside the factorisation (ffgp_potrf_rows)."""
+    dev = _device_of(Sigma, rows)
+    h = _lib.handle(dev.index)
+    _lib.bind_stream(h, dev.index)
+    n = Sigma.shape[0]
+    m = 0 if rows is None else rows.shape[0]
+    ld = _pad_ld(n)
+    W = torch.zeros((n + m, ld), dtype=torch.float64, device=dev)
+    W[:n, :n] = _dev(Sigma, dev)
+    if m:
+        W[n:, :n] = _dev(rows, dev)
+    rc = check(lib.ffgp_potrf_rows(h, _ptr(W), n, n + m, ld), "ffgp_potrf_rows")
+    if rc > 0:
+        _raise_not_pd(rc, "linalg.cholesky")
+    L = torch.tril(W[:n, :n])
+    return (L, W[n:, :n]) if m else (L, None)
+
+
+def cholesky(Sigma):
+    """Drop-in for torch.linalg.cholesky on the GP path (lower factor, raises LinAlgError if not PD)."""
+    L, _ = cholesky_with_rows(Sigma)
+    return L.to(device=Sigma.device, dtype=Sigma.dtype)
+
+
+@torch.no_grad()
+def gaussian_ll_v2(Y, cov):
+    """-LL of the reference's 'cholesky3' Gaussian_log_likelihood (Sigma^-2 quadratic form), from a given cov."""
+    dev = _device_of(Y, cov)
+    h = _lib.handle(dev.index)
+    _lib.bind_stream(h, dev.index)
+    n, d = Y.shape
+    ld = _pad_ld(n)
+    W = torch.zeros((n, ld), dtype=torch.float64, device=dev)
+    W[:, :n] = _dev(cov, dev)
+    rc = check(lib.ffgp_potrf(h, _ptr(W), n, ld), "ffgp_potrf")
+    if rc > 0:
+        _raise_not_pd(rc, "linalg.cholesky")
+    A = _dev(Y, dev).clone()
+    check(lib.ffgp_potrs(h, _ptr(W), n, ld, _ptr(A), d, d), "ffgp_potrs")
+    out = torch.empty((), dtype=torch.float64, device=dev)
+    check(lib.ffgp_nll_reduce(h, FFGP_LL_V2, _ptr(W), n, ld, _ptr(A), d, d, math.pi, _ptr(out)), "ffgp_nll_reduce")
+    return out
+
+
+@torch.no_grad()
+def matmul_nt(A, B, alpha=1.0):
+    """alpha * A @ B^T for device tensors A [m, k], B [n, k] on the fp64 matrix-core GEMM (ffgp_gemm)."""
+    dev = _device_of(A, B)
+    h = _lib.handle(dev.index)
+    _lib.bind_stream(h, dev.index)
+    a, b = _dev(A, dev), _dev(B, dev)
+    m, k = a.shape
+    n = b.shape[0]
+    out = torch.empty((m, n), dtype=torch.float64, device=dev)
+    check(lib.ffgp_gemm(h, 0, 0, 0, 0, _ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), n, m, n, k, float(alpha), 0.0),
+          "ffgp_gemm")
+    return out

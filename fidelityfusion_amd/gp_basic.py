@@ -1,0 +1,46 @@
+"""`GP_basic` (reference: GaussianProcess/gp_basic.py:15-153) -- the noise_variance^2 convention used by CAR.
+
+Sigma = K + noise_variance^2 I [+ the FULL y_var matrix when y_train = [y, y_var]] with no jitter (:63-65,117-119);
+only the 'cholesky3' branch is on the HIP path: forward = conditional Gaussian (:78-84), log_likelihood = the
+Sigma^-2 form shared with gp_computation_pack.Gaussian_log_likelihood (:130-143).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import functional as F
+from .gp_computation_pack import _check_method
+
+_METHODS_FWD = ("cholesky1", "cholesky3", "direct")
+_METHODS_LL = ("cholesky1", "cholesky2", "cholesky3", "direct", "torch_distribution_MN1", "torch_distribution_MN2")
+
+
+def _split(y_train):
+    if isinstance(y_train, list):
+        return y_train[0], y_train[1]
+    return y_train, None
+
+
+class GP_basic(nn.Module):
+    def __init__(self, kernel, noise_variance):
+        super().__init__()
+        self.kernel = kernel
+        self.noise_variance = nn.Parameter(torch.tensor([noise_variance]))
+
+    def forward(self, x_train, y_train, x_test, Kinv_method="cholesky3"):
+        _check_method(Kinv_method, _METHODS_FWD)
+        y_train, y_var = _split(y_train)
+        w, amp, clamp = self.kernel.effective()
+        mu, var = F.predict(x_train, y_train, x_test, w, amp, diag_add=self.noise_variance.pow(2), add_mat=y_var,
+                            clamp=clamp, full_cov=True, var_add_all=0.0)
+        return mu.squeeze(), var
+
+    def log_likelihood(self, x_train, y_train, Kinv_method="cholesky3"):
+        _check_method(Kinv_method, _METHODS_LL)
+        y_train, y_var = _split(y_train)
+        w, amp, clamp = self.kernel.effective()
+        nll = F.nlml(x_train, y_train, w, amp, diag_add=self.noise_variance.pow(2), add_mat=y_var, clamp=clamp,
+                     variant=F.FFGP_LL_V2, pi_const=math.pi)
+        ll = -nll
+        return ll.reshape(1, 1) if y_train.shape[1] == 1 else ll

@@ -1,0 +1,59 @@
+"""The "GP computation pack" (reference: GaussianProcess/gp_computation_pack.py) on libffgp.
+
+    Gaussian_log_likelihood(y, cov, Kinv_method='cholesky3')        :34-91
+    conditional_Gaussian(y, Sigma, K_s, K_ss, Kinv_method='cholesky3')  :93-118
+    negative_log_likelihood(kernel, log_beta, x_train, y_train)     :120-136  (returns +LL)
+
+Only the 'cholesky3' method -- the one every model in the reference uses -- is implemented; the other
+`Kinv_method`s of the reference are alternative formulas for the same quantities (explicit inverses, d=1 only)
+and raise NotImplementedError here, an unknown name raises ValueError as in the reference (:91,116).
+"""
+import math
+
+import torch
+
+from . import functional as F
+
+EPS = 1e-9
+JITTER = 1e-6
+PI = 3.1415
+
+_REFERENCE_METHODS = ("cholesky1", "cholesky2", "cholesky3", "direct", "torch_distribution_MN1", "torch_distribution_MN2")
+
+
+def _check_method(name, allowed):
+    if name == "cholesky3":
+        return
+    if name in allowed:
+        raise NotImplementedError("Kinv_method=%r: only 'cholesky3' is built on the HIP path" % name)
+    raise ValueError("Kinv_method should be either direct or cholesky")
+
+
+def Gaussian_log_likelihood(y, cov, Kinv_method="cholesky3"):
+    """LL of N(0, cov) with the reference's Sigma^-2 quadratic form (gamma = cholesky_solve(y, L), :76-80).
+    d == 1 returns shape [1, 1] as the reference does (:80), d > 1 a 0-dim tensor (:77)."""
+    assert len(y.shape) == 2 and len(cov.shape) == 2, "y, mean, cov should be 2D tensors"
+    _check_method(Kinv_method, _REFERENCE_METHODS)
+    ll = -F.gaussian_ll_v2(y, cov).to(device=y.device, dtype=y.dtype)
+    return ll.reshape(1, 1) if y.shape[1] == 1 else ll
+
+
+def conditional_Gaussian(y, Sigma, K_s, K_ss, Kinv_method="cholesky3"):
+    """mu = K_s^T Sigma^-1 y ; cov = K_ss - (L^-1 K_s)^T (L^-1 K_s)   (:103-110).
+    Both solves ride as passenger rows of one factorisation."""
+    _check_method(Kinv_method, ("cholesky1", "cholesky3", "direct"))
+    rows = torch.cat([y.T, K_s.T], 0)
+    _, R = F.cholesky_with_rows(Sigma, rows)
+    d = y.shape[1]
+    Gt, Vt = R[:d], R[d:]                       # Gamma^T [d, n], V^T [nt, n]
+    mu = F.matmul_nt(Vt, Gt).to(device=y.device, dtype=y.dtype)
+    cov = K_ss - F.matmul_nt(Vt, Vt).to(device=K_ss.device, dtype=K_ss.dtype)
+    return mu, cov
+
+
+def negative_log_likelihood(kernel, log_beta, x_train, y_train):
+    """Sigma = K + exp(-log_beta) I + 1e-6 mean(K) I ; returns +LL with pi = 3.1415 (:120-136)."""
+    w, amp, clamp = kernel.effective()
+    nll = F.nlml(x_train, y_train, w, amp, diag_add=log_beta.exp().pow(-1), mean_jitter=JITTER, clamp=clamp,
+                 variant=F.FFGP_LL_V1, pi_const=PI)
+    return -nll

@@ -1,0 +1,135 @@
+"""Per-fidelity sharding of the joint log marginal likelihood.
+
+The joint likelihood of the multi-fidelity models is a plain sum over fidelities of independent GP blocks with
+disjoint hyper-parameters -- `loss += cigp_list[f].compute_loss(...)` in MFGP_ver2023May/ResGP.py:232-246, and the
+2024 trainers optimise `gpr_list[i]` one after another (FidelityFusion_Models/ResGP.py:78-112, CIGAR.py:99-134).
+So the blocks shard embarrassingly: fidelity f -> rank (longest-processing-time first on N_f^3), every rank
+runs the fused HIP NLML(+gradient) on the blocks it owns, keeps their parameters and optimiser state, and the only
+exchange is ONE all-reduce(SUM) of the F-vector of per-block values per step (8*F bytes: latency-bound over xGMI,
+`torch.distributed` backend "nccl" = RCCL) so that every rank can log the joint NLML.  Prediction all-gathers
+the per-fidelity posteriors.  There is no data-path collective.
+
+The non-subset "fill" mode of the reference (MF_data.py:253-303) makes fidelity f's targets depend on the trained
+posterior of f-1 and therefore does not shard ("replicas only"); the aligned/subset regime does.
+"""
+import torch
+import torch.distributed as dist
+
+
+def partition_lpt(costs, world_size):
+    """Longest-processing-time-first assignment.  costs[f] ~ N_f^3 (+ N_f^2 d_f).  Returns owner[f] (rank)."""
+    order = sorted(range(len(costs)), key=lambda f: (-costs[f], f))
+    load = [0.0] * world_size
+    owner = [0] * len(costs)
+    for f in order:
+        r = min(range(world_size), key=lambda i: (load[i], i))
+        owner[f] = r
+        load[r] += costs[f]
+    return owner
+
+
+def block_cost(n, d):
+    return float(n) ** 3 / 3.0 + float(n) * float(n) * float(d)
+
+
+def _rank_world(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def hip_block_evaluator(device=None):
+    """Default evaluator: cigp (ARD kernel) on the fused HIP path.  block = dict(X, Y, length_scales,
+    signal_variance, log_beta); returns the block's +LL (what cigp.negative_log_likelihood returns) as a float."""
+    from . import kernel
+    from .cigp_v10 import cigp
+
+    def evaluate(block):
+        dev = device or torch.device("cuda", torch.cuda.current_device())
+        k = kernel.ARDKernel(len(block["length_scales"]))
+        with torch.no_grad():
+            k.length_scales.copy_(torch.as_tensor(block["length_scales"], dtype=k.length_scales.dtype))
+            k.signal_variance.copy_(torch.as_tensor(block["signal_variance"], dtype=k.signal_variance.dtype).reshape(1))
+        m = cigp(k, float(torch.as_tensor(block["log_beta"]).reshape(-1)[0])).to(dev).double()
+        X = torch.as_tensor(block["X"], dtype=torch.float64, device=dev)
+        Y = torch.as_tensor(block["Y"], dtype=torch.float64, device=dev)
+        with torch.no_grad():
+            return float(m.negative_log_likelihood(X, Y))
+
+    return evaluate
+
+
+def joint_ll(blocks, evaluator=None, group=None, reduce_device=None):
+    """Every rank evaluates the blocks it owns; one all-reduce(SUM) of the F-vector.
+    Returns (ll_per_block [F] tensor, joint LL float) -- identical on every rank."""
+    rank, world = _rank_world(group)
+    evaluator = evaluator or hip_block_evaluator()
+    costs = [block_cost(len(b["X"]), b["Y"].shape[1] if hasattr(b["Y"], "shape") else 1) for b in blocks]
+    owner = partition_lpt(costs, world)
+    if reduce_device is None:
+        use_cuda = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        reduce_device = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
+    vec = torch.zeros(len(blocks), dtype=torch.float64, device=reduce_device)
+    for f, b in enumerate(blocks):
+        if owner[f] == rank:
+            vec[f] = evaluator(b)
+    if world > 1:
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
+    return vec, float(vec.sum())
+
+
+def joint_nll_single_process(blocks, device=None):
+    """All blocks on one GPU (the N = 1 case of joint_ll); returns the list of per-block +LL."""
+    ev = hip_block_evaluator(torch.device(device) if device is not None else None)
+    return [ev(b) for b in blocks]
+
+
+class ShardedTrainer:
+    """One Adam step per call on every owned block (the reference's per-fidelity loop body,
+    FidelityFusion_Models/ResGP.py:82-88), then the scalar all-reduce for the joint value.
+    `make_model(f)` -> nn.Module with `.negative_log_likelihood(x, y)`; `data[f]` = (x, y)."""
+
+    def __init__(self, make_model, data, costs, lr=1e-2, group=None):
+        self.group = group
+        self.rank, self.world = _rank_world(group)
+        self.owner = partition_lpt(costs, self.world)
+        self.F = len(costs)
+        self.models, self.opts, self.data = {}, {}, {}
+        for f in range(self.F):
+            if self.owner[f] == self.rank:
+                self.models[f] = make_model(f)
+                self.opts[f] = torch.optim.Adam(self.models[f].parameters(), lr=lr)
+                self.data[f] = data[f]
+
+    def step(self, reduce_device=None):
+        dev = reduce_device
+        if dev is None:
+            use_cuda = dist.is_initialized() and dist.get_backend(self.group) == "nccl"
+            dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
+        vec = torch.zeros(self.F, dtype=torch.float64, device=dev)
+        for f, m in self.models.items():
+            self.opts[f].zero_grad()
+            loss = -m.negative_log_likelihood(*self.data[f])
+            loss.backward()
+            self.opts[f].step()
+            vec[f] = loss.detach().to(dev)
+        if self.world > 1:
+            dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.group)
+        return vec
+
+    def gather_posteriors(self, x_test):
+        """all-gather of the per-fidelity posterior means / variances at x_test (each rank computes its own
+        blocks; the cheap residual chain is applied by the caller, FidelityFusion_Models/CIGAR.py:75-76)."""
+        local = {}
+        with torch.no_grad():
+            for f, m in self.models.items():
+                mean, var = m(self.data[f][0], self.data[f][1], x_test)
+                local[f] = (mean.cpu(), var.cpu())
+        if self.world == 1:
+            return local
+        out = [None] * self.world
+        dist.all_gather_object(out, local, group=self.group)
+        merged = {}
+        for part in out:
+            merged.update(part)
+        return merged

@@ -1,0 +1,180 @@
+/*
+ * libffgp -- MI355X (gfx950) native Gaussian-process hot path: C ABI.
+ *
+ * Drop-in boundary for the GP computation path of IceLab-X/FidelityFusion.  The reference has no FFI of its
+ * own (it is pure Python on torch); each entry point below names the reference call it replaces
+ * (file:line relative to the reference root).  The Python shim (fidelityfusion_amd/_lib.py, ctypes) is the
+ * reference-side binding; INTEGRATION.md shows how the reference's modules would call it.
+ *
+ * Conventions
+ *   - every pointer named *_dev is a DEVICE pointer to row-major (C-contiguous) fp64 data;
+ *   - every call returns int: 0 = ok; > 0 = 1-based index of the first non-positive pivot (the matrix is not
+ *     positive definite -- torch.linalg.cholesky raises torch.linalg.LinAlgError there); < 0 = FFGP_ERR_*;
+ *   - work is enqueued on the handle's stream (ffgp_set_stream); calls that return a status derived from
+ *     device data (ffgp_potrf, ffgp_nlml_fused, ffgp_predict) synchronise that stream before returning;
+ *   - nothing here falls back to the CPU: without a gfx950 device ffgp_create fails.
+ *
+ * Parameterisation.  All of the reference's stationary kernels on this path are
+ *        K_ij = amp * exp(-1/2 * max(sum_k ((x_ik - x_jk) * w_k)^2, clamp_min))
+ *   K1 ARDKernel               (GaussianProcess/kernel.py:88-105):   w = 1/(|length_scales|+1e-9), amp = |signal_variance|, clamp 1e-30
+ *   K2 SquaredExponentialKernel(GaussianProcess/kernel.py:258-272):  w = exp(-length_scale) (all D), amp = exp(signal_variance)^2, clamp -inf
+ *   K3 SE_kernel 2023          (MFGP_ver2023May/kernel/SE_kernel.py:20-44): w = 1/length_scale (or exp form), amp = scale
+ * and every covariance on the path is
+ *        Sigma = K + diag_add*I + diag(diag_vec) + add_mat + add_all*11^T + mean_jitter*mean(K)*I
+ *   S1 cigp_v10.py:57-60           diag_add = exp(-log_beta)+1e-6, diag_vec = diag(y_var)
+ *   S2 gp_computation_pack.py:125  diag_add = exp(-log_beta), mean_jitter = 1e-6
+ *   S3 gp_basic.py:63-65,117-119   diag_add = noise_variance^2, add_mat = y_var
+ *   S4 MFGP_ver2023May/base_gp/cigp.py:124-127  diag_add = 1e-6 + 1/noise, add_all = y_var
+ * The raw->effective maps (abs, exp, pow) are O(D) and stay in the host language (torch autograd chains
+ * through them); the ABI takes the effective w/amp/diag_add as DEVICE scalars so no call forces a D2H copy
+ * of a parameter, and returns gradients with respect to those effective quantities.
+ */
+#ifndef FFGP_H
+#define FFGP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ffgp_handle ffgp_handle;
+
+enum {
+  FFGP_OK = 0,
+  FFGP_ERR_ARG = -1,    /* bad argument (null pointer, negative size, misaligned leading dimension) */
+  FFGP_ERR_HIP = -2,    /* a HIP runtime call failed (message on stderr) */
+  FFGP_ERR_ALLOC = -3,  /* device workspace allocation failed */
+  FFGP_ERR_NODEVICE = -4
+};
+
+/* likelihood formula variants */
+enum {
+  FFGP_LL_V1 = 1, /* nll = 1/2||L^-1 Y||^2 + d*sum(log L_ii) + 1/2*N*d*log(2*pi_const)
+                     cigp_v10.py:61-69; gp_computation_pack.py:128-136; base_gp/cigp.py:129-136 (pi_const = 3.1415) */
+  FFGP_LL_V2 = 2  /* -LL = 1/2(||Sigma^-1 Y||^2 + 2d*sum(log L_ii) + N*d*log(2*pi))  (the Sigma^-2 form of
+                     Gaussian_log_likelihood 'cholesky3', gp_computation_pack.py:65-80; gp_basic.py:130-143) */
+};
+
+/* prediction outputs */
+enum {
+  FFGP_VAR_FULL = 0, /* cov[Nt,Nt] = K** - V^T V + var_add_all              (cigp_v10.py:41-44; gp_computation_pack.py:108-110) */
+  FFGP_VAR_DIAG = 1  /* var[Nt]    = diag(K**) - colsum(V^2) + var_add_all  (base_gp/cigp.py:91-94) */
+};
+
+/* One GP block: inputs, targets, effective kernel/noise quantities.  All pointers are device pointers. */
+typedef struct {
+  int n;                  /* training points */
+  int D;                  /* input dimension */
+  int d;                  /* output columns */
+  const double* X_dev;    /* [n, D] */
+  const double* Y_dev;    /* [n, d] */
+  const double* w_dev;    /* [D]  inverse length scales */
+  const double* amp_dev;  /* [1]  amplitude */
+  double clamp_min;       /* lower clamp on the squared distance (1e-30 for K1, -inf for K2/K3) */
+  const double* diag_add_dev; /* [1] scalar added to the diagonal */
+  const double* diag_vec_dev; /* optional: entry i at diag_vec_dev[i*diag_stride] (pass the N x N y_var with stride N+1) */
+  long diag_stride;
+  const double* add_mat_dev;  /* optional full [n, n] matrix added to Sigma (only its lower triangle is read) */
+  int ld_add;
+  double add_all;         /* scalar added to every entry */
+  double mean_jitter;     /* coefficient of mean(K)*I (1e-6 for gp_computation_pack.negative_log_likelihood, else 0) */
+  int ll_variant;         /* FFGP_LL_V1 | FFGP_LL_V2 */
+  double pi_const;        /* 3.1415 for the V1 call sites, M_PI for V2 */
+} ffgp_problem;
+
+/* Gradients of the value returned by ffgp_nlml_fused with respect to the effective quantities.
+   Any pointer may be NULL (that gradient is skipped); all are device pointers. */
+typedef struct {
+  double* g_w_dev;        /* [D] */
+  double* g_amp_dev;      /* [1] */
+  double* g_diag_add_dev; /* [1]  (= tr G, plus the mean-jitter chain for S2) */
+  double* g_Y_dev;        /* [n, d] */
+  double* g_diag_vec_dev; /* [n]  (= diag G), optional */
+} ffgp_grads;
+
+/* ---- lifetime ------------------------------------------------------------------------------------------ */
+int ffgp_create(int device, ffgp_handle** out);
+int ffgp_destroy(ffgp_handle* h);
+int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL restores the handle's own stream */
+/* options: "timing" (0/1: record per-stage hipEvents), "nb_outer" (trailing-update block, multiple of 128),
+            "naive" (1: route factor kernels through the slow reference kernels; debugging only) */
+int ffgp_set_option(ffgp_handle* h, const char* key, double value);
+const char* ffgp_version(void);
+
+/* ---- building blocks ------------------------------------------------------------------------------------ */
+/* K(x1,x2) [+ Sigma extras when the matrix is square and symmetric].  Replaces kernel.forward
+   (GaussianProcess/kernel.py:88-105,258-272; MFGP_ver2023May/kernel/SE_kernel.py:20-44) and the torch.eye
+   adds at cigp_v10.py:31-32,57-60; gp_computation_pack.py:125-126; gp_basic.py:63-65; base_gp/cigp.py:79-81,124-127.
+   lower_only != 0: only tiles on/below the diagonal are written (n1 must equal n2).                      */
+int ffgp_assemble(ffgp_handle* h, const double* X1_dev, int n1, const double* X2_dev, int n2, int D,
+                  const double* w_dev, const double* amp_dev, double clamp_min, const double* diag_add_dev,
+                  const double* diag_vec_dev, long diag_stride, const double* add_mat_dev, int ld_add,
+                  double add_all, double mean_jitter, double* K_dev, int ldk, int lower_only);
+
+/* In-place lower Cholesky, A = L L^T (strictly-upper part is not referenced and not written).
+   Replaces torch.linalg.cholesky at cigp_v10.py:35,61; gp_computation_pack.py:67,105,128; gp_basic.py:80,131;
+   base_gp/cigp.py:83,129.  lda must be even and A_dev 16-byte aligned.                                     */
+int ffgp_potrf(ffgp_handle* h, double* A_dev, int n, int lda);
+
+/* Same factorisation with "passenger" rows: A is mtot x n (mtot >= n); the leading n x n block is factored and
+   rows n..mtot-1 come out as A[n:, :] L^-T, i.e. (L^-1 B)^T for a right-hand side stored transposed below Sigma.
+   This is how the fused paths obtain Gamma = L^-1 Y (cigp_v10.py:63) and V = L^-1 K_* (cigp_v10.py:36) inside
+   the factorisation's own matrix-core GEMMs instead of separate triangular sweeps.                            */
+int ffgp_potrf_rows(ffgp_handle* h, double* A_dev, int n, int mtot, int lda);
+
+/* B <- L^-1 B.  Replaces torch.triangular_solve(B, L, upper=False) (cigp_v10.py:36,63;
+   gp_computation_pack.py:130) and `L.inverse() @ B` (base_gp/cigp.py:131; gp_computation_pack.py:108).      */
+int ffgp_trsm_lower(ffgp_handle* h, const double* L_dev, int n, int ldl, double* B_dev, int nrhs, int ldb);
+
+/* B <- L^-T B (second half of cholesky_solve). */
+int ffgp_trsm_lower_t(ffgp_handle* h, const double* L_dev, int n, int ldl, double* B_dev, int nrhs, int ldb);
+
+/* B <- (L L^T)^-1 B.  Replaces torch.cholesky_solve (cigp_v10.py:39; gp_computation_pack.py:76,106). */
+int ffgp_potrs(ffgp_handle* h, const double* L_dev, int n, int ldl, double* B_dev, int nrhs, int ldb);
+
+/* out_dev[0] = 1/2*sum(M^2) + d*sum(log L_ii) + 1/2*n*d*log(2*pi_const)   (M = Gamma for V1, Sigma^-1 Y for V2 with
+   the log-det counted as in FFGP_LL_V2).  Replaces cigp_v10.py:67-68 / gp_computation_pack.py:79.          */
+int ffgp_nll_reduce(ffgp_handle* h, int variant, const double* L_dev, int n, int ldl, const double* M_dev, int d,
+                    int ldm, double pi_const, double* out_dev);
+
+/* Sinv (lower triangle) <- (L L^T)^-1 from the factor, via blocked TRTRI + LAUUM on the matrix cores. */
+int ffgp_potri(ffgp_handle* h, double* L_dev, int n, int ldl);
+
+/* C[m,n] = alpha * op(A) op(B) + beta * C on the fp64 matrix cores (the kernel under every O(N^3) stage).
+   opa = 0: A stored m x k (k contiguous); opa = 1: A stored k x m (m contiguous), i.e. op(A) = A^T.
+   opb = 0: B stored n x k (k contiguous), i.e. op(B) = B^T;  opb = 1: B stored k x n (n contiguous).
+   lower_tiles != 0: only elements with col <= row are computed/written (m >= n, origin on the diagonal).
+   tri: OR of 1 (k starts at the tile row), 2 (k starts at the tile column), 4 (k ends after the tile row),
+        8 (k ends after the tile column) -- skips k-tiles that are structurally zero for triangular operands.
+   Supported (opa, opb, lower_tiles): (0,0,*), (0,1,0), (1,0,0), (1,1,*).                                    */
+int ffgp_gemm(ffgp_handle* h, int opa, int opb, int lower_tiles, int tri, const double* A_dev, int lda,
+              const double* B_dev, int ldb, double* C_dev, int ldc, int m, int n, int k, double alpha, double beta);
+
+/* ---- fused hot path ------------------------------------------------------------------------------------- */
+/* nll_dev[0] <- negative log marginal likelihood of the block (V1: +nll; V2: -LL); if g != NULL also its
+   closed-form gradients.  One call = assemble -> potrf -> trsm/potrs -> reduce (-> potri -> fused gradient).
+   Replaces cigp.negative_log_likelihood (cigp_v10.py:50-69) + loss.backward() (FidelityFusion_Models/ResGP.py:84-87),
+   gp_computation_pack.negative_log_likelihood (:120-136), GP_basic.log_likelihood (gp_basic.py:94-143),
+   CIGP.compute_loss (MFGP_ver2023May/base_gp/cigp.py:99-136).  Returns 0, or the failing pivot index.       */
+int ffgp_nlml_fused(ffgp_handle* h, const ffgp_problem* p, double* nll_dev, const ffgp_grads* g);
+
+/* Posterior at Xs[nt, D] for the block p (its ll_variant/pi_const are ignored; Sigma extras are honoured
+   as given -- the reference's predict paths drop y_var, so callers pass the problem without it).
+   mean_dev[nt, d] = K*^T Sigma^-1 Y;  var per var_mode with var_add_all added to every entry.
+   Replaces cigp.forward (cigp_v10.py:24-48), conditional_Gaussian (gp_computation_pack.py:103-110),
+   GP_basic.forward (gp_basic.py:78-84), CIGP.forward (base_gp/cigp.py:78-95).                               */
+int ffgp_predict(ffgp_handle* h, const ffgp_problem* p, const double* Xs_dev, int nt, int var_mode,
+                 double var_add_all, double* mean_dev, double* var_dev, int ldv);
+
+/* ---- instrumentation ------------------------------------------------------------------------------------ */
+/* stage timings (ms) of the last fused call when option "timing" = 1; names are static strings */
+int ffgp_last_timings(ffgp_handle* h, float* ms_out, const char** names_out, int max_stages, int* n_stages);
+/* accumulated launches / algorithmic flops / device ms of the trailing-update SYRK kernel (the roofline kernel);
+   reset = 1 clears the counters after reading.  ms is only accumulated while option "timing" = 2.           */
+int ffgp_syrk_stats(ffgp_handle* h, double* flops, double* ms, long* launches, int reset);
+/* peak probe: runs a register-resident v_mfma_f64_16x16x4_f64 loop on every CU, returns measured TFLOP/s */
+int ffgp_mfma_f64_peak(ffgp_handle* h, double* tflops_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFGP_H */

@@ -1,0 +1,298 @@
+"""GPU: each HIP kernel family against numpy on the same seeded inputs, called through the C ABI (ctypes).
+These are the per-kernel tests (layer 2 of the pyramid in SURVEY.md section 4); end-to-end parity with the
+oracle and the golden fixtures is in test_gpu_parity.py."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ff():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from fidelityfusion_amd import _lib
+    h = _lib.handle(0)
+    _lib.bind_stream(h, 0)
+    return _lib, h
+
+
+def dev(a):
+    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda:0")
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def relerr(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def run_gemm(ff, opa, opb, lower, tri, A, B, C0, alpha, beta, pad=(0, 0, 0)):
+    """A is op(A) [m,k]; B is op(B) [k,n]; returns C.  Storage follows the op flags; pads add to the lds."""
+    _lib, h = ff
+    m, k = A.shape
+    n = B.shape[1]
+    As = A if opa == 0 else A.T
+    Bs = B.T if opb == 0 else B
+    def padded(M, extra):
+        buf = np.full((M.shape[0], M.shape[1] + extra), np.nan)
+        buf[:, :M.shape[1]] = M
+        return buf
+    Ab, Bb, Cb = padded(As, pad[0]), padded(Bs, pad[1]), padded(C0, pad[2])
+    Ad, Bd, Cd = dev(Ab), dev(Bb), dev(Cb)
+    rc = _lib.lib.ffgp_gemm(h, opa, opb, lower, tri, ptr(Ad), Ab.shape[1], ptr(Bd), Bb.shape[1], ptr(Cd), Cb.shape[1],
+                            m, n, k, alpha, beta)
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    out = Cd.cpu().numpy()
+    assert np.isnan(out[:, C0.shape[1]:]).all() or pad[2] == 0, "gemm wrote into the ldc padding"
+    return out[:, :C0.shape[1]]
+
+
+@pytest.mark.parametrize("opa,opb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("m,n,k", [(128, 128, 16), (256, 128, 64), (100, 77, 21), (1, 1, 1), (300, 200, 130), (129, 257, 48)])
+def test_gemm_layouts(ff, opa, opb, m, n, k):
+    rng = np.random.default_rng(m * 7 + n * 3 + k + opa * 2 + opb)
+    A = rng.standard_normal((m, k))
+    B = rng.standard_normal((k, n))      # asymmetric operands: a swapped row/col map cannot hide
+    C0 = rng.standard_normal((m, n))
+    out = run_gemm(ff, opa, opb, 0, 0, A, B, C0, -1.0, 1.0, pad=(2, 4, 6))
+    assert relerr(out, C0 - A @ B) < 1e-13, (opa, opb, m, n, k)
+    out = run_gemm(ff, opa, opb, 0, 0, A, B, np.full((m, n), np.nan), 2.0, 0.0, pad=(0, 0, 0))
+    assert relerr(out, 2.0 * A @ B) < 1e-13, "beta == 0 must not read C"
+
+
+def test_gemm_identity_asymmetric(ff):
+    """A = I with an asymmetric B: catches a transposed accumulator map (cdna guide, section 3)."""
+    B = np.arange(128 * 128, dtype=np.float64).reshape(128, 128)
+    out = run_gemm(ff, 0, 1, 0, 0, np.eye(128), B, np.zeros((128, 128)), 1.0, 0.0)
+    assert np.array_equal(out, B)
+    out = run_gemm(ff, 0, 0, 0, 0, np.eye(128), B, np.zeros((128, 128)), 1.0, 0.0)
+    assert np.array_equal(out, B)
+
+
+def test_gemm_unaligned_operands(ff):
+    """odd leading dimensions fall back to 8-byte loads"""
+    rng = np.random.default_rng(5)
+    A, B = rng.standard_normal((70, 33)), rng.standard_normal((33, 5))
+    for opa in (0, 1):
+        for opb in (0, 1):
+            out = run_gemm(ff, opa, opb, 0, 0, A, B, np.zeros((70, 5)), 1.0, 0.0, pad=(1, 1, 0) if (opa + opb) % 2 else (0, 0, 0))
+            assert relerr(out, A @ B) < 1e-13
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 32), (300, 300, 64), (700, 300, 128), (1300, 1300, 16), (1100, 129, 40)])
+@pytest.mark.parametrize("ops", [(0, 0), (1, 1)])
+def test_gemm_lower_trapezoid(ff, m, n, k, ops):
+    rng = np.random.default_rng(m + n + k)
+    A = rng.standard_normal((m, k))
+    B = rng.standard_normal((k, n))
+    C0 = rng.standard_normal((m, n))
+    out = run_gemm(ff, ops[0], ops[1], 1, 0, A, B, C0, -1.0, 1.0, pad=(0, 0, 2))
+    full = C0 - A @ B
+    mask = np.tril(np.ones((m, n), dtype=bool))
+    assert relerr(out[mask], full[mask]) < 1e-13
+    assert np.array_equal(out[~mask], C0[~mask]), "strictly-upper part must not be written"
+
+
+def test_gemm_triangular_k_ranges(ff):
+    rng = np.random.default_rng(9)
+    n = 520
+    Lt = np.tril(rng.standard_normal((n, n)))
+    M = rng.standard_normal((n, 200))
+    # hi_i: A lower-triangular (K-major), C = A @ M
+    out = run_gemm(ff, 0, 1, 0, 4, Lt, M, np.zeros((n, 200)), 1.0, 0.0)
+    assert relerr(out, Lt @ M) < 1e-13
+    # lo_j: B lower-triangular stored k x n, C = M^T-ish @ Lt
+    M2 = rng.standard_normal((150, n))
+    out = run_gemm(ff, 0, 1, 0, 2, M2, Lt, np.zeros((150, n)), 1.0, 0.0)
+    assert relerr(out, M2 @ Lt) < 1e-13
+    # lo_i with both MN-major, lower tiles: S = X^T X for lower-triangular X (LAUUM)
+    out = run_gemm(ff, 1, 1, 1, 1, Lt.T, Lt, np.zeros((n, n)), 1.0, 0.0)
+    ref = Lt.T @ Lt
+    mask = np.tril(np.ones((n, n), dtype=bool))
+    assert relerr(out[mask], ref[mask]) < 1e-13
+
+
+# ------------------------------------------------------------------------------------------------ Cholesky
+def spd(n, rng, cond=1e3):
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    ev = np.logspace(0, np.log10(cond), n)
+    return (Q * ev) @ Q.T
+
+
+def potrf(ff, S, rows=None, naive=False, nb_outer=None):
+    _lib, h = ff
+    n = S.shape[0]
+    m = 0 if rows is None else rows.shape[0]
+    ld = (n + 1) // 2 * 2 + 2
+    W = np.full((n + m, ld), np.nan)
+    W[:n, :n] = np.tril(S) + np.triu(np.full((n, n), 777.0), 1)   # poison above the diagonal: must not be read
+    if m:
+        W[n:, :n] = rows
+    Wd = dev(W)
+    _lib.lib.ffgp_set_option(h, b"naive", 1.0 if naive else 0.0)
+    if nb_outer:
+        _lib.lib.ffgp_set_option(h, b"nb_outer", float(nb_outer))
+    rc = _lib.lib.ffgp_potrf_rows(h, ptr(Wd), n, n + m, ld)
+    _lib.lib.ffgp_set_option(h, b"naive", 0.0)
+    _lib.lib.ffgp_set_option(h, b"nb_outer", 512.0)
+    out = Wd.cpu().numpy()
+    return rc, out, Wd, ld
+
+
+@pytest.mark.parametrize("n", [1, 16, 17, 100, 128, 129, 300, 511, 640, 1000, 1537])
+def test_potrf_matches_lapack(ff, n):
+    rng = np.random.default_rng(n)
+    S = spd(n, rng)
+    rc, out, _, _ = potrf(ff, S)
+    assert rc == 0
+    L = np.linalg.cholesky(S)
+    got = np.tril(out[:n, :n])
+    assert relerr(got, L) < 1e-11, n
+    up = out[:n, :n][np.triu_indices(n, 1)]
+    assert (up == 777.0).all(), "strictly-upper triangle was written"
+
+
+@pytest.mark.parametrize("n,nb", [(700, 128), (700, 256), (1300, 384)])
+def test_potrf_outer_block_sizes(ff, n, nb):
+    rng = np.random.default_rng(n + nb)
+    S = spd(n, rng)
+    rc, out, _, _ = potrf(ff, S, nb_outer=nb)
+    assert rc == 0
+    assert relerr(np.tril(out[:n, :n]), np.linalg.cholesky(S)) < 1e-11
+
+
+def test_potrf_naive_kernels_agree(ff):
+    rng = np.random.default_rng(2)
+    S = spd(200, rng)
+    rows = rng.standard_normal((3, 200))
+    rc1, o1, _, _ = potrf(ff, S, rows, naive=False)
+    rc2, o2, _, _ = potrf(ff, S, rows, naive=True)
+    assert rc1 == 0 and rc2 == 0
+    assert relerr(np.tril(o1[:200, :200]), np.tril(o2[:200, :200])) < 1e-11
+    assert relerr(o1[200:, :200], o2[200:, :200]) < 1e-10
+
+
+@pytest.mark.parametrize("n,m", [(100, 1), (257, 7), (640, 130), (1000, 300)])
+def test_potrf_passenger_rows(ff, n, m):
+    """rows below Sigma come out as rows @ L^-T  (Gamma^T, V^T of the fused paths)"""
+    import scipy.linalg as sla
+    rng = np.random.default_rng(n + m)
+    S = spd(n, rng)
+    R = rng.standard_normal((m, n))
+    rc, out, _, _ = potrf(ff, S, R)
+    assert rc == 0
+    L = np.linalg.cholesky(S)
+    ref = sla.solve_triangular(L, R.T, lower=True).T
+    assert relerr(out[n:, :n], ref) < 1e-10
+
+
+@pytest.mark.parametrize("n,bad", [(50, 1), (300, 130), (300, 300), (640, 513)])
+def test_potrf_reports_first_bad_pivot(ff, n, bad):
+    rng = np.random.default_rng(n + bad)
+    S = spd(n, rng, cond=10.0)
+    # make the leading minor of order `bad` singular/indefinite, earlier minors stay PD
+    L = np.linalg.cholesky(S)
+    L[bad - 1, bad - 1] = 0.0
+    S2 = L @ L.T
+    S2[bad - 1, bad - 1] -= 1.0
+    rc, _, _, _ = potrf(ff, S2)
+    assert rc == bad, (rc, bad)
+
+
+def test_trsm_and_potrs(ff):
+    import scipy.linalg as sla
+    _lib, h = ff
+    rng = np.random.default_rng(11)
+    for n, nrhs in [(300, 1), (300, 5), (700, 130)]:
+        S = spd(n, rng)
+        rc, out, Wd, ld = potrf(ff, S)
+        assert rc == 0
+        L = np.linalg.cholesky(S)
+        B = rng.standard_normal((n, nrhs))
+        Bd = dev(B)
+        assert _lib.lib.ffgp_trsm_lower(h, ptr(Wd), n, ld, ptr(Bd), nrhs, nrhs) == 0
+        torch.cuda.synchronize()
+        assert relerr(Bd.cpu().numpy(), sla.solve_triangular(L, B, lower=True)) < 1e-10
+        Bd = dev(B)
+        assert _lib.lib.ffgp_trsm_lower_t(h, ptr(Wd), n, ld, ptr(Bd), nrhs, nrhs) == 0
+        torch.cuda.synchronize()
+        assert relerr(Bd.cpu().numpy(), sla.solve_triangular(L.T, B, lower=False)) < 1e-10
+        Bd = dev(B)
+        assert _lib.lib.ffgp_potrs(h, ptr(Wd), n, ld, ptr(Bd), nrhs, nrhs) == 0
+        torch.cuda.synchronize()
+        assert relerr(Bd.cpu().numpy(), np.linalg.solve(S, B)) < 1e-9
+
+
+@pytest.mark.parametrize("n", [100, 128, 300, 700, 1100])
+def test_potri(ff, n):
+    _lib, h = ff
+    rng = np.random.default_rng(n)
+    S = spd(n, rng)
+    rc, out, Wd, ld = potrf(ff, S)
+    assert rc == 0
+    assert _lib.lib.ffgp_potri(h, ptr(Wd), n, ld) == 0
+    torch.cuda.synchronize()
+    got = np.tril(Wd.cpu().numpy()[:n, :n])
+    assert relerr(got, np.tril(np.linalg.inv(S))) < 1e-9
+
+
+# ------------------------------------------------------------------------------------------------ assembly
+@pytest.mark.parametrize("n1,n2,D", [(65, 33, 1), (64, 64, 5), (200, 131, 16), (130, 70, 37)])
+def test_assemble_rect(ff, n1, n2, D):
+    _lib, h = ff
+    rng = np.random.default_rng(n1 + n2 + D)
+    x1, x2 = rng.random((n1, D)) * 3, rng.random((n2, D)) * 3
+    w = rng.random(D) + 0.3
+    amp = np.array([1.7])
+    K = torch.empty((n1, n2), dtype=torch.float64, device="cuda:0")
+    rc = _lib.lib.ffgp_assemble(h, ptr(dev(x1)), n1, ptr(dev(x2)), n2, D, ptr(dev(w)), ptr(dev(amp)), 1e-30, None, None, 0,
+                                None, 0, 0.0, 0.0, ptr(K), n2, 0)
+    assert rc == 0
+    torch.cuda.synchronize()
+    diff = (x1[:, None, :] - x2[None, :, :]) * w
+    ref = 1.7 * np.exp(-0.5 * np.maximum((diff ** 2).sum(-1), 1e-30))
+    assert relerr(K.cpu().numpy(), ref) < 1e-14
+
+
+def test_assemble_sigma_extras(ff):
+    _lib, h = ff
+    rng = np.random.default_rng(3)
+    n, D = 150, 4
+    x = rng.random((n, D))
+    w, amp, dadd = rng.random(D) + 0.5, np.array([0.9]), np.array([0.31])
+    yv = rng.random((n, n))
+    am = rng.random((n, n))
+    xd = dev(x)
+    for lower in (0, 1):
+        K = torch.full((n, n), 555.0, dtype=torch.float64, device="cuda:0")
+        rc = _lib.lib.ffgp_assemble(h, ptr(xd), n, ptr(xd), n, D, ptr(dev(w)), ptr(dev(amp)), float("-inf"), ptr(dev(dadd)),
+                                    ptr(dev(yv)), n + 1, ptr(dev(am)), n, 0.25, 1e-6, ptr(K), n, lower)
+        assert rc == 0
+        torch.cuda.synchronize()
+        diff = (x[:, None, :] - x[None, :, :]) * w
+        K0 = 0.9 * np.exp(-0.5 * (diff ** 2).sum(-1))
+        low = np.tril(am) + np.tril(am, -1).T
+        ref = K0 + np.diag(0.31 + np.diag(yv)) + low + 0.25 + 1e-6 * K0.mean() * np.eye(n)
+        got = K.cpu().numpy()
+        mask = np.tril(np.ones((n, n), dtype=bool))
+        assert relerr(got[mask], ref[mask]) < 1e-13
+        if lower:
+            assert (got[~mask] == 555.0).all()
+        else:
+            assert relerr(got, ref) < 1e-13
+
+
+def test_mfma_peak_probe(ff):
+    _lib, h = ff
+    tf = _lib.mfma_f64_peak(0)
+    print("measured fp64 MFMA stream: %.1f TFLOP/s" % tf)
+    assert 10.0 < tf < 200.0
