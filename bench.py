@@ -133,7 +133,7 @@ def main():
     if rank == 0:
         achieved = stats["flops"] / (stats["ms"] * 1e-3) / 1e12 if stats["ms"] > 0 else 0.0
         out = {
-            "metric": "GP NLML+Cholesky throughput (NxN fp64 GF/s, %MFMA-roofline) at N=%d" % n,
+            "metric": "GP NLML+Cholesky throughput (NxN fp64 GF/s, %%MFMA-roofline) at N=%d" % n,
             "value": round(value, 1), "unit": "GF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",

@@ -254,7 +254,8 @@ def test_assemble_rect(ff, n1, n2, D):
     w = rng.random(D) + 0.3
     amp = np.array([1.7])
     K = torch.empty((n1, n2), dtype=torch.float64, device="cuda:0")
-    rc = _lib.lib.ffgp_assemble(h, ptr(dev(x1)), n1, ptr(dev(x2)), n2, D, ptr(dev(w)), ptr(dev(amp)), 1e-30, None, None, 0,
+    x1d, x2d, wd, ad = dev(x1), dev(x2), dev(w), dev(amp)   # keep the device buffers alive across the launch
+    rc = _lib.lib.ffgp_assemble(h, ptr(x1d), n1, ptr(x2d), n2, D, ptr(wd), ptr(ad), 1e-30, None, None, 0,
                                 None, 0, 0.0, 0.0, ptr(K), n2, 0)
     assert rc == 0
     torch.cuda.synchronize()
@@ -271,11 +272,11 @@ def test_assemble_sigma_extras(ff):
     w, amp, dadd = rng.random(D) + 0.5, np.array([0.9]), np.array([0.31])
     yv = rng.random((n, n))
     am = rng.random((n, n))
-    xd = dev(x)
+    xd, wd, ad, dd, yvd, amd = dev(x), dev(w), dev(amp), dev(dadd), dev(yv), dev(am)
     for lower in (0, 1):
         K = torch.full((n, n), 555.0, dtype=torch.float64, device="cuda:0")
-        rc = _lib.lib.ffgp_assemble(h, ptr(xd), n, ptr(xd), n, D, ptr(dev(w)), ptr(dev(amp)), float("-inf"), ptr(dev(dadd)),
-                                    ptr(dev(yv)), n + 1, ptr(dev(am)), n, 0.25, 1e-6, ptr(K), n, lower)
+        rc = _lib.lib.ffgp_assemble(h, ptr(xd), n, ptr(xd), n, D, ptr(wd), ptr(ad), float("-inf"), ptr(dd),
+                                    ptr(yvd), n + 1, ptr(amd), n, 0.25, 1e-6, ptr(K), n, lower)
         assert rc == 0
         torch.cuda.synchronize()
         diff = (x[:, None, :] - x[None, :, :]) * w
