@@ -74,6 +74,14 @@ int ffgp_create(int device, ffgp_handle** out) {
   FFGP_HIP(hipStreamCreate(&h->stream));
   h->own_stream = true;
   h->own = h->stream;
+  {
+    int lo = 0, hi = 0;  // numerically lowest value = greatest priority
+    FFGP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    FFGP_HIP(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, hi));
+    for (int i = 0; i < 4; ++i) FFGP_HIP(hipEventCreateWithFlags(&h->la_ev[i], hipEventDisableTiming));
+    h->lookahead = 1;
+    h->small_tile_threshold = 384;
+  }
   FFGP_HIP(hipMalloc(&h->d_info, 16 * sizeof(int)));
   FFGP_HIP(hipMalloc(&h->d_scal, SCAL_DOUBLES * sizeof(double)));
   FFGP_HIP(hipHostMalloc(&h->h_info, 16 * sizeof(int)));
@@ -100,6 +108,8 @@ int ffgp_destroy(ffgp_handle* h) {
   hipEventDestroy(h->syrk_ev[0]);
   hipEventDestroy(h->syrk_ev[1]);
   for (hipEvent_t e : h->syrk_pool) hipEventDestroy(e);
+  for (int i = 0; i < 4; ++i) hipEventDestroy(h->la_ev[i]);
+  hipStreamDestroy(h->aux);
   hipStreamDestroy(h->own);
   delete h;
   return FFGP_OK;
@@ -121,6 +131,16 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->nb_outer = v;
   } else if (!strcmp(key, "naive")) {
     h->use_naive = (int)value;
+  } else if (!strcmp(key, "gemm_tile")) {
+    const int v = (int)value;
+    if (v != 0 && v != 64 && v != 128) return FFGP_ERR_ARG;
+    h->force_ts = v;
+  } else if (!strcmp(key, "small_tile_threshold")) {
+    h->small_tile_threshold = (int)value;
+  } else if (!strcmp(key, "diag_dbg")) {
+    h->diag_dbg = (int)value;
+  } else if (!strcmp(key, "lookahead")) {
+    h->lookahead = (int)value;
   } else {
     return FFGP_ERR_ARG;
   }
@@ -181,6 +201,13 @@ int ffgp_gemm(ffgp_handle* h, int opa, int opb, int lower_tiles, int tri, const 
   FFGP_HIP(hipSetDevice(h->device));
   return ffgp_gemm_launch(h, opa ? OP_MNMAJOR : OP_KMAJOR, opb ? OP_MNMAJOR : OP_KMAJOR, lower_tiles ? TILES_LOWER : TILES_FULL,
                           0, A, lda, B, ldb, C, ldc, m, n, k, alpha, beta, tri);
+}
+
+/* (re)build the inverted 128x128 diagonal blocks of a factor (also the diag-kernel timing hook of tools/) */
+int ffgp_trtri_diag(ffgp_handle* h, const double* L, int n, int ldl) {
+  if (!h || !L) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  return ffgp_refresh_dinv(h, L, n, ldl);
 }
 
 int ffgp_potri(ffgp_handle* h, double* L, int n, int ldl) {

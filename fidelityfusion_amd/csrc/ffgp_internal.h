@@ -47,6 +47,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int total_tiles;
   int avec, bvec;      // 16-byte vector loads allowed for A / B
+  int prio;            // raise the wave priority (look-ahead panel GEMMs)
   // triangular operands: restrict the k range of tile (ti, tj) to [max(lo_i*ti, lo_j*tj)*128, min(K, hi_i*(ti+1)*128, ...))
   int lo_i, lo_j, hi_i, hi_j;
 };
@@ -55,6 +56,12 @@ struct ffgp_handle {
   int device;
   hipStream_t stream;   // stream work is enqueued on (caller's, or `own`)
   hipStream_t own;      // the handle's own stream
+  hipStream_t aux;      // high-priority side stream for the look-ahead panel factorisation
+  hipEvent_t la_ev[4];  // look-ahead hand-off events
+  int force_ts;         // 0 = automatic GEMM tile shape, 64 / 128 = forced (benchmarks, tests)
+  int small_tile_threshold;  // launches with fewer 128-tiles than this use the 64-tile
+  int diag_dbg;         // timing-only ablation mask of potrf_diag128 (0 in production)
+  int lookahead;        // 1 = overlap panel k+1 with the trailing update of step k
   bool own_stream;
   // workspace (grown on demand, never shrunk)
   double* ws;        // generic workspace

@@ -20,11 +20,20 @@
 // 8 A panels and ~8 B panels through its L2.
 #include "ffgp_internal.h"
 
-#define BM 128
-#define BN 128
 #define BK 16
-#define MNLD 144
-#define OPBUF 2304  // doubles per operand buffer = max(128*16, 16*144)
+
+// Tile geometry: TS x TS output tile per 256-thread workgroup, 4 waves as 2 x 2, each wave (TS/2) x (TS/2)
+//   TS = 128: 4 x 4 MFMA tiles per wave (128 accumulator VGPRs), 72 KiB LDS, 2 workgroups per CU -- the throughput shape
+//   TS =  64: 2 x 2 MFMA tiles per wave, 20 KiB LDS, up to 4 workgroups per CU -- the latency shape: a quarter of the
+//             per-tile MFMA chain and 4x the tiles, used when a launch has fewer 128-tiles than the chip has slots
+//             (panel TRSM/updates of the look-ahead chain, the tail of the factorisation)
+template <int TS>
+struct Geo {
+  static constexpr int WT = TS / 32;            // MFMA tiles per wave per dimension
+  static constexpr int NLD = TS / 32;           // 16-byte loads per thread per operand tile
+  static constexpr int MNLD = TS + 16;          // leading dimension of the MN-major LDS image
+  static constexpr int OPBUF = 16 * (TS + 16);  // doubles per operand buffer (>= TS*16)
+};
 
 __device__ __forceinline__ d2_t ld2_guard(const double* p, int rem, bool vec) {
   d2_t v = {0.0, 0.0};
@@ -41,42 +50,50 @@ __device__ __forceinline__ d2_t ld2_guard(const double* p, int rem, bool vec) {
   return v;
 }
 
-template <int OP>
+// GUARD = false: interior tile (all rows/cols in range, full k-tiles, 16-byte aligned operands): straight-line
+// vector loads, no per-element branches.
+template <int OP, int TS, bool GUARD>
 __device__ __forceinline__ void gload(const double* __restrict__ P, int ld, int r0, int R, int k0, int K, int tid,
-                                      bool vec, d2_t (&v)[4]) {
+                                      bool vec, d2_t (&v)[Geo<TS>::NLD]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < Geo<TS>::NLD; ++i) {
     const int idx = tid + 256 * i;
     d2_t z = {0.0, 0.0};
     if (OP == OP_KMAJOR) {
       const int row = idx >> 3, ch = idx & 7;
       const int gr = r0 + row, gk = k0 + ch * 2;
-      v[i] = (gr < R) ? ld2_guard(P + (size_t)gr * ld + gk, K - gk, vec) : z;
+      if (GUARD)
+        v[i] = (gr < R) ? ld2_guard(P + (size_t)gr * ld + gk, K - gk, vec) : z;
+      else
+        v[i] = *reinterpret_cast<const d2_t*>(P + (size_t)gr * ld + gk);
     } else {
-      const int kk = idx >> 6, c2 = idx & 63;
+      const int kk = idx / (TS / 2), c2 = idx % (TS / 2);
       const int gk = k0 + kk, gr = r0 + c2 * 2;
-      v[i] = (gk < K) ? ld2_guard(P + (size_t)gk * ld + gr, R - gr, vec) : z;
+      if (GUARD)
+        v[i] = (gk < K) ? ld2_guard(P + (size_t)gk * ld + gr, R - gr, vec) : z;
+      else
+        v[i] = *reinterpret_cast<const d2_t*>(P + (size_t)gk * ld + gr);
     }
   }
 }
 
-template <int OP>
-__device__ __forceinline__ void sstore(double* s, int tid, const d2_t (&v)[4]) {
+template <int OP, int TS>
+__device__ __forceinline__ void sstore(double* s, int tid, const d2_t (&v)[Geo<TS>::NLD]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < Geo<TS>::NLD; ++i) {
     const int idx = tid + 256 * i;
     if (OP == OP_KMAJOR) {
       const int row = idx >> 3, ch = idx & 7;
       *reinterpret_cast<d2_t*>(s + row * 16 + ((ch ^ ((row >> 1) & 7)) << 1)) = v[i];
     } else {
-      const int kk = idx >> 6, c2 = idx & 63;
-      *reinterpret_cast<d2_t*>(s + kk * MNLD + c2 * 2) = v[i];
+      const int kk = idx / (TS / 2), c2 = idx % (TS / 2);
+      *reinterpret_cast<d2_t*>(s + kk * Geo<TS>::MNLD + c2 * 2) = v[i];
     }
   }
 }
 
-// offset (doubles) of this lane's operand element for MFMA k-step kq, sub-tile 0 of the wave's 64 rows
-template <int OP>
+// offset (doubles) of this lane's operand element for MFMA k-step kq, sub-tile 0 of the wave's rows
+template <int OP, int TS>
 __device__ __forceinline__ void frag_offsets(int lane, int wbase, int (&off)[4]) {
 #pragma unroll
   for (int kq = 0; kq < 4; ++kq) {
@@ -85,7 +102,7 @@ __device__ __forceinline__ void frag_offsets(int lane, int wbase, int (&off)[4])
       const int c0 = (lane >> 5) ^ ((lane & 15) >> 1);
       off[kq] = row * 16 + ((((kq << 1) ^ c0)) << 1) + ((lane >> 4) & 1);
     } else {
-      off[kq] = (kq * 4 + (lane >> 4)) * MNLD + wbase + (lane & 15);
+      off[kq] = (kq * 4 + (lane >> 4)) * Geo<TS>::MNLD + wbase + (lane & 15);
     }
   }
 }
@@ -130,11 +147,56 @@ __device__ __forceinline__ void decode_tile(int t, int mode, int tiles_m, int ti
   }
 }
 
-template <int OPA, int OPB, int MODE, int TAG>
+template <int OPA, int OPB, int TS, bool GUARD>
+__device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, double* smem, int m0, int n0, int kt0, int kt1, int tid,
+                                              const int (&offA)[4], const int (&offB)[4],
+                                              d4_t (&acc)[Geo<TS>::WT][Geo<TS>::WT]) {
+  constexpr int WT = Geo<TS>::WT, NLD = Geo<TS>::NLD, OPBUF = Geo<TS>::OPBUF;
+  constexpr int subA = (OPA == OP_KMAJOR) ? 256 : 16;
+  constexpr int subB = (OPB == OP_KMAJOR) ? 256 : 16;
+  d2_t ra[NLD], rb[NLD];
+  gload<OPA, TS, GUARD>(p.A, p.lda, m0, p.m, kt0 * BK, p.k, tid, p.avec != 0, ra);
+  gload<OPB, TS, GUARD>(p.B, p.ldb, n0, p.n, kt0 * BK, p.k, tid, p.bvec != 0, rb);
+  sstore<OPA, TS>(smem, tid, ra);
+  sstore<OPB, TS>(smem + OPBUF, tid, rb);
+  __syncthreads();
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int par = (kt - kt0) & 1;
+    const double* sA = smem + par * (2 * OPBUF);
+    const double* sB = sA + OPBUF;
+    const bool more = (kt + 1 < kt1);
+    if (more) {
+      gload<OPA, TS, GUARD>(p.A, p.lda, m0, p.m, (kt + 1) * BK, p.k, tid, p.avec != 0, ra);
+      gload<OPB, TS, GUARD>(p.B, p.ldb, n0, p.n, (kt + 1) * BK, p.k, tid, p.bvec != 0, rb);
+    }
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+      double a[WT], b[WT];
+#pragma unroll
+      for (int i = 0; i < WT; ++i) a[i] = sA[offA[kq] + i * subA];
+#pragma unroll
+      for (int j = 0; j < WT; ++j) b[j] = sB[offB[kq] + j * subB];
+#pragma unroll
+      for (int i = 0; i < WT; ++i)
+#pragma unroll
+        for (int j = 0; j < WT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      double* dA = smem + (par ^ 1) * (2 * OPBUF);
+      sstore<OPA, TS>(dA, tid, ra);
+      sstore<OPB, TS>(dA + OPBUF, tid, rb);
+    }
+    __syncthreads();
+  }
+}
+
+template <int OPA, int OPB, int MODE, int TAG, int TS>
 __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
+  constexpr int WT = Geo<TS>::WT, OPBUF = Geo<TS>::OPBUF;
   __shared__ __attribute__((aligned(16))) double smem[4 * OPBUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+  if (p.prio) __builtin_amdgcn_s_setprio(2);  // panel GEMMs of the look-ahead chain outrank the trailing update
 
   // XCD-aware bijective remap of the block id, then banded tile order
   int t;
@@ -145,83 +207,51 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
   }
   int ti, tj;
   decode_tile(t, MODE, p.tiles_m, p.tiles_n, ti, tj);
-  const int m0 = ti * BM, n0 = tj * BN;
+  const int m0 = ti * TS, n0 = tj * TS;
 
-  d4_t acc[4][4];
+  d4_t acc[WT][WT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < WT; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < WT; ++j) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
 
   int offA[4], offB[4];
-  frag_offsets<OPA>(lane, wm * 64, offA);
-  frag_offsets<OPB>(lane, wn * 64, offB);
-  constexpr int subA = (OPA == OP_KMAJOR) ? 256 : 16;
-  constexpr int subB = (OPB == OP_KMAJOR) ? 256 : 16;
+  frag_offsets<OPA, TS>(lane, wm * (TS / 2), offA);
+  frag_offsets<OPB, TS>(lane, wn * (TS / 2), offB);
 
   // k range of this tile (triangular operands skip the k-tiles that are structurally zero)
   int kbeg = 0, kend = p.k;
-  if (p.lo_i) kbeg = max(kbeg, ti * BM);
-  if (p.lo_j) kbeg = max(kbeg, tj * BN);
-  if (p.hi_i) kend = min(kend, (ti + 1) * BM);
-  if (p.hi_j) kend = min(kend, (tj + 1) * BN);
+  if (p.lo_i) kbeg = max(kbeg, ti * TS);
+  if (p.lo_j) kbeg = max(kbeg, tj * TS);
+  if (p.hi_i) kend = min(kend, (ti + 1) * TS);
+  if (p.hi_j) kend = min(kend, (tj + 1) * TS);
   const int kt0 = kbeg / BK;
   const int kt1 = (kend + BK - 1) / BK;
 
   if (kt0 < kt1) {
-    d2_t ra[4], rb[4];
-    gload<OPA>(p.A, p.lda, m0, p.m, kt0 * BK, p.k, tid, p.avec != 0, ra);
-    gload<OPB>(p.B, p.ldb, n0, p.n, kt0 * BK, p.k, tid, p.bvec != 0, rb);
-    sstore<OPA>(smem, tid, ra);
-    sstore<OPB>(smem + OPBUF, tid, rb);
-    __syncthreads();
-
-    for (int kt = kt0; kt < kt1; ++kt) {
-      const int par = (kt - kt0) & 1;
-      const double* sA = smem + par * (2 * OPBUF);
-      const double* sB = sA + OPBUF;
-      const bool more = (kt + 1 < kt1);
-      if (more) {
-        gload<OPA>(p.A, p.lda, m0, p.m, (kt + 1) * BK, p.k, tid, p.avec != 0, ra);
-        gload<OPB>(p.B, p.ldb, n0, p.n, (kt + 1) * BK, p.k, tid, p.bvec != 0, rb);
-      }
-#pragma unroll
-      for (int kq = 0; kq < 4; ++kq) {
-        double a[4], b[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = sA[offA[kq] + i * subA];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = sB[offB[kq] + j * subB];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-      }
-      if (more) {
-        double* dA = smem + (par ^ 1) * (2 * OPBUF);
-        sstore<OPA>(dA, tid, ra);
-        sstore<OPB>(dA + OPBUF, tid, rb);
-      }
-      __syncthreads();
-    }
+    const bool interior = (m0 + TS <= p.m) && (n0 + TS <= p.n) && (kt1 * BK <= p.k) && p.avec && p.bvec;
+    if (interior)
+      gemm_mainloop<OPA, OPB, TS, false>(p, smem, m0, n0, kt0, kt1, tid, offA, offB, acc);
+    else
+      gemm_mainloop<OPA, OPB, TS, true>(p, smem, m0, n0, kt0, kt1, tid, offA, offB, acc);
   }
 
   // epilogue: lane holds rows (lane>>4)+4r, column lane&15 of each 16x16 accumulator tile
-  // (16 loads in flight per 16-row group: addresses are clamped in-bounds so the loads are unconditional and
+  // (loads batched per 16-row group: addresses are clamped in-bounds so the loads are unconditional and
   //  the compiler batches them instead of one vmcnt(0) round trip per element)
   const double alpha = p.alpha, beta = p.beta;
   const bool use_c = (beta != 0.0);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    double cv[4][4];
-    const int rbase = m0 + wm * 64 + i * 16 + (lane >> 4);
-    const int cbase = n0 + wn * 64 + (lane & 15);
+  for (int i = 0; i < WT; ++i) {
+    double cv[4][WT];
+    const int rbase = m0 + wm * (TS / 2) + i * 16 + (lane >> 4);
+    const int cbase = n0 + wn * (TS / 2) + (lane & 15);
     if (use_c) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rowc = min(rbase + 4 * r, p.m - 1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < WT; ++j) {
           const int colc = min(cbase + j * 16, p.n - 1);
           cv[r][j] = p.C[(size_t)rowc * p.ldc + colc];
         }
@@ -230,13 +260,13 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) cv[r][j] = 0.0;
+        for (int j = 0; j < WT; ++j) cv[r][j] = 0.0;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = rbase + 4 * r;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < WT; ++j) {
         const int col = cbase + j * 16;
         if (row < p.m && col < p.n && (MODE != TILES_LOWER || col <= row)) {
           p.C[(size_t)row * p.ldc + col] = alpha * acc[i][j][r] + beta * cv[r][j];
@@ -249,13 +279,39 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
 // ------------------------------------------------------------------------------------------------------------
 // host launcher
 // ------------------------------------------------------------------------------------------------------------
-template <int OPA, int OPB, int MODE, int TAG>
+template <int OPA, int OPB, int MODE, int TAG, int TS>
 static int launch_t(ffgp_handle* h, const GemmArgs& a) {
-  hipLaunchKernelGGL((ffgp_gemm_f64<OPA, OPB, MODE, TAG>), dim3(a.total_tiles), dim3(256), 0, h->stream, a);
+  hipLaunchKernelGGL((ffgp_gemm_f64<OPA, OPB, MODE, TAG, TS>), dim3(a.total_tiles), dim3(256), 0, h->stream, a);
   return FFGP_OK;
 }
 
+template <int TS>
+static int dispatch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, const GemmArgs& a) {
+  if (syrk_tag) {
+    // the trailing update of the blocked Cholesky gets its own instantiation so rocprofv3 --stats separates it
+    if (opa == OP_KMAJOR && opb == OP_KMAJOR && mode == TILES_LOWER) return launch_t<OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, TS>(h, a);
+  } else if (mode == TILES_LOWER) {
+    if (opa == OP_KMAJOR && opb == OP_KMAJOR) return launch_t<OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 0, TS>(h, a);
+    if (opa == OP_MNMAJOR && opb == OP_MNMAJOR) return launch_t<OP_MNMAJOR, OP_MNMAJOR, TILES_LOWER, 0, TS>(h, a);
+  } else {
+    if (opa == OP_KMAJOR && opb == OP_KMAJOR) return launch_t<OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, TS>(h, a);
+    if (opa == OP_KMAJOR && opb == OP_MNMAJOR) return launch_t<OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, TS>(h, a);
+    if (opa == OP_MNMAJOR && opb == OP_MNMAJOR) return launch_t<OP_MNMAJOR, OP_MNMAJOR, TILES_FULL, 0, TS>(h, a);
+    if (opa == OP_MNMAJOR && opb == OP_KMAJOR) return launch_t<OP_MNMAJOR, OP_KMAJOR, TILES_FULL, 0, TS>(h, a);
+  }
+  return FFGP_ERR_ARG;
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static int count_tiles(int mode, int m, int n, int ts, int& tm, int& tn) {
+  tm = (m + ts - 1) / ts;
+  tn = (n + ts - 1) / ts;
+  if (mode != TILES_LOWER) return tm * tn;
+  int total = 0;
+  for (int ti = 0; ti < tm; ++ti) total += (ti + 1 < tn) ? ti + 1 : tn;
+  return total;
+}
 
 int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, const double* A, int lda, const double* B,
                      int ldb, double* C, int ldc, int m, int n, int k, double alpha, double beta, int tri) {
@@ -265,6 +321,7 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
     return FFGP_ERR_ARG;
   }
   if (!A || !B || !C) return FFGP_ERR_ARG;
+  if (mode == TILES_LOWER && m < n) return FFGP_ERR_ARG;
   GemmArgs a;
   // vector (16-byte) operand loads need even leading dimensions and 16-byte aligned bases
   a.avec = (!(lda & 1) && aligned16(A)) ? 1 : 0;
@@ -273,18 +330,18 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   a.m = m; a.n = n; a.k = k;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.alpha = alpha; a.beta = beta;
+  a.prio = (h->stream == h->aux) ? 1 : 0;
   a.lo_i = (tri & TRI_LO_I) ? 1 : 0;
   a.lo_j = (tri & TRI_LO_J) ? 1 : 0;
   a.hi_i = (tri & TRI_HI_I) ? 1 : 0;
   a.hi_j = (tri & TRI_HI_J) ? 1 : 0;
-  a.tiles_m = (m + BM - 1) / BM;
-  a.tiles_n = (n + BN - 1) / BN;
-  if (mode == TILES_LOWER) {
-    if (m < n) return FFGP_ERR_ARG;
-    a.total_tiles = 0;
-    for (int ti = 0; ti < a.tiles_m; ++ti) a.total_tiles += (ti + 1 < a.tiles_n) ? ti + 1 : a.tiles_n;
-  } else {
-    a.total_tiles = a.tiles_m * a.tiles_n;
+  // tile shape: the 128-tile is the throughput shape; below ~1.5 tiles per CU the launch is latency-bound and
+  // the 64-tile (4x the workgroups, a quarter of the per-tile MFMA chain) finishes sooner
+  int ts = 128;
+  a.total_tiles = count_tiles(mode, m, n, 128, a.tiles_m, a.tiles_n);
+  if (h->force_ts == 64 || (h->force_ts == 0 && a.total_tiles < h->small_tile_threshold)) {
+    ts = 64;
+    a.total_tiles = count_tiles(mode, m, n, 64, a.tiles_m, a.tiles_n);
   }
   // timing == 2: bracket every trailing-update launch with its own event pair (no host sync inside the timed
   // region; ffgp_syrk_stats drains the pool afterwards)
@@ -302,19 +359,7 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
     ev_stop = h->syrk_pool[h->syrk_pool_used + 1];
     h->syrk_pool_used += 2;
   }
-  int rc = FFGP_ERR_ARG;
-  if (syrk_tag) {
-    // the trailing update of the blocked Cholesky gets its own instantiation so rocprofv3 --stats separates it
-    if (opa == OP_KMAJOR && opb == OP_KMAJOR && mode == TILES_LOWER) rc = launch_t<OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1>(h, a);
-  } else if (mode == TILES_LOWER) {
-    if (opa == OP_KMAJOR && opb == OP_KMAJOR) rc = launch_t<OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 0>(h, a);
-    else if (opa == OP_MNMAJOR && opb == OP_MNMAJOR) rc = launch_t<OP_MNMAJOR, OP_MNMAJOR, TILES_LOWER, 0>(h, a);
-  } else {
-    if (opa == OP_KMAJOR && opb == OP_KMAJOR) rc = launch_t<OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0>(h, a);
-    else if (opa == OP_KMAJOR && opb == OP_MNMAJOR) rc = launch_t<OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0>(h, a);
-    else if (opa == OP_MNMAJOR && opb == OP_MNMAJOR) rc = launch_t<OP_MNMAJOR, OP_MNMAJOR, TILES_FULL, 0>(h, a);
-    else if (opa == OP_MNMAJOR && opb == OP_KMAJOR) rc = launch_t<OP_MNMAJOR, OP_KMAJOR, TILES_FULL, 0>(h, a);
-  }
+  const int rc = (ts == 128) ? dispatch<128>(h, opa, opb, mode, syrk_tag, a) : dispatch<64>(h, opa, opb, mode, syrk_tag, a);
   if (rc != FFGP_OK) return rc;
   if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
   if (syrk_tag) {

@@ -17,14 +17,39 @@
 #include "ffgp_internal.h"
 
 #define NB FFGP_NB
-#define DLD 130                 // LDS leading dimension of the 128x128 image (conflict-free MFMA operand reads)
-#define DIAG_LDS_DOUBLES (NB * DLD + 8 * 256 + 128)
+// LDS image of the 128x128 diagonal block: only the 36 lower 16x16 blocks, each [16][17] doubles (the pad makes
+// the MFMA operand reads bank-conflict-free).  78 KiB instead of 130 KiB for the dense image: the kernel must
+// fit beside ONE resident GEMM workgroup (72 KiB of the CU's 160 KiB), otherwise the look-ahead panel factor
+// would never be scheduled while the trailing update occupies the chip.
+#define BLD 17
+#define BLKSZ (16 * BLD)
+#define NBLK_LOWER 36
+#define DIAG_LDS_DOUBLES (NBLK_LOWER * BLKSZ + 128)
 #define DIAG_LDS_BYTES (DIAG_LDS_DOUBLES * 8)
+
+__device__ __forceinline__ int blk_off(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * BLKSZ; }
 
 __device__ __forceinline__ double readlane_d(double x, int l) {
   int lo = __double2loint(x), hi = __double2hiint(x);
   lo = __builtin_amdgcn_readlane(lo, l);
   hi = __builtin_amdgcn_readlane(hi, l);
+  return __hiloint2double(hi, lo);
+}
+
+// value of x held by lane (16*(lane>>4) + J): DPP row broadcast inside each row of 16 lanes
+template <int J>
+__device__ __forceinline__ double row_bcast_d(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + J, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + J, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// value of x held by lane `src` (per-lane source): ds_bpermute
+__device__ __forceinline__ double bperm_d(double x, int src) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_ds_bpermute(src << 2, lo);
+  hi = __builtin_amdgcn_ds_bpermute(src << 2, hi);
   return __hiloint2double(hi, lo);
 }
 
@@ -34,6 +59,16 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
   for (int it = 0; it < 2; ++it) {
     const double e = __builtin_fma(-d * y, y, 1.0);
     y = __builtin_fma(0.5 * y, e, y);
+  }
+  return y;
+}
+
+__device__ __forceinline__ double rcp_nr(double d) {
+  double y = __builtin_amdgcn_rcp(d);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {  // v_rcp_f64 is good to ~2^-26; two Newton steps reach fp64 rounding level
+    const double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
   }
   return y;
 }
@@ -52,24 +87,86 @@ __device__ __forceinline__ void mma16(d4_t& acc, const double* pa, int lda_, con
   }
 }
 
+// one step of the in-register 16x16 Cholesky: the block is symmetric-full, lane (g = lane>>4, c = lane&15) holds
+// rows g+4r (r = 0..3) of column c.  Pivot J: rank-1 downdate of the whole block with column J / d, and the
+// lanes of column J keep their (scaled) column as the output.
+template <int J>
+__device__ __forceinline__ void chol16_step(double (&v)[4], double (&out)[4], int lane, int& bad, double* rd_slot) {
+  constexpr int PL = 16 * (J & 3) + J, PR = J >> 2;
+  double d = readlane_d(v[PR], PL);
+  if (!(d > 0.0)) {
+    if (!bad) bad = J + 1;
+    d = 1.0;
+  }
+  const double rinv = rcp_nr(d);
+  const double rs = rsqrt_nr(d);
+  const double rowj = bperm_d(v[PR], 16 * (J & 3) + (lane & 15));  // A[J][c]
+  double colj[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) colj[r] = row_bcast_d<J>(v[r]);      // A[g+4r][J]
+  if ((lane & 15) == J) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[r] = v[r] * rs;
+    if (lane == J) rd_slot[J] = rs;
+  }
+  const double t = rowj * rinv;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = __builtin_fma(-colj[r], t, v[r]);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // potrf_diag128: factor one diagonal block (nb <= 128 valid rows/cols, identity-padded) and invert it.
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ffgp_potrf_diag128(double* __restrict__ A, int lda, int nb,
                                                           double* __restrict__ Dinv, int* info, int row_base,
-                                                          int do_factor) {
+                                                          int do_factor, int dbg) {
+  // dbg: timing-only ablation mask (results are wrong when non-zero): 1 skip (b), 2 skip (c), 4 skip (a),
+  //      8 skip phase 3, 16 skip phase 4, 32 skip phase 5, 64 skip phase 2, 128 skip phase 0
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* S = lds;                    // [128][DLD]
-  double* Dg = lds + NB * DLD;        // [8][16][16] inverses of the 16x16 diagonal blocks
-  double* rd = Dg + 8 * 256;          // [128] reciprocals of the diagonal of L
+  double* S = lds;                      // 36 lower blocks [16][17]
+  double* rd = lds + NBLK_LOWER * BLKSZ;  // [128] reciprocals of the diagonal of L
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win issue arbitration against co-resident GEMM waves
 
-  // ---- phase 0: load (lower part; identity padding beyond nb; zeros above the diagonal)
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int r = idx >> 7, c = idx & 127;
-    double v = (r == c) ? 1.0 : 0.0;
-    if (r < nb && c <= r) v = A[(size_t)r * lda + c];
-    S[r * DLD + c] = v;
+  // ---- phase 0: load the lower blocks; diagonal blocks are completed symmetrically (mirror of the lower part),
+  //      rows/cols beyond nb are identity
+  if (!(dbg & 128)) {
+    // 32 unconditional 16-byte loads per thread, all in flight before the first LDS store (rows are clamped into
+    // the valid block; entries above the diagonal are fetched but never used)
+    d2_t lv[32];
+    const bool vec = !(lda & 1) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {
+      const int idx = tid + 256 * it;
+      const int r = min(idx >> 6, nb - 1), c = min((idx & 63) * 2, (nb - 1) & ~1);
+      const double* src = A + (size_t)r * lda + c;
+      if (vec) {
+        lv[it] = *reinterpret_cast<const d2_t*>(src);
+      } else {
+        lv[it].x = src[0];
+        lv[it].y = (c + 1 < nb) ? src[1] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {
+      const int idx = tid + 256 * it;
+      const int r = idx >> 6, c = (idx & 63) * 2;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int cc = c + e;
+        if (cc <= r) {
+          double v = (r == cc) ? 1.0 : 0.0;
+          if (r < nb) v = e ? lv[it].y : lv[it].x;
+          S[blk_off(r >> 4, cc >> 4) + (r & 15) * BLD + (cc & 15)] = v;
+        }
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 8 * 256; idx += 256) {
+      const int jj = idx >> 8, i = (idx >> 4) & 15, c = idx & 15;
+      double* Dj = S + blk_off(jj, jj);
+      if (c > i) Dj[i * BLD + c] = Dj[c * BLD + i];
+    }
   }
   __syncthreads();
 
@@ -77,63 +174,64 @@ __global__ __launch_bounds__(256) void ffgp_potrf_diag128(double* __restrict__ A
     // ---- phase 1: left-looking factorisation over 16-column blocks
     for (int jj = 0; jj < 8; ++jj) {
       // (a) S[i][jj] -= sum_{p<jj} S[i][p] * S[jj][p]^T   for block rows i = jj..7 (MFMA)
-      if (jj > 0) {
+      if (jj > 0 && !(dbg & 4)) {
         for (int i = jj + wave; i < 8; i += 4) {
           d4_t acc = {0.0, 0.0, 0.0, 0.0};
-          for (int p = 0; p < jj; ++p)
-            mma16<true>(acc, S + (i * 16) * DLD + p * 16, DLD, S + (jj * 16) * DLD + p * 16, DLD, lane);
+          for (int p = 0; p < jj; ++p) mma16<true>(acc, S + blk_off(i, p), BLD, S + blk_off(jj, p), BLD, lane);
+          double* dst = S + blk_off(i, jj);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) S[(i * 16 + (lane >> 4) + 4 * r) * DLD + jj * 16 + (lane & 15)] -= acc[r];
+          for (int r = 0; r < 4; ++r) dst[((lane >> 4) + 4 * r) * BLD + (lane & 15)] -= acc[r];
         }
       }
       __syncthreads();
-      // (b) wave 0: 16x16 Cholesky, one lane per row (lanes >= 16 shadow lanes & 15), column broadcasts by readlane
-      if (wave == 0) {
-        const int i = lane & 15;
-        double v[16];
+      // (b) wave 0: in-register 16x16 Cholesky (4 entries per lane, DPP / bpermute broadcasts)
+      if (wave == 0 && !(dbg & 1)) {
+        double* Dj = S + blk_off(jj, jj);
+        const int g = lane >> 4, c = lane & 15;
+        double v[4], out[4];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) v[c] = S[(jj * 16 + i) * DLD + jj * 16 + c];
+        for (int r = 0; r < 4; ++r) {
+          v[r] = Dj[(g + 4 * r) * BLD + c];
+          out[r] = 0.0;
+        }
         int bad = 0;
+        double* rds = rd + jj * 16;
+        chol16_step<0>(v, out, lane, bad, rds);
+        chol16_step<1>(v, out, lane, bad, rds);
+        chol16_step<2>(v, out, lane, bad, rds);
+        chol16_step<3>(v, out, lane, bad, rds);
+        chol16_step<4>(v, out, lane, bad, rds);
+        chol16_step<5>(v, out, lane, bad, rds);
+        chol16_step<6>(v, out, lane, bad, rds);
+        chol16_step<7>(v, out, lane, bad, rds);
+        chol16_step<8>(v, out, lane, bad, rds);
+        chol16_step<9>(v, out, lane, bad, rds);
+        chol16_step<10>(v, out, lane, bad, rds);
+        chol16_step<11>(v, out, lane, bad, rds);
+        chol16_step<12>(v, out, lane, bad, rds);
+        chol16_step<13>(v, out, lane, bad, rds);
+        chol16_step<14>(v, out, lane, bad, rds);
+        chol16_step<15>(v, out, lane, bad, rds);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          double d = readlane_d(v[j], j);
-          if (!(d > 0.0)) {
-            if (!bad) bad = j + 1;
-            d = 1.0;
-          }
-          const double rs = rsqrt_nr(d);
-          const double lij = (i == j) ? d * rs : v[j] * rs;
-          v[j] = lij;
-          if (lane == j) rd[jj * 16 + j] = rs;
-#pragma unroll
-          for (int c = j + 1; c < 16; ++c) {
-            const double lcj = readlane_d(lij, c);
-            v[c] -= lij * lcj;
-          }
-        }
-        if (lane < 16) {
-#pragma unroll
-          for (int c = 0; c < 16; ++c) S[(jj * 16 + i) * DLD + jj * 16 + c] = (c <= i) ? v[c] : 0.0;
-        }
+        for (int r = 0; r < 4; ++r) Dj[(g + 4 * r) * BLD + c] = (g + 4 * r >= c) ? out[r] : 0.0;
         if (bad && lane == 0 && (jj * 16 + bad) <= nb) atomicCAS(info, 0, row_base + jj * 16 + bad);
       }
       __syncthreads();
       // (c) rows below: x * L_jj^T = b by substitution, one lane per row; L_jj entries are LDS broadcasts
       {
         const int nrows = NB - (jj + 1) * 16;
-        if (tid < nrows) {
-          const int row = (jj + 1) * 16 + tid;
-          double* pr = S + row * DLD + jj * 16;
-          const double* Lj = S + (jj * 16) * DLD + jj * 16;
+        if (tid < nrows && !(dbg & 2)) {
+          double* pr = S + blk_off(jj + 1 + (tid >> 4), jj) + (tid & 15) * BLD;
+          const double* Lj = S + blk_off(jj, jj);
           double x[16];
 #pragma unroll
           for (int c = 0; c < 16; ++c) x[c] = pr[c];
 #pragma unroll
           for (int c = 0; c < 16; ++c) {
-            double s = x[c];
+            const double xc = x[c] * rd[jj * 16 + c];
+            x[c] = xc;
 #pragma unroll
-            for (int k = 0; k < c; ++k) s -= x[k] * Lj[c * DLD + k];
-            x[c] = s * rd[jj * 16 + c];
+            for (int k = c + 1; k < 16; ++k) x[k] = __builtin_fma(-xc, Lj[k * BLD + c], x[k]);
           }
 #pragma unroll
           for (int c = 0; c < 16; ++c) pr[c] = x[c];
@@ -142,74 +240,82 @@ __global__ __launch_bounds__(256) void ffgp_potrf_diag128(double* __restrict__ A
       __syncthreads();
     }
     // ---- phase 2: write L (lower part of the valid block)
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-      const int r = idx >> 7, c = idx & 127;
-      if (r < nb && c <= r) A[(size_t)r * lda + c] = S[r * DLD + c];
+    if (!(dbg & 64)) {
+#pragma unroll 8
+      for (int it = 0; it < 64; ++it) {
+        const int idx = tid + 256 * it;
+        const int r = idx >> 7, c = idx & 127;
+        if (c <= r && r < nb) A[(size_t)r * lda + c] = S[blk_off(r >> 4, c >> 4) + (r & 15) * BLD + (c & 15)];
+      }
     }
   } else {
     // inverse-only entry (Dinv refresh for a factor produced elsewhere): reciprocals of the diagonal
-    if (tid < NB) rd[tid] = 1.0 / S[tid * DLD + tid];
-    __syncthreads();
-  }
-
-  // ---- phase 3: inverses of the eight 16x16 diagonal blocks; 16 lanes per block (one per column), 4 blocks per wave
-  if (wave < 2) {
-    const int jj = wave * 4 + (lane >> 4), c = lane & 15;
-    const double* Lj = S + (jj * 16) * DLD + jj * 16;
-    double x[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      double s = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-      for (int k = 0; k < i; ++k) s -= Lj[i * DLD + k] * x[k];
-      x[i] = s * rd[jj * 16 + i];
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) Dg[jj * 256 + i * 16 + c] = x[i];
+    if (tid < NB) rd[tid] = 1.0 / S[blk_off(tid >> 4, tid >> 4) + (tid & 15) * BLD + (tid & 15)];
   }
   __syncthreads();
-  // diagonal blocks of the image now hold X_jj
-  for (int idx = tid; idx < 8 * 256; idx += 256) {
-    const int jj = idx >> 8, i = (idx >> 4) & 15, c = idx & 15;
-    S[(jj * 16 + i) * DLD + jj * 16 + c] = Dg[idx];
+
+  // ---- phase 3: inverses of the eight 16x16 diagonal blocks, in place; 16 lanes per block (one per column)
+  if (wave < 2 && !(dbg & 8)) {
+    const int jj = wave * 4 + (lane >> 4), c = lane & 15;
+    double* Lj = S + blk_off(jj, jj);
+    double x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const double xi = x[i] * rd[jj * 16 + i];
+      x[i] = xi;
+#pragma unroll
+      for (int k = i + 1; k < 16; ++k) x[k] = __builtin_fma(-xi, Lj[k * BLD + i], x[k]);
+    }
+    // every lane of the wave has finished reading L_jj (same instruction stream) before the block is overwritten
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Lj[i * BLD + c] = x[i];
   }
   __syncthreads();
 
   // ---- phase 4: in-place blocked inversion, block columns right to left:
   //      X[i>j, j] = -X[i>j, i>j] * L[i>j, j] * X_jj
-  for (int j = 6; j >= 0; --j) {
+  for (int j = (dbg & 16) ? -1 : 6; j >= 0; --j) {
     // T_i = L_ij * X_jj  (each wave overwrites only the blocks it read)
     for (int i = j + 1 + wave; i < 8; i += 4) {
       d4_t acc = {0.0, 0.0, 0.0, 0.0};
-      mma16<false>(acc, S + (i * 16) * DLD + j * 16, DLD, Dg + j * 256, 16, lane);
+      double* Bij = S + blk_off(i, j);
+      mma16<false>(acc, Bij, BLD, S + blk_off(j, j), BLD, lane);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) S[(i * 16 + (lane >> 4) + 4 * r) * DLD + j * 16 + (lane & 15)] = acc[r];
+      for (int r = 0; r < 4; ++r) Bij[((lane >> 4) + 4 * r) * BLD + (lane & 15)] = acc[r];
     }
     __syncthreads();
     // X_ij = -sum_{k=j+1..i} X_ik * T_k ; results parked in registers until every wave has read T
-    d4_t res[2];
-    int cnt = 0;
-    for (int i = j + 1 + wave; i < 8; i += 4) {
-      d4_t acc = {0.0, 0.0, 0.0, 0.0};
-      for (int k = j + 1; k <= i; ++k)
-        mma16<false>(acc, S + (i * 16) * DLD + k * 16, DLD, S + (k * 16) * DLD + j * 16, DLD, lane);
-      if (cnt == 0) res[0] = acc; else res[1] = acc;
-      ++cnt;
+    d4_t res0 = {0.0, 0.0, 0.0, 0.0}, res1 = {0.0, 0.0, 0.0, 0.0};
+    {
+      int cnt = 0;
+      for (int i = j + 1 + wave; i < 8; i += 4, ++cnt) {
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+        for (int k = j + 1; k <= i; ++k) mma16<false>(acc, S + blk_off(i, k), BLD, S + blk_off(k, j), BLD, lane);
+        if (cnt == 0) res0 = acc; else res1 = acc;
+      }
     }
     __syncthreads();
-    cnt = 0;
-    for (int i = j + 1 + wave; i < 8; i += 4) {
-      const d4_t acc = (cnt == 0) ? res[0] : res[1];
+    {
+      int cnt = 0;
+      for (int i = j + 1 + wave; i < 8; i += 4, ++cnt) {
+        const d4_t acc = (cnt == 0) ? res0 : res1;
+        double* Bij = S + blk_off(i, j);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) S[(i * 16 + (lane >> 4) + 4 * r) * DLD + j * 16 + (lane & 15)] = -acc[r];
-      ++cnt;
+        for (int r = 0; r < 4; ++r) Bij[((lane >> 4) + 4 * r) * BLD + (lane & 15)] = -acc[r];
+      }
     }
     __syncthreads();
   }
-  // ---- phase 5: write the inverse (dense 128x128, zeros above the diagonal)
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int r = idx >> 7, c = idx & 127;
-    Dinv[idx] = (c <= r) ? S[r * DLD + c] : 0.0;
+  // ---- phase 5: write the inverse (lower part; the strictly-upper part of the Dinv store is zero from allocation)
+  if (!(dbg & 32)) {
+#pragma unroll 8
+    for (int it = 0; it < 64; ++it) {
+      const int idx = tid + 256 * it;
+      const int r = idx >> 7, c = idx & 127;
+      if (c <= r) Dinv[idx] = S[blk_off(r >> 4, c >> 4) + (r & 15) * BLD + (c & 15)];
+    }
   }
 }
 
@@ -288,7 +394,7 @@ static int launch_diag(ffgp_handle* h, double* Ablk, int lda, int nb, double* Di
     g_diag_attr_set = true;
   }
   hipLaunchKernelGGL(ffgp_potrf_diag128, dim3(1), dim3(256), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk,
-                     h->d_info, row_base, do_factor);
+                     h->d_info, row_base, do_factor, h->diag_dbg);
   return FFGP_OK;
 }
 
@@ -300,6 +406,7 @@ int ffgp_ensure_dinv(ffgp_handle* h, int n) {
     h->dinv = nullptr;
     h->dinv_bytes = 0;
     if (hipMalloc(&h->dinv, need) != hipSuccess) return FFGP_ERR_ALLOC;
+    if (hipMemset(h->dinv, 0, need) != hipSuccess) return FFGP_ERR_HIP;  // strictly-upper parts stay zero forever
     h->dinv_bytes = need;
   }
   return FFGP_OK;
@@ -325,6 +432,31 @@ int ffgp_refresh_dinv(ffgp_handle* h, const double* L, int n, int ldl) {
   return FFGP_OK;
 }
 
+// factor one outer panel (columns k0 .. k0+w1) of the (mtot x n) matrix on h->stream: per 128-column block a
+// diagonal factor+inverse, the TRSM of every row below as one GEMM, and the update of the panel's remaining columns
+static int factor_panel(ffgp_handle* h, double* A, int n, int mtot, int lda, int k0, int w1) {
+  const int pend = k0 + w1;
+  for (int j0 = k0; j0 < pend; j0 += NB) {
+    const int jb = min(NB, n - j0);
+    double* Ajj = A + (size_t)j0 * lda + j0;
+    double* Dj = h->dinv + (size_t)(j0 / NB) * NB * NB;
+    FFGP_CHECK(launch_diag(h, Ajj, lda, jb, Dj, j0, 1));
+    const int mrows = mtot - (j0 + jb);
+    if (mrows > 0) {
+      double* A21 = A + (size_t)(j0 + jb) * lda + j0;
+      // TRSM as GEMM: A21 <- A21 * Dj^T (in place: one column tile, each workgroup rewrites only rows it read)
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, A21, lda, Dj, NB, A21, lda, mrows, jb, jb, 1.0, 0.0));
+      const int wrem = pend - (j0 + jb);
+      if (wrem > 0) {
+        double* C = A + (size_t)(j0 + jb) * lda + (j0 + jb);
+        FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 0, A21, lda, A21, lda, C, lda, mrows, wrem, jb, -1.0,
+                                    1.0));
+      }
+    }
+  }
+  return FFGP_OK;
+}
+
 // Factor the leading n x n block of A in place; rows n..mtot-1 (if any) are "passenger" rows that receive the
 // same right-hand transformations and come out as  A[n:, :] * L^-T  -- i.e. (L^-1 B)^T for B^T stored below
 // Sigma.  The fused NLML/predict paths put Y^T and K_*^T there, so the triangular solves ride inside the
@@ -346,34 +478,56 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
     if (mtot > n) hipLaunchKernelGGL(ffgp_trsm_rows_naive, dim3(mtot - n), dim3(64), 0, h->stream, A, lda, n);
   } else {
     const int NB1 = h->nb_outer;
-    for (int k0 = 0; k0 < n; k0 += NB1) {
-      const int w1 = min(NB1, n - k0);
-      const int pend = k0 + w1;  // end column of this outer panel
-      for (int j0 = k0; j0 < pend; j0 += NB) {
-        const int jb = min(NB, n - j0);
-        double* Ajj = A + (size_t)j0 * lda + j0;
-        double* Dj = h->dinv + (size_t)(j0 / NB) * NB * NB;
-        FFGP_CHECK(launch_diag(h, Ajj, lda, jb, Dj, j0, 1));
-        const int mrows = mtot - (j0 + jb);
-        if (mrows > 0) {
-          double* A21 = A + (size_t)(j0 + jb) * lda + j0;
-          // TRSM as GEMM: A21 <- A21 * Dj^T (in place: one column tile, each workgroup rewrites only rows it read)
-          FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, A21, lda, Dj, NB, A21, lda, mrows, jb, jb,
-                                      1.0, 0.0));
-          const int wrem = pend - (j0 + jb);
-          if (wrem > 0) {
-            double* C = A + (size_t)(j0 + jb) * lda + (j0 + jb);
-            FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 0, A21, lda, A21, lda, C, lda, mrows, wrem,
-                                        jb, -1.0, 1.0));
-          }
+    if (!h->lookahead || n <= NB1) {
+      for (int k0 = 0; k0 < n; k0 += NB1) {
+        const int w1 = min(NB1, n - k0);
+        const int pend = k0 + w1;  // end column of this outer panel
+        FFGP_CHECK(factor_panel(h, A, n, mtot, lda, k0, w1));
+        const int mt = n - pend;  // trailing columns; trailing rows include the passenger rows
+        if (mt > 0) {
+          double* P = A + (size_t)pend * lda + k0;
+          double* C = A + (size_t)pend * lda + pend;
+          FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P, lda, P, lda, C, lda, mtot - pend, mt, w1,
+                                      -1.0, 1.0));
         }
       }
-      const int mt = n - pend;  // trailing columns; trailing rows include the passenger rows
-      if (mt > 0) {
+    } else {
+      // Look-ahead: the trailing update of step k is split into (i) the columns of panel k+1 and (ii) the rest.
+      // Panel k+1 is factored on a second, high-priority stream as soon as (i) is done, so its latency-bound
+      // chain (diag factor -> TRSM -> panel update, x4) runs underneath the big (ii) SYRK of step k instead of
+      // in front of the next one.  Panel k+1 touches only its own columns; (ii) reads panel k and writes the
+      // columns to the right of panel k+1, so the two streams never alias.
+      hipStream_t main_s = h->stream;
+      FFGP_CHECK(factor_panel(h, A, n, mtot, lda, 0, min(NB1, n)));
+      int it = 0;
+      for (int k0 = 0; k0 < n; k0 += NB1, ++it) {
+        const int w1 = min(NB1, n - k0);
+        const int pend = k0 + w1;
+        const int mt = n - pend;
+        if (mt <= 0) break;
+        const int wn = min(NB1, mt);  // width of the next panel
         double* P = A + (size_t)pend * lda + k0;
         double* C = A + (size_t)pend * lda + pend;
-        FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P, lda, P, lda, C, lda, mtot - pend, mt, w1,
-                                    -1.0, 1.0));
+        // (i) next panel's columns (all rows below, passenger rows included)
+        FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P, lda, P, lda, C, lda, mtot - pend, wn, w1, -1.0,
+                                    1.0));
+        hipEvent_t ea = h->la_ev[(it & 1) * 2], eb = h->la_ev[(it & 1) * 2 + 1];
+        FFGP_HIP(hipEventRecord(ea, main_s));
+        FFGP_HIP(hipStreamWaitEvent(h->aux, ea, 0));
+        h->stream = h->aux;
+        const int rc = factor_panel(h, A, n, mtot, lda, pend, wn);
+        h->stream = main_s;
+        FFGP_CHECK(rc);
+        FFGP_HIP(hipEventRecord(eb, h->aux));
+        // (ii) the rest of the trailing matrix
+        const int mt2 = mt - wn;
+        if (mt2 > 0) {
+          double* P2 = A + (size_t)(pend + wn) * lda + k0;
+          double* C2 = A + (size_t)(pend + wn) * lda + (pend + wn);
+          FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P2, lda, P2, lda, C2, lda, mtot - pend - wn, mt2,
+                                      w1, -1.0, 1.0));
+        }
+        FFGP_HIP(hipStreamWaitEvent(main_s, eb, 0));
       }
     }
     h->dinv_L = A;

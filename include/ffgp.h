@@ -96,7 +96,8 @@ int ffgp_create(int device, ffgp_handle** out);
 int ffgp_destroy(ffgp_handle* h);
 int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL restores the handle's own stream */
 /* options: "timing" (0/1: record per-stage hipEvents), "nb_outer" (trailing-update block, multiple of 128),
-            "naive" (1: route factor kernels through the slow reference kernels; debugging only) */
+            "naive" (1: route factor kernels through the slow reference kernels; debugging only),
+            "lookahead" (default 1: factor panel k+1 on a high-priority side stream under the trailing update of step k) */
 int ffgp_set_option(ffgp_handle* h, const char* key, double value);
 const char* ffgp_version(void);
 
@@ -120,6 +121,10 @@ int ffgp_potrf(ffgp_handle* h, double* A_dev, int n, int lda);
    This is how the fused paths obtain Gamma = L^-1 Y (cigp_v10.py:63) and V = L^-1 K_* (cigp_v10.py:36) inside
    the factorisation's own matrix-core GEMMs instead of separate triangular sweeps.                            */
 int ffgp_potrf_rows(ffgp_handle* h, double* A_dev, int n, int mtot, int lda);
+
+/* Rebuild the handle's store of inverted 128x128 diagonal blocks for a factor L that this handle did not just
+   produce (the triangular solves and ffgp_potri consume it; ffgp_potrf leaves it up to date).               */
+int ffgp_trtri_diag(ffgp_handle* h, const double* L_dev, int n, int ldl);
 
 /* B <- L^-1 B.  Replaces torch.triangular_solve(B, L, upper=False) (cigp_v10.py:36,63;
    gp_computation_pack.py:130) and `L.inverse() @ B` (base_gp/cigp.py:131; gp_computation_pack.py:108).      */

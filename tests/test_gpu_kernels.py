@@ -56,9 +56,18 @@ def run_gemm(ff, opa, opb, lower, tri, A, B, C0, alpha, beta, pad=(0, 0, 0)):
     return out[:, :C0.shape[1]]
 
 
+@pytest.fixture(params=[64, 128])
+def tile(request, ff):
+    """run the test once per GEMM tile shape (the launcher picks automatically in production)"""
+    _lib, h = ff
+    assert _lib.lib.ffgp_set_option(h, b"gemm_tile", float(request.param)) == 0
+    yield request.param
+    _lib.lib.ffgp_set_option(h, b"gemm_tile", 0.0)
+
+
 @pytest.mark.parametrize("opa,opb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("m,n,k", [(128, 128, 16), (256, 128, 64), (100, 77, 21), (1, 1, 1), (300, 200, 130), (129, 257, 48)])
-def test_gemm_layouts(ff, opa, opb, m, n, k):
+def test_gemm_layouts(ff, tile, opa, opb, m, n, k):
     rng = np.random.default_rng(m * 7 + n * 3 + k + opa * 2 + opb)
     A = rng.standard_normal((m, k))
     B = rng.standard_normal((k, n))      # asymmetric operands: a swapped row/col map cannot hide
@@ -90,7 +99,7 @@ def test_gemm_unaligned_operands(ff):
 
 @pytest.mark.parametrize("m,n,k", [(128, 128, 32), (300, 300, 64), (700, 300, 128), (1300, 1300, 16), (1100, 129, 40)])
 @pytest.mark.parametrize("ops", [(0, 0), (1, 1)])
-def test_gemm_lower_trapezoid(ff, m, n, k, ops):
+def test_gemm_lower_trapezoid(ff, tile, m, n, k, ops):
     rng = np.random.default_rng(m + n + k)
     A = rng.standard_normal((m, k))
     B = rng.standard_normal((k, n))
@@ -102,7 +111,7 @@ def test_gemm_lower_trapezoid(ff, m, n, k, ops):
     assert np.array_equal(out[~mask], C0[~mask]), "strictly-upper part must not be written"
 
 
-def test_gemm_triangular_k_ranges(ff):
+def test_gemm_triangular_k_ranges(ff, tile):
     rng = np.random.default_rng(9)
     n = 520
     Lt = np.tril(rng.standard_normal((n, n)))
@@ -149,7 +158,7 @@ def potrf(ff, S, rows=None, naive=False, nb_outer=None):
 
 
 @pytest.mark.parametrize("n", [1, 16, 17, 100, 128, 129, 300, 511, 640, 1000, 1537])
-def test_potrf_matches_lapack(ff, n):
+def test_potrf_matches_lapack(ff, tile, n):
     rng = np.random.default_rng(n)
     S = spd(n, rng)
     rc, out, _, _ = potrf(ff, S)
@@ -233,7 +242,7 @@ def test_trsm_and_potrs(ff):
 
 
 @pytest.mark.parametrize("n", [100, 128, 300, 700, 1100])
-def test_potri(ff, n):
+def test_potri(ff, tile, n):
     _lib, h = ff
     rng = np.random.default_rng(n)
     S = spd(n, rng)

@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""GPU micro-benchmarks of the fp64 MFMA GEMM / SYRK kernel and of the factorisation stages (interleaved rounds
+in one process, min and median over rounds).  Usage on the GPU box:  python tools/gemm_bench.py [what ...]"""
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from fidelityfusion_amd import _lib
+
+
+def p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def timeit(fn, rounds=5):
+    ts = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return min(ts), float(np.median(ts))
+
+
+def main():
+    h = _lib.handle(0)
+    _lib.bind_stream(h, 0)
+    what = sys.argv[1:] or ["peak", "gemm", "syrk", "potrf"]
+    res = {}
+    if "peak" in what:
+        res["mfma_f64_stream_tflops"] = _lib.mfma_f64_peak(0)
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(0)
+    if "gemm" in what:
+        for (m, n, k) in [(8192, 8192, 512), (8192, 8192, 2048), (8192, 8192, 8192), (16384, 128, 128), (16384, 384, 128)]:
+            A = torch.rand((m, k), generator=g, device=dev, dtype=torch.float64) - 0.5
+            B = torch.rand((n, k), generator=g, device=dev, dtype=torch.float64) - 0.5
+            Cm = torch.zeros((m, n), device=dev, dtype=torch.float64)
+            for beta in (0.0, 1.0):
+                fn = lambda: _lib.lib.ffgp_gemm(h, 0, 0, 0, 0, p(A), k, p(B), k, p(Cm), n, m, n, k, -1.0, beta)
+                fn()
+                tmin, tmed = timeit(fn)
+                res["gemm_nt_%dx%dx%d_beta%d" % (m, n, k, int(beta))] = {"ms_min": tmin, "ms_med": tmed,
+                                                                        "tflops": 2.0 * m * n * k / tmin / 1e9}
+    if "syrk" in what:
+        for (m, k) in [(16384, 512), (16384, 1024), (8192, 512), (4096, 512), (2048, 512), (1024, 512)]:
+            A = torch.rand((m, k), generator=g, device=dev, dtype=torch.float64) - 0.5
+            Cm = torch.zeros((m, m), device=dev, dtype=torch.float64)
+            fn = lambda: _lib.lib.ffgp_gemm(h, 0, 0, 1, 0, p(A), k, p(A), k, p(Cm), m, m, m, k, -1.0, 1.0)
+            fn()
+            tmin, tmed = timeit(fn)
+            res["syrk_lower_%dx%d" % (m, k)] = {"ms_min": tmin, "ms_med": tmed, "tflops": 1.0 * m * (m + 1) * k / tmin / 1e9}
+    if "potrf" in what:
+        for n in (2048, 4096, 8192, 16384):
+            X = torch.rand((n, 8), generator=g, device=dev, dtype=torch.float64)
+            w = torch.ones(8, device=dev, dtype=torch.float64)
+            amp = torch.ones(1, device=dev, dtype=torch.float64)
+            dadd = torch.full((1,), 0.37, device=dev, dtype=torch.float64)
+            W = torch.empty((n, n), device=dev, dtype=torch.float64)
+            for nbo, la in ((512, 0), (256, 1), (512, 1), (1024, 1)):
+                _lib.set_option("nb_outer", nbo, 0)
+                _lib.set_option("lookahead", la, 0)
+
+                def fn():
+                    _lib.lib.ffgp_assemble(h, p(X), n, p(X), n, 8, p(w), p(amp), 1e-30, p(dadd), None, 0, None, 0, 0.0, 0.0,
+                                           p(W), n, 1)
+                    rc = _lib.lib.ffgp_potrf(h, p(W), n, n)
+                    assert rc == 0, rc
+                fn()
+                tmin, tmed = timeit(fn, rounds=3)
+                res["assemble+potrf_n%d_nbo%d_la%d" % (n, nbo, la)] = {"ms_min": tmin, "tflops": n ** 3 / 3.0 / tmin / 1e9}
+            _lib.set_option("nb_outer", 512, 0)
+            _lib.set_option("lookahead", 1, 0)
+    for k_, v in res.items():
+        print(k_, json.dumps(v))
+
+
+if __name__ == "__main__":
+    main()
+
+
+def diag_ablation():
+    """time potrf_diag128 alone (inverse-only and factor entry) with phases masked out"""
+    h = _lib.handle(0)
+    _lib.bind_stream(h, 0)
+    n = 128 * 64
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(0)
+    X = torch.rand((n, 8), generator=g, device=dev, dtype=torch.float64)
+    w = torch.ones(8, device=dev, dtype=torch.float64)
+    amp = torch.ones(1, device=dev, dtype=torch.float64)
+    dadd = torch.full((1,), 0.37, device=dev, dtype=torch.float64)
+    W = torch.empty((n, n), device=dev, dtype=torch.float64)
+    _lib.lib.ffgp_assemble(h, p(X), n, p(X), n, 8, p(w), p(amp), 1e-30, p(dadd), None, 0, None, 0, 0.0, 0.0, p(W), n, 1)
+    assert _lib.lib.ffgp_potrf(h, p(W), n, n) == 0
+    # 64 sequential launches of the inverse-only entry (phases 0,3,4,5)
+    for mask in (0, 8, 16, 32, 128, 8 + 16 + 32 + 128):
+        _lib.set_option("diag_dbg", mask, 0)
+        fn = lambda: _lib.lib.ffgp_trtri_diag(h, p(W), n, n)
+        fn()
+        tmin, _ = timeit(fn)
+        print("diag inverse-only entry, mask %3d: %.1f us per launch" % (mask, tmin * 1e3 / 64))
+    _lib.set_option("diag_dbg", 0, 0)
+
+
+if "diag" in sys.argv[1:]:
+    diag_ablation()
+
+
+def diag_factor_ablation():
+    h = _lib.handle(0)
+    _lib.bind_stream(h, 0)
+    dev = "cuda:0"
+    n = 128
+    g = torch.Generator(device=dev).manual_seed(0)
+    X = torch.rand((n, 8), generator=g, device=dev, dtype=torch.float64)
+    w = torch.ones(8, device=dev, dtype=torch.float64)
+    amp = torch.ones(1, device=dev, dtype=torch.float64)
+    dadd = torch.full((1,), 0.37, device=dev, dtype=torch.float64)
+    W0 = torch.empty((n, n), device=dev, dtype=torch.float64)
+    _lib.lib.ffgp_assemble(h, p(X), n, p(X), n, 8, p(w), p(amp), 1e-30, p(dadd), None, 0, None, 0, 0.0, 0.0, p(W0), n, 1)
+    Ws = [W0.clone() for _ in range(50)]
+    _lib.set_option("lookahead", 0, 0)
+    for mask in (0, 1, 2, 4, 64, 1 + 2 + 4 + 64, 255):
+        _lib.set_option("diag_dbg", mask, 0)
+
+        def fn():
+            for Wt in Ws:
+                Wt.copy_(W0)
+            for Wt in Ws:
+                _lib.lib.ffgp_potrf(h, p(Wt), n, n)
+        fn()
+        tmin, _ = timeit(fn)
+        print("potrf(n=128) x50 incl. host sync, mask %3d: %.1f us per call" % (mask, tmin * 1e3 / 50))
+    _lib.set_option("diag_dbg", 0, 0)
+    _lib.set_option("lookahead", 1, 0)
+
+
+if "diagf" in sys.argv[1:]:
+    diag_factor_ablation()
