@@ -94,8 +94,11 @@ struct ffgp_handle {
 // ---- gemm.hip
 // tri: OR of TRI_* -- the k range of output tile (ti,tj) is clipped to the structurally non-zero part
 enum { TRI_LO_I = 1, TRI_LO_J = 2, TRI_HI_I = 4, TRI_HI_J = 8 };
+// alias: which operand (if any) shares its buffer with C -- the launcher then picks a tile shape that is race-free
+enum { ALIAS_NONE = 0, ALIAS_A = 1, ALIAS_B = 2 };
 int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, const double* A, int lda, const double* B,
-                     int ldb, double* C, int ldc, int m, int n, int k, double alpha, double beta, int tri = 0);
+                     int ldb, double* C, int ldc, int m, int n, int k, double alpha, double beta, int tri = 0,
+                     int alias = ALIAS_NONE);
 // ---- potrf.hip
 int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int sync_info);
 int ffgp_ensure_dinv(ffgp_handle* h, int n);

@@ -27,9 +27,11 @@
 //   TS =  64: 2 x 2 MFMA tiles per wave, 20 KiB LDS, up to 4 workgroups per CU -- the latency shape: a quarter of the
 //             per-tile MFMA chain and 4x the tiles, used when a launch has fewer 128-tiles than the chip has slots
 //             (panel TRSM/updates of the look-ahead chain, the tail of the factorisation)
+//   TM x TN = 64 x 128 (FULL tiles only): the in-place TRSM shape -- one column tile spans the whole 128-wide panel
+//             block, so every workgroup re-writes only rows nobody else reads
 template <int TS>
-struct Geo {
-  static constexpr int WT = TS / 32;            // MFMA tiles per wave per dimension
+struct Geo {                                    // per-operand geometry (TS = tile extent of that operand)
+  static constexpr int WT = TS / 32;            // MFMA tiles per wave along this dimension
   static constexpr int NLD = TS / 32;           // 16-byte loads per thread per operand tile
   static constexpr int MNLD = TS + 16;          // leading dimension of the MN-major LDS image
   static constexpr int OPBUF = 16 * (TS + 16);  // doubles per operand buffer (>= TS*16)
@@ -147,53 +149,54 @@ __device__ __forceinline__ void decode_tile(int t, int mode, int tiles_m, int ti
   }
 }
 
-template <int OPA, int OPB, int TS, bool GUARD>
+template <int OPA, int OPB, int TM, int TN, bool GUARD>
 __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, double* smem, int m0, int n0, int kt0, int kt1, int tid,
                                               const int (&offA)[4], const int (&offB)[4],
-                                              d4_t (&acc)[Geo<TS>::WT][Geo<TS>::WT]) {
-  constexpr int WT = Geo<TS>::WT, NLD = Geo<TS>::NLD, OPBUF = Geo<TS>::OPBUF;
+                                              d4_t (&acc)[Geo<TM>::WT][Geo<TN>::WT]) {
+  constexpr int WM = Geo<TM>::WT, WN = Geo<TN>::WT;
+  constexpr int BUFA = Geo<TM>::OPBUF, BUFB = Geo<TN>::OPBUF, STAGE = BUFA + BUFB;
   constexpr int subA = (OPA == OP_KMAJOR) ? 256 : 16;
   constexpr int subB = (OPB == OP_KMAJOR) ? 256 : 16;
-  d2_t ra[NLD], rb[NLD];
-  gload<OPA, TS, GUARD>(p.A, p.lda, m0, p.m, kt0 * BK, p.k, tid, p.avec != 0, ra);
-  gload<OPB, TS, GUARD>(p.B, p.ldb, n0, p.n, kt0 * BK, p.k, tid, p.bvec != 0, rb);
-  sstore<OPA, TS>(smem, tid, ra);
-  sstore<OPB, TS>(smem + OPBUF, tid, rb);
+  d2_t ra[Geo<TM>::NLD], rb[Geo<TN>::NLD];
+  gload<OPA, TM, GUARD>(p.A, p.lda, m0, p.m, kt0 * BK, p.k, tid, p.avec != 0, ra);
+  gload<OPB, TN, GUARD>(p.B, p.ldb, n0, p.n, kt0 * BK, p.k, tid, p.bvec != 0, rb);
+  sstore<OPA, TM>(smem, tid, ra);
+  sstore<OPB, TN>(smem + BUFA, tid, rb);
   __syncthreads();
   for (int kt = kt0; kt < kt1; ++kt) {
     const int par = (kt - kt0) & 1;
-    const double* sA = smem + par * (2 * OPBUF);
-    const double* sB = sA + OPBUF;
+    const double* sA = smem + par * STAGE;
+    const double* sB = sA + BUFA;
     const bool more = (kt + 1 < kt1);
     if (more) {
-      gload<OPA, TS, GUARD>(p.A, p.lda, m0, p.m, (kt + 1) * BK, p.k, tid, p.avec != 0, ra);
-      gload<OPB, TS, GUARD>(p.B, p.ldb, n0, p.n, (kt + 1) * BK, p.k, tid, p.bvec != 0, rb);
+      gload<OPA, TM, GUARD>(p.A, p.lda, m0, p.m, (kt + 1) * BK, p.k, tid, p.avec != 0, ra);
+      gload<OPB, TN, GUARD>(p.B, p.ldb, n0, p.n, (kt + 1) * BK, p.k, tid, p.bvec != 0, rb);
     }
 #pragma unroll
     for (int kq = 0; kq < 4; ++kq) {
-      double a[WT], b[WT];
+      double a[WM], b[WN];
 #pragma unroll
-      for (int i = 0; i < WT; ++i) a[i] = sA[offA[kq] + i * subA];
+      for (int i = 0; i < WM; ++i) a[i] = sA[offA[kq] + i * subA];
 #pragma unroll
-      for (int j = 0; j < WT; ++j) b[j] = sB[offB[kq] + j * subB];
+      for (int j = 0; j < WN; ++j) b[j] = sB[offB[kq] + j * subB];
 #pragma unroll
-      for (int i = 0; i < WT; ++i)
+      for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (more) {
-      double* dA = smem + (par ^ 1) * (2 * OPBUF);
-      sstore<OPA, TS>(dA, tid, ra);
-      sstore<OPB, TS>(dA + OPBUF, tid, rb);
+      double* dA = smem + (par ^ 1) * STAGE;
+      sstore<OPA, TM>(dA, tid, ra);
+      sstore<OPB, TN>(dA + BUFA, tid, rb);
     }
     __syncthreads();
   }
 }
 
-template <int OPA, int OPB, int MODE, int TAG, int TS>
+template <int OPA, int OPB, int MODE, int TAG, int TM, int TN>
 __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
-  constexpr int WT = Geo<TS>::WT, OPBUF = Geo<TS>::OPBUF;
-  __shared__ __attribute__((aligned(16))) double smem[4 * OPBUF];
+  constexpr int WM = Geo<TM>::WT, WN = Geo<TN>::WT;
+  __shared__ __attribute__((aligned(16))) double smem[2 * (Geo<TM>::OPBUF + Geo<TN>::OPBUF)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   if (p.prio) __builtin_amdgcn_s_setprio(2);  // panel GEMMs of the look-ahead chain outrank the trailing update
@@ -207,33 +210,33 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
   }
   int ti, tj;
   decode_tile(t, MODE, p.tiles_m, p.tiles_n, ti, tj);
-  const int m0 = ti * TS, n0 = tj * TS;
+  const int m0 = ti * TM, n0 = tj * TN;
 
-  d4_t acc[WT][WT];
+  d4_t acc[WM][WN];
 #pragma unroll
-  for (int i = 0; i < WT; ++i)
+  for (int i = 0; i < WM; ++i)
 #pragma unroll
-    for (int j = 0; j < WT; ++j) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < WN; ++j) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
 
   int offA[4], offB[4];
-  frag_offsets<OPA, TS>(lane, wm * (TS / 2), offA);
-  frag_offsets<OPB, TS>(lane, wn * (TS / 2), offB);
+  frag_offsets<OPA, TM>(lane, wm * (TM / 2), offA);
+  frag_offsets<OPB, TN>(lane, wn * (TN / 2), offB);
 
   // k range of this tile (triangular operands skip the k-tiles that are structurally zero)
   int kbeg = 0, kend = p.k;
-  if (p.lo_i) kbeg = max(kbeg, ti * TS);
-  if (p.lo_j) kbeg = max(kbeg, tj * TS);
-  if (p.hi_i) kend = min(kend, (ti + 1) * TS);
-  if (p.hi_j) kend = min(kend, (tj + 1) * TS);
+  if (p.lo_i) kbeg = max(kbeg, ti * TM);
+  if (p.lo_j) kbeg = max(kbeg, tj * TN);
+  if (p.hi_i) kend = min(kend, (ti + 1) * TM);
+  if (p.hi_j) kend = min(kend, (tj + 1) * TN);
   const int kt0 = kbeg / BK;
   const int kt1 = (kend + BK - 1) / BK;
 
   if (kt0 < kt1) {
-    const bool interior = (m0 + TS <= p.m) && (n0 + TS <= p.n) && (kt1 * BK <= p.k) && p.avec && p.bvec;
+    const bool interior = (m0 + TM <= p.m) && (n0 + TN <= p.n) && (kt1 * BK <= p.k) && p.avec && p.bvec;
     if (interior)
-      gemm_mainloop<OPA, OPB, TS, false>(p, smem, m0, n0, kt0, kt1, tid, offA, offB, acc);
+      gemm_mainloop<OPA, OPB, TM, TN, false>(p, smem, m0, n0, kt0, kt1, tid, offA, offB, acc);
     else
-      gemm_mainloop<OPA, OPB, TS, true>(p, smem, m0, n0, kt0, kt1, tid, offA, offB, acc);
+      gemm_mainloop<OPA, OPB, TM, TN, true>(p, smem, m0, n0, kt0, kt1, tid, offA, offB, acc);
   }
 
   // epilogue: lane holds rows (lane>>4)+4r, column lane&15 of each 16x16 accumulator tile
@@ -242,16 +245,16 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
   const double alpha = p.alpha, beta = p.beta;
   const bool use_c = (beta != 0.0);
 #pragma unroll
-  for (int i = 0; i < WT; ++i) {
-    double cv[4][WT];
-    const int rbase = m0 + wm * (TS / 2) + i * 16 + (lane >> 4);
-    const int cbase = n0 + wn * (TS / 2) + (lane & 15);
+  for (int i = 0; i < WM; ++i) {
+    double cv[4][WN];
+    const int rbase = m0 + wm * (TM / 2) + i * 16 + (lane >> 4);
+    const int cbase = n0 + wn * (TN / 2) + (lane & 15);
     if (use_c) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rowc = min(rbase + 4 * r, p.m - 1);
 #pragma unroll
-        for (int j = 0; j < WT; ++j) {
+        for (int j = 0; j < WN; ++j) {
           const int colc = min(cbase + j * 16, p.n - 1);
           cv[r][j] = p.C[(size_t)rowc * p.ldc + colc];
         }
@@ -260,13 +263,13 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int j = 0; j < WT; ++j) cv[r][j] = 0.0;
+        for (int j = 0; j < WN; ++j) cv[r][j] = 0.0;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = rbase + 4 * r;
 #pragma unroll
-      for (int j = 0; j < WT; ++j) {
+      for (int j = 0; j < WN; ++j) {
         const int col = cbase + j * 16;
         if (row < p.m && col < p.n && (MODE != TILES_LOWER || col <= row)) {
           p.C[(size_t)row * p.ldc + col] = alpha * acc[i][j][r] + beta * cv[r][j];
@@ -279,9 +282,9 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
 // ------------------------------------------------------------------------------------------------------------
 // host launcher
 // ------------------------------------------------------------------------------------------------------------
-template <int OPA, int OPB, int MODE, int TAG, int TS>
+template <int OPA, int OPB, int MODE, int TAG, int TM, int TN>
 static int launch_t(ffgp_handle* h, const GemmArgs& a) {
-  hipLaunchKernelGGL((ffgp_gemm_f64<OPA, OPB, MODE, TAG, TS>), dim3(a.total_tiles), dim3(256), 0, h->stream, a);
+  hipLaunchKernelGGL((ffgp_gemm_f64<OPA, OPB, MODE, TAG, TM, TN>), dim3(a.total_tiles), dim3(256), 0, h->stream, a);
   return FFGP_OK;
 }
 
@@ -289,32 +292,34 @@ template <int TS>
 static int dispatch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, const GemmArgs& a) {
   if (syrk_tag) {
     // the trailing update of the blocked Cholesky gets its own instantiation so rocprofv3 --stats separates it
-    if (opa == OP_KMAJOR && opb == OP_KMAJOR && mode == TILES_LOWER) return launch_t<OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, TS>(h, a);
+    if (opa == OP_KMAJOR && opb == OP_KMAJOR && mode == TILES_LOWER) return launch_t<OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, TS, TS>(h, a);
   } else if (mode == TILES_LOWER) {
-    if (opa == OP_KMAJOR && opb == OP_KMAJOR) return launch_t<OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 0, TS>(h, a);
-    if (opa == OP_MNMAJOR && opb == OP_MNMAJOR) return launch_t<OP_MNMAJOR, OP_MNMAJOR, TILES_LOWER, 0, TS>(h, a);
+    if (opa == OP_KMAJOR && opb == OP_KMAJOR) return launch_t<OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 0, TS, TS>(h, a);
+    if (opa == OP_MNMAJOR && opb == OP_MNMAJOR) return launch_t<OP_MNMAJOR, OP_MNMAJOR, TILES_LOWER, 0, TS, TS>(h, a);
   } else {
-    if (opa == OP_KMAJOR && opb == OP_KMAJOR) return launch_t<OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, TS>(h, a);
-    if (opa == OP_KMAJOR && opb == OP_MNMAJOR) return launch_t<OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, TS>(h, a);
-    if (opa == OP_MNMAJOR && opb == OP_MNMAJOR) return launch_t<OP_MNMAJOR, OP_MNMAJOR, TILES_FULL, 0, TS>(h, a);
-    if (opa == OP_MNMAJOR && opb == OP_KMAJOR) return launch_t<OP_MNMAJOR, OP_KMAJOR, TILES_FULL, 0, TS>(h, a);
+    if (opa == OP_KMAJOR && opb == OP_KMAJOR) return launch_t<OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, TS, TS>(h, a);
+    if (opa == OP_KMAJOR && opb == OP_MNMAJOR) return launch_t<OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, TS, TS>(h, a);
+    if (opa == OP_MNMAJOR && opb == OP_MNMAJOR) return launch_t<OP_MNMAJOR, OP_MNMAJOR, TILES_FULL, 0, TS, TS>(h, a);
+    if (opa == OP_MNMAJOR && opb == OP_KMAJOR) return launch_t<OP_MNMAJOR, OP_KMAJOR, TILES_FULL, 0, TS, TS>(h, a);
   }
   return FFGP_ERR_ARG;
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-static int count_tiles(int mode, int m, int n, int ts, int& tm, int& tn) {
-  tm = (m + ts - 1) / ts;
-  tn = (n + ts - 1) / ts;
+static int count_tiles(int mode, int m, int n, int tsm, int tsn, int& tm, int& tn) {
+  tm = (m + tsm - 1) / tsm;
+  tn = (n + tsn - 1) / tsn;
   if (mode != TILES_LOWER) return tm * tn;
   int total = 0;
   for (int ti = 0; ti < tm; ++ti) total += (ti + 1 < tn) ? ti + 1 : tn;
   return total;
 }
 
+// alias: 0 = C aliases neither operand; ALIAS_A = C is A's buffer (row-wise in place: needs ONE column tile so
+// that no other workgroup reads the rows a workgroup re-writes); ALIAS_B = C is B's buffer (needs ONE row tile)
 int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, const double* A, int lda, const double* B,
-                     int ldb, double* C, int ldc, int m, int n, int k, double alpha, double beta, int tri) {
+                     int ldb, double* C, int ldc, int m, int n, int k, double alpha, double beta, int tri, int alias) {
   if (m <= 0 || n <= 0) return FFGP_OK;
   if (k <= 0) {
     // degenerate: C = beta*C handled by callers (never used on the hot path)
@@ -322,6 +327,8 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   }
   if (!A || !B || !C) return FFGP_ERR_ARG;
   if (mode == TILES_LOWER && m < n) return FFGP_ERR_ARG;
+  if (alias == ALIAS_A && (n > 128 || mode != TILES_FULL)) return FFGP_ERR_ARG;
+  if (alias == ALIAS_B && (m > 128 || mode != TILES_FULL)) return FFGP_ERR_ARG;
   GemmArgs a;
   // vector (16-byte) operand loads need even leading dimensions and 16-byte aligned bases
   a.avec = (!(lda & 1) && aligned16(A)) ? 1 : 0;
@@ -337,11 +344,16 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   a.hi_j = (tri & TRI_HI_J) ? 1 : 0;
   // tile shape: the 128-tile is the throughput shape; below ~1.5 tiles per CU the launch is latency-bound and
   // the 64-tile (4x the workgroups, a quarter of the per-tile MFMA chain) finishes sooner
-  int ts = 128;
-  a.total_tiles = count_tiles(mode, m, n, 128, a.tiles_m, a.tiles_n);
-  if (h->force_ts == 64 || (h->force_ts == 0 && a.total_tiles < h->small_tile_threshold)) {
-    ts = 64;
-    a.total_tiles = count_tiles(mode, m, n, 64, a.tiles_m, a.tiles_n);
+  int tsm = 128, tsn = 128;
+  a.total_tiles = count_tiles(mode, m, n, 128, 128, a.tiles_m, a.tiles_n);
+  const bool want_small = (h->force_ts == 64) || (h->force_ts == 0 && a.total_tiles < h->small_tile_threshold);
+  if (want_small) {
+    if (alias == 0 || (alias == ALIAS_A && n <= 64) || (alias == ALIAS_B && m <= 64)) {
+      tsm = tsn = 64;
+    } else if (alias == ALIAS_A && opa == OP_KMAJOR && opb == OP_KMAJOR) {
+      tsm = 64;  // 64 x 128: the whole panel-block width in one column tile
+    }
+    a.total_tiles = count_tiles(mode, m, n, tsm, tsn, a.tiles_m, a.tiles_n);
   }
   // timing == 2: bracket every trailing-update launch with its own event pair (no host sync inside the timed
   // region; ffgp_syrk_stats drains the pool afterwards)
@@ -359,7 +371,13 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
     ev_stop = h->syrk_pool[h->syrk_pool_used + 1];
     h->syrk_pool_used += 2;
   }
-  const int rc = (ts == 128) ? dispatch<128>(h, opa, opb, mode, syrk_tag, a) : dispatch<64>(h, opa, opb, mode, syrk_tag, a);
+  int rc;
+  if (tsm == 64 && tsn == 128)
+    rc = launch_t<OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, 64, 128>(h, a);
+  else if (tsm == 128)
+    rc = dispatch<128>(h, opa, opb, mode, syrk_tag, a);
+  else
+    rc = dispatch<64>(h, opa, opb, mode, syrk_tag, a);
   if (rc != FFGP_OK) return rc;
   if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
   if (syrk_tag) {

@@ -445,7 +445,8 @@ static int factor_panel(ffgp_handle* h, double* A, int n, int mtot, int lda, int
     if (mrows > 0) {
       double* A21 = A + (size_t)(j0 + jb) * lda + j0;
       // TRSM as GEMM: A21 <- A21 * Dj^T (in place: one column tile, each workgroup rewrites only rows it read)
-      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, A21, lda, Dj, NB, A21, lda, mrows, jb, jb, 1.0, 0.0));
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, A21, lda, Dj, NB, A21, lda, mrows, jb, jb, 1.0, 0.0, 0,
+                                  ALIAS_A));
       const int wrem = pend - (j0 + jb);
       if (wrem > 0) {
         double* C = A + (size_t)(j0 + jb) * lda + (j0 + jb);

@@ -22,7 +22,8 @@ int ffgp_trsm_lower_impl(ffgp_handle* h, const double* L, int n, int ldl, double
     double* Bb = B + (size_t)r0 * ldb;
     const double* Db = h->dinv + (size_t)(r0 / NB) * NB * NB;
     // in place: a single tile row (m = rb <= 128); every workgroup reads/writes only its own column tile
-    FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Db, NB, Bb, ldb, Bb, ldb, rb, nrhs, rb, 1.0, 0.0));
+    FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Db, NB, Bb, ldb, Bb, ldb, rb, nrhs, rb, 1.0, 0.0, 0,
+                                ALIAS_B));
     const int below = n - (r0 + rb);
     if (below > 0)
       FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, L + (size_t)(r0 + rb) * ldl + r0, ldl, Bb, ldb,
@@ -43,7 +44,8 @@ int ffgp_trsm_lower_t_impl(ffgp_handle* h, const double* L, int n, int ldl, doub
     double* Bb = B + (size_t)r0 * ldb;
     const double* Db = h->dinv + (size_t)b * NB * NB;
     // op(A) = Dinv_b^T: stored k x m with m contiguous = MN-major
-    FFGP_CHECK(ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_FULL, 0, Db, NB, Bb, ldb, Bb, ldb, rb, nrhs, rb, 1.0, 0.0));
+    FFGP_CHECK(ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_FULL, 0, Db, NB, Bb, ldb, Bb, ldb, rb, nrhs, rb, 1.0, 0.0, 0,
+                                ALIAS_B));
     if (r0 > 0)  // op(A) = L[b-rows, 0:r0]^T : stored k(=rb) x m(=r0), MN-major
       FFGP_CHECK(ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_FULL, 0, L + (size_t)r0 * ldl, ldl, Bb, ldb, B, ldb, r0,
                                   nrhs, rb, -1.0, 1.0));

@@ -170,6 +170,18 @@ def test_potrf_matches_lapack(ff, tile, n):
     assert (up == 777.0).all(), "strictly-upper triangle was written"
 
 
+@pytest.mark.parametrize("n", [4000, 6200])
+def test_potrf_large_matches_lapack(ff, n):
+    """many workgroups per launch, look-ahead stream active: catches cross-workgroup races the small cases cannot"""
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, 64))
+    S = B @ B.T + np.diag(rng.random(n) + 0.5)
+    for _ in range(2):
+        rc, out, _, _ = potrf(ff, S)
+        assert rc == 0
+        assert relerr(np.tril(out[:n, :n]), np.linalg.cholesky(S)) < 1e-11
+
+
 @pytest.mark.parametrize("n,nb", [(700, 128), (700, 256), (1300, 384)])
 def test_potrf_outer_block_sizes(ff, n, nb):
     rng = np.random.default_rng(n + nb)
