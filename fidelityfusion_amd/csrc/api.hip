@@ -78,9 +78,10 @@ int ffgp_create(int device, ffgp_handle** out) {
     int lo = 0, hi = 0;  // numerically lowest value = greatest priority
     FFGP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
     FFGP_HIP(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, hi));
-    for (int i = 0; i < 4; ++i) FFGP_HIP(hipEventCreateWithFlags(&h->la_ev[i], hipEventDisableTiming));
+    for (int i = 0; i < 6; ++i) FFGP_HIP(hipEventCreateWithFlags(&h->la_ev[i], hipEventDisableTiming));
     h->lookahead = 1;
-    h->small_tile_threshold = 384;
+    h->small_tile_threshold = 640;
+    h->la_split = 1;
   }
   FFGP_HIP(hipMalloc(&h->d_info, 16 * sizeof(int)));
   FFGP_HIP(hipMalloc(&h->d_scal, SCAL_DOUBLES * sizeof(double)));
@@ -108,7 +109,7 @@ int ffgp_destroy(ffgp_handle* h) {
   hipEventDestroy(h->syrk_ev[0]);
   hipEventDestroy(h->syrk_ev[1]);
   for (hipEvent_t e : h->syrk_pool) hipEventDestroy(e);
-  for (int i = 0; i < 4; ++i) hipEventDestroy(h->la_ev[i]);
+  for (int i = 0; i < 6; ++i) hipEventDestroy(h->la_ev[i]);
   hipStreamDestroy(h->aux);
   hipStreamDestroy(h->own);
   delete h;
@@ -139,6 +140,8 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->small_tile_threshold = (int)value;
   } else if (!strcmp(key, "diag_dbg")) {
     h->diag_dbg = (int)value;
+  } else if (!strcmp(key, "la_split")) {
+    h->la_split = (int)value;
   } else if (!strcmp(key, "lookahead")) {
     h->lookahead = (int)value;
   } else {

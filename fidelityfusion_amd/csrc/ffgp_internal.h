@@ -57,10 +57,11 @@ struct ffgp_handle {
   hipStream_t stream;   // stream work is enqueued on (caller's, or `own`)
   hipStream_t own;      // the handle's own stream
   hipStream_t aux;      // high-priority side stream for the look-ahead panel factorisation
-  hipEvent_t la_ev[4];  // look-ahead hand-off events
+  hipEvent_t la_ev[6];  // look-ahead hand-off events
   int force_ts;         // 0 = automatic GEMM tile shape, 64 / 128 = forced (benchmarks, tests)
   int small_tile_threshold;  // launches with fewer 128-tiles than this use the 64-tile
   int diag_dbg;         // timing-only ablation mask of potrf_diag128 (0 in production)
+  int la_split;         // 1 = issue the look-ahead part of the trailing update in two launches (first 128 columns first)
   int lookahead;        // 1 = overlap panel k+1 with the trailing update of step k
   bool own_stream;
   // workspace (grown on demand, never shrunk)

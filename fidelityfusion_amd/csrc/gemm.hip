@@ -202,8 +202,10 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
   if (p.prio) __builtin_amdgcn_s_setprio(2);  // panel GEMMs of the look-ahead chain outrank the trailing update
 
   // XCD-aware bijective remap of the block id, then banded tile order
-  int t;
-  {
+  // (triangular-operand launches have k ranges that shrink along the tile order: giving each XCD a contiguous
+  //  chunk would leave all the long tiles on XCD 0, so those launches keep the round-robin block order)
+  int t = blockIdx.x;
+  if (!(p.lo_i | p.lo_j | p.hi_i | p.hi_j)) {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);

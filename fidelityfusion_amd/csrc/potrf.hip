@@ -88,30 +88,69 @@ __device__ __forceinline__ void mma16(d4_t& acc, const double* pa, int lda_, con
 }
 
 // one step of the in-register 16x16 Cholesky: the block is symmetric-full, lane (g = lane>>4, c = lane&15) holds
-// rows g+4r (r = 0..3) of column c.  Pivot J: rank-1 downdate of the whole block with column J / d, and the
-// lanes of column J keep their (scaled) column as the output.
+// rows g+4r (r = 0..3) of column c.  Pivot J: rank-1 downdate of the whole block with column J / d.  Only
+// readlane -> rcp -> mul -> fma sits on the pivot-to-pivot dependency chain: the lanes of column J just park their
+// (unscaled) column and the pivot; the 1/sqrt(d) scaling happens once after the 16 steps.
 template <int J>
-__device__ __forceinline__ void chol16_step(double (&v)[4], double (&out)[4], int lane, int& bad, double* rd_slot) {
+__device__ __forceinline__ void chol16_step(double (&v)[4], double (&out)[4], double& dmine, int lane, int& bad) {
   constexpr int PL = 16 * (J & 3) + J, PR = J >> 2;
   double d = readlane_d(v[PR], PL);
-  if (!(d > 0.0)) {
-    if (!bad) bad = J + 1;
-    d = 1.0;
-  }
+  const bool ok = d > 0.0;
+  bad = (!ok && bad == 0) ? J + 1 : bad;
+  d = ok ? d : 1.0;
   const double rinv = rcp_nr(d);
-  const double rs = rsqrt_nr(d);
   const double rowj = bperm_d(v[PR], 16 * (J & 3) + (lane & 15));  // A[J][c]
   double colj[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) colj[r] = row_bcast_d<J>(v[r]);      // A[g+4r][J]
-  if ((lane & 15) == J) {
+  const bool mine = (lane & 15) == J;
+  dmine = mine ? d : dmine;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) out[r] = v[r] * rs;
-    if (lane == J) rd_slot[J] = rs;
-  }
+  for (int r = 0; r < 4; ++r) out[r] = mine ? v[r] : out[r];
   const double t = rowj * rinv;
 #pragma unroll
   for (int r = 0; r < 4; ++r) v[r] = __builtin_fma(-colj[r], t, v[r]);
+}
+
+// one level of the in-place blocked inversion by recursive doubling: pairs of inverted S-block-wide diagonal
+// blocks (S in units of 16) are merged,  X21 = -X22 * (L21 * X11).  Four (pair, block column) work items per
+// level = one per wave; a wave keeps its column of T = L21*X11 in registers across the barrier that protects
+// L21 from being overwritten while other waves still read it.
+template <int S_>
+__device__ __forceinline__ void inv_merge_level(double* S, int wave, int lane) {
+  const int pair = wave / S_, jl = wave % S_;
+  const int b0 = pair * 2 * S_;
+  const int j = b0 + jl;
+  d4_t T[S_];
+#pragma unroll
+  for (int ii = 0; ii < S_; ++ii) {
+    const int i = b0 + S_ + ii;
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k = j; k < b0 + S_; ++k) mma16<false>(acc, S + blk_off(i, k), BLD, S + blk_off(k, j), BLD, lane);
+    T[ii] = acc;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ii = 0; ii < S_; ++ii) {
+    double* dst = S + blk_off(b0 + S_ + ii, j);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[((lane >> 4) + 4 * r) * BLD + (lane & 15)] = T[ii][r];
+  }
+  d4_t R[S_];
+#pragma unroll
+  for (int ii = 0; ii < S_; ++ii) {
+    const int i = b0 + S_ + ii;
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k = b0 + S_; k <= i; ++k) mma16<false>(acc, S + blk_off(i, k), BLD, S + blk_off(k, j), BLD, lane);
+    R[ii] = acc;
+  }
+#pragma unroll
+  for (int ii = 0; ii < S_; ++ii) {
+    double* dst = S + blk_off(b0 + S_ + ii, j);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[((lane >> 4) + 4 * r) * BLD + (lane & 15)] = -R[ii][r];
+  }
+  __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -195,25 +234,27 @@ __global__ __launch_bounds__(256) void ffgp_potrf_diag128(double* __restrict__ A
           out[r] = 0.0;
         }
         int bad = 0;
-        double* rds = rd + jj * 16;
-        chol16_step<0>(v, out, lane, bad, rds);
-        chol16_step<1>(v, out, lane, bad, rds);
-        chol16_step<2>(v, out, lane, bad, rds);
-        chol16_step<3>(v, out, lane, bad, rds);
-        chol16_step<4>(v, out, lane, bad, rds);
-        chol16_step<5>(v, out, lane, bad, rds);
-        chol16_step<6>(v, out, lane, bad, rds);
-        chol16_step<7>(v, out, lane, bad, rds);
-        chol16_step<8>(v, out, lane, bad, rds);
-        chol16_step<9>(v, out, lane, bad, rds);
-        chol16_step<10>(v, out, lane, bad, rds);
-        chol16_step<11>(v, out, lane, bad, rds);
-        chol16_step<12>(v, out, lane, bad, rds);
-        chol16_step<13>(v, out, lane, bad, rds);
-        chol16_step<14>(v, out, lane, bad, rds);
-        chol16_step<15>(v, out, lane, bad, rds);
+        double dmine = 1.0;
+        chol16_step<0>(v, out, dmine, lane, bad);
+        chol16_step<1>(v, out, dmine, lane, bad);
+        chol16_step<2>(v, out, dmine, lane, bad);
+        chol16_step<3>(v, out, dmine, lane, bad);
+        chol16_step<4>(v, out, dmine, lane, bad);
+        chol16_step<5>(v, out, dmine, lane, bad);
+        chol16_step<6>(v, out, dmine, lane, bad);
+        chol16_step<7>(v, out, dmine, lane, bad);
+        chol16_step<8>(v, out, dmine, lane, bad);
+        chol16_step<9>(v, out, dmine, lane, bad);
+        chol16_step<10>(v, out, dmine, lane, bad);
+        chol16_step<11>(v, out, dmine, lane, bad);
+        chol16_step<12>(v, out, dmine, lane, bad);
+        chol16_step<13>(v, out, dmine, lane, bad);
+        chol16_step<14>(v, out, dmine, lane, bad);
+        chol16_step<15>(v, out, dmine, lane, bad);
+        const double rs = rsqrt_nr(dmine);  // this lane's column pivot
+        if (g == 0) rd[jj * 16 + c] = rs;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Dj[(g + 4 * r) * BLD + c] = (g + 4 * r >= c) ? out[r] : 0.0;
+        for (int r = 0; r < 4; ++r) Dj[(g + 4 * r) * BLD + c] = (g + 4 * r >= c) ? out[r] * rs : 0.0;
         if (bad && lane == 0 && (jj * 16 + bad) <= nb) atomicCAS(info, 0, row_base + jj * 16 + bad);
       }
       __syncthreads();
@@ -274,39 +315,11 @@ __global__ __launch_bounds__(256) void ffgp_potrf_diag128(double* __restrict__ A
   }
   __syncthreads();
 
-  // ---- phase 4: in-place blocked inversion, block columns right to left:
-  //      X[i>j, j] = -X[i>j, i>j] * L[i>j, j] * X_jj
-  for (int j = (dbg & 16) ? -1 : 6; j >= 0; --j) {
-    // T_i = L_ij * X_jj  (each wave overwrites only the blocks it read)
-    for (int i = j + 1 + wave; i < 8; i += 4) {
-      d4_t acc = {0.0, 0.0, 0.0, 0.0};
-      double* Bij = S + blk_off(i, j);
-      mma16<false>(acc, Bij, BLD, S + blk_off(j, j), BLD, lane);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Bij[((lane >> 4) + 4 * r) * BLD + (lane & 15)] = acc[r];
-    }
-    __syncthreads();
-    // X_ij = -sum_{k=j+1..i} X_ik * T_k ; results parked in registers until every wave has read T
-    d4_t res0 = {0.0, 0.0, 0.0, 0.0}, res1 = {0.0, 0.0, 0.0, 0.0};
-    {
-      int cnt = 0;
-      for (int i = j + 1 + wave; i < 8; i += 4, ++cnt) {
-        d4_t acc = {0.0, 0.0, 0.0, 0.0};
-        for (int k = j + 1; k <= i; ++k) mma16<false>(acc, S + blk_off(i, k), BLD, S + blk_off(k, j), BLD, lane);
-        if (cnt == 0) res0 = acc; else res1 = acc;
-      }
-    }
-    __syncthreads();
-    {
-      int cnt = 0;
-      for (int i = j + 1 + wave; i < 8; i += 4, ++cnt) {
-        const d4_t acc = (cnt == 0) ? res0 : res1;
-        double* Bij = S + blk_off(i, j);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Bij[((lane >> 4) + 4 * r) * BLD + (lane & 15)] = -acc[r];
-      }
-    }
-    __syncthreads();
+  // ---- phase 4: in-place blocked inversion by recursive doubling (16 -> 32 -> 64 -> 128), 2 barriers per level
+  if (!(dbg & 16)) {
+    inv_merge_level<1>(S, wave, lane);
+    inv_merge_level<2>(S, wave, lane);
+    inv_merge_level<4>(S, wave, lane);
   }
   // ---- phase 5: write the inverse (lower part; the strictly-upper part of the Dinv store is zero from allocation)
   if (!(dbg & 32)) {
@@ -434,7 +447,9 @@ int ffgp_refresh_dinv(ffgp_handle* h, const double* L, int n, int ldl) {
 
 // factor one outer panel (columns k0 .. k0+w1) of the (mtot x n) matrix on h->stream: per 128-column block a
 // diagonal factor+inverse, the TRSM of every row below as one GEMM, and the update of the panel's remaining columns
-static int factor_panel(ffgp_handle* h, double* A, int n, int mtot, int lda, int k0, int w1) {
+// `gate` (nullable): event the stream waits on before the panel's first update GEMM -- the look-ahead driver lets
+// the first diagonal factor + TRSM start as soon as the panel's first 128 columns carry the trailing update
+static int factor_panel(ffgp_handle* h, double* A, int n, int mtot, int lda, int k0, int w1, hipEvent_t gate = nullptr) {
   const int pend = k0 + w1;
   for (int j0 = k0; j0 < pend; j0 += NB) {
     const int jb = min(NB, n - j0);
@@ -449,6 +464,7 @@ static int factor_panel(ffgp_handle* h, double* A, int n, int mtot, int lda, int
                                   ALIAS_A));
       const int wrem = pend - (j0 + jb);
       if (wrem > 0) {
+        if (gate && j0 == k0) FFGP_HIP(hipStreamWaitEvent(h->stream, gate, 0));
         double* C = A + (size_t)(j0 + jb) * lda + (j0 + jb);
         FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 0, A21, lda, A21, lda, C, lda, mrows, wrem, jb, -1.0,
                                     1.0));
@@ -509,14 +525,25 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
         const int wn = min(NB1, mt);  // width of the next panel
         double* P = A + (size_t)pend * lda + k0;
         double* C = A + (size_t)pend * lda + pend;
-        // (i) next panel's columns (all rows below, passenger rows included)
-        FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P, lda, P, lda, C, lda, mtot - pend, wn, w1, -1.0,
+        // (i) next panel's columns (all rows below, passenger rows included), in two launches: its first 128
+        //     columns -- all the first diagonal factor + TRSM of panel k+1 need -- then the remaining ones
+        const int wa = h->la_split ? min(NB, wn) : wn;
+        FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P, lda, P, lda, C, lda, mtot - pend, wa, w1, -1.0,
                                     1.0));
-        hipEvent_t ea = h->la_ev[(it & 1) * 2], eb = h->la_ev[(it & 1) * 2 + 1];
+        hipEvent_t ea = h->la_ev[(it & 1) * 3], eg = h->la_ev[(it & 1) * 3 + 1], eb = h->la_ev[(it & 1) * 3 + 2];
         FFGP_HIP(hipEventRecord(ea, main_s));
         FFGP_HIP(hipStreamWaitEvent(h->aux, ea, 0));
+        hipEvent_t gate = nullptr;
+        if (wn > wa) {
+          double* Pb = A + (size_t)(pend + wa) * lda + k0;
+          double* Cb = A + (size_t)(pend + wa) * lda + (pend + wa);
+          FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, Pb, lda, Pb, lda, Cb, lda, mtot - pend - wa, wn - wa,
+                                      w1, -1.0, 1.0));
+          FFGP_HIP(hipEventRecord(eg, main_s));
+          gate = eg;
+        }
         h->stream = h->aux;
-        const int rc = factor_panel(h, A, n, mtot, lda, pend, wn);
+        const int rc = factor_panel(h, A, n, mtot, lda, pend, wn, gate);
         h->stream = main_s;
         FFGP_CHECK(rc);
         FFGP_HIP(hipEventRecord(eb, h->aux));

@@ -147,3 +147,68 @@ def diag_factor_ablation():
 
 if "diagf" in sys.argv[1:]:
     diag_factor_ablation()
+
+
+def potrf_sweep():
+    h = _lib.handle(0)
+    _lib.bind_stream(h, 0)
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(0)
+    for n in (16384, 8192):
+        X = torch.rand((n, 16), generator=g, device=dev, dtype=torch.float64)
+        w = torch.ones(16, device=dev, dtype=torch.float64)
+        amp = torch.ones(1, device=dev, dtype=torch.float64)
+        dadd = torch.full((1,), 0.37, device=dev, dtype=torch.float64)
+        W = torch.empty((n, n), device=dev, dtype=torch.float64)
+        for nbo in (512, 768, 1024):
+            for split in (0, 1):
+                for thr in (256, 384, 640):
+                    _lib.set_option("nb_outer", nbo, 0)
+                    _lib.set_option("la_split", split, 0)
+                    _lib.set_option("small_tile_threshold", thr, 0)
+
+                    def fn():
+                        _lib.lib.ffgp_assemble(h, p(X), n, p(X), n, 16, p(w), p(amp), 1e-30, p(dadd), None, 0, None, 0, 0.0,
+                                               0.0, p(W), n, 1)
+                        assert _lib.lib.ffgp_potrf(h, p(W), n, n) == 0
+                    fn()
+                    tmin, tmed = timeit(fn, rounds=3)
+                    print("n=%d nb_outer=%d split=%d thr=%d: %.2f ms (%.1f TF/s)" % (n, nbo, split, thr, tmin, n ** 3 / 3.0 / tmin / 1e9))
+    _lib.set_option("nb_outer", 512, 0)
+    _lib.set_option("la_split", 0, 0)
+    _lib.set_option("small_tile_threshold", 384, 0)
+
+
+if "sweep" in sys.argv[1:]:
+    potrf_sweep()
+
+
+def layout_bench():
+    h = _lib.handle(0)
+    _lib.bind_stream(h, 0)
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(0)
+    m = n = k = 8192
+    A = torch.rand((m, k), generator=g, device=dev, dtype=torch.float64) - 0.5
+    B = torch.rand((n, k), generator=g, device=dev, dtype=torch.float64) - 0.5
+    Cm = torch.zeros((m, n), device=dev, dtype=torch.float64)
+    for opa in (0, 1):
+        for opb in (0, 1):
+            for lower, tri in ((0, 0), (1, 0)):
+                if lower and opa != opb:
+                    continue
+                fn = lambda: _lib.lib.ffgp_gemm(h, opa, opb, lower, tri, p(A), k, p(B), k, p(Cm), n, m, n, k, -1.0, 0.0)
+                assert fn() == 0
+                tmin, tmed = timeit(fn, rounds=3)
+                fl = 2.0 * m * n * k * (0.5 if lower else 1.0)
+                print("gemm 8192^3 opa=%d opb=%d lower=%d: %.2f ms %.1f TF/s" % (opa, opb, lower, tmin, fl / tmin / 1e9))
+    # LAUUM / TRTRI shaped
+    X = torch.tril(A)
+    fn = lambda: _lib.lib.ffgp_gemm(h, 1, 1, 1, 1, p(X), k, p(X), k, p(Cm), n, m, n, k, 1.0, 0.0)
+    assert fn() == 0
+    tmin, _ = timeit(fn, rounds=3)
+    print("lauum-shaped 8192 (MN,MN,lower,lo_i): %.2f ms %.1f TF/s (n^3/3 flops)" % (tmin, m ** 3 / 3.0 / tmin / 1e9))
+
+
+if "layout" in sys.argv[1:]:
+    layout_bench()
