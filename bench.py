@@ -24,6 +24,26 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (vendor spec; 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz)
+ROOFLINE_KERNEL = "ffgp_gemm_f64<0, 0, 1, 1, 128, 128>"   # trailing SYRK update of the blocked Cholesky
+
+
+def recorded_traffic(n):
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/*_pmc_summary.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane streams on
+    gfx950).  bench.py cannot collect PMC counters itself; null when no recorded pass matches this workload."""
+    import glob
+    if n != 16384:
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None, None
+    try:
+        c = json.load(open(files[-1]))["counters"]
+        key = [k for k in c["FETCH_SIZE"] if k.startswith("void " + ROOFLINE_KERNEL)][0]
+        byt = (2.0 * c["FETCH_SIZE"][key]["per_launch"] + c["WRITE_SIZE"][key]["per_launch"]) * 1024.0
+        return byt, os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
 
 
 def nlml_flops(n, D, d):
@@ -132,6 +152,7 @@ def main():
 
     if rank == 0:
         achieved = stats["flops"] / (stats["ms"] * 1e-3) / 1e12 if stats["ms"] > 0 else 0.0
+        traffic, traffic_src = recorded_traffic(n)
         out = {
             "metric": "GP NLML+Cholesky throughput (NxN fp64 GF/s, %%MFMA-roofline) at N=%d" % n,
             "value": round(value, 1), "unit": "GF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -141,8 +162,10 @@ def main():
                                    % ("forward+gradients" if args.with_grad else "forward", n, D, d),
                        "N": n, "D": D, "d": d, "blocks": world, "parallelism": "fidelity-shard x%d" % world},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "ffgp_gemm_f64<0,0,1,1> (trailing SYRK update of the blocked Cholesky)",
+                         "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes/launch (PMC, recorded)", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": round(8.0 * stats["flops"] / max(stats["launches"], 1) / 512.0 * (1.0 + 1.0 / 16.0)),
+                         "kernel": ROOFLINE_KERNEL + " (trailing SYRK update of the blocked Cholesky, K = 512)",
                          "launches": stats["launches"], "avg_launch_ms": round(stats["ms"] / max(stats["launches"], 1), 4),
                          "avg_launch_gflop": round(stats["flops"] / max(stats["launches"], 1) / 1e9, 3)},
             "whole_path_frac_of_mfma_peak": round(value / world / 1e3 / FP64_MFMA_PEAK_TFLOPS, 4),

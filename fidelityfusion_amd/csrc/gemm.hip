@@ -246,35 +246,43 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
   //  the compiler batches them instead of one vmcnt(0) round trip per element)
   const double alpha = p.alpha, beta = p.beta;
   const bool use_c = (beta != 0.0);
+  const int rbase0 = m0 + wm * (TM / 2) + (lane >> 4);
+  const int cbase = n0 + wn * (TN / 2) + (lane & 15);
+  // software-pipelined over the WM 16-row groups: the C loads of group i+1 are in flight while group i is
+  // combined and stored
+  double cv[2][4][WN];
+  auto load_group = [&](int i, double (&dst)[4][WN]) {
 #pragma unroll
-  for (int i = 0; i < WM; ++i) {
-    double cv[4][WN];
-    const int rbase = m0 + wm * (TM / 2) + i * 16 + (lane >> 4);
-    const int cbase = n0 + wn * (TN / 2) + (lane & 15);
-    if (use_c) {
+    for (int r = 0; r < 4; ++r) {
+      const int rowc = min(rbase0 + i * 16 + 4 * r, p.m - 1);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rowc = min(rbase + 4 * r, p.m - 1);
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          const int colc = min(cbase + j * 16, p.n - 1);
-          cv[r][j] = p.C[(size_t)rowc * p.ldc + colc];
-        }
+      for (int j = 0; j < WN; ++j) {
+        const int colc = min(cbase + j * 16, p.n - 1);
+        dst[r][j] = p.C[(size_t)rowc * p.ldc + colc];
       }
-    } else {
+    }
+  };
+  if (use_c) {
+    load_group(0, cv[0]);
+  } else {
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) cv[r][j] = 0.0;
-    }
+        for (int j = 0; j < WN; ++j) cv[b][r][j] = 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    if (use_c && i + 1 < WM) load_group(i + 1, cv[(i + 1) & 1]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = rbase + 4 * r;
+      const int row = rbase0 + i * 16 + 4 * r;
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         const int col = cbase + j * 16;
         if (row < p.m && col < p.n && (MODE != TILES_LOWER || col <= row)) {
-          p.C[(size_t)row * p.ldc + col] = alpha * acc[i][j][r] + beta * cv[r][j];
+          p.C[(size_t)row * p.ldc + col] = alpha * acc[i][j][r] + beta * cv[i & 1][r][j];
         }
       }
     }
@@ -359,7 +367,7 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   }
   // timing == 2: bracket every trailing-update launch with its own event pair (no host sync inside the timed
   // region; ffgp_syrk_stats drains the pool afterwards)
-  const bool timed = (syrk_tag && h->timing == 2);
+  const bool timed = (syrk_tag && tsm == 128 && h->timing == 2);
   hipEvent_t ev_stop = nullptr;
   if (timed) {
     if (h->syrk_pool_used + 2 > (int)h->syrk_pool.size()) {
@@ -373,6 +381,7 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
     ev_stop = h->syrk_pool[h->syrk_pool_used + 1];
     h->syrk_pool_used += 2;
   }
+  if (tsm != 128) syrk_tag = 0;  // only the 128x128 trailing update is the roofline kernel (own instantiation + stats)
   int rc;
   if (tsm == 64 && tsn == 128)
     rc = launch_t<OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, 64, 128>(h, a);
