@@ -239,23 +239,23 @@ int ffgp_nlml_fused(ffgp_handle* h, const ffgp_problem* p, double* nll_dev, cons
   const int n = p->n, D = p->D, d = p->d;
   const bool want_grad = g && (g->g_w_dev || g->g_amp_dev || g->g_diag_add_dev || g->g_Y_dev || g->g_diag_vec_dev);
   const bool v2 = (p->ll_variant == FFGP_LL_V2);
-  if (v2 && want_grad) {
-    fprintf(stderr, "[ffgp] gradients of the V2 (Sigma^-2) likelihood are not implemented in this build\n");
-    return FFGP_ERR_ARG;
-  }
   const size_t ld = ffgp_round_up(n, 16);
   const size_t w0 = (size_t)(n + d) * ld;          // Sigma | Y^T  ->  L | Gamma^T
   const size_t n1 = ffgp_round_up((n + 1) / 2, FFGP_NB);
   size_t total = w0;
-  size_t o_X = 0, o_S = 0, o_T = 0, o_At = 0, o_P = 0, o_A = 0;
+  size_t o_X = 0, o_S = 0, o_T = 0, o_At = 0, o_P = 0, o_A = 0, o_Ct = 0, o_Bt = 0;
   if (want_grad) {
     o_X = total; total += (size_t)n * ld;          // L^-1
     o_S = total; total += (size_t)n * ld;          // Sigma^-1 -> G
     o_T = total; total += n1 * n1 + 16;            // TRTRI scratch
     o_At = total; total += (size_t)d * ld;         // A^T = (Sigma^-1 Y)^T
     o_P = total; total += ffgp_grad_partial_doubles(n, D) + 16;
+    if (v2) {
+      o_Ct = total; total += (size_t)d * ld;       // (L^-1 A)^T
+      o_Bt = total; total += (size_t)d * ld;       // B^T = (Sigma^-1 A)^T
+    }
   }
-  if (v2) {
+  if (v2 && !want_grad) {
     o_A = total; total += (size_t)n * ffgp_round_up(d, 2) + 16;
   }
   FFGP_CHECK(ffgp_ensure_ws(h, total * sizeof(double)));
@@ -273,7 +273,7 @@ int ffgp_nlml_fused(ffgp_handle* h, const ffgp_problem* p, double* nll_dev, cons
   stage_mark(h, 2);
   if (!v2) {
     FFGP_CHECK(ffgp_nll_reduce_impl(h, FFGP_LL_V1, W0, n, (int)ld, Gt, d, n, (int)ld, d, p->pi_const, nll_dev));
-  } else {
+  } else if (!want_grad) {
     // A = L^-T Gamma  (n x d), then ||A||^2
     double* A = h->ws + o_A;
     const int lda2 = ffgp_round_up(d, 2);
@@ -295,12 +295,30 @@ int ffgp_nlml_fused(ffgp_handle* h, const ffgp_problem* p, double* nll_dev, cons
     // A^T = Gamma^T L^-1   (d x n)
     FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Gt, (int)ld, X, (int)ld, At, (int)ld, d, n, n, 1.0, 0.0,
                                 TRI_LO_J));
-    // G = d/2 Sigma^-1 - 1/2 A A^T   (lower, in place of Sigma^-1)
-    FFGP_CHECK(ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_LOWER, 0, At, (int)ld, At, (int)ld, S, (int)ld, n, n, d, -0.5,
-                                0.5 * (double)d));
+    const double* gYt = At;  // V1: d nll / dY = A
+    if (!v2) {
+      // G = d/2 Sigma^-1 - 1/2 A A^T   (lower, in place of Sigma^-1)
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_LOWER, 0, At, (int)ld, At, (int)ld, S, (int)ld, n, n, d,
+                                  -0.5, 0.5 * (double)d));
+    } else {
+      // V2 (Sigma^-2 quadratic form): value from ||A||^2; B = Sigma^-1 A = L^-T (L^-1 A);
+      // G = d/2 Sigma^-1 - 1/2 (A B^T + B A^T);  d(-LL)/dY = B       
+      double* Ct = h->ws + o_Ct;
+      double* Bt = h->ws + o_Bt;
+      FFGP_CHECK(ffgp_nll_reduce_impl(h, FFGP_LL_V2, W0, n, (int)ld, At, d, n, (int)ld, d, p->pi_const, nll_dev));
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, At, (int)ld, X, (int)ld, Ct, (int)ld, d, n, n, 1.0, 0.0,
+                                  TRI_HI_J));
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Ct, (int)ld, X, (int)ld, Bt, (int)ld, d, n, n, 1.0,
+                                  0.0, TRI_LO_J));
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_LOWER, 0, At, (int)ld, Bt, (int)ld, S, (int)ld, n, n, d,
+                                  -0.5, 0.5 * (double)d));
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_LOWER, 0, Bt, (int)ld, At, (int)ld, S, (int)ld, n, n, d,
+                                  -0.5, 1.0));
+      gYt = Bt;
+    }
     FFGP_CHECK(ffgp_grad_impl(h, p->X_dev, n, D, p->w_dev, p->amp_dev, p->clamp_min, S, (int)ld, p->mean_jitter, g->g_w_dev,
                               g->g_amp_dev, g->g_diag_add_dev, g->g_diag_vec_dev, P));
-    if (g->g_Y_dev) FFGP_CHECK(ffgp_transpose(h, At, d, n, (int)ld, g->g_Y_dev, d, 1.0));
+    if (g->g_Y_dev) FFGP_CHECK(ffgp_transpose(h, gYt, d, n, (int)ld, g->g_Y_dev, d, 1.0));
     stage_mark(h, 6);
   }
   FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));

@@ -170,6 +170,15 @@ def test_gp_basic_golden(golden, tag):
     k = make_kernel(g, "ard")
     gp = GP_basic(k, float(g["noise_variance"][0])).to(DEV)
     X, Y, Xs = T(g["X"]), T(g["Y"]), T(g["Xs"])
+    # training use (CAR): gradients of the Sigma^-2 likelihood w.r.t. noise, kernel parameters and Y
+    Yg = T(g["Y"], grad=True)
+    llg = gp.log_likelihood(X, Yg)
+    assert tuple(llg.shape) == tuple(g["ll"].shape) and rel(llg, g["ll"]) < 1e-10
+    llg.sum().backward()
+    assert rel(gp.noise_variance.grad, g["g_noise_variance"]) < 1e-7
+    assert rel(k.length_scales.grad, g["g_length_scales"]) < 1e-7
+    assert rel(k.signal_variance.grad, g["g_signal_variance"]) < 1e-7
+    assert rel(Yg.grad, g["g_Y"]) < 1e-7
     with torch.no_grad():
         ll = gp.log_likelihood(X, Y)
         assert tuple(ll.shape) == tuple(g["ll"].shape)
@@ -197,30 +206,44 @@ def test_resgp_chain_golden(golden):
     residual targets with a y_var matrix; 5 steps per fidelity, losses/params/prediction vs the reference."""
     from fidelityfusion_amd import kernel
     from fidelityfusion_amd.cigp_v10 import cigp
+    from fidelityfusion_amd.mf_harness import resgp_predict, train_gp_blocks
     g = golden("resgp_chain")
     gprs = [cigp(kernel.SquaredExponentialKernel(), 1.0).to(DEV) for _ in range(2)]
-    params = [p for m in gprs for p in m.parameters()]
-    trace = []
     data = [(T(g["x0n"]), T(g["y0n"])), (T(g["x_res"]), [T(g["y_res_mean"]), T(g["y_res_var"])])]
-    for f in range(2):
-        opt = torch.optim.Adam(params, lr=1e-2)   # the reference rebuilds Adam over ALL parameters per fidelity
-        for _ in range(5):
-            opt.zero_grad()
-            loss = -gprs[f].negative_log_likelihood(*data[f])
-            trace.append(-float(loss))
-            loss.backward()
-            opt.step()
-    assert rel(np.array(trace), g["ll_trace"]) < 1e-8
+    trace = train_gp_blocks(gprs, data, max_iter=5, lr_init=1e-2)   # the reference's loop: fresh Adam over ALL params per fidelity
+    assert rel(-np.array(trace), g["ll_trace"]) < 1e-8
     for f in range(2):
         assert rel(gprs[f].log_beta, g[f"gpr_list__{f}__log_beta"]) < 1e-8
         assert rel(gprs[f].kernel.length_scale, g[f"gpr_list__{f}__kernel__length_scale"]) < 1e-8
         assert rel(gprs[f].kernel.signal_variance, g[f"gpr_list__{f}__kernel__signal_variance"]) < 1e-8
-    with torch.no_grad():
-        xt = T(g["xtn"])
-        m0, c0 = gprs[0](data[0][0], data[0][1], xt)
-        m1, c1 = gprs[1](data[1][0], data[1][1], xt)
-    assert rel(m0 + m1, g["ypred"]) < 1e-8
-    assert rel(c0 + c1, g["var_pred"]) < 1e-8
+    mean, cov = resgp_predict(gprs, data, T(g["xtn"]))
+    assert rel(mean, g["ypred"]) < 1e-8
+    assert rel(cov, g["var_pred"]) < 1e-8
+
+
+def test_resgp2023_joint_loss_golden(golden):
+    """BASELINE config 1 plumbing: the 2023 ResGP joint loss (sum over fidelities of CIGP.compute_loss on the
+    residual chain, MFGP_ver2023May/ResGP.py:200-246) trained with Adam as mfgp_demo.py:122-127 does."""
+    from fidelityfusion_amd.mf_harness import ResGP2023
+    g = golden("resgp2023_demo")
+    m = ResGP2023(2).to(DEV).double()
+    opt = torch.optim.Adam(m.parameters(), lr=0.01)
+    x, ys = T(g["x_train"]), [T(g["y0"]), T(g["y1"])]
+    trace = []
+    for _ in range(10):
+        opt.zero_grad()
+        nll = m.compute_loss(x, ys)
+        trace.append(float(nll.detach()))
+        nll.backward()
+        opt.step()
+    assert rel(np.array(trace), g["nll_trace"]) < 1e-8
+    for f in range(2):
+        assert rel(m.cigp_list[f].noise_box.value, g[f"cigp_list__{f}__noise_box__value"]) < 1e-7
+        assert rel(m.cigp_list[f].kernel.length_scale, g[f"cigp_list__{f}__kernel__length_scale"]) < 1e-7
+        assert rel(m.cigp_list[f].kernel.scale, g[f"cigp_list__{f}__kernel__scale"]) < 1e-7
+    pm, pv = m(T(g["x_eval"]))
+    assert rel(pm, g["pred_mean"]) < 1e-7
+    assert rel(pv, g["pred_var"]) < 1e-7
 
 
 def test_cigar_blocks_sum_golden(golden):
