@@ -158,8 +158,10 @@ def main():
             "value": round(value, 1), "unit": "GF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "single-fidelity cigp NLML %s, ARD kernel, N=%d D=%d d=%d per GPU (BASELINE configs[2])"
-                                   % ("forward+gradients" if args.with_grad else "forward", n, D, d),
+            "config": {"workload": "single-fidelity cigp NLML %s, ARD kernel, N=%d D=%d d=%d per GPU%s"
+                                   % ("forward+gradients" if args.with_grad else "forward", n, D, d,
+                                      " (BASELINE configs[2])" if (n, D, d) == (16384, 16, 1) else
+                                      " (BASELINE configs[1])" if (n, D, d) == (4096, 8, 1) else ""),
                        "N": n, "D": D, "d": d, "blocks": world, "parallelism": "fidelity-shard x%d" % world},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
@@ -172,7 +174,7 @@ def main():
             "stage_ms": {k: round(v, 3) for k, v in stages.items()},
             "nll": float(nll),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(D, d, min(args.cpu_sample_n, n))
         print(json.dumps(out))
     if world > 1:
