@@ -48,6 +48,8 @@ struct GemmArgs {
   int total_tiles;
   int avec, bvec;      // 16-byte vector loads allowed for A / B
   int prio;            // raise the wave priority (look-ahead panel GEMMs)
+  int batch;           // gridDim.y: identical problems at fixed element strides
+  long sA, sB, sC;
   // triangular operands: restrict the k range of tile (ti, tj) to [max(lo_i*ti, lo_j*tj)*128, min(K, hi_i*(ti+1)*128, ...))
   int lo_i, lo_j, hi_i, hi_j;
 };
@@ -99,7 +101,7 @@ enum { TRI_LO_I = 1, TRI_LO_J = 2, TRI_HI_I = 4, TRI_HI_J = 8 };
 enum { ALIAS_NONE = 0, ALIAS_A = 1, ALIAS_B = 2 };
 int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, const double* A, int lda, const double* B,
                      int ldb, double* C, int ldc, int m, int n, int k, double alpha, double beta, int tri = 0,
-                     int alias = ALIAS_NONE);
+                     int alias = ALIAS_NONE, int batch = 1, long sA = 0, long sB = 0, long sC = 0);
 // ---- potrf.hip
 int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int sync_info);
 int ffgp_ensure_dinv(ffgp_handle* h, int n);

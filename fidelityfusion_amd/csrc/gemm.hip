@@ -150,7 +150,8 @@ __device__ __forceinline__ void decode_tile(int t, int mode, int tiles_m, int ti
 }
 
 template <int OPA, int OPB, int TM, int TN, bool GUARD>
-__device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, double* smem, int m0, int n0, int kt0, int kt1, int tid,
+__device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, const double* __restrict__ Ag, const double* __restrict__ Bg,
+                                              double* smem, int m0, int n0, int kt0, int kt1, int tid,
                                               const int (&offA)[4], const int (&offB)[4],
                                               d4_t (&acc)[Geo<TM>::WT][Geo<TN>::WT]) {
   constexpr int WM = Geo<TM>::WT, WN = Geo<TN>::WT;
@@ -158,8 +159,8 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, double* smem, i
   constexpr int subA = (OPA == OP_KMAJOR) ? 256 : 16;
   constexpr int subB = (OPB == OP_KMAJOR) ? 256 : 16;
   d2_t ra[Geo<TM>::NLD], rb[Geo<TN>::NLD];
-  gload<OPA, TM, GUARD>(p.A, p.lda, m0, p.m, kt0 * BK, p.k, tid, p.avec != 0, ra);
-  gload<OPB, TN, GUARD>(p.B, p.ldb, n0, p.n, kt0 * BK, p.k, tid, p.bvec != 0, rb);
+  gload<OPA, TM, GUARD>(Ag, p.lda, m0, p.m, kt0 * BK, p.k, tid, p.avec != 0, ra);
+  gload<OPB, TN, GUARD>(Bg, p.ldb, n0, p.n, kt0 * BK, p.k, tid, p.bvec != 0, rb);
   sstore<OPA, TM>(smem, tid, ra);
   sstore<OPB, TN>(smem + BUFA, tid, rb);
   __syncthreads();
@@ -169,8 +170,8 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, double* smem, i
     const double* sB = sA + BUFA;
     const bool more = (kt + 1 < kt1);
     if (more) {
-      gload<OPA, TM, GUARD>(p.A, p.lda, m0, p.m, (kt + 1) * BK, p.k, tid, p.avec != 0, ra);
-      gload<OPB, TN, GUARD>(p.B, p.ldb, n0, p.n, (kt + 1) * BK, p.k, tid, p.bvec != 0, rb);
+      gload<OPA, TM, GUARD>(Ag, p.lda, m0, p.m, (kt + 1) * BK, p.k, tid, p.avec != 0, ra);
+      gload<OPB, TN, GUARD>(Bg, p.ldb, n0, p.n, (kt + 1) * BK, p.k, tid, p.bvec != 0, rb);
     }
 #pragma unroll
     for (int kq = 0; kq < 4; ++kq) {
@@ -200,6 +201,10 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   if (p.prio) __builtin_amdgcn_s_setprio(2);  // panel GEMMs of the look-ahead chain outrank the trailing update
+  // batched launches (gridDim.y > 1): identical problems at fixed strides (the levels of the blocked TRTRI)
+  const double* __restrict__ Ag = p.A + (size_t)blockIdx.y * p.sA;
+  const double* __restrict__ Bg = p.B + (size_t)blockIdx.y * p.sB;
+  double* __restrict__ Cg = p.C + (size_t)blockIdx.y * p.sC;
 
   // XCD-aware bijective remap of the block id, then banded tile order
   // (triangular-operand launches have k ranges that shrink along the tile order: giving each XCD a contiguous
@@ -236,9 +241,9 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
   if (kt0 < kt1) {
     const bool interior = (m0 + TM <= p.m) && (n0 + TN <= p.n) && (kt1 * BK <= p.k) && p.avec && p.bvec;
     if (interior)
-      gemm_mainloop<OPA, OPB, TM, TN, false>(p, smem, m0, n0, kt0, kt1, tid, offA, offB, acc);
+      gemm_mainloop<OPA, OPB, TM, TN, false>(p, Ag, Bg, smem, m0, n0, kt0, kt1, tid, offA, offB, acc);
     else
-      gemm_mainloop<OPA, OPB, TM, TN, true>(p, smem, m0, n0, kt0, kt1, tid, offA, offB, acc);
+      gemm_mainloop<OPA, OPB, TM, TN, true>(p, Ag, Bg, smem, m0, n0, kt0, kt1, tid, offA, offB, acc);
   }
 
   // epilogue: lane holds rows (lane>>4)+4r, column lane&15 of each 16x16 accumulator tile
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         const int colc = min(cbase + j * 16, p.n - 1);
-        dst[r][j] = p.C[(size_t)rowc * p.ldc + colc];
+        dst[r][j] = Cg[(size_t)rowc * p.ldc + colc];
       }
     }
   };
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
       for (int j = 0; j < WN; ++j) {
         const int col = cbase + j * 16;
         if (row < p.m && col < p.n && (MODE != TILES_LOWER || col <= row)) {
-          p.C[(size_t)row * p.ldc + col] = alpha * acc[i][j][r] + beta * cv[i & 1][r][j];
+          Cg[(size_t)row * p.ldc + col] = alpha * acc[i][j][r] + beta * cv[i & 1][r][j];
         }
       }
     }
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
 // ------------------------------------------------------------------------------------------------------------
 template <int OPA, int OPB, int MODE, int TAG, int TM, int TN>
 static int launch_t(ffgp_handle* h, const GemmArgs& a) {
-  hipLaunchKernelGGL((ffgp_gemm_f64<OPA, OPB, MODE, TAG, TM, TN>), dim3(a.total_tiles), dim3(256), 0, h->stream, a);
+  hipLaunchKernelGGL((ffgp_gemm_f64<OPA, OPB, MODE, TAG, TM, TN>), dim3(a.total_tiles, a.batch), dim3(256), 0, h->stream, a);
   return FFGP_OK;
 }
 
@@ -329,7 +334,8 @@ static int count_tiles(int mode, int m, int n, int tsm, int tsn, int& tm, int& t
 // alias: 0 = C aliases neither operand; ALIAS_A = C is A's buffer (row-wise in place: needs ONE column tile so
 // that no other workgroup reads the rows a workgroup re-writes); ALIAS_B = C is B's buffer (needs ONE row tile)
 int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, const double* A, int lda, const double* B,
-                     int ldb, double* C, int ldc, int m, int n, int k, double alpha, double beta, int tri, int alias) {
+                     int ldb, double* C, int ldc, int m, int n, int k, double alpha, double beta, int tri, int alias, int batch,
+                     long sA, long sB, long sC) {
   if (m <= 0 || n <= 0) return FFGP_OK;
   if (k <= 0) {
     // degenerate: C = beta*C handled by callers (never used on the hot path)
@@ -348,6 +354,9 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.alpha = alpha; a.beta = beta;
   a.prio = (h->stream == h->aux) ? 1 : 0;
+  a.batch = batch > 1 ? batch : 1;
+  a.sA = sA; a.sB = sB; a.sC = sC;
+  if ((sA & 1) || (sB & 1)) a.avec = a.bvec = 0;  // odd strides break the 16-byte alignment of later batch members
   a.lo_i = (tri & TRI_LO_I) ? 1 : 0;
   a.lo_j = (tri & TRI_LO_J) ? 1 : 0;
   a.hi_i = (tri & TRI_HI_I) ? 1 : 0;
@@ -356,7 +365,7 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   // the 64-tile (4x the workgroups, a quarter of the per-tile MFMA chain) finishes sooner
   int tsm = 128, tsn = 128;
   a.total_tiles = count_tiles(mode, m, n, 128, 128, a.tiles_m, a.tiles_n);
-  const bool want_small = (h->force_ts == 64) || (h->force_ts == 0 && a.total_tiles < h->small_tile_threshold);
+  const bool want_small = (h->force_ts == 64) || (h->force_ts == 0 && a.total_tiles * a.batch < h->small_tile_threshold);
   if (want_small) {
     if (alias == 0 || (alias == ALIAS_A && n <= 64) || (alias == ALIAS_B && m <= 64)) {
       tsm = tsn = 64;

@@ -65,33 +65,55 @@ __global__ void ffgp_copy_block_kernel(const double* __restrict__ src, int lds_,
   }
 }
 
-static int trtri_rec(ffgp_handle* h, const double* L, int ldl, double* X, int ldx, int r0, int n, double* T) {
-  if (n <= NB) {
-    const double* Db = h->dinv + (size_t)(r0 / NB) * NB * NB;
-    hipLaunchKernelGGL(ffgp_copy_block_kernel, dim3((n * n + 255) / 256), dim3(256), 0, h->stream, Db, NB,
-                       X + (size_t)r0 * ldx + r0, ldx, n, n);
-    return FFGP_OK;
+// batched copy of the inverted diagonal blocks into X's diagonal
+__global__ void ffgp_copy_dinv_kernel(const double* __restrict__ dinv, double* __restrict__ X, int ldx, int n) {
+  const int b = blockIdx.y;
+  const int r0 = b * NB;
+  const int nb = min(NB, n - r0);
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < NB * NB) {
+    const int r = idx >> 7, c = idx & 127;
+    if (r < nb && c <= r) X[(size_t)(r0 + r) * ldx + r0 + c] = dinv[(size_t)b * NB * NB + idx];
   }
-  const int n1 = ffgp_round_up((n + 1) / 2, NB);
-  const int n2 = n - n1;
-  FFGP_CHECK(trtri_rec(h, L, ldl, X, ldx, r0, n1, T));
-  FFGP_CHECK(trtri_rec(h, L, ldl, X, ldx, r0 + n1, n2, T));
-  const double* L21 = L + (size_t)(r0 + n1) * ldl + r0;
-  double* X11 = X + (size_t)r0 * ldx + r0;
-  double* X22 = X + (size_t)(r0 + n1) * ldx + (r0 + n1);
-  double* X21 = X + (size_t)(r0 + n1) * ldx + r0;
-  // T = L21 * X11       (n2 x n1; X11 lower: B[k][j] = 0 for k < j  -> k starts at the tile column)
-  FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, L21, ldl, X11, ldx, T, n1, n2, n1, n1, 1.0, 0.0, TRI_LO_J));
-  // X21 = -X22 * T      (X22 lower: A[i][k] = 0 for k > i -> k ends at the tile row)
-  FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, X22, ldx, T, n1, X21, ldx, n2, n1, n2, -1.0, 0.0, TRI_HI_I));
-  return FFGP_OK;
 }
 
-// X (n x n, ldx) <- L^-1; the strictly-upper triangle of X is zeroed.  Workspace T: (n/2 rounded) ^2 doubles.
+// X (n x n, ldx) <- L^-1; the strictly-upper triangle of X is zeroed.  Workspace T: >= n*n/4 + n*128 doubles.
+// Bottom-up by doubling: at level s every aligned pair of inverted s x s diagonal blocks is merged,
+//   inv([[L11,0],[L21,L22]]) = [[X11,0],[-X22 (L21 X11), X22]],
+// all full pairs of a level in ONE batched launch per product (2 launches per level instead of 2 per pair).
 int ffgp_trtri_impl(ffgp_handle* h, const double* L, int n, int ldl, double* X, int ldx, double* T) {
   FFGP_CHECK(ensure_dinv_for(h, L, n, ldl));
   FFGP_HIP(hipMemsetAsync(X, 0, (size_t)n * ldx * sizeof(double), h->stream));
-  return trtri_rec(h, L, ldl, X, ldx, 0, n, T);
+  const int nblk = (n + NB - 1) / NB;
+  hipLaunchKernelGGL(ffgp_copy_dinv_kernel, dim3(NB * NB / 256, nblk), dim3(256), 0, h->stream, h->dinv, X, ldx, n);
+  for (long s = NB; s < n; s *= 2) {
+    const int full = (int)(n / (2 * s));          // pairs with both halves complete
+    const long strideL = 2 * s * (long)ldl + 2 * s, strideX = 2 * s * (long)ldx + 2 * s;
+    if (full > 0) {
+      const double* L21 = L + (size_t)s * ldl;
+      double* X11 = X;
+      double* X22 = X + (size_t)s * ldx + s;
+      double* X21 = X + (size_t)s * ldx;
+      // T = L21 * X11   (X11 lower: k starts at the tile column);   X21 = -X22 * T   (X22 lower: k ends at the tile row)
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, L21, ldl, X11, ldx, T, (int)s, (int)s, (int)s, (int)s,
+                                  1.0, 0.0, TRI_LO_J, ALIAS_NONE, full, strideL, strideX, s * s));
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, X22, ldx, T, (int)s, X21, ldx, (int)s, (int)s, (int)s,
+                                  -1.0, 0.0, TRI_HI_I, ALIAS_NONE, full, strideX, s * s, strideX));
+    }
+    const long r0 = (long)full * 2 * s;           // ragged last pair: first half complete, second half partial
+    const long n2 = n - r0 - s;
+    if (n2 > 0) {
+      const double* L21 = L + (size_t)(r0 + s) * ldl + r0;
+      double* X11 = X + (size_t)r0 * ldx + r0;
+      double* X22 = X + (size_t)(r0 + s) * ldx + (r0 + s);
+      double* X21 = X + (size_t)(r0 + s) * ldx + r0;
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, L21, ldl, X11, ldx, T, (int)s, (int)n2, (int)s, (int)s,
+                                  1.0, 0.0, TRI_LO_J));
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, X22, ldx, T, (int)s, X21, ldx, (int)n2, (int)s, (int)n2,
+                                  -1.0, 0.0, TRI_HI_I));
+    }
+  }
+  return FFGP_OK;
 }
 
 // S (lower triangle, n x n, lds) <- X^T X  for lower-triangular X  (= Sigma^-1 when X = L^-1)
