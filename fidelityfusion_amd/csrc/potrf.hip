@@ -40,8 +40,8 @@ __device__ __forceinline__ double readlane_d(double x, int l) {
 template <int J>
 __device__ __forceinline__ double row_bcast_d(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + J, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + J, 0xf, 0xf, false);
+  lo = __builtin_amdgcn_mov_dpp(lo, 0x150 + J, 0xf, 0xf, true);   // every lane receives data: no `old` value to seed
+  hi = __builtin_amdgcn_mov_dpp(hi, 0x150 + J, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 
@@ -88,18 +88,25 @@ __device__ __forceinline__ void mma16(d4_t& acc, const double* pa, int lda_, con
 }
 
 // one step of the in-register 16x16 Cholesky: the block is symmetric-full, lane (g = lane>>4, c = lane&15) holds
-// rows g+4r (r = 0..3) of column c.  Pivot J: rank-1 downdate of the whole block with column J / d.  Only
-// readlane -> rcp -> mul -> fma sits on the pivot-to-pivot dependency chain: the lanes of column J just park their
-// (unscaled) column and the pivot; the 1/sqrt(d) scaling happens once after the 16 steps.
+// rows g+4r (r = 0..3) of column c.  Pivot J: rank-1 downdate of the whole block with column J / d.
+// The pivot-to-pivot dependency chain is  readlane -> rcp -> 3 fma -> fma  (fp64 VALU ops have ~24-cycle dependent
+// latency, so every op removed from the chain is ~10 % of the block's factor time):
+//   * 1/d = y0 (1 + e + e^2), e = 1 - d y0, with y0 = v_rcp_f64(d) (~2^-26): t = u + u*(e + e^2), u = A[J][c]*y0 --
+//     three dependent fmas after the rcp instead of two Newton steps plus a multiply;
+//   * the pivot is not sanitised on the chain: a non-positive pivot is flagged on the side and the block's
+//     results are then garbage (as LAPACK's are), but no control flow depends on them;
+//   * the lanes of column J park their unscaled column and pivot; 1/sqrt(d) scaling happens after the 16 steps;
+//   * the same eliminations are applied to an identity block W (off the chain, in its issue gaps), so that
+//     inv(L_jj) = diag(1/sqrt(d)) * W comes out with the factor and the rows below are solved on the matrix cores.
 template <int J>
-__device__ __forceinline__ void chol16_step(double (&v)[4], double (&out)[4], double& dmine, int lane, int& bad) {
+__device__ __forceinline__ void chol16_step(double (&v)[4], double (&w)[4], double (&out)[4], double& dmine, int lane,
+                                            int& bad) {
   constexpr int PL = 16 * (J & 3) + J, PR = J >> 2;
-  double d = readlane_d(v[PR], PL);
-  const bool ok = d > 0.0;
-  bad = (!ok && bad == 0) ? J + 1 : bad;
-  d = ok ? d : 1.0;
-  const double rinv = rcp_nr(d);
+  const double d = readlane_d(v[PR], PL);
+  bad = (!(d > 0.0) && bad == 0) ? J + 1 : bad;
+  const double y0 = __builtin_amdgcn_rcp(d);
   const double rowj = bperm_d(v[PR], 16 * (J & 3) + (lane & 15));  // A[J][c]
+  const double wrow = bperm_d(w[PR], 16 * (J & 3) + (lane & 15));  // W[J][c]
   double colj[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) colj[r] = row_bcast_d<J>(v[r]);      // A[g+4r][J]
@@ -107,9 +114,19 @@ __device__ __forceinline__ void chol16_step(double (&v)[4], double (&out)[4], do
   dmine = mine ? d : dmine;
 #pragma unroll
   for (int r = 0; r < 4; ++r) out[r] = mine ? v[r] : out[r];
-  const double t = rowj * rinv;
+  const double e = __builtin_fma(-d, y0, 1.0);
+  const double f = __builtin_fma(e, e, e);
+  const double u = rowj * y0;
+  const double t = __builtin_fma(u, f, u);          // A[J][c] / d
+  const double uw = wrow * y0;
+  const double tw = __builtin_fma(uw, f, uw);       // W[J][c] / d
 #pragma unroll
   for (int r = 0; r < 4; ++r) v[r] = __builtin_fma(-colj[r], t, v[r]);
+  // W rows above the pivot see multipliers that are rounding residue of already-eliminated entries (~1e-16 relative:
+  // harmless); only the pivot row itself must be left alone
+  colj[PR] = ((lane >> 4) == (J & 3)) ? 0.0 : colj[PR];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) w[r] = __builtin_fma(-colj[r], tw, w[r]);
 }
 
 // one level of the in-place blocked inversion by recursive doubling: pairs of inverted S-block-wide diagonal
@@ -223,59 +240,64 @@ __global__ __launch_bounds__(256) void ffgp_potrf_diag128(double* __restrict__ A
         }
       }
       __syncthreads();
-      // (b) wave 0: in-register 16x16 Cholesky (4 entries per lane, DPP / bpermute broadcasts)
+      // (b) wave 0: in-register 16x16 Cholesky + inverse (4 entries per lane, DPP / bpermute broadcasts).  L_jj goes
+      //     straight to global memory; its LDS slot receives inv(L_jj), which is all that (c) and the block
+      //     inversion need from it.
       if (wave == 0 && !(dbg & 1)) {
         double* Dj = S + blk_off(jj, jj);
         const int g = lane >> 4, c = lane & 15;
-        double v[4], out[4];
+        double v[4], w[4], out[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           v[r] = Dj[(g + 4 * r) * BLD + c];
+          w[r] = (g + 4 * r == c) ? 1.0 : 0.0;
           out[r] = 0.0;
         }
         int bad = 0;
         double dmine = 1.0;
-        chol16_step<0>(v, out, dmine, lane, bad);
-        chol16_step<1>(v, out, dmine, lane, bad);
-        chol16_step<2>(v, out, dmine, lane, bad);
-        chol16_step<3>(v, out, dmine, lane, bad);
-        chol16_step<4>(v, out, dmine, lane, bad);
-        chol16_step<5>(v, out, dmine, lane, bad);
-        chol16_step<6>(v, out, dmine, lane, bad);
-        chol16_step<7>(v, out, dmine, lane, bad);
-        chol16_step<8>(v, out, dmine, lane, bad);
-        chol16_step<9>(v, out, dmine, lane, bad);
-        chol16_step<10>(v, out, dmine, lane, bad);
-        chol16_step<11>(v, out, dmine, lane, bad);
-        chol16_step<12>(v, out, dmine, lane, bad);
-        chol16_step<13>(v, out, dmine, lane, bad);
-        chol16_step<14>(v, out, dmine, lane, bad);
-        chol16_step<15>(v, out, dmine, lane, bad);
-        const double rs = rsqrt_nr(dmine);  // this lane's column pivot
+        chol16_step<0>(v, w, out, dmine, lane, bad);
+        chol16_step<1>(v, w, out, dmine, lane, bad);
+        chol16_step<2>(v, w, out, dmine, lane, bad);
+        chol16_step<3>(v, w, out, dmine, lane, bad);
+        chol16_step<4>(v, w, out, dmine, lane, bad);
+        chol16_step<5>(v, w, out, dmine, lane, bad);
+        chol16_step<6>(v, w, out, dmine, lane, bad);
+        chol16_step<7>(v, w, out, dmine, lane, bad);
+        chol16_step<8>(v, w, out, dmine, lane, bad);
+        chol16_step<9>(v, w, out, dmine, lane, bad);
+        chol16_step<10>(v, w, out, dmine, lane, bad);
+        chol16_step<11>(v, w, out, dmine, lane, bad);
+        chol16_step<12>(v, w, out, dmine, lane, bad);
+        chol16_step<13>(v, w, out, dmine, lane, bad);
+        chol16_step<14>(v, w, out, dmine, lane, bad);
+        chol16_step<15>(v, w, out, dmine, lane, bad);
+        const double rs = rsqrt_nr(dmine);  // 1/sqrt(pivot) of this lane's column
         if (g == 0) rd[jj * 16 + c] = rs;
+        // L[i][c] = out * rs (rows >= c) -> global
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Dj[(g + 4 * r) * BLD + c] = (g + 4 * r >= c) ? out[r] * rs : 0.0;
+        for (int r = 0; r < 4; ++r) {
+          const int i = g + 4 * r;
+          const int gr = jj * 16 + i, gc = jj * 16 + c;
+          if (i >= c && gr < nb && !(dbg & 64)) A[(size_t)gr * lda + gc] = out[r] * rs;
+        }
+        // inv(L_jj)[i][c] = rs_i * W[i][c]; rs_i comes back through the LDS slot just written
+        __builtin_amdgcn_s_waitcnt(0);       // rd[] visible to the whole wave (same-wave LDS write -> read)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = g + 4 * r;
+          Dj[i * BLD + c] = (i >= c) ? w[r] * rd[jj * 16 + i] : 0.0;
+        }
         if (bad && lane == 0 && (jj * 16 + bad) <= nb) atomicCAS(info, 0, row_base + jj * 16 + bad);
       }
       __syncthreads();
-      // (c) rows below: x * L_jj^T = b by substitution, one lane per row; L_jj entries are LDS broadcasts
-      {
-        const int nrows = NB - (jj + 1) * 16;
-        if (tid < nrows && !(dbg & 2)) {
-          double* pr = S + blk_off(jj + 1 + (tid >> 4), jj) + (tid & 15) * BLD;
-          const double* Lj = S + blk_off(jj, jj);
-          double x[16];
+      // (c) rows below: X = B * inv(L_jj)^T on the matrix cores (4 MFMAs per 16-row block)
+      if (!(dbg & 2)) {
+        for (int i = jj + 1 + wave; i < 8; i += 4) {
+          d4_t acc = {0.0, 0.0, 0.0, 0.0};
+          double* Bij = S + blk_off(i, jj);
+          mma16<true>(acc, Bij, BLD, S + blk_off(jj, jj), BLD, lane);
 #pragma unroll
-          for (int c = 0; c < 16; ++c) x[c] = pr[c];
-#pragma unroll
-          for (int c = 0; c < 16; ++c) {
-            const double xc = x[c] * rd[jj * 16 + c];
-            x[c] = xc;
-#pragma unroll
-            for (int k = c + 1; k < 16; ++k) x[k] = __builtin_fma(-xc, Lj[k * BLD + c], x[k]);
-          }
-#pragma unroll
-          for (int c = 0; c < 16; ++c) pr[c] = x[c];
+          for (int r = 0; r < 4; ++r) Bij[((lane >> 4) + 4 * r) * BLD + (lane & 15)] = acc[r];
         }
       }
       __syncthreads();
@@ -286,7 +308,7 @@ __global__ __launch_bounds__(256) void ffgp_potrf_diag128(double* __restrict__ A
       for (int it = 0; it < 64; ++it) {
         const int idx = tid + 256 * it;
         const int r = idx >> 7, c = idx & 127;
-        if (c <= r && r < nb) A[(size_t)r * lda + c] = S[blk_off(r >> 4, c >> 4) + (r & 15) * BLD + (c & 15)];
+        if ((c >> 4) < (r >> 4) && r < nb) A[(size_t)r * lda + c] = S[blk_off(r >> 4, c >> 4) + (r & 15) * BLD + (c & 15)];
       }
     }
   } else {
@@ -295,8 +317,9 @@ __global__ __launch_bounds__(256) void ffgp_potrf_diag128(double* __restrict__ A
   }
   __syncthreads();
 
-  // ---- phase 3: inverses of the eight 16x16 diagonal blocks, in place; 16 lanes per block (one per column)
-  if (wave < 2 && !(dbg & 8)) {
+  // ---- phase 3 (inverse-only entry; the factor entry already left inv(L_jj) in the diagonal slots):
+  //      inverses of the eight 16x16 diagonal blocks, in place; 16 lanes per block (one per column)
+  if (!do_factor && wave < 2 && !(dbg & 8)) {
     const int jj = wave * 4 + (lane >> 4), c = lane & 15;
     double* Lj = S + blk_off(jj, jj);
     double x[16];

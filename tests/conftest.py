@@ -12,6 +12,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the HIP library is built in-tree (git-ignored); build it once if a fresh checkout has not done so yet
+    so = os.path.join(ROOT, "fidelityfusion_amd", "libffgp.so")
+    if not os.path.exists(so):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")
