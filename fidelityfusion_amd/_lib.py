@@ -55,6 +55,8 @@ EXPORTS = {
     "ffgp_nll_reduce": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int, C.c_double, _dp]),
     "ffgp_potri": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int]),
     "ffgp_nlml_fused": (C.c_int, [C.c_void_p, C.POINTER(Problem), _dp, C.POINTER(Grads)]),
+    "ffgp_nlml_fused_async": (C.c_int, [C.c_void_p, C.POINTER(Problem), _dp, C.POINTER(Grads)]),
+    "ffgp_wait": (C.c_int, [C.c_void_p]),
     "ffgp_predict": (C.c_int, [C.c_void_p, C.POINTER(Problem), _dp, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int]),
     "ffgp_last_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_char_p), C.c_int,
                                     C.POINTER(C.c_int)]),
@@ -96,8 +98,9 @@ def check(rc, what):
     return rc
 
 
-def handle(device_index=None):
-    """One ffgp handle per GPU of this process (one process per GPU is the deployment model)."""
+def handle(device_index=None, slot=0):
+    """ffgp handles of this process: one per (GPU, slot).  Slot 0 is the default; extra slots carry independent
+    GP blocks that should overlap on the same GPU (each handle owns its workspace and side stream)."""
     import torch
 
     if not torch.cuda.is_available():
@@ -106,12 +109,12 @@ def handle(device_index=None):
     if device_index is None:
         device_index = torch.cuda.current_device()
     with _lock:
-        h = _handles.get(device_index)
+        h = _handles.get((device_index, slot))
         if h is None:
             out = C.c_void_p()
             check(lib.ffgp_create(int(device_index), C.byref(out)), "ffgp_create")
             h = out
-            _handles[device_index] = h
+            _handles[(device_index, slot)] = h
     return h
 
 

@@ -42,5 +42,5 @@ class cigp(nn.Module):
         w, amp, clamp = self.kernel.effective()
         diag_add = self.log_beta.exp().pow(-1) + JITTER
         nll = F.nlml(x_train, y_train, w, amp, diag_add=diag_add, diag_vec=y_var, clamp=clamp, variant=F.FFGP_LL_V1,
-                     pi_const=PI)
+                     pi_const=PI, **F._slot_args())
         return -nll

@@ -82,10 +82,13 @@ int ffgp_create(int device, ffgp_handle** out) {
     h->lookahead = 1;
     h->small_tile_threshold = 640;
     h->la_split = 1;
+    h->aux_prio = 1;
   }
   FFGP_HIP(hipMalloc(&h->d_info, 16 * sizeof(int)));
+  FFGP_HIP(hipMemset(h->d_info, 0, 16 * sizeof(int)));
   FFGP_HIP(hipMalloc(&h->d_scal, SCAL_DOUBLES * sizeof(double)));
   FFGP_HIP(hipHostMalloc(&h->h_info, 16 * sizeof(int)));
+  memset(h->h_info, 0, 16 * sizeof(int));
   FFGP_HIP(hipHostMalloc(&h->h_scal, 64 * sizeof(double)));
   for (int i = 0; i <= FFGP_MAX_STAGES; ++i) FFGP_HIP(hipEventCreate(&h->ev[i]));
   FFGP_HIP(hipEventCreate(&h->syrk_ev[0]));
@@ -132,6 +135,8 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->nb_outer = v;
   } else if (!strcmp(key, "naive")) {
     h->use_naive = (int)value;
+  } else if (!strcmp(key, "aux_prio")) {
+    h->aux_prio = (int)value;
   } else if (!strcmp(key, "gemm_tile")) {
     const int v = (int)value;
     if (v != 0 && v != 64 && v != 128) return FFGP_ERR_ARG;
@@ -231,7 +236,36 @@ int ffgp_potri(ffgp_handle* h, double* L, int n, int ldl) {
 // ------------------------------------------------------------------------------------------------------------
 // fused NLML (+ gradients)
 // ------------------------------------------------------------------------------------------------------------
+static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll_dev, const ffgp_grads* g);
+
+// info[1] is sticky: the first failing pivot of any fused call enqueued since the last ffgp_wait
+__global__ void ffgp_sticky_info_kernel(int* info) {
+  if (info[1] == 0 && info[0] != 0) info[1] = info[0];
+}
+
+int ffgp_wait(ffgp_handle* h) {
+  if (!h) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  FFGP_HIP(hipStreamSynchronize(h->stream));
+  stage_collect(h);
+  const int rc = h->h_info[1] ? h->h_info[1] : h->h_info[0];
+  if (h->h_info[1]) {
+    h->h_info[1] = 0;
+    FFGP_HIP(hipMemsetAsync(h->d_info + 1, 0, sizeof(int), h->stream));
+  }
+  return rc;
+}
+
+int ffgp_nlml_fused_async(ffgp_handle* h, const ffgp_problem* p, double* nll_dev, const ffgp_grads* g) {
+  return nlml_fused_enqueue(h, p, nll_dev, g);
+}
+
 int ffgp_nlml_fused(ffgp_handle* h, const ffgp_problem* p, double* nll_dev, const ffgp_grads* g) {
+  FFGP_CHECK(nlml_fused_enqueue(h, p, nll_dev, g));
+  return ffgp_wait(h);
+}
+
+static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll_dev, const ffgp_grads* g) {
   if (!h || !p || !nll_dev) return FFGP_ERR_ARG;
   if (p->n <= 0 || p->D <= 0 || p->d <= 0 || !p->X_dev || !p->Y_dev || !p->w_dev || !p->amp_dev) return FFGP_ERR_ARG;
   if (p->ll_variant != FFGP_LL_V1 && p->ll_variant != FFGP_LL_V2) return FFGP_ERR_ARG;
@@ -321,10 +355,9 @@ int ffgp_nlml_fused(ffgp_handle* h, const ffgp_problem* p, double* nll_dev, cons
     if (g->g_Y_dev) FFGP_CHECK(ffgp_transpose(h, gYt, d, n, (int)ld, g->g_Y_dev, d, 1.0));
     stage_mark(h, 6);
   }
-  FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  FFGP_HIP(hipStreamSynchronize(h->stream));
-  stage_collect(h);
-  return h->h_info[0];
+  hipLaunchKernelGGL(ffgp_sticky_info_kernel, dim3(1), dim3(1), 0, h->stream, h->d_info);
+  FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  return FFGP_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -60,6 +60,7 @@ struct ffgp_handle {
   hipStream_t own;      // the handle's own stream
   hipStream_t aux;      // high-priority side stream for the look-ahead panel factorisation
   hipEvent_t la_ev[6];  // look-ahead hand-off events
+  int aux_prio;         // 1 = look-ahead chain kernels run at raised wave priority
   int force_ts;         // 0 = automatic GEMM tile shape, 64 / 128 = forced (benchmarks, tests)
   int small_tile_threshold;  // launches with fewer 128-tiles than this use the 64-tile
   int diag_dbg;         // timing-only ablation mask of potrf_diag128 (0 in production)

@@ -353,7 +353,7 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   a.m = m; a.n = n; a.k = k;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.alpha = alpha; a.beta = beta;
-  a.prio = (h->stream == h->aux) ? 1 : 0;
+  a.prio = (h->stream == h->aux && h->aux_prio) ? 1 : 0;
   a.batch = batch > 1 ? batch : 1;
   a.sA = sA; a.sB = sB; a.sC = sC;
   if ((sA & 1) || (sB & 1)) a.avec = a.bvec = 0;  // odd strides break the 16-byte alignment of later batch members

@@ -175,14 +175,14 @@ __device__ __forceinline__ void inv_merge_level(double* S, int wave, int lane) {
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ffgp_potrf_diag128(double* __restrict__ A, int lda, int nb,
                                                           double* __restrict__ Dinv, int* info, int row_base,
-                                                          int do_factor, int dbg) {
+                                                          int do_factor, int dbg, int prio) {
   // dbg: timing-only ablation mask (results are wrong when non-zero): 1 skip (b), 2 skip (c), 4 skip (a),
   //      8 skip phase 3, 16 skip phase 4, 32 skip phase 5, 64 skip phase 2, 128 skip phase 0
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* S = lds;                      // 36 lower blocks [16][17]
   double* rd = lds + NBLK_LOWER * BLKSZ;  // [128] reciprocals of the diagonal of L
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win issue arbitration against co-resident GEMM waves
+  if (prio) __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win issue arbitration against co-resident GEMM waves
 
   // ---- phase 0: load the lower blocks; diagonal blocks are completed symmetrically (mirror of the lower part),
   //      rows/cols beyond nb are identity
@@ -430,7 +430,7 @@ static int launch_diag(ffgp_handle* h, double* Ablk, int lda, int nb, double* Di
     g_diag_attr_set = true;
   }
   hipLaunchKernelGGL(ffgp_potrf_diag128, dim3(1), dim3(256), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk,
-                     h->d_info, row_base, do_factor, h->diag_dbg);
+                     h->d_info, row_base, do_factor, h->diag_dbg, h->aux_prio);
   return FFGP_OK;
 }
 

@@ -82,9 +82,10 @@ class _NLML(torch.autograd.Function):
     Gradients (closed form, computed by the same fused call): Y, w, amp, diag_add, diag_vec."""
 
     @staticmethod
-    def forward(ctx, X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, variant, pi_const):
+    def forward(ctx, X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, variant, pi_const, slot=0,
+                defer=False):
         dev = _device_of(X, Y, w, amp)
-        h = _lib.handle(dev.index)
+        h = _lib.handle(dev.index, slot)
         _lib.bind_stream(h, dev.index)
         keep = []
         p, (n, D, d) = _problem(dev, X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, variant,
@@ -110,10 +111,14 @@ class _NLML(torch.autograd.Function):
             if needs[4]:
                 grads["diag_vec"] = torch.empty((n,), dtype=torch.float64, device=dev)
                 g.g_diag_vec_dev = _ptr(grads["diag_vec"])
-        rc = check(lib.ffgp_nlml_fused(h, C.byref(p), _ptr(out), C.byref(g) if g is not None else None),
-                   "ffgp_nlml_fused")
-        if rc > 0:
-            _raise_not_pd(rc, "linalg.cholesky")
+        gref = C.byref(g) if g is not None else None
+        if defer:   # enqueue only: the caller collects the status with wait(slot) after launching its other blocks
+            check(lib.ffgp_nlml_fused_async(h, C.byref(p), _ptr(out), gref), "ffgp_nlml_fused_async")
+            _pending.setdefault((dev.index, slot), []).append(keep)
+        else:
+            rc = check(lib.ffgp_nlml_fused(h, C.byref(p), _ptr(out), gref), "ffgp_nlml_fused")
+            if rc > 0:
+                _raise_not_pd(rc, "linalg.cholesky")
         ctx.grads = grads
         ctx.meta = [(t.shape, t.dtype, t.device) if isinstance(t, torch.Tensor) else None
                     for t in (Y, w, amp, diag_add, diag_vec)]
@@ -135,14 +140,96 @@ class _NLML(torch.autograd.Function):
             return t.reshape(shape).to(device=device, dtype=dtype)
 
         return (None, fin("Y", 0), fin("w", 1), fin("amp", 2), fin("diag_add", 3), fin("diag_vec", 4), None, None, None,
-                None, None, None)
+                None, None, None, None, None)
+
+
+_pending = {}   # (device, slot) -> staging tensors of enqueued-but-not-waited calls (kept alive until wait)
 
 
 def nlml(X, Y, w, amp, diag_add=None, diag_vec=None, add_mat=None, add_all=0.0, mean_jitter=0.0, clamp=NEG_INF,
-         variant=FFGP_LL_V1, pi_const=PI_TRUNC):
+         variant=FFGP_LL_V1, pi_const=PI_TRUNC, slot=0, defer=False):
     """Negative log marginal likelihood of one GP block through the fused HIP path (assemble -> blocked Cholesky
-    with Y^T riding as passenger rows -> reductions -> closed-form gradients)."""
-    return _NLML.apply(X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, variant, pi_const)
+    with Y^T riding as passenger rows -> reductions -> closed-form gradients).
+
+    slot / defer: independent blocks can overlap on one GPU -- issue each under its own torch stream with its own
+    `slot` and `defer=True`, then call `wait(slot)` (see `concurrent_blocks`)."""
+    return _NLML.apply(X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, variant, pi_const, slot,
+                       defer)
+
+
+def wait(slot=0, device_index=None):
+    """Collect a deferred call: synchronises that slot's stream, raises LinAlgError if its Sigma was not PD."""
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    h = _lib.handle(device_index, slot)
+    rc = check(lib.ffgp_wait(h), "ffgp_wait")
+    _pending.pop((device_index, slot), None)
+    if rc > 0:
+        _raise_not_pd(rc, "linalg.cholesky")
+
+
+class concurrent_blocks:
+    """Run independent GP blocks concurrently on one GPU:
+
+        with concurrent_blocks(nslots=2) as cb:
+            for f, m in enumerate(models):
+                with cb.slot(f):                                  # own handle, own stream
+                    losses[f] = -m.negative_log_likelihood(x[f], y[f])
+        # on exit every slot has been waited for (LinAlgError raised if any block failed)
+
+    The likelihood modules pick the active slot up from this context."""
+    active = None
+
+    def __init__(self, nslots=2, device_index=None):
+        self.nslots = nslots
+        self.device_index = torch.cuda.current_device() if device_index is None else device_index
+        self.streams = [torch.cuda.Stream(self.device_index) for _ in range(nslots)]
+        self.used = set()
+        self.cur = None
+
+    def __enter__(self):
+        concurrent_blocks.active = self
+        self.origin = torch.cuda.current_stream(self.device_index)
+        for s in self.streams:
+            s.wait_stream(self.origin)
+        return self
+
+    def slot(self, i):
+        cb = self
+
+        class _Slot:
+            def __enter__(self_inner):
+                cb.cur = 1 + (i % cb.nslots)          # slot 0 stays the synchronous default handle
+                cb.used.add(cb.cur)
+                self_inner.ctx = torch.cuda.stream(cb.streams[cb.cur - 1])
+                self_inner.ctx.__enter__()
+
+            def __exit__(self_inner, *exc):
+                self_inner.ctx.__exit__(*exc)
+                cb.cur = None
+        return _Slot()
+
+    def __exit__(self, *exc):
+        concurrent_blocks.active = None
+        err = None
+        for sl in sorted(self.used):
+            try:
+                with torch.cuda.stream(self.streams[sl - 1]):
+                    wait(sl, self.device_index)
+            except torch.linalg.LinAlgError as e:   # keep draining the other slots
+                err = e
+        for s in self.streams:
+            self.origin.wait_stream(s)
+        if err is not None and exc[0] is None:
+            raise err
+        return False
+
+
+def _slot_args():
+    cb = concurrent_blocks.active
+    if cb is not None and cb.cur is not None:
+        return dict(slot=cb.cur, defer=True)
+    return dict(slot=0, defer=False)
 
 
 @torch.no_grad()

@@ -41,6 +41,6 @@ class GP_basic(nn.Module):
         y_train, y_var = _split(y_train)
         w, amp, clamp = self.kernel.effective()
         nll = F.nlml(x_train, y_train, w, amp, diag_add=self.noise_variance.pow(2), add_mat=y_var, clamp=clamp,
-                     variant=F.FFGP_LL_V2, pi_const=math.pi)
+                     variant=F.FFGP_LL_V2, pi_const=math.pi, **F._slot_args())
         ll = -nll
         return ll.reshape(1, 1) if y_train.shape[1] == 1 else ll

@@ -55,5 +55,5 @@ def negative_log_likelihood(kernel, log_beta, x_train, y_train):
     """Sigma = K + exp(-log_beta) I + 1e-6 mean(K) I ; returns +LL with pi = 3.1415 (:120-136)."""
     w, amp, clamp = kernel.effective()
     nll = F.nlml(x_train, y_train, w, amp, diag_add=log_beta.exp().pow(-1), mean_jitter=JITTER, clamp=clamp,
-                 variant=F.FFGP_LL_V1, pi_const=PI)
+                 variant=F.FFGP_LL_V1, pi_const=PI, **F._slot_args())
     return -nll

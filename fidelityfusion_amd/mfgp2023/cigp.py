@@ -124,4 +124,4 @@ class CIGP(torch.nn.Module):
         w, amp, clamp = self.kernel.effective()
         diag_add = self.noise_box.get().pow(-1).double() + JITTER
         return F.nlml(_flat(x), y, w, amp, diag_add=diag_add, add_all=float(y_var), clamp=clamp, variant=F.FFGP_LL_V1,
-                      pi_const=PI)
+                      pi_const=PI, **F._slot_args())

@@ -162,6 +162,14 @@ int ffgp_gemm(ffgp_handle* h, int opa, int opb, int lower_tiles, int tri, const 
    CIGP.compute_loss (MFGP_ver2023May/base_gp/cigp.py:99-136).  Returns 0, or the failing pivot index.       */
 int ffgp_nlml_fused(ffgp_handle* h, const ffgp_problem* p, double* nll_dev, const ffgp_grads* g);
 
+/* Same, enqueue only: returns as soon as the work is on the handle's stream (nll/gradients are valid after
+   ffgp_wait).  With one handle + stream per block, independent GP blocks (the fidelities of one model, the seeds
+   of an experiment sweep) overlap on one GPU: one block's latency-bound factorisation tail runs under another
+   block's trailing updates.                                                                                  */
+int ffgp_nlml_fused_async(ffgp_handle* h, const ffgp_problem* p, double* nll_dev, const ffgp_grads* g);
+/* Synchronise the handle's stream; returns the status of the last enqueued fused call (0 / failing pivot). */
+int ffgp_wait(ffgp_handle* h);
+
 /* Posterior at Xs[nt, D] for the block p (its ll_variant/pi_const are ignored; Sigma extras are honoured
    as given -- the reference's predict paths drop y_var, so callers pass the problem without it).
    mean_dev[nt, d] = K*^T Sigma^-1 Y;  var per var_mode with var_add_all added to every entry.

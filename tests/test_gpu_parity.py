@@ -259,6 +259,68 @@ def test_cigar_blocks_sum_golden(golden):
     assert abs(sum(lls) - float(g["ll_sum"])) < 1e-9 * abs(float(g["ll_sum"]))
 
 
+def test_concurrent_blocks_match_sequential():
+    """independent blocks issued on separate handles/streams (functional.concurrent_blocks) give the same values
+    and gradients as one-at-a-time evaluation; a non-PD block still raises after the others were drained"""
+    from oracle import gp_oracle as O
+    from fidelityfusion_amd import functional as F
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp
+    blocks = []
+    for f, (n, D, d) in enumerate([(900, 4, 3), (1300, 6, 1), (700, 3, 8), (1100, 5, 2)]):
+        X, Y = O.synthetic_xy(n, D, d, seed=10 + f)
+        blocks.append((T(X), T(Y), D))
+
+    def run(concurrent):
+        models = [cigp(kernel.ARDKernel(D), 0.7).to(DEV) for (_, _, D) in blocks]
+        losses = [None] * len(blocks)
+        if concurrent:
+            with F.concurrent_blocks(nslots=3) as cb:
+                for f, m in enumerate(models):
+                    with cb.slot(f):
+                        losses[f] = -m.negative_log_likelihood(blocks[f][0], blocks[f][1])
+        else:
+            for f, m in enumerate(models):
+                losses[f] = -m.negative_log_likelihood(blocks[f][0], blocks[f][1])
+        torch.stack(losses).sum().backward()
+        return [float(l) for l in losses], [m.kernel.length_scales.grad.clone() for m in models], \
+               [m.log_beta.grad.clone() for m in models]
+
+    l0, g0, b0 = run(False)
+    l1, g1, b1 = run(True)
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 1e-12 * abs(a)
+    for a, b in zip(g0 + b0, g1 + b1):
+        assert rel(b, a.cpu().numpy()) < 1e-12
+    # failure propagation
+    bad = cigp(kernel.ARDKernel(2), 0.0).to(DEV)
+    with torch.no_grad():
+        bad.kernel.signal_variance.fill_(0.0)
+        bad.log_beta.fill_(80.0)          # Sigma = 1e-6 * I + exp(-80) I ... plus a huge negative y_var below
+    X, Y = blocks[0][0][:64, :2], blocks[0][1][:64]
+    yv = -torch.eye(64, device=DEV, dtype=torch.float64)
+    with pytest.raises(torch.linalg.LinAlgError):
+        with F.concurrent_blocks(nslots=2) as cb:
+            with cb.slot(0):
+                bad.negative_log_likelihood(X, [Y, yv])
+            with cb.slot(1):
+                ok = cigp(kernel.ARDKernel(2), 0.7).to(DEV).negative_log_likelihood(X, Y)
+    assert np.isfinite(float(ok))
+    # a failure is sticky even when a later good block reuses the same slot before the wait
+    good = cigp(kernel.ARDKernel(2), 0.7).to(DEV)
+    with pytest.raises(torch.linalg.LinAlgError):
+        with F.concurrent_blocks(nslots=1) as cb:
+            with cb.slot(0):
+                bad.negative_log_likelihood(X, [Y, yv])
+            with cb.slot(0):
+                good.negative_log_likelihood(X, Y)
+    # ... and the slot is clean afterwards
+    with F.concurrent_blocks(nslots=1) as cb:
+        with cb.slot(0):
+            v = good.negative_log_likelihood(X, Y)
+    assert np.isfinite(float(v))
+
+
 # ------------------------------------------------------------------------------------------------ oracle, mid sizes
 @pytest.mark.parametrize("n,D,d", [(1000, 8, 1), (2048, 8, 4), (1537, 16, 64), (640, 3, 130)])
 def test_nlml_and_grads_vs_oracle(n, D, d):

@@ -212,3 +212,71 @@ def layout_bench():
 
 if "layout" in sys.argv[1:]:
     layout_bench()
+
+
+def prio_bench():
+    h = _lib.handle(0)
+    _lib.bind_stream(h, 0)
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(0)
+    n = 16384
+    X = torch.rand((n, 16), generator=g, device=dev, dtype=torch.float64)
+    w = torch.ones(16, device=dev, dtype=torch.float64)
+    amp = torch.ones(1, device=dev, dtype=torch.float64)
+    dadd = torch.full((1,), 0.37, device=dev, dtype=torch.float64)
+    W = torch.empty((n, n), device=dev, dtype=torch.float64)
+    for pr in (1, 0, 1, 0):
+        _lib.set_option("aux_prio", pr, 0)
+
+        def fn():
+            _lib.lib.ffgp_assemble(h, p(X), n, p(X), n, 16, p(w), p(amp), 1e-30, p(dadd), None, 0, None, 0, 0.0, 0.0, p(W), n, 1)
+            assert _lib.lib.ffgp_potrf(h, p(W), n, n) == 0
+        fn()
+        tmin, tmed = timeit(fn, rounds=4)
+        print("n=%d aux_prio=%d: min %.2f ms med %.2f ms" % (n, pr, tmin, tmed))
+    _lib.set_option("aux_prio", 1, 0)
+
+
+if "prio" in sys.argv[1:]:
+    prio_bench()
+
+
+def multiblock_bench():
+    """aggregate throughput of F independent GP blocks on ONE GPU: one at a time vs overlapped on separate slots"""
+    import time
+    from fidelityfusion_amd import functional as F
+    from oracle import gp_oracle as O
+    dev = torch.device("cuda:0")
+    for (n, D, d, nblk) in [(8192, 8, 1, 4), (8192, 8, 1024, 4), (16384, 16, 1, 2), (4096, 8, 1, 8)]:
+        data = []
+        for f in range(nblk):
+            X, Y = O.synthetic_xy(n, D, d, seed=f)
+            data.append((torch.tensor(X, device=dev), torch.tensor(Y, device=dev)))
+        w = torch.ones(D, dtype=torch.float64, device=dev)
+        amp = torch.ones(1, dtype=torch.float64, device=dev)
+        dadd = torch.tensor([np.exp(-1.0) + 1e-6], dtype=torch.float64, device=dev)
+        flops = nblk * (n ** 3 / 3.0 + float(n) * n * d + 2.0 * n * n * D)
+        for nslots in (1, 2, 3, 4):
+            def run():
+                if nslots == 1:
+                    return [F.nlml(x, y, w, amp, diag_add=dadd, clamp=1e-30) for x, y in data]
+                outs = []
+                with F.concurrent_blocks(nslots=nslots) as cb:
+                    for f, (x, y) in enumerate(data):
+                        with cb.slot(f):
+                            outs.append(F.nlml(x, y, w, amp, diag_add=dadd, clamp=1e-30, **F._slot_args()))
+                return outs
+            run()
+            torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                outs = run()
+                torch.cuda.synchronize()
+                best = min(best, time.perf_counter() - t0)
+            print("N=%d d=%d blocks=%d slots=%d: %.2f ms total, %.1f TF/s aggregate, nll0=%.6f" % (
+                n, d, nblk, nslots, best * 1e3, flops / best / 1e12, float(outs[0])))
+
+
+if "multiblock" in sys.argv[1:]:
+    multiblock_bench()
