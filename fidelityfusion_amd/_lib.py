@@ -13,6 +13,7 @@ _SO = os.path.join(_HERE, "libffgp.so")
 
 FFGP_LL_V1, FFGP_LL_V2 = 1, 2
 FFGP_VAR_FULL, FFGP_VAR_DIAG = 0, 1
+FFGP_KFUN_SE, FFGP_KFUN_MATERN12, FFGP_KFUN_MATERN32, FFGP_KFUN_MATERN52 = 0, 1, 2, 3
 PI_TRUNC = 3.1415  # GaussianProcess/cigp_v10.py:15 ; gp_computation_pack.py:17 ; MFGP_ver2023May/base_gp/cigp.py:6
 
 ERRORS = {-1: "FFGP_ERR_ARG", -2: "FFGP_ERR_HIP", -3: "FFGP_ERR_ALLOC", -4: "FFGP_ERR_NODEVICE"}
@@ -29,6 +30,7 @@ class Problem(C.Structure):
         ("add_mat_dev", _dp), ("ld_add", C.c_int),
         ("add_all", C.c_double), ("mean_jitter", C.c_double),
         ("ll_variant", C.c_int), ("pi_const", C.c_double),
+        ("kfun", C.c_int), ("kparam", C.c_double),
     ]
 
 
@@ -45,7 +47,7 @@ EXPORTS = {
     "ffgp_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ffgp_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "ffgp_assemble": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, C.c_double, _dp, _dp,
-                                C.c_long, _dp, C.c_int, C.c_double, C.c_double, _dp, C.c_int, C.c_int]),
+                                C.c_long, _dp, C.c_int, C.c_double, C.c_double, _dp, C.c_int, C.c_int, C.c_int, C.c_double]),
     "ffgp_potrf": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int]),
     "ffgp_potrf_rows": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, C.c_int]),
     "ffgp_trtri_diag": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int]),

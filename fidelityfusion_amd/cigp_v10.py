@@ -12,6 +12,10 @@ import torch.nn as nn
 
 from . import functional as F
 
+
+def _kfun(k):
+    return k.kfun() if hasattr(k, "kfun") else (0, 1.0)
+
 JITTER = 1e-6
 EPS = 1e-10
 PI = 3.1415
@@ -34,7 +38,7 @@ class cigp(nn.Module):
         w, amp, clamp = self.kernel.effective()
         noise = self.log_beta.exp().pow(-1)
         mean, var = F.predict(x_train, y_train, x_test, w, amp, diag_add=noise + JITTER, clamp=clamp, full_cov=True,
-                              var_add_all=float(noise))
+                              var_add_all=float(noise), kfun=_kfun(self.kernel))
         return mean, var
 
     def negative_log_likelihood(self, x_train, y_train):
@@ -42,5 +46,5 @@ class cigp(nn.Module):
         w, amp, clamp = self.kernel.effective()
         diag_add = self.log_beta.exp().pow(-1) + JITTER
         nll = F.nlml(x_train, y_train, w, amp, diag_add=diag_add, diag_vec=y_var, clamp=clamp, variant=F.FFGP_LL_V1,
-                     pi_const=PI, **F._slot_args())
+                     pi_const=PI, **F._slot_args(), kfun=_kfun(self.kernel))
         return -nll

@@ -6,7 +6,7 @@
 int ffgp_assemble_impl(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const double* w,
                        const double* amp, double clamp_min, const double* diag_add, const double* diag_vec,
                        long diag_stride, const double* add_mat, int ld_add, double add_all, double mean_jitter, double* K,
-                       int ldk, int lower_only);
+                       int ldk, int lower_only, int kfun, double kparam);
 int ffgp_transpose(ffgp_handle* h, const double* src, int rows, int cols, int ld_src, double* dst, int ld_dst, double scale);
 int ffgp_trtri_impl(ffgp_handle* h, const double* L, int n, int ldl, double* X, int ldx, double* T);
 int ffgp_lauum_impl(ffgp_handle* h, const double* X, int n, int ldx, double* S, int lds_);
@@ -14,7 +14,7 @@ int ffgp_nll_reduce_impl(ffgp_handle* h, int variant, const double* L, int n, in
                          int ldm, int d, double pi_const, double* out_dev);
 int ffgp_grad_impl(ffgp_handle* h, const double* X, int n, int D, const double* w, const double* amp, double clamp,
                    const double* G, int ldg, double mean_jitter, double* g_w, double* g_amp, double* g_diag_add,
-                   double* g_diag_vec, double* partial_ws);
+                   double* g_diag_vec, double* partial_ws, int kfun, double kparam);
 size_t ffgp_grad_partial_doubles(int n, int D);
 
 #define SCAL_DOUBLES 2048
@@ -158,11 +158,12 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
 int ffgp_assemble(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const double* w,
                   const double* amp, double clamp_min, const double* diag_add, const double* diag_vec, long diag_stride,
                   const double* add_mat, int ld_add, double add_all, double mean_jitter, double* K, int ldk,
-                  int lower_only) {
+                  int lower_only, int kfun, double kparam) {
   if (!h) return FFGP_ERR_ARG;
+  if (kfun < FFGP_KFUN_SE || kfun > FFGP_KFUN_MATERN52) return FFGP_ERR_ARG;
   FFGP_HIP(hipSetDevice(h->device));
   return ffgp_assemble_impl(h, X1, n1, X2, n2, D, w, amp, clamp_min, diag_add, diag_vec, diag_stride, add_mat, ld_add,
-                            add_all, mean_jitter, K, ldk, lower_only);
+                            add_all, mean_jitter, K, ldk, lower_only, kfun, kparam);
 }
 
 int ffgp_potrf(ffgp_handle* h, double* A, int n, int lda) {
@@ -269,6 +270,7 @@ static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll
   if (!h || !p || !nll_dev) return FFGP_ERR_ARG;
   if (p->n <= 0 || p->D <= 0 || p->d <= 0 || !p->X_dev || !p->Y_dev || !p->w_dev || !p->amp_dev) return FFGP_ERR_ARG;
   if (p->ll_variant != FFGP_LL_V1 && p->ll_variant != FFGP_LL_V2) return FFGP_ERR_ARG;
+  if (p->kfun < FFGP_KFUN_SE || p->kfun > FFGP_KFUN_MATERN52) return FFGP_ERR_ARG;
   FFGP_HIP(hipSetDevice(h->device));
   const int n = p->n, D = p->D, d = p->d;
   const bool want_grad = g && (g->g_w_dev || g->g_amp_dev || g->g_diag_add_dev || g->g_Y_dev || g->g_diag_vec_dev);
@@ -300,7 +302,7 @@ static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll
   stage_mark(h, 0);
   FFGP_CHECK(ffgp_assemble_impl(h, p->X_dev, n, p->X_dev, n, D, p->w_dev, p->amp_dev, p->clamp_min, p->diag_add_dev,
                                 p->diag_vec_dev, p->diag_stride, p->add_mat_dev, p->ld_add, p->add_all, p->mean_jitter,
-                                W0, (int)ld, 1));
+                                W0, (int)ld, 1, p->kfun, p->kparam));
   FFGP_CHECK(ffgp_transpose(h, p->Y_dev, n, d, d, Gt, (int)ld, 1.0));
   stage_mark(h, 1);
   FFGP_CHECK(ffgp_potrf_impl(h, W0, n, n + d, (int)ld, 0));
@@ -351,7 +353,7 @@ static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll
       gYt = Bt;
     }
     FFGP_CHECK(ffgp_grad_impl(h, p->X_dev, n, D, p->w_dev, p->amp_dev, p->clamp_min, S, (int)ld, p->mean_jitter, g->g_w_dev,
-                              g->g_amp_dev, g->g_diag_add_dev, g->g_diag_vec_dev, P));
+                              g->g_amp_dev, g->g_diag_add_dev, g->g_diag_vec_dev, P, p->kfun, p->kparam));
     if (g->g_Y_dev) FFGP_CHECK(ffgp_transpose(h, gYt, d, n, (int)ld, g->g_Y_dev, d, 1.0));
     stage_mark(h, 6);
   }
@@ -365,7 +367,7 @@ static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ffgp_var_diag_kernel(const double* __restrict__ Vt, int nt, int n, int ld,
                                                             const double* __restrict__ amp, double clamp, double add,
-                                                            double* __restrict__ var) {
+                                                            double* __restrict__ var, int kfun, double rinv) {
   // one wave per test point: var[t] = k(x*,x*) - sum_i Vt[t][i]^2 + add
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= nt) return;
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(256) void ffgp_var_diag_kernel(const double* __rest
     s = __builtin_fma(v, v, s);
   }
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-  if (lane == 0) var[t] = amp[0] * exp(-0.5 * fmax(0.0, clamp)) - s + add;
+  if (lane == 0) var[t] = amp[0] * ffgp_kfun_val(kfun, rinv, fmax(0.0, clamp)) - s + add;
 }
 
 int ffgp_predict(ffgp_handle* h, const ffgp_problem* p, const double* Xs, int nt, int var_mode, double var_add_all,
@@ -395,10 +397,10 @@ int ffgp_predict(ffgp_handle* h, const ffgp_problem* p, const double* Xs, int nt
   stage_mark(h, 0);
   FFGP_CHECK(ffgp_assemble_impl(h, p->X_dev, n, p->X_dev, n, D, p->w_dev, p->amp_dev, p->clamp_min, p->diag_add_dev,
                                 p->diag_vec_dev, p->diag_stride, p->add_mat_dev, p->ld_add, p->add_all, p->mean_jitter,
-                                W0, (int)ld, 1));
+                                W0, (int)ld, 1, p->kfun, p->kparam));
   FFGP_CHECK(ffgp_transpose(h, p->Y_dev, n, d, d, Gt, (int)ld, 1.0));
   FFGP_CHECK(ffgp_assemble_impl(h, Xs, nt, p->X_dev, n, D, p->w_dev, p->amp_dev, p->clamp_min, nullptr, nullptr, 0, nullptr, 0,
-                                0.0, 0.0, Vt, (int)ld, 0));
+                                0.0, 0.0, Vt, (int)ld, 0, p->kfun, p->kparam));
   stage_mark(h, 1);
   FFGP_CHECK(ffgp_potrf_impl(h, W0, n, n + d + nt, (int)ld, 0));
   stage_mark(h, 2);
@@ -408,12 +410,12 @@ int ffgp_predict(ffgp_handle* h, const ffgp_problem* p, const double* Xs, int nt
     if (var_mode == FFGP_VAR_FULL) {
       if (ldv < nt) return FFGP_ERR_ARG;
       FFGP_CHECK(ffgp_assemble_impl(h, Xs, nt, Xs, nt, D, p->w_dev, p->amp_dev, p->clamp_min, nullptr, nullptr, 0, nullptr, 0,
-                                    var_add_all, 0.0, var_dev, ldv, 0));
+                                    var_add_all, 0.0, var_dev, ldv, 0, p->kfun, p->kparam));
       FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, Vt, (int)ld, Vt, (int)ld, var_dev, ldv, nt, nt, n, -1.0,
                                   1.0));
     } else {
       hipLaunchKernelGGL(ffgp_var_diag_kernel, dim3((nt + 3) / 4), dim3(256), 0, h->stream, Vt, nt, n, (int)ld, p->amp_dev,
-                         p->clamp_min, var_add_all, var_dev);
+                         p->clamp_min, var_add_all, var_dev, p->kfun, (p->kparam != 0.0) ? 1.0 / p->kparam : 1.0);
     }
   }
   stage_mark(h, 3);

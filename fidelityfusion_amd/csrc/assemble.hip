@@ -22,6 +22,7 @@ struct AsmArgs {
   double* K; int ldk; int lower_only; int symmetric;
   double* ksum;   // nullable: accumulates sum(K) over the full n1 x n2 matrix
   int tiles_n;
+  int kfun; double rinv;   // radial profile and 1/rho
 };
 
 __global__ __launch_bounds__(256) void ffgp_assemble_kernel(AsmArgs a) {
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void ffgp_assemble_kernel(AsmArgs a) {
       const int col = c0 + tx + 16 * j;
       if (row < a.n1 && col < a.n2) {
         const double s = fmax(sq[i][j], a.clamp);
-        double k = amp * exp(-0.5 * s);
+        double k = amp * ffgp_kfun_val(a.kfun, a.rinv, s);
         tsum += k;
         if (a.symmetric) {
           if (row == col) {
@@ -149,7 +150,7 @@ int ffgp_transpose(ffgp_handle* h, const double* src, int rows, int cols, int ld
 int ffgp_assemble_impl(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const double* w,
                        const double* amp, double clamp_min, const double* diag_add, const double* diag_vec,
                        long diag_stride, const double* add_mat, int ld_add, double add_all, double mean_jitter, double* K,
-                       int ldk, int lower_only) {
+                       int ldk, int lower_only, int kfun, double kparam) {
   if (n1 <= 0 || n2 <= 0) return FFGP_OK;
   if (!X1 || !X2 || !w || !amp || !K || D <= 0 || ldk < n2) return FFGP_ERR_ARG;
   const bool symmetric = (X1 == X2 && n1 == n2);
@@ -163,6 +164,8 @@ int ffgp_assemble_impl(ffgp_handle* h, const double* X1, int n1, const double* X
   a.add_mat = add_mat; a.ld_add = ld_add; a.add_all = add_all;
   a.K = K; a.ldk = ldk; a.lower_only = lower_only ? 1 : 0; a.symmetric = symmetric ? 1 : 0;
   a.ksum = nullptr;
+  a.kfun = kfun;
+  a.rinv = (kparam != 0.0) ? 1.0 / kparam : 1.0;
   const int tm = (n1 + AT - 1) / AT;
   a.tiles_n = (n2 + AT - 1) / AT;
   const int tiles = lower_only ? tm * (tm + 1) / 2 : tm * a.tiles_n;

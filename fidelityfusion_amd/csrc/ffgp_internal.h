@@ -32,6 +32,29 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 
 static inline int ffgp_round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// radial profiles (include/ffgp.h FFGP_KFUN_*): value phi(s) and  -2 * dphi/ds  (the factor that turns G o K' into the
+// W matrix of the length-scale gradient; for the squared exponential it equals phi itself)
+__device__ __forceinline__ double ffgp_kfun_val(int kind, double rinv, double s) {
+  if (kind == FFGP_KFUN_SE) return exp(-0.5 * s);
+  if (kind == FFGP_KFUN_MATERN12) return exp(-sqrt(s) * rinv);
+  if (kind == FFGP_KFUN_MATERN32) {
+    const double a = sqrt(3.0 * s) * rinv;
+    return (1.0 + a) * exp(-a);
+  }
+  const double a = sqrt(5.0 * s) * rinv;
+  return (1.0 + a + (5.0 / 3.0) * s * rinv * rinv) * exp(-a);
+}
+__device__ __forceinline__ double ffgp_kfun_m2d(int kind, double rinv, double s) {
+  if (kind == FFGP_KFUN_SE) return exp(-0.5 * s);
+  if (kind == FFGP_KFUN_MATERN12) {
+    const double r = sqrt(s);
+    return rinv / r * exp(-r * rinv);
+  }
+  if (kind == FFGP_KFUN_MATERN32) return 3.0 * rinv * rinv * exp(-sqrt(3.0 * s) * rinv);
+  const double a = sqrt(5.0 * s) * rinv;
+  return (5.0 / 3.0) * rinv * rinv * (1.0 + a) * exp(-a);
+}
+
 // GEMM operand layouts.  "K-major": element (row, k) at P[row*ld + k]; "MN-major": at P[k*ld + row].
 enum { OP_KMAJOR = 0, OP_MNMAJOR = 1 };
 // tile scheduling modes: full rectangle / lower-triangular tiles of a symmetric update

@@ -20,6 +20,7 @@ struct GradArgs {
   const double* trG;      // device scalar (needed for the mean-jitter chain), may be null when coef == 0
   double mj_coef;         // mean_jitter / n^2
   double* partial;        // [blocks][D+1]: per-block partial sums (deterministic two-stage reduction)
+  int kfun; double rinv;  // radial profile and 1/rho
 };
 
 __global__ __launch_bounds__(256) void ffgp_grad_kernel(GradArgs a) {
@@ -82,10 +83,11 @@ __global__ __launch_bounds__(256) void ffgp_grad_kernel(GradArgs a) {
       double wv = 0.0;
       if (row < a.n && col <= row) {
         const double g = a.G[(size_t)row * a.ldg + col] + geff_add;
-        const double e = exp(-0.5 * fmax(sq[i][j], a.clamp));
+        const double sc = fmax(sq[i][j], a.clamp);
+        const double e = ffgp_kfun_val(a.kfun, a.rinv, sc);
         const double sym = (col < row) ? 2.0 : 1.0;
         s_amp += sym * g * e;
-        wv = (sq[i][j] >= a.clamp) ? sym * g * amp * e : 0.0;
+        wv = (sq[i][j] >= a.clamp) ? sym * g * amp * ffgp_kfun_m2d(a.kfun, a.rinv, sc) : 0.0;
       }
       Wl[i][j] = wv;
     }
@@ -186,7 +188,7 @@ __global__ void ffgp_copy_scalar(const double* src, double* dst) { dst[0] = src[
 
 int ffgp_grad_impl(ffgp_handle* h, const double* X, int n, int D, const double* w, const double* amp, double clamp,
                    const double* G, int ldg, double mean_jitter, double* g_w, double* g_amp, double* g_diag_add,
-                   double* g_diag_vec, double* partial_ws) {
+                   double* g_diag_vec, double* partial_ws, int kfun, double kparam) {
   double* trG = h->d_scal + 4;
   hipLaunchKernelGGL(ffgp_trace_kernel, dim3(1), dim3(1024), 0, h->stream, G, ldg, n, trG, g_diag_vec);
   if (g_diag_add) hipLaunchKernelGGL(ffgp_copy_scalar, dim3(1), dim3(1), 0, h->stream, trG, g_diag_add);
@@ -198,6 +200,8 @@ int ffgp_grad_impl(ffgp_handle* h, const double* X, int n, int D, const double* 
     a.G = G; a.ldg = ldg; a.trG = trG;
     a.mj_coef = (mean_jitter != 0.0) ? mean_jitter / ((double)n * (double)n) : 0.0;
     a.partial = partial_ws;
+    a.kfun = kfun;
+    a.rinv = (kparam != 0.0) ? 1.0 / kparam : 1.0;
     hipLaunchKernelGGL(ffgp_grad_kernel, dim3(blocks), dim3(256), 0, h->stream, a);
     hipLaunchKernelGGL(ffgp_grad_finish, dim3(D + 1), dim3(256), 0, h->stream, partial_ws, blocks, D, w, g_w, g_amp);
   }

@@ -40,7 +40,8 @@ def _raise_not_pd(rc, what):
         "(the leading minor of order %d is not positive-definite)." % (what, rc))
 
 
-def _problem(dev, X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, variant, pi_const, keep):
+def _problem(dev, X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, variant, pi_const, keep,
+             kfun=(0, 1.0)):
     Xd, Yd = _dev(X, dev), _dev(Y, dev)
     n, D = Xd.shape
     d = Yd.shape[1]
@@ -74,6 +75,7 @@ def _problem(dev, X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitte
     p.mean_jitter = float(mean_jitter)
     p.ll_variant = variant
     p.pi_const = pi_const
+    p.kfun, p.kparam = int(kfun[0]), float(kfun[1])
     return p, (n, D, d)
 
 
@@ -83,13 +85,13 @@ class _NLML(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, variant, pi_const, slot=0,
-                defer=False):
+                defer=False, kfun=(0, 1.0)):
         dev = _device_of(X, Y, w, amp)
         h = _lib.handle(dev.index, slot)
         _lib.bind_stream(h, dev.index)
         keep = []
         p, (n, D, d) = _problem(dev, X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, variant,
-                                pi_const, keep)
+                                pi_const, keep, kfun)
         needs = [isinstance(t, torch.Tensor) and t.requires_grad for t in (Y, w, amp, diag_add, diag_vec)]
         out = torch.empty((), dtype=torch.float64, device=dev)
         g = None
@@ -140,21 +142,21 @@ class _NLML(torch.autograd.Function):
             return t.reshape(shape).to(device=device, dtype=dtype)
 
         return (None, fin("Y", 0), fin("w", 1), fin("amp", 2), fin("diag_add", 3), fin("diag_vec", 4), None, None, None,
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
 _pending = {}   # (device, slot) -> staging tensors of enqueued-but-not-waited calls (kept alive until wait)
 
 
 def nlml(X, Y, w, amp, diag_add=None, diag_vec=None, add_mat=None, add_all=0.0, mean_jitter=0.0, clamp=NEG_INF,
-         variant=FFGP_LL_V1, pi_const=PI_TRUNC, slot=0, defer=False):
+         variant=FFGP_LL_V1, pi_const=PI_TRUNC, slot=0, defer=False, kfun=(0, 1.0)):
     """Negative log marginal likelihood of one GP block through the fused HIP path (assemble -> blocked Cholesky
     with Y^T riding as passenger rows -> reductions -> closed-form gradients).
 
     slot / defer: independent blocks can overlap on one GPU -- issue each under its own torch stream with its own
     `slot` and `defer=True`, then call `wait(slot)` (see `concurrent_blocks`)."""
     return _NLML.apply(X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, variant, pi_const, slot,
-                       defer)
+                       defer, kfun)
 
 
 def wait(slot=0, device_index=None):
@@ -234,14 +236,14 @@ def _slot_args():
 
 @torch.no_grad()
 def predict(X, Y, Xs, w, amp, diag_add=None, diag_vec=None, add_mat=None, add_all=0.0, mean_jitter=0.0, clamp=NEG_INF,
-            full_cov=True, var_add_all=0.0):
+            full_cov=True, var_add_all=0.0, kfun=(0, 1.0)):
     """Posterior mean [Nt, d] and covariance [Nt, Nt] (or variance [Nt]) at Xs."""
     dev = _device_of(X, Y, Xs, w, amp)
     h = _lib.handle(dev.index)
     _lib.bind_stream(h, dev.index)
     keep = []
     p, (n, D, d) = _problem(dev, X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, FFGP_LL_V1,
-                            PI_TRUNC, keep)
+                            PI_TRUNC, keep, kfun)
     Xsd = _dev(Xs, dev)
     nt = Xsd.shape[0]
     mean = torch.empty((nt, d), dtype=torch.float64, device=dev)
@@ -255,7 +257,7 @@ def predict(X, Y, Xs, w, amp, diag_add=None, diag_vec=None, add_mat=None, add_al
 
 
 @torch.no_grad()
-def kernel_matrix(x1, x2, w, amp, clamp=NEG_INF):
+def kernel_matrix(x1, x2, w, amp, clamp=NEG_INF, kfun=(0, 1.0)):
     """K(x1, x2) [n1, n2] on the device (no Sigma extras)."""
     dev = _device_of(x1, x2, w, amp)
     h = _lib.handle(dev.index)
@@ -270,7 +272,7 @@ def kernel_matrix(x1, x2, w, amp, clamp=NEG_INF):
     ad = _dev(amp.reshape(-1)[:1], dev)
     K = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float64, device=dev)
     check(lib.ffgp_assemble(h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], D, _ptr(wd), _ptr(ad), clamp, None, None, 0, None,
-                            0, 0.0, 0.0, _ptr(K), b.shape[0], 0), "ffgp_assemble")
+                            0, 0.0, 0.0, _ptr(K), b.shape[0], 0, int(kfun[0]), float(kfun[1])), "ffgp_assemble")
     odt = x1.dtype if x1.dtype.is_floating_point else torch.float64
     return K.to(device=x1.device, dtype=odt)
 

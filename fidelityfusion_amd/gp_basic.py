@@ -10,6 +10,10 @@ import torch
 import torch.nn as nn
 
 from . import functional as F
+
+
+def _kfun(k):
+    return k.kfun() if hasattr(k, "kfun") else (0, 1.0)
 from .gp_computation_pack import _check_method
 
 _METHODS_FWD = ("cholesky1", "cholesky3", "direct")
@@ -33,7 +37,7 @@ class GP_basic(nn.Module):
         y_train, y_var = _split(y_train)
         w, amp, clamp = self.kernel.effective()
         mu, var = F.predict(x_train, y_train, x_test, w, amp, diag_add=self.noise_variance.pow(2), add_mat=y_var,
-                            clamp=clamp, full_cov=True, var_add_all=0.0)
+                            clamp=clamp, full_cov=True, var_add_all=0.0, kfun=_kfun(self.kernel))
         return mu.squeeze(), var
 
     def log_likelihood(self, x_train, y_train, Kinv_method="cholesky3"):
@@ -41,6 +45,6 @@ class GP_basic(nn.Module):
         y_train, y_var = _split(y_train)
         w, amp, clamp = self.kernel.effective()
         nll = F.nlml(x_train, y_train, w, amp, diag_add=self.noise_variance.pow(2), add_mat=y_var, clamp=clamp,
-                     variant=F.FFGP_LL_V2, pi_const=math.pi, **F._slot_args())
+                     variant=F.FFGP_LL_V2, pi_const=math.pi, **F._slot_args(), kfun=_kfun(self.kernel))
         ll = -nll
         return ll.reshape(1, 1) if y_train.shape[1] == 1 else ll

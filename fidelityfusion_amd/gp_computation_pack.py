@@ -14,6 +14,10 @@ import torch
 
 from . import functional as F
 
+
+def _kfun(k):
+    return k.kfun() if hasattr(k, "kfun") else (0, 1.0)
+
 EPS = 1e-9
 JITTER = 1e-6
 PI = 3.1415
@@ -55,5 +59,5 @@ def negative_log_likelihood(kernel, log_beta, x_train, y_train):
     """Sigma = K + exp(-log_beta) I + 1e-6 mean(K) I ; returns +LL with pi = 3.1415 (:120-136)."""
     w, amp, clamp = kernel.effective()
     nll = F.nlml(x_train, y_train, w, amp, diag_add=log_beta.exp().pow(-1), mean_jitter=JITTER, clamp=clamp,
-                 variant=F.FFGP_LL_V1, pi_const=PI, **F._slot_args())
+                 variant=F.FFGP_LL_V1, pi_const=PI, **F._slot_args(), kfun=_kfun(kernel))
     return -nll

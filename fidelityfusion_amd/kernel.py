@@ -21,11 +21,15 @@ class _StationaryKernel(nn.Module):
     def effective(self):  # pragma: no cover - interface
         raise NotImplementedError
 
+    def kfun(self):
+        """(radial profile id, profile parameter) -- include/ffgp.h FFGP_KFUN_*; squared exponential by default."""
+        return (0, 1.0)
+
     def forward(self, x1, x2):
         """Covariance matrix [n1, n2].  (Differentiable use goes through the fused likelihood in cigp /
         gp_computation_pack; this standalone call returns a constant tensor.)"""
         w, amp, clamp = self.effective()
-        return F.kernel_matrix(x1, x2, w, amp, clamp)
+        return F.kernel_matrix(x1, x2, w, amp, clamp, self.kfun())
 
 
 class ARDKernel(_StationaryKernel):
@@ -53,3 +57,26 @@ class SquaredExponentialKernel(_StationaryKernel):
 
     def effective(self):
         return torch.exp(-self.length_scale), self.signal_variance.exp().pow(2), F.NEG_INF
+
+
+class MaternKernel(_StationaryKernel):
+    """Matern kernel with independent length scales, nu in {0.5, 1.5, 2.5} and the reference's extra `rho`
+    (GaussianProcess/kernel.py:109-169): K = |signal_variance| * phi_nu(cdist(x1/l, x2/l)^2 ; rho)."""
+
+    _KFUN = {0.5: 1, 1.5: 2, 2.5: 3}
+
+    def __init__(self, input_dim, initial_length_scale=1.0, initial_signal_variance=1.0, nu=2.5, rho=1, eps=EPS):
+        super().__init__()
+        self.length_scales = nn.Parameter(torch.ones(input_dim) * initial_length_scale)
+        self.signal_variance = nn.Parameter(torch.tensor([initial_signal_variance]))
+        self.eps = eps
+        self.nu = nu
+        self.rho = rho
+
+    def effective(self):
+        return 1.0 / (self.length_scales.abs() + self.eps), self.signal_variance.abs(), 1e-30
+
+    def kfun(self):
+        if self.nu not in self._KFUN:   # the reference returns None for any other nu (kernel.py:161-166)
+            raise ValueError("MaternKernel: nu must be 0.5, 1.5 or 2.5")
+        return (self._KFUN[self.nu], float(self.rho))

@@ -54,6 +54,14 @@ enum {
                      Gaussian_log_likelihood 'cholesky3', gp_computation_pack.py:65-80; gp_basic.py:130-143) */
 };
 
+/* radial profile of the stationary kernel, K = amp * phi(s), s = max(||(x - x') o w||^2, clamp_min) */
+enum {
+  FFGP_KFUN_SE = 0,        /* phi = exp(-s/2)                                                 (K1, K2, K3) */
+  FFGP_KFUN_MATERN12 = 1,  /* phi = exp(-sqrt(s)/rho)                       MaternKernel nu = 0.5, GaussianProcess/kernel.py:161-162 */
+  FFGP_KFUN_MATERN32 = 2,  /* phi = (1 + a) exp(-a),          a = sqrt(3s)/rho           nu = 1.5, kernel.py:163-164 */
+  FFGP_KFUN_MATERN52 = 3   /* phi = (1 + a + a^2/3) exp(-a),  a = sqrt(5s)/rho           nu = 2.5, kernel.py:165-166 */
+};
+
 /* prediction outputs */
 enum {
   FFGP_VAR_FULL = 0, /* cov[Nt,Nt] = K** - V^T V + var_add_all              (cigp_v10.py:41-44; gp_computation_pack.py:108-110) */
@@ -79,6 +87,8 @@ typedef struct {
   double mean_jitter;     /* coefficient of mean(K)*I (1e-6 for gp_computation_pack.negative_log_likelihood, else 0) */
   int ll_variant;         /* FFGP_LL_V1 | FFGP_LL_V2 */
   double pi_const;        /* 3.1415 for the V1 call sites, M_PI for V2 */
+  int kfun;               /* FFGP_KFUN_* (0 = squared exponential) */
+  double kparam;          /* rho of the Matern profiles (MaternKernel(rho=...), default 1); unused for SE */
 } ffgp_problem;
 
 /* Gradients of the value returned by ffgp_nlml_fused with respect to the effective quantities.
@@ -109,7 +119,7 @@ const char* ffgp_version(void);
 int ffgp_assemble(ffgp_handle* h, const double* X1_dev, int n1, const double* X2_dev, int n2, int D,
                   const double* w_dev, const double* amp_dev, double clamp_min, const double* diag_add_dev,
                   const double* diag_vec_dev, long diag_stride, const double* add_mat_dev, int ld_add,
-                  double add_all, double mean_jitter, double* K_dev, int ldk, int lower_only);
+                  double add_all, double mean_jitter, double* K_dev, int ldk, int lower_only, int kfun, double kparam);
 
 /* In-place lower Cholesky, A = L L^T (strictly-upper part is not referenced and not written).
    Replaces torch.linalg.cholesky at cigp_v10.py:35,61; gp_computation_pack.py:67,105,128; gp_basic.py:80,131;

@@ -54,6 +54,35 @@ def ard_kernel(x1, x2, length_scales, signal_variance):
     return np.abs(float(np.ravel(signal_variance)[0])) * np.exp(-0.5 * sq)
 
 
+def matern_profile(sq, nu, rho=1.0):
+    """phi_nu(sq; rho) of MaternKernel.forward, GaussianProcess/kernel.py:161-166 (sq = cdist^2, clamped)."""
+    if nu == 0.5:
+        return np.exp(-np.sqrt(sq) / rho)
+    if nu == 1.5:
+        return (1 + np.sqrt(3 * sq) / rho) * np.exp(-np.sqrt(3 * sq) / rho)
+    if nu == 2.5:
+        return (1 + np.sqrt(5 * sq) / rho + 5 / 3 * sq / rho ** 2) * np.exp(-np.sqrt(5 * sq) / rho)
+    raise ValueError("nu")
+
+
+def matern_profile_m2d(sq, nu, rho=1.0):
+    """-2 d(phi_nu)/d(sq): the factor of the length-scale gradient (equals phi for the squared exponential)."""
+    if nu == 0.5:
+        r = np.sqrt(sq)
+        return np.exp(-r / rho) / (rho * r)
+    if nu == 1.5:
+        return 3.0 / rho ** 2 * np.exp(-np.sqrt(3 * sq) / rho)
+    a = np.sqrt(5 * sq) / rho
+    return 5.0 / (3.0 * rho ** 2) * (1 + a) * np.exp(-a)
+
+
+def matern_kernel(x1, x2, length_scales, signal_variance, nu=2.5, rho=1.0):
+    """MaternKernel.forward, GaussianProcess/kernel.py:147-166."""
+    ell = np.abs(np.asarray(length_scales, dtype=np.float64)) + EPS
+    sq = cdist_sq(np.asarray(x1) / ell, np.asarray(x2) / ell)
+    return np.abs(float(np.ravel(signal_variance)[0])) * matern_profile(sq, nu, rho)
+
+
 def sqdist_expanded(x1, x2):
     """||a||^2 + ||b||^2 - 2ab^T, unclamped (kernel.py:271 ; SE_kernel.py:37-41)."""
     x1 = np.asarray(x1, dtype=np.float64)
@@ -210,10 +239,11 @@ def _G_matrix(L, Y, d):
     return 0.5 * (d * Sinv - A @ A.T), A
 
 
-def cigp_ll_and_grads(X, Y, length_scales, signal_variance, log_beta, y_var=None, kind="ard"):
+def cigp_ll_and_grads(X, Y, length_scales, signal_variance, log_beta, y_var=None, kind="ard", nu=None, rho=1.0):
     """cigp.negative_log_likelihood (returns +LL = -nll; cigp_v10.py:50-69) and d(LL)/d{params, Y}.
 
-    kind='ard': K1 with raw length_scales[D]; kind='se': K2 with scalar log length_scale.
+    kind='ard': K1 with raw length_scales[D] (nu = 0.5 | 1.5 | 2.5 switches to MaternKernel's profile);
+    kind='se': K2 with scalar log length_scale.
     """
     X = np.asarray(X, dtype=np.float64)
     Y = np.asarray(Y, dtype=np.float64)
@@ -223,7 +253,8 @@ def cigp_ll_and_grads(X, Y, length_scales, signal_variance, log_beta, y_var=None
         p = np.asarray(length_scales, dtype=np.float64)
         s = float(np.ravel(signal_variance)[0])
         ell = np.abs(p) + EPS
-        E = np.exp(-0.5 * cdist_sq(X / ell, X / ell))
+        sqc = cdist_sq(X / ell, X / ell)
+        E = np.exp(-0.5 * sqc) if nu is None else matern_profile(sqc, nu, rho)
         K = np.abs(s) * E
     else:
         ls = float(np.ravel(length_scales)[0])
@@ -235,8 +266,13 @@ def cigp_ll_and_grads(X, Y, length_scales, signal_variance, log_beta, y_var=None
     G, A = _G_matrix(L, Y, d)
     g = {"log_beta": -(-beta_inv * np.trace(G)), "Y": -A}
     if kind == "ard":
-        W = G * K
+        if nu is None:
+            W = G * K
+        else:  # W = -2 G o dK/d(sq); entries sitting on cdist's clamp carry no gradient (the diagonal)
+            W = np.where(sqc > 1e-30, G * np.abs(s) * matern_profile_m2d(np.maximum(sqc, 1e-30), nu, rho), 0.0)
         g["signal_variance"] = -(np.sign(s) * (G * E).sum())
+        W = W.copy()
+        np.fill_diagonal(W, 0.0)   # (x_i - x_i) = 0 exactly; keeps a huge Matern-1/2 W_ii out of the r_i x_i^2 - x_i W_ii x_i cancellation
         Xs = X
         r = W.sum(1)
         quad = 2.0 * ((r[:, None] * Xs * Xs).sum(0) - (Xs * (W @ Xs)).sum(0))

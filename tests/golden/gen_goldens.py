@@ -325,6 +325,31 @@ def main():
     except Exception as e:  # noqa
         print("train_log_resgp skipped:", repr(e))
 
+
+    # ------------------------------------------------------------------ Matern (SURVEY 8f "next" row 2): K, LL, grads, posterior
+    g2 = torch.Generator().manual_seed(777)   # own stream of random numbers: added after the fixtures above were frozen
+    for nu in (0.5, 1.5, 2.5):
+        n, D, d = 150, 4, 3
+        X, Y = make_xy(g2, n, D, d)
+        Y = Y.clone().requires_grad_(True)
+        k = rk.MaternKernel(D, nu=nu, rho=1.3)
+        with torch.no_grad():
+            k.length_scales.copy_((torch.rand(D, generator=g2) + 0.5) *
+                                  torch.where(torch.rand(D, generator=g2) > 0.3, 1.0, -1.0))
+            k.signal_variance.copy_(torch.tensor([-1.1]))
+        m = RCIGP(k, log_beta=0.9)
+        ll = m.negative_log_likelihood(X, Y)
+        ll.backward()
+        Xs = torch.rand(19, D, generator=g2)
+        x2 = torch.rand(40, D, generator=g2)
+        with torch.no_grad():
+            mean, var = m(X, Y.detach(), Xs)
+            K12 = k(X, x2)
+        save(f"matern_nu{str(nu).replace('.', '')}", X=X, Y=Y, x2=x2, K12=K12, nu=nu, rho=1.3, log_beta=m.log_beta, ll=ll,
+             g_log_beta=m.log_beta.grad, g_Y=Y.grad, length_scales=k.length_scales, g_length_scales=k.length_scales.grad,
+             signal_variance=k.signal_variance, g_signal_variance=k.signal_variance.grad, Xs=Xs, mean=mean, var=var)
+
+
     os.chdir(cwd)
 
 

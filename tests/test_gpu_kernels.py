@@ -277,7 +277,7 @@ def test_assemble_rect(ff, n1, n2, D):
     K = torch.empty((n1, n2), dtype=torch.float64, device="cuda:0")
     x1d, x2d, wd, ad = dev(x1), dev(x2), dev(w), dev(amp)   # keep the device buffers alive across the launch
     rc = _lib.lib.ffgp_assemble(h, ptr(x1d), n1, ptr(x2d), n2, D, ptr(wd), ptr(ad), 1e-30, None, None, 0,
-                                None, 0, 0.0, 0.0, ptr(K), n2, 0)
+                                None, 0, 0.0, 0.0, ptr(K), n2, 0, 0, 1.0)
     assert rc == 0
     torch.cuda.synchronize()
     diff = (x1[:, None, :] - x2[None, :, :]) * w
@@ -297,7 +297,7 @@ def test_assemble_sigma_extras(ff):
     for lower in (0, 1):
         K = torch.full((n, n), 555.0, dtype=torch.float64, device="cuda:0")
         rc = _lib.lib.ffgp_assemble(h, ptr(xd), n, ptr(xd), n, D, ptr(wd), ptr(ad), float("-inf"), ptr(dd),
-                                    ptr(yvd), n + 1, ptr(amd), n, 0.25, 1e-6, ptr(K), n, lower)
+                                    ptr(yvd), n + 1, ptr(amd), n, 0.25, 1e-6, ptr(K), n, lower, 0, 1.0)
         assert rc == 0
         torch.cuda.synchronize()
         diff = (x[:, None, :] - x[None, :, :]) * w

@@ -104,6 +104,38 @@ def test_cigp_golden(golden, tag):
     assert rel(var, g["var"]) < 1e-9
 
 
+@pytest.mark.parametrize("nu", ["05", "15", "25"])
+def test_matern_golden(golden, nu):
+    """SURVEY 8f 'next' row 2: MaternKernel (GaussianProcess/kernel.py:109-169) -- same tiles, different radial profile"""
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp
+    g = golden("matern_nu" + nu)
+    k = kernel.MaternKernel(g["X"].shape[1], nu=float(g["nu"]), rho=float(g["rho"]))
+    with torch.no_grad():
+        k.length_scales.copy_(torch.tensor(g["length_scales"]))
+        k.signal_variance.copy_(torch.tensor(g["signal_variance"]))
+    k = k.to(DEV)
+    # the reference evaluates the distance in expanded form (rounding noise ~1e-16 absolute in s); for nu = 0.5 the
+    # profile exp(-sqrt(s)) turns that into ~1e-8 relative differences between near-coincident points
+    ktol = 1e-7 if nu == "05" else 1e-12
+    assert rel(k(T(g["X"]), T(g["x2"])), g["K12"]) < ktol
+    m = cigp(k, float(g["log_beta"][0])).to(DEV)
+    Y = T(g["Y"], grad=True)
+    ll = m.negative_log_likelihood(T(g["X"]), Y)
+    assert rel(ll, g["ll"]) < (1e-8 if nu == "05" else 1e-11)
+    ll.backward()
+    gt = 1e-6 if nu == "05" else 1e-8
+    assert rel(m.log_beta.grad, g["g_log_beta"]) < gt
+    assert rel(Y.grad, g["g_Y"]) < gt
+    assert rel(k.signal_variance.grad, g["g_signal_variance"]) < gt
+    assert rel(k.length_scales.grad, g["g_length_scales"]) < gt
+    with torch.no_grad():
+        mean, var = m(T(g["X"]), Y.detach(), T(g["Xs"]))
+    assert rel(mean, g["mean"]) < gt and rel(var, g["var"]) < gt
+    with pytest.raises(ValueError):
+        kernel.MaternKernel(3, nu=2.0).kfun()
+
+
 @pytest.mark.parametrize("tag", ["d1", "d5"])
 def test_pack_nll_golden(golden, tag):
     import fidelityfusion_amd.gp_computation_pack as gp_pack
@@ -391,7 +423,7 @@ def test_full_size_properties(n, D):
     W = torch.empty((n + 1, ld), dtype=torch.float64, device=DEV)
     p = lambda t: C.c_void_p(t.data_ptr())
     assert _lib.lib.ffgp_assemble(h, p(Xd), n, p(Xd), n, D, p(w), p(amp), 1e-30, p(dadd), None, 0, None, 0, 0.0, 0.0,
-                                  p(W), ld, 1) == 0
+                                  p(W), ld, 1, 0, 1.0) == 0
     W[n, :] = Yd[:, 0]
     S_rows_idx = [0, 1, n // 3, n // 2 + 17, n - 1]
     S_rows = [W[i, : i + 1].clone() for i in S_rows_idx]

@@ -72,7 +72,7 @@ def main():
 
                 def fn():
                     _lib.lib.ffgp_assemble(h, p(X), n, p(X), n, 8, p(w), p(amp), 1e-30, p(dadd), None, 0, None, 0, 0.0, 0.0,
-                                           p(W), n, 1)
+                                           p(W), n, 1, 0, 1.0)
                     rc = _lib.lib.ffgp_potrf(h, p(W), n, n)
                     assert rc == 0, rc
                 fn()
@@ -100,7 +100,7 @@ def diag_ablation():
     amp = torch.ones(1, device=dev, dtype=torch.float64)
     dadd = torch.full((1,), 0.37, device=dev, dtype=torch.float64)
     W = torch.empty((n, n), device=dev, dtype=torch.float64)
-    _lib.lib.ffgp_assemble(h, p(X), n, p(X), n, 8, p(w), p(amp), 1e-30, p(dadd), None, 0, None, 0, 0.0, 0.0, p(W), n, 1)
+    _lib.lib.ffgp_assemble(h, p(X), n, p(X), n, 8, p(w), p(amp), 1e-30, p(dadd), None, 0, None, 0, 0.0, 0.0, p(W), n, 1, 0, 1.0)
     assert _lib.lib.ffgp_potrf(h, p(W), n, n) == 0
     # 64 sequential launches of the inverse-only entry (phases 0,3,4,5)
     for mask in (0, 8, 16, 32, 128, 8 + 16 + 32 + 128):
@@ -127,7 +127,7 @@ def diag_factor_ablation():
     amp = torch.ones(1, device=dev, dtype=torch.float64)
     dadd = torch.full((1,), 0.37, device=dev, dtype=torch.float64)
     W0 = torch.empty((n, n), device=dev, dtype=torch.float64)
-    _lib.lib.ffgp_assemble(h, p(X), n, p(X), n, 8, p(w), p(amp), 1e-30, p(dadd), None, 0, None, 0, 0.0, 0.0, p(W0), n, 1)
+    _lib.lib.ffgp_assemble(h, p(X), n, p(X), n, 8, p(w), p(amp), 1e-30, p(dadd), None, 0, None, 0, 0.0, 0.0, p(W0), n, 1, 0, 1.0)
     Ws = [W0.clone() for _ in range(50)]
     _lib.set_option("lookahead", 0, 0)
     for mask in (0, 1, 2, 4, 64, 1 + 2 + 4 + 64, 255):
@@ -169,7 +169,7 @@ def potrf_sweep():
 
                     def fn():
                         _lib.lib.ffgp_assemble(h, p(X), n, p(X), n, 16, p(w), p(amp), 1e-30, p(dadd), None, 0, None, 0, 0.0,
-                                               0.0, p(W), n, 1)
+                                               0.0, p(W), n, 1, 0, 1.0)
                         assert _lib.lib.ffgp_potrf(h, p(W), n, n) == 0
                     fn()
                     tmin, tmed = timeit(fn, rounds=3)
@@ -229,7 +229,7 @@ def prio_bench():
         _lib.set_option("aux_prio", pr, 0)
 
         def fn():
-            _lib.lib.ffgp_assemble(h, p(X), n, p(X), n, 16, p(w), p(amp), 1e-30, p(dadd), None, 0, None, 0, 0.0, 0.0, p(W), n, 1)
+            _lib.lib.ffgp_assemble(h, p(X), n, p(X), n, 16, p(w), p(amp), 1e-30, p(dadd), None, 0, None, 0, 0.0, 0.0, p(W), n, 1, 0, 1.0)
             assert _lib.lib.ffgp_potrf(h, p(W), n, n) == 0
         fn()
         tmin, tmed = timeit(fn, rounds=4)
