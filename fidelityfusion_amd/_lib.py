@@ -31,12 +31,13 @@ class Problem(C.Structure):
         ("add_all", C.c_double), ("mean_jitter", C.c_double),
         ("ll_variant", C.c_int), ("pi_const", C.c_double),
         ("kfun", C.c_int), ("kparam", C.c_double),
+        ("cov_dev", _dp), ("ld_cov", C.c_int),
     ]
 
 
 class Grads(C.Structure):
     _fields_ = [("g_w_dev", _dp), ("g_amp_dev", _dp), ("g_diag_add_dev", _dp), ("g_Y_dev", _dp),
-                ("g_diag_vec_dev", _dp)]
+                ("g_diag_vec_dev", _dp), ("g_cov_dev", _dp), ("ld_gcov", C.c_int)]
 
 
 EXPORTS = {
@@ -50,6 +51,8 @@ EXPORTS = {
                                 C.c_long, _dp, C.c_int, C.c_double, C.c_double, _dp, C.c_int, C.c_int, C.c_int, C.c_double]),
     "ffgp_potrf": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int]),
     "ffgp_potrf_rows": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, C.c_int]),
+    "ffgp_kernel_grad": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_double,
+                                   _dp, C.c_int, _dp, _dp]),
     "ffgp_trtri_diag": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int]),
     "ffgp_trsm_lower": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int]),
     "ffgp_trsm_lower_t": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int]),

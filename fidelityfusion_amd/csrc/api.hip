@@ -16,6 +16,29 @@ int ffgp_grad_impl(ffgp_handle* h, const double* X, int n, int D, const double* 
                    const double* G, int ldg, double mean_jitter, double* g_w, double* g_amp, double* g_diag_add,
                    double* g_diag_vec, double* partial_ws, int kfun, double kparam);
 size_t ffgp_grad_partial_doubles(int n, int D);
+int ffgp_kernel_grad_impl(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const double* w,
+                          const double* amp, double clamp, int kfun, double kparam, const double* dK, int ldk, double* g_w,
+                          double* g_amp);
+
+__global__ void ffgp_copy_lower_kernel(const double* __restrict__ src, int lds_, double* __restrict__ dst, int ldd, int n) {
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), r = blockIdx.y * 32 + (threadIdx.x >> 5) * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int rr = r + k;
+    if (rr < n && c <= rr) dst[(size_t)rr * ldd + c] = src[(size_t)rr * lds_ + c];
+  }
+}
+
+// lower triangle -> full symmetric matrix (gradient w.r.t. a caller-built covariance)
+__global__ void ffgp_symmetrize_kernel(const double* __restrict__ Gl, int ldg, double* __restrict__ out, int ldo, int n,
+                                       double scale) {
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), r = blockIdx.y * 32 + (threadIdx.x >> 5) * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int rr = r + k;
+    if (rr < n && c < n) out[(size_t)rr * ldo + c] = scale * ((c <= rr) ? Gl[(size_t)rr * ldg + c] : Gl[(size_t)c * ldg + rr]);
+  }
+}
 
 #define SCAL_DOUBLES 2048
 
@@ -212,6 +235,14 @@ int ffgp_gemm(ffgp_handle* h, int opa, int opb, int lower_tiles, int tri, const 
                           0, A, lda, B, ldb, C, ldc, m, n, k, alpha, beta, tri);
 }
 
+int ffgp_kernel_grad(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const double* w,
+                     const double* amp, double clamp_min, int kfun, double kparam, const double* dK, int ldk, double* g_w,
+                     double* g_amp) {
+  if (!h) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  return ffgp_kernel_grad_impl(h, X1, n1, X2, n2, D, w, amp, clamp_min, kfun, kparam, dK, ldk, g_w, g_amp);
+}
+
 /* (re)build the inverted 128x128 diagonal blocks of a factor (also the diag-kernel timing hook of tools/) */
 int ffgp_trtri_diag(ffgp_handle* h, const double* L, int n, int ldl) {
   if (!h || !L) return FFGP_ERR_ARG;
@@ -268,12 +299,17 @@ int ffgp_nlml_fused(ffgp_handle* h, const ffgp_problem* p, double* nll_dev, cons
 
 static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll_dev, const ffgp_grads* g) {
   if (!h || !p || !nll_dev) return FFGP_ERR_ARG;
-  if (p->n <= 0 || p->D <= 0 || p->d <= 0 || !p->X_dev || !p->Y_dev || !p->w_dev || !p->amp_dev) return FFGP_ERR_ARG;
+  const bool given_cov = (p->cov_dev != nullptr);
+  if (p->n <= 0 || p->d <= 0 || !p->Y_dev) return FFGP_ERR_ARG;
+  if (!given_cov && (p->D <= 0 || !p->X_dev || !p->w_dev || !p->amp_dev)) return FFGP_ERR_ARG;
+  if (given_cov && p->ld_cov < p->n) return FFGP_ERR_ARG;
   if (p->ll_variant != FFGP_LL_V1 && p->ll_variant != FFGP_LL_V2) return FFGP_ERR_ARG;
   if (p->kfun < FFGP_KFUN_SE || p->kfun > FFGP_KFUN_MATERN52) return FFGP_ERR_ARG;
   FFGP_HIP(hipSetDevice(h->device));
-  const int n = p->n, D = p->D, d = p->d;
-  const bool want_grad = g && (g->g_w_dev || g->g_amp_dev || g->g_diag_add_dev || g->g_Y_dev || g->g_diag_vec_dev);
+  const int n = p->n, D = given_cov ? 1 : p->D, d = p->d;
+  const bool want_grad = g && (g->g_w_dev || g->g_amp_dev || g->g_diag_add_dev || g->g_Y_dev || g->g_diag_vec_dev || g->g_cov_dev);
+  if (given_cov && g && (g->g_w_dev || g->g_amp_dev)) return FFGP_ERR_ARG;
+  if (g && g->g_cov_dev && g->ld_gcov < p->n) return FFGP_ERR_ARG;
   const bool v2 = (p->ll_variant == FFGP_LL_V2);
   const size_t ld = ffgp_round_up(n, 16);
   const size_t w0 = (size_t)(n + d) * ld;          // Sigma | Y^T  ->  L | Gamma^T
@@ -300,9 +336,14 @@ static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll
 
   h->n_stages = 0;
   stage_mark(h, 0);
-  FFGP_CHECK(ffgp_assemble_impl(h, p->X_dev, n, p->X_dev, n, D, p->w_dev, p->amp_dev, p->clamp_min, p->diag_add_dev,
-                                p->diag_vec_dev, p->diag_stride, p->add_mat_dev, p->ld_add, p->add_all, p->mean_jitter,
-                                W0, (int)ld, 1, p->kfun, p->kparam));
+  if (given_cov) {
+    hipLaunchKernelGGL(ffgp_copy_lower_kernel, dim3((n + 31) / 32, (n + 31) / 32), dim3(256), 0, h->stream, p->cov_dev, p->ld_cov,
+                       W0, (int)ld, n);
+  } else {
+    FFGP_CHECK(ffgp_assemble_impl(h, p->X_dev, n, p->X_dev, n, D, p->w_dev, p->amp_dev, p->clamp_min, p->diag_add_dev,
+                                  p->diag_vec_dev, p->diag_stride, p->add_mat_dev, p->ld_add, p->add_all, p->mean_jitter,
+                                  W0, (int)ld, 1, p->kfun, p->kparam));
+  }
   FFGP_CHECK(ffgp_transpose(h, p->Y_dev, n, d, d, Gt, (int)ld, 1.0));
   stage_mark(h, 1);
   FFGP_CHECK(ffgp_potrf_impl(h, W0, n, n + d, (int)ld, 0));
@@ -352,8 +393,11 @@ static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll
                                   -0.5, 1.0));
       gYt = Bt;
     }
-    FFGP_CHECK(ffgp_grad_impl(h, p->X_dev, n, D, p->w_dev, p->amp_dev, p->clamp_min, S, (int)ld, p->mean_jitter, g->g_w_dev,
-                              g->g_amp_dev, g->g_diag_add_dev, g->g_diag_vec_dev, P, p->kfun, p->kparam));
+    FFGP_CHECK(ffgp_grad_impl(h, p->X_dev, n, D, p->w_dev, p->amp_dev, p->clamp_min, S, (int)ld, given_cov ? 0.0 : p->mean_jitter,
+                              g->g_w_dev, g->g_amp_dev, g->g_diag_add_dev, g->g_diag_vec_dev, P, p->kfun, p->kparam));
+    if (g->g_cov_dev)
+      hipLaunchKernelGGL(ffgp_symmetrize_kernel, dim3((n + 31) / 32, (n + 31) / 32), dim3(256), 0, h->stream, S, (int)ld,
+                         g->g_cov_dev, g->ld_gcov, n, 1.0);
     if (g->g_Y_dev) FFGP_CHECK(ffgp_transpose(h, gYt, d, n, (int)ld, g->g_Y_dev, d, 1.0));
     stage_mark(h, 6);
   }

@@ -15,6 +15,7 @@
 
 struct GradArgs {
   const double* X; int n; int D;
+  const double* X2; int n2; int rect;   // rect = 1: dense [n, n2] weight matrix G (= dK of a standalone kernel call), no symmetry
   const double* w; const double* amp; double clamp;
   const double* G; int ldg;
   const double* trG;      // device scalar (needed for the mean-jitter chain), may be null when coef == 0
@@ -29,11 +30,21 @@ __global__ __launch_bounds__(256) void ffgp_grad_kernel(GradArgs a) {
   __shared__ double red[4][DC + 1];
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
   const int t = blockIdx.x;
-  int r = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-  while ((r + 1) * (r + 2) / 2 <= t) ++r;
-  while (r * (r + 1) / 2 > t) --r;
-  const int ti = r, tj = t - r * (r + 1) / 2;
+  int ti, tj;
+  if (a.rect) {
+    const int tn = (a.n2 + AT - 1) / AT;
+    ti = t / tn;
+    tj = t % tn;
+  } else {
+    int r = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((r + 1) * (r + 2) / 2 <= t) ++r;
+    while (r * (r + 1) / 2 > t) --r;
+    ti = r;
+    tj = t - r * (r + 1) / 2;
+  }
   const int r0 = ti * AT, c0 = tj * AT;
+  const double* __restrict__ Xc = a.rect ? a.X2 : a.X;   // points indexing the columns
+  const int nc = a.rect ? a.n2 : a.n;
 
   // pass 1: squared distances
   double sq[4][4];
@@ -48,7 +59,7 @@ __global__ __launch_bounds__(256) void ffgp_grad_kernel(GradArgs a) {
       const int row = idx >> 4, dd = idx & 15, gd = d0 + dd;
       const double wk = (gd < a.D) ? a.w[gd] : 0.0;
       x1s[row][dd] = (gd < a.D && r0 + row < a.n) ? a.X[(size_t)(r0 + row) * a.D + gd] * wk : 0.0;
-      x2t[dd][row] = (gd < a.D && c0 + row < a.n) ? a.X[(size_t)(c0 + row) * a.D + gd] * wk : 0.0;
+      x2t[dd][row] = (gd < a.D && c0 + row < nc) ? Xc[(size_t)(c0 + row) * a.D + gd] * wk : 0.0;
     }
     __syncthreads();
 #pragma unroll
@@ -81,11 +92,11 @@ __global__ __launch_bounds__(256) void ffgp_grad_kernel(GradArgs a) {
     for (int j = 0; j < 4; ++j) {
       const int col = c0 + tx + 16 * j;
       double wv = 0.0;
-      if (row < a.n && col <= row) {
+      if (row < a.n && (a.rect ? col < nc : col <= row)) {
         const double g = a.G[(size_t)row * a.ldg + col] + geff_add;
         const double sc = fmax(sq[i][j], a.clamp);
         const double e = ffgp_kfun_val(a.kfun, a.rinv, sc);
-        const double sym = (col < row) ? 2.0 : 1.0;
+        const double sym = (!a.rect && col < row) ? 2.0 : 1.0;
         s_amp += sym * g * e;
         wv = (sq[i][j] >= a.clamp) ? sym * g * amp * ffgp_kfun_m2d(a.kfun, a.rinv, sc) : 0.0;
       }
@@ -101,7 +112,7 @@ __global__ __launch_bounds__(256) void ffgp_grad_kernel(GradArgs a) {
       const int row = idx >> 4, dd = idx & 15, gd = d0 + dd;
       const double wk = (gd < a.D) ? a.w[gd] : 0.0;
       x1s[row][dd] = (gd < a.D && r0 + row < a.n) ? a.X[(size_t)(r0 + row) * a.D + gd] * wk : 0.0;
-      x2t[dd][row] = (gd < a.D && c0 + row < a.n) ? a.X[(size_t)(c0 + row) * a.D + gd] * wk : 0.0;
+      x2t[dd][row] = (gd < a.D && c0 + row < nc) ? Xc[(size_t)(c0 + row) * a.D + gd] * wk : 0.0;
     }
     __syncthreads();
     double accd[DC];
@@ -196,6 +207,7 @@ int ffgp_grad_impl(ffgp_handle* h, const double* X, int n, int D, const double* 
     const int tm = (n + AT - 1) / AT;
     const int blocks = tm * (tm + 1) / 2;
     GradArgs a;
+    a.X2 = X; a.n2 = n; a.rect = 0;
     a.X = X; a.n = n; a.D = D; a.w = w; a.amp = amp; a.clamp = clamp;
     a.G = G; a.ldg = ldg; a.trG = trG;
     a.mj_coef = (mean_jitter != 0.0) ? mean_jitter / ((double)n * (double)n) : 0.0;
@@ -212,4 +224,26 @@ int ffgp_grad_impl(ffgp_handle* h, const double* X, int n, int D, const double* 
 size_t ffgp_grad_partial_doubles(int n, int D) {
   const size_t tm = (n + AT - 1) / AT;
   return tm * (tm + 1) / 2 * (size_t)(D + 1);
+}
+
+
+// gradient of sum(dK o K(x1, x2)) w.r.t. w[D] and amp for a dense upstream dK [n1, n2] (backward of a standalone
+// kernel call; the fused likelihood never needs it)
+int ffgp_kernel_grad_impl(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const double* w,
+                          const double* amp, double clamp, int kfun, double kparam, const double* dK, int ldk, double* g_w,
+                          double* g_amp) {
+  if (n1 <= 0 || n2 <= 0) return FFGP_OK;
+  if (!X1 || !X2 || !w || !amp || !dK || D <= 0 || ldk < n2) return FFGP_ERR_ARG;
+  const int tm = (n1 + AT - 1) / AT, tn = (n2 + AT - 1) / AT;
+  const int blocks = tm * tn;
+  FFGP_CHECK(ffgp_ensure_ws(h, ((size_t)blocks * (D + 1) + 16) * sizeof(double)));
+  GradArgs a;
+  a.X = X1; a.n = n1; a.X2 = X2; a.n2 = n2; a.rect = 1; a.D = D; a.w = w; a.amp = amp; a.clamp = clamp;
+  a.G = dK; a.ldg = ldk; a.trG = nullptr; a.mj_coef = 0.0; a.partial = h->ws;
+  a.kfun = kfun;
+  a.rinv = (kparam != 0.0) ? 1.0 / kparam : 1.0;
+  hipLaunchKernelGGL(ffgp_grad_kernel, dim3(blocks), dim3(256), 0, h->stream, a);
+  hipLaunchKernelGGL(ffgp_grad_finish, dim3(D + 1), dim3(256), 0, h->stream, h->ws, blocks, D, w, g_w, g_amp);
+  if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
+  return FFGP_OK;
 }

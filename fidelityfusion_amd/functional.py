@@ -256,25 +256,52 @@ def predict(X, Y, Xs, w, amp, diag_add=None, diag_vec=None, add_mat=None, add_al
     return mean.to(device=Y.device, dtype=odt), var.to(device=Y.device, dtype=odt)
 
 
-@torch.no_grad()
+class _KernelMatrix(torch.autograd.Function):
+    """K(x1, x2) [n1, n2] (no Sigma extras); backward gives d/d{w, amp} for a dense upstream dK (ffgp_kernel_grad)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w, amp, clamp, kfun):
+        dev = _device_of(x1, x2, w, amp)
+        h = _lib.handle(dev.index)
+        _lib.bind_stream(h, dev.index)
+        a, b = _dev(x1, dev), _dev(x2, dev)
+        if a.dim() > 2:  # SE_kernel.py:29-32 flattens >2-D inputs
+            a, b = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+        D = a.shape[1]
+        wd = _dev(w.reshape(-1), dev)
+        if wd.numel() == 1 and D > 1:
+            wd = wd.expand(D).contiguous()
+        ad = _dev(amp.reshape(-1)[:1], dev)
+        K = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float64, device=dev)
+        check(lib.ffgp_assemble(h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], D, _ptr(wd), _ptr(ad), clamp, None, None, 0, None,
+                                0, 0.0, 0.0, _ptr(K), b.shape[0], 0, int(kfun[0]), float(kfun[1])), "ffgp_assemble")
+        ctx.saved = (a, b, wd, ad, clamp, kfun, dev)
+        ctx.meta = [(t.shape, t.dtype, t.device) for t in (w, amp)]
+        odt = x1.dtype if x1.dtype.is_floating_point else torch.float64
+        ctx.out = (x1.device, odt)
+        return K.to(device=x1.device, dtype=odt)
+
+    @staticmethod
+    def backward(ctx, dK):
+        a, b, wd, ad, clamp, kfun, dev = ctx.saved
+        h = _lib.handle(dev.index)
+        _lib.bind_stream(h, dev.index)
+        dKd = _dev(dK, dev)
+        D = a.shape[1]
+        g_w = torch.empty((D,), dtype=torch.float64, device=dev)
+        g_amp = torch.empty((1,), dtype=torch.float64, device=dev)
+        check(lib.ffgp_kernel_grad(h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], D, _ptr(wd), _ptr(ad), clamp, int(kfun[0]),
+                                   float(kfun[1]), _ptr(dKd), dKd.shape[1], _ptr(g_w), _ptr(g_amp)), "ffgp_kernel_grad")
+        (ws, wdt, wdev), (as_, adt, adev) = ctx.meta
+        if math.prod(ws) == 1 and D > 1:
+            g_w = g_w.sum().reshape(1)
+        return (None, None, g_w.reshape(ws).to(device=wdev, dtype=wdt), g_amp.reshape(as_).to(device=adev, dtype=adt),
+                None, None)
+
+
 def kernel_matrix(x1, x2, w, amp, clamp=NEG_INF, kfun=(0, 1.0)):
-    """K(x1, x2) [n1, n2] on the device (no Sigma extras)."""
-    dev = _device_of(x1, x2, w, amp)
-    h = _lib.handle(dev.index)
-    _lib.bind_stream(h, dev.index)
-    a, b = _dev(x1, dev), _dev(x2, dev)
-    if a.dim() > 2:  # SE_kernel.py:29-32 flattens >2-D inputs
-        a, b = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
-    D = a.shape[1]
-    wd = _dev(w.reshape(-1), dev)
-    if wd.numel() == 1 and D > 1:
-        wd = wd.expand(D).contiguous()
-    ad = _dev(amp.reshape(-1)[:1], dev)
-    K = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float64, device=dev)
-    check(lib.ffgp_assemble(h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], D, _ptr(wd), _ptr(ad), clamp, None, None, 0, None,
-                            0, 0.0, 0.0, _ptr(K), b.shape[0], 0, int(kfun[0]), float(kfun[1])), "ffgp_assemble")
-    odt = x1.dtype if x1.dtype.is_floating_point else torch.float64
-    return K.to(device=x1.device, dtype=odt)
+    """K(x1, x2) [n1, n2] on the device (no Sigma extras); differentiable w.r.t. w and amp."""
+    return _KernelMatrix.apply(x1, x2, w, amp, clamp, kfun)
 
 
 def _pad_ld(n):
@@ -308,24 +335,52 @@ def cholesky(Sigma):
     return L.to(device=Sigma.device, dtype=Sigma.dtype)
 
 
-@torch.no_grad()
+class _GaussNLLFromCov(torch.autograd.Function):
+    """value(Y, cov) for a caller-built covariance (V1: +nll, V2: -LL of the Sigma^-2 form); backward returns
+    d/dY and the symmetric d/d(cov) -- what torch's cholesky backward gives the reference."""
+
+    @staticmethod
+    def forward(ctx, Y, cov, variant, pi_const):
+        dev = _device_of(Y, cov)
+        h = _lib.handle(dev.index)
+        _lib.bind_stream(h, dev.index)
+        Yd, Cd = _dev(Y, dev), _dev(cov, dev)
+        n, d = Yd.shape
+        p = Problem()
+        p.n, p.D, p.d = n, 0, d
+        p.Y_dev, p.cov_dev, p.ld_cov = _ptr(Yd), _ptr(Cd), Cd.shape[1]
+        p.ll_variant, p.pi_const = variant, pi_const
+        out = torch.empty((), dtype=torch.float64, device=dev)
+        g = None
+        ctx.grads = {}
+        if Y.requires_grad or cov.requires_grad:
+            g = Grads()
+            ctx.grads["Y"] = torch.empty((n, d), dtype=torch.float64, device=dev)
+            ctx.grads["cov"] = torch.empty((n, n), dtype=torch.float64, device=dev)
+            g.g_Y_dev, g.g_cov_dev, g.ld_gcov = _ptr(ctx.grads["Y"]), _ptr(ctx.grads["cov"]), n
+        rc = check(lib.ffgp_nlml_fused(h, C.byref(p), _ptr(out), C.byref(g) if g is not None else None), "ffgp_nlml_fused")
+        if rc > 0:
+            _raise_not_pd(rc, "linalg.cholesky")
+        ctx.meta = [(t.shape, t.dtype, t.device) for t in (Y, cov)]
+        return out.to(device=Y.device, dtype=Y.dtype if Y.dtype.is_floating_point else torch.float64)
+
+    @staticmethod
+    def backward(ctx, gout):
+        outs = []
+        for key, (shape, dtype, device) in zip(("Y", "cov"), ctx.meta):
+            t = ctx.grads[key] * gout.to(device=ctx.grads[key].device, dtype=torch.float64)
+            outs.append(t.reshape(shape).to(device=device, dtype=dtype))
+        return outs[0], outs[1], None, None
+
+
+def gaussian_nll_from_cov(Y, cov, variant=FFGP_LL_V2, pi_const=math.pi):
+    return _GaussNLLFromCov.apply(Y, cov, variant, pi_const)
+
+
 def gaussian_ll_v2(Y, cov):
-    """-LL of the reference's 'cholesky3' Gaussian_log_likelihood (Sigma^-2 quadratic form), from a given cov."""
-    dev = _device_of(Y, cov)
-    h = _lib.handle(dev.index)
-    _lib.bind_stream(h, dev.index)
-    n, d = Y.shape
-    ld = _pad_ld(n)
-    W = torch.zeros((n, ld), dtype=torch.float64, device=dev)
-    W[:, :n] = _dev(cov, dev)
-    rc = check(lib.ffgp_potrf(h, _ptr(W), n, ld), "ffgp_potrf")
-    if rc > 0:
-        _raise_not_pd(rc, "linalg.cholesky")
-    A = _dev(Y, dev).clone()
-    check(lib.ffgp_potrs(h, _ptr(W), n, ld, _ptr(A), d, d), "ffgp_potrs")
-    out = torch.empty((), dtype=torch.float64, device=dev)
-    check(lib.ffgp_nll_reduce(h, FFGP_LL_V2, _ptr(W), n, ld, _ptr(A), d, d, math.pi, _ptr(out)), "ffgp_nll_reduce")
-    return out
+    """-LL of the reference's 'cholesky3' Gaussian_log_likelihood (Sigma^-2 quadratic form), from a given cov;
+    differentiable w.r.t. Y and cov."""
+    return gaussian_nll_from_cov(Y, cov, FFGP_LL_V2, math.pi)
 
 
 @torch.no_grad()

@@ -38,7 +38,7 @@ def Gaussian_log_likelihood(y, cov, Kinv_method="cholesky3"):
     d == 1 returns shape [1, 1] as the reference does (:80), d > 1 a 0-dim tensor (:77)."""
     assert len(y.shape) == 2 and len(cov.shape) == 2, "y, mean, cov should be 2D tensors"
     _check_method(Kinv_method, _REFERENCE_METHODS)
-    ll = -F.gaussian_ll_v2(y, cov).to(device=y.device, dtype=y.dtype)
+    ll = -F.gaussian_ll_v2(y, cov)   # differentiable w.r.t. y and cov (closed-form V2 gradients)
     return ll.reshape(1, 1) if y.shape[1] == 1 else ll
 
 

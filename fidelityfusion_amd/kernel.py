@@ -26,8 +26,8 @@ class _StationaryKernel(nn.Module):
         return (0, 1.0)
 
     def forward(self, x1, x2):
-        """Covariance matrix [n1, n2].  (Differentiable use goes through the fused likelihood in cigp /
-        gp_computation_pack; this standalone call returns a constant tensor.)"""
+        """Covariance matrix [n1, n2]; differentiable w.r.t. the kernel parameters (the fused likelihood in cigp /
+        gp_computation_pack does not go through this call -- it assembles Sigma and its gradient in one pass)."""
         w, amp, clamp = self.effective()
         return F.kernel_matrix(x1, x2, w, amp, clamp, self.kfun())
 

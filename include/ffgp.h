@@ -89,6 +89,10 @@ typedef struct {
   double pi_const;        /* 3.1415 for the V1 call sites, M_PI for V2 */
   int kfun;               /* FFGP_KFUN_* (0 = squared exponential) */
   double kparam;          /* rho of the Matern profiles (MaternKernel(rho=...), default 1); unused for SE */
+  const double* cov_dev;  /* optional: a caller-built covariance [n, n] (lower triangle read).  When set, nothing is
+                             assembled (X, w, amp, the diag and add fields are ignored) -- the Gaussian_log_likelihood(y, cov) call
+                             shape of gp_computation_pack.py:34-91 -- and the gradient comes back through g_cov_dev */
+  int ld_cov;
 } ffgp_problem;
 
 /* Gradients of the value returned by ffgp_nlml_fused with respect to the effective quantities.
@@ -99,6 +103,8 @@ typedef struct {
   double* g_diag_add_dev; /* [1]  (= tr G, plus the mean-jitter chain for S2) */
   double* g_Y_dev;        /* [n, d] */
   double* g_diag_vec_dev; /* [n]  (= diag G), optional */
+  double* g_cov_dev;      /* [n, n] full symmetric d(value)/d(cov) (what torch's cholesky backward returns), optional */
+  int ld_gcov;
 } ffgp_grads;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------ */
@@ -131,6 +137,12 @@ int ffgp_potrf(ffgp_handle* h, double* A_dev, int n, int lda);
    This is how the fused paths obtain Gamma = L^-1 Y (cigp_v10.py:63) and V = L^-1 K_* (cigp_v10.py:36) inside
    the factorisation's own matrix-core GEMMs instead of separate triangular sweeps.                            */
 int ffgp_potrf_rows(ffgp_handle* h, double* A_dev, int n, int mtot, int lda);
+
+/* Backward of a standalone kernel evaluation: g_w[D], g_amp[1] = d sum(dK o K(x1,x2)) / d{w, amp} for a dense upstream
+   dK [n1, n2] (autograd through kernel.forward when a caller builds its own Sigma, e.g. GaussianProcess/cigp_withMean.py:52). */
+int ffgp_kernel_grad(ffgp_handle* h, const double* X1_dev, int n1, const double* X2_dev, int n2, int D,
+                     const double* w_dev, const double* amp_dev, double clamp_min, int kfun, double kparam,
+                     const double* dK_dev, int ldk, double* g_w_dev, double* g_amp_dev);
 
 /* Rebuild the handle's store of inverted 128x128 diagonal blocks for a factor L that this handle did not just
    produce (the triangular solves and ffgp_potri consume it; ffgp_potrf leaves it up to date).               */

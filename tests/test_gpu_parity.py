@@ -183,9 +183,13 @@ def test_cigp2023_golden(golden, tag):
 def test_v2_and_conditional_golden(golden, tag):
     import fidelityfusion_amd.gp_computation_pack as gp_pack
     g = golden("nlml_v2_" + tag)
-    ll = gp_pack.Gaussian_log_likelihood(T(g["Y"]), T(g["cov"]))
+    Yg, covg = T(g["Y"], grad=True), T(g["cov"], grad=True)
+    ll = gp_pack.Gaussian_log_likelihood(Yg, covg)
     assert tuple(ll.shape) == tuple(int(v) for v in g["ll_shape"])
     assert rel(ll, g["ll"]) < 1e-10
+    ll.sum().backward()                     # autograd through a caller-built covariance (cigp_withMean.py:52-53)
+    assert rel(Yg.grad, g["g_Y"]) < 1e-8
+    assert rel(covg.grad, g["g_cov"]) < 1e-8
     mu, cov = gp_pack.conditional_Gaussian(T(g["Y"]), T(g["cov"]), T(g["Ks"]), T(g["Kss"]))
     assert rel(mu, g["mu"]) < 1e-9
     assert rel(cov, g["cond_cov"]) < 1e-9
@@ -222,6 +226,26 @@ def test_gp_basic_golden(golden, tag):
         assert rel(gp.log_likelihood(X, [Y, yv]), g["ll_yvar"]) < 1e-10
         mu, var = gp.forward(X, [Y, yv], Xs)
         assert rel(mu, g["mu_yvar"]) < 1e-9 and rel(var, g["var_yvar"]) < 1e-9
+
+
+@pytest.mark.parametrize("tag", ["d1", "d6"])
+def test_composed_sigma_autograd_golden(golden, tag):
+    """A caller that builds Sigma itself -- K = kernel(x, x) (autograd through the standalone kernel call) plus a noise
+    term in torch -- and hands it to gp_pack.Gaussian_log_likelihood, as GaussianProcess/cigp_withMean.py:52-53 and
+    Bayesian_optimization/cigp.py do: gradients must equal GP_basic's (same arithmetic, gp_basic.py:117-143)."""
+    import fidelityfusion_amd.gp_computation_pack as gp_pack
+    g = golden("gp_basic_" + tag)
+    k = make_kernel(g, "ard")
+    noise = T(g["noise_variance"], grad=True)
+    X, Y = T(g["X"]), T(g["Y"], grad=True)
+    Sigma = k(X, X) + noise.pow(2) * torch.eye(X.shape[0], device=DEV)
+    ll = gp_pack.Gaussian_log_likelihood(Y, Sigma)
+    assert rel(ll, g["ll"]) < 1e-10
+    ll.sum().backward()
+    assert rel(noise.grad, g["g_noise_variance"]) < 1e-7
+    assert rel(k.length_scales.grad, g["g_length_scales"]) < 1e-7
+    assert rel(k.signal_variance.grad, g["g_signal_variance"]) < 1e-7
+    assert rel(Y.grad, g["g_Y"]) < 1e-7
 
 
 def test_not_positive_definite_raises():
