@@ -13,7 +13,7 @@ _SO = os.path.join(_HERE, "libffgp.so")
 
 FFGP_LL_V1, FFGP_LL_V2 = 1, 2
 FFGP_VAR_FULL, FFGP_VAR_DIAG = 0, 1
-FFGP_KFUN_SE, FFGP_KFUN_MATERN12, FFGP_KFUN_MATERN32, FFGP_KFUN_MATERN52 = 0, 1, 2, 3
+FFGP_KFUN_SE, FFGP_KFUN_MATERN12, FFGP_KFUN_MATERN32, FFGP_KFUN_MATERN52, FFGP_KFUN_RQ = 0, 1, 2, 3, 4
 PI_TRUNC = 3.1415  # GaussianProcess/cigp_v10.py:15 ; gp_computation_pack.py:17 ; MFGP_ver2023May/base_gp/cigp.py:6
 
 ERRORS = {-1: "FFGP_ERR_ARG", -2: "FFGP_ERR_HIP", -3: "FFGP_ERR_ALLOC", -4: "FFGP_ERR_NODEVICE"}
@@ -37,7 +37,7 @@ class Problem(C.Structure):
 
 class Grads(C.Structure):
     _fields_ = [("g_w_dev", _dp), ("g_amp_dev", _dp), ("g_diag_add_dev", _dp), ("g_Y_dev", _dp),
-                ("g_diag_vec_dev", _dp), ("g_cov_dev", _dp), ("ld_gcov", C.c_int)]
+                ("g_diag_vec_dev", _dp), ("g_cov_dev", _dp), ("ld_gcov", C.c_int), ("g_kparam_dev", _dp)]
 
 
 EXPORTS = {
@@ -52,7 +52,7 @@ EXPORTS = {
     "ffgp_potrf": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int]),
     "ffgp_potrf_rows": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, C.c_int]),
     "ffgp_kernel_grad": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_double,
-                                   _dp, C.c_int, _dp, _dp]),
+                                   _dp, C.c_int, _dp, _dp, _dp]),
     "ffgp_trtri_diag": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int]),
     "ffgp_trsm_lower": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int]),
     "ffgp_trsm_lower_t": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int]),

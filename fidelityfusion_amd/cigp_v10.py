@@ -35,14 +35,37 @@ class cigp(nn.Module):
 
     def forward(self, x_train, y_train, x_test):
         y_train, _ = _split(y_train)
+        if not hasattr(self.kernel, "effective"):
+            return self._forward_composed(x_train, y_train, x_test)
         w, amp, clamp = self.kernel.effective()
         noise = self.log_beta.exp().pow(-1)
         mean, var = F.predict(x_train, y_train, x_test, w, amp, diag_add=noise + JITTER, clamp=clamp, full_cov=True,
                               var_add_all=float(noise), kfun=_kfun(self.kernel))
         return mean, var
 
+    # composed kernels (SumKernel(LinearKernel, MaternKernel) of the reference's own demos, cigp_v10.py:81,111,147):
+    # the parts are evaluated on the device, Sigma is composed there and enters the fused factorisation as cov_dev
+    @torch.no_grad()
+    def _forward_composed(self, x_train, y_train, x_test):
+        from .gp_computation_pack import conditional_Gaussian
+        noise = self.log_beta.exp().pow(-1)
+        Sigma = F.add_diagonal(F.kernel_on_device(self.kernel, x_train, x_train), noise, JITTER)
+        K_s = F.kernel_on_device(self.kernel, x_train, x_test)
+        K_ss = F.kernel_on_device(self.kernel, x_test, x_test)
+        mean, var = conditional_Gaussian(y_train, Sigma, K_s, K_ss)
+        var = var + noise.to(var.device)
+        odt = y_train.dtype if y_train.dtype.is_floating_point else torch.float64
+        return mean.to(device=y_train.device, dtype=odt), var.to(device=y_train.device, dtype=odt)
+
+    def _nll_composed(self, x_train, y_train, y_var):
+        K = F.kernel_on_device(self.kernel, x_train, x_train)
+        Sigma = F.add_diagonal(K, self.log_beta.exp().pow(-1), JITTER, y_var.diag() if y_var is not None else None)
+        return F.gaussian_nll_from_cov(y_train, Sigma, F.FFGP_LL_V1, PI)
+
     def negative_log_likelihood(self, x_train, y_train):
         y_train, y_var = _split(y_train)
+        if not hasattr(self.kernel, "effective"):
+            return -self._nll_composed(x_train, y_train, y_var)
         w, amp, clamp = self.kernel.effective()
         diag_add = self.log_beta.exp().pow(-1) + JITTER
         nll = F.nlml(x_train, y_train, w, amp, diag_add=diag_add, diag_vec=y_var, clamp=clamp, variant=F.FFGP_LL_V1,

@@ -14,11 +14,11 @@ int ffgp_nll_reduce_impl(ffgp_handle* h, int variant, const double* L, int n, in
                          int ldm, int d, double pi_const, double* out_dev);
 int ffgp_grad_impl(ffgp_handle* h, const double* X, int n, int D, const double* w, const double* amp, double clamp,
                    const double* G, int ldg, double mean_jitter, double* g_w, double* g_amp, double* g_diag_add,
-                   double* g_diag_vec, double* partial_ws, int kfun, double kparam);
+                   double* g_diag_vec, double* partial_ws, int kfun, double kparam, double* g_kparam);
 size_t ffgp_grad_partial_doubles(int n, int D);
 int ffgp_kernel_grad_impl(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const double* w,
                           const double* amp, double clamp, int kfun, double kparam, const double* dK, int ldk, double* g_w,
-                          double* g_amp);
+                          double* g_amp, double* g_kparam);
 
 __global__ void ffgp_copy_lower_kernel(const double* __restrict__ src, int lds_, double* __restrict__ dst, int ldd, int n) {
   const int c = blockIdx.x * 32 + (threadIdx.x & 31), r = blockIdx.y * 32 + (threadIdx.x >> 5) * 4;
@@ -183,7 +183,7 @@ int ffgp_assemble(ffgp_handle* h, const double* X1, int n1, const double* X2, in
                   const double* add_mat, int ld_add, double add_all, double mean_jitter, double* K, int ldk,
                   int lower_only, int kfun, double kparam) {
   if (!h) return FFGP_ERR_ARG;
-  if (kfun < FFGP_KFUN_SE || kfun > FFGP_KFUN_MATERN52) return FFGP_ERR_ARG;
+  if (kfun < FFGP_KFUN_SE || kfun > FFGP_KFUN_RQ) return FFGP_ERR_ARG;
   FFGP_HIP(hipSetDevice(h->device));
   return ffgp_assemble_impl(h, X1, n1, X2, n2, D, w, amp, clamp_min, diag_add, diag_vec, diag_stride, add_mat, ld_add,
                             add_all, mean_jitter, K, ldk, lower_only, kfun, kparam);
@@ -237,10 +237,11 @@ int ffgp_gemm(ffgp_handle* h, int opa, int opb, int lower_tiles, int tri, const 
 
 int ffgp_kernel_grad(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const double* w,
                      const double* amp, double clamp_min, int kfun, double kparam, const double* dK, int ldk, double* g_w,
-                     double* g_amp) {
+                     double* g_amp, double* g_kparam) {
   if (!h) return FFGP_ERR_ARG;
+  if (kfun < FFGP_KFUN_SE || kfun > FFGP_KFUN_RQ) return FFGP_ERR_ARG;
   FFGP_HIP(hipSetDevice(h->device));
-  return ffgp_kernel_grad_impl(h, X1, n1, X2, n2, D, w, amp, clamp_min, kfun, kparam, dK, ldk, g_w, g_amp);
+  return ffgp_kernel_grad_impl(h, X1, n1, X2, n2, D, w, amp, clamp_min, kfun, kparam, dK, ldk, g_w, g_amp, g_kparam);
 }
 
 /* (re)build the inverted 128x128 diagonal blocks of a factor (also the diag-kernel timing hook of tools/) */
@@ -304,11 +305,12 @@ static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll
   if (!given_cov && (p->D <= 0 || !p->X_dev || !p->w_dev || !p->amp_dev)) return FFGP_ERR_ARG;
   if (given_cov && p->ld_cov < p->n) return FFGP_ERR_ARG;
   if (p->ll_variant != FFGP_LL_V1 && p->ll_variant != FFGP_LL_V2) return FFGP_ERR_ARG;
-  if (p->kfun < FFGP_KFUN_SE || p->kfun > FFGP_KFUN_MATERN52) return FFGP_ERR_ARG;
+  if (p->kfun < FFGP_KFUN_SE || p->kfun > FFGP_KFUN_RQ) return FFGP_ERR_ARG;
   FFGP_HIP(hipSetDevice(h->device));
   const int n = p->n, D = given_cov ? 1 : p->D, d = p->d;
-  const bool want_grad = g && (g->g_w_dev || g->g_amp_dev || g->g_diag_add_dev || g->g_Y_dev || g->g_diag_vec_dev || g->g_cov_dev);
-  if (given_cov && g && (g->g_w_dev || g->g_amp_dev)) return FFGP_ERR_ARG;
+  const bool want_grad = g && (g->g_w_dev || g->g_amp_dev || g->g_diag_add_dev || g->g_Y_dev || g->g_diag_vec_dev || g->g_cov_dev ||
+                                g->g_kparam_dev);
+  if (given_cov && g && (g->g_w_dev || g->g_amp_dev || g->g_kparam_dev)) return FFGP_ERR_ARG;
   if (g && g->g_cov_dev && g->ld_gcov < p->n) return FFGP_ERR_ARG;
   const bool v2 = (p->ll_variant == FFGP_LL_V2);
   const size_t ld = ffgp_round_up(n, 16);
@@ -394,7 +396,8 @@ static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll
       gYt = Bt;
     }
     FFGP_CHECK(ffgp_grad_impl(h, p->X_dev, n, D, p->w_dev, p->amp_dev, p->clamp_min, S, (int)ld, given_cov ? 0.0 : p->mean_jitter,
-                              g->g_w_dev, g->g_amp_dev, g->g_diag_add_dev, g->g_diag_vec_dev, P, p->kfun, p->kparam));
+                              g->g_w_dev, g->g_amp_dev, g->g_diag_add_dev, g->g_diag_vec_dev, P, p->kfun, p->kparam,
+                              g->g_kparam_dev));
     if (g->g_cov_dev)
       hipLaunchKernelGGL(ffgp_symmetrize_kernel, dim3((n + 31) / 32, (n + 31) / 32), dim3(256), 0, h->stream, S, (int)ld,
                          g->g_cov_dev, g->ld_gcov, n, 1.0);

@@ -41,6 +41,7 @@ __device__ __forceinline__ double ffgp_kfun_val(int kind, double rinv, double s)
     const double a = sqrt(3.0 * s) * rinv;
     return (1.0 + a) * exp(-a);
   }
+  if (kind == FFGP_KFUN_RQ) return pow(1.0 + 0.5 * s * rinv, -1.0 / rinv);   // rinv = 1/alpha
   const double a = sqrt(5.0 * s) * rinv;
   return (1.0 + a + (5.0 / 3.0) * s * rinv * rinv) * exp(-a);
 }
@@ -51,8 +52,16 @@ __device__ __forceinline__ double ffgp_kfun_m2d(int kind, double rinv, double s)
     return rinv / r * exp(-r * rinv);
   }
   if (kind == FFGP_KFUN_MATERN32) return 3.0 * rinv * rinv * exp(-sqrt(3.0 * s) * rinv);
+  if (kind == FFGP_KFUN_RQ) return pow(1.0 + 0.5 * s * rinv, -1.0 / rinv - 1.0);
   const double a = sqrt(5.0 * s) * rinv;
   return (5.0 / 3.0) * rinv * rinv * (1.0 + a) * exp(-a);
+}
+// d phi / d kparam for the profiles whose parameter is learnable in the reference (RQ's alpha, kernel.py:295);
+// phi is the value already computed.  Matern's rho is a constructor constant there -> 0.
+__device__ __forceinline__ double ffgp_kfun_dparam(int kind, double rinv, double s, double phi) {
+  if (kind != FFGP_KFUN_RQ) return 0.0;
+  const double u = 0.5 * s * rinv;
+  return phi * (u / (1.0 + u) - log1p(u));
 }
 
 // GEMM operand layouts.  "K-major": element (row, k) at P[row*ld + k]; "MN-major": at P[k*ld + row].

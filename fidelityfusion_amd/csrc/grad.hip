@@ -20,7 +20,7 @@ struct GradArgs {
   const double* G; int ldg;
   const double* trG;      // device scalar (needed for the mean-jitter chain), may be null when coef == 0
   double mj_coef;         // mean_jitter / n^2
-  double* partial;        // [blocks][D+1]: per-block partial sums (deterministic two-stage reduction)
+  double* partial;        // [blocks][D+2]: per-block partial sums (deterministic two-stage reduction): w[D], amp, kparam
   int kfun; double rinv;  // radial profile and 1/rho
 };
 
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void ffgp_grad_kernel(GradArgs a) {
   const double amp = a.amp[0];
   const double geff_add = (a.mj_coef != 0.0) ? a.mj_coef * a.trG[0] : 0.0;
   double Wl[4][4];
-  double s_amp = 0.0;
+  double s_amp = 0.0, s_kp = 0.0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = r0 + ty + 16 * i;
@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void ffgp_grad_kernel(GradArgs a) {
         const double e = ffgp_kfun_val(a.kfun, a.rinv, sc);
         const double sym = (!a.rect && col < row) ? 2.0 : 1.0;
         s_amp += sym * g * e;
+        if (a.kfun == FFGP_KFUN_RQ) s_kp += sym * g * amp * ffgp_kfun_dparam(a.kfun, a.rinv, sc, e);
         wv = (sq[i][j] >= a.clamp) ? sym * g * amp * ffgp_kfun_m2d(a.kfun, a.rinv, sc) : 0.0;
       }
       Wl[i][j] = wv;
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void ffgp_grad_kernel(GradArgs a) {
     }
     __syncthreads();
     if (tid < DC && d0 + tid < a.D)
-      a.partial[(size_t)blockIdx.x * (a.D + 1) + d0 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+      a.partial[(size_t)blockIdx.x * (a.D + 2) + d0 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
     __syncthreads();
   }
   {
@@ -150,18 +151,24 @@ __global__ __launch_bounds__(256) void ffgp_grad_kernel(GradArgs a) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
     if ((tid & 63) == 0) red[tid >> 6][DC] = v;
     __syncthreads();
-    if (tid == 0) a.partial[(size_t)blockIdx.x * (a.D + 1) + a.D] = red[0][DC] + red[1][DC] + red[2][DC] + red[3][DC];
+    if (tid == 0) a.partial[(size_t)blockIdx.x * (a.D + 2) + a.D] = red[0][DC] + red[1][DC] + red[2][DC] + red[3][DC];
+    __syncthreads();
+    v = s_kp;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((tid & 63) == 0) red[tid >> 6][DC] = v;
+    __syncthreads();
+    if (tid == 0) a.partial[(size_t)blockIdx.x * (a.D + 2) + a.D + 1] = red[0][DC] + red[1][DC] + red[2][DC] + red[3][DC];
   }
 }
 
-// out_w[k] = -(1/w_k) * sum_b partial[b][k] ; out_amp = sum_b partial[b][D]
+// out_w[k] = -(1/w_k) * sum_b partial[b][k] ; out_amp = sum_b partial[b][D] ; out_kparam = sum_b partial[b][D+1]
 __global__ __launch_bounds__(256) void ffgp_grad_finish(const double* __restrict__ partial, int blocks, int D,
                                                         const double* __restrict__ w, double* __restrict__ g_w,
-                                                        double* __restrict__ g_amp) {
+                                                        double* __restrict__ g_amp, double* __restrict__ g_kparam) {
   __shared__ double red[4];
   const int k = blockIdx.x;  // 0..D
   double s = 0.0;
-  for (int b = threadIdx.x; b < blocks; b += 256) s += partial[(size_t)b * (D + 1) + k];
+  for (int b = threadIdx.x; b < blocks; b += 256) s += partial[(size_t)b * (D + 2) + k];
   for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -169,8 +176,10 @@ __global__ __launch_bounds__(256) void ffgp_grad_finish(const double* __restrict
     s = red[0] + red[1] + red[2] + red[3];
     if (k < D) {
       if (g_w) g_w[k] = -s / w[k];
-    } else if (g_amp) {
-      g_amp[0] = s;
+    } else if (k == D) {
+      if (g_amp) g_amp[0] = s;
+    } else if (g_kparam) {
+      g_kparam[0] = s;
     }
   }
 }
@@ -199,11 +208,11 @@ __global__ void ffgp_copy_scalar(const double* src, double* dst) { dst[0] = src[
 
 int ffgp_grad_impl(ffgp_handle* h, const double* X, int n, int D, const double* w, const double* amp, double clamp,
                    const double* G, int ldg, double mean_jitter, double* g_w, double* g_amp, double* g_diag_add,
-                   double* g_diag_vec, double* partial_ws, int kfun, double kparam) {
+                   double* g_diag_vec, double* partial_ws, int kfun, double kparam, double* g_kparam) {
   double* trG = h->d_scal + 4;
   hipLaunchKernelGGL(ffgp_trace_kernel, dim3(1), dim3(1024), 0, h->stream, G, ldg, n, trG, g_diag_vec);
   if (g_diag_add) hipLaunchKernelGGL(ffgp_copy_scalar, dim3(1), dim3(1), 0, h->stream, trG, g_diag_add);
-  if (g_w || g_amp) {
+  if (g_w || g_amp || g_kparam) {
     const int tm = (n + AT - 1) / AT;
     const int blocks = tm * (tm + 1) / 2;
     GradArgs a;
@@ -215,7 +224,7 @@ int ffgp_grad_impl(ffgp_handle* h, const double* X, int n, int D, const double* 
     a.kfun = kfun;
     a.rinv = (kparam != 0.0) ? 1.0 / kparam : 1.0;
     hipLaunchKernelGGL(ffgp_grad_kernel, dim3(blocks), dim3(256), 0, h->stream, a);
-    hipLaunchKernelGGL(ffgp_grad_finish, dim3(D + 1), dim3(256), 0, h->stream, partial_ws, blocks, D, w, g_w, g_amp);
+    hipLaunchKernelGGL(ffgp_grad_finish, dim3(D + 2), dim3(256), 0, h->stream, partial_ws, blocks, D, w, g_w, g_amp, g_kparam);
   }
   if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
   return FFGP_OK;
@@ -223,7 +232,7 @@ int ffgp_grad_impl(ffgp_handle* h, const double* X, int n, int D, const double* 
 
 size_t ffgp_grad_partial_doubles(int n, int D) {
   const size_t tm = (n + AT - 1) / AT;
-  return tm * (tm + 1) / 2 * (size_t)(D + 1);
+  return tm * (tm + 1) / 2 * (size_t)(D + 2);
 }
 
 
@@ -231,19 +240,19 @@ size_t ffgp_grad_partial_doubles(int n, int D) {
 // kernel call; the fused likelihood never needs it)
 int ffgp_kernel_grad_impl(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const double* w,
                           const double* amp, double clamp, int kfun, double kparam, const double* dK, int ldk, double* g_w,
-                          double* g_amp) {
+                          double* g_amp, double* g_kparam) {
   if (n1 <= 0 || n2 <= 0) return FFGP_OK;
   if (!X1 || !X2 || !w || !amp || !dK || D <= 0 || ldk < n2) return FFGP_ERR_ARG;
   const int tm = (n1 + AT - 1) / AT, tn = (n2 + AT - 1) / AT;
   const int blocks = tm * tn;
-  FFGP_CHECK(ffgp_ensure_ws(h, ((size_t)blocks * (D + 1) + 16) * sizeof(double)));
+  FFGP_CHECK(ffgp_ensure_ws(h, ((size_t)blocks * (D + 2) + 16) * sizeof(double)));
   GradArgs a;
   a.X = X1; a.n = n1; a.X2 = X2; a.n2 = n2; a.rect = 1; a.D = D; a.w = w; a.amp = amp; a.clamp = clamp;
   a.G = dK; a.ldg = ldk; a.trG = nullptr; a.mj_coef = 0.0; a.partial = h->ws;
   a.kfun = kfun;
   a.rinv = (kparam != 0.0) ? 1.0 / kparam : 1.0;
   hipLaunchKernelGGL(ffgp_grad_kernel, dim3(blocks), dim3(256), 0, h->stream, a);
-  hipLaunchKernelGGL(ffgp_grad_finish, dim3(D + 1), dim3(256), 0, h->stream, h->ws, blocks, D, w, g_w, g_amp);
+  hipLaunchKernelGGL(ffgp_grad_finish, dim3(D + 2), dim3(256), 0, h->stream, h->ws, blocks, D, w, g_w, g_amp, g_kparam);
   if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
   return FFGP_OK;
 }

@@ -75,7 +75,7 @@ def _problem(dev, X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitte
     p.mean_jitter = float(mean_jitter)
     p.ll_variant = variant
     p.pi_const = pi_const
-    p.kfun, p.kparam = int(kfun[0]), float(kfun[1])
+    p.kfun, p.kparam = int(kfun[0]), float(kfun[1])   # a learnable profile parameter (RQ's alpha) arrives as a tensor
     return p, (n, D, d)
 
 
@@ -85,14 +85,16 @@ class _NLML(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, variant, pi_const, slot=0,
-                defer=False, kfun=(0, 1.0)):
+                defer=False, kfun=(0, 1.0), kparam=None):
         dev = _device_of(X, Y, w, amp)
+        if kparam is not None:
+            kfun = (kfun[0], float(kparam.detach()))
         h = _lib.handle(dev.index, slot)
         _lib.bind_stream(h, dev.index)
         keep = []
         p, (n, D, d) = _problem(dev, X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, variant,
                                 pi_const, keep, kfun)
-        needs = [isinstance(t, torch.Tensor) and t.requires_grad for t in (Y, w, amp, diag_add, diag_vec)]
+        needs = [isinstance(t, torch.Tensor) and t.requires_grad for t in (Y, w, amp, diag_add, diag_vec, kparam)]
         out = torch.empty((), dtype=torch.float64, device=dev)
         g = None
         grads = {}
@@ -113,6 +115,9 @@ class _NLML(torch.autograd.Function):
             if needs[4]:
                 grads["diag_vec"] = torch.empty((n,), dtype=torch.float64, device=dev)
                 g.g_diag_vec_dev = _ptr(grads["diag_vec"])
+            if needs[5]:
+                grads["kparam"] = torch.empty((1,), dtype=torch.float64, device=dev)
+                g.g_kparam_dev = _ptr(grads["kparam"])
         gref = C.byref(g) if g is not None else None
         if defer:   # enqueue only: the caller collects the status with wait(slot) after launching its other blocks
             check(lib.ffgp_nlml_fused_async(h, C.byref(p), _ptr(out), gref), "ffgp_nlml_fused_async")
@@ -123,7 +128,7 @@ class _NLML(torch.autograd.Function):
                 _raise_not_pd(rc, "linalg.cholesky")
         ctx.grads = grads
         ctx.meta = [(t.shape, t.dtype, t.device) if isinstance(t, torch.Tensor) else None
-                    for t in (Y, w, amp, diag_add, diag_vec)]
+                    for t in (Y, w, amp, diag_add, diag_vec, kparam)]
         return out.to(device=Y.device, dtype=Y.dtype if Y.dtype.is_floating_point else torch.float64)
 
     @staticmethod
@@ -142,7 +147,7 @@ class _NLML(torch.autograd.Function):
             return t.reshape(shape).to(device=device, dtype=dtype)
 
         return (None, fin("Y", 0), fin("w", 1), fin("amp", 2), fin("diag_add", 3), fin("diag_vec", 4), None, None, None,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, fin("kparam", 5))
 
 
 _pending = {}   # (device, slot) -> staging tensors of enqueued-but-not-waited calls (kept alive until wait)
@@ -155,8 +160,16 @@ def nlml(X, Y, w, amp, diag_add=None, diag_vec=None, add_mat=None, add_all=0.0, 
 
     slot / defer: independent blocks can overlap on one GPU -- issue each under its own torch stream with its own
     `slot` and `defer=True`, then call `wait(slot)` (see `concurrent_blocks`)."""
+    kfun, kparam = _split_kfun(kfun)
     return _NLML.apply(X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, variant, pi_const, slot,
-                       defer, kfun)
+                       defer, kfun, kparam)
+
+
+def _split_kfun(kfun):
+    """(id, float | tensor) -> ((id, float), tensor | None): a tensor parameter is differentiated (g_kparam)."""
+    if isinstance(kfun[1], torch.Tensor):
+        return (int(kfun[0]), float(kfun[1].detach())), kfun[1]
+    return (int(kfun[0]), float(kfun[1])), None
 
 
 def wait(slot=0, device_index=None):
@@ -242,6 +255,7 @@ def predict(X, Y, Xs, w, amp, diag_add=None, diag_vec=None, add_mat=None, add_al
     h = _lib.handle(dev.index)
     _lib.bind_stream(h, dev.index)
     keep = []
+    kfun, _ = _split_kfun(kfun)
     p, (n, D, d) = _problem(dev, X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, FFGP_LL_V1,
                             PI_TRUNC, keep, kfun)
     Xsd = _dev(Xs, dev)
@@ -260,8 +274,10 @@ class _KernelMatrix(torch.autograd.Function):
     """K(x1, x2) [n1, n2] (no Sigma extras); backward gives d/d{w, amp} for a dense upstream dK (ffgp_kernel_grad)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, w, amp, clamp, kfun):
+    def forward(ctx, x1, x2, w, amp, clamp, kfun, kparam=None):
         dev = _device_of(x1, x2, w, amp)
+        if kparam is not None:
+            kfun = (kfun[0], float(kparam.detach()))
         h = _lib.handle(dev.index)
         _lib.bind_stream(h, dev.index)
         a, b = _dev(x1, dev), _dev(x2, dev)
@@ -277,6 +293,7 @@ class _KernelMatrix(torch.autograd.Function):
                                 0, 0.0, 0.0, _ptr(K), b.shape[0], 0, int(kfun[0]), float(kfun[1])), "ffgp_assemble")
         ctx.saved = (a, b, wd, ad, clamp, kfun, dev)
         ctx.meta = [(t.shape, t.dtype, t.device) for t in (w, amp)]
+        ctx.kp_meta = (kparam.shape, kparam.dtype, kparam.device) if kparam is not None and kparam.requires_grad else None
         odt = x1.dtype if x1.dtype.is_floating_point else torch.float64
         ctx.out = (x1.device, odt)
         return K.to(device=x1.device, dtype=odt)
@@ -290,18 +307,48 @@ class _KernelMatrix(torch.autograd.Function):
         D = a.shape[1]
         g_w = torch.empty((D,), dtype=torch.float64, device=dev)
         g_amp = torch.empty((1,), dtype=torch.float64, device=dev)
+        g_kp = torch.empty((1,), dtype=torch.float64, device=dev) if ctx.kp_meta is not None else None
         check(lib.ffgp_kernel_grad(h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], D, _ptr(wd), _ptr(ad), clamp, int(kfun[0]),
-                                   float(kfun[1]), _ptr(dKd), dKd.shape[1], _ptr(g_w), _ptr(g_amp)), "ffgp_kernel_grad")
+                                   float(kfun[1]), _ptr(dKd), dKd.shape[1], _ptr(g_w), _ptr(g_amp), _ptr(g_kp)),
+              "ffgp_kernel_grad")
         (ws, wdt, wdev), (as_, adt, adev) = ctx.meta
         if math.prod(ws) == 1 and D > 1:
             g_w = g_w.sum().reshape(1)
+        if g_kp is not None:
+            ks, kdt, kdev = ctx.kp_meta
+            g_kp = g_kp.reshape(ks).to(device=kdev, dtype=kdt)
         return (None, None, g_w.reshape(ws).to(device=wdev, dtype=wdt), g_amp.reshape(as_).to(device=adev, dtype=adt),
-                None, None)
+                None, None, g_kp)
 
 
 def kernel_matrix(x1, x2, w, amp, clamp=NEG_INF, kfun=(0, 1.0)):
-    """K(x1, x2) [n1, n2] on the device (no Sigma extras); differentiable w.r.t. w and amp."""
-    return _KernelMatrix.apply(x1, x2, w, amp, clamp, kfun)
+    """K(x1, x2) [n1, n2] on the device (no Sigma extras); differentiable w.r.t. w, amp and a tensor profile
+    parameter."""
+    kfun, kparam = _split_kfun(kfun)
+    return _KernelMatrix.apply(x1, x2, w, amp, clamp, kfun, kparam)
+
+
+def kernel_on_device(kernel, x1, x2):
+    """kernel(x1, x2) as a differentiable fp64 tensor resident on the compute device -- the entry of the composed
+    path for kernels without a fused (w, amp, profile) descriptor (SumKernel, ProductKernel, LinearKernel, user
+    modules).  Kernels of this package are evaluated on device-resident inputs; anything else is called as the
+    caller wrote it and its result moved."""
+    dev = _device_of(x1, x2)
+    if getattr(kernel, "_ffgp_device_aware", False):
+        x1 = x1.to(device=dev, dtype=torch.float64)
+        x2 = x2.to(device=dev, dtype=torch.float64)
+    return kernel(x1, x2).to(device=dev, dtype=torch.float64)
+
+
+def add_diagonal(K, *terms):
+    """K + sum(terms) * I without an N x N identity (differentiable; terms are scalars / [1] tensors / [N] vectors)."""
+    S = K.clone()
+    dg = S.diagonal()
+    for t in terms:
+        if t is None:
+            continue
+        dg.add_(t.to(device=K.device, dtype=K.dtype).reshape(-1) if isinstance(t, torch.Tensor) else t)
+    return S
 
 
 def _pad_ld(n):
@@ -383,16 +430,40 @@ def gaussian_ll_v2(Y, cov):
     return gaussian_nll_from_cov(Y, cov, FFGP_LL_V2, math.pi)
 
 
-@torch.no_grad()
-def matmul_nt(A, B, alpha=1.0):
-    """alpha * A @ B^T for device tensors A [m, k], B [n, k] on the fp64 matrix-core GEMM (ffgp_gemm)."""
-    dev = _device_of(A, B)
+def _gemm(dev, opa, opb, A, B, m, n, k, alpha):
     h = _lib.handle(dev.index)
     _lib.bind_stream(h, dev.index)
-    a, b = _dev(A, dev), _dev(B, dev)
-    m, k = a.shape
-    n = b.shape[0]
     out = torch.empty((m, n), dtype=torch.float64, device=dev)
-    check(lib.ffgp_gemm(h, 0, 0, 0, 0, _ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), n, m, n, k, float(alpha), 0.0),
-          "ffgp_gemm")
+    if m and n:
+        check(lib.ffgp_gemm(h, opa, opb, 0, 0, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out), n, m, n, k, float(alpha),
+                            0.0), "ffgp_gemm")
     return out
+
+
+class _MatmulNT(torch.autograd.Function):
+    """alpha * A @ B^T on the fp64 matrix-core GEMM; the two backward products run on the same kernel."""
+
+    @staticmethod
+    def forward(ctx, A, B, alpha):
+        dev = _device_of(A, B)
+        a, b = _dev(A, dev), _dev(B, dev)
+        ctx.saved = (a, b, alpha, dev)
+        ctx.meta = [(t.dtype, t.device) for t in (A, B)]
+        return _gemm(dev, 0, 0, a, b, a.shape[0], b.shape[0], a.shape[1], alpha)
+
+    @staticmethod
+    def backward(ctx, dC):
+        a, b, alpha, dev = ctx.saved
+        dc = _dev(dC, dev)
+        (adt, adev), (bdt, bdev) = ctx.meta
+        dA = dB = None
+        if ctx.needs_input_grad[0]:   # dA = alpha dC B        [m, n] x [n, k]
+            dA = _gemm(dev, 0, 1, dc, b, a.shape[0], a.shape[1], b.shape[0], alpha).to(device=adev, dtype=adt)
+        if ctx.needs_input_grad[1]:   # dB = alpha dC^T A      [n, m] x [m, k]
+            dB = _gemm(dev, 1, 1, dc, a, b.shape[0], b.shape[1], a.shape[0], alpha).to(device=bdev, dtype=bdt)
+        return dA, dB, None
+
+
+def matmul_nt(A, B, alpha=1.0):
+    """alpha * A @ B^T for A [m, k], B [n, k] on the fp64 matrix-core GEMM (ffgp_gemm); fp64 result on the device."""
+    return _MatmulNT.apply(A, B, alpha)

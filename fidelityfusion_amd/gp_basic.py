@@ -35,14 +35,36 @@ class GP_basic(nn.Module):
     def forward(self, x_train, y_train, x_test, Kinv_method="cholesky3"):
         _check_method(Kinv_method, _METHODS_FWD)
         y_train, y_var = _split(y_train)
+        if not hasattr(self.kernel, "effective"):
+            return self._forward_composed(x_train, y_train, y_var, x_test)
         w, amp, clamp = self.kernel.effective()
         mu, var = F.predict(x_train, y_train, x_test, w, amp, diag_add=self.noise_variance.pow(2), add_mat=y_var,
                             clamp=clamp, full_cov=True, var_add_all=0.0, kfun=_kfun(self.kernel))
         return mu.squeeze(), var
 
+    # composed kernels (gp_basic.py:170-173 tries Linear / Sum kernels): Sigma is built on the device from the
+    # differentiable kernel call and enters the fused factorisation as ffgp_problem.cov_dev
+    def _sigma_composed(self, x_train, y_var):
+        Sigma = F.add_diagonal(F.kernel_on_device(self.kernel, x_train, x_train), self.noise_variance.pow(2))
+        if y_var is not None:
+            Sigma = Sigma + y_var.to(device=Sigma.device, dtype=Sigma.dtype)
+        return Sigma
+
+    @torch.no_grad()
+    def _forward_composed(self, x_train, y_train, y_var, x_test):
+        from .gp_computation_pack import conditional_Gaussian
+        K_s = F.kernel_on_device(self.kernel, x_train, x_test)
+        K_ss = F.kernel_on_device(self.kernel, x_test, x_test)
+        mu, var = conditional_Gaussian(y_train, self._sigma_composed(x_train, y_var), K_s, K_ss)
+        odt = y_train.dtype if y_train.dtype.is_floating_point else torch.float64
+        return mu.to(device=y_train.device, dtype=odt).squeeze(), var.to(device=y_train.device, dtype=odt)
+
     def log_likelihood(self, x_train, y_train, Kinv_method="cholesky3"):
         _check_method(Kinv_method, _METHODS_LL)
         y_train, y_var = _split(y_train)
+        if not hasattr(self.kernel, "effective"):
+            ll = -F.gaussian_nll_from_cov(y_train, self._sigma_composed(x_train, y_var), F.FFGP_LL_V2, math.pi)
+            return ll.reshape(1, 1) if y_train.shape[1] == 1 else ll
         w, amp, clamp = self.kernel.effective()
         nll = F.nlml(x_train, y_train, w, amp, diag_add=self.noise_variance.pow(2), add_mat=y_var, clamp=clamp,
                      variant=F.FFGP_LL_V2, pi_const=math.pi, **F._slot_args(), kfun=_kfun(self.kernel))

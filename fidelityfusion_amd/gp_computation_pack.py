@@ -46,7 +46,8 @@ def conditional_Gaussian(y, Sigma, K_s, K_ss, Kinv_method="cholesky3"):
     """mu = K_s^T Sigma^-1 y ; cov = K_ss - (L^-1 K_s)^T (L^-1 K_s)   (:103-110).
     Both solves ride as passenger rows of one factorisation."""
     _check_method(Kinv_method, ("cholesky1", "cholesky3", "direct"))
-    rows = torch.cat([y.T, K_s.T], 0)
+    dev = F._device_of(y, Sigma, K_s)
+    rows = torch.cat([F._dev(y, dev).T, F._dev(K_s, dev).T], 0)
     _, R = F.cholesky_with_rows(Sigma, rows)
     d = y.shape[1]
     Gt, Vt = R[:d], R[d:]                       # Gamma^T [d, n], V^T [nt, n]
@@ -57,6 +58,10 @@ def conditional_Gaussian(y, Sigma, K_s, K_ss, Kinv_method="cholesky3"):
 
 def negative_log_likelihood(kernel, log_beta, x_train, y_train):
     """Sigma = K + exp(-log_beta) I + 1e-6 mean(K) I ; returns +LL with pi = 3.1415 (:120-136)."""
+    if not hasattr(kernel, "effective"):   # composed kernel: Sigma is built on the device, then the fused factorisation
+        K = F.kernel_on_device(kernel, x_train, x_train)
+        Sigma = F.add_diagonal(K, log_beta.exp().pow(-1), JITTER * K.mean())
+        return -F.gaussian_nll_from_cov(y_train, Sigma, F.FFGP_LL_V1, PI)
     w, amp, clamp = kernel.effective()
     nll = F.nlml(x_train, y_train, w, amp, diag_add=log_beta.exp().pow(-1), mean_jitter=JITTER, clamp=clamp,
                  variant=F.FFGP_LL_V1, pi_const=PI, **F._slot_args(), kfun=_kfun(kernel))

@@ -1,6 +1,8 @@
 """Kernel modules with the reference's names, parameters and call signature
-(`GaussianProcess/kernel.py`: ARDKernel :65-105, SquaredExponentialKernel :239-272); the covariance itself is
-assembled by the HIP library.
+(`GaussianProcess/kernel.py`: LinearKernel :23-63, ARDKernel :65-105, MaternKernel :109-169, SumKernel :172-203,
+ProductKernel :205-236, SquaredExponentialKernel :239-272, RationalQuadraticKernel :275-310); the covariance itself
+is assembled by the HIP library.  Not provided: MaternKernel_scalarLengthScale (:312-347) -- its sqrt of an
+unclamped norm-expansion distance is NaN whenever rounding leaves a diagonal entry negative.
 
 Each module owns the same raw nn.Parameters as the reference (names show up in state_dict logs,
 `FidelityFusion_Models/log/ResGP/train.log:2`) and exposes `effective()` -> (w, amp, clamp): the inverse length
@@ -18,6 +20,8 @@ EPS = 1e-9
 
 
 class _StationaryKernel(nn.Module):
+    _ffgp_device_aware = True
+
     def effective(self):  # pragma: no cover - interface
         raise NotImplementedError
 
@@ -80,3 +84,67 @@ class MaternKernel(_StationaryKernel):
         if self.nu not in self._KFUN:   # the reference returns None for any other nu (kernel.py:161-166)
             raise ValueError("MaternKernel: nu must be 0.5, 1.5 or 2.5")
         return (self._KFUN[self.nu], float(self.rho))
+
+
+class RationalQuadraticKernel(_StationaryKernel):
+    """K = signal_variance^2 * (1 + sqdist / (2 alpha length_scale^2))^-alpha, scalar length scale, all three raw
+    parameters learnable, no clamp on the distance (kernel.py:275-310).  alpha's gradient comes back through
+    ffgp_grads.g_kparam_dev."""
+
+    def __init__(self, length_scale=1., signal_variance=1., alpha=1.):
+        super().__init__()
+        self.length_scale = nn.Parameter(torch.tensor([length_scale]))
+        self.signal_variance = nn.Parameter(torch.tensor([signal_variance]))
+        self.alpha = nn.Parameter(torch.tensor([alpha]))
+
+    def effective(self):
+        return 1.0 / self.length_scale, self.signal_variance.pow(2), F.NEG_INF
+
+    def kfun(self):
+        return (4, self.alpha)
+
+
+class LinearKernel(nn.Module):
+    """K = |signal_variance| * ((x1 - center) / length_scales) ((x2 - center) / length_scales)^T  (kernel.py:23-63);
+    the product runs on the fp64 matrix-core GEMM, forward and backward."""
+    _ffgp_device_aware = True
+
+    def __init__(self, input_dim, initial_length_scale=1.0, initial_signal_variance=1.0):
+        super().__init__()
+        self.length_scales = nn.Parameter(torch.ones(input_dim) * initial_length_scale)
+        self.signal_variance = nn.Parameter(torch.tensor([initial_signal_variance]))
+        self.center = nn.Parameter(torch.zeros(input_dim))
+
+    def forward(self, x1, x2):
+        c, ls = self.center.to(x1.device), self.length_scales.to(x1.device)
+        z1, z2 = (x1 - c) / ls, (x2 - c) / ls
+        K = F.matmul_nt(z1, z2)
+        odt = x1.dtype if x1.dtype.is_floating_point else torch.float64
+        K = K.to(device=x1.device, dtype=odt)
+        return K * self.signal_variance.abs().to(K.device)
+
+
+class _Pair(nn.Module):
+    def __init__(self, kernel1, kernel2):
+        super().__init__()
+        self.kernel1 = kernel1
+        self.kernel2 = kernel2
+
+    @property
+    def _ffgp_device_aware(self):
+        return all(getattr(k, "_ffgp_device_aware", False) for k in (self.kernel1, self.kernel2))
+
+
+class SumKernel(_Pair):
+    """kernel1(x1, x2) + kernel2(x1, x2)  (kernel.py:172-203).  No fused descriptor: the GP modules evaluate the two
+    parts on the device and hand the composed Sigma to the fused factorisation (ffgp_problem.cov_dev)."""
+
+    def forward(self, x1, x2):
+        return self.kernel1(x1, x2) + self.kernel2(x1, x2)
+
+
+class ProductKernel(_Pair):
+    """kernel1(x1, x2) * kernel2(x1, x2)  (kernel.py:205-236)."""
+
+    def forward(self, x1, x2):
+        return self.kernel1(x1, x2) * self.kernel2(x1, x2)

@@ -59,7 +59,8 @@ enum {
   FFGP_KFUN_SE = 0,        /* phi = exp(-s/2)                                                 (K1, K2, K3) */
   FFGP_KFUN_MATERN12 = 1,  /* phi = exp(-sqrt(s)/rho)                       MaternKernel nu = 0.5, GaussianProcess/kernel.py:161-162 */
   FFGP_KFUN_MATERN32 = 2,  /* phi = (1 + a) exp(-a),          a = sqrt(3s)/rho           nu = 1.5, kernel.py:163-164 */
-  FFGP_KFUN_MATERN52 = 3   /* phi = (1 + a + a^2/3) exp(-a),  a = sqrt(5s)/rho           nu = 2.5, kernel.py:165-166 */
+  FFGP_KFUN_MATERN52 = 3,  /* phi = (1 + a + a^2/3) exp(-a),  a = sqrt(5s)/rho           nu = 2.5, kernel.py:165-166 */
+  FFGP_KFUN_RQ = 4         /* phi = (1 + s/(2 alpha))^(-alpha), kparam = alpha (learnable: g_kparam)  RationalQuadraticKernel, kernel.py:297-310 */
 };
 
 /* prediction outputs */
@@ -105,6 +106,7 @@ typedef struct {
   double* g_diag_vec_dev; /* [n]  (= diag G), optional */
   double* g_cov_dev;      /* [n, n] full symmetric d(value)/d(cov) (what torch's cholesky backward returns), optional */
   int ld_gcov;
+  double* g_kparam_dev;   /* [1] d(value)/d(kparam) for FFGP_KFUN_RQ (alpha is an nn.Parameter, kernel.py:295), optional */
 } ffgp_grads;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------ */
@@ -142,7 +144,7 @@ int ffgp_potrf_rows(ffgp_handle* h, double* A_dev, int n, int mtot, int lda);
    dK [n1, n2] (autograd through kernel.forward when a caller builds its own Sigma, e.g. GaussianProcess/cigp_withMean.py:52). */
 int ffgp_kernel_grad(ffgp_handle* h, const double* X1_dev, int n1, const double* X2_dev, int n2, int D,
                      const double* w_dev, const double* amp_dev, double clamp_min, int kfun, double kparam,
-                     const double* dK_dev, int ldk, double* g_w_dev, double* g_amp_dev);
+                     const double* dK_dev, int ldk, double* g_w_dev, double* g_amp_dev, double* g_kparam_dev);
 
 /* Rebuild the handle's store of inverted 128x128 diagonal blocks for a factor L that this handle did not just
    produce (the triangular solves and ffgp_potri consume it; ffgp_potrf leaves it up to date).               */

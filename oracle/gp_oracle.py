@@ -343,6 +343,92 @@ def cigp2023_nll_and_grads(X, Y, length_scale, scale, exp_format, noise_value, y
 # ----------------------------------------------------------------------------------------------------------
 # posteriors (rows P1-P3)
 # ----------------------------------------------------------------------------------------------------------
+# ---------------------------------------------------------------------------------------------------------------
+# Remaining kernels of GaussianProcess/kernel.py and their parameter gradients for a given upstream
+# weight  Gw = d(value)/dK  (for value = +LL of the V1 likelihood: Gw = -G; for a product kernel: Gw o K_other).
+# ---------------------------------------------------------------------------------------------------------------
+def linear_kernel(x1, x2, length_scales, signal_variance, center):
+    """LinearKernel.forward, kernel.py:45-63: |s| * ((x1 - c)/l) ((x2 - c)/l)^T  (raw l: no abs, no eps)."""
+    ls = np.asarray(length_scales, dtype=np.float64)
+    c = np.asarray(center, dtype=np.float64)
+    z1 = (np.asarray(x1, dtype=np.float64) - c) / ls
+    z2 = (np.asarray(x2, dtype=np.float64) - c) / ls
+    return z1 @ z2.T * abs(float(np.ravel(signal_variance)[0]))
+
+
+def linear_kernel_grads(X, length_scales, signal_variance, center, Gw):
+    ls = np.asarray(length_scales, dtype=np.float64)
+    c = np.asarray(center, dtype=np.float64)
+    s = float(np.ravel(signal_variance)[0])
+    Z = (np.asarray(X, dtype=np.float64) - c) / ls
+    dZ = abs(s) * (Gw + Gw.T) @ Z                     # value depends on Z through both factors
+    return {"length_scales": -(dZ * Z).sum(0) / ls,  # dZ/dl = -Z/l
+            "center": -dZ.sum(0) / ls,
+            "signal_variance": np.sign(s) * (Gw * (Z @ Z.T)).sum()}
+
+
+def rq_kernel(x1, x2, length_scale, signal_variance, alpha):
+    """RationalQuadraticKernel.forward, kernel.py:297-310 (norm-expansion distance, scalar raw parameters)."""
+    ls, sv, al = (float(np.ravel(v)[0]) for v in (length_scale, signal_variance, alpha))
+    return sv ** 2 * np.power(1.0 + 0.5 * sqdist_expanded(x1, x2) / al / ls ** 2, -al)
+
+
+def rq_kernel_grads(X, length_scale, signal_variance, alpha, Gw):
+    ls, sv, al = (float(np.ravel(v)[0]) for v in (length_scale, signal_variance, alpha))
+    u = 0.5 * sqdist_expanded(X, X) / al / ls ** 2
+    base = 1.0 + u
+    phi = np.power(base, -al)
+    return {"signal_variance": 2.0 * sv * (Gw * phi).sum(),
+            "length_scale": sv ** 2 * (Gw * (-al) * np.power(base, -al - 1.0) * (-2.0 * u / ls)).sum(),
+            "alpha": sv ** 2 * (Gw * phi * (u / base - np.log(base))).sum()}
+
+
+def ard_kernel_grads(X, length_scales, signal_variance, Gw, nu=None, rho=1.0):
+    """ARDKernel (nu=None) / MaternKernel gradients for an upstream weight on K(X, X); same algebra as
+    cigp_ll_and_grads, sign-free."""
+    X = np.asarray(X, dtype=np.float64)
+    p = np.asarray(length_scales, dtype=np.float64)
+    s = float(np.ravel(signal_variance)[0])
+    ell = np.abs(p) + EPS
+    sqc = cdist_sq(X / ell, X / ell)
+    E = np.exp(-0.5 * sqc) if nu is None else matern_profile(sqc, nu, rho)
+    Gs = 0.5 * (Gw + Gw.T)
+    if nu is None:
+        W = Gs * np.abs(s) * E
+    else:
+        W = np.where(sqc > 1e-30, Gs * np.abs(s) * matern_profile_m2d(np.maximum(sqc, 1e-30), nu, rho), 0.0)
+    W = W.copy()
+    np.fill_diagonal(W, 0.0)
+    r = W.sum(1)
+    quad = 2.0 * ((r[:, None] * X * X).sum(0) - (X * (W @ X)).sum(0))   # sum_ij W_ij (x_ik - x_jk)^2
+    # dK/dl_k = K' d(sq)/dl_k with d(sq)/dl_k = -2 sign(p) (x_ik - x_jk)^2 / l^3 and W = -2 Gw o K'
+    return {"signal_variance": np.sign(s) * (Gw * E).sum(),
+            "length_scales": np.sign(p) / ell ** 3 * quad}
+
+
+def composed_ll_and_grads(X, Y, parts, combine, sigma_fn, dsigma_scalar, variant="v1"):
+    """LL (+LL as the reference's `negative_log_likelihood` returns it, or the V2 `log_likelihood`) of a GP whose
+    kernel is the sum / product of `parts` = [(K_fn(X)->K, grads_fn(X, Gw)->dict), ...]; sigma_fn(K) -> Sigma.
+    Returns LL, [grads per part], d LL / d Sigma (symmetric), d LL / dY."""
+    Ks = [kf(X) for kf, _ in parts]
+    K = Ks[0] + Ks[1] if combine == "sum" else Ks[0] * Ks[1]
+    S = sigma_fn(K)
+    Y = np.asarray(Y, dtype=np.float64)
+    d = Y.shape[1]
+    if variant == "v1":
+        nll, L, _ = nll_v1_from_sigma(S, Y)
+        G, A = _G_matrix(L, Y, d)
+        ll, dS, dY = -nll, -G, -A
+    else:
+        ll, dS, dY = ll_v2_grads(Y, S)
+    dK = dS + dsigma_scalar(dS, K)      # chain through any K-dependent diagonal term (pack's mean(K) jitter)
+    out = []
+    for i, (_, gf) in enumerate(parts):
+        Gw = dK if combine == "sum" else dK * Ks[1 - i]
+        out.append(gf(X, Gw))
+    return ll, out, dS, dY
+
+
 def cigp_forward(X, Y, Xs, kernel_fn, log_beta):
     """P1: cigp.forward, cigp_v10.py:24-48.  y_var is ignored; the noise scalar lands on EVERY entry."""
     K = kernel_fn(X, X)

@@ -349,6 +349,88 @@ def main():
              g_log_beta=m.log_beta.grad, g_Y=Y.grad, length_scales=k.length_scales, g_length_scales=k.length_scales.grad,
              signal_variance=k.signal_variance, g_signal_variance=k.signal_variance.grad, Xs=Xs, mean=mean, var=var)
 
+    # ------------------------------------------------------------------ Linear / RQ / Sum / Product kernels
+    g3 = torch.Generator().manual_seed(888)   # own stream again: older fixtures stay bit-reproducible
+
+    def rnd(*shape, lo=0.5, hi=1.5):
+        return torch.rand(*shape, generator=g3) * (hi - lo) + lo
+
+    def grads_of(mod):
+        return {"g__" + n.replace(".", "__"): p.grad for n, p in mod.named_parameters()}
+
+    def params_of(mod):
+        return {"p__" + n.replace(".", "__"): p for n, p in mod.named_parameters()}
+
+    D = 3
+    x1, x2 = torch.rand(33, D, generator=g3) * 2 - 0.5, torch.rand(21, D, generator=g3) * 2 - 0.5
+    lin = rk.LinearKernel(D)
+    rq = rk.RationalQuadraticKernel(length_scale=0.8, signal_variance=-1.2, alpha=1.7)
+    with torch.no_grad():
+        lin.length_scales.copy_(rnd(D) * torch.tensor([1.0, -1.0, 1.0]))
+        lin.center.copy_(rnd(D, lo=-0.3, hi=0.3))
+        lin.signal_variance.copy_(torch.tensor([-0.7]))
+    with torch.no_grad():
+        save("k_linear_rq", x1=x1, x2=x2, K_lin=lin(x1, x2), K_rq=rq(x1, x2), **params_of(lin),
+             rq_length_scale=rq.length_scale, rq_signal_variance=rq.signal_variance, rq_alpha=rq.alpha)
+
+    # cigp with the reference demos' own kernel: SumKernel(LinearKernel, MaternKernel)  (cigp_v10.py:81,111,147)
+    n, d = 120, 2
+    X, Y = make_xy(g3, n, D, d)
+    Y = Y.clone().requires_grad_(True)
+    k = rk.SumKernel(rk.LinearKernel(D), rk.MaternKernel(D))
+    with torch.no_grad():
+        k.kernel1.length_scales.copy_(rnd(D, lo=1.0, hi=2.0))
+        k.kernel1.center.copy_(rnd(D, lo=-0.2, hi=0.2))
+        k.kernel1.signal_variance.copy_(torch.tensor([0.3]))
+        k.kernel2.length_scales.copy_(rnd(D) * torch.tensor([-1.0, 1.0, 1.0]))
+        k.kernel2.signal_variance.copy_(torch.tensor([1.4]))
+    m = RCIGP(k, log_beta=1.2)
+    ll = m.negative_log_likelihood(X, Y)
+    ll.backward()
+    Xs = torch.rand(17, D, generator=g3)
+    with torch.no_grad():
+        mean, var = m(X, Y.detach(), Xs)
+    save("cigp_sum_linear_matern", X=X, Y=Y, Xs=Xs, ll=ll, g_Y=Y.grad, mean=mean, var=var, **params_of(m), **grads_of(m))
+
+    # cigp with the rational-quadratic kernel (learnable alpha), y_var given
+    X, Y = make_xy(g3, n, D, d)
+    Y = Y.clone().requires_grad_(True)
+    y_var = torch.diag(torch.rand(n, generator=g3) * 0.05) + 0.01 * torch.rand(n, n, generator=g3)  # only the diagonal counts
+    m = RCIGP(rk.RationalQuadraticKernel(length_scale=0.6, signal_variance=1.3, alpha=0.9), log_beta=0.7)
+    ll = m.negative_log_likelihood(X, [Y, y_var])
+    ll.backward()
+    with torch.no_grad():
+        mean, var = m(X, [Y.detach(), y_var], Xs)
+    save("cigp_rq_yvar", X=X, Y=Y, y_var=y_var, Xs=Xs, ll=ll, g_Y=Y.grad, mean=mean, var=var, **params_of(m), **grads_of(m))
+
+    # gp_computation_pack.negative_log_likelihood with ProductKernel(ARDKernel, RationalQuadraticKernel)
+    X, Y = make_xy(g3, n, D, 1)
+    Y = Y.clone().requires_grad_(True)
+    k = rk.ProductKernel(rk.ARDKernel(D), rk.RationalQuadraticKernel(length_scale=1.1, signal_variance=0.9, alpha=2.2))
+    with torch.no_grad():
+        k.kernel1.length_scales.copy_(rnd(D) * torch.tensor([1.0, 1.0, -1.0]))
+        k.kernel1.signal_variance.copy_(torch.tensor([-1.6]))
+    log_beta = torch.nn.Parameter(torch.tensor([1.5]))
+    ll = rpack.negative_log_likelihood(k, log_beta, X, Y)
+    ll.backward()
+    save("pack_prod_ard_rq", X=X, Y=Y, ll=ll, g_Y=Y.grad, log_beta=log_beta, g_log_beta=log_beta.grad, **params_of(k),
+         **grads_of(k))
+
+    # GP_basic with SumKernel(LinearKernel, ARDKernel): V2 likelihood + conditional-Gaussian forward
+    X, Y = make_xy(g3, n, D, d)
+    Y = Y.clone().requires_grad_(True)
+    k = rk.SumKernel(rk.LinearKernel(D), rk.ARDKernel(D))
+    with torch.no_grad():
+        k.kernel1.length_scales.copy_(rnd(D, lo=1.0, hi=2.0))
+        k.kernel1.signal_variance.copy_(torch.tensor([0.5]))
+        k.kernel2.length_scales.copy_(rnd(D))
+    m = RGPB(k, noise_variance=0.4)
+    ll = m.log_likelihood(X, Y)
+    ll.sum().backward()
+    with torch.no_grad():
+        mu, var = m(X, Y.detach(), Xs)
+    save("gpbasic_sum_linear_ard", X=X, Y=Y, Xs=Xs, ll=ll, g_Y=Y.grad, mu=mu, var=var, **params_of(m), **grads_of(m))
+
 
     os.chdir(cwd)
 

@@ -136,6 +136,161 @@ def test_matern_golden(golden, nu):
         kernel.MaternKernel(3, nu=2.0).kfun()
 
 
+# ------------------------------------------------------------- Linear / RQ / Sum / Product kernels
+def _load_params(mod, g, prefix=""):
+    """copy p__<path> arrays of a fixture into the module's parameters; returns {path: golden gradient}"""
+    want = {}
+    with torch.no_grad():
+        for name, p in mod.named_parameters():
+            key = prefix + name.replace(".", "__")
+            p.copy_(torch.tensor(g["p__" + key]).reshape(p.shape))
+            want[name] = g["g__" + key] if ("g__" + key) in g else None
+    return want
+
+
+def _check_param_grads(mod, want, tol=1e-8):
+    for name, p in mod.named_parameters():
+        if want[name] is not None:
+            assert p.grad is not None, name
+            assert rel(p.grad, want[name]) < tol, name
+
+
+def test_linear_rq_kernels_golden(golden):
+    from fidelityfusion_amd import kernel
+    g = golden("k_linear_rq")
+    lin = kernel.LinearKernel(3)
+    with torch.no_grad():
+        lin.length_scales.copy_(torch.tensor(g["p__length_scales"]))
+        lin.center.copy_(torch.tensor(g["p__center"]))
+        lin.signal_variance.copy_(torch.tensor(g["p__signal_variance"]))
+    assert rel(lin(T(g["x1"]), T(g["x2"])), g["K_lin"]) < 1e-13
+    rq = kernel.RationalQuadraticKernel(float(g["rq_length_scale"][0]), float(g["rq_signal_variance"][0]),
+                                        float(g["rq_alpha"][0]))
+    assert rel(rq(T(g["x1"]), T(g["x2"])), g["K_rq"]) < 1e-12
+    # CPU tensors in, CPU tensor out (the reference's 2024 API is CPU-only)
+    K = rq(torch.tensor(g["x1"]), torch.tensor(g["x2"]))
+    assert K.device.type == "cpu" and rel(K, g["K_rq"]) < 1e-12
+
+
+@pytest.mark.parametrize("where", ["cuda", "cpu"])
+def test_cigp_sum_linear_matern_golden(golden, where):
+    """cigp over SumKernel(LinearKernel, MaternKernel), the kernel of the reference's own demos (cigp_v10.py:81,111,147):
+    composed on the device, factored through ffgp_problem.cov_dev, gradients through ffgp_kernel_grad / ffgp_gemm."""
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp
+    g = golden("cigp_sum_linear_matern")
+    m = cigp(kernel.SumKernel(kernel.LinearKernel(3), kernel.MaternKernel(3)), 0.0)
+    want = _load_params(m, g)
+    dev = DEV if where == "cuda" else "cpu"
+    m = m.to(dev)
+    X, Xs = torch.tensor(g["X"], device=dev), torch.tensor(g["Xs"], device=dev)
+    Y = torch.tensor(g["Y"], device=dev, requires_grad=True)
+    ll = m.negative_log_likelihood(X, Y)
+    assert ll.device.type == where and rel(ll, g["ll"]) < 1e-11
+    ll.backward()
+    assert rel(Y.grad, g["g_Y"]) < 1e-8
+    _check_param_grads(m, want)
+    with torch.no_grad():
+        mean, var = m(X, Y.detach(), Xs)
+    assert rel(mean, g["mean"]) < 1e-8 and rel(var, g["var"]) < 1e-8
+
+
+def test_cigp_rq_yvar_golden(golden):
+    """RationalQuadraticKernel on the FUSED path (profile FFGP_KFUN_RQ; alpha's gradient = ffgp_grads.g_kparam_dev)"""
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp
+    g = golden("cigp_rq_yvar")
+    m = cigp(kernel.RationalQuadraticKernel(), 0.0)
+    want = _load_params(m, g)
+    m = m.to(DEV)
+    Y = T(g["Y"], grad=True)
+    ll = m.negative_log_likelihood(T(g["X"]), [Y, T(g["y_var"])])
+    assert rel(ll, g["ll"]) < 1e-11
+    ll.backward()
+    assert rel(Y.grad, g["g_Y"]) < 1e-8
+    _check_param_grads(m, want)
+    with torch.no_grad():
+        mean, var = m(T(g["X"]), [Y.detach(), T(g["y_var"])], T(g["Xs"]))
+    assert rel(mean, g["mean"]) < 1e-8 and rel(var, g["var"]) < 1e-8
+    # the standalone kernel call differentiates alpha too (ffgp_kernel_grad): compare with the closed form
+    k = m.kernel
+    for p in k.parameters():
+        p.grad = None
+    dK = T(np.random.default_rng(0).standard_normal((120, 17)))
+    (k(T(g["X"]), T(g["Xs"])) * dK).sum().backward()
+    X, Xs = g["X"], g["Xs"]
+    ls, sv, al = (float(g["p__kernel__" + n][0]) for n in ("length_scale", "signal_variance", "alpha"))
+    sq = ((X[:, None, :] - Xs[None, :, :]) ** 2).sum(-1)
+    u = 0.5 * sq / al / ls ** 2
+    phi = (1 + u) ** (-al)
+    Gw = dK.cpu().numpy()
+    assert rel(k.alpha.grad, sv ** 2 * (Gw * phi * (u / (1 + u) - np.log1p(u))).sum()) < 1e-10
+    assert rel(k.signal_variance.grad, 2 * sv * (Gw * phi).sum()) < 1e-10
+    assert rel(k.length_scale.grad, sv ** 2 * (Gw * al * (1 + u) ** (-al - 1) * 2 * u / ls).sum()) < 1e-10
+
+
+def test_pack_prod_ard_rq_golden(golden):
+    import fidelityfusion_amd.gp_computation_pack as gp_pack
+    from fidelityfusion_amd import kernel
+    g = golden("pack_prod_ard_rq")
+    k = kernel.ProductKernel(kernel.ARDKernel(3), kernel.RationalQuadraticKernel())
+    want = _load_params(k, g)
+    k = k.to(DEV)
+    log_beta = T(g["log_beta"], grad=True)
+    Y = T(g["Y"], grad=True)
+    ll = gp_pack.negative_log_likelihood(k, log_beta, T(g["X"]), Y)
+    assert rel(ll, g["ll"]) < 1e-11
+    ll.backward()
+    assert rel(Y.grad, g["g_Y"]) < 1e-8
+    assert rel(log_beta.grad, g["g_log_beta"]) < 1e-8
+    _check_param_grads(k, want)
+
+
+def test_gpbasic_sum_linear_ard_golden(golden):
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.gp_basic import GP_basic
+    g = golden("gpbasic_sum_linear_ard")
+    m = GP_basic(kernel.SumKernel(kernel.LinearKernel(3), kernel.ARDKernel(3)), 1.0)
+    want = _load_params(m, g)
+    m = m.to(DEV)
+    Y = T(g["Y"], grad=True)
+    ll = m.log_likelihood(T(g["X"]), Y)
+    assert rel(ll, g["ll"]) < 1e-11
+    ll.sum().backward()
+    assert rel(Y.grad, g["g_Y"]) < 1e-8
+    _check_param_grads(m, want)
+    with torch.no_grad():
+        mu, var = m(T(g["X"]), Y.detach(), T(g["Xs"]))
+    assert tuple(mu.shape) == g["mu"].shape
+    assert rel(mu, g["mu"]) < 1e-8 and rel(var, g["var"]) < 1e-8
+
+
+def test_user_defined_kernel_module():
+    """Any nn.Module kernel written in plain torch (CPU parameters, no descriptor) still runs: its K is moved to the
+    device and factored there; gradients flow back through torch autograd into the user's parameters."""
+    from fidelityfusion_amd.cigp_v10 import cigp
+    from oracle import gp_oracle as O
+
+    class Poly(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = torch.nn.Parameter(torch.tensor([0.7]))
+
+        def forward(self, x1, x2):
+            return (x1 @ x2.T + self.c) ** 2
+
+    rng = np.random.default_rng(3)
+    X, Y = rng.uniform(size=(90, 2)), rng.standard_normal((90, 2))
+    m = cigp(Poly(), 0.5)
+    ll = m.negative_log_likelihood(torch.tensor(X), torch.tensor(Y))
+    ll.backward()
+    K = (X @ X.T + 0.7) ** 2
+    nll, L, _ = O.nll_v1_from_sigma(O.sigma_cigp(K, 0.5), Y)
+    assert rel(ll, -nll) < 1e-11
+    G, _ = O._G_matrix(L, Y, 2)
+    assert rel(m.kernel.c.grad, (-G * 2 * (X @ X.T + 0.7)).sum()) < 1e-8
+
+
 @pytest.mark.parametrize("tag", ["d1", "d5"])
 def test_pack_nll_golden(golden, tag):
     import fidelityfusion_amd.gp_computation_pack as gp_pack

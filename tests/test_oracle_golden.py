@@ -173,3 +173,113 @@ def test_matern(golden, nu):
     mean, var = O.cigp_forward(g["X"], g["Y"], g["Xs"], kf, g["log_beta"])
     close(mean, g["mean"], 1e-9)
     close(var, g["var"], 1e-9)
+
+
+# ------------------------------------------------------------------ Linear / RQ / Sum / Product kernels
+def _pg(g, prefix):
+    """parameters / gradients stored as p__<module path> / g__<module path> by the generator"""
+    return ({k[len("p__" + prefix):]: g[k] for k in g if k.startswith("p__" + prefix)},
+            {k[len("g__" + prefix):]: g[k] for k in g if k.startswith("g__" + prefix)})
+
+
+def _lin_part(p):
+    return (lambda X: O.linear_kernel(X, X, p["length_scales"], p["signal_variance"], p["center"]),
+            lambda X, Gw: O.linear_kernel_grads(X, p["length_scales"], p["signal_variance"], p["center"], Gw))
+
+
+def _ard_part(p, nu=None):
+    kf = (lambda X: O.ard_kernel(X, X, p["length_scales"], p["signal_variance"])) if nu is None else \
+         (lambda X: O.matern_kernel(X, X, p["length_scales"], p["signal_variance"], nu, 1.0))
+    return kf, lambda X, Gw: O.ard_kernel_grads(X, p["length_scales"], p["signal_variance"], Gw, nu=nu)
+
+
+def _rq_part(p):
+    return (lambda X: O.rq_kernel(X, X, p["length_scale"], p["signal_variance"], p["alpha"]),
+            lambda X, Gw: O.rq_kernel_grads(X, p["length_scale"], p["signal_variance"], p["alpha"], Gw))
+
+
+def test_k_linear_rq(golden):
+    g = golden("k_linear_rq")
+    close(O.linear_kernel(g["x1"], g["x2"], g["p__length_scales"], g["p__signal_variance"], g["p__center"]), g["K_lin"], 1e-12)
+    close(O.rq_kernel(g["x1"], g["x2"], g["rq_length_scale"], g["rq_signal_variance"], g["rq_alpha"]), g["K_rq"], 1e-12)
+
+
+def test_cigp_sum_linear_matern(golden):
+    """cigp over SumKernel(LinearKernel, MaternKernel) -- the reference demos' kernel (cigp_v10.py:81,111,147)"""
+    g = golden("cigp_sum_linear_matern")
+    p1, g1 = _pg(g, "kernel__kernel1__")
+    p2, g2 = _pg(g, "kernel__kernel2__")
+    lb = g["p__log_beta"]
+    ll, (o1, o2), dS, dY = O.composed_ll_and_grads(g["X"], g["Y"], [_lin_part(p1), _ard_part(p2, nu=2.5)], "sum",
+                                                   lambda K: O.sigma_cigp(K, lb), lambda dS, K: 0.0)
+    close(ll, g["ll"])
+    close(dY, g["g_Y"], 1e-8)
+    close(-np.exp(-lb[0]) * np.trace(dS), g["g__log_beta"], 1e-8)
+    for k in g1:
+        close(o1[k], g1[k], 1e-8)
+    for k in g2:
+        close(o2[k], g2[k], 1e-8)
+    kf = lambda a, b: (O.linear_kernel(a, b, p1["length_scales"], p1["signal_variance"], p1["center"]) +
+                       O.matern_kernel(a, b, p2["length_scales"], p2["signal_variance"], 2.5, 1.0))
+    mean, var = O.cigp_forward(g["X"], g["Y"], g["Xs"], kf, lb)
+    close(mean, g["mean"], 1e-8)
+    close(var, g["var"], 1e-8)
+
+
+def test_cigp_rq_yvar(golden):
+    g = golden("cigp_rq_yvar")
+    p, gr = _pg(g, "kernel__")
+    lb = g["p__log_beta"]
+    K = O.rq_kernel(g["X"], g["X"], p["length_scale"], p["signal_variance"], p["alpha"])
+    nll, L, _ = O.nll_v1_from_sigma(O.sigma_cigp(K, lb, g["y_var"]), g["Y"])
+    close(-nll, g["ll"])
+    G, A = O._G_matrix(L, g["Y"], g["Y"].shape[1])
+    close(-A, g["g_Y"], 1e-8)
+    close(np.exp(-lb[0]) * np.trace(G), g["g__log_beta"], 1e-8)
+    o = O.rq_kernel_grads(g["X"], p["length_scale"], p["signal_variance"], p["alpha"], -G)
+    for k in gr:
+        close(o[k], gr[k], 1e-8)
+    kf = lambda a, b: O.rq_kernel(a, b, p["length_scale"], p["signal_variance"], p["alpha"])
+    mean, var = O.cigp_forward(g["X"], g["Y"], g["Xs"], kf, lb)
+    close(mean, g["mean"], 1e-8)
+    close(var, g["var"], 1e-8)
+
+
+def test_pack_prod_ard_rq(golden):
+    """gp_computation_pack.negative_log_likelihood over ProductKernel(ARDKernel, RationalQuadraticKernel)"""
+    g = golden("pack_prod_ard_rq")
+    p1, g1 = _pg(g, "kernel1__")
+    p2, g2 = _pg(g, "kernel2__")
+    lb = g["log_beta"]
+    n = g["X"].shape[0]
+    ll, (o1, o2), dS, dY = O.composed_ll_and_grads(
+        g["X"], g["Y"], [_ard_part(p1), _rq_part(p2)], "prod", lambda K: O.sigma_pack(K, lb),
+        lambda dS, K: O.JITTER * np.trace(dS) / (n * n))       # Sigma's mean(K) jitter: every dK entry gets tr(dS)/n^2
+    close(ll, g["ll"])
+    close(dY, g["g_Y"], 1e-8)
+    close(-np.exp(-lb[0]) * np.trace(dS), g["g_log_beta"], 1e-8)
+    for k in g1:
+        close(o1[k], g1[k], 1e-8)
+    for k in g2:
+        close(o2[k], g2[k], 1e-8)
+
+
+def test_gpbasic_sum_linear_ard(golden):
+    g = golden("gpbasic_sum_linear_ard")
+    p1, g1 = _pg(g, "kernel__kernel1__")
+    p2, g2 = _pg(g, "kernel__kernel2__")
+    nv = g["p__noise_variance"]
+    ll, (o1, o2), dS, dY = O.composed_ll_and_grads(g["X"], g["Y"], [_lin_part(p1), _ard_part(p2)], "sum",
+                                                   lambda K: O.sigma_basic(K, nv), lambda dS, K: 0.0, variant="v2")
+    close(ll, g["ll"])
+    close(dY, g["g_Y"], 1e-8)
+    close(2.0 * nv[0] * np.trace(dS), g["g__noise_variance"], 1e-8)
+    for k in g1:
+        close(o1[k], g1[k], 1e-8)
+    for k in g2:
+        close(o2[k], g2[k], 1e-8)
+    kf = lambda a, b: (O.linear_kernel(a, b, p1["length_scales"], p1["signal_variance"], p1["center"]) +
+                       O.ard_kernel(a, b, p2["length_scales"], p2["signal_variance"]))
+    mu, var = O.gp_basic_forward(g["X"], g["Y"], g["Xs"], kf, nv)
+    close(mu, g["mu"], 1e-8)
+    close(var, g["var"], 1e-8)
