@@ -172,6 +172,7 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->la_split = (int)value;
   } else if (!strcmp(key, "lookahead")) {
     h->lookahead = (int)value;
+
   } else {
     return FFGP_ERR_ARG;
   }

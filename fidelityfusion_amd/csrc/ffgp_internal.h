@@ -78,6 +78,8 @@ struct GemmArgs {
   double alpha, beta;  // C = alpha*op(A)op(B) + beta*C   (beta == 0 -> C not read)
   int tiles_m, tiles_n;
   int total_tiles;
+  int grid;            // gridDim.x (= total_tiles)
+  int fast;            // alpha = +-1, beta in {0,1}, offsets fit 32 bits: interior tiles take the scalar-addressed form
   int avec, bvec;      // 16-byte vector loads allowed for A / B
   int prio;            // raise the wave priority (look-ahead panel GEMMs)
   int batch;           // gridDim.y: identical problems at fixed element strides

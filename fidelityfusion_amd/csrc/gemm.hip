@@ -22,6 +22,30 @@
 
 #define BK 16
 
+// tools/trace_gemm.py builds a second library with -DFFGP_GEMM_TRACE: every workgroup stamps s_memtime at the
+// phase boundaries of each tile (never compiled into libffgp.so)
+#ifdef FFGP_GEMM_TRACE
+__device__ unsigned long long* ffgp_trace_buf = nullptr;
+extern "C" int ffgp_debug_set_trace(void* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(ffgp_trace_buf), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#define FFGP_TRACE(slot)                                                                            \
+  do {                                                                                              \
+    if (tid == 0 && ffgp_trace_buf) {                                                               \
+      ffgp_trace_buf[(size_t)bid * 8 + (slot)] = __builtin_readcyclecounter();                      \
+      if ((slot) == 0) {                                                                            \
+        unsigned hwid = 0, xcc = 0;                                                                 \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));                          \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                          \
+        ffgp_trace_buf[(size_t)bid * 8 + 6] = ((unsigned long long)xcc << 32) | hwid;               \
+        ffgp_trace_buf[(size_t)bid * 8 + 7] = wall_clock64();                                       \
+      }                                                                                             \
+    }                                                                                               \
+  } while (0)
+#else
+#define FFGP_TRACE(slot)
+#endif
+
 // Tile geometry: TS x TS output tile per 256-thread workgroup, 4 waves as 2 x 2, each wave (TS/2) x (TS/2)
 //   TS = 128: 4 x 4 MFMA tiles per wave (128 accumulator VGPRs), 72 KiB LDS, 2 workgroups per CU -- the throughput shape
 //   TS =  64: 2 x 2 MFMA tiles per wave, 20 KiB LDS, up to 4 workgroups per CU -- the latency shape: a quarter of the
@@ -109,33 +133,46 @@ __device__ __forceinline__ void frag_offsets(int lane, int wbase, int (&off)[4])
   }
 }
 
+// Tile order -> (ti, tj).  Everything here is wave-uniform; it is written without integer divisions on the common
+// path (full 8-row bands) so it stays on the scalar unit: a workgroup's prologue shares its SIMDs with the MFMA
+// stream of the other resident workgroup, and every vector instruction it needs waits behind a 64-cycle MFMA.
 __device__ __forceinline__ void decode_tile(int t, int mode, int tiles_m, int tiles_n, int& ti, int& tj) {
   const int G = 8;
   if (mode == TILES_FULL) {
     const int band_sz = G * tiles_n;
-    const int b = t / band_sz;
-    const int r0 = b * G;
+    int r0 = 0;
+    while (t >= band_sz) {
+      t -= band_sz;
+      r0 += G;
+    }
     const int hgt = min(G, tiles_m - r0);
-    const int tt = t - b * band_sz;
-    tj = tt / hgt;
-    ti = r0 + tt % hgt;
+    if (hgt == G) {
+      tj = t >> 3;
+      ti = r0 + (t & 7);
+    } else {
+      tj = t / hgt;
+      ti = r0 + t % hgt;
+    }
   } else {
     // lower trapezoid (m >= n, origin on the diagonal): tile row ti owns columns 0..min(ti, tiles_n-1)
     int r0 = 0, hgt = 0, fc = 0;
     while (true) {
       hgt = min(G, tiles_m - r0);
-      fc = min(r0, tiles_n);  // columns every row of the band owns
-      int tri = 0;
-      for (int c = 0; c < hgt; ++c)
-        if (r0 + c < tiles_n) tri += hgt - c;
-      const int cnt = hgt * fc + tri;
+      fc = min(r0, tiles_n);                      // columns every row of the band owns
+      const int nc = max(0, min(hgt, tiles_n - r0));  // rows of the band that reach the diagonal
+      const int cnt = hgt * fc + nc * hgt - nc * (nc - 1) / 2;
       if (t < cnt) break;
       t -= cnt;
       r0 += hgt;
     }
     if (t < hgt * fc) {
-      tj = t / hgt;
-      ti = r0 + t % hgt;
+      if (hgt == G) {
+        tj = t >> 3;
+        ti = r0 + (t & 7);
+      } else {
+        tj = t / hgt;
+        ti = r0 + t % hgt;
+      }
     } else {
       t -= hgt * fc;
       int c = 0;
@@ -147,6 +184,114 @@ __device__ __forceinline__ void decode_tile(int t, int mode, int tiles_m, int ti
       ti = r0 + c + t;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Fast form: interior tile, 16-byte aligned operands, alpha = +-1, beta in {0, 1}, no partial store.
+// Every global address is  (uniform 64-bit base in SGPRs) + (loop-invariant 32-bit per-lane offset) + immediate,
+// so a tile's prologue and epilogue contain almost no vector-ALU instructions: the C tile is loaded straight into
+// the accumulators while the first operand tiles are in flight, alpha = -1 is the MFMA's own negate-A modifier,
+// and the epilogue is 64 plain stores.
+// ------------------------------------------------------------------------------------------------------------
+template <int OP, int TS>
+__device__ __forceinline__ void lane_byte_offsets(int ld, int tid, unsigned (&voff)[Geo<TS>::NLD]) {
+#pragma unroll
+  for (int i = 0; i < Geo<TS>::NLD; ++i) {
+    const int idx = tid + 256 * i;
+    if (OP == OP_KMAJOR) {
+      const int row = idx >> 3, ch = idx & 7;
+      voff[i] = (unsigned)(row * ld + ch * 2) * 8u;
+    } else {
+      const int kk = idx / (TS / 2), c2 = idx % (TS / 2);
+      voff[i] = (unsigned)(kk * ld + c2 * 2) * 8u;
+    }
+  }
+}
+
+template <int TS>
+__device__ __forceinline__ void gload_fast(const char* __restrict__ base, const unsigned (&voff)[Geo<TS>::NLD],
+                                           d2_t (&v)[Geo<TS>::NLD]) {
+#pragma unroll
+  for (int i = 0; i < Geo<TS>::NLD; ++i) v[i] = *reinterpret_cast<const d2_t*>(base + voff[i]);
+}
+
+template <int OPA, int OPB, int TM, int TN, bool NEG>
+__device__ __forceinline__ void gemm_tile_fast(const char* __restrict__ baseA, const char* __restrict__ baseB, size_t stepA,
+                                               size_t stepB, char* __restrict__ baseC, size_t row4_bytes, unsigned voffC,
+                                               bool load_c, double* smem, int nkt, int tid,
+                                               const unsigned (&voffA)[Geo<TM>::NLD], const unsigned (&voffB)[Geo<TN>::NLD],
+                                               const int (&offA)[4], const int (&offB)[4], int trace_bid) {
+  constexpr int WM = Geo<TM>::WT, WN = Geo<TN>::WT;
+  constexpr int BUFA = Geo<TM>::OPBUF, BUFB = Geo<TN>::OPBUF, STAGE = BUFA + BUFB;
+  constexpr int subA = (OPA == OP_KMAJOR) ? 256 : 16;
+  constexpr int subB = (OPB == OP_KMAJOR) ? 256 : 16;
+  d2_t ra[Geo<TM>::NLD], rb[Geo<TN>::NLD];
+  gload_fast<TM>(baseA, voffA, ra);
+  gload_fast<TN>(baseB, voffB, rb);
+  d4_t acc[WM][WN];
+  if (load_c) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const char* rowb = baseC + (size_t)(i * 4 + r) * row4_bytes;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j][r] = *reinterpret_cast<const double*>(rowb + voffC + j * 128);
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+  }
+  sstore<OPA, TM>(smem, tid, ra);
+  sstore<OPB, TN>(smem + BUFA, tid, rb);
+  __syncthreads();
+#ifdef FFGP_GEMM_TRACE
+  if (tid == 0 && ffgp_trace_buf) ffgp_trace_buf[(size_t)trace_bid * 8 + 1] = __builtin_readcyclecounter();
+#endif
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int par = kt & 1;
+    const double* sA = smem + par * STAGE;
+    const double* sB = sA + BUFA;
+    const bool more = (kt + 1 < nkt);
+    if (more) {
+      baseA += stepA;
+      baseB += stepB;
+      gload_fast<TM>(baseA, voffA, ra);
+      gload_fast<TN>(baseB, voffB, rb);
+    }
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+      double a[WM], b[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a[i] = sA[offA[kq] + i * subA];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) b[j] = sB[offB[kq] + j * subB];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, NEG ? 1 : 0);  // blgp bit 0: -A
+    }
+    if (more) {
+      double* dA = smem + (par ^ 1) * STAGE;
+      sstore<OPA, TM>(dA, tid, ra);
+      sstore<OPB, TN>(dA + BUFA, tid, rb);
+    }
+    __syncthreads();
+  }
+#ifdef FFGP_GEMM_TRACE
+  if (tid == 0 && ffgp_trace_buf) ffgp_trace_buf[(size_t)trace_bid * 8 + 2] = __builtin_readcyclecounter();
+#endif
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      char* rowb = baseC + (size_t)(i * 4 + r) * row4_bytes;
+#pragma unroll
+      for (int j = 0; j < WN; ++j) *reinterpret_cast<double*>(rowb + voffC + j * 128) = acc[i][j][r];
+    }
 }
 
 template <int OPA, int OPB, int TM, int TN, bool GUARD>
@@ -206,28 +351,31 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
   const double* __restrict__ Bg = p.B + (size_t)blockIdx.y * p.sB;
   double* __restrict__ Cg = p.C + (size_t)blockIdx.y * p.sC;
 
-  // XCD-aware bijective remap of the block id, then banded tile order
+  int offA[4], offB[4];
+  frag_offsets<OPA, TM>(lane, wm * (TM / 2), offA);
+  frag_offsets<OPB, TN>(lane, wn * (TN / 2), offB);
+  const bool fast_ab = p.fast && p.avec && p.bvec;
+
+  // One workgroup per tile.  (A persistent 2-per-CU grid was measured and dropped: it keeps the two workgroups of
+  // a CU in lock-step, so their prologues and epilogues coincide instead of hiding under each other's k loop.)
+  const int bid = blockIdx.x;
+  FFGP_TRACE(0);
+  // XCD-aware bijective remap of the block id, then banded tile order (hardware deals workgroup ids round-robin
+  // over the 8 XCDs).
   // (triangular-operand launches have k ranges that shrink along the tile order: giving each XCD a contiguous
   //  chunk would leave all the long tiles on XCD 0, so those launches keep the round-robin block order)
-  int t = blockIdx.x;
+  int t = bid;
   if (!(p.lo_i | p.lo_j | p.hi_i | p.hi_j)) {
-    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int nwg = p.total_tiles;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   int ti, tj;
   decode_tile(t, MODE, p.tiles_m, p.tiles_n, ti, tj);
+  // wave-uniform by construction; pin them to SGPRs so every tile base below is scalar arithmetic
+  ti = __builtin_amdgcn_readfirstlane(ti);
+  tj = __builtin_amdgcn_readfirstlane(tj);
   const int m0 = ti * TM, n0 = tj * TN;
-
-  d4_t acc[WM][WN];
-#pragma unroll
-  for (int i = 0; i < WM; ++i)
-#pragma unroll
-    for (int j = 0; j < WN; ++j) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
-
-  int offA[4], offB[4];
-  frag_offsets<OPA, TM>(lane, wm * (TM / 2), offA);
-  frag_offsets<OPB, TN>(lane, wn * (TN / 2), offB);
 
   // k range of this tile (triangular operands skip the k-tiles that are structurally zero)
   int kbeg = 0, kend = p.k;
@@ -238,14 +386,45 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
   const int kt0 = kbeg / BK;
   const int kt1 = (kend + BK - 1) / BK;
 
+  const bool interior = (m0 + TM <= p.m) && (n0 + TN <= p.n) && (kt1 * BK <= p.k) && p.avec && p.bvec;
+  if (fast_ab && interior && kt0 < kt1 && !(MODE == TILES_LOWER && m0 < n0 + TN)) {
+    const size_t k0 = (size_t)kt0 * BK;
+    const char* bA = reinterpret_cast<const char*>(Ag) +
+                     ((OPA == OP_KMAJOR) ? ((size_t)m0 * p.lda + k0) : (k0 * p.lda + m0)) * 8;
+    const char* bB = reinterpret_cast<const char*>(Bg) +
+                     ((OPB == OP_KMAJOR) ? ((size_t)n0 * p.ldb + k0) : (k0 * p.ldb + n0)) * 8;
+    const size_t stepA = (OPA == OP_KMAJOR) ? (size_t)BK * 8 : (size_t)BK * p.lda * 8;
+    const size_t stepB = (OPB == OP_KMAJOR) ? (size_t)BK * 8 : (size_t)BK * p.ldb * 8;
+    char* bC = reinterpret_cast<char*>(Cg) + ((size_t)m0 * p.ldc + n0) * 8;
+    const size_t row4 = (size_t)p.ldc * 32;   // 4 rows of C
+    unsigned voffA[Geo<TM>::NLD], voffB[Geo<TN>::NLD];   // per-lane byte offsets (a dozen VALU ops per tile)
+    lane_byte_offsets<OPA, TM>(p.lda, tid, voffA);
+    lane_byte_offsets<OPB, TN>(p.ldb, tid, voffB);
+    const unsigned voffC = (unsigned)((wm * (TM / 2) + (lane >> 4)) * p.ldc + wn * (TN / 2) + (lane & 15)) * 8u;
+    if (p.alpha < 0.0)
+      gemm_tile_fast<OPA, OPB, TM, TN, true>(bA, bB, stepA, stepB, bC, row4, voffC, p.beta != 0.0, smem, kt1 - kt0, tid, voffA,
+                                             voffB, offA, offB, bid);
+    else
+      gemm_tile_fast<OPA, OPB, TM, TN, false>(bA, bB, stepA, stepB, bC, row4, voffC, p.beta != 0.0, smem, kt1 - kt0, tid, voffA,
+                                              voffB, offA, offB, bid);
+    FFGP_TRACE(3);
+    return;
+  }
+
+  d4_t acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+
   if (kt0 < kt1) {
-    const bool interior = (m0 + TM <= p.m) && (n0 + TN <= p.n) && (kt1 * BK <= p.k) && p.avec && p.bvec;
     if (interior)
       gemm_mainloop<OPA, OPB, TM, TN, false>(p, Ag, Bg, smem, m0, n0, kt0, kt1, tid, offA, offB, acc);
     else
       gemm_mainloop<OPA, OPB, TM, TN, true>(p, Ag, Bg, smem, m0, n0, kt0, kt1, tid, offA, offB, acc);
   }
 
+  FFGP_TRACE(2);
   // epilogue: lane holds rows (lane>>4)+4r, column lane&15 of each 16x16 accumulator tile
   // (loads batched per 16-row group: addresses are clamped in-bounds so the loads are unconditional and
   //  the compiler batches them instead of one vmcnt(0) round trip per element)
@@ -292,6 +471,7 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
       }
     }
   }
+  FFGP_TRACE(3);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -299,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
 // ------------------------------------------------------------------------------------------------------------
 template <int OPA, int OPB, int MODE, int TAG, int TM, int TN>
 static int launch_t(ffgp_handle* h, const GemmArgs& a) {
-  hipLaunchKernelGGL((ffgp_gemm_f64<OPA, OPB, MODE, TAG, TM, TN>), dim3(a.total_tiles, a.batch), dim3(256), 0, h->stream, a);
+  hipLaunchKernelGGL((ffgp_gemm_f64<OPA, OPB, MODE, TAG, TM, TN>), dim3(a.grid, a.batch), dim3(256), 0, h->stream, a);
   return FFGP_OK;
 }
 
@@ -390,6 +570,11 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
     ev_stop = h->syrk_pool[h->syrk_pool_used + 1];
     h->syrk_pool_used += 2;
   }
+  // fast form (see gemm_tile_fast): alpha = +-1, beta in {0, 1}; per-lane byte offsets must fit 32 bits
+  a.fast = ((alpha == 1.0 || alpha == -1.0) && (beta == 0.0 || beta == 1.0) && (size_t)lda * 8 * 130 < 0xffffffffull &&
+            (size_t)ldb * 8 * 130 < 0xffffffffull && (size_t)ldc * 8 * 130 < 0xffffffffull)
+               ? 1 : 0;
+  a.grid = a.total_tiles;
   if (tsm != 128) syrk_tag = 0;  // only the 128x128 trailing update is the roofline kernel (own instantiation + stats)
   int rc;
   if (tsm == 64 && tsn == 128)

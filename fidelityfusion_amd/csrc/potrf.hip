@@ -26,6 +26,9 @@
 #define NBLK_LOWER 36
 #define DIAG_LDS_DOUBLES (NBLK_LOWER * BLKSZ + 128)
 #define DIAG_LDS_BYTES (DIAG_LDS_DOUBLES * 8)
+// 8 waves: wave 0 runs the serial 16x16 factor chain, the other seven do the MFMA work in its shadow
+#define DIAG_THREADS 512
+#define DIAG_WAVES (DIAG_THREADS / 64)
 
 __device__ __forceinline__ int blk_off(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * BLKSZ; }
 
@@ -134,38 +137,49 @@ __device__ __forceinline__ void chol16_step(double (&v)[4], double (&w)[4], doub
 // level = one per wave; a wave keeps its column of T = L21*X11 in registers across the barrier that protects
 // L21 from being overwritten while other waves still read it.
 template <int S_>
-__device__ __forceinline__ void inv_merge_level(double* S, int wave, int lane) {
+__device__ __forceinline__ void inv_merge_level(double* S, int wave, int lane, double* __restrict__ Dinv, bool wr) {
+  const bool act = wave < 4;   // four work items per level; any further waves only take part in the barriers
   const int pair = wave / S_, jl = wave % S_;
   const int b0 = pair * 2 * S_;
   const int j = b0 + jl;
   d4_t T[S_];
+  if (act) {
 #pragma unroll
-  for (int ii = 0; ii < S_; ++ii) {
-    const int i = b0 + S_ + ii;
-    d4_t acc = {0.0, 0.0, 0.0, 0.0};
-    for (int k = j; k < b0 + S_; ++k) mma16<false>(acc, S + blk_off(i, k), BLD, S + blk_off(k, j), BLD, lane);
-    T[ii] = acc;
+    for (int ii = 0; ii < S_; ++ii) {
+      const int i = b0 + S_ + ii;
+      d4_t acc = {0.0, 0.0, 0.0, 0.0};
+      for (int k = j; k < b0 + S_; ++k) mma16<false>(acc, S + blk_off(i, k), BLD, S + blk_off(k, j), BLD, lane);
+      T[ii] = acc;
+    }
   }
   __syncthreads();
+  if (act) {
 #pragma unroll
-  for (int ii = 0; ii < S_; ++ii) {
-    double* dst = S + blk_off(b0 + S_ + ii, j);
+    for (int ii = 0; ii < S_; ++ii) {
+      double* dst = S + blk_off(b0 + S_ + ii, j);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dst[((lane >> 4) + 4 * r) * BLD + (lane & 15)] = T[ii][r];
-  }
-  d4_t R[S_];
+      for (int r = 0; r < 4; ++r) dst[((lane >> 4) + 4 * r) * BLD + (lane & 15)] = T[ii][r];
+    }
+    d4_t R[S_];
 #pragma unroll
-  for (int ii = 0; ii < S_; ++ii) {
-    const int i = b0 + S_ + ii;
-    d4_t acc = {0.0, 0.0, 0.0, 0.0};
-    for (int k = b0 + S_; k <= i; ++k) mma16<false>(acc, S + blk_off(i, k), BLD, S + blk_off(k, j), BLD, lane);
-    R[ii] = acc;
-  }
+    for (int ii = 0; ii < S_; ++ii) {
+      const int i = b0 + S_ + ii;
+      d4_t acc = {0.0, 0.0, 0.0, 0.0};
+      for (int k = b0 + S_; k <= i; ++k) mma16<false>(acc, S + blk_off(i, k), BLD, S + blk_off(k, j), BLD, lane);
+      R[ii] = acc;
+    }
 #pragma unroll
-  for (int ii = 0; ii < S_; ++ii) {
-    double* dst = S + blk_off(b0 + S_ + ii, j);
+    for (int ii = 0; ii < S_; ++ii) {
+      double* dst = S + blk_off(b0 + S_ + ii, j);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dst[((lane >> 4) + 4 * r) * BLD + (lane & 15)] = -R[ii][r];
+      for (int r = 0; r < 4; ++r) dst[((lane >> 4) + 4 * r) * BLD + (lane & 15)] = -R[ii][r];
+      // the block is final: it also goes straight to the Dinv store (no separate write-out pass)
+      if (wr) {
+        double* g = Dinv + (size_t)((b0 + S_ + ii) * 16 + (lane >> 4)) * NB + j * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g[(size_t)4 * r * NB] = -R[ii][r];
+      }
+    }
   }
   __syncthreads();
 }
@@ -173,7 +187,7 @@ __device__ __forceinline__ void inv_merge_level(double* S, int wave, int lane) {
 // ------------------------------------------------------------------------------------------------------------
 // potrf_diag128: factor one diagonal block (nb <= 128 valid rows/cols, identity-padded) and invert it.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ffgp_potrf_diag128(double* __restrict__ A, int lda, int nb,
+__global__ __launch_bounds__(DIAG_THREADS) void ffgp_potrf_diag128(double* __restrict__ A, int lda, int nb,
                                                           double* __restrict__ Dinv, int* info, int row_base,
                                                           int do_factor, int dbg, int prio) {
   // dbg: timing-only ablation mask (results are wrong when non-zero): 1 skip (b), 2 skip (c), 4 skip (a),
@@ -189,11 +203,12 @@ __global__ __launch_bounds__(256) void ffgp_potrf_diag128(double* __restrict__ A
   if (!(dbg & 128)) {
     // 32 unconditional 16-byte loads per thread, all in flight before the first LDS store (rows are clamped into
     // the valid block; entries above the diagonal are fetched but never used)
-    d2_t lv[32];
+    constexpr int NLOAD = 8192 / DIAG_THREADS;
+    d2_t lv[NLOAD];
     const bool vec = !(lda & 1) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
 #pragma unroll
-    for (int it = 0; it < 32; ++it) {
-      const int idx = tid + 256 * it;
+    for (int it = 0; it < NLOAD; ++it) {
+      const int idx = tid + DIAG_THREADS * it;
       const int r = min(idx >> 6, nb - 1), c = min((idx & 63) * 2, (nb - 1) & ~1);
       const double* src = A + (size_t)r * lda + c;
       if (vec) {
@@ -204,8 +219,8 @@ __global__ __launch_bounds__(256) void ffgp_potrf_diag128(double* __restrict__ A
       }
     }
 #pragma unroll
-    for (int it = 0; it < 32; ++it) {
-      const int idx = tid + 256 * it;
+    for (int it = 0; it < NLOAD; ++it) {
+      const int idx = tid + DIAG_THREADS * it;
       const int r = idx >> 6, c = (idx & 63) * 2;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
@@ -218,7 +233,7 @@ __global__ __launch_bounds__(256) void ffgp_potrf_diag128(double* __restrict__ A
       }
     }
     __syncthreads();
-    for (int idx = tid; idx < 8 * 256; idx += 256) {
+    for (int idx = tid; idx < 8 * 256; idx += DIAG_THREADS) {
       const int jj = idx >> 8, i = (idx >> 4) & 15, c = idx & 15;
       double* Dj = S + blk_off(jj, jj);
       if (c > i) Dj[i * BLD + c] = Dj[c * BLD + i];
@@ -227,13 +242,17 @@ __global__ __launch_bounds__(256) void ffgp_potrf_diag128(double* __restrict__ A
   __syncthreads();
 
   if (do_factor) {
-    // ---- phase 1: left-looking factorisation over 16-column blocks
+    // ---- phase 1: left-looking factorisation over 16-column blocks, with one block column of look-ahead:
+    //      while wave 0 factors the 16x16 diagonal block jj in registers, waves 1-3 already apply blocks p < jj to
+    //      block column jj+1, so that step jj+1 only has the single product with block column jj left on the chain
+    const bool wr = !(dbg & 64);
     for (int jj = 0; jj < 8; ++jj) {
-      // (a) S[i][jj] -= sum_{p<jj} S[i][p] * S[jj][p]^T   for block rows i = jj..7 (MFMA)
+      d4_t T = {0.0, 0.0, 0.0, 0.0};   // this wave's block (j = wave - 1) of L[jj][:] * X, see the shadow work in (b)
+      // (a) the one missing term: S[i][jj] -= S[i][jj-1] * S[jj][jj-1]^T   for block rows i = jj..7 (MFMA)
       if (jj > 0 && !(dbg & 4)) {
-        for (int i = jj + wave; i < 8; i += 4) {
+        for (int i = jj + wave; i < 8; i += DIAG_WAVES) {
           d4_t acc = {0.0, 0.0, 0.0, 0.0};
-          for (int p = 0; p < jj; ++p) mma16<true>(acc, S + blk_off(i, p), BLD, S + blk_off(jj, p), BLD, lane);
+          mma16<true>(acc, S + blk_off(i, jj - 1), BLD, S + blk_off(jj, jj - 1), BLD, lane);
           double* dst = S + blk_off(i, jj);
 #pragma unroll
           for (int r = 0; r < 4; ++r) dst[((lane >> 4) + 4 * r) * BLD + (lane & 15)] -= acc[r];
@@ -278,38 +297,74 @@ __global__ __launch_bounds__(256) void ffgp_potrf_diag128(double* __restrict__ A
         for (int r = 0; r < 4; ++r) {
           const int i = g + 4 * r;
           const int gr = jj * 16 + i, gc = jj * 16 + c;
-          if (i >= c && gr < nb && !(dbg & 64)) A[(size_t)gr * lda + gc] = out[r] * rs;
+          if (i >= c && gr < nb && wr) A[(size_t)gr * lda + gc] = out[r] * rs;
         }
         // inv(L_jj)[i][c] = rs_i * W[i][c]; rs_i comes back through the LDS slot just written
         __builtin_amdgcn_s_waitcnt(0);       // rd[] visible to the whole wave (same-wave LDS write -> read)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = g + 4 * r;
-          Dj[i * BLD + c] = (i >= c) ? w[r] * rd[jj * 16 + i] : 0.0;
+          const double x = (i >= c) ? w[r] * rd[jj * 16 + i] : 0.0;
+          Dj[i * BLD + c] = x;
+          if (i >= c && !(dbg & 32)) Dinv[(size_t)(jj * 16 + i) * NB + jj * 16 + c] = x;
         }
         if (bad && lane == 0 && (jj * 16 + bad) <= nb) atomicCAS(info, 0, row_base + jj * 16 + bad);
+      } else if (wave != 0 && jj > 0) {
+        // in the shadow of the 16x16 factor (waves 1..3):
+        // look-ahead: S[i][jj+1] -= sum_{p<jj} S[i][p] * S[jj+1][p]^T  for block rows i = jj+1..7
+        if (jj < 7 && !(dbg & 4)) {
+          for (int i = jj + 1 + (wave - 1); i < 8; i += DIAG_WAVES - 1) {
+            d4_t acc = {0.0, 0.0, 0.0, 0.0};
+            for (int p = 0; p < jj; ++p) mma16<true>(acc, S + blk_off(i, p), BLD, S + blk_off(jj + 1, p), BLD, lane);
+            double* dst = S + blk_off(i, jj + 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[((lane >> 4) + 4 * r) * BLD + (lane & 15)] -= acc[r];
+          }
+        }
+        // incremental inverse, row block jj: T[jj][j] = sum_{k=j}^{jj-1} L[jj][k] * X[k][j]  (X = inv(L), rows < jj
+        // already sit in place of L's); the products with inv(L_jj) follow in (c).  T stays in registers.
+        if (!(dbg & 16) && wave - 1 < jj) {
+          const int j = wave - 1;
+          for (int k = j; k < jj; ++k) mma16<false>(T, S + blk_off(jj, k), BLD, S + blk_off(k, j), BLD, lane);
+        }
       }
       __syncthreads();
-      // (c) rows below: X = B * inv(L_jj)^T on the matrix cores (4 MFMAs per 16-row block)
+      // (c) rows below: X = B * inv(L_jj)^T on the matrix cores (4 MFMAs per 16-row block); the finished block of L
+      //     goes to LDS (later steps read it) and straight to global memory
       if (!(dbg & 2)) {
-        for (int i = jj + 1 + wave; i < 8; i += 4) {
+        for (int i = jj + 1 + wave; i < 8; i += DIAG_WAVES) {
           d4_t acc = {0.0, 0.0, 0.0, 0.0};
           double* Bij = S + blk_off(i, jj);
           mma16<true>(acc, Bij, BLD, S + blk_off(jj, jj), BLD, lane);
 #pragma unroll
           for (int r = 0; r < 4; ++r) Bij[((lane >> 4) + 4 * r) * BLD + (lane & 15)] = acc[r];
+          if (wr) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int gr = i * 16 + (lane >> 4) + 4 * r;
+              if (gr < nb) A[(size_t)gr * lda + jj * 16 + (lane & 15)] = acc[r];
+            }
+          }
+        }
+      }
+      // (c') inverse, row block jj: X[jj][j] = -inv(L_jj) * T[jj][j].  The accumulator layout of T (lane group g,
+      //      register r <-> row g + 4r) IS the MFMA B-operand layout of k-step r, so T never leaves its registers.
+      if (wave != 0 && wave - 1 < jj && !(dbg & 16)) {
+        const double* Wj = S + blk_off(jj, jj);
+        const int j = wave - 1;
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wj[(lane & 15) * BLD + kq * 4 + (lane >> 4)], T[kq], acc, 0, 0, 0);
+        double* dst = S + blk_off(jj, j);
+        double* g = Dinv + (size_t)(jj * 16 + (lane >> 4)) * NB + j * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dst[((lane >> 4) + 4 * r) * BLD + (lane & 15)] = -acc[r];
+          if (!(dbg & 32)) g[(size_t)4 * r * NB] = -acc[r];
         }
       }
       __syncthreads();
-    }
-    // ---- phase 2: write L (lower part of the valid block)
-    if (!(dbg & 64)) {
-#pragma unroll 8
-      for (int it = 0; it < 64; ++it) {
-        const int idx = tid + 256 * it;
-        const int r = idx >> 7, c = idx & 127;
-        if ((c >> 4) < (r >> 4) && r < nb) A[(size_t)r * lda + c] = S[blk_off(r >> 4, c >> 4) + (r & 15) * BLD + (c & 15)];
-      }
     }
   } else {
     // inverse-only entry (Dinv refresh for a factor produced elsewhere): reciprocals of the diagonal
@@ -335,23 +390,22 @@ __global__ __launch_bounds__(256) void ffgp_potrf_diag128(double* __restrict__ A
     // every lane of the wave has finished reading L_jj (same instruction stream) before the block is overwritten
 #pragma unroll
     for (int i = 0; i < 16; ++i) Lj[i * BLD + c] = x[i];
+    if (!(dbg & 32)) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (i >= c) Dinv[(size_t)(jj * 16 + i) * NB + jj * 16 + c] = x[i];
+    }
   }
   __syncthreads();
 
-  // ---- phase 4: in-place blocked inversion by recursive doubling (16 -> 32 -> 64 -> 128), 2 barriers per level
-  if (!(dbg & 16)) {
-    inv_merge_level<1>(S, wave, lane);
-    inv_merge_level<2>(S, wave, lane);
-    inv_merge_level<4>(S, wave, lane);
-  }
-  // ---- phase 5: write the inverse (lower part; the strictly-upper part of the Dinv store is zero from allocation)
-  if (!(dbg & 32)) {
-#pragma unroll 8
-    for (int it = 0; it < 64; ++it) {
-      const int idx = tid + 256 * it;
-      const int r = idx >> 7, c = idx & 127;
-      if (c <= r) Dinv[idx] = S[blk_off(r >> 4, c >> 4) + (r & 15) * BLD + (c & 15)];
-    }
+  // ---- phase 4: in-place blocked inversion by recursive doubling (16 -> 32 -> 64 -> 128), 2 barriers per level;
+  //      every block is written to the Dinv store the moment it is final (the strictly-upper part of the store is
+  //      zero from allocation)
+  if (!do_factor && !(dbg & 16)) {   // (the factor entry built the inverse row block by row block, see (c'))
+    const bool wi = !(dbg & 32);
+    inv_merge_level<1>(S, wave, lane, Dinv, wi);   // (4 work items per level: waves 4..7 only keep the barriers)
+    inv_merge_level<2>(S, wave, lane, Dinv, wi);
+    inv_merge_level<4>(S, wave, lane, Dinv, wi);
   }
 }
 
@@ -429,7 +483,7 @@ static int launch_diag(ffgp_handle* h, double* Ablk, int lda, int nb, double* Di
                                  hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
     g_diag_attr_set = true;
   }
-  hipLaunchKernelGGL(ffgp_potrf_diag128, dim3(1), dim3(256), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk,
+  hipLaunchKernelGGL(ffgp_potrf_diag128, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk,
                      h->d_info, row_base, do_factor, h->diag_dbg, h->aux_prio);
   return FFGP_OK;
 }

@@ -280,3 +280,4 @@ def multiblock_bench():
 
 if "multiblock" in sys.argv[1:]:
     multiblock_bench()
+
