@@ -46,6 +46,18 @@ def recorded_traffic(n):
         return None, None
 
 
+def synthetic_xy(n, D, d, seed=0):
+    """The benchmark's deterministic workload: X ~ U[0,1)^D, Y = sin(2 pi X w) + 0.1 randn, normalised
+    the way FidelityFusion_Models/MF_data.py:26-28 normalises y (mean / unbiased std over all entries)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    X = rng.random((n, D))
+    W = rng.random((D, d))
+    Y = np.sin(2.0 * np.pi * (X @ W)) + 0.1 * rng.standard_normal((n, d))
+    Y = (Y - Y.mean()) / (Y.std(ddof=1) + 1e-10)
+    return X, Y
+
+
 def nlml_flops(n, D, d):
     """N^3/3 (Cholesky) + N^2 d (Gamma = L^-1 Y) + 2 N^2 D (distance contractions)."""
     return n ** 3 / 3.0 + float(n) * n * d + 2.0 * n * n * D
@@ -60,7 +72,7 @@ def cpu_baseline(D, d, n_sample):
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         cores = os.cpu_count() or 1
-    X, Y = O.synthetic_xy(n_sample, D, d, seed=0)
+    X, Y = synthetic_xy(n_sample, D, d, seed=0)
     ls, sv, lb = np.ones(D), [1.0], [1.0]
     O.nlml_forward_ard(X[:512], Y[:512], ls, sv, lb)   # warm the BLAS threads
     t0 = time.perf_counter()
@@ -82,6 +94,7 @@ def main():
     ap.add_argument("--cpu-sample-n", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-grad", action="store_true", help="time forward + closed-form gradients instead")
+    ap.add_argument("--opt", action="append", default=[], help="library option key=value (development A/B runs)")
     args = ap.parse_args()
 
     import numpy as np
@@ -100,11 +113,13 @@ def main():
 
     from fidelityfusion_amd import _lib
     from fidelityfusion_amd import functional as F
-    from oracle import gp_oracle as O
+    for kv in args.opt:   # development switches (tools/): --opt la_split=1 --opt tile32_threshold=0 ...
+        key, val = kv.split("=")
+        _lib.set_option(key, float(val), local_rank)
 
     n, D, d = args.n, args.D, args.d
     # one independent block per rank (fidelity f = rank): same shape, different seed
-    X, Y = O.synthetic_xy(n, D, d, seed=rank)
+    X, Y = synthetic_xy(n, D, d, seed=rank)
     Xd = torch.tensor(X, dtype=torch.float64, device=dev)
     Yd = torch.tensor(Y, dtype=torch.float64, device=dev, requires_grad=args.with_grad)
     # reference initial hyper-parameters: length_scales = 1 (kernel.py:84), signal_variance = 1, log_beta = 1 (ResGP.py:27)

@@ -101,9 +101,10 @@ int ffgp_create(int device, ffgp_handle** out) {
     int lo = 0, hi = 0;  // numerically lowest value = greatest priority
     FFGP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
     FFGP_HIP(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, hi));
-    for (int i = 0; i < 6; ++i) FFGP_HIP(hipEventCreateWithFlags(&h->la_ev[i], hipEventDisableTiming));
+    for (int i = 0; i < 8; ++i) FFGP_HIP(hipEventCreateWithFlags(&h->la_ev[i], hipEventDisableTiming));
     h->lookahead = 1;
     h->small_tile_threshold = 640;
+    h->tile32_threshold = 1024;
     h->la_split = 1;
     h->aux_prio = 1;
   }
@@ -135,7 +136,7 @@ int ffgp_destroy(ffgp_handle* h) {
   hipEventDestroy(h->syrk_ev[0]);
   hipEventDestroy(h->syrk_ev[1]);
   for (hipEvent_t e : h->syrk_pool) hipEventDestroy(e);
-  for (int i = 0; i < 6; ++i) hipEventDestroy(h->la_ev[i]);
+  for (int i = 0; i < 8; ++i) hipEventDestroy(h->la_ev[i]);
   hipStreamDestroy(h->aux);
   hipStreamDestroy(h->own);
   delete h;
@@ -162,10 +163,12 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->aux_prio = (int)value;
   } else if (!strcmp(key, "gemm_tile")) {
     const int v = (int)value;
-    if (v != 0 && v != 64 && v != 128) return FFGP_ERR_ARG;
+    if (v != 0 && v != 32 && v != 64 && v != 128) return FFGP_ERR_ARG;
     h->force_ts = v;
   } else if (!strcmp(key, "small_tile_threshold")) {
     h->small_tile_threshold = (int)value;
+  } else if (!strcmp(key, "tile32_threshold")) {
+    h->tile32_threshold = (int)value;
   } else if (!strcmp(key, "diag_dbg")) {
     h->diag_dbg = (int)value;
   } else if (!strcmp(key, "la_split")) {

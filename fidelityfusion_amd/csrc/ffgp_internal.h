@@ -93,10 +93,11 @@ struct ffgp_handle {
   hipStream_t stream;   // stream work is enqueued on (caller's, or `own`)
   hipStream_t own;      // the handle's own stream
   hipStream_t aux;      // high-priority side stream for the look-ahead panel factorisation
-  hipEvent_t la_ev[6];  // look-ahead hand-off events
+  hipEvent_t la_ev[8];  // look-ahead hand-off events
   int aux_prio;         // 1 = look-ahead chain kernels run at raised wave priority
-  int force_ts;         // 0 = automatic GEMM tile shape, 64 / 128 = forced (benchmarks, tests)
+  int force_ts;         // 0 = automatic GEMM tile shape, 32 / 64 / 128 = forced (benchmarks, tests)
   int small_tile_threshold;  // launches with fewer 128-tiles than this use the 64-tile
+  int tile32_threshold;      // K-major launches with fewer 64-tiles than this use 32-row tiles
   int diag_dbg;         // timing-only ablation mask of potrf_diag128 (0 in production)
   int la_split;         // 1 = issue the look-ahead part of the trailing update in two launches (first 128 columns first)
   int lookahead;        // 1 = overlap panel k+1 with the trailing update of step k

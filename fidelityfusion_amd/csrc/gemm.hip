@@ -215,7 +215,11 @@ __device__ __forceinline__ void gload_fast(const char* __restrict__ base, const 
   for (int i = 0; i < Geo<TS>::NLD; ++i) v[i] = *reinterpret_cast<const d2_t*>(base + voff[i]);
 }
 
-template <int OPA, int OPB, int TM, int TN, bool NEG>
+// PD = register prefetch depth in k-tiles.  The 128x128 tile keeps one k-tile in flight (64 MFMAs per wave per k-tile
+// cover any memory latency, and its registers are spoken for); the small latency-shape tiles have only 4-16 MFMAs per
+// k-tile, far less than an L2/HBM round trip, so they keep PD k-tiles of operands in flight in (cheap) registers --
+// otherwise every one of their K/16 steps costs a full memory latency and a K = 512 launch of 32x32 tiles takes 30 us.
+template <int OPA, int OPB, int TM, int TN, bool NEG, int PD>
 __device__ __forceinline__ void gemm_tile_fast(const char* __restrict__ baseA, const char* __restrict__ baseB, size_t stepA,
                                                size_t stepB, char* __restrict__ baseC, size_t row4_bytes, unsigned voffC,
                                                bool load_c, double* smem, int nkt, int tid,
@@ -225,9 +229,15 @@ __device__ __forceinline__ void gemm_tile_fast(const char* __restrict__ baseA, c
   constexpr int BUFA = Geo<TM>::OPBUF, BUFB = Geo<TN>::OPBUF, STAGE = BUFA + BUFB;
   constexpr int subA = (OPA == OP_KMAJOR) ? 256 : 16;
   constexpr int subB = (OPB == OP_KMAJOR) ? 256 : 16;
-  d2_t ra[Geo<TM>::NLD], rb[Geo<TN>::NLD];
-  gload_fast<TM>(baseA, voffA, ra);
-  gload_fast<TN>(baseB, voffB, rb);
+  static_assert(PD == 1 || (PD & 1) == 0, "prefetch depth must be 1 or even (LDS stage parity is compile-time)");
+  d2_t ra[PD][Geo<TM>::NLD], rb[PD][Geo<TN>::NLD];
+#pragma unroll
+  for (int s = 0; s < PD; ++s) {
+    if (s < nkt) {
+      gload_fast<TM>(baseA + s * stepA, voffA, ra[s]);
+      gload_fast<TN>(baseB + s * stepB, voffB, rb[s]);
+    }
+  }
   d4_t acc[WM][WN];
   if (load_c) {
 #pragma unroll
@@ -244,42 +254,48 @@ __device__ __forceinline__ void gemm_tile_fast(const char* __restrict__ baseA, c
 #pragma unroll
       for (int j = 0; j < WN; ++j) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
   }
-  sstore<OPA, TM>(smem, tid, ra);
-  sstore<OPB, TN>(smem + BUFA, tid, rb);
+  sstore<OPA, TM>(smem, tid, ra[0]);
+  sstore<OPB, TN>(smem + BUFA, tid, rb[0]);
   __syncthreads();
 #ifdef FFGP_GEMM_TRACE
   if (tid == 0 && ffgp_trace_buf) ffgp_trace_buf[(size_t)trace_bid * 8 + 1] = __builtin_readcyclecounter();
 #endif
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int par = kt & 1;
-    const double* sA = smem + par * STAGE;
-    const double* sB = sA + BUFA;
-    const bool more = (kt + 1 < nkt);
-    if (more) {
-      baseA += stepA;
-      baseB += stepB;
-      gload_fast<TM>(baseA, voffA, ra);
-      gload_fast<TN>(baseB, voffB, rb);
+  baseA += (size_t)PD * stepA;   // next tile to fetch
+  baseB += (size_t)PD * stepB;
+  for (int kt0 = 0; kt0 < nkt; kt0 += PD) {
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+      const int kt = kt0 + u;
+      if (kt >= nkt) break;
+      const int par = (PD == 1) ? (kt & 1) : (u & 1);
+      const double* sA = smem + par * STAGE;
+      const double* sB = sA + BUFA;
+      if (kt + PD < nkt) {   // slot u was drained into LDS one step ago
+        gload_fast<TM>(baseA, voffA, ra[u]);
+        gload_fast<TN>(baseB, voffB, rb[u]);
+        baseA += stepA;
+        baseB += stepB;
+      }
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) {
+        double a[WM], b[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[i] = sA[offA[kq] + i * subA];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) b[j] = sB[offB[kq] + j * subB];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, NEG ? 1 : 0);  // blgp bit 0: -A
+      }
+      if (kt + 1 < nkt) {
+        double* dA = smem + (par ^ 1) * STAGE;
+        sstore<OPA, TM>(dA, tid, ra[(u + 1) % PD]);
+        sstore<OPB, TN>(dA + BUFA, tid, rb[(u + 1) % PD]);
+      }
+      __syncthreads();
     }
-#pragma unroll
-    for (int kq = 0; kq < 4; ++kq) {
-      double a[WM], b[WN];
-#pragma unroll
-      for (int i = 0; i < WM; ++i) a[i] = sA[offA[kq] + i * subA];
-#pragma unroll
-      for (int j = 0; j < WN; ++j) b[j] = sB[offB[kq] + j * subB];
-#pragma unroll
-      for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, NEG ? 1 : 0);  // blgp bit 0: -A
-    }
-    if (more) {
-      double* dA = smem + (par ^ 1) * STAGE;
-      sstore<OPA, TM>(dA, tid, ra);
-      sstore<OPB, TN>(dA + BUFA, tid, rb);
-    }
-    __syncthreads();
   }
 #ifdef FFGP_GEMM_TRACE
   if (tid == 0 && ffgp_trace_buf) ffgp_trace_buf[(size_t)trace_bid * 8 + 2] = __builtin_readcyclecounter();
@@ -397,15 +413,16 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
     const size_t stepB = (OPB == OP_KMAJOR) ? (size_t)BK * 8 : (size_t)BK * p.ldb * 8;
     char* bC = reinterpret_cast<char*>(Cg) + ((size_t)m0 * p.ldc + n0) * 8;
     const size_t row4 = (size_t)p.ldc * 32;   // 4 rows of C
+    constexpr int PD = (TM == 128 && TN == 128) ? 1 : 4;
     unsigned voffA[Geo<TM>::NLD], voffB[Geo<TN>::NLD];   // per-lane byte offsets (a dozen VALU ops per tile)
     lane_byte_offsets<OPA, TM>(p.lda, tid, voffA);
     lane_byte_offsets<OPB, TN>(p.ldb, tid, voffB);
     const unsigned voffC = (unsigned)((wm * (TM / 2) + (lane >> 4)) * p.ldc + wn * (TN / 2) + (lane & 15)) * 8u;
     if (p.alpha < 0.0)
-      gemm_tile_fast<OPA, OPB, TM, TN, true>(bA, bB, stepA, stepB, bC, row4, voffC, p.beta != 0.0, smem, kt1 - kt0, tid, voffA,
+      gemm_tile_fast<OPA, OPB, TM, TN, true, PD>(bA, bB, stepA, stepB, bC, row4, voffC, p.beta != 0.0, smem, kt1 - kt0, tid, voffA,
                                              voffB, offA, offB, bid);
     else
-      gemm_tile_fast<OPA, OPB, TM, TN, false>(bA, bB, stepA, stepB, bC, row4, voffC, p.beta != 0.0, smem, kt1 - kt0, tid, voffA,
+      gemm_tile_fast<OPA, OPB, TM, TN, false, PD>(bA, bB, stepA, stepB, bC, row4, voffC, p.beta != 0.0, smem, kt1 - kt0, tid, voffA,
                                               voffB, offA, offB, bid);
     FFGP_TRACE(3);
     return;
@@ -542,17 +559,29 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   a.hi_i = (tri & TRI_HI_I) ? 1 : 0;
   a.hi_j = (tri & TRI_HI_J) ? 1 : 0;
   // tile shape: the 128-tile is the throughput shape; below ~1.5 tiles per CU the launch is latency-bound and
-  // the 64-tile (4x the workgroups, a quarter of the per-tile MFMA chain) finishes sooner
+  // the 64-tile (4x the workgroups, a quarter of the per-tile MFMA chain) finishes sooner; the kernels of the
+  // factorisation's dependency chain (K-major operands) go one step further to 32-row tiles when even the 64-tiles
+  // would leave most CUs with a single 4-16 us MFMA chain
   int tsm = 128, tsn = 128;
   a.total_tiles = count_tiles(mode, m, n, 128, 128, a.tiles_m, a.tiles_n);
-  const bool want_small = (h->force_ts == 64) || (h->force_ts == 0 && a.total_tiles * a.batch < h->small_tile_threshold);
-  if (want_small) {
+  int level = 0;
+  if (h->force_ts == 64) level = 1;
+  else if (h->force_ts == 32) level = 2;
+  else if (h->force_ts == 0 && a.total_tiles * a.batch < h->small_tile_threshold) level = 1;
+  const bool kk = (opa == OP_KMAJOR && opb == OP_KMAJOR);
+  if (level >= 1) {
     if (alias == 0 || (alias == ALIAS_A && n <= 64) || (alias == ALIAS_B && m <= 64)) {
       tsm = tsn = 64;
-    } else if (alias == ALIAS_A && opa == OP_KMAJOR && opb == OP_KMAJOR) {
+    } else if (alias == ALIAS_A && kk) {
       tsm = 64;  // 64 x 128: the whole panel-block width in one column tile
     }
     a.total_tiles = count_tiles(mode, m, n, tsm, tsn, a.tiles_m, a.tiles_n);
+    if (h->force_ts == 0 && level == 1 && kk && a.batch == 1 && tsm == 64 && a.total_tiles < h->tile32_threshold) level = 2;
+    if (level == 2 && kk && tsm == 64 && a.batch == 1) {
+      tsm = 32;
+      if (tsn == 64) tsn = 32;   // 32 x 32, or 32 x 128 for the in-place TRSM
+      a.total_tiles = count_tiles(mode, m, n, tsm, tsn, a.tiles_m, a.tiles_n);
+    }
   }
   // timing == 2: bracket every trailing-update launch with its own event pair (no host sync inside the timed
   // region; ffgp_syrk_stats drains the pool afterwards)
@@ -579,6 +608,11 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   int rc;
   if (tsm == 64 && tsn == 128)
     rc = launch_t<OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, 64, 128>(h, a);
+  else if (tsm == 32 && tsn == 128)
+    rc = launch_t<OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, 32, 128>(h, a);
+  else if (tsm == 32)
+    rc = (mode == TILES_LOWER) ? launch_t<OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 0, 32, 32>(h, a)
+                               : launch_t<OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, 32, 32>(h, a);
   else if (tsm == 128)
     rc = dispatch<128>(h, opa, opb, mode, syrk_tag, a);
   else

@@ -586,14 +586,20 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
         }
       }
     } else {
-      // Look-ahead: the trailing update of step k is split into (i) the columns of panel k+1 and (ii) the rest.
-      // Panel k+1 is factored on a second, high-priority stream as soon as (i) is done, so its latency-bound
-      // chain (diag factor -> TRSM -> panel update, x4) runs underneath the big (ii) SYRK of step k instead of
-      // in front of the next one.  Panel k+1 touches only its own columns; (ii) reads panel k and writes the
+      // Look-ahead.  The trailing update of step k is cut into S_a (the first 128 columns of panel k+1 -- all that its
+      // first diagonal factor and TRSM read), S_b (the rest of panel k+1's columns) and S_ii (everything to the right).
+      // The side stream (high priority) runs the dependency chain  S_a(k) -> panel k+1 (diag -> TRSM -> update, x4)
+      // back to back; the main stream runs S_b(k), S_ii(k).  While the trailing matrix is large the chain hides under
+      // S_ii; once it is small the chain IS the critical path -- which is why S_a sits on the chain's own stream:
+      // a cross-stream event hand-off costs ~13 us, and the only waits left on the chain are for events that fired
+      // long before (S_ii(k-1), S_b(k)).  Panel k+1 touches only its own columns; S_ii reads panel k and writes the
       // columns to the right of panel k+1, so the two streams never alias.
       hipStream_t main_s = h->stream;
       FFGP_CHECK(factor_panel(h, A, n, mtot, lda, 0, min(NB1, n)));
+      FFGP_HIP(hipEventRecord(h->la_ev[6], main_s));
+      FFGP_HIP(hipStreamWaitEvent(h->aux, h->la_ev[6], 0));
       int it = 0;
+      hipEvent_t eb_prev = nullptr, ei_prev = nullptr;
       for (int k0 = 0; k0 < n; k0 += NB1, ++it) {
         const int w1 = min(NB1, n - k0);
         const int pend = k0 + w1;
@@ -602,14 +608,16 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
         const int wn = min(NB1, mt);  // width of the next panel
         double* P = A + (size_t)pend * lda + k0;
         double* C = A + (size_t)pend * lda + pend;
-        // (i) next panel's columns (all rows below, passenger rows included), in two launches: its first 128
-        //     columns -- all the first diagonal factor + TRSM of panel k+1 need -- then the remaining ones
+        hipEvent_t eb = h->la_ev[(it & 1) * 3], eg = h->la_ev[(it & 1) * 3 + 1], ei = h->la_ev[(it & 1) * 3 + 2];
         const int wa = h->la_split ? min(NB, wn) : wn;
-        FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P, lda, P, lda, C, lda, mtot - pend, wa, w1, -1.0,
-                                    1.0));
-        hipEvent_t ea = h->la_ev[(it & 1) * 3], eg = h->la_ev[(it & 1) * 3 + 1], eb = h->la_ev[(it & 1) * 3 + 2];
-        FFGP_HIP(hipEventRecord(ea, main_s));
-        FFGP_HIP(hipStreamWaitEvent(h->aux, ea, 0));
+        // side stream: S_a(k) (after S_ii(k-1), which carried panel k-1 into these columns)
+        if (ei_prev) FFGP_HIP(hipStreamWaitEvent(h->aux, ei_prev, 0));
+        h->stream = h->aux;
+        int rc = ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P, lda, P, lda, C, lda, mtot - pend, wa, w1, -1.0, 1.0);
+        h->stream = main_s;
+        FFGP_CHECK(rc);
+        // main stream: S_b(k) once panel k is complete
+        if (eb_prev) FFGP_HIP(hipStreamWaitEvent(main_s, eb_prev, 0));
         hipEvent_t gate = nullptr;
         if (wn > wa) {
           double* Pb = A + (size_t)(pend + wa) * lda + k0;
@@ -619,21 +627,26 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
           FFGP_HIP(hipEventRecord(eg, main_s));
           gate = eg;
         }
+        // side stream: panel k+1
         h->stream = h->aux;
-        const int rc = factor_panel(h, A, n, mtot, lda, pend, wn, gate);
+        rc = factor_panel(h, A, n, mtot, lda, pend, wn, gate);
         h->stream = main_s;
         FFGP_CHECK(rc);
         FFGP_HIP(hipEventRecord(eb, h->aux));
-        // (ii) the rest of the trailing matrix
+        eb_prev = eb;
+        // main stream: S_ii(k), the rest of the trailing matrix
         const int mt2 = mt - wn;
+        ei_prev = nullptr;
         if (mt2 > 0) {
           double* P2 = A + (size_t)(pend + wn) * lda + k0;
           double* C2 = A + (size_t)(pend + wn) * lda + (pend + wn);
           FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P2, lda, P2, lda, C2, lda, mtot - pend - wn, mt2,
                                       w1, -1.0, 1.0));
+          FFGP_HIP(hipEventRecord(ei, main_s));
+          ei_prev = ei;
         }
-        FFGP_HIP(hipStreamWaitEvent(main_s, eb, 0));
       }
+      if (eb_prev) FFGP_HIP(hipStreamWaitEvent(main_s, eb_prev, 0));
     }
     h->dinv_L = A;
     h->dinv_n = n;

@@ -56,7 +56,7 @@ def run_gemm(ff, opa, opb, lower, tri, A, B, C0, alpha, beta, pad=(0, 0, 0)):
     return out[:, :C0.shape[1]]
 
 
-@pytest.fixture(params=[64, 128])
+@pytest.fixture(params=[32, 64, 128])
 def tile(request, ff):
     """run the test once per GEMM tile shape (the launcher picks automatically in production)"""
     _lib, h = ff

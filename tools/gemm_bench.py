@@ -281,3 +281,31 @@ def multiblock_bench():
 if "multiblock" in sys.argv[1:]:
     multiblock_bench()
 
+
+
+def tile32_sweep():
+    h = _lib.handle(0)
+    _lib.bind_stream(h, 0)
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(0)
+    for n in (16384, 8192, 4096):
+        X = torch.rand((n, 16), generator=g, device=dev, dtype=torch.float64)
+        w = torch.ones(16, device=dev, dtype=torch.float64)
+        amp = torch.ones(1, device=dev, dtype=torch.float64)
+        dadd = torch.full((1,), 0.37, device=dev, dtype=torch.float64)
+        W = torch.empty((n, n), device=dev, dtype=torch.float64)
+        for thr in (0, 256, 512, 1024, 2048, 4096, 100000):
+            _lib.set_option("tile32_threshold", thr, 0)
+
+            def fn():
+                _lib.lib.ffgp_assemble(h, p(X), n, p(X), n, 16, p(w), p(amp), 1e-30, p(dadd), None, 0, None, 0, 0.0, 0.0, p(W), n, 1,
+                                       0, 1.0)
+                assert _lib.lib.ffgp_potrf(h, p(W), n, n) == 0
+            fn()
+            tmin, tmed = timeit(fn, rounds=3)
+            print("n=%d tile32_threshold=%d: %.2f ms (%.1f TF/s)" % (n, thr, tmin, n ** 3 / 3.0 / tmin / 1e9))
+    _lib.set_option("tile32_threshold", 1024, 0)
+
+
+if "tile32" in sys.argv[1:]:
+    tile32_sweep()
