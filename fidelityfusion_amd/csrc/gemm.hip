@@ -215,6 +215,10 @@ __device__ __forceinline__ void gload_fast(const char* __restrict__ base, const 
   for (int i = 0; i < Geo<TS>::NLD; ++i) v[i] = *reinterpret_cast<const d2_t*>(base + voff[i]);
 }
 
+// doubles per operand buffer: the K-major image is exactly [TS][16]; the MN-major one is [16][TS + 16]
+template <int OP, int TS>
+constexpr int opbuf() { return OP == OP_KMAJOR ? TS * 16 : Geo<TS>::OPBUF; }
+
 // PD = register prefetch depth in k-tiles.  The 128x128 tile keeps one k-tile in flight (64 MFMAs per wave per k-tile
 // cover any memory latency, and its registers are spoken for); the small latency-shape tiles have only 4-16 MFMAs per
 // k-tile, far less than an L2/HBM round trip, so they keep PD k-tiles of operands in flight in (cheap) registers --
@@ -226,7 +230,7 @@ __device__ __forceinline__ void gemm_tile_fast(const char* __restrict__ baseA, c
                                                const unsigned (&voffA)[Geo<TM>::NLD], const unsigned (&voffB)[Geo<TN>::NLD],
                                                const int (&offA)[4], const int (&offB)[4], int trace_bid) {
   constexpr int WM = Geo<TM>::WT, WN = Geo<TN>::WT;
-  constexpr int BUFA = Geo<TM>::OPBUF, BUFB = Geo<TN>::OPBUF, STAGE = BUFA + BUFB;
+  constexpr int BUFA = opbuf<OPA, TM>(), BUFB = opbuf<OPB, TN>(), STAGE = BUFA + BUFB;
   constexpr int subA = (OPA == OP_KMAJOR) ? 256 : 16;
   constexpr int subB = (OPB == OP_KMAJOR) ? 256 : 16;
   static_assert(PD == 1 || (PD & 1) == 0, "prefetch depth must be 1 or even (LDS stage parity is compile-time)");
@@ -316,7 +320,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, const double* _
                                               const int (&offA)[4], const int (&offB)[4],
                                               d4_t (&acc)[Geo<TM>::WT][Geo<TN>::WT]) {
   constexpr int WM = Geo<TM>::WT, WN = Geo<TN>::WT;
-  constexpr int BUFA = Geo<TM>::OPBUF, BUFB = Geo<TN>::OPBUF, STAGE = BUFA + BUFB;
+  constexpr int BUFA = opbuf<OPA, TM>(), BUFB = opbuf<OPB, TN>(), STAGE = BUFA + BUFB;
   constexpr int subA = (OPA == OP_KMAJOR) ? 256 : 16;
   constexpr int subB = (OPB == OP_KMAJOR) ? 256 : 16;
   d2_t ra[Geo<TM>::NLD], rb[Geo<TN>::NLD];
@@ -358,7 +362,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, const double* _
 template <int OPA, int OPB, int MODE, int TAG, int TM, int TN>
 __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
   constexpr int WM = Geo<TM>::WT, WN = Geo<TN>::WT;
-  __shared__ __attribute__((aligned(16))) double smem[2 * (Geo<TM>::OPBUF + Geo<TN>::OPBUF)];
+  __shared__ __attribute__((aligned(16))) double smem[2 * (opbuf<OPA, TM>() + opbuf<OPB, TN>())];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   if (p.prio) __builtin_amdgcn_s_setprio(2);  // panel GEMMs of the look-ahead chain outrank the trailing update
