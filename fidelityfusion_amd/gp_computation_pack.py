@@ -3,6 +3,7 @@
     Gaussian_log_likelihood(y, cov, Kinv_method='cholesky3')        :34-91
     conditional_Gaussian(y, Sigma, K_s, K_ss, Kinv_method='cholesky3')  :93-118
     negative_log_likelihood(kernel, log_beta, x_train, y_train)     :120-136  (returns +LL)
+    Tensor_linear(l_shape, h_shape)                                 :138-159  (CIGAR's learnable fidelity map)
 
 Only the 'cholesky3' method -- the one every model in the reference uses -- is implemented; the other
 `Kinv_method`s of the reference are alternative formulas for the same quantities (explicit inverses, d=1 only)
@@ -66,3 +67,39 @@ def negative_log_likelihood(kernel, log_beta, x_train, y_train):
     nll = F.nlml(x_train, y_train, w, amp, diag_add=log_beta.exp().pow(-1), mean_jitter=JITTER, clamp=clamp,
                  variant=F.FFGP_LL_V1, pi_const=PI, **F._slot_args(), kfun=_kfun(kernel))
     return -nll
+
+
+class Tensor_linear(torch.nn.Module):
+    """CIGAR's learnable map from the low-fidelity output shape to the high-fidelity one (reference :138-159;
+    `FidelityFusion_Models/CIGAR.py:33-36,75,122`): one matrix per output mode, initialised to the identity, or to
+    its bilinear interpolation when the high fidelity is finer.  The product -- N x d_l x d_h, 17 GFLOP per call at
+    config 4's d = 1024, inside every training step together with its two backward products -- runs on the fp64
+    matrix-core GEMM.  Kept quirk: every mode product is applied to the INPUT, not to the running result, so only
+    the last mode's matrix acts (:156-158)."""
+
+    def __init__(self, l_shape, h_shape):
+        super().__init__()
+        self.l_shape = l_shape
+        self.h_shape = h_shape
+        vectors = []
+        for i in range(len(self.l_shape)):
+            if self.l_shape[i] < self.h_shape[i]:
+                init = torch.eye(self.l_shape[i])
+                init = torch.nn.functional.interpolate(init.reshape(1, 1, *init.shape), (self.l_shape[i], self.h_shape[i]),
+                                                       mode="bilinear")
+                init = init.squeeze().T
+            elif self.l_shape[i] == self.h_shape[i]:
+                init = torch.eye(self.l_shape[i])
+            else:   # the reference leaves init_tensor unbound here (NameError / stale value)
+                raise ValueError("Tensor_linear: the high-fidelity shape must not be coarser than the low-fidelity one")
+            vectors.append(torch.nn.Parameter(init))
+        self.vectors = torch.nn.ParameterList(vectors)
+
+    def forward(self, x):
+        i = len(self.l_shape) - 1
+        V = self.vectors[i]                       # [h_i, l_i]
+        xm = x.movedim(i + 1, -1)
+        y = F.matmul_nt(xm.reshape(-1, xm.shape[-1]), V)
+        odt = x.dtype if x.dtype.is_floating_point else torch.float64
+        y = y.to(device=x.device, dtype=odt)
+        return y.reshape(*xm.shape[:-1], V.shape[0]).movedim(-1, i + 1)

@@ -429,6 +429,14 @@ def composed_ll_and_grads(X, Y, parts, combine, sigma_fn, dsigma_scalar, variant
     return ll, out, dS, dY
 
 
+def tensor_linear(x, vectors):
+    """Tensor_linear.forward, gp_computation_pack.py:155-159: `y = mode_dot(x, vectors[i], i + 1)` is evaluated on the
+    INPUT for every i, so the value returned is the last mode's product alone."""
+    i = len(vectors) - 1
+    V = np.asarray(vectors[i], dtype=np.float64)            # [h_i, l_i]
+    return np.moveaxis(np.tensordot(np.asarray(x, dtype=np.float64), V, axes=([i + 1], [1])), -1, i + 1)
+
+
 def cigp_forward(X, Y, Xs, kernel_fn, log_beta):
     """P1: cigp.forward, cigp_v10.py:24-48.  y_var is ignored; the noise scalar lands on EVERY entry."""
     K = kernel_fn(X, X)

