@@ -35,7 +35,10 @@ class cigp(nn.Module):
 
     def forward(self, x_train, y_train, x_test):
         y_train, _ = _split(y_train)
-        if not hasattr(self.kernel, "effective"):
+        # the fused posterior is a no_grad path (every prediction call of the reference's models sits under
+        # torch.no_grad()); with autograd on -- acquisition functions differentiating mean / variance w.r.t. x_test,
+        # Bayesian_optimization/acq.py -- the same quantities are composed from differentiable pieces
+        if not hasattr(self.kernel, "effective") or torch.is_grad_enabled():
             return self._forward_composed(x_train, y_train, x_test)
         w, amp, clamp = self.kernel.effective()
         noise = self.log_beta.exp().pow(-1)
@@ -45,7 +48,6 @@ class cigp(nn.Module):
 
     # composed kernels (SumKernel(LinearKernel, MaternKernel) of the reference's own demos, cigp_v10.py:81,111,147):
     # the parts are evaluated on the device, Sigma is composed there and enters the fused factorisation as cov_dev
-    @torch.no_grad()
     def _forward_composed(self, x_train, y_train, x_test):
         from .gp_computation_pack import conditional_Gaussian
         noise = self.log_beta.exp().pow(-1)

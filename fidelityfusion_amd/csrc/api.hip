@@ -19,6 +19,9 @@ size_t ffgp_grad_partial_doubles(int n, int D);
 int ffgp_kernel_grad_impl(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const double* w,
                           const double* amp, double clamp, int kfun, double kparam, const double* dK, int ldk, double* g_w,
                           double* g_amp, double* g_kparam);
+int ffgp_kernel_wt_impl(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const double* w,
+                        const double* amp, double clamp, int kfun, double kparam, const double* dK, int ldk, double* Wt,
+                        int ldw);
 
 __global__ void ffgp_copy_lower_kernel(const double* __restrict__ src, int lds_, double* __restrict__ dst, int ldd, int n) {
   const int c = blockIdx.x * 32 + (threadIdx.x & 31), r = blockIdx.y * 32 + (threadIdx.x >> 5) * 4;
@@ -237,6 +240,15 @@ int ffgp_gemm(ffgp_handle* h, int opa, int opb, int lower_tiles, int tri, const 
   FFGP_HIP(hipSetDevice(h->device));
   return ffgp_gemm_launch(h, opa ? OP_MNMAJOR : OP_KMAJOR, opb ? OP_MNMAJOR : OP_KMAJOR, lower_tiles ? TILES_LOWER : TILES_FULL,
                           0, A, lda, B, ldb, C, ldc, m, n, k, alpha, beta, tri);
+}
+
+int ffgp_kernel_input_weights(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const double* w,
+                              const double* amp, double clamp_min, int kfun, double kparam, const double* dK, int ldk,
+                              double* Wt, int ldw) {
+  if (!h) return FFGP_ERR_ARG;
+  if (kfun < FFGP_KFUN_SE || kfun > FFGP_KFUN_RQ) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  return ffgp_kernel_wt_impl(h, X1, n1, X2, n2, D, w, amp, clamp_min, kfun, kparam, dK, ldk, Wt, ldw);
 }
 
 int ffgp_kernel_grad(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const double* w,

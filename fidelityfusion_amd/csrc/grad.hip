@@ -256,3 +256,82 @@ int ffgp_kernel_grad_impl(ffgp_handle* h, const double* X1, int n1, const double
   if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
   return FFGP_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Input gradients of a kernel call (posterior-in-the-loop: acquisition functions differentiate the posterior w.r.t.
+// the test inputs, Bayesian_optimization/acq.py:10-80).  For an upstream dK [n1, n2] the kernel writes
+//     Wt_ij = dK_ij * amp * (-2 phi'(s_ij))      (0 where the distance sits on the clamp)
+// from which  dX1 = -w^2 o (rowsum(Wt) o X1 - Wt X2),  dX2 = -w^2 o (colsum(Wt) o X2 - Wt^T X1)  are two thin GEMMs
+// on the matrix cores (done by the caller with a ones column appended to X, so the sums ride along).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ffgp_kernel_wt_kernel(GradArgs a, double* __restrict__ Wt, int ldw) {
+  __shared__ double x1s[AT][DC + 1];
+  __shared__ double x2t[DC][AT + 1];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int tn = (a.n2 + AT - 1) / AT;
+  const int ti = blockIdx.x / tn, tj = blockIdx.x % tn;
+  const int r0 = ti * AT, c0 = tj * AT;
+  double sq[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sq[i][j] = 0.0;
+  for (int d0 = 0; d0 < a.D; d0 += DC) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = tid + 256 * q;
+      const int row = idx >> 4, dd = idx & 15, gd = d0 + dd;
+      const double wk = (gd < a.D) ? a.w[gd] : 0.0;
+      x1s[row][dd] = (gd < a.D && r0 + row < a.n) ? a.X[(size_t)(r0 + row) * a.D + gd] * wk : 0.0;
+      x2t[dd][row] = (gd < a.D && c0 + row < a.n2) ? a.X2[(size_t)(c0 + row) * a.D + gd] * wk : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int dd = 0; dd < DC; ++dd) {
+      double p[4], q2[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) p[i] = x1s[ty + 16 * i][dd];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q2[j] = x2t[dd][tx + 16 * j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const double df = p[i] - q2[j];
+          sq[i][j] = __builtin_fma(df, df, sq[i][j]);
+        }
+    }
+    __syncthreads();
+  }
+  const double amp = a.amp[0];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = r0 + ty + 16 * i;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = c0 + tx + 16 * j;
+      if (row < a.n && col < a.n2) {
+        const double g = a.G[(size_t)row * a.ldg + col];
+        const double sc = fmax(sq[i][j], a.clamp);
+        Wt[(size_t)row * ldw + col] = (sq[i][j] >= a.clamp) ? g * amp * ffgp_kfun_m2d(a.kfun, a.rinv, sc) : 0.0;
+      }
+    }
+  }
+}
+
+int ffgp_kernel_wt_impl(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const double* w,
+                        const double* amp, double clamp, int kfun, double kparam, const double* dK, int ldk, double* Wt,
+                        int ldw) {
+  if (n1 <= 0 || n2 <= 0) return FFGP_OK;
+  if (!X1 || !X2 || !w || !amp || !dK || !Wt || D <= 0 || ldk < n2 || ldw < n2) return FFGP_ERR_ARG;
+  GradArgs a;
+  a.X = X1; a.n = n1; a.X2 = X2; a.n2 = n2; a.rect = 1; a.D = D; a.w = w; a.amp = amp; a.clamp = clamp;
+  a.G = dK; a.ldg = ldk; a.trG = nullptr; a.mj_coef = 0.0; a.partial = nullptr;
+  a.kfun = kfun;
+  a.rinv = (kparam != 0.0) ? 1.0 / kparam : 1.0;
+  const int tm = (n1 + AT - 1) / AT, tn = (n2 + AT - 1) / AT;
+  hipLaunchKernelGGL(ffgp_kernel_wt_kernel, dim3(tm * tn), dim3(256), 0, h->stream, a, Wt, ldw);
+  if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
+  return FFGP_OK;
+}

@@ -293,6 +293,7 @@ class _KernelMatrix(torch.autograd.Function):
                                 0, 0.0, 0.0, _ptr(K), b.shape[0], 0, int(kfun[0]), float(kfun[1])), "ffgp_assemble")
         ctx.saved = (a, b, wd, ad, clamp, kfun, dev)
         ctx.meta = [(t.shape, t.dtype, t.device) for t in (w, amp)]
+        ctx.xmeta = [(t.shape, t.dtype, t.device) for t in (x1, x2)]
         ctx.kp_meta = (kparam.shape, kparam.dtype, kparam.device) if kparam is not None and kparam.requires_grad else None
         odt = x1.dtype if x1.dtype.is_floating_point else torch.float64
         ctx.out = (x1.device, odt)
@@ -317,13 +318,34 @@ class _KernelMatrix(torch.autograd.Function):
         if g_kp is not None:
             ks, kdt, kdev = ctx.kp_meta
             g_kp = g_kp.reshape(ks).to(device=kdev, dtype=kdt)
-        return (None, None, g_w.reshape(ws).to(device=wdev, dtype=wdt), g_amp.reshape(as_).to(device=adev, dtype=adt),
+        gx1 = gx2 = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            # input gradients (acquisition functions differentiate the posterior w.r.t. the test points):
+            # Wt = dK o amp o (-2 phi') from the library, then two thin products with a ones column riding along
+            n1, n2 = a.shape[0], b.shape[0]
+            Wt = torch.empty((n1, n2), dtype=torch.float64, device=dev)
+            check(lib.ffgp_kernel_input_weights(h, _ptr(a), n1, _ptr(b), n2, D, _ptr(wd), _ptr(ad), clamp, int(kfun[0]),
+                                                float(kfun[1]), _ptr(dKd), dKd.shape[1], _ptr(Wt), n2),
+                  "ffgp_kernel_input_weights")
+            w2 = (wd * wd).reshape(1, D)
+            one = lambda t: torch.cat([t, torch.ones((t.shape[0], 1), dtype=torch.float64, device=dev)], 1)
+            if ctx.needs_input_grad[0]:
+                P = _gemm(dev, 0, 1, Wt, one(b), n1, D + 1, n2, 1.0)          # [Wt X2 | rowsum(Wt)]
+                gx1 = -w2 * (P[:, D:] * a - P[:, :D])
+                shp, dt, dv = ctx.xmeta[0]
+                gx1 = gx1.reshape(shp).to(device=dv, dtype=dt)
+            if ctx.needs_input_grad[1]:
+                P = _gemm(dev, 1, 1, Wt, one(a), n2, D + 1, n1, 1.0)          # [Wt^T X1 | colsum(Wt)]
+                gx2 = w2 * (P[:, :D] - P[:, D:] * b)
+                shp, dt, dv = ctx.xmeta[1]
+                gx2 = gx2.reshape(shp).to(device=dv, dtype=dt)
+        return (gx1, gx2, g_w.reshape(ws).to(device=wdev, dtype=wdt), g_amp.reshape(as_).to(device=adev, dtype=adt),
                 None, None, g_kp)
 
 
 def kernel_matrix(x1, x2, w, amp, clamp=NEG_INF, kfun=(0, 1.0)):
-    """K(x1, x2) [n1, n2] on the device (no Sigma extras); differentiable w.r.t. w, amp and a tensor profile
-    parameter."""
+    """K(x1, x2) [n1, n2] on the device (no Sigma extras); differentiable w.r.t. the inputs x1 / x2, w, amp and a
+    tensor profile parameter."""
     kfun, kparam = _split_kfun(kfun)
     return _KernelMatrix.apply(x1, x2, w, amp, clamp, kfun, kparam)
 
@@ -380,6 +402,58 @@ def cholesky(Sigma):
     """Drop-in for torch.linalg.cholesky on the GP path (lower factor, raises LinAlgError if not PD)."""
     L, _ = cholesky_with_rows(Sigma)
     return L.to(device=Sigma.device, dtype=Sigma.dtype)
+
+
+class _CondGauss(torch.autograd.Function):
+    """mu = K_s^T Sigma^-1 y, cov = K_ss - K_s^T Sigma^-1 K_s (gp_computation_pack.py:103-110); y^T and K_s^T ride as
+    passenger rows of ONE factorisation.  Backward (closed form; B = Sigma^-1 K_s, alpha = Sigma^-1 y come from one
+    L^T solve on the saved factor, everything else is GEMMs):
+        dK_s = alpha Gmu^T - B (Gc + Gc^T)      dK_ss = Gc      dy = B Gmu
+        dSigma = -1/2 (dy alpha^T + alpha dy^T) + 1/2 B (Gc + Gc^T) B^T          (symmetric, as torch's cholesky backward)"""
+
+    @staticmethod
+    def forward(ctx, y, Sigma, K_s, K_ss):
+        dev = _device_of(y, Sigma, K_s, K_ss)
+        yd, Ksd = _dev(y, dev), _dev(K_s, dev)
+        d = yd.shape[1]
+        L, R = cholesky_with_rows(Sigma, torch.cat([yd.T, Ksd.T], 0))
+        Gt, Vt = R[:d].contiguous(), R[d:].contiguous()      # Gamma^T [d, n], V^T [nt, n]
+        mu = _gemm(dev, 0, 0, Vt, Gt, Vt.shape[0], d, Vt.shape[1], 1.0)
+        cov = _dev(K_ss, dev) - _gemm(dev, 0, 0, Vt, Vt, Vt.shape[0], Vt.shape[0], Vt.shape[1], 1.0)
+        ctx.saved = (L, Gt, Vt, dev)
+        ctx.meta = [(t.shape, t.dtype, t.device) for t in (y, Sigma, K_s, K_ss)]
+        odt = y.dtype if y.dtype.is_floating_point else torch.float64
+        return mu.to(device=y.device, dtype=odt), cov.to(device=K_ss.device, dtype=K_ss.dtype)
+
+    @staticmethod
+    def backward(ctx, Gmu, Gc):
+        L, Gt, Vt, dev = ctx.saved
+        n, d, nt = L.shape[0], Gt.shape[0], Vt.shape[0]
+        h = _lib.handle(dev.index)
+        _lib.bind_stream(h, dev.index)
+        X = torch.cat([Gt, Vt], 0).T.contiguous()            # [n, d + nt]  ->  [alpha | B] = L^-T [Gamma | V]
+        check(lib.ffgp_trsm_lower_t(h, _ptr(L), n, L.stride(0), _ptr(X), d + nt, X.stride(0)), "ffgp_trsm_lower_t")
+        alpha, B = X[:, :d].contiguous(), X[:, d:].contiguous()
+        Gmu = torch.zeros((nt, d), dtype=torch.float64, device=dev) if Gmu is None else _dev(Gmu, dev)
+        Gc = torch.zeros((nt, nt), dtype=torch.float64, device=dev) if Gc is None else _dev(Gc, dev)
+        Gs = (Gc + Gc.T).contiguous()
+        BGs = _gemm(dev, 0, 0, B, Gs, n, nt, nt, 1.0)         # B Gs   (Gs symmetric: NT form is fine)
+        out = [None, None, None, None]
+        dy = _gemm(dev, 0, 1, B, Gmu, n, d, nt, 1.0)          # B Gmu
+        if ctx.needs_input_grad[0]:
+            out[0] = dy
+        if ctx.needs_input_grad[1]:
+            T1 = _gemm(dev, 0, 0, dy, alpha, n, n, d, 1.0)    # dy alpha^T
+            out[1] = -0.5 * (T1 + T1.T) + _gemm(dev, 0, 0, BGs, B, n, n, nt, 0.5)
+        if ctx.needs_input_grad[2]:
+            out[2] = _gemm(dev, 0, 0, alpha, Gmu, n, nt, d, 1.0) - BGs
+        if ctx.needs_input_grad[3]:
+            out[3] = Gc
+        return tuple(None if t is None else t.reshape(m[0]).to(device=m[2], dtype=m[1]) for t, m in zip(out, ctx.meta))
+
+
+def conditional_gaussian(y, Sigma, K_s, K_ss):
+    return _CondGauss.apply(y, Sigma, K_s, K_ss)
 
 
 class _GaussNLLFromCov(torch.autograd.Function):

@@ -35,7 +35,7 @@ class GP_basic(nn.Module):
     def forward(self, x_train, y_train, x_test, Kinv_method="cholesky3"):
         _check_method(Kinv_method, _METHODS_FWD)
         y_train, y_var = _split(y_train)
-        if not hasattr(self.kernel, "effective"):
+        if not hasattr(self.kernel, "effective") or torch.is_grad_enabled():   # autograd on: differentiable composition
             return self._forward_composed(x_train, y_train, y_var, x_test)
         w, amp, clamp = self.kernel.effective()
         mu, var = F.predict(x_train, y_train, x_test, w, amp, diag_add=self.noise_variance.pow(2), add_mat=y_var,
@@ -50,7 +50,6 @@ class GP_basic(nn.Module):
             Sigma = Sigma + y_var.to(device=Sigma.device, dtype=Sigma.dtype)
         return Sigma
 
-    @torch.no_grad()
     def _forward_composed(self, x_train, y_train, y_var, x_test):
         from .gp_computation_pack import conditional_Gaussian
         K_s = F.kernel_on_device(self.kernel, x_train, x_test)

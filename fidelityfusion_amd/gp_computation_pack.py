@@ -45,16 +45,11 @@ def Gaussian_log_likelihood(y, cov, Kinv_method="cholesky3"):
 
 def conditional_Gaussian(y, Sigma, K_s, K_ss, Kinv_method="cholesky3"):
     """mu = K_s^T Sigma^-1 y ; cov = K_ss - (L^-1 K_s)^T (L^-1 K_s)   (:103-110).
-    Both solves ride as passenger rows of one factorisation."""
+    Both solves ride as passenger rows of one factorisation; differentiable w.r.t. all four arguments (closed-form
+    backward on the saved factor), which is what acquisition optimisers differentiate through
+    (Bayesian_optimization/cigp.py:52-70, acq.py:10-80)."""
     _check_method(Kinv_method, ("cholesky1", "cholesky3", "direct"))
-    dev = F._device_of(y, Sigma, K_s)
-    rows = torch.cat([F._dev(y, dev).T, F._dev(K_s, dev).T], 0)
-    _, R = F.cholesky_with_rows(Sigma, rows)
-    d = y.shape[1]
-    Gt, Vt = R[:d], R[d:]                       # Gamma^T [d, n], V^T [nt, n]
-    mu = F.matmul_nt(Vt, Gt).to(device=y.device, dtype=y.dtype)
-    cov = K_ss - F.matmul_nt(Vt, Vt).to(device=K_ss.device, dtype=K_ss.dtype)
-    return mu, cov
+    return F.conditional_gaussian(y, Sigma, K_s, K_ss)
 
 
 def negative_log_likelihood(kernel, log_beta, x_train, y_train):

@@ -146,6 +146,15 @@ int ffgp_kernel_grad(ffgp_handle* h, const double* X1_dev, int n1, const double*
                      const double* w_dev, const double* amp_dev, double clamp_min, int kfun, double kparam,
                      const double* dK_dev, int ldk, double* g_w_dev, double* g_amp_dev, double* g_kparam_dev);
 
+/* Input gradients of a kernel call -- backward of `kernel(x1, x2)` w.r.t. x1 / x2, which the reference's autograd provides
+ * and its acquisition optimisers rely on (Bayesian_optimization/acq.py:10-80 differentiate the posterior w.r.t. the test
+ * points; CIGP_withMean.forward Bayesian_optimization/cigp.py:52-70).  For an upstream dK [n1, n2] writes
+ *     Wt_ij = dK_ij * amp * (-2 phi'(s_ij))     (0 where the squared distance sits on the clamp)
+ * so that dX1 = -w^2 o (rowsum(Wt) o X1 - Wt X2) and dX2 = -w^2 o (colsum(Wt) o X2 - Wt^T X1): two thin ffgp_gemm calls. */
+int ffgp_kernel_input_weights(ffgp_handle* h, const double* X1_dev, int n1, const double* X2_dev, int n2, int D,
+                              const double* w_dev, const double* amp_dev, double clamp_min, int kfun, double kparam,
+                              const double* dK_dev, int ldk, double* Wt_dev, int ldw);
+
 /* Rebuild the handle's store of inverted 128x128 diagonal blocks for a factor L that this handle did not just
    produce (the triangular solves and ffgp_potri consume it; ffgp_potrf leaves it up to date).               */
 int ffgp_trtri_diag(ffgp_handle* h, const double* L_dev, int n, int ldl);

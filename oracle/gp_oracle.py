@@ -429,6 +429,33 @@ def composed_ll_and_grads(X, Y, parts, combine, sigma_fn, dsigma_scalar, variant
     return ll, out, dS, dY
 
 
+def ard_input_grads(x1, x2, length_scales, signal_variance, Gw, nu=None, rho=1.0):
+    """d sum(Gw o K(x1, x2)) / dx1, / dx2 for ARDKernel (nu=None) / MaternKernel -- what autograd returns through
+    kernel.py:100-105 / :138-169 (entries on cdist's clamp carry no gradient)."""
+    x1, x2 = np.asarray(x1, dtype=np.float64), np.asarray(x2, dtype=np.float64)
+    ell = np.abs(np.asarray(length_scales, dtype=np.float64)) + EPS
+    s = float(np.ravel(signal_variance)[0])
+    sq = cdist_sq(x1 / ell, x2 / ell)
+    m2d = np.exp(-0.5 * sq) if nu is None else matern_profile_m2d(np.maximum(sq, 1e-30), nu, rho)
+    Wt = np.where(sq > 1e-30, Gw * np.abs(s) * m2d, 0.0)          # = -2 Gw o dK/d(sq)
+    w2 = 1.0 / ell ** 2
+    g1 = -w2 * (Wt.sum(1)[:, None] * x1 - Wt @ x2)
+    g2 = w2 * (Wt.T @ x1 - Wt.sum(0)[:, None] * x2)
+    return g1, g2
+
+
+def conditional_gaussian_grads(Y, Sigma, K_s, Gmu, Gc):
+    """Gradients of sum(Gmu o mu) + sum(Gc o cov) for mu, cov = conditional_gaussian(...): (dY, dSigma symmetric,
+    dK_s, dK_ss)."""
+    L = cholesky_lower(Sigma)
+    alpha = cho_solve(L, np.asarray(Y, dtype=np.float64))
+    B = cho_solve(L, np.asarray(K_s, dtype=np.float64))
+    Gs = Gc + Gc.T
+    dy = B @ Gmu
+    dS = -0.5 * (dy @ alpha.T + alpha @ dy.T) + 0.5 * B @ Gs @ B.T
+    return dy, dS, alpha @ Gmu.T - B @ Gs, Gc
+
+
 def tensor_linear(x, vectors):
     """Tensor_linear.forward, gp_computation_pack.py:155-159: `y = mode_dot(x, vectors[i], i + 1)` is evaluated on the
     INPUT for every i, so the value returned is the last mode's product alone."""

@@ -499,6 +499,59 @@ def main():
         extra.update({f"res{fi}_x": xr, f"res{fi}_mean": yr[0], f"res{fi}_var": yr[1]})
     save("cigar_chain", x0n=x0n, y0n=y0n, xtn=xtn, ll_trace=np.array(losses), ypred=yp, var_pred=vp, **extra, **sd)
 
+    # ------------------------------------------------------------------ posterior in the loop: input gradients
+    g5 = torch.Generator().manual_seed(4242)
+    kin = {}
+    D = 3
+    kernels = {"ard": rk.ARDKernel(D), "se": rk.SquaredExponentialKernel(0.3, 0.2), "matern15": rk.MaternKernel(D, nu=1.5),
+               "rq": rk.RationalQuadraticKernel(0.9, 1.1, 1.4)}
+    with torch.no_grad():
+        kernels["ard"].length_scales.copy_(torch.tensor([0.7, -1.3, 0.9]))
+        kernels["matern15"].length_scales.copy_(torch.tensor([1.2, 0.8, -0.6]))
+    for tag, k in kernels.items():
+        a = (torch.rand(23, D, generator=g5) * 2).requires_grad_(True)
+        b = (torch.rand(17, D, generator=g5) * 2).requires_grad_(True)
+        R = torch.randn(23, 17, generator=g5)
+        Rs = torch.randn(17, 17, generator=g5)
+        ((k(a, b) * R).sum() + (k(b, b) * Rs).sum()).backward()
+        kin.update({f"{tag}_x1": a, f"{tag}_x2": b, f"{tag}_R": R, f"{tag}_Rs": Rs, f"{tag}_gx1": a.grad, f"{tag}_gx2": b.grad})
+        kin.update({f"{tag}_p__{n_}": p_ for n_, p_ in k.named_parameters()})
+    save("kernel_input_grads", **kin)
+
+    # cigp.forward differentiated w.r.t. x_test / y / parameters (what an acquisition optimiser does, acq.py:48-58)
+    n, d, nt = 70, 2, 9
+    X, Y = make_xy(g5, n, D, d)
+    Y = Y.clone().requires_grad_(True)
+    k = rk.ARDKernel(D)
+    with torch.no_grad():
+        k.length_scales.copy_(torch.tensor([0.8, 1.1, -0.9]))
+        k.signal_variance.copy_(torch.tensor([1.3]))
+    m = RCIGP(k, log_beta=1.4)
+    xs = torch.rand(nt, D, generator=g5).requires_grad_(True)
+    R1, R2 = torch.randn(nt, d, generator=g5), torch.randn(nt, nt, generator=g5)
+    mean, var = m(X, Y, xs)
+    ((mean * R1).sum() + (var * R2).sum()).backward()
+    save("cigp_forward_grads", X=X, Y=Y, xs=xs, R1=R1, R2=R2, mean=mean, var=var, g_xs=xs.grad, g_Y=Y.grad,
+         **params_of(m), **grads_of(m))
+
+    # Bayesian_optimization/cigp.py CIGP_withMean.forward (normalisers + conditional_Gaussian) and its x_test gradient
+    try:
+        sys.modules.setdefault("GaussianProcess.gp_transform", types.ModuleType("GaussianProcess.gp_transform"))
+        from Bayesian_optimization.cigp import CIGP_withMean as RBO
+        xtr = torch.rand(40, 2, generator=g5) * 5
+        ytr = torch.hstack([torch.sin(xtr.sum(1, keepdim=True)), torch.cos(xtr[:, :1])]) + 0.1 * torch.randn(40, 2, generator=g5)
+        kb = rk.ARDKernel(2)
+        bo = RBO(2, 2, kb, 0.3)
+        xq = (torch.rand(11, 2, generator=g5) * 5).requires_grad_(True)
+        Rm, Rc = torch.randn(11, 2, generator=g5), torch.randn(11, 2, generator=g5)
+        mu, cov = bo(xtr, ytr, xq)
+        ((mu * Rm).sum() + (cov * Rc).sum()).backward()
+        ll = bo.log_likelihood(xtr, ytr)
+        save("bo_cigp_withmean", xtr=xtr, ytr=ytr, xq=xq, Rm=Rm, Rc=Rc, mu=mu, cov=cov, g_xq=xq.grad, ll=ll,
+             noise_variance=bo.noise_variance, length_scales=kb.length_scales, signal_variance=kb.signal_variance)
+    except Exception as e:  # noqa
+        print("bo_cigp_withmean skipped:", repr(e))
+
 
     os.chdir(cwd)
 

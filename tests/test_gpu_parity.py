@@ -322,6 +322,74 @@ def test_cigar_chain_golden(golden):
     assert rel(vp, g["var_pred"]) < 1e-7
 
 
+# ------------------------------------------------------------------------ posterior in the loop
+def test_kernel_input_grads_golden(golden):
+    """backward of kernel(x1, x2) w.r.t. its inputs (ffgp_kernel_input_weights + two thin GEMMs), incl. k(x, x)"""
+    from fidelityfusion_amd import kernel
+    g = golden("kernel_input_grads")
+    ks = {"ard": kernel.ARDKernel(3), "se": kernel.SquaredExponentialKernel(), "matern15": kernel.MaternKernel(3, nu=1.5),
+          "rq": kernel.RationalQuadraticKernel()}
+    for tag, k in ks.items():
+        with torch.no_grad():
+            for n_, p_ in k.named_parameters():
+                p_.copy_(torch.tensor(g[f"{tag}_p__{n_}"]).reshape(p_.shape))
+        a, b = T(g[f"{tag}_x1"], grad=True), T(g[f"{tag}_x2"], grad=True)
+        ((k(a, b) * T(g[f"{tag}_R"])).sum() + (k(b, b) * T(g[f"{tag}_Rs"])).sum()).backward()
+        assert rel(a.grad, g[f"{tag}_gx1"]) < 1e-9, tag
+        assert rel(b.grad, g[f"{tag}_gx2"]) < 1e-9, tag
+
+
+@pytest.mark.parametrize("where", ["cuda", "cpu"])
+def test_cigp_forward_grads_golden(golden, where):
+    """cigp.forward with autograd on: gradients w.r.t. x_test (acquisition optimisation), y and every parameter"""
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp
+    g = golden("cigp_forward_grads")
+    m = cigp(kernel.ARDKernel(3), 0.0)
+    want = _load_params(m, g)
+    dev = DEV if where == "cuda" else "cpu"
+    m = m.to(dev)
+    tt = lambda a, gr=False: torch.tensor(np.asarray(a), dtype=torch.float64, device=dev, requires_grad=gr)
+    Y, xs = tt(g["Y"], True), tt(g["xs"], True)
+    mean, var = m(tt(g["X"]), Y, xs)
+    assert rel(mean, g["mean"]) < 1e-9 and rel(var, g["var"]) < 1e-9
+    ((mean * tt(g["R1"])).sum() + (var * tt(g["R2"])).sum()).backward()
+    assert xs.grad.device.type == where
+    assert rel(xs.grad, g["g_xs"]) < 1e-8
+    assert rel(Y.grad, g["g_Y"]) < 1e-8
+    _check_param_grads(m, want)
+    with torch.no_grad():   # the fused no_grad posterior gives the same numbers
+        mean2, var2 = m(tt(g["X"]), Y.detach(), xs.detach())
+    assert rel(mean2, g["mean"]) < 1e-9 and rel(var2, g["var"]) < 1e-9
+
+
+def test_bo_cigp_withmean_golden(golden):
+    """Bayesian_optimization/cigp.py CIGP_withMean (:52-76) written against the drop-in kernel + gp_computation_pack:
+    posterior, its gradient w.r.t. the query points, and the log likelihood"""
+    import fidelityfusion_amd.gp_computation_pack as gp_pack
+    from fidelityfusion_amd import kernel
+    g = golden("bo_cigp_withmean")
+    k = kernel.ARDKernel(2)
+    with torch.no_grad():
+        k.length_scales.copy_(torch.tensor(g["length_scales"]))
+        k.signal_variance.copy_(torch.tensor(g["signal_variance"]))
+    noise = torch.tensor(g["noise_variance"])
+    xtr, ytr, xq = torch.tensor(g["xtr"]), torch.tensor(g["ytr"]), torch.tensor(g["xq"], requires_grad=True)
+    Xm, Xs_, Ym, Ys = xtr.mean(0), xtr.std(0), ytr.mean(0), ytr.std(0)
+    x, y, xt = (xtr - Xm) / Xs_, (ytr - Ym) / Ys, (xq - Xm) / Xs_
+    n = len(x)
+    K = k(x, x) + noise.pow(2) * torch.eye(n) + 1e-6 * torch.eye(n)
+    mu, cov = gp_pack.conditional_Gaussian(y, K, k(x, xt), k(xt, xt))
+    cov = cov.diag().view(-1, 1).expand_as(mu)
+    mu = mu * Ys + Ym
+    cov = cov * Ys ** 2
+    assert rel(mu, g["mu"]) < 1e-9 and rel(cov, g["cov"]) < 1e-9
+    ((mu * torch.tensor(g["Rm"])).sum() + (cov * torch.tensor(g["Rc"])).sum()).backward()
+    assert rel(xq.grad, g["g_xq"]) < 1e-8
+    ll = gp_pack.Gaussian_log_likelihood(y, k(x, x) + noise.pow(2) * torch.eye(n))
+    assert rel(ll, g["ll"]) < 1e-10
+
+
 def test_user_defined_kernel_module():
     """Any nn.Module kernel written in plain torch (CPU parameters, no descriptor) still runs: its K is moved to the
     device and factored there; gradients flow back through torch autograd into the user's parameters."""

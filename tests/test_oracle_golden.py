@@ -290,3 +290,35 @@ def test_tensor_linear(golden, tag, nv):
     g = golden("tensor_linear")
     vs = [g[f"{tag}_v{i}"] for i in range(nv)]
     close(O.tensor_linear(g[f"{tag}_x"], vs), g[f"{tag}_y"], 1e-12)
+
+
+# ------------------------------------------------------------------ posterior in the loop
+def test_kernel_input_grads(golden):
+    g = golden("kernel_input_grads")
+    for tag, nu in (("ard", None), ("matern15", 1.5)):
+        ls, sv = g[f"{tag}_p__length_scales"], g[f"{tag}_p__signal_variance"]
+        g1, g2 = O.ard_input_grads(g[f"{tag}_x1"], g[f"{tag}_x2"], ls, sv, g[f"{tag}_R"], nu=nu)
+        _, g2a = O.ard_input_grads(g[f"{tag}_x2"], g[f"{tag}_x2"], ls, sv, g[f"{tag}_Rs"], nu=nu)
+        g1b, _ = O.ard_input_grads(g[f"{tag}_x2"], g[f"{tag}_x2"], ls, sv, g[f"{tag}_Rs"], nu=nu)
+        close(g1, g[f"{tag}_gx1"], 1e-9)
+        close(g2 + g2a + g1b, g[f"{tag}_gx2"], 1e-9)
+
+
+def test_cigp_forward_grads(golden):
+    """cigp.forward (cigp_v10.py:24-48) differentiated w.r.t. x_test and y: kernel input gradients chained through the
+    closed-form conditional-Gaussian backward"""
+    g = golden("cigp_forward_grads")
+    ls, sv, lb = g["p__kernel__length_scales"], g["p__kernel__signal_variance"], g["p__log_beta"]
+    kf = lambda a, b: O.ard_kernel(a, b, ls, sv)
+    X, Y, xs = g["X"], g["Y"], g["xs"]
+    mean, var = O.cigp_forward(X, Y, xs, kf, lb)
+    close(mean, g["mean"], 1e-9)
+    close(var, g["var"], 1e-9)
+    S = O.sigma_cigp(kf(X, X), lb)
+    dy, dS, dKs, dKss = O.conditional_gaussian_grads(Y, S, kf(X, xs), g["R1"], g["R2"])
+    close(dy, g["g_Y"], 1e-8)
+    _, gxs_a = O.ard_input_grads(X, xs, ls, sv, dKs)
+    g1, g2 = O.ard_input_grads(xs, xs, ls, sv, dKss)
+    close(gxs_a + g1 + g2, g["g_xs"], 1e-8)
+    # log_beta: Sigma's diagonal and the noise added to every entry of var both carry exp(-log_beta)
+    close(-np.exp(-lb[0]) * (np.trace(dS) + g["R2"].sum()), g["g__log_beta"], 1e-8)
