@@ -505,12 +505,19 @@ int ffgp_ensure_dinv(ffgp_handle* h, int n) {
 // (re)build the inverted diagonal blocks for a factor that is already in L (used when a caller hands us a
 // factor this handle did not just produce)
 int ffgp_refresh_dinv(ffgp_handle* h, const double* L, int n, int ldl) {
+  // a factor that only GREW since the store was built (rows appended to the same buffer, functional.Posterior.append)
+  // keeps its leading blocks: rebuild from the last, possibly partial, old block on -- unless the store must be
+  // re-allocated, which drops its content
+  int b_first = 0;
+  const size_t need = (size_t)((n + NB - 1) / NB) * NB * NB * sizeof(double);
+  if (!h->use_naive && h->dinv_L == L && h->dinv_ld == ldl && h->dinv_n > 0 && n > h->dinv_n && need <= h->dinv_bytes)
+    b_first = h->dinv_n / NB;
   FFGP_CHECK(ffgp_ensure_dinv(h, n));
   const int nblk = (n + NB - 1) / NB;
   if (h->use_naive) {
     hipLaunchKernelGGL(ffgp_dinv_naive, dim3(nblk), dim3(128), 0, h->stream, L, ldl, n, h->dinv);
   } else {
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = b_first; b < nblk; ++b) {
       const int r0 = b * NB;
       FFGP_CHECK(launch_diag(h, const_cast<double*>(L) + (size_t)r0 * ldl + r0, ldl, min(NB, n - r0),
                              h->dinv + (size_t)b * NB * NB, r0, 0));

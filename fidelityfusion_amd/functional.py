@@ -541,3 +541,114 @@ class _MatmulNT(torch.autograd.Function):
 def matmul_nt(A, B, alpha=1.0):
     """alpha * A @ B^T for A [m, k], B [n, k] on the fp64 matrix-core GEMM (ffgp_gemm); fp64 result on the device."""
     return _MatmulNT.apply(A, B, alpha)
+
+
+class Posterior:
+    """A factored GP block kept on the device: factor once, query many times, append points without refactorising
+    (the reference's `cigp.forward` re-runs `torch.linalg.cholesky` on every call,
+    cigp_v10.py:31-35 -- inside an acquisition loop or when serving predictions that is N^3/3 per query for a factor
+    that has not changed).
+
+        predict(Xs)      assembly of K_s, one TRSM sweep on the cached factor (N^2 nt), two thin GEMMs
+        append(X, Y)     L21 = (L^-1 K_nk)^T, L22 = chol(S_kk - L21 L21^T): O(N^2 k) instead of O(N^3 / 3)
+
+    Parameters are the library's effective ones (w, amp, diag_add, clamp, kfun), frozen at construction."""
+
+    def __init__(self, X, Y, w, amp, diag_add, clamp=NEG_INF, kfun=(0, 1.0), capacity=None):
+        dev = _device_of(X, Y, w, amp)
+        self.dev = dev
+        self.kfun, _ = _split_kfun(kfun)
+        self.clamp = clamp
+        Xd, Yd = _dev(X, dev), _dev(Y, dev)
+        n, D = Xd.shape
+        wd = _dev(w.reshape(-1), dev)
+        self.w = wd.expand(D).contiguous() if wd.numel() == 1 and D > 1 else wd
+        self.amp = _dev(amp.reshape(-1)[:1], dev)
+        self.dadd = _dev(diag_add.reshape(-1)[:1], dev)
+        self.cap = max(int(capacity or 0), n)
+        self.ld = _pad_ld(self.cap)
+        self.W = torch.zeros((self.cap, self.ld), dtype=torch.float64, device=dev)
+        self.X = torch.empty((self.cap, D), dtype=torch.float64, device=dev)
+        self.X[:n] = Xd
+        self.n, self.D, self.d = n, D, Yd.shape[1]
+        h = self._h()
+        self._assemble(Xd, Xd, self.W, self.ld, lower=1, diag=True)
+        rc = check(lib.ffgp_potrf(h, _ptr(self.W), n, self.ld), "ffgp_potrf")
+        if rc > 0:
+            _raise_not_pd(rc, "linalg.cholesky")
+        self.Gamma = Yd.clone()
+        check(lib.ffgp_trsm_lower(h, _ptr(self.W), n, self.ld, _ptr(self.Gamma), self.d, self.d), "ffgp_trsm_lower")
+        self._solve_alpha()
+
+    def _h(self):
+        h = _lib.handle(self.dev.index)
+        _lib.bind_stream(h, self.dev.index)
+        return h
+
+    def _assemble(self, A, B, out, ld, lower, diag):
+        check(lib.ffgp_assemble(self._h(), _ptr(A), A.shape[0], _ptr(B), B.shape[0], self.D, _ptr(self.w), _ptr(self.amp),
+                                self.clamp, _ptr(self.dadd) if diag else None, None, 0, None, 0, 0.0, 0.0, _ptr(out), ld, lower,
+                                int(self.kfun[0]), float(self.kfun[1])), "ffgp_assemble")
+
+    def _solve_alpha(self):
+        self.alpha = self.Gamma.clone()
+        check(lib.ffgp_trsm_lower_t(self._h(), _ptr(self.W), self.n, self.ld, _ptr(self.alpha), self.d, self.d),
+              "ffgp_trsm_lower_t")
+
+    @torch.no_grad()
+    def predict(self, Xs, full_cov=True, var_add_all=0.0):
+        """mean [nt, d], covariance [nt, nt] (or variance [nt]) at Xs; the noise convention is the caller's
+        (`var_add_all` lands on every entry, cigp_v10.py:44)."""
+        dev, n = self.dev, self.n
+        Xsd = _dev(Xs, dev)
+        nt = Xsd.shape[0]
+        Ks = torch.empty((n, nt), dtype=torch.float64, device=dev)
+        self._assemble(self.X[:n], Xsd, Ks, nt, lower=0, diag=False)
+        mean = _gemm(dev, 1, 1, Ks, self.alpha, nt, self.d, n, 1.0)                 # K_s^T alpha
+        check(lib.ffgp_trsm_lower(self._h(), _ptr(self.W), n, self.ld, _ptr(Ks), nt, nt), "ffgp_trsm_lower")   # V = L^-1 K_s
+        if full_cov:
+            var = torch.empty((nt, nt), dtype=torch.float64, device=dev)
+            self._assemble(Xsd, Xsd, var, nt, lower=0, diag=False)
+            var = var - _gemm(dev, 1, 1, Ks, Ks, nt, nt, n, 1.0) + var_add_all
+        else:
+            var = float(self.amp) - (Ks * Ks).sum(0) + var_add_all      # phi(0) = 1 for every radial profile
+        return mean, var
+
+    @torch.no_grad()
+    def append(self, X_new, Y_new):
+        """Extend the factor by k points: the new block row of L is a TRSM on the cached factor, the new diagonal
+        block a k x k Cholesky of the Schur complement."""
+        dev, n, h = self.dev, self.n, self._h()
+        Xn, Yn = _dev(X_new, dev), _dev(Y_new, dev)
+        k = Xn.shape[0]
+        if n + k > self.cap:       # grow geometrically; the factor is copied once
+            cap = max(n + k, 2 * self.cap)
+            ld = _pad_ld(cap)
+            W = torch.zeros((cap, ld), dtype=torch.float64, device=dev)
+            W[:n, :n] = self.W[:n, :n]
+            Xb = torch.empty((cap, self.D), dtype=torch.float64, device=dev)
+            Xb[:n] = self.X[:n]
+            self.W, self.X, self.cap, self.ld = W, Xb, cap, ld
+        B = torch.empty((n, k), dtype=torch.float64, device=dev)
+        self._assemble(self.X[:n], Xn, B, k, lower=0, diag=False)
+        check(lib.ffgp_trsm_lower(h, _ptr(self.W), n, self.ld, _ptr(B), k, k), "ffgp_trsm_lower")        # L^-1 K_nk = L21^T
+        ks = _pad_ld(k)
+        S = torch.zeros((k, ks), dtype=torch.float64, device=dev)
+        self._assemble(Xn, Xn, S, ks, lower=0, diag=True)
+        S[:, :k] -= _gemm(dev, 1, 1, B, B, k, k, n, 1.0)                                                 # Schur complement
+        # the small factor goes through a second handle: this handle's store of inverted diagonal blocks stays
+        # attached to the big factor and is only extended by the new blocks
+        h2 = _lib.handle(dev.index, 1)
+        _lib.bind_stream(h2, dev.index)
+        rc = check(lib.ffgp_potrf(h2, _ptr(S), k, ks), "ffgp_potrf")
+        if rc > 0:
+            _raise_not_pd(n + rc, "linalg.cholesky")
+        G_new = Yn - _gemm(dev, 1, 1, B, self.Gamma, k, self.d, n, 1.0)                                  # y_new - L21 Gamma
+        check(lib.ffgp_trsm_lower(h2, _ptr(S), k, ks, _ptr(G_new), self.d, self.d), "ffgp_trsm_lower")
+        self.W[n:n + k, :n] = B.T
+        self.W[n:n + k, n:n + k] = torch.tril(S[:, :k])
+        self.X[n:n + k] = Xn
+        self.Gamma = torch.cat([self.Gamma, G_new], 0)
+        self.n = n + k
+        self._solve_alpha()
+

@@ -390,6 +390,65 @@ def test_bo_cigp_withmean_golden(golden):
     assert rel(ll, g["ll"]) < 1e-10
 
 
+def test_posterior_reuse_and_append():
+    """factor once / query many / append without refactorising.  (1) a cached factor gives the fused
+    posterior's numbers; (2) building on n0 points and appending the rest in two chunks equals building on all of them;
+    (3) cigp.forward re-uses its factor exactly while tensors and parameters are unchanged, and never afterwards."""
+    import copy
+    from fidelityfusion_amd import functional as F
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp
+    from oracle import gp_oracle as O
+    rng = np.random.default_rng(5)
+    n, D, d, nt = 700, 4, 3, 37          # crosses 128-block boundaries; odd offsets on append
+    X, Y, Xs = rng.uniform(size=(n, D)), rng.standard_normal((n, d)), rng.uniform(size=(nt, D))
+    ls, sv, lb = np.array([0.6, 0.9, 1.3, 0.8]), np.array([1.2]), 1.1
+    kf = lambda a, b: O.ard_kernel(a, b, ls, sv)
+    mean_o, var_o = O.cigp_forward(X, Y, Xs, kf, lb)
+    w, amp = T(1.0 / (np.abs(ls) + 1e-9)), T(np.abs(sv))
+    dadd = T([np.exp(-lb) + 1e-6])
+    post = F.Posterior(T(X), T(Y), w, amp, dadd, clamp=1e-30)
+    mean, var = post.predict(T(Xs), var_add_all=float(np.exp(-lb)))
+    assert rel(mean, mean_o) < 1e-9 and rel(var, var_o) < 1e-9
+    _, vd = post.predict(T(Xs), full_cov=False, var_add_all=float(np.exp(-lb)))
+    assert rel(vd, np.diag(var_o)) < 1e-9
+    inc = F.Posterior(T(X[:301]), T(Y[:301]), w, amp, dadd, clamp=1e-30, capacity=400)   # forces one reallocation
+    inc.append(T(X[301:430]), T(Y[301:430]))
+    inc.append(T(X[430:]), T(Y[430:]))
+    assert inc.n == n
+    m2, v2 = inc.predict(T(Xs), var_add_all=float(np.exp(-lb)))
+    assert rel(m2, mean_o) < 1e-9 and rel(v2, var_o) < 1e-9
+    assert rel(torch.tril(inc.W[:n, :n]), np.linalg.cholesky(O.sigma_cigp(kf(X, X), lb))) < 1e-11
+
+    k = kernel.ARDKernel(D)
+    with torch.no_grad():
+        k.length_scales.copy_(torch.tensor(ls))
+        k.signal_variance.copy_(torch.tensor(sv))
+    m = cigp(k, lb).to(DEV)
+    xt, yt = T(X), T(Y)
+    with torch.no_grad():
+        a1, b1 = m(xt, yt, T(Xs))
+        p1 = m._post[2]
+        a2, b2 = m(xt, yt, T(Xs[:5]))
+        assert m._post[2] is p1                                   # same tensors, same versions: factor re-used
+        assert rel(a1, mean_o) < 1e-9 and rel(b1, var_o) < 1e-9 and rel(a2, mean_o[:5]) < 1e-9
+        m.log_beta.add_(0.3)                                      # what optimizer.step() does: in-place update
+        a3, _ = m(xt, yt, T(Xs))
+        assert m._post[2] is not p1
+        assert rel(a3, O.cigp_forward(X, Y, Xs, kf, lb + 0.3)[0]) < 1e-9
+        p3 = m._post[2]
+        yt2 = yt.clone()                                          # a different tensor object (even with equal data)
+        m(xt, yt2, T(Xs))
+        assert m._post[2] is not p3
+        yt2.mul_(2.0)                                             # same object, modified in place
+        a5, _ = m(xt, yt2, T(Xs))
+        assert rel(a5, 2.0 * O.cigp_forward(X, Y, Xs, kf, lb + 0.3)[0]) < 1e-9
+    m_copy = copy.deepcopy(m)
+    assert m_copy._post is None or m_copy._post[2] is not None    # deepcopy / pickling do not choke on the cache
+    import pickle
+    assert pickle.loads(pickle.dumps(m))._post is None
+
+
 def test_user_defined_kernel_module():
     """Any nn.Module kernel written in plain torch (CPU parameters, no descriptor) still runs: its K is moved to the
     device and factored there; gradients flow back through torch autograd into the user's parameters."""
