@@ -9,6 +9,9 @@ parity and benchmarks exercise it the way the reference does:
   * `resgp_predict`    -- `ResGP.forward` (ResGP.py:31-65): sum of per-fidelity posterior means and covariances;
   * `CIGAR` / `train_cigar` -- `CIGAR.forward` and `train_CIGAR` (FidelityFusion_Models/CIGAR.py:40-134): residual
                           blocks behind the learnable `Tensor_linear` fidelity map, y given as [mean, variance];
+  * `fidelity_kernel_MCMC`, `ContinuousAutoRegression`, `train_car` -- CAR (FidelityFusion_Models/
+                          CAR_ContinuousAutoRegression.py:14-133): `GP_basic` blocks whose residual kernels are a base
+                          kernel times a Monte-Carlo fidelity integral;
   * `ResGP2023`        -- the 2023 joint loss `loss = sum_f cigp_list[f].compute_loss(x, res_f)` with the fixed-rho
                           residual chain (MFGP_ver2023May/ResGP.py:200-246, multiscale_coupling/Residual.py:9-33) and
                           its `forward` (:145-171), aligned / subset regime (one shared x).
@@ -16,6 +19,7 @@ parity and benchmarks exercise it the way the reference does:
 import torch
 
 from .cigp_v10 import cigp
+from .gp_basic import GP_basic
 from .gp_computation_pack import Tensor_linear
 from .mfgp2023 import CIGP
 
@@ -147,5 +151,115 @@ def train_cigar(model, data0, fills, max_iter=100, lr_init=1e-1):
                 ll = model.gpr_list[f].negative_log_likelihood(x, [res_mean, res_var])
                 trace.append(float(ll.detach()))
                 (-ll).backward()
+                optimizer.step()
+    return trace, data
+
+
+class fidelity_kernel_MCMC(torch.nn.Module):
+    """CAR's fidelity kernel (CAR_ContinuousAutoRegression.py:14-67): kernel1(x1, x2) times
+    |signal_variance| * MC-integral over the fidelity indicator, 100 uniform samples drawn after
+    `torch.manual_seed(105)` on every call (the reference reseeds the global generator there; kept).  The scalar is
+    plain torch (autograd reaches b, length_scales, signal_variance); it is folded into the base kernel's amplitude, so
+    a stationary kernel1 stays on the fused path (`effective()` / `kfun()`)."""
+    _ffgp_device_aware = True
+
+    def __init__(self, input_dim, kernel1, lf, hf, b, initial_length_scale=1.0, initial_signal_variance=1.0, eps=1e-3):
+        super().__init__()
+        self.kernel1 = kernel1
+        self.b = b
+        self.lf = lf
+        self.hf = hf
+        self.length_scales = torch.nn.Parameter(torch.ones(input_dim) * initial_length_scale)
+        self.signal_variance = torch.nn.Parameter(torch.tensor([initial_signal_variance]))
+        self.eps = eps
+        self.seed = 105
+
+    def scale(self):
+        length_scales = torch.abs(self.length_scales) + self.eps
+        N = 100
+        torch.manual_seed(self.seed)
+        z1 = torch.rand(N) * (self.hf - self.lf) + self.lf
+        z2 = torch.rand(N) * (self.hf - self.lf) + self.lf
+        ls = length_scales.cpu()
+        dist_z = (z1 / ls - z2 / ls) ** 2
+        b = self.b.cpu()
+        z_part = (-b * (z1 - self.hf) - b * (z2 - self.hf) - 0.5 * dist_z).exp()
+        z_part_mc = z_part.mean() * (self.hf - self.lf) * (self.hf - self.lf)
+        return self.signal_variance.abs().cpu() * z_part_mc
+
+    @property
+    def effective(self):
+        # hasattr(kernel, "effective") is how the GP modules pick the fused path: only a stationary base kernel has it
+        if not hasattr(self.kernel1, "effective"):
+            raise AttributeError("effective")
+        return self._effective
+
+    def _effective(self):
+        w, amp, clamp = self.kernel1.effective()
+        return w, amp * self.scale().to(amp.device), clamp
+
+    def kfun(self):
+        return self.kernel1.kfun() if hasattr(self.kernel1, "kfun") else (0, 1.0)
+
+    def forward(self, x1, x2):
+        K = self.kernel1(x1, x2)
+        return self.scale().to(K.device) * K
+
+
+class ContinuousAutoRegression(torch.nn.Module):
+    """CAR (:69-114) on the drop-in blocks; `data[i] = (x, y)` replaces the data manager (fidelity 0, then the
+    residual sets `train_car` produces)."""
+
+    def __init__(self, fidelity_num, kernel_list, b_init=1.0):
+        super().__init__()
+        self.fidelity_num = fidelity_num
+        self.b = torch.nn.Parameter(torch.tensor(b_init))
+        blocks = [GP_basic(kernel=kernel_list[0], noise_variance=1.0)]
+        for f in range(fidelity_num - 1):
+            input_dim = kernel_list[0].length_scales.shape[0]
+            blocks.append(GP_basic(kernel=fidelity_kernel_MCMC(input_dim, kernel_list[f + 1], f, f + 1, self.b),
+                                   noise_variance=1.0))
+        self.cigp_list = torch.nn.ModuleList(blocks)
+
+    def forward(self, data, x_test):
+        y_high = cov_high = y_low = cov_low = None
+        for i in range(self.fidelity_num):
+            x_train, y_train = data[i]
+            if i == 0:
+                y_low, cov_low = self.cigp_list[0](x_train, y_train, x_test)
+                if self.fidelity_num == 1:
+                    y_high, cov_high = y_low, cov_low
+            else:
+                y_res, cov_res = self.cigp_list[i](x_train, y_train, x_test)
+                y_high = y_low + self.b * y_res
+                cov_high = cov_low + (self.b ** 2) * cov_res
+                y_low, cov_low = y_high, cov_high
+        return y_high, cov_high
+
+
+def train_car(model, data0, overlaps, max_iter=100, lr_init=1e-1):
+    """`train_CAR` (:116-148).  overlaps[i-1] = (y_low, subset_x, y_high) on the shared inputs of fidelities i-1 and i.
+    Returns (LL trace, data list for `ContinuousAutoRegression.forward`)."""
+    trace, data = [], [data0]
+    for f in range(model.fidelity_num):
+        optimizer = torch.optim.Adam(model.parameters(), lr=lr_init)
+        if f == 0:
+            x, y = data0
+            for _ in range(max_iter):
+                optimizer.zero_grad()
+                ll = model.cigp_list[0].log_likelihood(x, y)
+                trace.append(float(ll.detach()))
+                (-ll).sum().backward()
+                optimizer.step()
+        else:
+            y_low, x, y_high = overlaps[f - 1]
+            for i in range(max_iter):
+                optimizer.zero_grad()
+                y_res = y_high - model.b.exp() * y_low
+                if i == max_iter - 1:
+                    data.append((x.detach(), y_res.detach()))
+                ll = model.cigp_list[f].log_likelihood(x, y_res)
+                trace.append(float(ll.detach()))
+                (-ll).sum().backward()
                 optimizer.step()
     return trace, data

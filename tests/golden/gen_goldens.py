@@ -552,6 +552,52 @@ def main():
     except Exception as e:  # noqa
         print("bo_cigp_withmean skipped:", repr(e))
 
+    # ------------------------------------------------------------------ CAR: GP_basic blocks behind the MC fidelity kernel (last item)
+    from FidelityFusion_Models.CAR_ContinuousAutoRegression import ContinuousAutoRegression as RCAR, train_CAR
+    torch.manual_seed(21)
+    pool = torch.rand(100, 1) * 10
+    perm = torch.randperm(100)
+    idx = [torch.sort(perm[:n_]).values for n_ in (60, 45, 30)]
+    xs = [pool[i] for i in idx]
+    ys = [torch.sin(xs[0]) - 0.5 * torch.sin(2 * xs[0]) + 0.05 * torch.rand(60, 1),
+          torch.sin(xs[1]) - 0.3 * torch.sin(2 * xs[1]) + 0.05 * torch.rand(45, 1),
+          torch.sin(xs[2]) + 0.05 * torch.rand(30, 1)]
+    xt = torch.linspace(0, 10, 13).reshape(-1, 1)
+    mgr = MultiFidelityDataManager([{"raw_fidelity_name": str(i), "fidelity_indicator": i, "X": xs[i], "Y": ys[i]} for i in range(3)])
+    car = RCAR(3, [rk.ARDKernel(1) for _ in range(3)], b_init=1.0)
+    lls, overlaps = [], []
+    _orig_ll = RGPB.log_likelihood
+    _orig_ov = MultiFidelityDataManager.get_overlap_input_data
+
+    def _spy_ll(self, x, y, *a, **kw):
+        r = _orig_ll(self, x, y, *a, **kw)
+        lls.append(float(r))
+        return r
+
+    def _spy_ov(self, *a, **kw):
+        r = _orig_ov(self, *a, **kw)
+        overlaps.append(r)
+        return r
+
+    RGPB.log_likelihood = _spy_ll
+    MultiFidelityDataManager.get_overlap_input_data = _spy_ov
+    with contextlib.redirect_stdout(io.StringIO()):
+        train_CAR(car, mgr, max_iter=4, lr_init=1e-2)
+    RGPB.log_likelihood = _orig_ll
+    MultiFidelityDataManager.get_overlap_input_data = _orig_ov
+    with torch.no_grad():
+        yp, vp = car(mgr, xt)
+    extra = {}
+    for fi, ov in enumerate(overlaps, start=1):
+        extra.update({f"ov{fi}_ylow": ov[1], f"ov{fi}_x": ov[2], f"ov{fi}_yhigh": ov[3]})
+        # what CAR.forward reads back: get_data(-i) NORMALISES the stored residual set with a Normalizer of its own
+        # (MF_data.py:134-135,141-143), although the block was trained on the un-normalised one -- kept as is
+        rx, ry = mgr.get_data(-fi)
+        extra.update({f"res{fi}_x_fwd": rx, f"res{fi}_y_fwd": ry})
+    x0, y0 = mgr.get_data(0)
+    sd = {k.replace(".", "__"): v for k, v in car.state_dict().items()}
+    save("car_chain", x0=x0, y0=y0, xt=xt, ll_trace=np.array(lls), ypred=yp, var_pred=vp, **extra, **sd)
+
 
     os.chdir(cwd)
 

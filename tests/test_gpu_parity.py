@@ -449,6 +449,32 @@ def test_posterior_reuse_and_append():
     assert pickle.loads(pickle.dumps(m))._post is None
 
 
+def test_car_chain_golden(golden):
+    """FidelityFusion_Models/CAR_ContinuousAutoRegression.py: GP_basic blocks (V2 likelihood) whose residual kernels are
+    ARD x the Monte-Carlo fidelity integral sharing the parameter b; train_CAR (3 fidelities x 4 Adam steps) and
+    forward against the reference run -- SURVEY 8f row 2's last item, on the fused path."""
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.mf_harness import ContinuousAutoRegression, train_car
+    g = golden("car_chain")
+    tt = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    model = ContinuousAutoRegression(3, [kernel.ARDKernel(1) for _ in range(3)], b_init=1.0).double()
+    assert hasattr(model.cigp_list[1].kernel, "effective")          # stationary base: fused path
+    overlaps = [(tt(g[f"ov{i}_ylow"]), tt(g[f"ov{i}_x"]), tt(g[f"ov{i}_yhigh"])) for i in (1, 2)]
+    trace, data = train_car(model, (tt(g["x0"]), tt(g["y0"])), overlaps, max_iter=4, lr_init=1e-2)
+    assert rel(np.array(trace), g["ll_trace"]) < 1e-8
+    for name, p in model.state_dict().items():
+        assert rel(p, g[name.replace(".", "__")]) < 1e-7, name
+    for i in (1, 2):   # the residual sets the loop produced are the reference's (before its data manager re-normalises them)
+        sx, sy = data[i]
+        assert rel(sx, g[f"ov{i}_x"]) < 1e-13
+    # CAR.forward reads the residual sets back through get_data(-i), which normalises them with their own Normalizer
+    # although the blocks were trained un-normalised (MF_data.py:134-143): the fixture holds what forward consumed
+    fwd = [data[0]] + [(tt(g[f"res{i}_x_fwd"]), tt(g[f"res{i}_y_fwd"])) for i in (1, 2)]
+    with torch.no_grad():
+        yp, vp = model(fwd, tt(g["xt"]))
+    assert rel(yp, g["ypred"]) < 1e-7 and rel(vp, g["var_pred"]) < 1e-7
+
+
 def test_user_defined_kernel_module():
     """Any nn.Module kernel written in plain torch (CPU parameters, no descriptor) still runs: its K is moved to the
     device and factored there; gradients flow back through torch autograd into the user's parameters."""
