@@ -9,6 +9,8 @@ parity and benchmarks exercise it the way the reference does:
   * `resgp_predict`    -- `ResGP.forward` (ResGP.py:31-65): sum of per-fidelity posterior means and covariances;
   * `CIGAR` / `train_cigar` -- `CIGAR.forward` and `train_CIGAR` (FidelityFusion_Models/CIGAR.py:40-134): residual
                           blocks behind the learnable `Tensor_linear` fidelity map, y given as [mean, variance];
+  * `GAR` / `train_gar`   -- `GAR.forward` and `train_GAR` (FidelityFusion_Models/GAR.py:14-127): the same residual chain
+                          with `HOGP_simple` blocks on tensor-valued outputs;
   * `fidelity_kernel_MCMC`, `ContinuousAutoRegression`, `train_car` -- CAR (FidelityFusion_Models/
                           CAR_ContinuousAutoRegression.py:14-133): `GP_basic` blocks whose residual kernels are a base
                           kernel times a Monte-Carlo fidelity integral;
@@ -20,6 +22,7 @@ import torch
 
 from .cigp_v10 import cigp
 from .gp_basic import GP_basic
+from .hogp_simple import HOGP_simple
 from .gp_computation_pack import Tensor_linear
 from .mfgp2023 import CIGP
 
@@ -263,3 +266,61 @@ def train_car(model, data0, overlaps, max_iter=100, lr_init=1e-1):
                 (-ll).sum().backward()
                 optimizer.step()
     return trace, data
+
+
+class GAR(torch.nn.Module):
+    """`FidelityFusion_Models/GAR.py:14-72` on the drop-in blocks; `xs[i]` = training inputs of block i (fidelity 0,
+    then the residual sets), which is all `forward` reads from the data manager (the blocks cache K, A, g)."""
+
+    def __init__(self, fidelity_num, kernel_list, data_shape_list):
+        super().__init__()
+        self.fidelity_num = fidelity_num
+        blocks = []
+        for i in range(fidelity_num):
+            k = i + 1 if i < len(data_shape_list) - 1 else len(data_shape_list) - 1
+            blocks.append(HOGP_simple(kernel=kernel_list[i], noise_variance=1.0, output_shape=data_shape_list[k]))
+        self.hogp_list = torch.nn.ModuleList(blocks)
+        self.Tensor_linear_list = torch.nn.ModuleList(
+            [Tensor_linear(data_shape_list[i], data_shape_list[i + 1]) for i in range(fidelity_num - 1)])
+
+    def forward(self, xs, x_test, to_fidelity=None):
+        level = to_fidelity if to_fidelity is not None else self.fidelity_num - 1
+        mean_high = var_high = mean_low = var_low = None
+        for i in range(level + 1):
+            if i == 0:
+                mean_low, var_low = self.hogp_list[0].forward(xs[0], x_test)
+                if level == 0:
+                    mean_high, var_high = mean_low, var_low
+            else:
+                mean_res, var_res = self.hogp_list[i].forward(xs[i], x_test)
+                mean_high = self.Tensor_linear_list[i - 1](mean_low) + mean_res
+                var_high = self.Tensor_linear_list[i - 1](var_low) + var_res
+                mean_low, var_low = mean_high, var_high
+        return mean_high, var_high
+
+
+def train_gar(model, data0, fills, max_iter=100, lr_init=1e-1):
+    """`train_GAR` (GAR.py:74-127), non-subset mode; same conventions as `train_cigar`.  Returns (loss trace, xs)."""
+    trace, xs = [], [data0[0]]
+    for f in range(model.fidelity_num):
+        optimizer = torch.optim.Adam(model.parameters(), lr=lr_init)
+        if f == 0:
+            x, y = data0
+            for _ in range(max_iter):
+                optimizer.zero_grad()
+                loss = model.hogp_list[0].log_likelihood(x, y)
+                trace.append(float(loss.detach()))
+                loss.backward()
+                optimizer.step()
+        else:
+            x, y_low, y_high = fills[f - 1]
+            xs.append(x.detach())
+            for _ in range(max_iter):
+                optimizer.zero_grad()
+                res_mean = y_high[0] - model.Tensor_linear_list[f - 1](y_low[0])
+                res_var = (y_high[1] - y_low[1]).abs()
+                loss = model.hogp_list[f].log_likelihood(x, [res_mean, res_var])
+                trace.append(float(loss.detach()))
+                loss.backward()
+                optimizer.step()
+    return trace, xs

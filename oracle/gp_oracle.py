@@ -456,6 +456,46 @@ def conditional_gaussian_grads(Y, Sigma, K_s, Gmu, Gc):
     return dy, dS, alpha @ Gmu.T - B @ Gs, Gc
 
 
+def _mode_dot(t, M, mode):
+    return np.moveaxis(np.tensordot(t, M, axes=([mode], [1])), -1, mode)
+
+
+def hogp_ll(Ks, Y, noise_variance):
+    """HOGP_simple.log_likelihood, two_fidelity_models/hogp_simple.py:79-126: Ks = [K_x, K_1, ...] (already evaluated),
+    Y [N, d1, ...].  Returns (loss = +NLL / (N prod d), A, g, eigen pairs)."""
+    eig = [np.linalg.eigh(np.asarray(K, dtype=np.float64)) for K in Ks]
+    A = eig[0][0]
+    for lam, _ in eig[1:]:
+        A = np.multiply.outer(A, lam)
+    A = A + 1.0 / float(np.ravel(noise_variance)[0])
+    T1 = np.asarray(Y, dtype=np.float64)
+    for i, (_, U) in enumerate(eig):
+        T1 = _mode_dot(T1, U.T, i)
+    T3, g = T1 * A ** -0.5, T1 / A
+    for i, (_, U) in enumerate(eig):
+        T3 = _mode_dot(T3, U, i)
+        g = _mode_dot(g, U, i)
+    nd = A.size
+    ll = -0.5 * nd * np.log(2.0 * np.pi) - 0.5 * np.log(A).sum() - 0.5 * (T3 ** 2).sum()
+    return -ll / nd, A, g, eig
+
+
+def hogp_forward(K_star, K_ss_diag, Ks, A, g, eig):
+    """HOGP_simple.forward (:46-77); K_star = k(x_test, x_train)."""
+    mean = g
+    for i, M in enumerate([K_star] + list(Ks[1:])):
+        mean = _mode_dot(mean, M, i)
+    dk = np.asarray(K_ss_diag, dtype=np.float64)
+    for K in Ks[1:]:
+        dk = np.multiply.outer(dk, np.diag(K))
+    S2 = A                                              # (A * A^-1/2)^2
+    evs = [(K_star @ np.linalg.inv(Ks[0]) @ eig[0][1]) ** 2] + [U ** 2 for _, U in eig[1:]]
+    sp = S2
+    for i, M in enumerate(evs):
+        sp = _mode_dot(sp, M, i)
+    return mean, dk + sp
+
+
 def tensor_linear(x, vectors):
     """Tensor_linear.forward, gp_computation_pack.py:155-159: `y = mode_dot(x, vectors[i], i + 1)` is evaluated on the
     INPUT for every i, so the value returned is the last mode's product alone."""

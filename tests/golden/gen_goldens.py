@@ -536,7 +536,6 @@ def main():
 
     # Bayesian_optimization/cigp.py CIGP_withMean.forward (normalisers + conditional_Gaussian) and its x_test gradient
     try:
-        sys.modules.setdefault("GaussianProcess.gp_transform", types.ModuleType("GaussianProcess.gp_transform"))
         from Bayesian_optimization.cigp import CIGP_withMean as RBO
         xtr = torch.rand(40, 2, generator=g5) * 5
         ytr = torch.hstack([torch.sin(xtr.sum(1, keepdim=True)), torch.cos(xtr[:, :1])]) + 0.1 * torch.randn(40, 2, generator=g5)
@@ -597,6 +596,72 @@ def main():
     x0, y0 = mgr.get_data(0)
     sd = {k.replace(".", "__"): v for k, v in car.state_dict().items()}
     save("car_chain", x0=x0, y0=y0, xt=xt, ll_trace=np.array(lls), ypred=yp, var_pred=vp, **extra, **sd)
+
+    # ------------------------------------------------------------------ HOGP block (H1-H2; GAR's per-fidelity model, config 5)
+    from FidelityFusion_Models.two_fidelity_models.hogp_simple import HOGP_simple as RHOGP
+    g6 = torch.Generator().manual_seed(31337)
+    n, Dx, d1, d2, nt = 48, 2, 5, 4, 7
+    Xh = torch.rand(n, Dx, generator=g6) * 6
+    Wh = torch.rand(Dx, d1 * d2, generator=g6)
+    Yh = (torch.sin(Xh @ Wh) + 0.05 * torch.randn(n, d1 * d2, generator=g6)).reshape(n, d1, d2).requires_grad_(True)
+    Xth = torch.rand(nt, Dx, generator=g6) * 6
+    kh = rk.ARDKernel(Dx)
+    with torch.no_grad():
+        kh.length_scales.copy_(torch.tensor([0.9, 1.4]))
+        kh.signal_variance.copy_(torch.tensor([1.2]))
+    hm = RHOGP(kh, 0.8, [d1, d2]).double()   # the grid is built with .float() (hogp_simple.py:35)
+    loss = hm.log_likelihood(Xh, Yh)
+    loss.backward()
+    with torch.no_grad():
+        mu_h, var_h = hm.forward(Xh, Xth)
+    save("hogp_block", X=Xh, Y=Yh, Xt=Xth, loss=loss, g_Y=Yh.grad, g_noise_variance=hm.noise_variance.grad,
+         g_length_scales=kh.length_scales.grad, g_signal_variance=kh.signal_variance.grad,
+         length_scales=kh.length_scales, signal_variance=kh.signal_variance, noise_variance=hm.noise_variance,
+         A=hm.A, g=hm.g, mean=mu_h, var=var_h, eig0=hm.K_eigen[0].value, eig1=hm.K_eigen[1].value, eig2=hm.K_eigen[2].value)
+
+    # ------------------------------------------------------------------ GAR chain (config 5 plumbing): HOGP blocks + Tensor_linear, 2 fidelities
+    from FidelityFusion_Models.GAR import GAR as RGAR, train_GAR
+    torch.manual_seed(33)
+    oshape = (4, 3)
+    pool = torch.rand(60, 2) * 4
+    perm = torch.randperm(60)
+    idx = [torch.sort(perm[:n_]).values for n_ in (40, 28)]
+    xs = [pool[i] for i in idx]
+    Wg = torch.rand(2, 12)
+    fg = lambda x, a: (torch.sin(x @ Wg * a) + 0.2 * a * torch.cos(x.sum(1, keepdim=True))).reshape(-1, *oshape)
+    ys = [fg(xs[0], 0.8) + 0.02 * torch.rand(40, *oshape), fg(xs[1], 1.0) + 0.02 * torch.rand(28, *oshape)]
+    xt = torch.rand(6, 2) * 4
+    mgr = MultiFidelityDataManager([{"raw_fidelity_name": str(i), "fidelity_indicator": i, "X": xs[i], "Y": ys[i]} for i in range(2)])
+    gar = RGAR(2, [rk.SquaredExponentialKernel() for _ in range(2)], [oshape, oshape], if_nonsubset=True).double()
+    hl, fills = [], []
+    _orig_h = RHOGP.log_likelihood
+    _orig_fill = MultiFidelityDataManager.get_nonsubset_fill_data
+
+    def _spy_h(self, x, y):
+        r = _orig_h(self, x, y)
+        hl.append(float(r))
+        return r
+
+    def _spy_fill2(self, mdl, f1, f2):
+        r = _orig_fill(self, mdl, f1, f2)
+        fills.append(r)
+        return r
+
+    RHOGP.log_likelihood = _spy_h
+    MultiFidelityDataManager.get_nonsubset_fill_data = _spy_fill2
+    with contextlib.redirect_stdout(io.StringIO()):
+        train_GAR(gar, mgr, max_iter=3, lr_init=1e-2, debugger=None)
+    RHOGP.log_likelihood = _orig_h
+    MultiFidelityDataManager.get_nonsubset_fill_data = _orig_fill
+    with torch.no_grad():
+        xtn = mgr.normalizelayer[1].normalize_x(xt)
+        yp, vp = gar(mgr, xtn)
+    x0n, y0n = mgr.get_data(0, normal=True)
+    sx, ylo, yhi = fills[0]
+    xr, _ = mgr.get_data_by_name("res-1")
+    sd = {k.replace(".", "__"): v for k, v in gar.state_dict().items()}
+    save("gar_chain", x0n=x0n, y0n=y0n, xtn=xtn, loss_trace=np.array(hl), ypred=yp, var_pred=vp, fill_x=sx,
+         fill_ylow_mean=ylo[0], fill_ylow_var=ylo[1], fill_yhigh_mean=yhi[0], fill_yhigh_var=yhi[1], res_x=xr, **sd)
 
 
     os.chdir(cwd)

@@ -322,3 +322,22 @@ def test_cigp_forward_grads(golden):
     close(gxs_a + g1 + g2, g["g_xs"], 1e-8)
     # log_beta: Sigma's diagonal and the noise added to every entry of var both carry exp(-log_beta)
     close(-np.exp(-lb[0]) * (np.trace(dS) + g["R2"].sum()), g["g__log_beta"], 1e-8)
+
+
+def test_hogp_block(golden):
+    """H1-H2: HOGP_simple (GAR's block): loss, cached A and g, posterior mean and the reference's variance expression"""
+    g = golden("hogp_block")
+    ls, sv = g["length_scales"], g["signal_variance"]
+    kf = lambda a, b: O.ard_kernel(a, b, ls, sv)
+    grids = [np.arange(d, dtype=np.float64).reshape(-1, 1) for d in g["Y"].shape[1:]]
+    # the shared D-dimensional ARD kernel meets the 1-column grids through numpy/torch broadcasting of x / length_scales
+    Ks = [kf(g["X"], g["X"])] + [kf(np.repeat(gr, len(ls), 1), np.repeat(gr, len(ls), 1)) for gr in grids]
+    loss, A, gg, eig = O.hogp_ll(Ks, g["Y"], g["noise_variance"])
+    close(loss, g["loss"], 1e-10)
+    close(A, g["A"], 1e-10)
+    close(gg, g["g"], 1e-7)
+    for i in range(3):
+        close(eig[i][0], g[f"eig{i}"], 1e-9, atol=1e-12)
+    mean, var = O.hogp_forward(kf(g["Xt"], g["X"]), np.diag(kf(g["Xt"], g["Xt"])), Ks, A, gg, eig)
+    close(mean, g["mean"], 1e-7)
+    close(var, g["var"], 1e-6)
