@@ -581,11 +581,20 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
     }
     a.total_tiles = count_tiles(mode, m, n, tsm, tsn, a.tiles_m, a.tiles_n);
     if (h->force_ts == 0 && level == 1 && kk && a.batch == 1 && tsm == 64 && a.total_tiles < h->tile32_threshold) level = 2;
-    if (level == 2 && kk && tsm == 64 && a.batch == 1) {
+    // 32-row tiles: 32 x 32 for products that alias nothing; an in-place product must keep ONE column tile (C = A's
+    // buffer: a second column tile would overwrite columns the first still reads as its k range), so it takes
+    // 32 x 128 whatever its width; C = B's buffer (one ROW tile needed) stays on the 64-tile
+    if (level == 2 && kk && tsm == 64 && a.batch == 1 && alias != ALIAS_B) {
       tsm = 32;
-      if (tsn == 64) tsn = 32;   // 32 x 32, or 32 x 128 for the in-place TRSM
+      tsn = (alias == ALIAS_A) ? 128 : 32;
       a.total_tiles = count_tiles(mode, m, n, tsm, tsn, a.tiles_m, a.tiles_n);
     }
+  }
+  // invariant of the in-place products, whatever shape was chosen above: ONE column tile when C is A's buffer, ONE row
+  // tile when C is B's (a violation is a data race between workgroups, not an error the GPU would report)
+  if ((alias == ALIAS_A && a.tiles_n != 1) || (alias == ALIAS_B && a.tiles_m != 1)) {
+    fprintf(stderr, "[ffgp] gemm: in-place launch would be split across %d x %d tiles (alias %d)\n", a.tiles_m, a.tiles_n, alias);
+    return FFGP_ERR_ARG;
   }
   // timing == 2: bracket every trailing-update launch with its own event pair (no host sync inside the timed
   // region; ffgp_syrk_stats drains the pool afterwards)

@@ -1,7 +1,7 @@
 """`GP_basic` (reference: GaussianProcess/gp_basic.py:15-153) -- the noise_variance^2 convention used by CAR.
 
 Sigma = K + noise_variance^2 I [+ the FULL y_var matrix when y_train = [y, y_var]] with no jitter (:63-65,117-119);
-only the 'cholesky3' branch is on the HIP path: forward = conditional Gaussian (:78-84), log_likelihood = the
+the 'cholesky3' branch is the fused path (the other spellings are composed from the same device pieces): forward = conditional Gaussian (:78-84), log_likelihood = the
 Sigma^-2 form shared with gp_computation_pack.Gaussian_log_likelihood (:130-143).
 """
 import math
@@ -33,7 +33,7 @@ class GP_basic(nn.Module):
         self.noise_variance = nn.Parameter(torch.tensor([noise_variance]))
 
     def forward(self, x_train, y_train, x_test, Kinv_method="cholesky3"):
-        _check_method(Kinv_method, _METHODS_FWD)
+        _check_method(Kinv_method, (), _METHODS_FWD)   # three spellings of the same posterior (:66-88)
         y_train, y_var = _split(y_train)
         if not hasattr(self.kernel, "effective") or torch.is_grad_enabled():   # autograd on: differentiable composition
             return self._forward_composed(x_train, y_train, y_var, x_test)
@@ -59,8 +59,12 @@ class GP_basic(nn.Module):
         return mu.to(device=y_train.device, dtype=odt).squeeze(), var.to(device=y_train.device, dtype=odt)
 
     def log_likelihood(self, x_train, y_train, Kinv_method="cholesky3"):
-        _check_method(Kinv_method, _METHODS_LL)
+        _check_method(Kinv_method, _METHODS_LL, ("cholesky1", "cholesky2", "cholesky3", "direct"))
         y_train, y_var = _split(y_train)
+        if Kinv_method != "cholesky3":   # the alternative formulas (:120-129,141-143), composed from the same device pieces
+            from .gp_computation_pack import _alt_terms
+            quad, const = _alt_terms(y_train, self._sigma_composed(x_train, y_var).to(y_train.device), Kinv_method)
+            return -0.5 * ((quad.sum() if Kinv_method == "cholesky2" else quad) + const)
         if not hasattr(self.kernel, "effective"):
             ll = -F.gaussian_nll_from_cov(y_train, self._sigma_composed(x_train, y_var), F.FFGP_LL_V2, math.pi)
             return ll.reshape(1, 1) if y_train.shape[1] == 1 else ll

@@ -5,9 +5,10 @@
     negative_log_likelihood(kernel, log_beta, x_train, y_train)     :120-136  (returns +LL)
     Tensor_linear(l_shape, h_shape)                                 :138-159  (CIGAR's learnable fidelity map)
 
-Only the 'cholesky3' method -- the one every model in the reference uses -- is implemented; the other
-`Kinv_method`s of the reference are alternative formulas for the same quantities (explicit inverses, d=1 only)
-and raise NotImplementedError here, an unknown name raises ValueError as in the reference (:91,116).
+'cholesky3' -- the method every model in the reference uses -- is the fused path; 'cholesky1', 'cholesky2' and
+'direct' (alternative formulas with their own quirks, used by no model) are composed from the same device pieces;
+the two `torch_distribution_MN*` branches (which in the reference only run when N equals the output dimension) raise
+NotImplementedError, an unknown name raises ValueError as in the reference (:91,116).
 """
 import math
 
@@ -26,21 +27,48 @@ PI = 3.1415
 _REFERENCE_METHODS = ("cholesky1", "cholesky2", "cholesky3", "direct", "torch_distribution_MN1", "torch_distribution_MN2")
 
 
-def _check_method(name, allowed):
-    if name == "cholesky3":
+def _check_method(name, allowed, built):
+    if name in built:
         return
     if name in allowed:
-        raise NotImplementedError("Kinv_method=%r: only 'cholesky3' is built on the HIP path" % name)
+        raise NotImplementedError("Kinv_method=%r is not built on the HIP path (in the reference these two branches only "
+                                  "run when N equals the output dimension)" % name)
     raise ValueError("Kinv_method should be either direct or cholesky")
 
 
+def _logdet(cov):
+    """log|cov| through the fused factorisation (differentiable): the V1 value of a zero column is sum(log L_ii) + const"""
+    n = cov.shape[0]
+    z = torch.zeros((n, 1), dtype=cov.dtype, device=cov.device)
+    return 2.0 * (F.gaussian_nll_from_cov(z, cov, F.FFGP_LL_V1, math.pi) - 0.5 * n * math.log(2.0 * math.pi))
+
+
 def Gaussian_log_likelihood(y, cov, Kinv_method="cholesky3"):
-    """LL of N(0, cov) with the reference's Sigma^-2 quadratic form (gamma = cholesky_solve(y, L), :76-80).
-    d == 1 returns shape [1, 1] as the reference does (:80), d > 1 a 0-dim tensor (:77)."""
+    """LL of N(0, cov).  'cholesky3' (what every model uses): the reference's Sigma^-2 quadratic form
+    (gamma = cholesky_solve(y, L), :76-80); d == 1 returns shape [1, 1] as the reference does (:80), d > 1 a 0-dim
+    tensor (:77).  The alternative formulas keep their own quirks: 'cholesky1' / 'direct' (:55-59,82-84) use the true
+    y^T Sigma^-1 y but count the log-determinant twice and return a [d, d] matrix; 'cholesky2' (:60-63) the Sigma^-2
+    form with the double log-determinant.  All are differentiable w.r.t. y and cov."""
     assert len(y.shape) == 2 and len(cov.shape) == 2, "y, mean, cov should be 2D tensors"
-    _check_method(Kinv_method, _REFERENCE_METHODS)
-    ll = -F.gaussian_ll_v2(y, cov)   # differentiable w.r.t. y and cov (closed-form V2 gradients)
-    return ll.reshape(1, 1) if y.shape[1] == 1 else ll
+    _check_method(Kinv_method, _REFERENCE_METHODS, ("cholesky1", "cholesky2", "cholesky3", "direct"))
+    if Kinv_method == "cholesky3":
+        ll = -F.gaussian_ll_v2(y, cov)   # differentiable w.r.t. y and cov (closed-form V2 gradients)
+        return ll.reshape(1, 1) if y.shape[1] == 1 else ll
+    quad, const = _alt_terms(y, cov, Kinv_method)
+    return -0.5 * (quad + const)
+
+
+def _alt_terms(y, cov, Kinv_method):
+    """(quadratic form [d, d], 2 log|cov| + N log 2 pi) of the alternative formulas"""
+    n, d = y.shape
+    const = 2.0 * _logdet(cov).to(y.device) + n * math.log(2.0 * math.pi)
+    if Kinv_method in ("cholesky1", "direct"):
+        quad, _ = F.conditional_gaussian(y, cov, y, torch.zeros((d, d), dtype=y.dtype, device=y.device))   # y^T Sigma^-1 y
+    else:
+        eye = torch.eye(n, dtype=y.dtype, device=y.device)
+        alpha, _ = F.conditional_gaussian(y, cov, eye, torch.zeros((n, n), dtype=y.dtype, device=y.device))  # Sigma^-1 y
+        quad = F.matmul_nt(alpha.T.contiguous(), alpha.T.contiguous()).to(device=y.device, dtype=y.dtype)
+    return quad, const
 
 
 def conditional_Gaussian(y, Sigma, K_s, K_ss, Kinv_method="cholesky3"):
@@ -48,7 +76,7 @@ def conditional_Gaussian(y, Sigma, K_s, K_ss, Kinv_method="cholesky3"):
     Both solves ride as passenger rows of one factorisation; differentiable w.r.t. all four arguments (closed-form
     backward on the saved factor), which is what acquisition optimisers differentiate through
     (Bayesian_optimization/cigp.py:52-70, acq.py:10-80)."""
-    _check_method(Kinv_method, ("cholesky1", "cholesky3", "direct"))
+    _check_method(Kinv_method, (), ("cholesky1", "cholesky3", "direct"))   # three spellings of the same quantities
     return F.conditional_gaussian(y, Sigma, K_s, K_ss)
 
 

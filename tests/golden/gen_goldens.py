@@ -663,6 +663,29 @@ def main():
     save("gar_chain", x0n=x0n, y0n=y0n, xtn=xtn, loss_trace=np.array(hl), ypred=yp, var_pred=vp, fill_x=sx,
          fill_ylow_mean=ylo[0], fill_ylow_var=ylo[1], fill_yhigh_mean=yhi[0], fill_yhigh_var=yhi[1], res_x=xr, **sd)
 
+    # ------------------------------------------------------------------ L3: the other Kinv_methods of Gaussian_log_likelihood / conditional_Gaussian
+    g7 = torch.Generator().manual_seed(2718)
+    alt = {}
+    for tag, d in (("d1", 1), ("d3", 3)):
+        n = 40
+        Xa, Ya = make_xy(g7, n, 2, d)
+        ka = rk.ARDKernel(2)
+        cov0 = (ka(Xa, Xa) + 0.3 * torch.eye(n)).detach()
+        Ks = ka(Xa, torch.rand(6, 2, generator=g7)).detach()
+        Kss = torch.eye(6)
+        alt.update({f"{tag}_Y": Ya, f"{tag}_cov": cov0, f"{tag}_Ks": Ks, f"{tag}_Kss": Kss})
+        for meth in ("cholesky1", "cholesky2", "direct"):
+            yv = Ya.clone().requires_grad_(True)
+            cv = cov0.clone().requires_grad_(True)
+            ll = rpack.Gaussian_log_likelihood(yv, cv, Kinv_method=meth)
+            R = torch.randn(ll.shape, generator=g7)
+            (ll * R).sum().backward()
+            alt.update({f"{tag}_{meth}_ll": ll, f"{tag}_{meth}_R": R, f"{tag}_{meth}_gY": yv.grad, f"{tag}_{meth}_gcov": cv.grad})
+        for meth in ("cholesky1", "direct"):
+            mu, cc = rpack.conditional_Gaussian(Ya, cov0, Ks, Kss, Kinv_method=meth)
+            alt.update({f"{tag}_{meth}_mu": mu, f"{tag}_{meth}_ccov": cc})
+    save("kinv_methods", **alt)
+
 
     os.chdir(cwd)
 

@@ -531,6 +531,30 @@ def test_gar_chain_golden(golden):
     assert rel(vp, g["var_pred"]) < 2e-2
 
 
+@pytest.mark.parametrize("tag", ["d1", "d3"])
+def test_kinv_methods_golden(golden, tag):
+    """Row L3: the alternative Kinv_methods (gp_computation_pack.py:55-63,82-84,96-116) keep their quirks -- true
+    y^T Sigma^-1 y or the Sigma^-2 form, the log-determinant counted twice, a [d, d] result -- and their gradients"""
+    import fidelityfusion_amd.gp_computation_pack as gp_pack
+    g = golden("kinv_methods")
+    for meth in ("cholesky1", "cholesky2", "direct"):
+        y, cov = T(g[f"{tag}_Y"], grad=True), T(g[f"{tag}_cov"], grad=True)
+        ll = gp_pack.Gaussian_log_likelihood(y, cov, Kinv_method=meth)
+        assert tuple(ll.shape) == g[f"{tag}_{meth}_ll"].shape and rel(ll, g[f"{tag}_{meth}_ll"]) < 1e-10, meth
+        (ll * T(g[f"{tag}_{meth}_R"])).sum().backward()
+        assert rel(y.grad, g[f"{tag}_{meth}_gY"]) < 1e-8, meth
+        gc = g[f"{tag}_{meth}_gcov"]
+        assert rel(cov.grad, 0.5 * (gc + gc.T)) < 1e-8, meth    # torch.inverse's backward is not symmetrised; ours is
+    for meth in ("cholesky1", "direct"):
+        mu, cc = gp_pack.conditional_Gaussian(T(g[f"{tag}_Y"]), T(g[f"{tag}_cov"]), T(g[f"{tag}_Ks"]), T(g[f"{tag}_Kss"]),
+                                              Kinv_method=meth)
+        assert rel(mu, g[f"{tag}_{meth}_mu"]) < 1e-9 and rel(cc, g[f"{tag}_{meth}_ccov"]) < 1e-9
+    with pytest.raises(NotImplementedError):
+        gp_pack.Gaussian_log_likelihood(T(g[f"{tag}_Y"]), T(g[f"{tag}_cov"]), Kinv_method="torch_distribution_MN1")
+    with pytest.raises(ValueError):
+        gp_pack.Gaussian_log_likelihood(T(g[f"{tag}_Y"]), T(g[f"{tag}_cov"]), Kinv_method="nope")
+
+
 def test_user_defined_kernel_module():
     """Any nn.Module kernel written in plain torch (CPU parameters, no descriptor) still runs: its K is moved to the
     device and factored there; gradients flow back through torch autograd into the user's parameters."""
@@ -764,11 +788,14 @@ def test_concurrent_blocks_match_sequential():
                [m.log_beta.grad.clone() for m in models]
 
     l0, g0, b0 = run(False)
-    l1, g1, b1 = run(True)
-    for a, b in zip(l0, l1):
-        assert abs(a - b) <= 1e-12 * abs(a)
-    for a, b in zip(g0 + b0, g1 + b1):
-        assert rel(b, a.cpu().numpy()) < 1e-12
+    # repeated: a race between workgroups of an in-place panel GEMM (the 700-point block's 60-column last panel, once
+    # split over two column tiles) showed up in ~30 % of CONCURRENT runs and never in sequential ones
+    for _ in range(12):
+        l1, g1, b1 = run(True)
+        for a, b in zip(l0, l1):
+            assert abs(a - b) <= 1e-12 * abs(a)
+        for a, b in zip(g0 + b0, g1 + b1):
+            assert rel(b, a.cpu().numpy()) < 1e-12
     # failure propagation
     bad = cigp(kernel.ARDKernel(2), 0.0).to(DEV)
     with torch.no_grad():
