@@ -2,7 +2,12 @@
 """Lane-level numpy emulation of the index math in csrc/gemm.hip and csrc/potrf.hip (no GPU in the build
 container).  Each helper mirrors a device function line by line: 64-lane vectors stand for a wavefront,
 `mfma_f64_16x16x4` follows the gfx950 operand/accumulator lane maps (cdna_hip_programming.md section 3).
-Run:  python tools/emulate_kernels.py   (asserts; prints 'emulation ok')."""
+Run:  python tools/emulate_kernels.py   (asserts; prints 'emulation ok').
+
+Written before the first GPU run to validate lane maps and LDS layouts.  The GEMM part still describes the kernel's
+operand images and accumulator layout (they did not change); the diagonal-factor part models the FIRST version of
+potrf_diag128 (dense [128][130] image, substitution TRSM) -- the current kernel (packed 16x16 blocks, in-register
+factor, incremental inverse) is validated on the GPU against LAPACK instead (tests/test_gpu_kernels.py)."""
 import numpy as np
 
 LANES = np.arange(64)
