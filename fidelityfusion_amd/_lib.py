@@ -8,6 +8,11 @@ import ctypes as C
 import os
 import threading
 
+# PyTorch-ROCm ships its own libamdhip64; libffgp.so names the same SONAME.  torch must be imported BEFORE the
+# library is dlopen'ed so that both bind to the ONE runtime already in the process -- loaded the other way round the
+# process ends up with two HIP runtimes and hipGetDeviceCount() in the second one reports no device.
+import torch  # noqa: F401  (device memory, streams)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libffgp.so")
 
