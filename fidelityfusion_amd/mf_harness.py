@@ -9,6 +9,9 @@ parity and benchmarks exercise it the way the reference does:
   * `resgp_predict`    -- `ResGP.forward` (ResGP.py:31-65): sum of per-fidelity posterior means and covariances;
   * `CIGAR` / `train_cigar` -- `CIGAR.forward` and `train_CIGAR` (FidelityFusion_Models/CIGAR.py:40-134): residual
                           blocks behind the learnable `Tensor_linear` fidelity map, y given as [mean, variance];
+  * `AR` / `train_ar`, `NAR` / `train_nar` -- FidelityFusion_Models/AR_autoRegression.py:11-133 (residual chain with a
+                          learnable rho per fidelity, trained through dNLL/dY and dNLL/dy_var) and NAR.py:11-113
+                          (the low-fidelity prediction concatenated to the inputs);
   * `GAR` / `train_gar`   -- `GAR.forward` and `train_GAR` (FidelityFusion_Models/GAR.py:14-127): the same residual chain
                           with `HOGP_simple` blocks on tensor-valued outputs;
   * `fidelity_kernel_MCMC`, `ContinuousAutoRegression`, `train_car` -- CAR (FidelityFusion_Models/
@@ -324,3 +327,103 @@ def train_gar(model, data0, fills, max_iter=100, lr_init=1e-1):
                 loss.backward()
                 optimizer.step()
     return trace, xs
+
+
+class AR(torch.nn.Module):
+    """`AR_autoRegression.py:11-80` on the drop-in blocks; `data[0] = (x, y)`, `data[i] = (x, [res_mean, res_var])`."""
+
+    def __init__(self, fidelity_num, kernel_list, rho_init=1.0):
+        super().__init__()
+        self.fidelity_num = fidelity_num
+        self.gpr_list = torch.nn.ModuleList([cigp(kernel=kernel_list[i], log_beta=1.0) for i in range(fidelity_num)])
+        self.rho_list = torch.nn.ParameterList([torch.nn.Parameter(torch.tensor(rho_init)) for _ in range(fidelity_num - 1)])
+
+    def forward(self, data, x_test, to_fidelity=None):
+        level = to_fidelity if to_fidelity is not None else self.fidelity_num - 1
+        y_high = cov_high = y_low = cov_low = None
+        for i in range(level + 1):
+            x_train, y_train = data[i]
+            if i == 0:
+                y_low, cov_low = self.gpr_list[0](x_train, y_train, x_test)
+                if level == 0:
+                    y_high, cov_high = y_low, cov_low
+            else:
+                y_res, cov_res = self.gpr_list[i](x_train, y_train, x_test)
+                y_high = y_low + self.rho_list[i - 1] * y_res
+                cov_high = cov_low + (self.rho_list[i - 1] ** 2) * cov_res
+                y_low, cov_low = y_high, cov_high
+        return y_high, cov_high
+
+
+def train_ar(model, data0, fills, max_iter=100, lr_init=1e-1):
+    """`train_AR` (:82-133), non-subset mode; conventions as `train_cigar`."""
+    trace, data = [], [data0]
+    for f in range(model.fidelity_num):
+        optimizer = torch.optim.Adam(model.parameters(), lr=lr_init)
+        if f == 0:
+            x, y = data0
+            for _ in range(max_iter):
+                optimizer.zero_grad()
+                ll = model.gpr_list[0].negative_log_likelihood(x, y)
+                trace.append(float(ll.detach()))
+                (-ll).backward()
+                optimizer.step()
+        else:
+            x, y_low, y_high = fills[f - 1]
+            rho = model.rho_list[f - 1]
+            for i in range(max_iter):
+                optimizer.zero_grad()
+                res_mean = y_high[0] - rho * y_low[0]
+                res_var = (y_high[1] - rho * y_low[1]).abs()
+                if i == max_iter - 1:
+                    data.append((x.detach(), [res_mean.detach(), res_var.detach()]))
+                ll = model.gpr_list[f].negative_log_likelihood(x, [res_mean, res_var])
+                trace.append(float(ll.detach()))
+                (-ll).backward()
+                optimizer.step()
+    return trace, data
+
+
+class NAR(torch.nn.Module):
+    """`NAR.py:11-58`: block i > 0 is a GP on [x, prediction of block i-1]."""
+
+    def __init__(self, fidelity_num, kernel_list):
+        super().__init__()
+        self.fidelity_num = fidelity_num
+        self.gpr_list = torch.nn.ModuleList([cigp(kernel=kernel_list[i], log_beta=1.0) for i in range(fidelity_num)])
+
+    def forward(self, data, x_test, to_fidelity=None):
+        level = to_fidelity if to_fidelity is not None else self.fidelity_num - 1
+        y_high = cov_high = y_low = None
+        for i in range(level + 1):
+            x_train, y_train = data[i]
+            if i == 0:
+                y_low, cov_low = self.gpr_list[0](x_train, y_train, x_test)
+                if level == 0:
+                    y_high, cov_high = y_low, cov_low
+            else:
+                concat_input = torch.cat([x_test, y_low.reshape(-1, 1)], dim=-1)
+                y_high, cov_high = self.gpr_list[i](x_train, y_train, concat_input)
+                y_low = y_high
+        return y_high, cov_high
+
+
+def train_nar(model, data0, fills, max_iter=100, lr_init=1e-1):
+    """`train_NAR` (:60-113), non-subset mode: fills[i-1] as in `train_cigar`; the block trains on [x, y_low_mean]."""
+    trace, data = [], [data0]
+    for f in range(model.fidelity_num):
+        optimizer = torch.optim.Adam(model.parameters(), lr=lr_init)
+        if f == 0:
+            x, y = data0
+        else:
+            sx, y_low, y_high = fills[f - 1]
+            x = torch.cat([sx, y_low[0]], dim=-1)
+            y = [y_high[0], y_high[1]]
+            data.append((x.detach(), [y[0].detach(), y[1].detach()]))
+        for _ in range(max_iter):
+            optimizer.zero_grad()
+            ll = model.gpr_list[f].negative_log_likelihood(x, y)
+            trace.append(float(ll.detach()))
+            (-ll).backward()
+            optimizer.step()
+    return trace, data

@@ -686,6 +686,51 @@ def main():
             alt.update({f"{tag}_{meth}_mu": mu, f"{tag}_{meth}_ccov": cc})
     save("kinv_methods", **alt)
 
+    # ------------------------------------------------------------------ AR and NAR chains (the remaining 2024 trainers on cigp)
+    from FidelityFusion_Models.AR_autoRegression import AR as RAR, train_AR
+    from FidelityFusion_Models.NAR import NAR as RNAR, train_NAR
+    for tag, Model, trainer in (("ar", RAR, train_AR), ("nar", RNAR, train_NAR)):
+        torch.manual_seed(41)
+        x_all = torch.rand(110, 1) * 8
+        il = torch.sort(torch.randperm(110)[:70]).values
+        ih = torch.sort(torch.randperm(110)[:45]).values
+        xl, xh = x_all[il], x_all[ih]
+        yl = torch.sin(xl) - 0.4 * torch.sin(2 * xl) + 0.05 * torch.rand(70, 1)
+        yh = torch.sin(xh) + 0.05 * torch.rand(45, 1)
+        xt = torch.linspace(0, 8, 11).reshape(-1, 1)
+        mgr = MultiFidelityDataManager([{"raw_fidelity_name": "0", "fidelity_indicator": 0, "X": xl, "Y": yl},
+                                        {"raw_fidelity_name": "1", "fidelity_indicator": 1, "X": xh, "Y": yh}])
+        kl = [rk.SquaredExponentialKernel(), rk.SquaredExponentialKernel()]
+        model = Model(2, kl, if_nonsubset=True) if tag == "nar" else Model(2, kl, rho_init=1.0, if_nonsubset=True)
+        losses, fills = [], []
+        _orig = RCIGP.negative_log_likelihood
+        _orig_fill = MultiFidelityDataManager.get_nonsubset_fill_data
+
+        def _spy(self, x, y):
+            r = _orig(self, x, y)
+            losses.append(float(r))
+            return r
+
+        def _spy_fill3(self, mdl, f1, f2):
+            r = _orig_fill(self, mdl, f1, f2)
+            fills.append(r)
+            return r
+
+        RCIGP.negative_log_likelihood = _spy
+        MultiFidelityDataManager.get_nonsubset_fill_data = _spy_fill3
+        with contextlib.redirect_stdout(io.StringIO()):
+            trainer(model, mgr, max_iter=5, lr_init=1e-2, debugger=None)
+        RCIGP.negative_log_likelihood = _orig
+        MultiFidelityDataManager.get_nonsubset_fill_data = _orig_fill
+        with torch.no_grad():
+            xtn = mgr.normalizelayer[1].normalize_x(xt)
+            yp, vp = model(mgr, xtn)
+        x0n, y0n = mgr.get_data(0, normal=True)
+        sx, ylo, yhi = fills[0]
+        sd = {k.replace(".", "__"): v for k, v in model.state_dict().items()}
+        save(f"{tag}_chain", x0n=x0n, y0n=y0n, xtn=xtn, ll_trace=np.array(losses), ypred=yp, var_pred=vp, fill_x=sx,
+             fill_ylow_mean=ylo[0], fill_ylow_var=ylo[1], fill_yhigh_mean=yhi[0], fill_yhigh_var=yhi[1], **sd)
+
 
     os.chdir(cwd)
 

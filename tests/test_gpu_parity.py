@@ -555,6 +555,28 @@ def test_kinv_methods_golden(golden, tag):
         gp_pack.Gaussian_log_likelihood(T(g[f"{tag}_Y"]), T(g[f"{tag}_cov"]), Kinv_method="nope")
 
 
+@pytest.mark.parametrize("which", ["ar", "nar"])
+def test_ar_nar_chain_golden(golden, which):
+    """train_AR / AR.forward (AR_autoRegression.py: learnable rho trained through dNLL/dY and dNLL/dy_var) and
+    train_NAR / NAR.forward (NAR.py: low-fidelity prediction concatenated to the inputs) on the drop-in cigp"""
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd import mf_harness as H
+    g = golden(which + "_chain")
+    tt = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    kl = [kernel.SquaredExponentialKernel() for _ in range(2)]
+    model = (H.AR(2, kl, rho_init=1.0) if which == "ar" else H.NAR(2, kl)).double()
+    fills = [(tt(g["fill_x"]), [tt(g["fill_ylow_mean"]), tt(g["fill_ylow_var"])],
+              [tt(g["fill_yhigh_mean"]), tt(g["fill_yhigh_var"])])]
+    train = H.train_ar if which == "ar" else H.train_nar
+    trace, data = train(model, (tt(g["x0n"]), tt(g["y0n"])), fills, max_iter=5, lr_init=1e-2)
+    assert rel(np.array(trace), g["ll_trace"]) < 1e-8
+    for name, p in model.state_dict().items():
+        assert rel(p, g[name.replace(".", "__")]) < 1e-7, name
+    with torch.no_grad():
+        yp, vp = model(data, tt(g["xtn"]))
+    assert rel(yp, g["ypred"]) < 1e-7 and rel(vp, g["var_pred"]) < 1e-7
+
+
 def test_user_defined_kernel_module():
     """Any nn.Module kernel written in plain torch (CPU parameters, no descriptor) still runs: its K is moved to the
     device and factored there; gradients flow back through torch autograd into the user's parameters."""
