@@ -108,11 +108,13 @@ int ffgp_create(int device, ffgp_handle** out) {
     h->lookahead = 1;
     h->small_tile_threshold = 640;
     h->tile32_threshold = 1024;
+    h->polite_m = 8192;
     h->la_split = 1;
     h->aux_prio = 1;
   }
   FFGP_HIP(hipMalloc(&h->d_info, 16 * sizeof(int)));
   FFGP_HIP(hipMemset(h->d_info, 0, 16 * sizeof(int)));
+  FFGP_HIP(hipDeviceSynchronize());   // NULL-stream memset: make it visible before any (non-blocking) stream touches it
   FFGP_HIP(hipMalloc(&h->d_scal, SCAL_DOUBLES * sizeof(double)));
   FFGP_HIP(hipHostMalloc(&h->h_info, 16 * sizeof(int)));
   memset(h->h_info, 0, 16 * sizeof(int));
@@ -178,6 +180,8 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->la_split = (int)value;
   } else if (!strcmp(key, "lookahead")) {
     h->lookahead = (int)value;
+  } else if (!strcmp(key, "polite_m")) {
+    h->polite_m = (int)value;
 
   } else {
     return FFGP_ERR_ARG;

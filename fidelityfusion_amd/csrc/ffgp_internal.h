@@ -79,6 +79,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int total_tiles;
   int grid;            // gridDim.x (= total_tiles)
+  int pad_lds;         // bytes of unused dynamic LDS requested at launch (occupancy control)
   int fast;            // alpha = +-1, beta in {0,1}, offsets fit 32 bits: interior tiles take the scalar-addressed form
   int avec, bvec;      // 16-byte vector loads allowed for A / B
   int prio;            // raise the wave priority (look-ahead panel GEMMs)
@@ -101,6 +102,7 @@ struct ffgp_handle {
   int diag_dbg;         // timing-only ablation mask of potrf_diag128 (0 in production)
   int la_split;         // 1 = issue the look-ahead part of the trailing update in two launches (first 128 columns first)
   int lookahead;        // 1 = overlap panel k+1 with the trailing update of step k
+  int polite_m;         // trailing updates with fewer rows than this run one workgroup per CU (0 = never)
   bool own_stream;
   // workspace (grown on demand, never shrunk)
   double* ws;        // generic workspace

@@ -500,7 +500,17 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
 // ------------------------------------------------------------------------------------------------------------
 template <int OPA, int OPB, int MODE, int TAG, int TM, int TN>
 static int launch_t(ffgp_handle* h, const GemmArgs& a) {
-  hipLaunchKernelGGL((ffgp_gemm_f64<OPA, OPB, MODE, TAG, TM, TN>), dim3(a.grid, a.batch), dim3(256), 0, h->stream, a);
+  // a.pad_lds > 0: reserve that much extra LDS so that only ONE of these workgroups fits a CU ("polite" trailing update,
+  // see ffgp_gemm_launch) -- the kernel never touches it
+  if (a.pad_lds > 0) {
+    static bool attr_set = false;   // per instantiation
+    if (!attr_set) {
+      FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffgp_gemm_f64<OPA, OPB, MODE, TAG, TM, TN>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL((ffgp_gemm_f64<OPA, OPB, MODE, TAG, TM, TN>), dim3(a.grid, a.batch), dim3(256), a.pad_lds, h->stream, a);
   return FFGP_OK;
 }
 
@@ -617,6 +627,12 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
             (size_t)ldb * 8 * 130 < 0xffffffffull && (size_t)ldc * 8 * 130 < 0xffffffffull)
                ? 1 : 0;
   a.grid = a.total_tiles;
+  // "Polite" trailing update: once the factorisation is bound by its dependency chain (trailing matrix below polite_m
+  // rows) the 128-tile SYRK is launched with LDS padding so that only one of its workgroups fits a CU.  Alone it still
+  // runs the MFMA pipe at ~70 %, and the other half of every CU -- VGPRs, LDS, issue slots -- is free for the chain's
+  // kernels at all times instead of only when a SYRK workgroup happens to exit.
+  a.pad_lds = 0;
+  if (syrk_tag && tsm == 128 && h->lookahead && h->polite_m > 0 && m < h->polite_m && h->stream != h->aux) a.pad_lds = 40 * 1024;
   if (tsm != 128) syrk_tag = 0;  // only the 128x128 trailing update is the roofline kernel (own instantiation + stats)
   int rc;
   if (tsm == 64 && tsn == 128)

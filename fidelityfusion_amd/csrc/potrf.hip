@@ -496,7 +496,11 @@ int ffgp_ensure_dinv(ffgp_handle* h, int n) {
     h->dinv = nullptr;
     h->dinv_bytes = 0;
     if (hipMalloc(&h->dinv, need) != hipSuccess) return FFGP_ERR_ALLOC;
-    if (hipMemset(h->dinv, 0, need) != hipSuccess) return FFGP_ERR_HIP;  // strictly-upper parts stay zero forever
+    // strictly-upper parts stay zero forever.  The memset must be ORDERED with the kernels that fill the store: a plain
+    // hipMemset runs on the NULL stream, which does not synchronise with the (non-blocking) streams this library works
+    // on -- it could land after the first diagonal-block kernel had written its inverse and wipe it (seen as wrong
+    // factors on the first use of a fresh handle only).
+    if (hipMemsetAsync(h->dinv, 0, need, h->stream) != hipSuccess) return FFGP_ERR_HIP;
     h->dinv_bytes = need;
   }
   return FFGP_OK;

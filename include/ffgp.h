@@ -113,9 +113,18 @@ typedef struct {
 int ffgp_create(int device, ffgp_handle** out);
 int ffgp_destroy(ffgp_handle* h);
 int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL restores the handle's own stream */
-/* options: "timing" (0/1: record per-stage hipEvents), "nb_outer" (trailing-update block, multiple of 128),
+/* options: "timing" (0/1: record per-stage hipEvents; 2: also an event pair around every trailing-update launch),
+            "nb_outer" (trailing-update block, multiple of 128; default 512),
             "naive" (1: route factor kernels through the slow reference kernels; debugging only),
-            "lookahead" (default 1: factor panel k+1 on a high-priority side stream under the trailing update of step k) */
+            "lookahead" (default 1: factor panel k+1 on a high-priority side stream under the trailing update of step k),
+            "la_split" (default 1: the look-ahead column update covers the next panel's first 128 columns only),
+            "aux_prio" (default 1: raised wave priority for the side stream's kernels),
+            "gemm_tile" (0 = automatic; 32 / 64 / 128 force the GEMM tile shape -- tests and benchmarks),
+            "small_tile_threshold" (default 640: launches with fewer 128-tiles use 64-tiles),
+            "tile32_threshold" (default 1024: K-major launches with fewer 64-tiles use 32-row tiles),
+            "polite_m" (default 8192: trailing updates with fewer rows run one workgroup per CU so that the side
+                        stream's kernels always find free registers and LDS),
+            "diag_dbg" (timing-only ablation mask of the diagonal-block kernel; results are wrong when non-zero)       */
 int ffgp_set_option(ffgp_handle* h, const char* key, double value);
 const char* ffgp_version(void);
 

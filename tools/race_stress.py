@@ -15,7 +15,13 @@ torch.set_default_dtype(torch.float64)
 DEV = "cuda:0"
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
+BIG = "big" in sys.argv[3:]
+from fidelityfusion_amd import _lib
+for kv in sys.argv[3:]:
+    if "=" in kv:
+        key, val = kv.split("=")
+        for slot in range(6):
+            _lib.lib.ffgp_set_option(_lib.handle(0, slot), key.encode(), float(val))
 bad = 0
 for r in range(rounds):
     nb = int(rng.integers(2, 6))
@@ -52,6 +58,7 @@ for r in range(rounds):
         out += [y.grad.cpu().numpy().copy() for _, y in blocks]
         return out
 
+    print("round", r, [(b[0].shape[0], b[1].shape[1]) for b in blocks], flush=True)
     ref = run(False)
     for rep in range(4):
         got = run(True)
