@@ -23,6 +23,8 @@ int ffgp_kernel_wt_impl(ffgp_handle* h, const double* X1, int n1, const double* 
                         const double* amp, double clamp, int kfun, double kparam, const double* dK, int ldk, double* Wt,
                         int ldw);
 
+int ffgp_rows_in_impl(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, unsigned char* found);
+
 __global__ void ffgp_copy_lower_kernel(const double* __restrict__ src, int lds_, double* __restrict__ dst, int ldd, int n) {
   const int c = blockIdx.x * 32 + (threadIdx.x & 31), r = blockIdx.y * 32 + (threadIdx.x >> 5) * 4;
 #pragma unroll
@@ -253,6 +255,12 @@ int ffgp_kernel_input_weights(ffgp_handle* h, const double* X1, int n1, const do
   if (kfun < FFGP_KFUN_SE || kfun > FFGP_KFUN_RQ) return FFGP_ERR_ARG;
   FFGP_HIP(hipSetDevice(h->device));
   return ffgp_kernel_wt_impl(h, X1, n1, X2, n2, D, w, amp, clamp_min, kfun, kparam, dK, ldk, Wt, ldw);
+}
+
+int ffgp_rows_in(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, unsigned char* found) {
+  if (!h) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  return ffgp_rows_in_impl(h, X1, n1, X2, n2, D, found);
 }
 
 int ffgp_kernel_grad(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const double* w,

@@ -652,3 +652,19 @@ class Posterior:
         self.n = n + k
         self._solve_alpha()
 
+
+
+@torch.no_grad()
+def rows_in(x1, x2):
+    """Boolean mask [n1]: row i of x1 equals some row of x2 (exact IEEE ==, as the reference's broadcast comparison in
+    MF_data.py:196-199) -- a device hash join (ffgp_rows_in)."""
+    dev = _device_of(x1, x2)
+    h = _lib.handle(dev.index)
+    _lib.bind_stream(h, dev.index)
+    a, b = _dev(x1, dev), _dev(x2, dev)
+    D = int(math.prod(a.shape[1:])) if a.dim() > 1 else 1
+    a, b = a.reshape(a.shape[0], D), b.reshape(b.shape[0], int(math.prod(b.shape[1:])) if b.dim() > 1 else 1)
+    found = torch.zeros((a.shape[0],), dtype=torch.uint8, device=dev)
+    if a.shape[0] and D > 0 and a.shape[1] == b.shape[1]:
+        check(lib.ffgp_rows_in(h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], a.shape[1], _ptr(found)), "ffgp_rows_in")
+    return found.bool().to(x1.device)

@@ -427,3 +427,12 @@ def train_nar(model, data0, fills, max_iter=100, lr_init=1e-1):
             (-ll).backward()
             optimizer.step()
     return trace, data
+
+
+def overlap_and_unique(x1, y1, x2, y2):
+    """The data manager's subset bookkeeping (`get_overlap_input_data` / `get_unique_input_data`, MF_data.py:176-252,
+    un-normalised): rows of (x1, y1) / (x2, y2) whose inputs occur in both sets, and the rows that do not.  The two
+    masks come from the device hash join instead of the reference's N1 x N2 x D broadcast comparison."""
+    from . import functional as F
+    m1, m2 = F.rows_in(x1, x2), F.rows_in(x2, x1)
+    return (x1[m1], y1[m1], x2[m2], y2[m2]), (x1[~m1], y1[~m1], x2[~m2], y2[~m2])

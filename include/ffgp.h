@@ -155,6 +155,11 @@ int ffgp_kernel_grad(ffgp_handle* h, const double* X1_dev, int n1, const double*
                      const double* w_dev, const double* amp_dev, double clamp_min, int kfun, double kparam,
                      const double* dK_dev, int ldk, double* g_w_dev, double* g_amp_dev, double* g_kparam_dev);
 
+/* found_dev[i] = 1 iff row i of X1 [n1, D] equals (IEEE ==, element-wise) some row of X2 [n2, D]: the subset / unique-point
+ * masks of the reference's data manager, `torch.all(x1.unsqueeze(1) == x2.unsqueeze(0), -1).any(-1)`
+ * (FidelityFusion_Models/MF_data.py:196-199,234-237), as a device hash join instead of an N1 x N2 x D boolean temporary. */
+int ffgp_rows_in(ffgp_handle* h, const double* X1_dev, int n1, const double* X2_dev, int n2, int D, unsigned char* found_dev);
+
 /* Input gradients of a kernel call -- backward of `kernel(x1, x2)` w.r.t. x1 / x2, which the reference's autograd provides
  * and its acquisition optimisers rely on (Bayesian_optimization/acq.py:10-80 differentiate the posterior w.r.t. the test
  * points; CIGP_withMean.forward Bayesian_optimization/cigp.py:52-70).  For an upstream dK [n1, n2] writes

@@ -577,6 +577,43 @@ def test_ar_nar_chain_golden(golden, which):
     assert rel(yp, g["ypred"]) < 1e-7 and rel(vp, g["var_pred"]) < 1e-7
 
 
+@pytest.mark.timeout(180)
+def test_rows_in_matches_reference_broadcast():
+    """the data manager's subset / unique masks (MF_data.py:196-199,234-237) from the device hash join:
+    same answer as the N1 x N2 x D broadcast comparison, incl. duplicates, -0.0 == +0.0, NaN != NaN, empty sets"""
+    from fidelityfusion_amd import functional as F
+    from fidelityfusion_amd.mf_harness import overlap_and_unique
+    rng = np.random.default_rng(9)
+    for n1, n2, D in [(1, 1, 1), (37, 0, 3), (300, 211, 1), (1000, 1500, 5), (2500, 1700, 16), (129, 4000, 2)]:
+        pool = np.round(rng.standard_normal((max(n1, n2, 1) // 2 + 3, D)), 1)      # coarse values: many exact repeats
+        x1 = pool[rng.integers(0, len(pool), n1)] if n1 else np.zeros((0, D))
+        x2 = pool[rng.integers(0, len(pool), n2)] if n2 else np.zeros((0, D))
+        x1 = x1 + (rng.random((n1, 1)) < 0.3) * rng.integers(1, 4, (n1, 1))         # push ~30 % of x1 out of the pool
+        if n1 > 5 and n2 > 5:
+            x1[0] = x2[0] = 0.0
+            x1[0, 0] = -0.0                                                           # -0.0 == +0.0
+            x1[1] = x2[1]
+            x1[1, -1] = np.nan
+            x2[2, 0] = np.nan                                                         # NaN never matches
+            x1[2] = x2[2]
+        t1, t2 = torch.tensor(x1), torch.tensor(x2)
+        want1 = torch.all(t1.unsqueeze(1) == t2.unsqueeze(0), dim=-1).any(-1)
+        want2 = torch.all(t2.unsqueeze(1) == t1.unsqueeze(0), dim=-1).any(-1)
+        got1, got2 = F.rows_in(t1, t2), F.rows_in(t2, t1)
+        assert got1.dtype == torch.bool and got1.device.type == "cpu"
+        assert torch.equal(got1, want1) and torch.equal(got2, want2), (n1, n2, D)
+        gd = F.rows_in(t1.to(DEV), t2.to(DEV))
+        assert gd.device.type == "cuda" and torch.equal(gd.cpu(), want1)
+    y1, y2 = torch.arange(n1, dtype=torch.float64).reshape(-1, 1), torch.arange(n2, dtype=torch.float64).reshape(-1, 1)
+    (cx1, cy1, cx2, cy2), (ux1, uy1, ux2, uy2) = overlap_and_unique(t1, y1, t2, y2)
+    assert torch.equal(cy1, y1[want1]) and torch.equal(cy2, y2[want2]) and torch.equal(uy1, y1[~want1]) and torch.equal(uy2, y2[~want2])
+    # benchmark-sized sanity: 16384 x 16 against 16384 x 16 with a known 50 % overlap
+    big = torch.rand((24576, 16), dtype=torch.float64, device=DEV)
+    a, b = big[:16384], big[8192:]
+    m = F.rows_in(a, b)
+    assert int(m.sum()) == 8192 and bool(m[8192:].all()) and not bool(m[:8192].any())
+
+
 def test_user_defined_kernel_module():
     """Any nn.Module kernel written in plain torch (CPU parameters, no descriptor) still runs: its K is moved to the
     device and factored there; gradients flow back through torch autograd into the user's parameters."""
