@@ -731,6 +731,32 @@ def main():
         save(f"{tag}_chain", x0n=x0n, y0n=y0n, xtn=xtn, ll_trace=np.array(losses), ypred=yp, var_pred=vp, fill_x=sx,
              fill_ylow_mean=ylo[0], fill_ylow_var=ylo[1], fill_yhigh_mean=yhi[0], fill_yhigh_var=yhi[1], **sd)
 
+    # ------------------------------------------------------------------ 2023-API HOGP (base_gp/hogp.py): loss, gradients, forward
+    try:
+        from MFGP_ver2023May.base_gp.hogp import HOGP as RHOGP23
+        g8 = torch.Generator().manual_seed(777123)
+        n, Dx, d1, d2, nt = 40, 2, 4, 3, 6
+        X23 = torch.rand(n, Dx, generator=g8) * 5
+        Y23 = torch.sin(X23 @ torch.rand(Dx, d1 * d2, generator=g8)).reshape(n, d1, d2) + 0.05 * torch.randn(n, d1, d2, generator=g8)
+        Y23 = Y23.requires_grad_(True)
+        Xt23 = torch.rand(nt, Dx, generator=g8) * 5
+        h23 = RHOGP23({"fidelity_shapes": [d1, d2], "noise": {"init_value": 0.7, "format": "linear"}}).double()
+        with torch.no_grad():
+            for i, kk in enumerate(h23.kernel_list):
+                kk.length_scale.fill_(0.8 + 0.3 * i)
+                kk.scale.fill_(1.1 + 0.1 * i)
+        loss23 = h23.compute_loss(X23, Y23, y_var=0.05)
+        loss23.backward()
+        mu23, var23 = h23.forward(Xt23)
+        extra = {}
+        for i, kk in enumerate(h23.kernel_list):
+            extra.update({f"k{i}_length_scale": kk.length_scale, f"k{i}_scale": kk.scale,
+                          f"g_k{i}_length_scale": kk.length_scale.grad, f"g_k{i}_scale": kk.scale.grad})
+        save("hogp2023_block", X=X23, Y=Y23, Xt=Xt23, loss=loss23, g_Y=Y23.grad, noise=h23.noise_box.value,
+             g_noise=h23.noise_box.value.grad, mean=mu23, var=var23, A=h23.A, **extra)
+    except Exception as e:  # noqa
+        print("hogp2023_block skipped:", repr(e))
+
 
     os.chdir(cwd)
 

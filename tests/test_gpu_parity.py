@@ -614,6 +614,32 @@ def test_rows_in_matches_reference_broadcast():
     assert int(m.sum()) == 8192 and bool(m[8192:].all()) and not bool(m[:8192].any())
 
 
+def test_hogp2023_block_golden(golden):
+    """2023-API HOGP (MFGP_ver2023May/base_gp/hogp.py:140-233): per-mode kernels, noise box, y_var, stateful train data;
+    loss, every gradient (through the eigendecompositions) and the forward's mean / variance expression"""
+    from fidelityfusion_amd.mfgp2023 import HOGP
+    g = golden("hogp2023_block")
+    m = HOGP({"fidelity_shapes": [4, 3], "noise": {"init_value": float(g["noise"]), "format": "linear"}}).double()
+    with torch.no_grad():
+        for i, kk in enumerate(m.kernel_list):
+            kk.length_scale.fill_(float(g[f"k{i}_length_scale"]))
+            kk.scale.fill_(float(g[f"k{i}_scale"]))
+    m = m.to(DEV)
+    Y = T(g["Y"], grad=True)
+    loss = m.compute_loss(T(g["X"]), Y, y_var=0.05)
+    assert rel(loss, g["loss"]) < 1e-10 and rel(m.A, g["A"]) < 1e-10
+    loss.backward()
+    assert rel(Y.grad, g["g_Y"]) < 1e-7
+    assert rel(m.noise_box.value.grad, g["g_noise"]) < 1e-7
+    for i, kk in enumerate(m.kernel_list):
+        assert rel(kk.length_scale.grad, g[f"g_k{i}_length_scale"]) < 1e-6, i
+        assert rel(kk.scale.grad, g[f"g_k{i}_scale"]) < 1e-6, i
+    mean, var = m.forward(T(g["Xt"]))
+    assert rel(mean, g["mean"]) < 1e-7 and rel(var, g["var"]) < 1e-7
+    with pytest.raises(ValueError):
+        HOGP({})
+
+
 def test_user_defined_kernel_module():
     """Any nn.Module kernel written in plain torch (CPU parameters, no descriptor) still runs: its K is moved to the
     device and factored there; gradients flow back through torch autograd into the user's parameters."""
