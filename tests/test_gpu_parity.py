@@ -941,6 +941,74 @@ def test_nlml_and_grads_vs_oracle(n, D, d):
     assert rel(mean, mr) < 1e-8 and rel(var, vr) < 1e-8
 
 
+@pytest.mark.timeout(300)
+def test_fuzz_all_model_classes_vs_oracle():
+    """Seeded fuzz: random (n, D, d), parameters of either sign, optional y_var, all four likelihood conventions
+    (cigp V1, gp_pack V1 + mean(K) jitter, GP_basic V2 + full y_var matrix, ARD and Matern profiles) against the
+    oracle: value, every gradient, posterior.  n crosses the 128 / 512 block boundaries with arbitrary remainders."""
+    from oracle import gp_oracle as O
+    import fidelityfusion_amd.gp_computation_pack as gp_pack
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp
+    from fidelityfusion_amd.gp_basic import GP_basic
+    rng = np.random.default_rng(2026)
+    for case in range(36):
+        n = int(rng.choice([rng.integers(1, 40), rng.integers(40, 300), rng.integers(300, 1200)]))
+        D, d, nt = int(rng.integers(1, 12)), int(rng.choice([1, 2, 5, 33])), int(rng.integers(1, 30))
+        X, Xs = rng.random((n, D)), rng.random((nt, D))
+        Y = np.sin(2 * np.pi * X @ rng.random((D, d))) + 0.1 * rng.standard_normal((n, d))
+        ls = (rng.random(D) * 1.5 + 0.4) * np.where(rng.random(D) > 0.5, 1.0, -1.0)
+        sv = np.array([(rng.random() + 0.5) * (1 if rng.random() > 0.5 else -1)])
+        which = case % 4
+        nu = [None, 1.5, 2.5][case % 3] if which == 0 else None
+        k = kernel.ARDKernel(D) if nu is None else kernel.MaternKernel(D, nu=nu)
+        with torch.no_grad():
+            k.length_scales.copy_(torch.tensor(ls))
+            k.signal_variance.copy_(torch.tensor(sv))
+        Yt = T(Y, grad=True)
+        tag = "case %d (which=%d n=%d D=%d d=%d nu=%s)" % (case, which, n, D, d, nu)
+        if which in (0, 1):       # cigp, without / with y_var (an N x N matrix of which only the diagonal counts)
+            lb = float(rng.normal())
+            yv = None if which == 0 else np.diag(rng.random(n) * 0.2) + 0.05 * rng.random((n, n))
+            m = cigp(k, lb).to(DEV)
+            ll = m.negative_log_likelihood(T(X), Yt if yv is None else [Yt, T(yv)])
+            ll.backward()
+            ll_ref, gr = O.cigp_ll_and_grads(X, Y, ls, sv, [lb], y_var=yv, nu=nu)
+            assert rel(ll, ll_ref) < 1e-9, tag
+            assert rel(m.log_beta.grad, gr["log_beta"]) < 1e-6, tag
+            kf = (lambda a, b: O.ard_kernel(a, b, ls, sv)) if nu is None else (lambda a, b: O.matern_kernel(a, b, ls, sv, nu, 1.0))
+            with torch.no_grad():
+                mean, var = m(T(X), T(Y), T(Xs))
+            mr, vr = O.cigp_forward(X, Y, Xs, kf, [lb])
+            assert rel(mean, mr) < 1e-7 and rel(var, vr) < 1e-7, tag
+        elif which == 2:          # gp_computation_pack.negative_log_likelihood (mean(K) jitter)
+            lb = torch.tensor([float(rng.normal())], device=DEV, requires_grad=True)
+            ll = gp_pack.negative_log_likelihood(k.to(DEV), lb, T(X), Yt)
+            ll.backward()
+            ll_ref, gr = O.pack_ll_and_grads(X, Y, ls, sv, [float(lb.detach())])
+            assert rel(ll, ll_ref) < 1e-9, tag
+            assert rel(lb.grad, gr["log_beta"]) < 1e-6, tag
+        else:                     # GP_basic V2 with the FULL y_var matrix added
+            nv = float(rng.random() + 0.3)
+            R = rng.standard_normal((n, n)) * 0.05
+            yv = R @ R.T
+            m = GP_basic(k, nv).to(DEV)
+            ll = m.log_likelihood(T(X), [Yt, T(yv)])
+            ll.sum().backward()
+            S = O.sigma_basic(O.ard_kernel(X, X, ls, sv), [nv], yv)
+            ll_ref, g_cov, g_Y = O.ll_v2_grads(Y, S)
+            assert rel(ll, ll_ref) < 1e-9, tag
+            assert rel(m.noise_variance.grad, 2 * nv * np.trace(g_cov)) < 1e-6, tag
+            gr = {"Y": g_Y, **O.ard_kernel_grads(X, ls, sv, g_cov)}
+            with torch.no_grad():
+                mu, cov = m(T(X), [T(Y), T(yv)], T(Xs))
+            mr, cr = O.gp_basic_forward(X, Y, Xs, lambda a, b: O.ard_kernel(a, b, ls, sv), [nv], yv)
+            assert rel(mu, mr) < 1e-7 and rel(cov, cr) < 1e-7, tag
+        assert rel(Yt.grad, gr["Y"]) < 1e-6, tag
+        assert rel(k.length_scales.grad, gr["length_scales"]) < 1e-6, tag
+        assert rel(k.signal_variance.grad, gr["signal_variance"]) < 1e-6, tag
+
+
 def test_empty_and_ragged_edges():
     """N = 1, Nt = 1, d > N, D = 1: the edge shapes the reference's demos can produce"""
     from oracle import gp_oracle as O
