@@ -102,6 +102,7 @@ struct ffgp_handle {
   int diag_dbg;         // timing-only ablation mask of potrf_diag128 (0 in production)
   int la_split;         // 1 = issue the look-ahead part of the trailing update in two launches (first 128 columns first)
   int lookahead;        // 1 = overlap panel k+1 with the trailing update of step k
+  int diag_attr_set;    // dynamic-LDS attribute of potrf_diag128 set on this handle's device
   int polite_m;         // trailing updates with fewer rows than this run one workgroup per CU (0 = never)
   bool own_stream;
   // workspace (grown on demand, never shrunk)

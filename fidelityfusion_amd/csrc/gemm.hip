@@ -502,14 +502,9 @@ template <int OPA, int OPB, int MODE, int TAG, int TM, int TN>
 static int launch_t(ffgp_handle* h, const GemmArgs& a) {
   // a.pad_lds > 0: reserve that much extra LDS so that only ONE of these workgroups fits a CU ("polite" trailing update,
   // see ffgp_gemm_launch) -- the kernel never touches it
-  if (a.pad_lds > 0) {
-    static bool attr_set = false;   // per instantiation
-    if (!attr_set) {
-      FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffgp_gemm_f64<OPA, OPB, MODE, TAG, TM, TN>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-      attr_set = true;
-    }
-  }
+  if (a.pad_lds > 0)   // (set per launch: the attribute is per device context, and this path runs ~10 times per factorisation)
+    FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffgp_gemm_f64<OPA, OPB, MODE, TAG, TM, TN>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   hipLaunchKernelGGL((ffgp_gemm_f64<OPA, OPB, MODE, TAG, TM, TN>), dim3(a.grid, a.batch), dim3(256), a.pad_lds, h->stream, a);
   return FFGP_OK;
 }

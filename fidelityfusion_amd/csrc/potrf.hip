@@ -475,13 +475,11 @@ __global__ __launch_bounds__(128) void ffgp_dinv_naive(const double* L, int ldl,
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
-static bool g_diag_attr_set = false;
-
 static int launch_diag(ffgp_handle* h, double* Ablk, int lda, int nb, double* Dinv_blk, int row_base, int do_factor) {
-  if (!g_diag_attr_set) {
+  if (!h->diag_attr_set) {   // per handle = per device (the attribute lives in the device's context)
     FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
-    g_diag_attr_set = true;
+    h->diag_attr_set = 1;
   }
   hipLaunchKernelGGL(ffgp_potrf_diag128, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk,
                      h->d_info, row_base, do_factor, h->diag_dbg, h->aux_prio);
@@ -492,7 +490,11 @@ int ffgp_ensure_dinv(ffgp_handle* h, int n) {
   const int nblk = (n + NB - 1) / NB;
   const size_t need = (size_t)nblk * NB * NB * sizeof(double);
   if (need > h->dinv_bytes) {
-    if (h->dinv) hipFree(h->dinv);
+    if (h->dinv) {   // work enqueued earlier on this handle may still read the old store
+      hipStreamSynchronize(h->stream);
+      if (h->aux) hipStreamSynchronize(h->aux);
+      hipFree(h->dinv);
+    }
     h->dinv = nullptr;
     h->dinv_bytes = 0;
     if (hipMalloc(&h->dinv, need) != hipSuccess) return FFGP_ERR_ALLOC;
