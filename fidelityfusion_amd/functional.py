@@ -554,31 +554,49 @@ class Posterior:
 
     Parameters are the library's effective ones (w, amp, diag_add, clamp, kfun), frozen at construction."""
 
-    def __init__(self, X, Y, w, amp, diag_add, clamp=NEG_INF, kfun=(0, 1.0), capacity=None):
+    def __init__(self, X, Y, w, amp, diag_add, clamp=NEG_INF, kfun=(0, 1.0), capacity=None, first_query=None,
+                 var_add_all=0.0):
+        """first_query (optional [nt, D]): its K_s^T rides, with Y^T, as passenger rows of the factorisation itself, so
+        the first answer (`self.first` = (mean, covariance)) costs what the fused one-shot posterior costs; the rows
+        below the factor are scratch afterwards (later appends overwrite them)."""
         dev = _device_of(X, Y, w, amp)
         self.dev = dev
         self.kfun, _ = _split_kfun(kfun)
         self.clamp = clamp
         Xd, Yd = _dev(X, dev), _dev(Y, dev)
         n, D = Xd.shape
+        d = Yd.shape[1]
         wd = _dev(w.reshape(-1), dev)
         self.w = wd.expand(D).contiguous() if wd.numel() == 1 and D > 1 else wd
         self.amp = _dev(amp.reshape(-1)[:1], dev)
         self.dadd = _dev(diag_add.reshape(-1)[:1], dev)
+        Xq = _dev(first_query, dev) if first_query is not None else None
+        nt = Xq.shape[0] if Xq is not None else 0
         self.cap = max(int(capacity or 0), n)
         self.ld = _pad_ld(self.cap)
-        self.W = torch.zeros((self.cap, self.ld), dtype=torch.float64, device=dev)
+        rows = max(self.cap, n + d + nt)                      # room for the passenger rows of the first factorisation
+        self.W = torch.zeros((rows, self.ld), dtype=torch.float64, device=dev)
         self.X = torch.empty((self.cap, D), dtype=torch.float64, device=dev)
         self.X[:n] = Xd
-        self.n, self.D, self.d = n, D, Yd.shape[1]
+        self.n, self.D, self.d = n, D, d
         h = self._h()
         self._assemble(Xd, Xd, self.W, self.ld, lower=1, diag=True)
-        rc = check(lib.ffgp_potrf(h, _ptr(self.W), n, self.ld), "ffgp_potrf")
+        self.W[n:n + d, :n] = Yd.T
+        if nt:
+            self._assemble(Xq, Xd, self.W[n + d:], self.ld, lower=0, diag=False)          # K_s^T [nt, n]
+        rc = check(lib.ffgp_potrf_rows(h, _ptr(self.W), n, n + d + nt, self.ld), "ffgp_potrf_rows")
         if rc > 0:
             _raise_not_pd(rc, "linalg.cholesky")
-        self.Gamma = Yd.clone()
-        check(lib.ffgp_trsm_lower(h, _ptr(self.W), n, self.ld, _ptr(self.Gamma), self.d, self.d), "ffgp_trsm_lower")
-        self._solve_alpha()
+        Gt = self.W[n:n + d, :n].contiguous()                 # Gamma^T
+        self.Gamma = Gt.T.contiguous()
+        self.alpha = None                                     # Sigma^-1 Y: solved when a later query needs it
+        self.first = None
+        if nt:
+            Vt = self.W[n + d:n + d + nt, :n].contiguous()    # V^T = (L^-1 K_s)^T
+            mean = _gemm(dev, 0, 0, Vt, Gt, nt, d, n, 1.0)
+            var = torch.empty((nt, nt), dtype=torch.float64, device=dev)
+            self._assemble(Xq, Xq, var, nt, lower=0, diag=False)
+            self.first = (mean, var - _gemm(dev, 0, 0, Vt, Vt, nt, nt, n, 1.0) + var_add_all)
 
     def _h(self):
         h = _lib.handle(self.dev.index)
@@ -602,6 +620,8 @@ class Posterior:
         dev, n = self.dev, self.n
         Xsd = _dev(Xs, dev)
         nt = Xsd.shape[0]
+        if self.alpha is None:
+            self._solve_alpha()
         Ks = torch.empty((n, nt), dtype=torch.float64, device=dev)
         self._assemble(self.X[:n], Xsd, Ks, nt, lower=0, diag=False)
         mean = _gemm(dev, 1, 1, Ks, self.alpha, nt, self.d, n, 1.0)                 # K_s^T alpha
@@ -621,7 +641,7 @@ class Posterior:
         dev, n, h = self.dev, self.n, self._h()
         Xn, Yn = _dev(X_new, dev), _dev(Y_new, dev)
         k = Xn.shape[0]
-        if n + k > self.cap:       # grow geometrically; the factor is copied once
+        if n + k > self.cap or n + k > self.W.shape[0]:       # grow geometrically; the factor is copied once
             cap = max(n + k, 2 * self.cap)
             ld = _pad_ld(cap)
             W = torch.zeros((cap, ld), dtype=torch.float64, device=dev)
@@ -650,7 +670,7 @@ class Posterior:
         self.X[n:n + k] = Xn
         self.Gamma = torch.cat([self.Gamma, G_new], 0)
         self.n = n + k
-        self._solve_alpha()
+        self.alpha = None
 
 
 
