@@ -2,6 +2,7 @@
 These are the per-kernel tests (layer 2 of the pyramid in SURVEY.md section 4); end-to-end parity with the
 oracle and the golden fixtures is in test_gpu_parity.py."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -318,3 +319,23 @@ def test_mfma_peak_probe(ff):
     tf = _lib.mfma_f64_peak(0)
     print("measured fp64 MFMA stream: %.1f TFLOP/s" % tf)
     assert 10.0 < tf < 200.0
+
+
+@pytest.mark.timeout(300)
+def test_c_abi_standalone_consumer(tmp_path):
+    """examples/nlml_c_abi.cpp: a C++ program that links libffgp.so directly (no Python, no torch in the process),
+    runs the fused NLML + gradients and checks one gradient against a finite difference of the value"""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "nlml_c_abi")
+    libdir = os.path.join(root, "fidelityfusion_amd")
+    subprocess.check_call([hipcc, "-O2", "--offload-arch=gfx950", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "nlml_c_abi.cpp"), "-L", libdir, "-lffgp",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    out = subprocess.run([exe, "1500", "6", "3"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "c-abi example ok" in out.stdout
