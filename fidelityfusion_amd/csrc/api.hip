@@ -110,7 +110,7 @@ int ffgp_create(int device, ffgp_handle** out) {
     h->lookahead = 1;
     h->small_tile_threshold = 640;
     h->tile32_threshold = 1024;
-    h->polite_m = 8192;
+    h->polite_m = 6144;
     h->la_split = 1;
     h->aux_prio = 1;
   }

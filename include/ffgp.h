@@ -122,7 +122,7 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
             "gemm_tile" (0 = automatic; 32 / 64 / 128 force the GEMM tile shape -- tests and benchmarks),
             "small_tile_threshold" (default 640: launches with fewer 128-tiles use 64-tiles),
             "tile32_threshold" (default 1024: K-major launches with fewer 64-tiles use 32-row tiles),
-            "polite_m" (default 8192: trailing updates with fewer rows run one workgroup per CU so that the side
+            "polite_m" (default 6144: trailing updates with fewer rows run one workgroup per CU so that the side
                         stream's kernels always find free registers and LDS),
             "diag_dbg" (timing-only ablation mask of the diagonal-block kernel; results are wrong when non-zero)       */
 int ffgp_set_option(ffgp_handle* h, const char* key, double value);
