@@ -60,6 +60,10 @@ EXPORTS = {
                                    _dp, C.c_int, _dp, _dp, _dp]),
     "ffgp_kernel_input_weights": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_int,
                                             C.c_double, _dp, C.c_int, _dp, C.c_int]),
+    "ffgp_syevj_small": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, C.c_int, C.c_long, _dp, C.c_int, C.c_long, _dp, C.c_long,
+                                   C.c_int]),
+    "ffgp_gemm_batched": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_long, _dp, C.c_int, C.c_long, _dp,
+                                    C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]),
     "ffgp_rows_in": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_int, C.c_int, _dp]),
     "ffgp_trtri_diag": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int]),
     "ffgp_trsm_lower": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int]),

@@ -25,6 +25,9 @@ int ffgp_kernel_wt_impl(ffgp_handle* h, const double* X1, int n1, const double* 
 
 int ffgp_rows_in_impl(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, unsigned char* found);
 
+int ffgp_syevj_small_impl(ffgp_handle* h, const double* M, int n, int ldm, int batch, long strideM, double* Q, int ldq,
+                          long strideQ, double* evals, long strideE, int descending);
+
 __global__ void ffgp_copy_lower_kernel(const double* __restrict__ src, int lds_, double* __restrict__ dst, int ldd, int n) {
   const int c = blockIdx.x * 32 + (threadIdx.x & 31), r = blockIdx.y * 32 + (threadIdx.x >> 5) * 4;
 #pragma unroll
@@ -255,6 +258,22 @@ int ffgp_kernel_input_weights(ffgp_handle* h, const double* X1, int n1, const do
   if (kfun < FFGP_KFUN_SE || kfun > FFGP_KFUN_RQ) return FFGP_ERR_ARG;
   FFGP_HIP(hipSetDevice(h->device));
   return ffgp_kernel_wt_impl(h, X1, n1, X2, n2, D, w, amp, clamp_min, kfun, kparam, dK, ldk, Wt, ldw);
+}
+
+int ffgp_syevj_small(ffgp_handle* h, const double* M, int n, int ldm, int batch, long strideM, double* Q, int ldq, long strideQ,
+                     double* evals, long strideE, int descending) {
+  if (!h) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  return ffgp_syevj_small_impl(h, M, n, ldm, batch, strideM, Q, ldq, strideQ, evals, strideE, descending);
+}
+
+int ffgp_gemm_batched(ffgp_handle* h, int opa, int opb, int lower_tiles, const double* A, int lda, long strideA, const double* B,
+                      int ldb, long strideB, double* C, int ldc, long strideC, int m, int n, int k, double alpha, double beta,
+                      int batch) {
+  if (!h) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  return ffgp_gemm_launch(h, opa ? OP_MNMAJOR : OP_KMAJOR, opb ? OP_MNMAJOR : OP_KMAJOR, lower_tiles ? TILES_LOWER : TILES_FULL,
+                          0, A, lda, B, ldb, C, ldc, m, n, k, alpha, beta, 0, ALIAS_NONE, batch, strideA, strideB, strideC);
 }
 
 int ffgp_rows_in(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, unsigned char* found) {

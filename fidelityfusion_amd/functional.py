@@ -688,3 +688,53 @@ def rows_in(x1, x2):
     if a.shape[0] and D > 0 and a.shape[1] == b.shape[1]:
         check(lib.ffgp_rows_in(h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], a.shape[1], _ptr(found)), "ffgp_rows_in")
     return found.bool().to(x1.device)
+
+
+@torch.no_grad()
+def _syevj_small(M, descending=False):
+    """batched hand-written Jacobi eigensolver for [B, n, n] (n <= 64) device tensors: (evals [B, n], Q [B, n, n])"""
+    dev = M.device
+    h = _lib.handle(dev.index)
+    _lib.bind_stream(h, dev.index)
+    B, n = M.shape[0], M.shape[-1]
+    M = M.contiguous()
+    Q = torch.empty((B, n, n), dtype=torch.float64, device=dev)
+    ev = torch.empty((B, n), dtype=torch.float64, device=dev)
+    check(lib.ffgp_syevj_small(h, _ptr(M), n, n, B, n * n, _ptr(Q), n, n * n, _ptr(ev), n, 1 if descending else 0),
+          "ffgp_syevj_small")
+    return ev, Q
+
+
+class _EighSmall(torch.autograd.Function):
+    """torch.linalg.eigh for one symmetric matrix with n <= 64 on the hand-written LDS Jacobi kernel (ffgp_syevj_small),
+    with the standard backward  gK = sym( U (diag(g_lambda) + (U^T g_U) o E) U^T ),  E_ij = 1 / (lambda_j - lambda_i)."""
+
+    @staticmethod
+    def forward(ctx, K):
+        dev = _device_of(K)
+        ev, Q = _syevj_small(_dev(K, dev)[None])
+        ctx.save_for_backward(ev[0], Q[0])
+        ctx.meta = (K.dtype, K.device)
+        return ev[0].to(device=K.device, dtype=K.dtype), Q[0].to(device=K.device, dtype=K.dtype)
+
+    @staticmethod
+    def backward(ctx, g_ev, g_Q):
+        ev, U = ctx.saved_tensors
+        dev = ev.device
+        n = ev.shape[0]
+        inner = torch.zeros((n, n), dtype=torch.float64, device=dev)
+        if g_Q is not None:
+            S = _gemm(dev, 1, 1, U, _dev(g_Q, dev), n, n, n, 1.0)                # U^T g_U
+            diff = ev.unsqueeze(0) - ev.unsqueeze(1)                               # lambda_j - lambda_i
+            E = torch.where(diff != 0, 1.0 / diff, torch.zeros_like(diff))
+            inner = S * E
+        if g_ev is not None:
+            inner = inner + torch.diag(_dev(g_ev, dev))
+        gK = _gemm(dev, 0, 0, _gemm(dev, 0, 1, U, inner.contiguous(), n, n, n, 1.0), U, n, n, n, 1.0)   # U inner U^T
+        gK = 0.5 * (gK + gK.T)
+        return gK.to(device=ctx.meta[1], dtype=ctx.meta[0])
+
+
+def eigh_small(K):
+    """(eigenvalues ascending [n], eigenvectors [n, n]) of a symmetric K with n <= 64, differentiable"""
+    return _EighSmall.apply(K)

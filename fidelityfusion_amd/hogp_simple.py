@@ -7,9 +7,13 @@ Same constructor, parameters (`noise_variance`, the shared kernel, `grid`, `mapp
 
 What runs where: the covariance matrices come from the library's assembly (differentiable `kernel_matrix`), every
 mode product -- the O(N^2 prod(d)) part: 550 GFLOP each at N = 8192, d = 64 x 64 -- runs on the fp64 matrix-core
-GEMM (`functional.matmul_nt`, forward and backward), and the symmetric eigendecompositions are rocSOLVER's
-(`torch.linalg.eigh` on the device: 0.66 s at N = 8192): a vendor-library call, not a hand-written kernel -- the one
-place on this path where that is so.  Autograd chains the pieces (eigh's backward is torch's).
+GEMM (`functional.matmul_nt`, forward and backward).  Symmetric eigendecompositions: matrices up to 64 x 64 -- the
+per-mode kernels -- run on the hand-written LDS Jacobi solver (`ffgp_syevj_small`); the N x N input kernel goes to
+rocSOLVER (`torch.linalg.eigh` on the device: 0.66 s at N = 8192): a vendor-library call, not a hand-written kernel --
+the one place on this path where that is so.  (A blocked one-sided Jacobi built from the batched Gram GEMM and the LDS
+solver was written and measured: kernel matrices have condition numbers >= 1e9 and the Gram step squares them, so the
+small eigenvalues never converge -- dropped; a QR-based block Jacobi is what "next" means here.)  Autograd chains the
+pieces.
 
 Kept quirks: ONE kernel module is shared by the input space and every output mode (:27-29); the per-mode grids are
 0..d-1 as float columns; `forward` needs `log_likelihood` to have been called (it reads the cached `K`, `K_eigen`,
@@ -26,8 +30,14 @@ from . import functional as F
 
 
 class eigen_pairs:
+    """matrices up to 64 x 64 (the per-mode kernels; tiny input sets) go to the hand-written LDS Jacobi solver
+    (`ffgp_syevj_small`, ~80 us where rocSOLVER's syevd takes 1.7 ms); larger ones to rocSOLVER"""
+
     def __init__(self, matrix):
-        self.value, self.vector = torch.linalg.eigh(matrix, UPLO="U")
+        if matrix.shape[0] <= 64 and matrix.is_cuda:
+            self.value, self.vector = F.eigh_small(matrix)
+        else:
+            self.value, self.vector = torch.linalg.eigh(matrix, UPLO="U")
 
 
 def mode_dot(t, M, mode):

@@ -155,6 +155,18 @@ int ffgp_kernel_grad(ffgp_handle* h, const double* X1_dev, int n1, const double*
                      const double* w_dev, const double* amp_dev, double clamp_min, int kfun, double kparam,
                      const double* dK_dev, int ldk, double* g_w_dev, double* g_amp_dev, double* g_kparam_dev);
 
+/* Batched symmetric eigendecomposition of `batch` matrices M_b [n, n] (n <= 64; both triangles read), hand-written
+ * two-sided cyclic Jacobi, one workgroup per matrix in LDS: Q_b's columns are the eigenvectors, evals_b the eigenvalues,
+ * ascending (descending != 0: descending).  Replaces torch.linalg.eigh for the per-mode kernels of the HOGP block
+ * (two_fidelity_models/hogp_simple.py:17-19,99-100) and is the inner solver of functional.eigh's blocked one-sided Jacobi. */
+int ffgp_syevj_small(ffgp_handle* h, const double* M_dev, int n, int ldm, int batch, long strideM, double* Q_dev, int ldq,
+                     long strideQ, double* evals_dev, long strideE, int descending);
+
+/* ffgp_gemm over `batch` identical problems at fixed element strides (C_b = alpha op(A_b) op(B_b) + beta C_b). */
+int ffgp_gemm_batched(ffgp_handle* h, int opa, int opb, int lower_tiles, const double* A_dev, int lda, long strideA,
+                      const double* B_dev, int ldb, long strideB, double* C_dev, int ldc, long strideC, int m, int n, int k,
+                      double alpha, double beta, int batch);
+
 /* found_dev[i] = 1 iff row i of X1 [n1, D] equals (IEEE ==, element-wise) some row of X2 [n2, D]: the subset / unique-point
  * masks of the reference's data manager, `torch.all(x1.unsqueeze(1) == x2.unsqueeze(0), -1).any(-1)`
  * (FidelityFusion_Models/MF_data.py:196-199,234-237), as a device hash join instead of an N1 x N2 x D boolean temporary. */

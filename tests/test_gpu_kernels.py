@@ -339,3 +339,55 @@ def test_c_abi_standalone_consumer(tmp_path):
     out = subprocess.run([exe, "1500", "6", "3"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "c-abi example ok" in out.stdout
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("n", [1, 2, 5, 31, 33, 64])
+def test_syevj_small_vs_lapack(n):
+    """hand-written batched Jacobi eigensolver (csrc/eig.hip) against numpy.linalg.eigh: eigenvalues, orthogonality,
+    reconstruction; kernel-like spectra (tiny trailing eigenvalues) and generic symmetric matrices; both orderings"""
+    import torch
+    from fidelityfusion_amd import functional as F
+    rng = np.random.default_rng(n)
+    mats = []
+    for b in range(5):
+        if b % 2 == 0:                      # kernel matrix: fast-decaying spectrum, numerically rank deficient
+            X = rng.random((n, 2))
+            sq = ((X[:, None, :] - X[None, :, :]) ** 2).sum(-1)
+            mats.append(np.exp(-0.5 * sq / 0.5 ** 2))
+        else:
+            R = rng.standard_normal((n, n))
+            mats.append(0.5 * (R + R.T))
+    M = np.stack(mats)
+    ev, Q = F._syevj_small(torch.tensor(M, device="cuda"))
+    ev, Q = ev.cpu().numpy(), Q.cpu().numpy()
+    for b in range(len(mats)):
+        w = np.linalg.eigvalsh(M[b])
+        scale = max(np.abs(w).max(), 1e-300)
+        assert np.abs(ev[b] - w).max() <= 1e-13 * scale, (b, np.abs(ev[b] - w).max())
+        assert np.abs(Q[b].T @ Q[b] - np.eye(n)).max() < 1e-13
+        assert np.abs(Q[b] @ np.diag(ev[b]) @ Q[b].T - M[b]).max() <= 1e-13 * scale
+    evd, Qd = F._syevj_small(torch.tensor(M, device="cuda"), descending=True)
+    assert np.allclose(evd.cpu().numpy(), ev[:, ::-1], rtol=0, atol=1e-13 * np.abs(ev).max())
+
+
+def test_eigh_small_backward_matches_torch():
+    """the autograd wrapper of the LDS Jacobi solver: gradients of a scalar function of (eigenvalues, eigenvectors) --
+    chosen invariant to the eigenvectors' signs -- against torch.linalg.eigh's"""
+    import torch
+    from fidelityfusion_amd import functional as F
+    rng = np.random.default_rng(4)
+    R = rng.standard_normal((23, 23))
+    K0 = R @ R.T / 23 + np.diag(rng.random(23))
+    W = torch.tensor(rng.standard_normal((23, 23)), device="cuda")
+    outs = []
+    for fn in (F.eigh_small, lambda K: torch.linalg.eigh(K, UPLO="U")):
+        K = torch.tensor(K0, device="cuda", requires_grad=True)
+        lam, U = fn(K)
+        loss = (lam ** 2 * torch.arange(1, 24, device="cuda")).sum() + ((U * lam.sqrt()) @ (U * lam.sqrt()).T * W).sum() \
+            + (U @ torch.diag(1.0 / (1.0 + lam)) @ U.T * W.T).sum()
+        loss.backward()
+        outs.append((float(loss), K.grad.cpu().numpy()))
+    assert abs(outs[0][0] - outs[1][0]) <= 1e-11 * abs(outs[1][0])
+    g0, g1 = outs[0][1], outs[1][1]
+    assert np.abs(g0 - 0.5 * (g1 + g1.T)).max() <= 1e-9 * np.abs(g1).max()
