@@ -53,7 +53,7 @@ class cigp(nn.Module):
         # queries of a trained model (acquisition loops, serving) then cost one TRSM sweep instead of N^3/3.
         noise = self.log_beta.exp().pow(-1)
         objs = [x_train, y_train] + list(self.parameters())
-        vers = tuple(t._version for t in objs)
+        vers = tuple((t._version, t.data_ptr()) for t in objs)   # in-place updates bump the version; `p.data = ...` moves the pointer
         c = self._post
         if c is not None and len(c[0]) == len(objs) and all(r() is t for r, t in zip(c[0], objs)) and c[1] == vers:
             mean, var = c[2].predict(x_test, full_cov=True, var_add_all=float(noise))
