@@ -12,8 +12,8 @@ per-mode kernels -- run on the hand-written LDS Jacobi solver (`ffgp_syevj_small
 rocSOLVER (`torch.linalg.eigh` on the device: 0.66 s at N = 8192): a vendor-library call, not a hand-written kernel --
 the one place on this path where that is so.  (A blocked one-sided Jacobi built from the batched Gram GEMM and the LDS
 solver was written and measured: kernel matrices have condition numbers >= 1e9 and the Gram step squares them, so the
-small eigenvalues never converge -- dropped; a QR-based block Jacobi is what "next" means here.)  Autograd chains the
-pieces.
+small eigenvalues never converge -- dropped; a QR-based block Jacobi is what "next" means here.)  The likelihood's
+backward is closed-form (`_KronNLL`): GEMMs only, no differentiation through `eigh`.
 
 Kept quirks: ONE kernel module is shared by the input space and every output mode (:27-29); the per-mode grids are
 0..d-1 as float columns; `forward` needs `log_likelihood` to have been called (it reads the cached `K`, `K_eigen`,
@@ -61,6 +61,93 @@ def _outer(vs):
     return out
 
 
+class _KronNLL(torch.autograd.Function):
+    """+NLL / numel of vec(Y) ~ N(0, K_0 (x) K_1 (x) ... + diag(tau)) through the per-mode eigendecompositions
+    (hogp_simple.py:92-117 of the reference), with a closed-form backward instead of autograd through `eigh`:
+
+        S = (x)K_m + diag(tau),  A = (x)lambda_m + tau,  g = S^-1 y  (the tensor the reference caches as `self.g`)
+        dNLL/dY    = g
+        dNLL/dA    = 1/2 (1/A - (T_1/A)^2)   elementwise in the eigenbasis, where tau is added (summed for a scalar tau)
+        dNLL/dK_m  = 1/2 U_m diag(c_m) U_m^T  -  1/2 g_(m) [g x_{m' != m} K_m']_(m)^T,
+                     c_m[i] = sum_{others} (prod_{m' != m} lambda_m') / A
+
+    No eigenvector derivatives (the 1 / (lambda_i - lambda_j) terms of eigh's backward, ill-defined for the clustered
+    spectra kernel matrices have) appear; every O(N^2 prod d) / O(N^3) product runs on the fp64 matrix-core GEMM.
+    That form holds for the reference's scalar tau = 1/noise (+ scalar y_var).  An elementwise y_var is added to A in
+    the eigenbasis (MFGP_ver2023May/base_gp/hogp.py:118), which makes S depend on the eigenvectors themselves; that
+    case takes the general eigh pullback, written out in `backward`.
+    """
+
+    @staticmethod
+    def forward(ctx, cache, y, tau, *Ks):
+        es = [eigen_pairs(K) for K in Ks]
+        A = _outer([e.value for e in es]) + tau
+        Ainv = A.reciprocal()
+        T_1 = multi_mode_dot(y, [e.vector.T.contiguous() for e in es])
+        W = T_1 * Ainv
+        g = multi_mode_dot(W, [e.vector for e in es])
+        nd = A.numel()
+        nll = 0.5 * nd * math.log(2 * math.pi) + 0.5 * torch.log(A).sum() + 0.5 * (T_1 * W).sum()
+        cache.update(eigen=es, A=A, g=g)
+        ctx.pack = (es, Ainv, W, g, Ks, tau.shape, nd)
+        return nll / nd
+
+    @staticmethod
+    def backward(ctx, dl):
+        es, Ainv, W, g, Ks, tau_shape, nd = ctx.pack
+        s = dl / nd
+        need = ctx.needs_input_grad
+        dY = g * s if need[1] else None
+        dtau = None
+        if need[2]:
+            # tau sits on A (the eigenbasis diagonal): d/dA [1/2 log A + 1/2 T_1^2 / A] = 1/2 (1/A - W^2)
+            dtau = (0.5 * s * (Ainv - W * W)).sum_to_size(tau_shape)
+        n = len(Ks)
+        dKs = [None] * n
+        uniform = math.prod(tau_shape) == 1
+        if any(need[3:]):
+            P0 = mode_dot(g, Ks[0], 0) if uniform and any(need[4:]) else None   # the one N^2 prod(d) product the modes m >= 1 share
+            for m in range(n):
+                if not need[3 + m]:
+                    continue
+                t = Ainv if uniform else Ainv - W * W
+                for mp in range(n):
+                    if mp != m:
+                        shape = [1] * n
+                        shape[mp] = -1
+                        t = t * es[mp].value.reshape(shape)
+                c = t.sum(dim=[a for a in range(n) if a != m])
+                U = es[m].vector
+                if uniform:
+                    term1 = F.matmul_nt(U * c.unsqueeze(0), U)
+                    P = g if m == 0 else P0
+                    for mp in range(1, n):
+                        if mp != m:
+                            P = mode_dot(P, Ks[mp], mp)
+                    gm = g.movedim(m, 0).reshape(g.shape[m], -1)
+                    Pm = P.movedim(m, 0).reshape(g.shape[m], -1)
+                    dKs[m] = (0.5 * s) * (term1 - F.matmul_nt(gm, Pm))
+                else:
+                    # an elementwise tau lives in the eigenbasis, so S depends on the eigenvectors themselves: the
+                    # general eigh pullback U (diag(dlambda) + (U^T dU) / (lambda_j - lambda_i)) U^T with U^T dU = T_1(m) W(m)^T
+                    lam = es[m].value
+                    T1m = (W / Ainv).movedim(m, 0).reshape(g.shape[m], -1)
+                    Wm = W.movedim(m, 0).reshape(g.shape[m], -1)
+                    E = lam.unsqueeze(0) - lam.unsqueeze(1)
+                    E.diagonal().fill_(float("inf"))
+                    X = F.matmul_nt(T1m, Wm) / E
+                    X.diagonal().add_(0.5 * c)
+                    dKs[m] = s * F.matmul_nt(F.matmul_nt(U, X.T.contiguous()), U)
+        return (None, dY, dtau) + tuple(dKs)
+
+
+def kron_nll(y, tau, Ks):
+    """(loss, cache): loss = +NLL / numel; cache holds the (detached) `eigen` pairs, `A` and `g` of this evaluation"""
+    cache = {}
+    loss = _KronNLL.apply(cache, y, tau, *Ks)
+    return loss, cache
+
+
 class HOGP_simple(nn.Module):
     def __init__(self, kernel, noise_variance, output_shape, learnable_grid=False, learnable_map=False):
         super().__init__()
@@ -95,24 +182,14 @@ class HOGP_simple(nn.Module):
         dev = self._dev()
         y = y_train.to(device=dev, dtype=torch.float64)
         self.K.clear()
-        self.K_eigen.clear()
         self.K.append(self._kernel(0, x_train, x_train))
-        self.K_eigen.append(eigen_pairs(self.K[-1]))
         for i in range(len(self.kernel_list) - 1):
             _in = mode_dot(self.grid[i].to(device=dev, dtype=torch.float64), self.mapping_vector[i].to(device=dev, dtype=torch.float64), 0)
             self.K.append(self._kernel(i + 1, _in, _in))
-            self.K_eigen.append(eigen_pairs(self.K[-1]))
-        A = _outer([e.value for e in self.K_eigen])
-        A = A + self.noise_variance.to(dev).pow(-1)
-        T_1 = multi_mode_dot(y, [e.vector.T.contiguous() for e in self.K_eigen])
-        T_3 = multi_mode_dot(T_1 * A.pow(-1 / 2), [e.vector for e in self.K_eigen])
-        b = T_3.reshape(-1)
-        g = multi_mode_dot(T_1 * A.pow(-1), [e.vector for e in self.K_eigen])
-        self.A = A
-        self.g = g
-        nd = A.numel()
-        loss = -0.5 * nd * math.log(2 * math.pi) - 0.5 * torch.log(A).sum() - 0.5 * (b * b).sum()
-        loss = -loss / nd
+        loss, cache = kron_nll(y, self.noise_variance.to(dev).pow(-1), self.K)
+        self.K_eigen[:] = cache["eigen"]
+        self.A = cache["A"]
+        self.g = cache["g"]
         odt = y_train.dtype if y_train.dtype.is_floating_point else torch.float64
         return loss.to(device=y_train.device, dtype=odt)
 

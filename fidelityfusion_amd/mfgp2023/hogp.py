@@ -8,7 +8,7 @@ import math
 
 import torch
 
-from ..hogp_simple import _outer, eigen_pairs, mode_dot, multi_mode_dot
+from ..hogp_simple import _outer, kron_nll, mode_dot, multi_mode_dot
 from .. import functional as F
 from .cigp import GP_noise_box, SE_kernel, _merge, _single
 
@@ -66,14 +66,11 @@ class HOGP(torch.nn.Module):
     def compute_kernel_cache(self):
         dev = self._dev()
         ks = [F.kernel_on_device(self.kernel_list[0], self.train_x, self.train_x)]
-        es = [eigen_pairs(ks[-1])]
         for i in range(self.n_dim):
             _in = mode_dot(self.grid[i].to(device=dev, dtype=torch.float64),
                            self.mapping_vector[i].to(device=dev, dtype=torch.float64), 0)
             ks.append(F.kernel_on_device(self.kernel_list[i + 1], _in, _in))
-            es.append(eigen_pairs(ks[-1]))
-        self.k_result_cache = ks
-        self.eigen_cache = es
+        self.k_result_cache = ks   # the eigen pairs (`eigen_cache`) come out of the likelihood evaluation
 
     def compute_loss(self, x, y, x_var=0.0, y_var=0.0, update_data=False):
         x, y = _single(x), _single(y)
@@ -82,17 +79,12 @@ class HOGP(torch.nn.Module):
             self.train_y = y
         self.compute_kernel_cache()
         dev = self._dev()
-        A = _outer([e.value for e in self.eigen_cache])
-        A = A + self.noise_box.get().to(dev).pow(-1)
-        A = A + (y_var.to(device=dev, dtype=torch.float64) if isinstance(y_var, torch.Tensor) else y_var)
-        T_1 = multi_mode_dot(self.train_y.to(device=dev, dtype=torch.float64), [e.vector.T.contiguous() for e in self.eigen_cache])
-        T_3 = multi_mode_dot(T_1 * A.pow(-1 / 2), [e.vector for e in self.eigen_cache])
-        b = T_3.reshape(-1)
-        self.g = multi_mode_dot(T_1 * A.pow(-1), [e.vector for e in self.eigen_cache])
-        self.A = A
-        nd = A.numel()
-        loss = -0.5 * nd * math.log(2 * math.pi) - 0.5 * torch.log(A).sum() - 0.5 * (b * b).sum()
-        loss = -loss / nd
+        tau = self.noise_box.get().to(dev).pow(-1)
+        tau = tau + (y_var.to(device=dev, dtype=torch.float64) if isinstance(y_var, torch.Tensor) else y_var)
+        loss, cache = kron_nll(self.train_y.to(device=dev, dtype=torch.float64), tau, self.k_result_cache)
+        self.eigen_cache = cache["eigen"]
+        self.A = cache["A"]
+        self.g = cache["g"]
         odt = y.dtype if y.dtype.is_floating_point else torch.float64
         return loss.to(device=y.device, dtype=odt)
 

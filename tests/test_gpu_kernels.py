@@ -371,6 +371,55 @@ def test_syevj_small_vs_lapack(n):
     assert np.allclose(evd.cpu().numpy(), ev[:, ::-1], rtol=0, atol=1e-13 * np.abs(ev).max())
 
 
+@pytest.mark.parametrize("shape,tau_kind", [((37, 5, 4), "scalar"), ((70, 6), "scalar"), ((20, 3, 4, 2), "tensor")])
+def test_kron_nll_closed_form_backward(shape, tau_kind):
+    """the Kronecker-structured likelihood of HOGP (hogp_simple.py:92-117): value and the closed-form gradients w.r.t. Y,
+    tau and every K_m against the dense definition 1/2 log|S| + 1/2 y^T S^-1 y, S = kron(K_m) + tau I, differentiated
+    by torch (scalar tau), and against torch autograd through `eigh` for an elementwise tau (which lives in the
+    eigenbasis, as the reference's y_var does)"""
+    import math
+    import torch
+    from fidelityfusion_amd.hogp_simple import kron_nll, multi_mode_dot, _outer
+    rng = np.random.default_rng(11)
+    Ks0 = []
+    for dm in shape:
+        R = rng.standard_normal((dm, dm))
+        Ks0.append(R @ R.T / dm + 0.1 * np.eye(dm))
+    Y0 = rng.standard_normal(shape)
+    nd = int(np.prod(shape))
+    tau0 = np.array([0.7]) if tau_kind == "scalar" else 0.5 + rng.random(shape)
+
+    def leaves():
+        return (torch.tensor(Y0, device="cuda", requires_grad=True), torch.tensor(tau0, device="cuda", requires_grad=True),
+                [torch.tensor(K, device="cuda", requires_grad=True) for K in Ks0])
+
+    y, tau, Ks = leaves()
+    loss, cache = kron_nll(y, tau, Ks)
+    loss.backward()
+    y2, tau2, Ks2 = leaves()
+    if tau_kind == "scalar":
+        S = Ks2[0]
+        for K in Ks2[1:]:
+            S = torch.kron(S, K)
+        S = S + tau2 * torch.eye(nd, device="cuda", dtype=torch.float64)
+        v = y2.reshape(-1, 1)
+        ref = (0.5 * nd * math.log(2 * math.pi) + 0.5 * torch.logdet(S) + 0.5 * (v.T @ torch.linalg.solve(S, v)).sum()) / nd
+        g_ref = torch.linalg.solve(S.detach(), v.detach()).reshape(shape)
+        assert np.abs((cache["g"] - g_ref).cpu().numpy()).max() <= 1e-10 * float(g_ref.abs().max())
+    else:
+        es = [torch.linalg.eigh(K, UPLO="U") for K in Ks2]
+        A = _outer([e[0] for e in es]) + tau2
+        T1 = multi_mode_dot(y2, [e[1].T.contiguous() for e in es])
+        ref = (0.5 * nd * math.log(2 * math.pi) + 0.5 * torch.log(A).sum() + 0.5 * (T1 * T1 / A).sum()) / nd
+    ref.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-12 * abs(float(ref.detach()))
+    sym = lambda G: 0.5 * (G + G.T)
+    pairs = [(y.grad, y2.grad), (tau.grad, tau2.grad)] + [(sym(a.grad), sym(b.grad)) for a, b in zip(Ks, Ks2)]
+    for a, b in pairs:
+        assert a.shape == b.shape
+        assert np.abs((a - b).cpu().numpy()).max() <= 1e-9 * max(float(b.abs().max()), 1e-300)
+
+
 def test_eigh_small_backward_matches_torch():
     """the autograd wrapper of the LDS Jacobi solver: gradients of a scalar function of (eigenvalues, eigenvectors) --
     chosen invariant to the eigenvectors' signs -- against torch.linalg.eigh's"""
@@ -387,7 +436,7 @@ def test_eigh_small_backward_matches_torch():
         loss = (lam ** 2 * torch.arange(1, 24, device="cuda")).sum() + ((U * lam.sqrt()) @ (U * lam.sqrt()).T * W).sum() \
             + (U @ torch.diag(1.0 / (1.0 + lam)) @ U.T * W.T).sum()
         loss.backward()
-        outs.append((float(loss), K.grad.cpu().numpy()))
+        outs.append((float(loss.detach()), K.grad.cpu().numpy()))
     assert abs(outs[0][0] - outs[1][0]) <= 1e-11 * abs(outs[1][0])
     g0, g1 = outs[0][1], outs[1][1]
     assert np.abs(g0 - 0.5 * (g1 + g1.T)).max() <= 1e-9 * np.abs(g1).max()
