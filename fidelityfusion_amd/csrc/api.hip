@@ -114,6 +114,7 @@ int ffgp_create(int device, ffgp_handle** out) {
     h->small_tile_threshold = 640;
     h->tile32_threshold = 1024;
     h->polite_m = 6144;
+    h->split_rem_max = 180;
     h->la_split = 1;
     h->aux_prio = 1;
   }
@@ -187,6 +188,8 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->lookahead = (int)value;
   } else if (!strcmp(key, "polite_m")) {
     h->polite_m = (int)value;
+  } else if (!strcmp(key, "split_rem_max")) {
+    h->split_rem_max = (int)value;
 
   } else {
     return FFGP_ERR_ARG;

@@ -359,42 +359,18 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, const double* _
   }
 }
 
-template <int OPA, int OPB, int MODE, int TAG, int TM, int TN>
-__global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
+// One output tile (ti, tj) of shape TM x TN: k loop + epilogue.  Everything that depends on the tile shape lives here so
+// that a launch can mix shapes (see the split tail in ffgp_gemm_f64).
+template <int OPA, int OPB, int MODE, int TM, int TN>
+__device__ __forceinline__ void gemm_one_tile(const GemmArgs& p, const double* __restrict__ Ag, const double* __restrict__ Bg,
+                                              double* __restrict__ Cg, double* smem, int ti, int tj, const int tid, const int bid) {
   constexpr int WM = Geo<TM>::WT, WN = Geo<TN>::WT;
-  __shared__ __attribute__((aligned(16))) double smem[2 * (opbuf<OPA, TM>() + opbuf<OPB, TN>())];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  if (p.prio) __builtin_amdgcn_s_setprio(2);  // panel GEMMs of the look-ahead chain outrank the trailing update
-  // batched launches (gridDim.y > 1): identical problems at fixed strides (the levels of the blocked TRTRI)
-  const double* __restrict__ Ag = p.A + (size_t)blockIdx.y * p.sA;
-  const double* __restrict__ Bg = p.B + (size_t)blockIdx.y * p.sB;
-  double* __restrict__ Cg = p.C + (size_t)blockIdx.y * p.sC;
-
   int offA[4], offB[4];
   frag_offsets<OPA, TM>(lane, wm * (TM / 2), offA);
   frag_offsets<OPB, TN>(lane, wn * (TN / 2), offB);
   const bool fast_ab = p.fast && p.avec && p.bvec;
-
-  // One workgroup per tile.  (A persistent 2-per-CU grid was measured and dropped: it keeps the two workgroups of
-  // a CU in lock-step, so their prologues and epilogues coincide instead of hiding under each other's k loop.)
-  const int bid = blockIdx.x;
-  FFGP_TRACE(0);
-  // XCD-aware bijective remap of the block id, then banded tile order (hardware deals workgroup ids round-robin
-  // over the 8 XCDs).
-  // (triangular-operand launches have k ranges that shrink along the tile order: giving each XCD a contiguous
-  //  chunk would leave all the long tiles on XCD 0, so those launches keep the round-robin block order)
-  int t = bid;
-  if (!(p.lo_i | p.lo_j | p.hi_i | p.hi_j)) {
-    const int nwg = p.total_tiles;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  int ti, tj;
-  decode_tile(t, MODE, p.tiles_m, p.tiles_n, ti, tj);
-  // wave-uniform by construction; pin them to SGPRs so every tile base below is scalar arithmetic
-  ti = __builtin_amdgcn_readfirstlane(ti);
-  tj = __builtin_amdgcn_readfirstlane(tj);
   const int m0 = ti * TM, n0 = tj * TN;
 
   // k range of this tile (triangular operands skip the k-tiles that are structurally zero)
@@ -493,6 +469,53 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
     }
   }
   FFGP_TRACE(3);
+}
+
+template <int OPA, int OPB, int MODE, int TAG, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) double smem[2 * (opbuf<OPA, TM>() + opbuf<OPB, TN>())];
+  const int tid = threadIdx.x;
+  if (p.prio) __builtin_amdgcn_s_setprio(2);  // panel GEMMs of the look-ahead chain outrank the trailing update
+  // batched launches (gridDim.y > 1): identical problems at fixed strides (the levels of the blocked TRTRI)
+  const double* __restrict__ Ag = p.A + (size_t)blockIdx.y * p.sA;
+  const double* __restrict__ Bg = p.B + (size_t)blockIdx.y * p.sB;
+  double* __restrict__ Cg = p.C + (size_t)blockIdx.y * p.sC;
+
+  // One workgroup per tile.  (A persistent 2-per-CU grid was measured and dropped: it keeps the two workgroups of
+  // a CU in lock-step, so their prologues and epilogues coincide instead of hiding under each other's k loop.)
+  const int bid = blockIdx.x;
+  FFGP_TRACE(0);
+  if constexpr (TM == 128 && TN == 128) {
+    // Split tail: equal-sized tiles finish in rounds of (resident workgroups) and the last round is mostly idle CUs.
+    // The launcher may therefore hand the last `split` 128-tiles of the tile order out as quarter tiles (64 x 64), placed
+    // at the END of the grid: they start as slots free up under the last full round and level the finish line.
+    if (bid >= p.split_at) {
+      const int q = bid - p.split_at;
+      int Ti, Tj;
+      decode_tile(p.split_at + (q >> 2), MODE, p.tiles_m, p.tiles_n, Ti, Tj);
+      const int ti = __builtin_amdgcn_readfirstlane(2 * Ti + ((q >> 1) & 1));
+      const int tj = __builtin_amdgcn_readfirstlane(2 * Tj + (q & 1));
+      if (ti * 64 >= p.m || tj * 64 >= p.n || (MODE == TILES_LOWER && tj > ti)) return;
+      gemm_one_tile<OPA, OPB, MODE, 64, 64>(p, Ag, Bg, Cg, smem, ti, tj, tid, bid);
+      return;
+    }
+  }
+  // XCD-aware bijective remap of the block id, then banded tile order (hardware deals workgroup ids round-robin
+  // over the 8 XCDs).
+  // (triangular-operand launches have k ranges that shrink along the tile order: giving each XCD a contiguous
+  //  chunk would leave all the long tiles on XCD 0, so those launches keep the round-robin block order)
+  int t = bid;
+  if (!(p.lo_i | p.lo_j | p.hi_i | p.hi_j)) {
+    const int nwg = p.total_tiles;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  int ti, tj;
+  decode_tile(t, MODE, p.tiles_m, p.tiles_n, ti, tj);
+  // wave-uniform by construction; pin them to SGPRs so every tile base below is scalar arithmetic
+  ti = __builtin_amdgcn_readfirstlane(ti);
+  tj = __builtin_amdgcn_readfirstlane(tj);
+  gemm_one_tile<OPA, OPB, MODE, TM, TN>(p, Ag, Bg, Cg, smem, ti, tj, tid, bid);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -622,6 +645,18 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
             (size_t)ldb * 8 * 130 < 0xffffffffull && (size_t)ldc * 8 * 130 < 0xffffffffull)
                ? 1 : 0;
   a.grid = a.total_tiles;
+  a.split_at = 0x7fffffff;
+  // Split tail (see ffgp_gemm_f64): with T equal tiles on 256 CUs the last (T mod 256) tiles run on otherwise idle CUs for a
+  // whole tile time; when that remainder is small, hand it out as 64 x 64 quarters -- 4x the workgroups, a quarter of the
+  // chain each -- which start under the last full round.  (An in-place or batched launch never splits.)
+  if (tsm == 128 && tsn == 128 && alias == 0 && a.batch == 1 && h->force_ts == 0 && h->split_rem_max > 0 && a.total_tiles > 256) {
+    const int rem = a.total_tiles % 256;
+    if (rem > 0 && rem <= h->split_rem_max) {
+      a.split_at = a.total_tiles - rem;
+      a.total_tiles = a.split_at;          // the XCD remap permutes the whole-tile part only
+      a.grid = a.split_at + 4 * rem;
+    }
+  }
   // "Polite" trailing update: once the factorisation is bound by its dependency chain (trailing matrix below polite_m
   // rows) the 128-tile SYRK is launched with LDS padding so that only one of its workgroups fits a CU.  Alone it still
   // runs the MFMA pipe at ~70 %, and the other half of every CU -- VGPRs, LDS, issue slots -- is free for the chain's

@@ -112,6 +112,36 @@ def test_gemm_lower_trapezoid(ff, tile, m, n, k, ops):
     assert np.array_equal(out[~mask], C0[~mask]), "strictly-upper part must not be written"
 
 
+@pytest.mark.parametrize("case", [
+    ("full", 0, 0, 2176, 2176, 40, 0), ("full", 0, 1, 2200, 2150, 24, 0), ("full", 1, 0, 2090, 2300, 33, 0), ("full", 1, 1, 2176, 2304, 16, 0),
+    ("lower", 0, 0, 2944, 2944, 48, 0), ("lower", 0, 0, 3000, 3000, 20, 0), ("lower", 1, 1, 3500, 1300, 36, 0),
+    ("lower", 1, 1, 2944, 2944, 2944, 1), ("full", 0, 1, 2300, 2176, 2300, 4)])
+def test_gemm_split_tail(ff, case):
+    """the split tail of the 128-tile launches (last tiles mod 256 handed out as 64 x 64 quarters): same bits as the
+    unsplit launch, nothing written outside the region, ragged edges and triangular k ranges included"""
+    _lib, h = ff
+    mode, opa, opb, m, n, k, tri = case
+    rng = np.random.default_rng(m + 3 * n + k)
+    if tri == 1:     # LAUUM shape: X^T X for lower-triangular X, both MN-major
+        X = np.tril(rng.standard_normal((m, m)))
+        A, B = X.T.copy(), X
+    elif tri == 4:   # A lower-triangular (K-major)
+        A, B = np.tril(rng.standard_normal((m, m))), rng.standard_normal((m, n))
+    else:
+        A, B = rng.standard_normal((m, k)), rng.standard_normal((k, n))
+    C0 = rng.standard_normal((m, n))
+    outs = []
+    for rem_max in (255.0, 0.0):
+        assert _lib.lib.ffgp_set_option(h, b"split_rem_max", rem_max) == 0
+        outs.append(run_gemm(ff, opa, opb, 1 if mode == "lower" else 0, tri, A, B, C0, -1.0, 1.0, pad=(0, 0, 2)))
+    _lib.lib.ffgp_set_option(h, b"split_rem_max", 180.0)
+    assert np.array_equal(outs[0], outs[1]), "split and unsplit launches must agree bit for bit"
+    full = C0 - A @ B
+    mask = np.tril(np.ones((m, n), dtype=bool)) if mode == "lower" else np.ones((m, n), dtype=bool)
+    assert relerr(outs[0][mask], full[mask]) < 1e-12
+    assert np.array_equal(outs[0][~mask], C0[~mask])
+
+
 def test_gemm_triangular_k_ranges(ff, tile):
     rng = np.random.default_rng(9)
     n = 520

@@ -309,3 +309,50 @@ def tile32_sweep():
 
 if "tile32" in sys.argv[1:]:
     tile32_sweep()
+
+
+def split_sweep():
+    """split tail of the 128-tile launches: the trailing SYRK at every size the N = 16384 factorisation sees, and the
+    whole factorisation, for split_rem_max = 0 (off) / 100 / 180 / 255"""
+    h = _lib.handle(0)
+    _lib.bind_stream(h, 0)
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(0)
+    k = 512
+    A = torch.rand((16384, k), generator=g, device=dev, dtype=torch.float64) - 0.5
+    Cm = torch.zeros((16384, 16384), device=dev, dtype=torch.float64)
+    opts = (0, 100, 180, 255)
+    tot = {o: 0.0 for o in opts}
+    for m in range(15872, 2047, -512):
+        T = m // 128
+        tiles = T * (T + 1) // 2
+        row = []
+        for o in opts:
+            _lib.set_option("split_rem_max", o, 0)
+            fn = lambda: _lib.lib.ffgp_gemm(h, 0, 0, 1, 0, p(A), k, p(A), k, p(Cm), 16384, m, m, k, -1.0, 1.0)
+            fn()
+            tmin, _ = timeit(fn, rounds=7)
+            tot[o] += tmin
+            row.append("%.3f" % tmin)
+        print("m=%5d tiles=%5d rem=%3d: ms %s" % (m, tiles, tiles % 256, " / ".join(row)))
+    print("sum over sizes: " + " / ".join("%d: %.2f ms" % (o, tot[o]) for o in opts))
+    n = 16384
+    X = torch.rand((n, 16), generator=g, device=dev, dtype=torch.float64)
+    w = torch.ones(16, device=dev, dtype=torch.float64)
+    amp = torch.ones(1, device=dev, dtype=torch.float64)
+    dadd = torch.full((1,), 0.37, device=dev, dtype=torch.float64)
+    for o in opts + opts:
+        _lib.set_option("split_rem_max", o, 0)
+
+        def fn():
+            _lib.lib.ffgp_assemble(h, p(X), n, p(X), n, 16, p(w), p(amp), 1e-30, p(dadd), None, 0, None, 0, 0.0, 0.0, p(Cm), n, 1, 0,
+                                   1.0)
+            assert _lib.lib.ffgp_potrf(h, p(Cm), n, n) == 0
+        fn()
+        tmin, tmed = timeit(fn, rounds=5)
+        print("assemble+potrf n=%d split_rem_max=%d: %.2f ms min, %.2f med" % (n, o, tmin, tmed))
+    _lib.set_option("split_rem_max", 180, 0)
+
+
+if "split" in sys.argv[1:]:
+    split_sweep()
