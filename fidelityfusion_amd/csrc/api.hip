@@ -92,32 +92,14 @@ extern "C" {
 
 const char* ffgp_version(void) { return "ffgp 0.1 (gfx950, fp64 MFMA)"; }
 
-int ffgp_create(int device, ffgp_handle** out) {
-  if (!out) return FFGP_ERR_ARG;
-  int count = 0;
-  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) {
-    fprintf(stderr, "[ffgp] no usable HIP device (requested %d of %d); libffgp has no CPU fallback\n", device, count);
-    return FFGP_ERR_NODEVICE;
-  }
-  FFGP_HIP(hipSetDevice(device));
-  ffgp_handle* h = new ffgp_handle();  // value-initialised: every POD member is zero
-  h->device = device;
+static int create_resources(ffgp_handle* h) {
   FFGP_HIP(hipStreamCreate(&h->stream));
   h->own_stream = true;
   h->own = h->stream;
-  {
-    int lo = 0, hi = 0;  // numerically lowest value = greatest priority
-    FFGP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    FFGP_HIP(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, hi));
-    for (int i = 0; i < 8; ++i) FFGP_HIP(hipEventCreateWithFlags(&h->la_ev[i], hipEventDisableTiming));
-    h->lookahead = 1;
-    h->small_tile_threshold = 640;
-    h->tile32_threshold = 1024;
-    h->polite_m = 6144;
-    h->split_rem_max = 180;
-    h->la_split = 1;
-    h->aux_prio = 1;
-  }
+  int lo = 0, hi = 0;  // numerically lowest value = greatest priority
+  FFGP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  FFGP_HIP(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, hi));
+  for (int i = 0; i < 8; ++i) FFGP_HIP(hipEventCreateWithFlags(&h->la_ev[i], hipEventDisableTiming));
   FFGP_HIP(hipMalloc(&h->d_info, 16 * sizeof(int)));
   FFGP_HIP(hipMemset(h->d_info, 0, 16 * sizeof(int)));
   FFGP_HIP(hipDeviceSynchronize());   // NULL-stream memset: make it visible before any (non-blocking) stream touches it
@@ -128,7 +110,32 @@ int ffgp_create(int device, ffgp_handle** out) {
   for (int i = 0; i <= FFGP_MAX_STAGES; ++i) FFGP_HIP(hipEventCreate(&h->ev[i]));
   FFGP_HIP(hipEventCreate(&h->syrk_ev[0]));
   FFGP_HIP(hipEventCreate(&h->syrk_ev[1]));
+  return FFGP_OK;
+}
+
+int ffgp_create(int device, ffgp_handle** out) {
+  if (!out) return FFGP_ERR_ARG;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) {
+    fprintf(stderr, "[ffgp] no usable HIP device (requested %d of %d); libffgp has no CPU fallback\n", device, count);
+    return FFGP_ERR_NODEVICE;
+  }
+  FFGP_HIP(hipSetDevice(device));
+  ffgp_handle* h = new ffgp_handle();  // value-initialised: every POD member is zero
+  h->device = device;
+  h->lookahead = 1;
+  h->small_tile_threshold = 640;
+  h->tile32_threshold = 1024;
+  h->polite_m = 6144;
+  h->split_rem_max = 180;
+  h->la_split = 1;
+  h->aux_prio = 1;
   h->nb_outer = 512;
+  const int rc = create_resources(h);
+  if (rc != FFGP_OK) {   // release whatever was created before the failure
+    ffgp_destroy(h);
+    return rc;
+  }
   *out = h;
   return FFGP_OK;
 }
@@ -136,20 +143,23 @@ int ffgp_create(int device, ffgp_handle** out) {
 int ffgp_destroy(ffgp_handle* h) {
   if (!h) return FFGP_OK;
   hipSetDevice(h->device);
-  hipStreamSynchronize(h->stream);
+  if (h->own) hipStreamSynchronize(h->own);
+  if (h->aux) hipStreamSynchronize(h->aux);
   if (h->ws) hipFree(h->ws);
   if (h->dinv) hipFree(h->dinv);
-  hipFree(h->d_info);
-  hipFree(h->d_scal);
-  hipHostFree(h->h_info);
-  hipHostFree(h->h_scal);
-  for (int i = 0; i <= FFGP_MAX_STAGES; ++i) hipEventDestroy(h->ev[i]);
-  hipEventDestroy(h->syrk_ev[0]);
-  hipEventDestroy(h->syrk_ev[1]);
+  if (h->d_info) hipFree(h->d_info);
+  if (h->d_scal) hipFree(h->d_scal);
+  if (h->h_info) hipHostFree(h->h_info);
+  if (h->h_scal) hipHostFree(h->h_scal);
+  for (int i = 0; i <= FFGP_MAX_STAGES; ++i)
+    if (h->ev[i]) hipEventDestroy(h->ev[i]);
+  for (int i = 0; i < 2; ++i)
+    if (h->syrk_ev[i]) hipEventDestroy(h->syrk_ev[i]);
   for (hipEvent_t e : h->syrk_pool) hipEventDestroy(e);
-  for (int i = 0; i < 8; ++i) hipEventDestroy(h->la_ev[i]);
-  hipStreamDestroy(h->aux);
-  hipStreamDestroy(h->own);
+  for (int i = 0; i < 8; ++i)
+    if (h->la_ev[i]) hipEventDestroy(h->la_ev[i]);
+  if (h->aux) hipStreamDestroy(h->aux);
+  if (h->own) hipStreamDestroy(h->own);
   delete h;
   return FFGP_OK;
 }
