@@ -59,8 +59,11 @@ class GP_basic(nn.Module):
         return mu.to(device=y_train.device, dtype=odt).squeeze(), var.to(device=y_train.device, dtype=odt)
 
     def log_likelihood(self, x_train, y_train, Kinv_method="cholesky3"):
-        _check_method(Kinv_method, _METHODS_LL, ("cholesky1", "cholesky2", "cholesky3", "direct"))
+        _check_method(Kinv_method, _METHODS_LL, _METHODS_LL)
         y_train, y_var = _split(y_train)
+        if Kinv_method.startswith("torch_distribution_MN"):   # (:147-151) N copies of the normalising constant, d == N only
+            from .gp_computation_pack import _mvn_at_its_mean
+            return _mvn_at_its_mean(y_train, self._sigma_composed(x_train, y_var).to(y_train.device))
         if Kinv_method != "cholesky3":   # the alternative formulas (:120-129,141-143), composed from the same device pieces
             from .gp_computation_pack import _alt_terms
             quad, const = _alt_terms(y_train, self._sigma_composed(x_train, y_var).to(y_train.device), Kinv_method)

@@ -7,8 +7,9 @@
 
 'cholesky3' -- the method every model in the reference uses -- is the fused path; 'cholesky1', 'cholesky2' and
 'direct' (alternative formulas with their own quirks, used by no model) are composed from the same device pieces;
-the two `torch_distribution_MN*` branches (which in the reference only run when N equals the output dimension) raise
-NotImplementedError, an unknown name raises ValueError as in the reference (:91,116).
+the two `torch_distribution_MN*` branches (:85-88) read y's last axis as the event axis, so they only run when d == N and
+then return N copies of the normalising constant -- built from the same device log-determinant; an unknown name raises
+ValueError as in the reference (:91,116).
 """
 import math
 
@@ -50,12 +51,25 @@ def Gaussian_log_likelihood(y, cov, Kinv_method="cholesky3"):
     y^T Sigma^-1 y but count the log-determinant twice and return a [d, d] matrix; 'cholesky2' (:60-63) the Sigma^-2
     form with the double log-determinant.  All are differentiable w.r.t. y and cov."""
     assert len(y.shape) == 2 and len(cov.shape) == 2, "y, mean, cov should be 2D tensors"
-    _check_method(Kinv_method, _REFERENCE_METHODS, ("cholesky1", "cholesky2", "cholesky3", "direct"))
+    _check_method(Kinv_method, _REFERENCE_METHODS, _REFERENCE_METHODS)
+    if Kinv_method.startswith("torch_distribution_MN"):
+        return _mvn_at_its_mean(y, cov)
     if Kinv_method == "cholesky3":
         ll = -F.gaussian_ll_v2(y, cov)   # differentiable w.r.t. y and cov (closed-form V2 gradients)
         return ll.reshape(1, 1) if y.shape[1] == 1 else ll
     quad, const = _alt_terms(y, cov, Kinv_method)
     return -0.5 * (quad + const)
+
+
+def _mvn_at_its_mean(y, cov):
+    """`MultivariateNormal(y, scale_tril=L | covariance_matrix=cov).log_prob(y)` (:85-88; gp_basic.py:147-151): the rows of
+    y are N location vectors whose length must equal cov's size, and each is evaluated at itself -- N copies of
+    -N/2 log 2 pi - 1/2 log|cov|, differentiable w.r.t. cov through the fused factorisation"""
+    n = cov.shape[0]
+    if y.shape[1] != n:   # torch.distributions refuses the broadcast the same way
+        raise ValueError("torch_distribution_MN*: y's last dimension (%d) must equal the covariance size (%d)" % (y.shape[1], n))
+    val = -0.5 * n * math.log(2.0 * math.pi) - 0.5 * _logdet(cov).to(y.device)
+    return val.reshape(1).expand(y.shape[0]).to(y.dtype if y.dtype.is_floating_point else torch.float64)
 
 
 def _alt_terms(y, cov, Kinv_method):

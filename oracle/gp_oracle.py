@@ -218,6 +218,22 @@ def ll_v2(Y, cov):
     return -0.5 * ((A * A).sum() + 2.0 * d * np.log(np.diag(L)).sum() + n * d * np.log(2.0 * np.pi)), L, A
 
 
+def ll_alt(Y, cov, method):
+    """L3: the other Kinv_method branches of Gaussian_log_likelihood (gp_computation_pack.py:55-63,82-88), quirks kept:
+    'cholesky1' / 'direct' use the true y^T Sigma^-1 y but return a [d, d] matrix with the log-determinant counted
+    twice; 'cholesky2' the Sigma^-2 form; the two torch_distribution_MN* branches evaluate N(y_i | y_i, cov) for the N
+    rows of y (which must have length N): N copies of the normalising constant."""
+    n = Y.shape[0]
+    L = cholesky_lower(cov)
+    logdet = 2.0 * np.log(np.diag(L)).sum()
+    if method.startswith("torch_distribution_MN"):
+        assert Y.shape[1] == n
+        return np.full(n, -0.5 * n * np.log(2.0 * np.pi) - 0.5 * logdet)
+    A = cho_solve(L, Y)
+    quad = Y.T @ A if method in ("cholesky1", "direct") else A.T @ A
+    return -0.5 * (quad + 2.0 * logdet + n * np.log(2.0 * np.pi))
+
+
 def ll_v2_grads(Y, cov):
     """Closed-form d(LL_v2)/d(cov), d(LL_v2)/dY."""
     ll, L, A = ll_v2(Y, cov)

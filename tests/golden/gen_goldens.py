@@ -66,7 +66,12 @@ def npy(t):
     return np.asarray(t, dtype=np.float64)
 
 
+ONLY = [t for t in os.environ.get("FFGP_GOLDEN_ONLY", "").split(",") if t]   # regenerate just these fixtures
+
+
 def save(name, **arrays):
+    if ONLY and name not in ONLY:
+        return
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **{k: npy(v) for k, v in arrays.items()})
     print("wrote", path, {k: np.shape(v) for k, v in arrays.items()})
@@ -685,6 +690,27 @@ def main():
             mu, cc = rpack.conditional_Gaussian(Ya, cov0, Ks, Kss, Kinv_method=meth)
             alt.update({f"{tag}_{meth}_mu": mu, f"{tag}_{meth}_ccov": cc})
     save("kinv_methods", **alt)
+
+    # the two torch_distribution_MN* branches (:85-88; gp_basic.py:147-151): MultivariateNormal(loc=y, ...) reads y's LAST
+    # axis as the event axis, so they only run when d == N, and log_prob(y) at loc = y is the normalising constant N times
+    g8 = torch.Generator().manual_seed(3141)
+    n = 12
+    Xm, Ym = make_xy(g8, n, 2, n)
+    km = rk.ARDKernel(2)
+    covm = (km(Xm, Xm) + 0.2 * torch.eye(n)).detach()
+    mn = {"X": Xm, "Y": Ym, "cov": covm}
+    for meth in ("torch_distribution_MN1", "torch_distribution_MN2"):
+        cv = covm.clone().requires_grad_(True)
+        ll = rpack.Gaussian_log_likelihood(Ym, cv, Kinv_method=meth)
+        R = torch.randn(ll.shape, generator=g8)
+        (ll * R).sum().backward()
+        mn.update({f"{meth}_ll": ll, f"{meth}_R": R, f"{meth}_gcov": cv.grad})
+        gb = RGPB(rk.ARDKernel(2), noise_variance=0.5)
+        llb = gb.log_likelihood(Xm, Ym, Kinv_method=meth)
+        llb.sum().backward()
+        mn.update({f"{meth}_basic_ll": llb, f"{meth}_basic_g_noise": gb.noise_variance.grad,
+                   f"{meth}_basic_g_ls": gb.kernel.length_scales.grad, f"{meth}_basic_g_sv": gb.kernel.signal_variance.grad})
+    save("kinv_mn", **mn)
 
     # ------------------------------------------------------------------ AR and NAR chains (the remaining 2024 trainers on cigp)
     from FidelityFusion_Models.AR_autoRegression import AR as RAR, train_AR

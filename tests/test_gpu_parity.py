@@ -549,10 +549,32 @@ def test_kinv_methods_golden(golden, tag):
         mu, cc = gp_pack.conditional_Gaussian(T(g[f"{tag}_Y"]), T(g[f"{tag}_cov"]), T(g[f"{tag}_Ks"]), T(g[f"{tag}_Kss"]),
                                               Kinv_method=meth)
         assert rel(mu, g[f"{tag}_{meth}_mu"]) < 1e-9 and rel(cc, g[f"{tag}_{meth}_ccov"]) < 1e-9
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):   # y's last axis is the event axis of MultivariateNormal: d must equal N
         gp_pack.Gaussian_log_likelihood(T(g[f"{tag}_Y"]), T(g[f"{tag}_cov"]), Kinv_method="torch_distribution_MN1")
     with pytest.raises(ValueError):
         gp_pack.Gaussian_log_likelihood(T(g[f"{tag}_Y"]), T(g[f"{tag}_cov"]), Kinv_method="nope")
+
+
+@pytest.mark.parametrize("meth", ["torch_distribution_MN1", "torch_distribution_MN2"])
+def test_kinv_mn_golden(golden, meth):
+    """the torch_distribution_MN* branches (gp_computation_pack.py:85-88; gp_basic.py:147-151), which run when d == N"""
+    import fidelityfusion_amd.gp_computation_pack as gp_pack
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.gp_basic import GP_basic
+    g = golden("kinv_mn")
+    cov = T(g["cov"], grad=True)
+    ll = gp_pack.Gaussian_log_likelihood(T(g["Y"]), cov, Kinv_method=meth)
+    assert tuple(ll.shape) == g[f"{meth}_ll"].shape and rel(ll, g[f"{meth}_ll"]) < 1e-12
+    (ll * T(g[f"{meth}_R"])).sum().backward()
+    gc = g[f"{meth}_gcov"]
+    assert rel(cov.grad, 0.5 * (gc + gc.T)) < 1e-9
+    gb = GP_basic(kernel.ARDKernel(2), noise_variance=0.5).double()
+    llb = gb.log_likelihood(T(g["X"]), T(g["Y"]), Kinv_method=meth)
+    assert tuple(llb.shape) == g[f"{meth}_basic_ll"].shape and rel(llb, g[f"{meth}_basic_ll"]) < 1e-12
+    llb.sum().backward()
+    assert rel(gb.noise_variance.grad, g[f"{meth}_basic_g_noise"]) < 1e-9
+    assert rel(gb.kernel.length_scales.grad, g[f"{meth}_basic_g_ls"]) < 1e-8
+    assert rel(gb.kernel.signal_variance.grad, g[f"{meth}_basic_g_sv"]) < 1e-9
 
 
 @pytest.mark.parametrize("which", ["ar", "nar"])

@@ -104,6 +104,21 @@ def test_v2_and_conditional(golden, tag):
     close(cov, g["cond_cov"], 1e-9)
 
 
+def test_kinv_alternatives(golden):
+    """row L3: the alternative Kinv_methods, incl. the two torch_distribution_MN* branches (d == N only)"""
+    g = golden("kinv_methods")
+    for tag in ("d1", "d3"):
+        for meth in ("cholesky1", "cholesky2", "direct"):
+            close(O.ll_alt(g[f"{tag}_Y"], g[f"{tag}_cov"], meth), g[f"{tag}_{meth}_ll"], 1e-10)
+    g = golden("kinv_mn")
+    for meth in ("torch_distribution_MN1", "torch_distribution_MN2"):
+        ll = O.ll_alt(g["Y"], g["cov"], meth)
+        assert ll.shape == g[f"{meth}_ll"].shape
+        close(ll, g[f"{meth}_ll"], 1e-12)
+        # d(sum_i R_i ll_i)/dcov = -1/2 sum(R) cov^-1
+        close(-0.5 * g[f"{meth}_R"].sum() * np.linalg.inv(g["cov"]), 0.5 * (g[f"{meth}_gcov"] + g[f"{meth}_gcov"].T), 1e-9)
+
+
 @pytest.mark.parametrize("tag", ["d1", "d6"])
 def test_gp_basic(golden, tag):
     g = golden("gp_basic_" + tag)
