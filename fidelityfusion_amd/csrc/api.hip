@@ -128,6 +128,7 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->tile32_threshold = 1024;
   h->polite_m = 6144;
   h->split_rem_max = 180;
+  h->band_log2 = 3;
   h->la_split = 1;
   h->aux_prio = 1;
   h->nb_outer = 512;
@@ -200,6 +201,9 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->polite_m = (int)value;
   } else if (!strcmp(key, "split_rem_max")) {
     h->split_rem_max = (int)value;
+  } else if (!strcmp(key, "band_log2")) {
+    if (value < 0 || value > 6) return FFGP_ERR_ARG;
+    h->band_log2 = (int)value;
 
   } else {
     return FFGP_ERR_ARG;

@@ -80,6 +80,7 @@ struct GemmArgs {
   int total_tiles;
   int grid;            // gridDim.x (= total_tiles, or split_at + 4 * (tiles handed out as quarters))
   int split_at;        // 128-tile launches: blocks >= split_at process 64 x 64 quarters of the tiles [split_at, all) (INT_MAX = none)
+  int band_log2;       // tile order: bands of 2^band_log2 tile rows, column-major inside a band
   int pad_lds;         // bytes of unused dynamic LDS requested at launch (occupancy control)
   int fast;            // alpha = +-1, beta in {0,1}, offsets fit 32 bits: interior tiles take the scalar-addressed form
   int avec, bvec;      // 16-byte vector loads allowed for A / B
@@ -104,6 +105,7 @@ struct ffgp_handle {
   int la_split;         // 1 = issue the look-ahead part of the trailing update in two launches (first 128 columns first)
   int lookahead;        // 1 = overlap panel k+1 with the trailing update of step k
   int diag_attr_set;    // dynamic-LDS attribute of potrf_diag128 set on this handle's device
+  int band_log2;        // GEMM tile order: band height 2^band_log2 tile rows (default 3)
   int split_rem_max;    // split tail of the 128-tile launches: quarter the last (tiles mod 256) tiles when that is <= this (0 = off)
   int polite_m;         // trailing updates with fewer rows than this run one workgroup per CU (0 = never)
   bool own_stream;

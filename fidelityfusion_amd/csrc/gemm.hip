@@ -136,8 +136,8 @@ __device__ __forceinline__ void frag_offsets(int lane, int wbase, int (&off)[4])
 // Tile order -> (ti, tj).  Everything here is wave-uniform; it is written without integer divisions on the common
 // path (full 8-row bands) so it stays on the scalar unit: a workgroup's prologue shares its SIMDs with the MFMA
 // stream of the other resident workgroup, and every vector instruction it needs waits behind a 64-cycle MFMA.
-__device__ __forceinline__ void decode_tile(int t, int mode, int tiles_m, int tiles_n, int& ti, int& tj) {
-  const int G = 8;
+__device__ __forceinline__ void decode_tile(int t, int mode, int tiles_m, int tiles_n, int& ti, int& tj, const int GL = 3) {
+  const int G = 1 << GL;
   if (mode == TILES_FULL) {
     const int band_sz = G * tiles_n;
     int r0 = 0;
@@ -147,8 +147,8 @@ __device__ __forceinline__ void decode_tile(int t, int mode, int tiles_m, int ti
     }
     const int hgt = min(G, tiles_m - r0);
     if (hgt == G) {
-      tj = t >> 3;
-      ti = r0 + (t & 7);
+      tj = t >> GL;
+      ti = r0 + (t & (G - 1));
     } else {
       tj = t / hgt;
       ti = r0 + t % hgt;
@@ -167,8 +167,8 @@ __device__ __forceinline__ void decode_tile(int t, int mode, int tiles_m, int ti
     }
     if (t < hgt * fc) {
       if (hgt == G) {
-        tj = t >> 3;
-        ti = r0 + (t & 7);
+        tj = t >> GL;
+        ti = r0 + (t & (G - 1));
       } else {
         tj = t / hgt;
         ti = r0 + t % hgt;
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
     if (bid >= p.split_at) {
       const int q = bid - p.split_at;
       int Ti, Tj;
-      decode_tile(p.split_at + (q >> 2), MODE, p.tiles_m, p.tiles_n, Ti, Tj);
+      decode_tile(p.split_at + (q >> 2), MODE, p.tiles_m, p.tiles_n, Ti, Tj, p.band_log2);
       const int ti = __builtin_amdgcn_readfirstlane(2 * Ti + ((q >> 1) & 1));
       const int tj = __builtin_amdgcn_readfirstlane(2 * Tj + (q & 1));
       if (ti * 64 >= p.m || tj * 64 >= p.n || (MODE == TILES_LOWER && tj > ti)) return;
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   int ti, tj;
-  decode_tile(t, MODE, p.tiles_m, p.tiles_n, ti, tj);
+  decode_tile(t, MODE, p.tiles_m, p.tiles_n, ti, tj, p.band_log2);
   // wave-uniform by construction; pin them to SGPRs so every tile base below is scalar arithmetic
   ti = __builtin_amdgcn_readfirstlane(ti);
   tj = __builtin_amdgcn_readfirstlane(tj);
@@ -646,6 +646,7 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
                ? 1 : 0;
   a.grid = a.total_tiles;
   a.split_at = 0x7fffffff;
+  a.band_log2 = h->band_log2;
   // Split tail (see ffgp_gemm_f64): with T equal tiles on 256 CUs the last (T mod 256) tiles run on otherwise idle CUs for a
   // whole tile time; when that remainder is small, hand it out as 64 x 64 quarters -- 4x the workgroups, a quarter of the
   // chain each -- which start under the last full round.  (An in-place or batched launch never splits.)
