@@ -201,6 +201,12 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->polite_m = (int)value;
   } else if (!strcmp(key, "split_rem_max")) {
     h->split_rem_max = (int)value;
+  } else if (!strcmp(key, "nb_big")) {
+    const int v = (int)value;
+    if (v != 0 && (v < FFGP_NB || v % FFGP_NB)) return FFGP_ERR_ARG;
+    h->nb_big = v;
+  } else if (!strcmp(key, "nb_big_until")) {
+    h->nb_big_until = (int)value;
   } else if (!strcmp(key, "band_log2")) {
     if (value < 0 || value > 6) return FFGP_ERR_ARG;
     h->band_log2 = (int)value;

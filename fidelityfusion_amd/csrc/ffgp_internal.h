@@ -134,6 +134,7 @@ struct ffgp_handle {
   int syrk_pool_used;
   // tuning knobs
   int nb_outer;      // outer (trailing-update) block size, multiple of FFGP_NB
+  int nb_big, nb_big_until;  // wider outer block while more than nb_big_until columns remain (0 = off)
   int use_naive;     // debug: route potrf through the naive kernels
 };
 

@@ -585,9 +585,12 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
     if (mtot > n) hipLaunchKernelGGL(ffgp_trsm_rows_naive, dim3(mtot - n), dim3(64), 0, h->stream, A, lda, n);
   } else {
     const int NB1 = h->nb_outer;
+    // panel width at column k0: the wide block while more than nb_big_until columns remain (the SYRK's fixed per-tile
+    // cost is amortised over a longer k loop where the chain still hides under it), nb_outer after that
+    auto pw = [&](int k0) { return (h->nb_big > NB1 && n - k0 > h->nb_big_until) ? h->nb_big : NB1; };
     if (!h->lookahead || n <= NB1) {
-      for (int k0 = 0; k0 < n; k0 += NB1) {
-        const int w1 = min(NB1, n - k0);
+      for (int k0 = 0; k0 < n; k0 += pw(k0)) {
+        const int w1 = min(pw(k0), n - k0);
         const int pend = k0 + w1;  // end column of this outer panel
         FFGP_CHECK(factor_panel(h, A, n, mtot, lda, k0, w1));
         const int mt = n - pend;  // trailing columns; trailing rows include the passenger rows
@@ -608,17 +611,17 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
       // long before (S_ii(k-1), S_b(k)).  Panel k+1 touches only its own columns; S_ii reads panel k and writes the
       // columns to the right of panel k+1, so the two streams never alias.
       hipStream_t main_s = h->stream;
-      FFGP_CHECK(factor_panel(h, A, n, mtot, lda, 0, min(NB1, n)));
+      FFGP_CHECK(factor_panel(h, A, n, mtot, lda, 0, min(pw(0), n)));
       FFGP_HIP(hipEventRecord(h->la_ev[6], main_s));
       FFGP_HIP(hipStreamWaitEvent(h->aux, h->la_ev[6], 0));
       int it = 0;
       hipEvent_t eb_prev = nullptr, ei_prev = nullptr;
-      for (int k0 = 0; k0 < n; k0 += NB1, ++it) {
-        const int w1 = min(NB1, n - k0);
+      for (int k0 = 0; k0 < n; k0 += pw(k0), ++it) {
+        const int w1 = min(pw(k0), n - k0);
         const int pend = k0 + w1;
         const int mt = n - pend;
         if (mt <= 0) break;
-        const int wn = min(NB1, mt);  // width of the next panel
+        const int wn = min(pw(pend), mt);  // width of the next panel
         double* P = A + (size_t)pend * lda + k0;
         double* C = A + (size_t)pend * lda + pend;
         hipEvent_t eb = h->la_ev[(it & 1) * 3], eg = h->la_ev[(it & 1) * 3 + 1], ei = h->la_ev[(it & 1) * 3 + 2];

@@ -126,6 +126,8 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
                         stream's kernels always find free registers and LDS),
             "split_rem_max" (default 180: a 128-tile launch whose tile count leaves a remainder <= this modulo the 256 CUs
                         hands those last tiles out as 64 x 64 quarters -- same bits, a shorter last round; 0 = never),
+            "nb_big" / "nb_big_until" (default 0: a wider outer block while more than nb_big_until columns remain; measured
+                        neutral at N = 16384 -- tools/ab_forward.py),
             "band_log2" (default 3: the GEMM tile order walks bands of 2^k tile rows, column-major inside a band),
             "diag_dbg" (timing-only ablation mask of the diagonal-block kernel; results are wrong when non-zero)       */
 int ffgp_set_option(ffgp_handle* h, const char* key, double value);
