@@ -16,7 +16,7 @@ SO = os.path.join(ROOT, "fidelityfusion_amd", "libffgp_trace.so")
 
 
 def build():
-    srcs = ["gemm.hip", "potrf.hip", "assemble.hip", "solve.hip", "grad.hip", "api.hip"]
+    srcs = ["gemm.hip", "potrf.hip", "assemble.hip", "solve.hip", "grad.hip", "join.hip", "eig.hip", "api.hip"]
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DFFGP_GEMM_TRACE", "-shared",
            "-Wno-unused-value", "-Wno-unused-result", "-I" + os.path.join(ROOT, "include"), "-o", SO] + [os.path.join(CSRC, f) for f in srcs]
     subprocess.check_call(cmd)
