@@ -41,29 +41,45 @@ class cigp(nn.Module):
         state["_post"] = None
         return state
 
-    def forward(self, x_train, y_train, x_test):
-        y_train, _ = _split(y_train)
-        # the fused posterior is a no_grad path (every prediction call of the reference's models sits under
-        # torch.no_grad()); with autograd on -- acquisition functions differentiating mean / variance w.r.t. x_test,
-        # Bayesian_optimization/acq.py -- the same quantities are composed from differentiable pieces
-        if not hasattr(self.kernel, "effective") or torch.is_grad_enabled():
-            return self._forward_composed(x_train, y_train, x_test)
-        # The reference refactorises Sigma on every call (:31-35).  Here the factor is kept while the SAME tensor
-        # objects (x_train, y_train, every parameter) are passed with unchanged in-place version counters -- repeated
-        # queries of a trained model (acquisition loops, serving) then cost one TRSM sweep instead of N^3/3.
-        noise = self.log_beta.exp().pow(-1)
+    def _cached_posterior(self, x_train, y_train, first_query=None, var_add_all=0.0):
+        """(F.Posterior, fresh): the factor of (x_train, y_train, parameters), kept while the SAME tensor objects are
+        passed with unchanged in-place version counters (in-place updates bump the version; `p.data = ...` moves the
+        pointer).  The reference refactorises Sigma on every call (:31-35); repeated queries of a trained model
+        (acquisition loops, serving) cost one TRSM sweep here instead of N^3/3."""
         objs = [x_train, y_train] + list(self.parameters())
-        vers = tuple((t._version, t.data_ptr()) for t in objs)   # in-place updates bump the version; `p.data = ...` moves the pointer
+        vers = tuple((t._version, t.data_ptr()) for t in objs)
         c = self._post
         if c is not None and len(c[0]) == len(objs) and all(r() is t for r, t in zip(c[0], objs)) and c[1] == vers:
-            mean, var = c[2].predict(x_test, full_cov=True, var_add_all=float(noise))
-        else:   # first query: K_s^T rides in the factorisation (the cost of the fused one-shot posterior), factor kept
+            return c[2], False
+        with torch.no_grad():
             w, amp, clamp = self.kernel.effective()
+            noise = self.log_beta.exp().pow(-1)
             post = F.Posterior(x_train, y_train, w, amp, noise + JITTER, clamp=clamp, kfun=_kfun(self.kernel),
-                               first_query=x_test, var_add_all=float(noise))
-            self._post = ([weakref.ref(t) for t in objs], vers, post)
-            mean, var = post.first
+                               first_query=first_query, var_add_all=var_add_all)
+        self._post = ([weakref.ref(t) for t in objs], vers, post)
+        return post, True
+
+    def forward(self, x_train, y_train, x_test):
+        y_train, _ = _split(y_train)
         odt = y_train.dtype if y_train.dtype.is_floating_point else torch.float64
+        fused = hasattr(self.kernel, "effective")
+        if fused and torch.is_grad_enabled() and not (x_train.requires_grad or y_train.requires_grad
+                                                      or any(p.requires_grad for p in self.parameters())):
+            # autograd on, model frozen (`model.requires_grad_(False)`): only the query points can want gradients -- the
+            # acquisition optimisers of Bayesian_optimization/acq.py:50-62 -- so the factor is cached and the query is
+            # differentiated on it
+            post, _ = self._cached_posterior(x_train, y_train)
+            mean, var = post.predict_diff(x_test, full_cov=True, var_add_all=float(self.log_beta.exp().pow(-1)))
+            return mean.to(device=y_train.device, dtype=odt), var.to(device=y_train.device, dtype=odt)
+        # the fused posterior is a no_grad path (every prediction call of the reference's models sits under
+        # torch.no_grad()); with autograd on and a trainable model the same quantities are composed from differentiable
+        # pieces, gradients flowing to x_test, the parameters and y_train as in the reference
+        if not fused or torch.is_grad_enabled():
+            return self._forward_composed(x_train, y_train, x_test)
+        noise = float(self.log_beta.exp().pow(-1))
+        # first query: K_s^T rides in the factorisation (the cost of the fused one-shot posterior), factor kept
+        post, fresh = self._cached_posterior(x_train, y_train, first_query=x_test, var_add_all=noise)
+        mean, var = post.first if fresh else post.predict(x_test, full_cov=True, var_add_all=noise)
         return mean.to(device=y_train.device, dtype=odt), var.to(device=y_train.device, dtype=odt)
 
     # composed kernels (SumKernel(LinearKernel, MaternKernel) of the reference's own demos, cigp_v10.py:81,111,147):

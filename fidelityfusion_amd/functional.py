@@ -543,6 +543,52 @@ def matmul_nt(A, B, alpha=1.0):
     return _MatmulNT.apply(A, B, alpha)
 
 
+class _PosteriorQuery(torch.autograd.Function):
+    """mean = K_s^T alpha, var = K_ss - V^T V (V = L^-1 K_s) on a CACHED factor, differentiable w.r.t. K_s and K_ss only
+    (the factor, alpha and the hyper-parameters are constants of a `Posterior`): what an acquisition optimiser needs to
+    move its query points (Bayesian_optimization/acq.py:50-62) -- one TRSM sweep forward, one backward, no
+    refactorisation.   dK_s = alpha Gm^T - Sigma^-1 K_s (Gv + Gv^T)   [diag mode: - 2 Sigma^-1 K_s diag(gv)],  dK_ss = Gv."""
+
+    @staticmethod
+    def forward(ctx, post, Ks, Kss, full_cov):
+        dev, n = post.dev, post.n
+        nt = Ks.shape[1]
+        if post.alpha is None:
+            post._solve_alpha()
+        Ksd = _dev(Ks, dev)
+        mean = _gemm(dev, 1, 1, Ksd, post.alpha, nt, post.d, n, 1.0)
+        V = Ksd.clone()
+        check(lib.ffgp_trsm_lower(post._h(), _ptr(post.W), n, post.ld, _ptr(V), nt, nt), "ffgp_trsm_lower")
+        if full_cov:
+            var = _dev(Kss, dev) - _gemm(dev, 1, 1, V, V, nt, nt, n, 1.0)
+        else:
+            var = _dev(Kss, dev) - (V * V).sum(0)
+        ctx.pack = (post, V, n, full_cov, post.alpha)
+        return mean, var
+
+    @staticmethod
+    def backward(ctx, Gm, Gv):
+        post, V, n, full_cov, alpha = ctx.pack
+        if post.n != n:
+            raise RuntimeError("Posterior.append() was called between a differentiable query and its backward()")
+        dev = post.dev
+        nt = V.shape[1]
+        dKs = torch.zeros_like(V)
+        if Gm is not None:
+            dKs = _gemm(dev, 0, 0, alpha, _dev(Gm, dev), n, nt, post.d, 1.0)          # alpha Gm^T
+        dKss = None
+        if Gv is not None:
+            B = V.clone()
+            check(lib.ffgp_trsm_lower_t(post._h(), _ptr(post.W), n, post.ld, _ptr(B), nt, nt), "ffgp_trsm_lower_t")   # Sigma^-1 K_s
+            g = _dev(Gv, dev)
+            if full_cov:
+                dKs = dKs - _gemm(dev, 0, 0, B, (g + g.T).contiguous(), n, nt, nt, 1.0)
+            else:
+                dKs = dKs - 2.0 * B * g.unsqueeze(0)
+            dKss = g
+        return None, dKs, dKss, None
+
+
 class Posterior:
     """A factored GP block kept on the device: factor once, query many times, append points without refactorising
     (the reference's `cigp.forward` re-runs `torch.linalg.cholesky` on every call,
@@ -633,6 +679,20 @@ class Posterior:
         else:
             var = float(self.amp) - (Ks * Ks).sum(0) + var_add_all      # phi(0) = 1 for every radial profile
         return mean, var
+
+    def predict_diff(self, Xs, full_cov=True, var_add_all=0.0):
+        """`predict` with autograd w.r.t. the query points: K_s and K_ss come from the differentiable kernel call, the
+        solves run on the cached factor (`_PosteriorQuery`).  The hyper-parameters, X and Y are constants here -- use
+        the model's own forward under autograd when their gradients are wanted as well."""
+        dev, n = self.dev, self.n
+        Xsd = Xs.to(device=dev, dtype=torch.float64)
+        Ks = kernel_matrix(self.X[:n], Xsd, self.w, self.amp, self.clamp, kfun=self.kfun)
+        if full_cov:
+            Kss = kernel_matrix(Xsd, Xsd, self.w, self.amp, self.clamp, kfun=self.kfun)
+        else:
+            Kss = self.amp.expand(Xsd.shape[0])                  # phi(0) = 1 for every radial profile
+        mean, var = _PosteriorQuery.apply(self, Ks, Kss, full_cov)
+        return mean, var + var_add_all
 
     @torch.no_grad()
     def append(self, X_new, Y_new):

@@ -30,7 +30,7 @@ def T(a, grad=False):
 
 def rel(a, b):
     a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, dtype=np.float64)
     return float(np.abs(a.reshape(b.shape) - b).max() / max(np.abs(b).max(), 1e-300))
 
 
@@ -361,6 +361,53 @@ def test_cigp_forward_grads_golden(golden, where):
     with torch.no_grad():   # the fused no_grad posterior gives the same numbers
         mean2, var2 = m(tt(g["X"]), Y.detach(), xs.detach())
     assert rel(mean2, g["mean"]) < 1e-9 and rel(var2, g["var"]) < 1e-9
+
+
+@pytest.mark.parametrize("where", ["cuda", "cpu"])
+def test_cigp_forward_frozen_model_query_gradients_golden(golden, where):
+    """a frozen model (`requires_grad_(False)`) queried with autograd on -- the acquisition optimisers' loop,
+    Bayesian_optimization/acq.py:50-62 -- differentiates the query on the CACHED factor: same mean / var / d/dx_test as the
+    reference, on the first call (factorises) and on later ones (one TRSM sweep each way), also after the query moved"""
+    from fidelityfusion_amd import functional as F
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp
+    g = golden("cigp_forward_grads")
+    m = cigp(kernel.ARDKernel(3), 0.0)
+    _load_params(m, g)
+    dev = DEV if where == "cuda" else "cpu"
+    m = m.to(dev).requires_grad_(False)
+    tt = lambda a, gr=False: torch.tensor(np.asarray(a), dtype=torch.float64, device=dev, requires_grad=gr)
+    X, Y = tt(g["X"]), tt(g["Y"])
+    for rep in range(3):
+        xs = tt(g["xs"], True)
+        mean, var = m(X, Y, xs)
+        assert mean.requires_grad and rel(mean, g["mean"]) < 1e-9 and rel(var, g["var"]) < 1e-9
+        ((mean * tt(g["R1"])).sum() + (var * tt(g["R2"])).sum()).backward()
+        assert xs.grad.device.type == where and rel(xs.grad, g["g_xs"]) < 1e-8, rep
+        post = m._post[2]
+        if rep == 0:
+            first = post
+        assert post is first, "the factor must be reused"
+    # a moved query: against the differentiable composition of a trainable copy
+    xs2 = (tt(g["xs"]) * 0.9 + 0.05).requires_grad_(True)
+    mean, var = m(X, Y, xs2)
+    (mean.sum() + (var * var).sum()).backward()
+    m2 = cigp(kernel.ARDKernel(3), 0.0)
+    _load_params(m2, g)
+    m2 = m2.to(dev)
+    xs3 = xs2.detach().clone().requires_grad_(True)
+    mean3, var3 = m2(X, Y, xs3)
+    (mean3.sum() + (var3 * var3).sum()).backward()
+    assert rel(mean, mean3) < 1e-10 and rel(var, var3) < 1e-9 and rel(xs2.grad, xs3.grad) < 1e-8
+    # diagonal mode of the cached query = the diagonal of the full one
+    xs4 = xs2.detach().clone().requires_grad_(True)
+    mu_d, v_d = first.predict_diff(xs4, full_cov=False, var_add_all=0.25)
+    assert rel(v_d, var.diagonal().detach().to(v_d.device) - float(m.log_beta.exp().pow(-1)) + 0.25) < 1e-9
+    (v_d * torch.arange(1, len(v_d) + 1, device=v_d.device)).sum().backward()
+    xs5 = xs2.detach().clone().requires_grad_(True)
+    _, v_f = first.predict_diff(xs5, full_cov=True, var_add_all=0.25)
+    (v_f.diagonal() * torch.arange(1, len(v_d) + 1, device=v_f.device)).sum().backward()
+    assert rel(xs4.grad, xs5.grad) < 1e-8
 
 
 def test_bo_cigp_withmean_golden(golden):

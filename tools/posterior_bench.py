@@ -22,3 +22,29 @@ for n in (8192, 16384):
         post.append(Xn[:8], Yn[:8]); torch.cuda.synchronize()
         t3 = time.perf_counter(); post.append(Xn[8:], Yn[8:]); torch.cuda.synchronize(); t4 = time.perf_counter()
     print("N=%d: first query (factor) %.1f ms, repeated query (nt=256) %.2f ms, append 56 points %.2f ms" % (n, (t1 - t0) * 1e3, min(ts) * 1e3, (t4 - t3) * 1e3))
+
+# acquisition-optimiser step (Bayesian_optimization/acq.py:50-62): UCB of the posterior at 64 moving query points,
+# backward to the points -- trainable model (differentiable composition, refactorises) vs frozen model (cached factor)
+for n in (2048, 16384):
+    g = torch.Generator(device=dev).manual_seed(1)
+    X = torch.rand((n, 16), generator=g, device=dev); Y = torch.randn((n, 1), generator=g, device=dev)
+    out = []
+    for frozen in (False, True):
+        m = cigp(kernel.ARDKernel(16), 1.0).to(dev).requires_grad_(not frozen)
+        xq = torch.rand((64, 16), generator=g, device=dev).requires_grad_(True)
+        opt = torch.optim.Adam([xq], lr=0.05)
+
+        def step():
+            opt.zero_grad()
+            mean, var = m(X, Y, xq)
+            (-(mean.squeeze() + 2.0 * var.diagonal().clamp_min(1e-12).sqrt()).sum()).backward()
+            opt.step()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        out.append((time.perf_counter() - t0) / 5 * 1e3)
+    print("N=%d acquisition step (64 query points, UCB, Adam): trainable model %.2f ms, frozen model on the cached factor %.2f ms" % (n, out[0], out[1]))
