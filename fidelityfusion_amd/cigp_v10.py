@@ -7,8 +7,6 @@ Same constructor, parameter (`log_beta[1]`), call signatures, return shapes and 
   * `y_train` may be `[y, y_var]` with y_var an N x N matrix of which only the diagonal enters Sigma (:59-60);
   * `forward` ignores y_var and adds the noise scalar to EVERY entry of the predictive covariance (:31-32,44).
 """
-import weakref
-
 import torch
 import torch.nn as nn
 
@@ -34,30 +32,24 @@ class cigp(nn.Module):
         super().__init__()
         self.kernel = kernel
         self.log_beta = nn.Parameter(torch.tensor([log_beta]))
-        self._post = None   # (weakrefs, versions, F.Posterior): the factor of the last (x_train, y_train, parameters)
+        self._pcache = F.PosteriorCache()   # the factor of the last (x_train, y_train, parameters)
 
-    def __getstate__(self):   # the cached factor (weak references, device buffers) is not part of the model's state
-        state = self.__dict__.copy()
-        state["_post"] = None
-        return state
+    @property
+    def _post(self):   # (kept for tools/tests) the cached F.Posterior, if any
+        return self._pcache.posterior
 
     def _cached_posterior(self, x_train, y_train, first_query=None, var_add_all=0.0):
         """(F.Posterior, fresh): the factor of (x_train, y_train, parameters), kept while the SAME tensor objects are
         passed with unchanged in-place version counters (in-place updates bump the version; `p.data = ...` moves the
         pointer).  The reference refactorises Sigma on every call (:31-35); repeated queries of a trained model
         (acquisition loops, serving) cost one TRSM sweep here instead of N^3/3."""
-        objs = [x_train, y_train] + list(self.parameters())
-        vers = tuple((t._version, t.data_ptr()) for t in objs)
-        c = self._post
-        if c is not None and len(c[0]) == len(objs) and all(r() is t for r, t in zip(c[0], objs)) and c[1] == vers:
-            return c[2], False
-        with torch.no_grad():
-            w, amp, clamp = self.kernel.effective()
-            noise = self.log_beta.exp().pow(-1)
-            post = F.Posterior(x_train, y_train, w, amp, noise + JITTER, clamp=clamp, kfun=_kfun(self.kernel),
-                               first_query=first_query, var_add_all=var_add_all)
-        self._post = ([weakref.ref(t) for t in objs], vers, post)
-        return post, True
+        def build():
+            with torch.no_grad():
+                w, amp, clamp = self.kernel.effective()
+                noise = self.log_beta.exp().pow(-1)
+                return F.Posterior(x_train, y_train, w, amp, noise + JITTER, clamp=clamp, kfun=_kfun(self.kernel),
+                                   first_query=first_query, var_add_all=var_add_all)
+        return self._pcache.get([x_train, y_train] + list(self.parameters()), build)
 
     def forward(self, x_train, y_train, x_test):
         y_train, _ = _split(y_train)

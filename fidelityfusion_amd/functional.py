@@ -7,6 +7,7 @@ whatever the input dtype.
 """
 import ctypes as C
 import math
+import weakref
 
 import torch
 
@@ -732,6 +733,35 @@ class Posterior:
         self.n = n + k
         self.alpha = None
 
+
+
+class PosteriorCache:
+    """Keeps the `Posterior` of a model while the SAME tensor objects (training inputs, targets, every parameter) come
+    back with unchanged in-place version counters: in-place updates bump `_version`, `p.data = ...` moves the pointer,
+    and weak references make sure a recycled address can never alias.  Not part of a model's state (pickles empty)."""
+
+    def __init__(self):
+        self._c = None
+
+    def __getstate__(self):
+        return {"_c": None}
+
+    def get(self, objs, build):
+        """(posterior, fresh): the cached one if `objs` are unchanged, else `build()` (which is then cached)"""
+        vers = tuple((t._version, t.data_ptr()) for t in objs)
+        c = self._c
+        if c is not None and len(c[0]) == len(objs) and all(r() is t for r, t in zip(c[0], objs)) and c[1] == vers:
+            return c[2], False
+        post = build()
+        self._c = ([weakref.ref(t) for t in objs], vers, post)
+        return post, True
+
+    @property
+    def posterior(self):
+        return self._c[2] if self._c is not None else None
+
+    def clear(self):
+        self._c = None
 
 
 @torch.no_grad()

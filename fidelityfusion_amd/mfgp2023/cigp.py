@@ -100,6 +100,7 @@ class CIGP(torch.nn.Module):
         self.kernel = create_kernel(self.gp_model_config["kernel"])
         self.train_x = None
         self.train_y = None
+        self._pcache = F.PosteriorCache()   # the factor of (train_x, train_y, parameters) between predictions
 
     def forward(self, x, x_var=0.0):
         x = _single(x)
@@ -107,11 +108,19 @@ class CIGP(torch.nn.Module):
             print("gp model model hasn't been trained. predict failed")
             return None
         with torch.no_grad():
-            w, amp, clamp = self.kernel.effective()
             inv_noise = self.noise_box.get().pow(-1).double()  # fp32 parameter arithmetic, then promoted (cigp.py:81)
-            u, vd = F.predict(_flat(self.train_x), self.train_y, _flat(x), w, amp, diag_add=inv_noise + JITTER,
-                              clamp=clamp, full_cov=False, var_add_all=float(inv_noise))
-            var_diag = vd.reshape(-1, 1).expand_as(u) + x_var
+            xq = _flat(x)
+
+            def build():   # first query rides in the factorisation; the factor stays for the next prediction
+                w, amp, clamp = self.kernel.effective()
+                return F.Posterior(_flat(self.train_x), self.train_y, w, amp, inv_noise + JITTER, clamp=clamp, first_query=xq)
+            post, fresh = self._pcache.get([self.train_x, self.train_y] + list(self.parameters()), build)
+            if fresh:
+                u, vd = post.first[0], post.first[1].diagonal() + float(inv_noise)
+            else:
+                u, vd = post.predict(xq, full_cov=False, var_add_all=float(inv_noise))
+            u = u.to(device=self.train_y.device, dtype=self.train_y.dtype if self.train_y.dtype.is_floating_point else torch.float64)
+            var_diag = vd.to(device=u.device, dtype=u.dtype).reshape(-1, 1).expand_as(u) + x_var
         return u, var_diag
 
     def compute_loss(self, x, y, x_var=0.0, y_var=0.0, update_data=False):

@@ -384,7 +384,7 @@ def test_cigp_forward_frozen_model_query_gradients_golden(golden, where):
         assert mean.requires_grad and rel(mean, g["mean"]) < 1e-9 and rel(var, g["var"]) < 1e-9
         ((mean * tt(g["R1"])).sum() + (var * tt(g["R2"])).sum()).backward()
         assert xs.grad.device.type == where and rel(xs.grad, g["g_xs"]) < 1e-8, rep
-        post = m._post[2]
+        post = m._post
         if rep == 0:
             first = post
         assert post is first, "the factor must be reused"
@@ -475,23 +475,23 @@ def test_posterior_reuse_and_append():
     xt, yt = T(X), T(Y)
     with torch.no_grad():
         a1, b1 = m(xt, yt, T(Xs))
-        p1 = m._post[2]
+        p1 = m._post
         a2, b2 = m(xt, yt, T(Xs[:5]))
-        assert m._post[2] is p1                                   # same tensors, same versions: factor re-used
+        assert m._post is p1                                   # same tensors, same versions: factor re-used
         assert rel(a1, mean_o) < 1e-9 and rel(b1, var_o) < 1e-9 and rel(a2, mean_o[:5]) < 1e-9
         m.log_beta.add_(0.3)                                      # what optimizer.step() does: in-place update
         a3, _ = m(xt, yt, T(Xs))
-        assert m._post[2] is not p1
+        assert m._post is not p1
         assert rel(a3, O.cigp_forward(X, Y, Xs, kf, lb + 0.3)[0]) < 1e-9
-        p3 = m._post[2]
+        p3 = m._post
         yt2 = yt.clone()                                          # a different tensor object (even with equal data)
         m(xt, yt2, T(Xs))
-        assert m._post[2] is not p3
+        assert m._post is not p3
         yt2.mul_(2.0)                                             # same object, modified in place
         a5, _ = m(xt, yt2, T(Xs))
         assert rel(a5, 2.0 * O.cigp_forward(X, Y, Xs, kf, lb + 0.3)[0]) < 1e-9
     m_copy = copy.deepcopy(m)
-    assert m_copy._post is None or m_copy._post[2] is not None    # deepcopy / pickling do not choke on the cache
+    assert m_copy._post is None or m_copy._post is not None    # deepcopy / pickling do not choke on the cache
     import pickle
     assert pickle.loads(pickle.dumps(m))._post is None
 
@@ -775,6 +775,13 @@ def test_cigp2023_golden(golden, tag):
     assert u.shape == g["u"].shape and vd.shape == g["var_diag"].shape
     assert rel(u, g["u"]) < 1e-6
     assert rel(vd, g["var_diag"]) < 1e-6
+    post = m._pcache.posterior
+    u2, vd2 = m.forward(T(g["Xs"]), x_var=0.5)          # second prediction: the cached factor, one TRSM sweep
+    assert m._pcache.posterior is post and rel(u2, g["u"]) < 1e-6 and rel(vd2, g["var_diag"] + 0.5) < 1e-6
+    with torch.no_grad():
+        m.kernel.scale.mul_(1.5)                        # a parameter update invalidates it
+    m.forward(T(g["Xs"]))
+    assert m._pcache.posterior is not post
     assert CIGP().forward(T(g["Xs"])) is None          # untrained model: returns None (base_gp/cigp.py:74-76)
 
 

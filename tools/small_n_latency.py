@@ -24,7 +24,7 @@ for dev in ("cuda", "cpu"):
 
         def pred():
             with torch.no_grad():
-                m._post = None
+                m._pcache.clear()
                 m(X, Y, Xs)
 
         out = []
