@@ -31,6 +31,7 @@ class GP_basic(nn.Module):
         super().__init__()
         self.kernel = kernel
         self.noise_variance = nn.Parameter(torch.tensor([noise_variance]))
+        self._pcache = F.PosteriorCache()   # the factor of (x_train, y_train, parameters) between predictions
 
     def forward(self, x_train, y_train, x_test, Kinv_method="cholesky3"):
         _check_method(Kinv_method, (), _METHODS_FWD)   # three spellings of the same posterior (:66-88)
@@ -38,9 +39,19 @@ class GP_basic(nn.Module):
         if not hasattr(self.kernel, "effective") or torch.is_grad_enabled():   # autograd on: differentiable composition
             return self._forward_composed(x_train, y_train, y_var, x_test)
         w, amp, clamp = self.kernel.effective()
-        mu, var = F.predict(x_train, y_train, x_test, w, amp, diag_add=self.noise_variance.pow(2), add_mat=y_var,
-                            clamp=clamp, full_cov=True, var_add_all=0.0, kfun=_kfun(self.kernel))
-        return mu.squeeze(), var
+        if y_var is not None:
+            mu, var = F.predict(x_train, y_train, x_test, w, amp, diag_add=self.noise_variance.pow(2), add_mat=y_var,
+                                clamp=clamp, full_cov=True, var_add_all=0.0, kfun=_kfun(self.kernel))
+            return mu.squeeze(), var
+        # the reference refactorises on every call (:78-84); the factor is kept while the same tensors come back unchanged
+
+        def build():
+            return F.Posterior(x_train, y_train, w, amp, self.noise_variance.pow(2), clamp=clamp, kfun=_kfun(self.kernel),
+                               first_query=x_test)
+        post, fresh = self._pcache.get([x_train, y_train] + list(self.parameters()), build)
+        mu, var = post.first if fresh else post.predict(x_test, full_cov=True)
+        odt = y_train.dtype if y_train.dtype.is_floating_point else torch.float64
+        return mu.to(device=y_train.device, dtype=odt).squeeze(), var.to(device=y_train.device, dtype=odt)
 
     # composed kernels (gp_basic.py:170-173 tries Linear / Sum kernels): Sigma is built on the device from the
     # differentiable kernel call and enters the fused factorisation as ffgp_problem.cov_dev
