@@ -129,6 +129,9 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->polite_m = 6144;
   h->split_rem_max = 180;
   h->band_log2 = 3;
+  h->super_block = 1024;
+  h->splitk_min_k = 2048;
+  h->super_min_n = 2048;
   h->la_split = 1;
   h->aux_prio = 1;
   h->nb_outer = 512;
@@ -148,6 +151,9 @@ int ffgp_destroy(ffgp_handle* h) {
   if (h->aux) hipStreamSynchronize(h->aux);
   if (h->ws) hipFree(h->ws);
   if (h->dinv) hipFree(h->dinv);
+  if (h->sinv) hipFree(h->sinv);
+  if (h->tsw) hipFree(h->tsw);
+  if (h->skw) hipFree(h->skw);
   if (h->d_info) hipFree(h->d_info);
   if (h->d_scal) hipFree(h->d_scal);
   if (h->h_info) hipHostFree(h->h_info);
@@ -207,6 +213,15 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->nb_big = v;
   } else if (!strcmp(key, "nb_big_until")) {
     h->nb_big_until = (int)value;
+  } else if (!strcmp(key, "super_block")) {
+    const int v = (int)value;
+    if (v != 0 && (v < 2 * FFGP_NB || (v & (v - 1)))) return FFGP_ERR_ARG;   // 0, or a power of two >= 256
+    h->super_block = v;
+    h->sinv_L = nullptr;
+  } else if (!strcmp(key, "splitk_min_k")) {
+    h->splitk_min_k = (int)value;
+  } else if (!strcmp(key, "super_min_n")) {
+    h->super_min_n = (int)value;
   } else if (!strcmp(key, "band_log2")) {
     if (value < 0 || value > 6) return FFGP_ERR_ARG;
     h->band_log2 = (int)value;
@@ -333,6 +348,7 @@ int ffgp_potri(ffgp_handle* h, double* L, int n, int ldl) {
   FFGP_CHECK(ffgp_trtri_impl(h, L, n, ldl, X, (int)ld, T));
   FFGP_CHECK(ffgp_lauum_impl(h, X, n, (int)ld, L, ldl));
   h->dinv_L = nullptr;  // the buffer no longer holds the factor
+  h->sinv_L = nullptr;
   return FFGP_OK;
 }
 

@@ -116,6 +116,19 @@ struct ffgp_handle {
   size_t dinv_bytes;
   const double* dinv_L;  // factor the Dinv store currently belongs to (pointer, n, ld); nullptr = stale
   int dinv_n, dinv_ld;
+  // inverses of the S x S diagonal super-blocks of the factor the Dinv store belongs to (built on demand by the
+  // triangular sweeps: 8x fewer, 8x deeper steps than the 128-block sweep) + the sweep's output buffer
+  double* sinv;
+  size_t sinv_bytes;
+  const double* sinv_L;
+  int sinv_n, sinv_ld, sinv_S;
+  double* tsw;       // n x nrhs staging of the super-block sweep
+  size_t tsw_bytes;
+  double* skw;       // split-K partial products
+  size_t skw_bytes;
+  int splitk_min_k;  // thin products (<= 64 tiles of 64 x 64) with k >= this are cut along k (0 = never)
+  int super_block;   // S (multiple of 128, power-of-two multiple): 0 = sweeps always go block by block
+  int super_min_n;   // factors smaller than this keep the 128-block sweep
   int* d_info;       // device status word(s)
   double* d_scal;    // small device scalar scratch (64 doubles)
   int* h_info;       // pinned host mirror

@@ -560,6 +560,40 @@ static int count_tiles(int mode, int m, int n, int tsm, int tsn, int& tm, int& t
   return total;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Split-K for thin products.  K_s^T alpha (nt x d), V^T V (nt x nt), the kernel's input-gradient products: a handful of
+// output tiles with k = N -- four workgroups grinding through k = 16384 take 1 ms for 8 MFLOP.  Such launches are cut
+// along k into a batched launch (each member one k chunk, partial products into a workspace) and summed in a FIXED
+// order by a second kernel, so the result does not depend on scheduling.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ffgp_splitk_reduce(const double* __restrict__ P, int ldp, long sP, int parts, double* __restrict__ C,
+                                                         int ldc, int m, int n, double beta) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)m * n) return;
+  const int r = (int)(e / n), c = (int)(e - (long)r * n);
+  double acc = 0.0;
+  const double* p = P + (size_t)r * ldp + c;
+  for (int s = 0; s < parts; ++s) acc += p[(size_t)s * sP];
+  double* dst = C + (size_t)r * ldc + c;
+  *dst = (beta != 0.0) ? acc + beta * *dst : acc;
+}
+
+static int ensure_skw(ffgp_handle* h, size_t bytes) {
+  if (bytes <= h->skw_bytes) return FFGP_OK;
+  if (h->skw) {
+    hipStreamSynchronize(h->stream);
+    if (h->aux) hipStreamSynchronize(h->aux);
+    hipFree(h->skw);
+  }
+  h->skw = nullptr;
+  h->skw_bytes = 0;
+  const size_t gran = (size_t)16 << 20;
+  const size_t want = (bytes + gran - 1) / gran * gran;
+  if (hipMalloc(&h->skw, want) != hipSuccess) return FFGP_ERR_ALLOC;
+  h->skw_bytes = want;
+  return FFGP_OK;
+}
+
 // alias: 0 = C aliases neither operand; ALIAS_A = C is A's buffer (row-wise in place: needs ONE column tile so
 // that no other workgroup reads the rows a workgroup re-writes); ALIAS_B = C is B's buffer (needs ONE row tile)
 int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, const double* A, int lda, const double* B,
@@ -574,6 +608,36 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   if (mode == TILES_LOWER && m < n) return FFGP_ERR_ARG;
   if (alias == ALIAS_A && (n > 128 || mode != TILES_FULL)) return FFGP_ERR_ARG;
   if (alias == ALIAS_B && (m > 128 || mode != TILES_FULL)) return FFGP_ERR_ARG;
+  if (h->splitk_min_k > 0 && alias == 0 && batch <= 1 && tri == 0 && mode == TILES_FULL && !syrk_tag && k >= h->splitk_min_k &&
+      h->stream != h->aux) {
+    const int t64 = ((m + 63) / 64) * ((n + 63) / 64);
+    if (t64 <= 64) {
+      const int ldp = (n + 1) & ~1;
+      int parts = min(k / 512, (768 + t64 - 1) / t64);
+      parts = (int)min((size_t)parts, ((size_t)64 << 20) / sizeof(double) / ((size_t)m * ldp) - 1);   // workspace cap: 64 MiB
+      if (parts >= 2) {
+        const int kc = (k / parts) & ~31;                 // chunk length: a multiple of the k tile (and even)
+        const int rem = k - kc * parts;                   // < 32 * parts: its own, short, launch
+        const long sP = (long)m * ldp;
+        FFGP_CHECK(ensure_skw(h, (size_t)(parts + 1) * sP * sizeof(double)));
+        const long sA = (opa == OP_KMAJOR) ? kc : (long)kc * lda;
+        const long sB = (opb == OP_KMAJOR) ? kc : (long)kc * ldb;
+        const int saved = h->splitk_min_k;
+        h->splitk_min_k = 0;                              // the chunk launches themselves are never split again
+        int rc = ffgp_gemm_launch(h, opa, opb, TILES_FULL, 0, A, lda, B, ldb, h->skw, ldp, m, n, kc, alpha, 0.0, 0, ALIAS_NONE, parts,
+                                  sA, sB, sP);
+        if (rc == FFGP_OK && rem > 0)
+          rc = ffgp_gemm_launch(h, opa, opb, TILES_FULL, 0, A + (size_t)parts * sA, lda, B + (size_t)parts * sB, ldb,
+                                h->skw + (size_t)parts * sP, ldp, m, n, rem, alpha, 0.0);
+        h->splitk_min_k = saved;
+        FFGP_CHECK(rc);
+        const long total = (long)m * n;
+        hipLaunchKernelGGL(ffgp_splitk_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->skw, ldp, sP,
+                           parts + (rem > 0 ? 1 : 0), C, ldc, m, n, beta);
+        return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
+      }
+    }
+  }
   GemmArgs a;
   // vector (16-byte) operand loads need even leading dimensions and 16-byte aligned bases
   a.avec = (!(lda & 1) && aligned16(A)) ? 1 : 0;

@@ -519,6 +519,7 @@ int ffgp_refresh_dinv(ffgp_handle* h, const double* L, int n, int ldl) {
   if (!h->use_naive && h->dinv_L == L && h->dinv_ld == ldl && h->dinv_n > 0 && n > h->dinv_n && need <= h->dinv_bytes)
     b_first = h->dinv_n / NB;
   FFGP_CHECK(ffgp_ensure_dinv(h, n));
+  h->sinv_L = nullptr;
   const int nblk = (n + NB - 1) / NB;
   if (h->use_naive) {
     hipLaunchKernelGGL(ffgp_dinv_naive, dim3(nblk), dim3(128), 0, h->stream, L, ldl, n, h->dinv);
@@ -578,6 +579,7 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
   FFGP_CHECK(ffgp_ensure_dinv(h, n));
   FFGP_HIP(hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
   h->dinv_L = nullptr;
+  h->sinv_L = nullptr;   // super-block inverses belong to the factor that is about to be overwritten
 
   if (h->use_naive) {
     hipLaunchKernelGGL(ffgp_potrf_naive, dim3(1), dim3(256), 0, h->stream, A, lda, n, h->d_info);

@@ -11,11 +11,139 @@ static int ensure_dinv_for(ffgp_handle* h, const double* L, int n, int ldl) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Super-block sweeps.  A 128-block sweep is a chain of 2 n/128 dependent launches with k = 128 each: for a thin
+// right-hand side (posterior queries, appended points, the backward of a conditional Gaussian) that is pure launch
+// latency -- 7 ms at n = 16384 for work that takes 1.4 ms.  The inverses of the S x S diagonal super-blocks (S = 1024:
+// three doubling levels above the 128-block inverses the factorisation leaves behind, n S^2 / 3 flops, built once per
+// factor and cached in the handle) turn it into 2 n/S launches with k = S.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void ffgp_copy_dinv_super_kernel(const double* __restrict__ dinv, double* __restrict__ Xc, int S, int n) {
+  const int b = blockIdx.y;              // 128-block index
+  const int r0 = b * NB;
+  const int nb = min(NB, n - r0);
+  const int sb = r0 / S, off = r0 % S;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < NB * NB) {
+    const int r = idx >> 7, c = idx & 127;
+    if (r < nb && c <= r) Xc[(size_t)sb * S * S + (size_t)(off + r) * S + off + c] = dinv[(size_t)b * NB * NB + idx];
+  }
+}
+
+static int ensure_sinv_for(ffgp_handle* h, const double* L, int n, int ldl) {
+  FFGP_CHECK(ensure_dinv_for(h, L, n, ldl));
+  const int S = h->super_block;
+  if (h->sinv_L == L && h->sinv_n == n && h->sinv_ld == ldl && h->sinv_S == S) return FFGP_OK;
+  const int nsb = (n + S - 1) / S;
+  // store: nsb super-blocks of S x S, then the T scratch of the doubling levels (S x S / 2 doubles)
+  const size_t need = ((size_t)nsb * S * S + (size_t)S * S / 2) * sizeof(double);
+  if (need > h->sinv_bytes) {
+    if (h->sinv) {
+      hipStreamSynchronize(h->stream);
+      hipFree(h->sinv);
+    }
+    h->sinv = nullptr;
+    h->sinv_bytes = 0;
+    if (hipMalloc(&h->sinv, need) != hipSuccess) return FFGP_ERR_ALLOC;
+    h->sinv_bytes = need;
+  }
+  double* Xc = h->sinv;
+  double* T = h->sinv + (size_t)nsb * S * S;
+  FFGP_HIP(hipMemsetAsync(Xc, 0, (size_t)nsb * S * S * sizeof(double), h->stream));
+  const int nblk = (n + NB - 1) / NB;
+  hipLaunchKernelGGL(ffgp_copy_dinv_super_kernel, dim3(NB * NB / 256, nblk), dim3(256), 0, h->stream, h->dinv, Xc, S, n);
+  for (int sb = 0; sb < nsb; ++sb) {
+    const int o = sb * S;
+    const int ns = min(S, n - o);
+    const double* Ls = L + (size_t)o * ldl + o;
+    double* Xs = Xc + (size_t)sb * S * S;
+    for (long s = NB; s < ns; s *= 2) {   // same doubling as ffgp_trtri_impl, confined to this super-block
+      const int full = (int)(ns / (2 * s));
+      const long strideL = 2 * s * (long)ldl + 2 * s, strideX = 2 * s * (long)S + 2 * s;
+      if (full > 0) {
+        FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Ls + (size_t)s * ldl, ldl, Xs, S, T, (int)s, (int)s,
+                                    (int)s, (int)s, 1.0, 0.0, TRI_LO_J, ALIAS_NONE, full, strideL, strideX, s * s));
+        FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Xs + (size_t)s * S + s, S, T, (int)s, Xs + (size_t)s * S,
+                                    S, (int)s, (int)s, (int)s, -1.0, 0.0, TRI_HI_I, ALIAS_NONE, full, strideX, s * s, strideX));
+      }
+      const long r0 = (long)full * 2 * s;
+      const long n2 = ns - r0 - s;
+      if (n2 > 0) {
+        FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Ls + (size_t)(r0 + s) * ldl + r0, ldl,
+                                    Xs + (size_t)r0 * S + r0, S, T, (int)s, (int)n2, (int)s, (int)s, 1.0, 0.0, TRI_LO_J));
+        FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Xs + (size_t)(r0 + s) * S + (r0 + s), S, T, (int)s,
+                                    Xs + (size_t)(r0 + s) * S + r0, S, (int)n2, (int)s, (int)n2, -1.0, 0.0, TRI_HI_I));
+      }
+    }
+  }
+  h->sinv_L = L;
+  h->sinv_n = n;
+  h->sinv_ld = ldl;
+  h->sinv_S = S;
+  return FFGP_OK;
+}
+
+static int ensure_tsw(ffgp_handle* h, size_t bytes) {
+  if (bytes <= h->tsw_bytes) return FFGP_OK;
+  if (h->tsw) {
+    hipStreamSynchronize(h->stream);
+    hipFree(h->tsw);
+  }
+  h->tsw = nullptr;
+  h->tsw_bytes = 0;
+  const size_t gran = (size_t)16 << 20;
+  const size_t want = (bytes + gran - 1) / gran * gran;
+  if (hipMalloc(&h->tsw, want) != hipSuccess) return FFGP_ERR_ALLOC;
+  h->tsw_bytes = want;
+  return FFGP_OK;
+}
+
+static inline bool use_super(const ffgp_handle* h, int n) {
+  return h->super_block > 0 && !h->use_naive && n >= h->super_min_n && n > h->super_block;
+}
+
+// transposed = 0: B <- L^-1 B (top-down);  1: B <- L^-T B (bottom-up).  V_b = Xinv_b(^T) B_b goes to the staging buffer (it
+// cannot be formed in place: every row of B_b feeds every row of V_b), the update of the remaining rows reads it from there.
+static int trsm_super(ffgp_handle* h, const double* L, int n, int ldl, double* B, int nrhs, int ldb, int transposed) {
+  FFGP_CHECK(ensure_sinv_for(h, L, n, ldl));
+  const int S = h->super_block;
+  const int nsb = (n + S - 1) / S;
+  const int ldv = (nrhs + 1) & ~1;   // even: 16-byte operand loads
+  FFGP_CHECK(ensure_tsw(h, (size_t)n * ldv * sizeof(double)));
+  double* V = h->tsw;
+  for (int i = 0; i < nsb; ++i) {
+    const int sb = transposed ? nsb - 1 - i : i;
+    const int r0 = sb * S;
+    const int rb = min(S, n - r0);
+    const double* Xs = h->sinv + (size_t)sb * S * S;
+    double* Bb = B + (size_t)r0 * ldb;
+    double* Vb = V + (size_t)r0 * ldv;
+    if (!transposed) {
+      // V_b = Xinv_b B_b  (Xinv_b lower: k ends at the tile row)
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Xs, S, Bb, ldb, Vb, ldv, rb, nrhs, rb, 1.0, 0.0, TRI_HI_I));
+      const int below = n - (r0 + rb);
+      if (below > 0)
+        FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, L + (size_t)(r0 + rb) * ldl + r0, ldl, Vb, ldv,
+                                    B + (size_t)(r0 + rb) * ldb, ldb, below, nrhs, rb, -1.0, 1.0));
+    } else {
+      // V_b = Xinv_b^T B_b  (stored k x m, m contiguous; upper triangular: k starts at the tile row)
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_FULL, 0, Xs, S, Bb, ldb, Vb, ldv, rb, nrhs, rb, 1.0, 0.0, TRI_LO_I));
+      if (r0 > 0)
+        FFGP_CHECK(ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_FULL, 0, L + (size_t)r0 * ldl, ldl, Vb, ldv, B, ldb, r0, nrhs,
+                                    rb, -1.0, 1.0));
+    }
+  }
+  FFGP_HIP(hipMemcpy2DAsync(B, (size_t)ldb * sizeof(double), V, (size_t)ldv * sizeof(double), (size_t)nrhs * sizeof(double), n,
+                            hipMemcpyDeviceToDevice, h->stream));
+  return FFGP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // B <- L^-1 B   (forward, blocked by 128):  B_b <- Dinv_b B_b ;  B[below] -= L[below, b] B_b
 // ------------------------------------------------------------------------------------------------------------
 int ffgp_trsm_lower_impl(ffgp_handle* h, const double* L, int n, int ldl, double* B, int nrhs, int ldb) {
   if (n <= 0 || nrhs <= 0) return FFGP_OK;
   if (!L || !B || ldl < n || ldb < nrhs) return FFGP_ERR_ARG;
+  if (use_super(h, n)) return trsm_super(h, L, n, ldl, B, nrhs, ldb, 0);
   FFGP_CHECK(ensure_dinv_for(h, L, n, ldl));
   for (int r0 = 0; r0 < n; r0 += NB) {
     const int rb = min(NB, n - r0);
@@ -36,6 +164,7 @@ int ffgp_trsm_lower_impl(ffgp_handle* h, const double* L, int n, int ldl, double
 int ffgp_trsm_lower_t_impl(ffgp_handle* h, const double* L, int n, int ldl, double* B, int nrhs, int ldb) {
   if (n <= 0 || nrhs <= 0) return FFGP_OK;
   if (!L || !B || ldl < n || ldb < nrhs) return FFGP_ERR_ARG;
+  if (use_super(h, n)) return trsm_super(h, L, n, ldl, B, nrhs, ldb, 1);
   FFGP_CHECK(ensure_dinv_for(h, L, n, ldl));
   const int nblk = (n + NB - 1) / NB;
   for (int b = nblk - 1; b >= 0; --b) {

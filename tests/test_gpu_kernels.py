@@ -142,6 +142,25 @@ def test_gemm_split_tail(ff, case):
     assert np.array_equal(outs[0][~mask], C0[~mask])
 
 
+@pytest.mark.parametrize("opa,opb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("m,n,k", [(256, 1, 16384), (256, 256, 8192), (70, 33, 5000), (64, 64, 2048 + 17), (1, 1, 4096), (130, 512, 3000)])
+def test_gemm_split_k(ff, opa, opb, m, n, k):
+    """thin products with a long k are cut along k (batched partial products + a fixed-order reduction): values, beta,
+    untouched ldc padding, and bit-for-bit repeatability"""
+    rng = np.random.default_rng(m + 5 * n + k + opa * 2 + opb)
+    A = rng.standard_normal((m, k))
+    B = rng.standard_normal((k, n))
+    C0 = rng.standard_normal((m, n))
+    ref = C0 - A @ B
+    scale = np.abs(A) @ np.abs(B)
+    out = run_gemm(ff, opa, opb, 0, 0, A, B, C0, -1.0, 1.0, pad=(2, 4, 6))
+    assert np.abs(out - ref).max() <= 1e-14 * scale.max() * np.sqrt(k)
+    out2 = run_gemm(ff, opa, opb, 0, 0, A, B, C0, -1.0, 1.0, pad=(2, 4, 6))
+    assert np.array_equal(out, out2), "the reduction order is fixed: repeated launches agree bit for bit"
+    out = run_gemm(ff, opa, opb, 0, 0, A, B, np.full((m, n), np.nan), 2.0, 0.0)
+    assert np.abs(out - 2.0 * A @ B).max() <= 2e-14 * scale.max() * np.sqrt(k), "beta == 0 must not read C"
+
+
 def test_gemm_triangular_k_ranges(ff, tile):
     rng = np.random.default_rng(9)
     n = 520
@@ -282,6 +301,41 @@ def test_trsm_and_potrs(ff):
         assert _lib.lib.ffgp_potrs(h, ptr(Wd), n, ld, ptr(Bd), nrhs, nrhs) == 0
         torch.cuda.synchronize()
         assert relerr(Bd.cpu().numpy(), np.linalg.solve(S, B)) < 1e-9
+
+
+@pytest.mark.parametrize("S,cases", [(256, [(300, 7), (640, 130), (1000, 301), (1537, 1), (257, 3)]),
+                                     (512, [(1100, 33), (2049, 2)]), (1024, [(2500, 33), (3072, 1)])])
+def test_trsm_super_block_sweeps(ff, S, cases):
+    """the super-block sweeps (inverted S x S diagonal super-blocks, 2 n/S launches instead of 2 n/128): forward, transposed
+    and potrs against scipy, ragged last super-block and odd right-hand-side counts included; the cached inverses follow
+    the factor (a second factorisation in the same buffer must not reuse them)"""
+    import scipy.linalg as sla
+    _lib, h = ff
+    rng = np.random.default_rng(S)
+    assert _lib.lib.ffgp_set_option(h, b"super_block", float(S)) == 0
+    assert _lib.lib.ffgp_set_option(h, b"super_min_n", 1.0) == 0
+    try:
+        for n, nrhs in cases:
+            for rep in range(2):     # rep 1: same size, new matrix -> very likely the same device buffer
+                A = spd(n, rng)
+                rc, out, Wd, ld = potrf(ff, A)
+                assert rc == 0
+                L = np.linalg.cholesky(A)
+                B = rng.standard_normal((n, nrhs))
+                for fn, ref in ((_lib.lib.ffgp_trsm_lower, sla.solve_triangular(L, B, lower=True)),
+                                (_lib.lib.ffgp_trsm_lower_t, sla.solve_triangular(L.T, B, lower=False)),
+                                (_lib.lib.ffgp_potrs, sla.cho_solve((L, True), B))):
+                    Bp = np.full((n, nrhs + 3), np.nan)      # padded leading dimension: nothing may land in the padding
+                    Bp[:, :nrhs] = B
+                    Bd = dev(Bp)
+                    assert fn(h, ptr(Wd), n, ld, ptr(Bd), nrhs, nrhs + 3) == 0
+                    torch.cuda.synchronize()
+                    got = Bd.cpu().numpy()
+                    assert np.isnan(got[:, nrhs:]).all()
+                    assert relerr(got[:, :nrhs], ref) < 1e-9, (S, n, nrhs, fn.__name__)
+    finally:
+        _lib.lib.ffgp_set_option(h, b"super_block", 1024.0)
+        _lib.lib.ffgp_set_option(h, b"super_min_n", 2048.0)
 
 
 @pytest.mark.parametrize("n", [100, 128, 300, 700, 1100])
