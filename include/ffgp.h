@@ -128,6 +128,9 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
                         hands those last tiles out as 64 x 64 quarters -- same bits, a shorter last round; 0 = never),
             "nb_big" / "nb_big_until" (default 0: a wider outer block while more than nb_big_until columns remain; measured
                         neutral at N = 16384 -- tools/ab_forward.py),
+            "super_block" / "super_min_n" (default 1024 / 2048: triangular sweeps on factors of at least super_min_n rows go
+                        through inverted super_block x super_block diagonal blocks; 0 = always block by block),
+            "splitk_min_k" (default 2048: products with <= 64 tiles of 64 x 64 and k >= this are cut along k; 0 = never),
             "band_log2" (default 3: the GEMM tile order walks bands of 2^k tile rows, column-major inside a band),
             "diag_dbg" (timing-only ablation mask of the diagonal-block kernel; results are wrong when non-zero)       */
 int ffgp_set_option(ffgp_handle* h, const char* key, double value);
