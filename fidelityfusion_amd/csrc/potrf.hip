@@ -490,20 +490,24 @@ int ffgp_ensure_dinv(ffgp_handle* h, int n) {
   const int nblk = (n + NB - 1) / NB;
   const size_t need = (size_t)nblk * NB * NB * sizeof(double);
   if (need > h->dinv_bytes) {
-    if (h->dinv) {   // work enqueued earlier on this handle may still read the old store
-      hipStreamSynchronize(h->stream);
-      if (h->aux) hipStreamSynchronize(h->aux);
-      hipFree(h->dinv);
-    }
-    h->dinv = nullptr;
-    h->dinv_bytes = 0;
-    if (hipMalloc(&h->dinv, need) != hipSuccess) return FFGP_ERR_ALLOC;
+    // grow with head-room and KEEP the content: a factor that gains rows (functional.Posterior.append) keeps the inverses
+    // of its leading blocks, and ffgp_refresh_dinv only builds the new ones
+    const size_t want = need + need / 4 + (size_t)8 * NB * NB * sizeof(double);
+    double* fresh = nullptr;
+    if (hipMalloc(&fresh, want) != hipSuccess) return FFGP_ERR_ALLOC;
     // strictly-upper parts stay zero forever.  The memset must be ORDERED with the kernels that fill the store: a plain
     // hipMemset runs on the NULL stream, which does not synchronise with the (non-blocking) streams this library works
     // on -- it could land after the first diagonal-block kernel had written its inverse and wipe it (seen as wrong
     // factors on the first use of a fresh handle only).
-    if (hipMemsetAsync(h->dinv, 0, need, h->stream) != hipSuccess) return FFGP_ERR_HIP;
-    h->dinv_bytes = need;
+    if (hipMemsetAsync(fresh, 0, want, h->stream) != hipSuccess) return FFGP_ERR_HIP;
+    if (h->dinv) {
+      if (h->aux) hipStreamSynchronize(h->aux);   // work enqueued earlier on this handle may still read / write the old store
+      if (hipMemcpyAsync(fresh, h->dinv, h->dinv_bytes, hipMemcpyDeviceToDevice, h->stream) != hipSuccess) return FFGP_ERR_HIP;
+      hipStreamSynchronize(h->stream);
+      hipFree(h->dinv);
+    }
+    h->dinv = fresh;
+    h->dinv_bytes = want;
   }
   return FFGP_OK;
 }
@@ -515,11 +519,10 @@ int ffgp_refresh_dinv(ffgp_handle* h, const double* L, int n, int ldl) {
   // keeps its leading blocks: rebuild from the last, possibly partial, old block on -- unless the store must be
   // re-allocated, which drops its content
   int b_first = 0;
-  const size_t need = (size_t)((n + NB - 1) / NB) * NB * NB * sizeof(double);
-  if (!h->use_naive && h->dinv_L == L && h->dinv_ld == ldl && h->dinv_n > 0 && n > h->dinv_n && need <= h->dinv_bytes)
+  if (!h->use_naive && h->dinv_L == L && h->dinv_ld == ldl && h->dinv_n > 0 && n > h->dinv_n)
     b_first = h->dinv_n / NB;
   FFGP_CHECK(ffgp_ensure_dinv(h, n));
-  h->sinv_L = nullptr;
+  if (b_first == 0) h->sinv_L = nullptr;   // a factor that only grew keeps its leading super-block inverses as well
   const int nblk = (n + NB - 1) / NB;
   if (h->use_naive) {
     hipLaunchKernelGGL(ffgp_dinv_naive, dim3(nblk), dim3(128), 0, h->stream, L, ldl, n, h->dinv);

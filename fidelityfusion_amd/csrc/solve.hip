@@ -17,8 +17,8 @@ static int ensure_dinv_for(ffgp_handle* h, const double* L, int n, int ldl) {
 // three doubling levels above the 128-block inverses the factorisation leaves behind, n S^2 / 3 flops, built once per
 // factor and cached in the handle) turn it into 2 n/S launches with k = S.
 // ------------------------------------------------------------------------------------------------------------
-__global__ void ffgp_copy_dinv_super_kernel(const double* __restrict__ dinv, double* __restrict__ Xc, int S, int n) {
-  const int b = blockIdx.y;              // 128-block index
+__global__ void ffgp_copy_dinv_super_kernel(const double* __restrict__ dinv, double* __restrict__ Xc, int S, int n, int b0) {
+  const int b = b0 + blockIdx.y;         // 128-block index
   const int r0 = b * NB;
   const int nb = min(NB, n - r0);
   const int sb = r0 / S, off = r0 % S;
@@ -30,28 +30,37 @@ __global__ void ffgp_copy_dinv_super_kernel(const double* __restrict__ dinv, dou
 }
 
 static int ensure_sinv_for(ffgp_handle* h, const double* L, int n, int ldl) {
-  FFGP_CHECK(ensure_dinv_for(h, L, n, ldl));
   const int S = h->super_block;
+  // a factor that only GREW since the store was built (Posterior.append) keeps its complete leading super-blocks
+  int sb_first = 0;
+  if (h->sinv_L == L && h->sinv_ld == ldl && h->sinv_S == S && h->sinv_n > 0 && n > h->sinv_n && h->dinv_L == L) sb_first = h->sinv_n / S;
+  FFGP_CHECK(ensure_dinv_for(h, L, n, ldl));   // (an incremental Dinv refresh leaves sinv_L in place, a full one clears it)
   if (h->sinv_L == L && h->sinv_n == n && h->sinv_ld == ldl && h->sinv_S == S) return FFGP_OK;
+  if (h->sinv_L != L) sb_first = 0;
   const int nsb = (n + S - 1) / S;
-  // store: nsb super-blocks of S x S, then the T scratch of the doubling levels (S x S / 2 doubles)
-  const size_t need = ((size_t)nsb * S * S + (size_t)S * S / 2) * sizeof(double);
+  // store: the T scratch of the doubling levels (S x S / 2 doubles) first, then nsb super-blocks of S x S
+  const size_t tsz = (size_t)S * S / 2;
+  const size_t need = (tsz + (size_t)nsb * S * S) * sizeof(double);
   if (need > h->sinv_bytes) {
+    const size_t want = need + (size_t)2 * S * S * sizeof(double);   // head-room: appended points rarely re-allocate
+    double* fresh = nullptr;
+    if (hipMalloc(&fresh, want) != hipSuccess) return FFGP_ERR_ALLOC;
     if (h->sinv) {
+      if (sb_first > 0)
+        FFGP_HIP(hipMemcpyAsync(fresh, h->sinv, (tsz + (size_t)sb_first * S * S) * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
       hipStreamSynchronize(h->stream);
       hipFree(h->sinv);
     }
-    h->sinv = nullptr;
-    h->sinv_bytes = 0;
-    if (hipMalloc(&h->sinv, need) != hipSuccess) return FFGP_ERR_ALLOC;
-    h->sinv_bytes = need;
+    h->sinv = fresh;
+    h->sinv_bytes = want;
   }
-  double* Xc = h->sinv;
-  double* T = h->sinv + (size_t)nsb * S * S;
-  FFGP_HIP(hipMemsetAsync(Xc, 0, (size_t)nsb * S * S * sizeof(double), h->stream));
+  double* T = h->sinv;
+  double* Xc = h->sinv + tsz;
+  FFGP_HIP(hipMemsetAsync(Xc + (size_t)sb_first * S * S, 0, (size_t)(nsb - sb_first) * S * S * sizeof(double), h->stream));
   const int nblk = (n + NB - 1) / NB;
-  hipLaunchKernelGGL(ffgp_copy_dinv_super_kernel, dim3(NB * NB / 256, nblk), dim3(256), 0, h->stream, h->dinv, Xc, S, n);
-  for (int sb = 0; sb < nsb; ++sb) {
+  const int b0 = sb_first * (S / NB);
+  hipLaunchKernelGGL(ffgp_copy_dinv_super_kernel, dim3(NB * NB / 256, nblk - b0), dim3(256), 0, h->stream, h->dinv, Xc, S, n, b0);
+  for (int sb = sb_first; sb < nsb; ++sb) {
     const int o = sb * S;
     const int ns = min(S, n - o);
     const double* Ls = L + (size_t)o * ldl + o;
@@ -114,7 +123,7 @@ static int trsm_super(ffgp_handle* h, const double* L, int n, int ldl, double* B
     const int sb = transposed ? nsb - 1 - i : i;
     const int r0 = sb * S;
     const int rb = min(S, n - r0);
-    const double* Xs = h->sinv + (size_t)sb * S * S;
+    const double* Xs = h->sinv + (size_t)S * S / 2 + (size_t)sb * S * S;
     double* Bb = B + (size_t)r0 * ldb;
     double* Vb = V + (size_t)r0 * ldv;
     if (!transposed) {

@@ -496,6 +496,42 @@ def test_posterior_reuse_and_append():
     assert pickle.loads(pickle.dumps(m))._post is None
 
 
+def test_posterior_append_with_super_block_sweeps():
+    """the same append sequence with the triangular sweeps forced through (small) inverted super-blocks: queries between
+    appends exercise the incremental refresh of the Dinv store and of the super-block inverses (a factor that only grew
+    keeps its leading blocks), within one buffer and across a reallocation"""
+    from fidelityfusion_amd import _lib
+    from fidelityfusion_amd import functional as F
+    from oracle import gp_oracle as O
+    rng = np.random.default_rng(6)
+    n, D, d, nt = 1500, 3, 2, 21
+    X, Y, Xs = rng.uniform(size=(n, D)), rng.standard_normal((n, d)), rng.uniform(size=(nt, D))
+    ls, sv, lb = np.array([0.7, 1.1, 0.9]), np.array([0.8]), 0.7
+    kf = lambda a, b: O.ard_kernel(a, b, ls, sv)
+    w, amp, dadd = T(1.0 / (np.abs(ls) + 1e-9)), T(np.abs(sv)), T([np.exp(-lb) + 1e-6])
+    for key, val in (("super_block", 256.0), ("super_min_n", 1.0)):
+        _lib.set_option(key, val, 0)
+    try:
+        cuts = [600, 650, 777, 1024, 1300, n]          # within a super-block, across one, onto a boundary, past the capacity
+        inc = F.Posterior(T(X[:cuts[0]]), T(Y[:cuts[0]]), w, amp, dadd, clamp=1e-30, capacity=1100)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            m0, v0 = inc.predict(T(Xs), var_add_all=0.1)             # a query between appends: builds / extends the stores
+            mo, vo = O.cigp_forward(X[:a], Y[:a], Xs, kf, lb)
+            assert rel(m0, mo) < 1e-9 and rel(v0, vo - np.exp(-lb) + 0.1) < 1e-9, a
+            inc.append(T(X[a:b]), T(Y[a:b]))
+        m1, v1 = inc.predict(T(Xs), var_add_all=float(np.exp(-lb)))
+        mo, vo = O.cigp_forward(X, Y, Xs, kf, lb)
+        assert rel(m1, mo) < 1e-9 and rel(v1, vo) < 1e-9
+        xq = T(Xs).requires_grad_(True)                               # and the differentiable query (transposed sweep)
+        mq, vq = inc.predict_diff(xq, var_add_all=float(np.exp(-lb)))
+        assert rel(mq, mo) < 1e-9 and rel(vq, vo) < 1e-9
+        (mq.sum() + vq.diagonal().sum()).backward()
+        assert torch.isfinite(xq.grad).all()
+    finally:
+        _lib.set_option("super_block", 1024.0, 0)
+        _lib.set_option("super_min_n", 2048.0, 0)
+
+
 def test_car_chain_golden(golden):
     """FidelityFusion_Models/CAR_ContinuousAutoRegression.py: GP_basic blocks (V2 likelihood) whose residual kernels are
     ARD x the Monte-Carlo fidelity integral sharing the parameter b; train_CAR (3 fidelities x 4 Adam steps) and
