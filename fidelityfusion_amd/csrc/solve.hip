@@ -17,15 +17,18 @@ static int ensure_dinv_for(ffgp_handle* h, const double* L, int n, int ldl) {
 // three doubling levels above the 128-block inverses the factorisation leaves behind, n S^2 / 3 flops, built once per
 // factor and cached in the handle) turn it into 2 n/S launches with k = S.
 // ------------------------------------------------------------------------------------------------------------
+// The store is addressed like an n x n matrix with leading dimension S: element (r, c) of the block-diagonal inverse at
+// Xc[r * S + c].  Rows overlap in memory, but only the band c in (r - S, r] is ever touched and band entries never collide.
+// What it buys: stepping one pair down the diagonal is the SAME stride (2s * S + 2s) inside a super-block and across
+// super-block boundaries, so every doubling level is one batched launch over all pairs of the matrix.
 __global__ void ffgp_copy_dinv_super_kernel(const double* __restrict__ dinv, double* __restrict__ Xc, int S, int n, int b0) {
   const int b = b0 + blockIdx.y;         // 128-block index
   const int r0 = b * NB;
   const int nb = min(NB, n - r0);
-  const int sb = r0 / S, off = r0 % S;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < NB * NB) {
     const int r = idx >> 7, c = idx & 127;
-    if (r < nb && c <= r) Xc[(size_t)sb * S * S + (size_t)(off + r) * S + off + c] = dinv[(size_t)b * NB * NB + idx];
+    if (r < nb && c <= r) Xc[(size_t)(r0 + r) * S + r0 + c] = dinv[(size_t)b * NB * NB + idx];
   }
 }
 
@@ -37,51 +40,55 @@ static int ensure_sinv_for(ffgp_handle* h, const double* L, int n, int ldl) {
   FFGP_CHECK(ensure_dinv_for(h, L, n, ldl));   // (an incremental Dinv refresh leaves sinv_L in place, a full one clears it)
   if (h->sinv_L == L && h->sinv_n == n && h->sinv_ld == ldl && h->sinv_S == S) return FFGP_OK;
   if (h->sinv_L != L) sb_first = 0;
-  const int nsb = (n + S - 1) / S;
-  // store: the T scratch of the doubling levels (S x S / 2 doubles) first, then nsb super-blocks of S x S
-  const size_t tsz = (size_t)S * S / 2;
-  const size_t need = (tsz + (size_t)nsb * S * S) * sizeof(double);
+  // store: the band first, then the T scratch of the doubling levels
+  // (one s x s product per pair: n * S / 4 doubles at the last level)
+  const size_t band = (size_t)n * (S + 1) + S;   // element (r, c <= r) sits at r * S + c: the last one at (n - 1) * (S + 1)
+  const size_t need = (band + (size_t)n * S / 4 + (size_t)S * S) * sizeof(double);
   if (need > h->sinv_bytes) {
-    const size_t want = need + (size_t)2 * S * S * sizeof(double);   // head-room: appended points rarely re-allocate
+    const size_t want = need + need / 8;   // head-room: appended points rarely re-allocate
     double* fresh = nullptr;
     if (hipMalloc(&fresh, want) != hipSuccess) return FFGP_ERR_ALLOC;
     if (h->sinv) {
       if (sb_first > 0)
-        FFGP_HIP(hipMemcpyAsync(fresh, h->sinv, (tsz + (size_t)sb_first * S * S) * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        FFGP_HIP(hipMemcpyAsync(fresh, h->sinv, ((size_t)sb_first * S * S + (size_t)sb_first * S) * sizeof(double),
+                                hipMemcpyDeviceToDevice, h->stream));
       hipStreamSynchronize(h->stream);
       hipFree(h->sinv);
     }
     h->sinv = fresh;
     h->sinv_bytes = want;
   }
-  double* T = h->sinv;
-  double* Xc = h->sinv + tsz;
-  FFGP_HIP(hipMemsetAsync(Xc + (size_t)sb_first * S * S, 0, (size_t)(nsb - sb_first) * S * S * sizeof(double), h->stream));
+  double* Xc = h->sinv;
+  double* T = h->sinv + (h->sinv_bytes / sizeof(double) - ((size_t)n * S / 4 + (size_t)S * S));   // scratch at the end of the buffer
+  const size_t o_first = (size_t)sb_first * S * S + (size_t)sb_first * S;     // first element of super-block sb_first
+  FFGP_HIP(hipMemsetAsync(Xc + o_first, 0, (band - o_first) * sizeof(double), h->stream));
   const int nblk = (n + NB - 1) / NB;
   const int b0 = sb_first * (S / NB);
   hipLaunchKernelGGL(ffgp_copy_dinv_super_kernel, dim3(NB * NB / 256, nblk - b0), dim3(256), 0, h->stream, h->dinv, Xc, S, n, b0);
-  for (int sb = sb_first; sb < nsb; ++sb) {
-    const int o = sb * S;
-    const int ns = min(S, n - o);
-    const double* Ls = L + (size_t)o * ldl + o;
-    double* Xs = Xc + (size_t)sb * S * S;
-    for (long s = NB; s < ns; s *= 2) {   // same doubling as ffgp_trtri_impl, confined to this super-block
-      const int full = (int)(ns / (2 * s));
-      const long strideL = 2 * s * (long)ldl + 2 * s, strideX = 2 * s * (long)S + 2 * s;
-      if (full > 0) {
-        FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Ls + (size_t)s * ldl, ldl, Xs, S, T, (int)s, (int)s,
-                                    (int)s, (int)s, 1.0, 0.0, TRI_LO_J, ALIAS_NONE, full, strideL, strideX, s * s));
-        FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Xs + (size_t)s * S + s, S, T, (int)s, Xs + (size_t)s * S,
-                                    S, (int)s, (int)s, (int)s, -1.0, 0.0, TRI_HI_I, ALIAS_NONE, full, strideX, s * s, strideX));
-      }
-      const long r0 = (long)full * 2 * s;
-      const long n2 = ns - r0 - s;
-      if (n2 > 0) {
-        FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Ls + (size_t)(r0 + s) * ldl + r0, ldl,
-                                    Xs + (size_t)r0 * S + r0, S, T, (int)s, (int)n2, (int)s, (int)s, 1.0, 0.0, TRI_LO_J));
-        FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Xs + (size_t)(r0 + s) * S + (r0 + s), S, T, (int)s,
-                                    Xs + (size_t)(r0 + s) * S + r0, S, (int)n2, (int)s, (int)n2, -1.0, 0.0, TRI_HI_I));
-      }
+  const int r_first = sb_first * S;
+  for (long s = NB; s < S && s < n - r_first; s *= 2) {   // the doubling of ffgp_trtri_impl, stopped below the super-block size
+    const int p_first = (int)(r_first / (2 * s));
+    const int full = (int)(n / (2 * s)) - p_first;  // pairs with both halves complete (pairs never straddle a super-block)
+    const long strideL = 2 * s * (long)ldl + 2 * s, strideX = 2 * s * (long)S + 2 * s;
+    const double* Lp = L + (size_t)p_first * strideL;
+    double* Xp = Xc + (size_t)p_first * strideX;
+    if (full > 0) {
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Lp + (size_t)s * ldl, ldl, Xp, S, T, (int)s, (int)s, (int)s,
+                                  (int)s, 1.0, 0.0, TRI_LO_J, ALIAS_NONE, full, strideL, strideX, s * s));
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Xp + (size_t)s * S + s, S, T, (int)s, Xp + (size_t)s * S, S,
+                                  (int)s, (int)s, (int)s, -1.0, 0.0, TRI_HI_I, ALIAS_NONE, full, strideX, s * s, strideX));
+    }
+    const long r0 = ((long)p_first + full) * 2 * s;   // ragged last pair: first half complete, second half partial
+    const long n2 = n - r0 - s;
+    if (n2 > 0) {
+      const double* L21 = L + (size_t)(r0 + s) * ldl + r0;
+      double* X11 = Xc + (size_t)r0 * S + r0;
+      double* X22 = Xc + (size_t)(r0 + s) * S + (r0 + s);
+      double* X21 = Xc + (size_t)(r0 + s) * S + r0;
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, L21, ldl, X11, S, T, (int)s, (int)n2, (int)s, (int)s, 1.0, 0.0,
+                                  TRI_LO_J));
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, X22, S, T, (int)s, X21, S, (int)n2, (int)s, (int)n2, -1.0, 0.0,
+                                  TRI_HI_I));
     }
   }
   h->sinv_L = L;
@@ -123,7 +130,7 @@ static int trsm_super(ffgp_handle* h, const double* L, int n, int ldl, double* B
     const int sb = transposed ? nsb - 1 - i : i;
     const int r0 = sb * S;
     const int rb = min(S, n - r0);
-    const double* Xs = h->sinv + (size_t)S * S / 2 + (size_t)sb * S * S;
+    const double* Xs = h->sinv + (size_t)sb * S * S + (size_t)sb * S;   // band addressing, ld = S
     double* Bb = B + (size_t)r0 * ldb;
     double* Vb = V + (size_t)r0 * ldv;
     if (!transposed) {
