@@ -131,6 +131,7 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->band_log2 = 3;
   h->super_block = 1024;
   h->splitk_min_k = 2048;
+  h->skinny_max_n = 8;
   h->super_min_n = 2048;
   h->la_split = 1;
   h->aux_prio = 1;
@@ -218,6 +219,8 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     if (v != 0 && (v < 2 * FFGP_NB || (v & (v - 1)))) return FFGP_ERR_ARG;   // 0, or a power of two >= 256
     h->super_block = v;
     h->sinv_L = nullptr;
+  } else if (!strcmp(key, "skinny_max_n")) {
+    h->skinny_max_n = (int)value;
   } else if (!strcmp(key, "splitk_min_k")) {
     h->splitk_min_k = (int)value;
   } else if (!strcmp(key, "super_min_n")) {

@@ -594,6 +594,102 @@ static int ensure_skw(ffgp_handle* h, size_t bytes) {
   return FFGP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Skinny products: C[m x n] with n <= 8 (single-output GPs: alpha = Sigma^-1 y, the d = 1 sweeps).  On the 64 x 64 MFMA tile
+// such a launch does 8-64x the arithmetic it needs and, worse, walks its k loop with m / 64 workgroups; it is a
+// matrix-vector product and bound by reading A once.  K-major A: one wave per row, lanes across k.  MN-major A (op(A) =
+// A^T): lanes across the rows (coalesced), the 8 waves of a workgroup split k and combine through LDS in a fixed order.
+// ------------------------------------------------------------------------------------------------------------
+struct SkinnyArgs {
+  const double* A;
+  const double* B;
+  double* C;
+  int m, n, k, lda, ldb, ldc, opb;
+  double alpha, beta;
+};
+
+__device__ __forceinline__ double skinny_b(const SkinnyArgs& p, int kk, int j) {
+  return (p.opb == OP_KMAJOR) ? p.B[(size_t)j * p.ldb + kk] : p.B[(size_t)kk * p.ldb + j];
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void ffgp_skinny_kmajor(SkinnyArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.m) return;
+  const double* __restrict__ a = p.A + (size_t)row * p.lda;
+  double acc[NC];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) acc[j] = 0.0;
+#pragma unroll 4
+  for (int k0 = lane * 2; k0 < p.k; k0 += 128) {
+    const double a0 = a[k0];
+    const bool two = k0 + 1 < p.k;
+    const double a1 = two ? a[k0 + 1] : 0.0;
+#pragma unroll
+    for (int j = 0; j < NC; ++j)
+      if (j < p.n) {
+        acc[j] = __builtin_fma(a0, skinny_b(p, k0, j), acc[j]);
+        if (two) acc[j] = __builtin_fma(a1, skinny_b(p, k0 + 1, j), acc[j]);
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < NC; ++j)
+    for (int o = 32; o > 0; o >>= 1) acc[j] += __shfl_down(acc[j], o);
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < NC; ++j)
+      if (j < p.n) {
+        double* dst = p.C + (size_t)row * p.ldc + j;
+        *dst = (p.beta != 0.0) ? p.alpha * acc[j] + p.beta * *dst : p.alpha * acc[j];
+      }
+  }
+}
+
+template <int NC>
+__global__ __launch_bounds__(512) void ffgp_skinny_mnmajor(SkinnyArgs p) {
+  __shared__ double red[8][NC][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * 64 + lane;
+  const int kchunk = (p.k + 7) / 8;
+  const int kb = w * kchunk, ke = min(p.k, kb + kchunk);
+  double acc[NC];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) acc[j] = 0.0;
+  if (row < p.m) {
+    const double* __restrict__ a = p.A + row;
+#pragma unroll 8
+    for (int kk = kb; kk < ke; ++kk) {
+      const double av = a[(size_t)kk * p.lda];
+#pragma unroll
+      for (int j = 0; j < NC; ++j)
+        if (j < p.n) acc[j] = __builtin_fma(av, skinny_b(p, kk, j), acc[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NC; ++j) red[w][j][lane] = acc[j];
+  __syncthreads();
+  if (w == 0 && row < p.m) {
+#pragma unroll
+    for (int j = 0; j < NC; ++j)
+      if (j < p.n) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += red[q][j][lane];
+        double* dst = p.C + (size_t)row * p.ldc + j;
+        *dst = (p.beta != 0.0) ? p.alpha * s + p.beta * *dst : p.alpha * s;
+      }
+  }
+}
+
+template <int NC>
+static void launch_skinny(ffgp_handle* h, int opa, const SkinnyArgs& a) {
+  if (opa == OP_KMAJOR)
+    hipLaunchKernelGGL(ffgp_skinny_kmajor<NC>, dim3((a.m + 3) / 4), dim3(256), 0, h->stream, a);
+  else
+    hipLaunchKernelGGL(ffgp_skinny_mnmajor<NC>, dim3((a.m + 63) / 64), dim3(512), 0, h->stream, a);
+}
+
 // alias: 0 = C aliases neither operand; ALIAS_A = C is A's buffer (row-wise in place: needs ONE column tile so
 // that no other workgroup reads the rows a workgroup re-writes); ALIAS_B = C is B's buffer (needs ONE row tile)
 int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, const double* A, int lda, const double* B,
@@ -637,6 +733,19 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
         return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
       }
     }
+  }
+  if (h->skinny_max_n > 0 && n <= h->skinny_max_n && n <= 8 && alias == 0 && batch <= 1 && tri == 0 && mode == TILES_FULL && !syrk_tag &&
+      h->stream != h->aux) {
+    SkinnyArgs sk;
+    sk.A = A; sk.B = B; sk.C = C;
+    sk.m = m; sk.n = n; sk.k = k;
+    sk.lda = lda; sk.ldb = ldb; sk.ldc = ldc; sk.opb = opb;
+    sk.alpha = alpha; sk.beta = beta;
+    if (n == 1) launch_skinny<1>(h, opa, sk);
+    else if (n == 2) launch_skinny<2>(h, opa, sk);
+    else if (n <= 4) launch_skinny<4>(h, opa, sk);
+    else launch_skinny<8>(h, opa, sk);
+    return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
   }
   GemmArgs a;
   // vector (16-byte) operand loads need even leading dimensions and 16-byte aligned bases

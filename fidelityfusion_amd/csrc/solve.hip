@@ -126,6 +126,9 @@ static int trsm_super(ffgp_handle* h, const double* L, int n, int ldl, double* B
   const int ldv = (nrhs + 1) & ~1;   // even: 16-byte operand loads
   FFGP_CHECK(ensure_tsw(h, (size_t)n * ldv * sizeof(double)));
   double* V = h->tsw;
+  // skinny right-hand sides go to the matrix-vector kernels, which take no k clipping: the store holds true zeros above
+  // the diagonal of every super-block, so the unclipped product is the same number
+  const bool thin = h->skinny_max_n > 0 && nrhs <= h->skinny_max_n && nrhs <= 8;
   for (int i = 0; i < nsb; ++i) {
     const int sb = transposed ? nsb - 1 - i : i;
     const int r0 = sb * S;
@@ -135,14 +138,14 @@ static int trsm_super(ffgp_handle* h, const double* L, int n, int ldl, double* B
     double* Vb = V + (size_t)r0 * ldv;
     if (!transposed) {
       // V_b = Xinv_b B_b  (Xinv_b lower: k ends at the tile row)
-      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Xs, S, Bb, ldb, Vb, ldv, rb, nrhs, rb, 1.0, 0.0, TRI_HI_I));
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Xs, S, Bb, ldb, Vb, ldv, rb, nrhs, rb, 1.0, 0.0, thin ? 0 : TRI_HI_I));
       const int below = n - (r0 + rb);
       if (below > 0)
         FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, L + (size_t)(r0 + rb) * ldl + r0, ldl, Vb, ldv,
                                     B + (size_t)(r0 + rb) * ldb, ldb, below, nrhs, rb, -1.0, 1.0));
     } else {
       // V_b = Xinv_b^T B_b  (stored k x m, m contiguous; upper triangular: k starts at the tile row)
-      FFGP_CHECK(ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_FULL, 0, Xs, S, Bb, ldb, Vb, ldv, rb, nrhs, rb, 1.0, 0.0, TRI_LO_I));
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_FULL, 0, Xs, S, Bb, ldb, Vb, ldv, rb, nrhs, rb, 1.0, 0.0, thin ? 0 : TRI_LO_I));
       if (r0 > 0)
         FFGP_CHECK(ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_FULL, 0, L + (size_t)r0 * ldl, ldl, Vb, ldv, B, ldb, r0, nrhs,
                                     rb, -1.0, 1.0));

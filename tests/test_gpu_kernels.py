@@ -161,6 +161,24 @@ def test_gemm_split_k(ff, opa, opb, m, n, k):
     assert np.abs(out - 2.0 * A @ B).max() <= 2e-14 * scale.max() * np.sqrt(k), "beta == 0 must not read C"
 
 
+@pytest.mark.parametrize("opa,opb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("m,n,k", [(1, 1, 1), (63, 1, 7), (64, 2, 128), (300, 3, 1000), (5000, 1, 1024), (4500, 5, 4099), (129, 8, 515),
+                                   (1024, 1, 1024)])
+def test_gemm_skinny(ff, opa, opb, m, n, k):
+    """products with at most 8 output columns run on the matrix-vector kernels: every layout, ragged sizes, odd leading
+    dimensions, beta, untouched padding"""
+    rng = np.random.default_rng(m + 7 * n + k + opa * 2 + opb)
+    A = rng.standard_normal((m, k))
+    B = rng.standard_normal((k, n))
+    C0 = rng.standard_normal((m, n))
+    scale = (np.abs(A) @ np.abs(B)).max() + 1.0
+    for pad in ((0, 0, 0), (1, 3, 5)):
+        out = run_gemm(ff, opa, opb, 0, 0, A, B, C0, -1.0, 1.0, pad=pad)
+        assert np.abs(out - (C0 - A @ B)).max() <= 1e-14 * scale * np.sqrt(k + 1.0)
+    out = run_gemm(ff, opa, opb, 0, 0, A, B, np.full((m, n), np.nan), 0.5, 0.0)
+    assert np.abs(out - 0.5 * A @ B).max() <= 1e-14 * scale * np.sqrt(k + 1.0), "beta == 0 must not read C"
+
+
 def test_gemm_triangular_k_ranges(ff, tile):
     rng = np.random.default_rng(9)
     n = 520
