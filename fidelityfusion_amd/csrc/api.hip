@@ -127,6 +127,7 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->small_tile_threshold = 640;
   h->tile32_threshold = 1024;
   h->polite_m = 6144;
+  h->polite_pad_kb = 40;
   h->split_rem_max = 180;
   h->band_log2 = 3;
   h->super_block = 1024;
@@ -206,6 +207,9 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->lookahead = (int)value;
   } else if (!strcmp(key, "polite_m")) {
     h->polite_m = (int)value;
+  } else if (!strcmp(key, "polite_pad_kb")) {
+    if (value < 17 || value > 90) return FFGP_ERR_ARG;   // > 16: two padded workgroups must not fit a CU (2 x (64 + pad) > 160)
+    h->polite_pad_kb = (int)value;
   } else if (!strcmp(key, "split_rem_max")) {
     h->split_rem_max = (int)value;
   } else if (!strcmp(key, "nb_big")) {

@@ -107,6 +107,7 @@ struct ffgp_handle {
   int diag_attr_set;    // dynamic-LDS attribute of potrf_diag128 set on this handle's device
   int band_log2;        // GEMM tile order: band height 2^band_log2 tile rows (default 3)
   int split_rem_max;    // split tail of the 128-tile launches: quarter the last (tiles mod 256) tiles when that is <= this (0 = off)
+  int polite_pad_kb;    // LDS padding (KiB) of a polite trailing-update workgroup
   int polite_m;         // trailing updates with fewer rows than this run one workgroup per CU (0 = never)
   bool own_stream;
   // workspace (grown on demand, never shrunk)

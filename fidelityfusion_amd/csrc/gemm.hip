@@ -836,7 +836,7 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   // runs the MFMA pipe at ~70 %, and the other half of every CU -- VGPRs, LDS, issue slots -- is free for the chain's
   // kernels at all times instead of only when a SYRK workgroup happens to exit.
   a.pad_lds = 0;
-  if (syrk_tag && tsm == 128 && h->lookahead && h->polite_m > 0 && m < h->polite_m && h->stream != h->aux) a.pad_lds = 40 * 1024;
+  if (syrk_tag && tsm == 128 && h->lookahead && h->polite_m > 0 && m < h->polite_m && h->stream != h->aux) a.pad_lds = h->polite_pad_kb * 1024;
   if (tsm != 128) syrk_tag = 0;  // only the 128x128 trailing update is the roofline kernel (own instantiation + stats)
   int rc;
   if (tsm == 64 && tsn == 128)

@@ -124,6 +124,8 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
             "tile32_threshold" (default 1024: K-major launches with fewer 64-tiles use 32-row tiles),
             "polite_m" (default 6144: trailing updates with fewer rows run one workgroup per CU so that the side
                         stream's kernels always find free registers and LDS),
+            "polite_pad_kb" (default 40: the LDS padding of a polite workgroup; 17 would leave room for the diagonal-block kernel
+                        beside it -- measured neutral),
             "split_rem_max" (default 180: a 128-tile launch whose tile count leaves a remainder <= this modulo the 256 CUs
                         hands those last tiles out as 64 x 64 quarters -- same bits, a shorter last round; 0 = never),
             "nb_big" / "nb_big_until" (default 0: a wider outer block while more than nb_big_until columns remain; measured
