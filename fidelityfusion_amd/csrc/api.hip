@@ -131,7 +131,7 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->split_rem_max = 180;
   h->band_log2 = 3;
   h->super_block = 1024;
-  h->splitk_min_k = 2048;
+  h->splitk_min_k = 1024;
   h->skinny_max_n = 8;
   h->super_min_n = 2048;
   h->la_split = 1;

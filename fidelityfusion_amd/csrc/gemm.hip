@@ -709,7 +709,7 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
     const int t64 = ((m + 63) / 64) * ((n + 63) / 64);
     if (t64 <= 64) {
       const int ldp = (n + 1) & ~1;
-      int parts = min(k / 512, (768 + t64 - 1) / t64);
+      int parts = min(k / 256, (768 + t64 - 1) / t64);   // chunks of at least 256, enough of them to fill the chip
       parts = (int)min((size_t)parts, ((size_t)64 << 20) / sizeof(double) / ((size_t)m * ldp) - 1);   // workspace cap: 64 MiB
       if (parts >= 2) {
         const int kc = (k / parts) & ~31;                 // chunk length: a multiple of the k tile (and even)

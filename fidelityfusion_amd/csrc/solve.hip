@@ -128,7 +128,8 @@ static int trsm_super(ffgp_handle* h, const double* L, int n, int ldl, double* B
   double* V = h->tsw;
   // skinny right-hand sides go to the matrix-vector kernels, which take no k clipping: the store holds true zeros above
   // the diagonal of every super-block, so the unclipped product is the same number
-  const bool thin = h->skinny_max_n > 0 && nrhs <= h->skinny_max_n && nrhs <= 8;
+  // (the same holds for right-hand sides narrow enough for the split-K path: <= 64 output tiles per super-block)
+  const bool thin = (h->skinny_max_n > 0 && nrhs <= h->skinny_max_n && nrhs <= 8) || (h->splitk_min_k > 0 && S >= h->splitk_min_k && (S / 64) * ((nrhs + 63) / 64) <= 64);
   for (int i = 0; i < nsb; ++i) {
     const int sb = transposed ? nsb - 1 - i : i;
     const int r0 = sb * S;

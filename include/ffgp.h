@@ -133,7 +133,7 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
             "super_block" / "super_min_n" (default 1024 / 2048: triangular sweeps on factors of at least super_min_n rows go
                         through inverted super_block x super_block diagonal blocks; 0 = always block by block),
             "skinny_max_n" (default 8: products with at most this many output columns run on the matrix-vector kernels; 0 = never),
-            "splitk_min_k" (default 2048: products with <= 64 tiles of 64 x 64 and k >= this are cut along k; 0 = never),
+            "splitk_min_k" (default 1024: products with <= 64 tiles of 64 x 64 and k >= this are cut along k; 0 = never),
             "band_log2" (default 3: the GEMM tile order walks bands of 2^k tile rows, column-major inside a band),
             "diag_dbg" (timing-only ablation mask of the diagonal-block kernel; results are wrong when non-zero)       */
 int ffgp_set_option(ffgp_handle* h, const char* key, double value);
