@@ -532,6 +532,35 @@ def test_posterior_append_with_super_block_sweeps():
         _lib.set_option("super_min_n", 2048.0, 0)
 
 
+@pytest.mark.parametrize("n,d,nt", [(4500, 1, 77), (5200, 3, 300)])
+def test_posterior_large_n_matches_fused_predict(n, d, nt):
+    """default settings at a size where the cached-factor queries run through the inverted 1024-blocks, the split-K and the
+    matrix-vector kernels: same numbers as the fused one-shot posterior (passenger rows, none of those paths), for the
+    first query, a repeated one, the diagonal mode and after an append"""
+    from fidelityfusion_amd import functional as F
+    g = torch.Generator(device=DEV).manual_seed(n)
+    X = torch.rand((n, 6), generator=g, device=DEV, dtype=torch.float64)
+    Y = torch.randn((n, d), generator=g, device=DEV, dtype=torch.float64)
+    Xs = torch.rand((nt, 6), generator=g, device=DEV, dtype=torch.float64)
+    w = torch.full((6,), 1.7, device=DEV, dtype=torch.float64)
+    amp = torch.tensor([0.9], device=DEV, dtype=torch.float64)
+    dadd = torch.tensor([0.05], device=DEV, dtype=torch.float64)
+    with torch.no_grad():
+        m_ref, v_ref = F.predict(X, Y, Xs, w, amp, diag_add=dadd, clamp=1e-30, full_cov=True, var_add_all=0.3)
+        k0 = n - 130
+        post = F.Posterior(X[:k0], Y[:k0], w, amp, dadd, clamp=1e-30, first_query=Xs, var_add_all=0.3)
+        post.predict(Xs)                                   # a query on the shorter factor builds the stores ...
+        post.append(X[k0:], Y[k0:])                        # ... which the append then has to extend
+        for rep in range(2):
+            m1, v1 = post.predict(Xs, full_cov=True, var_add_all=0.3)
+            assert rel(m1, m_ref) < 1e-9 and rel(v1, v_ref) < 1e-9, rep
+        _, vd = post.predict(Xs, full_cov=False, var_add_all=0.3)
+        assert rel(vd, v_ref.diagonal()) < 1e-9
+        full = F.Posterior(X, Y, w, amp, dadd, clamp=1e-30)
+        m2, v2 = full.predict(Xs, full_cov=True, var_add_all=0.3)
+        assert rel(m2, m_ref) < 1e-9 and rel(v2, v_ref) < 1e-9
+
+
 def test_car_chain_golden(golden):
     """FidelityFusion_Models/CAR_ContinuousAutoRegression.py: GP_basic blocks (V2 likelihood) whose residual kernels are
     ARD x the Monte-Carlo fidelity integral sharing the parameter b; train_CAR (3 fidelities x 4 Adam steps) and
