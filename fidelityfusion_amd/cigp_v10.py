@@ -77,12 +77,14 @@ class cigp(nn.Module):
     # composed kernels (SumKernel(LinearKernel, MaternKernel) of the reference's own demos, cigp_v10.py:81,111,147):
     # the parts are evaluated on the device, Sigma is composed there and enters the fused factorisation as cov_dev
     def _forward_composed(self, x_train, y_train, x_test):
-        from .gp_computation_pack import conditional_Gaussian
         noise = self.log_beta.exp().pow(-1)
         Sigma = F.add_diagonal(F.kernel_on_device(self.kernel, x_train, x_train), noise, JITTER)
         K_s = F.kernel_on_device(self.kernel, x_train, x_test)
         K_ss = F.kernel_on_device(self.kernel, x_test, x_test)
-        mean, var = conditional_Gaussian(y_train, Sigma, K_s, K_ss)
+        # a trainable model queried again and again with unchanged parameters (an acquisition loop that never froze it):
+        # the factor of Sigma is the cached one, only the backward formulas run -- gradients still reach the parameters and y
+        post = self._cached_posterior(x_train, y_train)[0] if hasattr(self.kernel, "effective") else None
+        mean, var = F.conditional_gaussian(y_train, Sigma, K_s, K_ss, factor=post)
         var = var + noise.to(var.device)
         odt = y_train.dtype if y_train.dtype.is_floating_point else torch.float64
         return mean.to(device=y_train.device, dtype=odt), var.to(device=y_train.device, dtype=odt)

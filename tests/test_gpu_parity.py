@@ -358,6 +358,22 @@ def test_cigp_forward_grads_golden(golden, where):
     assert rel(xs.grad, g["g_xs"]) < 1e-8
     assert rel(Y.grad, g["g_Y"]) < 1e-8
     _check_param_grads(m, want)
+    # asked again with the same tensors and unchanged parameters, the trainable model differentiates on its CACHED factor
+    # (conditional_gaussian(factor=...)): same values, same gradients for the query, y and every parameter
+    Xt = tt(g["X"])
+    for rep in range(2):
+        for p in m.parameters():
+            p.grad = None
+        Y.grad = None
+        xs2 = tt(g["xs"], True)
+        mean, var = m(Xt, Y, xs2)
+        if rep == 1:
+            assert m._post is post, "second call must reuse the factor"
+        post = m._post
+        assert rel(mean, g["mean"]) < 1e-9 and rel(var, g["var"]) < 1e-9
+        ((mean * tt(g["R1"])).sum() + (var * tt(g["R2"])).sum()).backward()
+        assert rel(xs2.grad, g["g_xs"]) < 1e-8 and rel(Y.grad, g["g_Y"]) < 1e-8
+        _check_param_grads(m, want)
     with torch.no_grad():   # the fused no_grad posterior gives the same numbers
         mean2, var2 = m(tt(g["X"]), Y.detach(), xs.detach())
     assert rel(mean2, g["mean"]) < 1e-9 and rel(var2, g["var"]) < 1e-9
