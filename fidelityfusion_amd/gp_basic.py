@@ -62,10 +62,18 @@ class GP_basic(nn.Module):
         return Sigma
 
     def _forward_composed(self, x_train, y_train, y_var, x_test):
-        from .gp_computation_pack import conditional_Gaussian
         K_s = F.kernel_on_device(self.kernel, x_train, x_test)
         K_ss = F.kernel_on_device(self.kernel, x_test, x_test)
-        mu, var = conditional_Gaussian(y_train, self._sigma_composed(x_train, y_var), K_s, K_ss)
+        post = None
+        if y_var is None and hasattr(self.kernel, "effective"):
+            # asked again with unchanged parameters (an acquisition loop): the factor of Sigma is the cached one and only the
+            # closed-form backward runs; gradients reach the parameters and y as before
+            def build():
+                with torch.no_grad():
+                    w, amp, clamp = self.kernel.effective()
+                    return F.Posterior(x_train, y_train, w, amp, self.noise_variance.pow(2), clamp=clamp, kfun=_kfun(self.kernel))
+            post, _ = self._pcache.get([x_train, y_train] + list(self.parameters()), build)
+        mu, var = F.conditional_gaussian(y_train, self._sigma_composed(x_train, y_var), K_s, K_ss, factor=post)
         odt = y_train.dtype if y_train.dtype.is_floating_point else torch.float64
         return mu.to(device=y_train.device, dtype=odt).squeeze(), var.to(device=y_train.device, dtype=odt)
 

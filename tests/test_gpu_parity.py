@@ -577,6 +577,44 @@ def test_posterior_large_n_matches_fused_predict(n, d, nt):
         assert rel(m2, m_ref) < 1e-9 and rel(v2, v_ref) < 1e-9
 
 
+def test_gp_basic_forward_autograd_cached_factor():
+    """GP_basic.forward with autograd on (fused kernel, no y_var): the differentiable posterior on the cached factor gives the
+    gradients of the plain composition (conditional_Gaussian without a factor) -- query points, y, noise and kernel
+    parameters -- on the call that factorises and on the next one that does not"""
+    import fidelityfusion_amd.gp_computation_pack as gp_pack
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.gp_basic import GP_basic
+    rng = np.random.default_rng(21)
+    n, D, d, nt = 333, 3, 2, 9
+    X, Yv, Xs = rng.uniform(size=(n, D)), rng.standard_normal((n, d)), rng.uniform(size=(nt, D))
+    R1, R2 = rng.standard_normal((nt, d)), rng.standard_normal((nt, nt))
+
+    def run(explicit, reps):
+        m = GP_basic(kernel.ARDKernel(D), 0.45).double().to(DEV)
+        with torch.no_grad():
+            m.kernel.length_scales.copy_(torch.tensor([0.7, 1.2, 0.9]))
+        Xt, Y = T(X), T(Yv, grad=True)
+        outs = []
+        for _ in range(reps):
+            for p in m.parameters():
+                p.grad = None
+            Y.grad = None
+            xs = T(Xs, grad=True)
+            if explicit:
+                K = m.kernel(Xt, Xt) + m.noise_variance.pow(2) * torch.eye(n, device=DEV, dtype=torch.float64)
+                mu, var = gp_pack.conditional_Gaussian(Y, K, m.kernel(Xt, xs), m.kernel(xs, xs))
+            else:
+                mu, var = m(Xt, Y, xs)
+            ((mu.reshape(nt, d) * T(R1)).sum() + (var * T(R2)).sum()).backward()
+            outs.append([mu.detach().reshape(nt, d), var.detach(), xs.grad, Y.grad.clone(), m.noise_variance.grad.clone(),
+                         m.kernel.length_scales.grad.clone(), m.kernel.signal_variance.grad.clone()])
+        return outs
+    ref = run(True, 1)[0]
+    for got in run(False, 2):
+        for a, b in zip(got, ref):
+            assert rel(a, b) < 1e-8
+
+
 def test_car_chain_golden(golden):
     """FidelityFusion_Models/CAR_ContinuousAutoRegression.py: GP_basic blocks (V2 likelihood) whose residual kernels are
     ARD x the Monte-Carlo fidelity integral sharing the parameter b; train_CAR (3 fidelities x 4 Adam steps) and
