@@ -615,6 +615,39 @@ def test_gp_basic_forward_autograd_cached_factor():
             assert rel(a, b) < 1e-8
 
 
+@pytest.mark.timeout(300)
+def test_hogp_block_full_size_properties():
+    """one HOGP block at BASELINE config 5's size (N = 8192, d = 64 x 64), through size-independent properties: the cached
+    g solves (K_x (x) K_1 (x) K_2 + I / noise) g = y (residual through the mode products), A is positive, the loss equals
+    the dense formula's pieces, and the closed-form backward fills finite gradients of the right shapes"""
+    import math
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.hogp_simple import HOGP_simple, multi_mode_dot
+    n, d1, d2 = 8192, 64, 64
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    X = torch.rand((n, 8), generator=gen, device=DEV, dtype=torch.float64)
+    Y = torch.randn((n, d1, d2), generator=gen, device=DEV, dtype=torch.float64)
+    m = HOGP_simple(kernel.ARDKernel(8), 0.8, [d1, d2]).double().to(DEV)
+    loss = m.log_likelihood(X, Y)
+    assert torch.isfinite(loss)
+    with torch.no_grad():
+        tau = float(m.noise_variance.pow(-1))
+        resid = multi_mode_dot(m.g, m.K) + tau * m.g - Y
+        assert float(resid.abs().max()) <= 1e-7 * float(Y.abs().max())
+        assert float(m.A.min()) > 0.0
+        nd = m.A.numel()
+        quad = float((Y * m.g).sum())                         # y^T S^-1 y
+        want = (0.5 * nd * math.log(2 * math.pi) + 0.5 * float(torch.log(m.A).sum()) + 0.5 * quad) / nd
+        assert abs(float(loss) - want) <= 1e-9 * abs(want)
+    loss.backward()
+    for p in (m.noise_variance, m.kernel_list[0].length_scales, m.kernel_list[0].signal_variance):
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+    with torch.no_grad():
+        mu, var = m.forward(X, X[:16])
+    assert mu.shape == (16, d1, d2) and var.shape == (16, d1, d2)
+    assert float((mu - Y[:16]).abs().max()) < float(Y.abs().max())     # interpolates towards the data, not garbage
+
+
 def test_car_chain_golden(golden):
     """FidelityFusion_Models/CAR_ContinuousAutoRegression.py: GP_basic blocks (V2 likelihood) whose residual kernels are
     ARD x the Monte-Carlo fidelity integral sharing the parameter b; train_CAR (3 fidelities x 4 Adam steps) and
