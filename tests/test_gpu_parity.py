@@ -1297,3 +1297,38 @@ def test_full_size_properties(n, D):
     torch.cuda.empty_cache()
     out = F.nlml(Xd, Yd, w, amp, diag_add=dadd, clamp=1e-30)
     assert abs(float(out) - nll) < 1e-10 * abs(nll)
+
+
+@pytest.mark.timeout(300)
+def test_c4_block_full_size_properties():
+    """one block of BASELINE config 4 (N = 8192, D = 8, d = 1024) through the fused NLML + gradients: dNLL/dY = Sigma^-1 Y
+    solves Sigma alpha = Y on sampled rows, and the hyper-parameter gradients agree with central differences of the
+    fused value itself"""
+    from fidelityfusion_amd import functional as F
+    from oracle import gp_oracle as O
+    n, D, d = 8192, 8, 1024
+    X, Y = O.synthetic_xy(n, D, d, seed=4)
+    Xd = T(X)
+    Yd = T(Y, grad=True)
+    w0, amp0, dadd0 = np.full(D, 0.9), np.array([1.3]), np.array([np.exp(-1.0) + 1e-6])
+    w, amp, dadd = T(w0, grad=True), T(amp0, grad=True), T(dadd0, grad=True)
+    nll = F.nlml(Xd, Yd, w, amp, diag_add=dadd, clamp=1e-30)
+    nll.backward()
+    alpha = Yd.grad
+    rows = [0, 1, n // 3, n - 1]
+    with torch.no_grad():
+        Krows = F.kernel_matrix(Xd[rows], Xd, w.detach(), amp.detach(), 1e-30)
+        rec = Krows @ alpha + float(dadd) * alpha[rows]
+        assert float((rec - Yd[rows]).abs().max()) <= 1e-8 * float(Yd.abs().max())
+
+        def val(wv, av, dv):
+            return float(F.nlml(Xd, Yd.detach(), T(wv), T(av), diag_add=T(dv), clamp=1e-30))
+        eps = 1e-5
+        fd_amp = (val(w0, amp0 + eps, dadd0) - val(w0, amp0 - eps, dadd0)) / (2 * eps)
+        fd_dadd = (val(w0, amp0, dadd0 + eps) - val(w0, amp0, dadd0 - eps)) / (2 * eps)
+        e3 = np.zeros(D)
+        e3[3] = eps
+        fd_w3 = (val(w0 + e3, amp0, dadd0) - val(w0 - e3, amp0, dadd0)) / (2 * eps)
+    assert abs(fd_amp - float(amp.grad)) <= 1e-6 * abs(float(amp.grad))
+    assert abs(fd_dadd - float(dadd.grad)) <= 1e-6 * abs(float(dadd.grad))
+    assert abs(fd_w3 - float(w.grad[3])) <= 1e-6 * abs(float(w.grad[3]))
