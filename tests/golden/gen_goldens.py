@@ -712,6 +712,45 @@ def main():
                    f"{meth}_basic_g_ls": gb.kernel.length_scales.grad, f"{meth}_basic_g_sv": gb.kernel.signal_variance.grad})
     save("kinv_mn", **mn)
 
+    # ------------------------------------------------------------------ the two hand-written GP modules next to cigp_v10:
+    # CIGP_withMean (cigp_withMean.py:29-64) and MultiTaskGP_cigp.CIGP (:14-50); both import their siblings by bare name
+    sys.path.insert(0, os.path.join(REF, "GaussianProcess"))
+    with contextlib.redirect_stdout(io.StringIO()):
+        import cigp_withMean as rwm
+        import MultiTaskGP_cigp as rmt
+        import kernel as rk_bare
+    g9 = torch.Generator().manual_seed(1618)
+    Xw, Yw = make_xy(g9, 48, 2, 3)
+    Xq = torch.rand(7, 2, generator=g9)
+    torch.manual_seed(77)                                   # the mean MLP's initialisation
+    mw = rwm.CIGP_withMean(2, 3, kernel=rk_bare.ARDKernel(2), noise_variance=0.6)
+    sdw = {k.replace(".", "__"): v.clone() for k, v in mw.state_dict().items()}
+    xq = Xq.clone().requires_grad_(True)
+    Yg = Yw.clone().requires_grad_(True)
+    mu, cov = mw(Xw, Yg, xq)
+    R1, R2 = torch.randn(mu.shape, generator=g9), torch.randn(cov.shape, generator=g9)
+    ((mu * R1).sum() + (cov * R2).sum()).backward()
+    fw = {f"fwd_g_{k.replace('.', '__')}": p.grad.clone() for k, p in mw.named_parameters()}
+    fw.update(fwd_g_xq=xq.grad.clone(), fwd_g_Y=Yg.grad.clone())
+    for p_ in mw.parameters():
+        p_.grad = None
+    llw = mw.log_likelihood(Xw, Yw)
+    llw.backward()
+    lw = {f"ll_g_{k.replace('.', '__')}": p.grad.clone() for k, p in mw.named_parameters()}
+    mm = rmt.CIGP(rk_bare.ARDKernel(2), noise_variance=0.4)
+    out_mt = {}
+    for tag, Ym in (("d3", Yw), ("d1", Yw[:, :1].contiguous())):
+        for p_ in mm.parameters():
+            p_.grad = None
+        with torch.no_grad():
+            mu_m, cov_m = mm(Xw, Ym, Xq)
+        ll_m = mm.log_likelihood(Xw, Ym)
+        ll_m.backward()
+        out_mt.update({f"mt_{tag}_mu": mu_m, f"mt_{tag}_cov": cov_m, f"mt_{tag}_ll": ll_m,
+                       f"mt_{tag}_g_noise": mm.noise_variance.grad.clone(), f"mt_{tag}_g_ls": mm.kernel.length_scales.grad.clone(),
+                       f"mt_{tag}_g_sv": mm.kernel.signal_variance.grad.clone()})
+    save("gp_withmean_multitask", X=Xw, Y=Yw, Xq=Xq, R1=R1, R2=R2, mu=mu, cov=cov, ll=llw, **sdw, **fw, **lw, **out_mt)
+
     # ------------------------------------------------------------------ AR and NAR chains (the remaining 2024 trainers on cigp)
     from FidelityFusion_Models.AR_autoRegression import AR as RAR, train_AR
     from FidelityFusion_Models.NAR import NAR as RNAR, train_NAR

@@ -648,6 +648,49 @@ def test_hogp_block_full_size_properties():
     assert float((mu - Y[:16]).abs().max()) < float(Y.abs().max())     # interpolates towards the data, not garbage
 
 
+@pytest.mark.parametrize("where", ["cuda", "cpu"])
+def test_withmean_and_multitask_golden(golden, where):
+    """the two hand-written GP modules next to cigp_v10 (GaussianProcess/cigp_withMean.py:29-64, MultiTaskGP_cigp.py:14-50):
+    values and every gradient (kernel, noise, the mean MLP, the query points, y) against the reference's autograd"""
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.MultiTaskGP_cigp import CIGP
+    from fidelityfusion_amd.cigp_withMean import CIGP_withMean
+    g = golden("gp_withmean_multitask")
+    dev = DEV if where == "cuda" else "cpu"
+    tt = lambda a, gr=False: torch.tensor(np.asarray(a), dtype=torch.float64, device=dev, requires_grad=gr)
+    m = CIGP_withMean(2, 3, kernel=kernel.ARDKernel(2), noise_variance=0.6).double()
+    names = [k for k, _ in m.named_parameters()]
+    m.load_state_dict({k: torch.tensor(g[k.replace(".", "__")]) for k in names})
+    m = m.to(dev)
+    X, Y, xq = tt(g["X"]), tt(g["Y"], True), tt(g["Xq"], True)
+    mu, cov = m(X, Y, xq)
+    assert rel(mu, g["mu"]) < 1e-9 and rel(cov, g["cov"]) < 1e-9
+    ((mu * tt(g["R1"]).to(mu.device)).sum() + (cov * tt(g["R2"]).to(cov.device)).sum()).backward()
+    assert rel(xq.grad, g["fwd_g_xq"]) < 1e-8 and rel(Y.grad, g["fwd_g_Y"]) < 1e-8
+    for k, p in m.named_parameters():
+        assert rel(p.grad, g["fwd_g_" + k.replace(".", "__")]) < 1e-7, k
+        p.grad = None
+    ll = m.log_likelihood(X, Y.detach())
+    assert tuple(ll.shape) == g["ll"].shape and rel(ll, g["ll"]) < 1e-10
+    ll.backward()
+    for k, p in m.named_parameters():
+        assert rel(p.grad, g["ll_g_" + k.replace(".", "__")]) < 1e-7, k
+    mt = CIGP(kernel.ARDKernel(2), noise_variance=0.4).double().to(dev)
+    for tag, Ym in (("d3", g["Y"]), ("d1", g["Y"][:, :1])):
+        for p in mt.parameters():
+            p.grad = None
+        with torch.no_grad():
+            mu_m, cov_m = mt(X, tt(Ym), tt(g["Xq"]))
+        assert tuple(mu_m.shape) == g[f"mt_{tag}_mu"].shape and tuple(cov_m.shape) == g[f"mt_{tag}_cov"].shape
+        assert rel(mu_m, g[f"mt_{tag}_mu"]) < 1e-9 and rel(cov_m, g[f"mt_{tag}_cov"]) < 1e-9
+        ll_m = mt.log_likelihood(X, tt(Ym))
+        assert tuple(ll_m.shape) == g[f"mt_{tag}_ll"].shape and rel(ll_m, g[f"mt_{tag}_ll"]) < 1e-10
+        ll_m.backward()
+        assert rel(mt.noise_variance.grad, g[f"mt_{tag}_g_noise"]) < 1e-8
+        assert rel(mt.kernel.length_scales.grad, g[f"mt_{tag}_g_ls"]) < 1e-8
+        assert rel(mt.kernel.signal_variance.grad, g[f"mt_{tag}_g_sv"]) < 1e-8
+
+
 def test_car_chain_golden(golden):
     """FidelityFusion_Models/CAR_ContinuousAutoRegression.py: GP_basic blocks (V2 likelihood) whose residual kernels are
     ARD x the Monte-Carlo fidelity integral sharing the parameter b; train_CAR (3 fidelities x 4 Adam steps) and

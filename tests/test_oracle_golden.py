@@ -119,6 +119,34 @@ def test_kinv_alternatives(golden):
         close(-0.5 * g[f"{meth}_R"].sum() * np.linalg.inv(g["cov"]), 0.5 * (g[f"{meth}_gcov"] + g[f"{meth}_gcov"].T), 1e-9)
 
 
+def test_withmean_and_multitask(golden):
+    """CIGP_withMean (cigp_withMean.py:44-62: conditional Gaussian / Sigma^-2 likelihood of the residual y - m(x), m a small
+    MLP) and MultiTaskGP_cigp.CIGP (:20-50: diagonal covariance expanded; log-determinant counted once)"""
+    g = golden("gp_withmean_multitask")
+    X, Y, Xq = g["X"], g["Y"], g["Xq"]
+
+    def mlp(x):
+        h = x @ g["mean_func__0__weight"].T + g["mean_func__0__bias"]
+        h = np.where(h > 0, h, 0.01 * h)                      # nn.LeakyReLU default slope
+        return h @ g["mean_func__2__weight"].T + g["mean_func__2__bias"]
+    kf = lambda a, b: O.ard_kernel(a, b, g["kernel__length_scales"], g["kernel__signal_variance"])
+    S = O.sigma_basic(kf(X, X), g["noise_variance"])
+    mu, cov = O.conditional_gaussian(Y - mlp(X), S, kf(X, Xq), kf(Xq, Xq))
+    close(mu + mlp(Xq), g["mu"], 1e-9)
+    close(cov, g["cov"], 1e-9)
+    close(O.ll_v2(Y - mlp(X), S)[0], g["ll"], 1e-10)
+    kf0 = lambda a, b: O.ard_kernel(a, b, np.ones(2), np.ones(1))   # the second model keeps the kernel's initial parameters
+    S0 = O.sigma_basic(kf0(X, X), np.array([0.4]))
+    for tag, Ym in (("d3", Y), ("d1", Y[:, :1])):
+        mu, cov = O.conditional_gaussian(Ym, S0, kf0(X, Xq), kf0(Xq, Xq))
+        close(np.squeeze(mu), g[f"mt_{tag}_mu"], 1e-9)
+        close(np.broadcast_to(np.diag(cov)[:, None], mu.shape), g[f"mt_{tag}_cov"], 1e-9)
+        ll, L, A = O.ll_v2(Ym, S0)
+        d = Ym.shape[1]
+        ll_once = ll + 0.5 * (d - 1) * (2.0 * np.log(np.diag(L)).sum() + len(X) * np.log(2.0 * np.pi))
+        close(ll_once, g[f"mt_{tag}_ll"], 1e-10)
+
+
 @pytest.mark.parametrize("tag", ["d1", "d6"])
 def test_gp_basic(golden, tag):
     g = golden("gp_basic_" + tag)
