@@ -356,6 +356,33 @@ def test_trsm_super_block_sweeps(ff, S, cases):
         _lib.lib.ffgp_set_option(h, b"super_min_n", 2048.0)
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_solves_fuzz_default_paths(ff, seed):
+    """random sizes around the switch points of the solve paths (128-block / super-block sweeps, MFMA tiles / split-K /
+    matrix-vector kernels) with the library's default settings: trsm, trsm^T and potrs residuals against the factor itself
+    (L X = B, L^T X = B, L L^T X = B evaluated in fp64 on the device)"""
+    _lib, h = ff
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.choice([rng.integers(1500, 2048), rng.integers(2048, 2300), rng.integers(2300, 5200), 1024 * rng.integers(2, 5)]))
+    nrhs = int(rng.choice([1, 2, rng.integers(3, 9), rng.integers(9, 70), rng.integers(200, 320)]))
+    g = torch.Generator(device="cuda:0").manual_seed(seed)
+    X = torch.rand((n, 5), generator=g, device="cuda:0", dtype=torch.float64)
+    K = torch.exp(-0.5 * torch.cdist(X, X) ** 2) + 0.3 * torch.eye(n, device="cuda:0", dtype=torch.float64)
+    ld = n + (n & 1) + 2
+    W = torch.zeros((n, ld), device="cuda:0", dtype=torch.float64)
+    W[:, :n] = torch.tril(K)
+    assert _lib.lib.ffgp_potrf(h, ptr(W), n, ld) == 0
+    L = torch.tril(W[:, :n])
+    B = torch.randn((n, nrhs), generator=g, device="cuda:0", dtype=torch.float64)
+    scale = float(B.abs().max())
+    for fn, back in ((_lib.lib.ffgp_trsm_lower, lambda Z: L @ Z), (_lib.lib.ffgp_trsm_lower_t, lambda Z: L.T @ Z),
+                     (_lib.lib.ffgp_potrs, lambda Z: L @ (L.T @ Z))):
+        Z = B.clone()
+        assert fn(h, ptr(W), n, ld, ptr(Z), nrhs, nrhs) == 0
+        torch.cuda.synchronize()
+        assert float((back(Z) - B).abs().max()) <= 1e-9 * scale * max(1.0, float(Z.abs().max())), (n, nrhs, fn.__name__)
+
+
 @pytest.mark.parametrize("n", [100, 128, 300, 700, 1100])
 def test_potri(ff, tile, n):
     _lib, h = ff
