@@ -104,21 +104,25 @@ class _NLML(torch.autograd.Function):
             if needs[0]:
                 grads["Y"] = torch.empty((n, d), dtype=torch.float64, device=dev)
                 g.g_Y_dev = _ptr(grads["Y"])
+            # the scalar-sized gradients share one buffer [w (D) | amp | diag_add | kparam]: one scaling launch in backward
+            small = torch.empty((D + 3,), dtype=torch.float64, device=dev)
+            grads["_small"] = small
+            base, step = small.data_ptr(), small.element_size()
             if needs[1]:
-                grads["w"] = torch.empty((D,), dtype=torch.float64, device=dev)
-                g.g_w_dev = _ptr(grads["w"])
+                grads["w"] = small[:D]
+                g.g_w_dev = C.c_void_p(base)
             if needs[2]:
-                grads["amp"] = torch.empty((1,), dtype=torch.float64, device=dev)
-                g.g_amp_dev = _ptr(grads["amp"])
+                grads["amp"] = small[D:D + 1]
+                g.g_amp_dev = C.c_void_p(base + D * step)
             if needs[3]:
-                grads["diag_add"] = torch.empty((1,), dtype=torch.float64, device=dev)
-                g.g_diag_add_dev = _ptr(grads["diag_add"])
+                grads["diag_add"] = small[D + 1:D + 2]
+                g.g_diag_add_dev = C.c_void_p(base + (D + 1) * step)
             if needs[4]:
                 grads["diag_vec"] = torch.empty((n,), dtype=torch.float64, device=dev)
                 g.g_diag_vec_dev = _ptr(grads["diag_vec"])
             if needs[5]:
-                grads["kparam"] = torch.empty((1,), dtype=torch.float64, device=dev)
-                g.g_kparam_dev = _ptr(grads["kparam"])
+                grads["kparam"] = small[D + 2:D + 3]
+                g.g_kparam_dev = C.c_void_p(base + (D + 2) * step)
         gref = C.byref(g) if g is not None else None
         if defer:   # enqueue only: the caller collects the status with wait(slot) after launching its other blocks
             check(lib.ffgp_nlml_fused_async(h, C.byref(p), _ptr(out), gref), "ffgp_nlml_fused_async")
@@ -134,13 +138,21 @@ class _NLML(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        gr = ctx.grads
+        gr = dict(ctx.grads)
+        small = gr.pop("_small", None)
+        if small is not None:   # scale the scalar-sized gradients in one launch, then hand out views
+            D = small.numel() - 3
+            scaled = small * gout.to(device=small.device, dtype=torch.float64)
+            views = {"w": scaled[:D], "amp": scaled[D:D + 1], "diag_add": scaled[D + 1:D + 2], "kparam": scaled[D + 2:D + 3]}
 
         def fin(key, idx):
             if key not in gr or ctx.meta[idx] is None:
                 return None
             shape, dtype, device = ctx.meta[idx]
-            t = gr[key] * gout.to(device=gr[key].device, dtype=torch.float64)
+            if key in ("w", "amp", "diag_add", "kparam"):
+                t = views[key]
+            else:
+                t = gr[key] * gout.to(device=gr[key].device, dtype=torch.float64)
             if key == "w" and math.prod(shape) == 1 and t.numel() > 1:
                 t = t.sum().reshape(1)  # a scalar length scale was broadcast over the D input dimensions
             if key == "diag_vec" and len(shape) == 2:
