@@ -1,21 +1,37 @@
 #!/usr/bin/env python3
-"""Headline benchmark: GP NLML + Cholesky throughput (fp64) on MI355X -- BASELINE.json's metric on its config C3
-(single-fidelity cigp, ARD kernel, N = 16384, D = 16, d = 1).
+"""Headline benchmark: GP NLML + Cholesky throughput (fp64) on MI355X -- BASELINE.json's metric.
 
-A step = one pass of the hot path over one GP block: covariance assembly -> blocked Cholesky (Y^T riding as a
-passenger row, so Gamma = L^-1 Y comes out of the factorisation's own GEMMs) -> log-det / ||Gamma||^2 reductions
--> NLML scalar, with X, Y and the hyper-parameters already resident in HBM.  With N > 1 ranks every rank runs one
-such block per step (per-fidelity sharding: independent blocks, no data-path collective) and the F = N per-block
-values are summed by ONE 8*N-byte all-reduce (RCCL) per step -- weak scaling.
+A step = one pass of the hot path over one batch of GP blocks: covariance assembly -> blocked Cholesky (Y^T riding as
+passenger rows, so Gamma = L^-1 Y comes out of the factorisation's own GEMMs) -> log-det / ||Gamma||^2 reductions ->
+NLML scalar, with X, Y and the hyper-parameters already resident in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 16384] [--D 16] [--d 1]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+Workloads (--workload):
+  headline (default)  BASELINE configs[2]: single-fidelity cigp, ARD kernel, N = 16384, D = 16, d = 1 -- one such block
+                      per rank (weak scaling; fidelity f = rank), ONE 8*F-byte all-reduce of the per-block values per step.
+  c2                  BASELINE configs[1]: N = 4096, D = 8, d = 1 (same sharding as headline).
+  cigar4              BASELINE configs[3]: F = 4 fixed blocks of N = 8192, D = 8, d = 1024 (strong scaling).
+  gar8                BASELINE configs[4]: F = 8 fixed blocks of N = 8192, D = 8, d = 4096 (strong scaling).
+For the fixed-F workloads the blocks are dealt to the ranks by longest-processing-time-first
+(fidelityfusion_amd.sharding.partition_lpt -- the reference's per-fidelity loop, FidelityFusion_Models/CIGAR.py:99-134,
+GAR.py:76-126; the sum MFGP_ver2023May/ResGP.py:232-246); a rank that owns several blocks overlaps them on its GPU
+(functional.concurrent_blocks); one all-reduce(SUM) of the F-vector per step.  The default run also times both fixed-F
+workloads for a few steps after the headline and reports them under "sharded", so that one `--gpus N` sweep carries the
+GAR-8 / CIGAR-4 curve next to the headline.
 
-Prints ONE JSON line on rank 0.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload W]
+
+With --gpus N > 1 and no WORLD_SIZE in the environment the script launches its own N ranks (child processes, one per GPU,
+rendezvous on 127.0.0.1) BEFORE importing torch or touching the GPU; under `python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N` it is one of the ranks.  Rank 0 prints ONE JSON line.
+
+--backend gloo --dry runs the launch / partition / all-reduce / JSON plumbing on CPU with a stand-in block value (no GPU,
+no likelihood arithmetic): the CPU test of the multi-rank path (tests/test_bench_launch.py).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,26 +42,73 @@ if ROOT not in sys.path:
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (vendor spec; 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz)
 ROOFLINE_KERNEL = "ffgp_gemm_f64<0, 0, 1, 1, 128, 128>"   # trailing SYRK update of the blocked Cholesky
 
+WORKLOADS = {   # name: (F or None = one block per rank, N, D, d, BASELINE config index)
+    "headline": (None, 16384, 16, 1, 2),
+    "c2": (None, 4096, 8, 1, 1),
+    "cigar4": (4, 8192, 8, 1024, 3),
+    "gar8": (8, 8192, 8, 4096, 4),
+}
 
-def recorded_traffic(n):
-    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/*_pmc_summary.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane streams on
-    gfx950).  bench.py cannot collect PMC counters itself; null when no recorded pass matches this workload."""
-    import glob
-    if n != 16384:
-        return None, None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
-    if not files:
-        return None, None
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="headline")
+    ap.add_argument("--n", type=int, default=None, help="override the workload's N (development)")
+    ap.add_argument("--D", type=int, default=None)
+    ap.add_argument("--d", type=int, default=None)
+    ap.add_argument("--blocks", type=int, default=None, help="override F of a fixed-F workload (development / --dry)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sharded", action="store_true", help="skip the fixed-F legs after the headline")
+    ap.add_argument("--cpu-budget-s", type=float, default=30.0, help="wall-clock bound of the CPU baseline leg")
+    ap.add_argument("--with-grad", action="store_true", help="time forward + closed-form gradients instead")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
+    ap.add_argument("--dry", action="store_true", help="CPU plumbing run (needs --backend gloo): no GPU work")
+    ap.add_argument("--opt", action="append", default=[], help="library option key=value (development A/B runs)")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# self-launch: the parent never imports torch, never touches the GPU, never exec's
+# ---------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
     try:
-        c = json.load(open(files[-1]))["counters"]
-        key = [k for k in c["FETCH_SIZE"] if k.startswith("void " + ROOFLINE_KERNEL)][0]
-        byt = (2.0 * c["FETCH_SIZE"][key]["per_launch"] + c["WRITE_SIZE"][key]["per_launch"]) * 1024.0
-        return byt, os.path.relpath(files[-1], ROOT)
-    except Exception:
-        return None, None
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                r = p.poll()
+                if r is None:
+                    continue
+                pending.remove(p)
+                if r != 0:                  # one rank died: the others would wait in a collective for ever
+                    rc = rc or r
+                    for q in pending:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# workload pieces
+# ---------------------------------------------------------------------------------------------------------------
 def synthetic_xy(n, D, d, seed=0):
     """The benchmark's deterministic workload: X ~ U[0,1)^D, Y = sin(2 pi X w) + 0.1 randn, normalised
     the way FidelityFusion_Models/MF_data.py:26-28 normalises y (mean / unbiased std over all entries)."""
@@ -58,45 +121,84 @@ def synthetic_xy(n, D, d, seed=0):
     return X, Y
 
 
+def synthetic_xy_device(n, D, d, seed, dev):
+    """Same recipe generated on the device (the d = 4096 blocks of the fixed-F workloads: 268 MB of targets each)."""
+    import math
+    import torch
+    g = torch.Generator(device=dev).manual_seed(1000 + seed)
+    X = torch.rand((n, D), generator=g, device=dev, dtype=torch.float64)
+    W = torch.rand((D, d), generator=g, device=dev, dtype=torch.float64)
+    Y = torch.sin(2.0 * math.pi * (X @ W)) + 0.1 * torch.randn((n, d), generator=g, device=dev, dtype=torch.float64)
+    Y = (Y - Y.mean()) / (Y.std() + 1e-10)
+    return X, Y
+
+
 def nlml_flops(n, D, d):
     """N^3/3 (Cholesky) + N^2 d (Gamma = L^-1 Y) + 2 N^2 D (distance contractions)."""
     return n ** 3 / 3.0 + float(n) * n * d + 2.0 * n * n * D
 
 
-def cpu_baseline(D, d, n_sample):
-    """The oracle ("port" of the reference's torch-CPU path) timed on this box's host cores on a bounded sample."""
-    import numpy as np
-    from oracle import gp_oracle as O
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    X, Y = synthetic_xy(n_sample, D, d, seed=0)
-    ls, sv, lb = np.ones(D), [1.0], [1.0]
-    O.nlml_forward_ard(X[:512], Y[:512], ls, sv, lb)   # warm the BLAS threads
-    t0 = time.perf_counter()
-    ll = O.nlml_forward_ard(X, Y, ls, sv, lb)
-    dt = time.perf_counter() - t0
-    return {"value": round(nlml_flops(n_sample, D, d) / dt / 1e9, 2), "unit": "GF/s", "cores": int(cores), "kind": "port",
-            "sample": "1 NLML forward of the oracle at N=%d D=%d d=%d (%.2f s), numpy/OpenBLAS" % (n_sample, D, d, dt),
-            "ll": float(ll)}
+def recorded_traffic(n):
+    """HBM bytes per launch of the roofline kernel, REPLAYED from the committed rocprofv3 PMC passes of this same
+    command (profiles/*_pmc_summary.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane streams on
+    gfx950) -- bench.py cannot collect PMC counters itself.  None when no recorded pass covers this workload; raises
+    if a recorded pass exists but no longer contains the roofline kernel (a renamed kernel must not go unnoticed)."""
+    import glob
+    if n != 16384:
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None, None
+    c = json.load(open(files[-1]))["counters"]
+    keys = [k for k in c["FETCH_SIZE"] if k.startswith("void " + ROOFLINE_KERNEL)]
+    if not keys:
+        raise RuntimeError("%s holds no counters for the roofline kernel %s -- re-record the PMC pass"
+                           % (files[-1], ROOFLINE_KERNEL))
+    byt = (2.0 * c["FETCH_SIZE"][keys[0]]["per_launch"] + c["WRITE_SIZE"][keys[0]]["per_launch"]) * 1024.0
+    return byt, os.path.relpath(files[-1], ROOT)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=16384)
-    ap.add_argument("--D", type=int, default=16)
-    ap.add_argument("--d", type=int, default=1)
-    ap.add_argument("--cpu-sample-n", type=int, default=8192)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--with-grad", action="store_true", help="time forward + closed-form gradients instead")
-    ap.add_argument("--opt", action="append", default=[], help="library option key=value (development A/B runs)")
-    args = ap.parse_args()
+def cpu_baseline(budget_s, gpu_nll):
+    """The reference's torch-CPU operator sequence (oracle/torch_cpu_ref.py: cdist -> exp -> eye adds -> linalg.cholesky
+    -> solve_triangular -> V1 formula; autograd for the backward) timed on this box's host cores at C2 and C3 (SURVEY
+    8d), 1 warm-up + min of 3 where the budget allows, next to the GPU's value on the same inputs (in-run parity)."""
+    import torch
+    from oracle import torch_cpu_ref as T
+    torch.set_num_threads(os.cpu_count() or 1)
+    host = T.host_description()
+    out = {"unit": "GF/s", "cores": int(torch.get_num_threads()), "kind": "port", "host": host, "configs": {}}
+    t_leg = time.perf_counter()
+    for name, share in (("c2", 0.25), ("headline", 1.0)):
+        _, n, D, d, _ = WORKLOADS[name]
+        left = budget_s - (time.perf_counter() - t_leg)
+        if left < 1.0:
+            break
+        X, Y = synthetic_xy(n, D, d, seed=0)
+        Xt, Yt = torch.tensor(X), torch.tensor(Y)
+        one = lambda k: torch.ones(k, dtype=torch.float64)
+        r = T.time_cigp(Xt, Yt, one(D), one(1), one(1), repeats=3, with_backward=True, budget_s=left * share)
+        fl = nlml_flops(n, D, d)
+        c = {"N": n, "D": D, "d": d, "fwd_ms": round(r["fwd_s"] * 1e3, 2), "fwd_gflops": round(fl / r["fwd_s"] / 1e9, 1),
+             "fwd_bwd_ms": None if r["fwd_bwd_s"] is None else round(r["fwd_bwd_s"] * 1e3, 2),
+             "fwd_bwd_gflops": None if r["fwd_bwd_s"] is None else round(3.0 * fl / r["fwd_bwd_s"] / 1e9, 1),
+             "stage_ms": None if r["stages_s"] is None else {k: round(v * 1e3, 2) for k, v in r["stages_s"].items()},
+             "cpu_ll": r["ll"]}
+        if gpu_nll.get(name) is not None:    # cigp returns +LL = -nll: same inputs, same parameters
+            c["gpu_ll"] = -gpu_nll[name]
+            c["rel_err"] = abs(c["gpu_ll"] - c["cpu_ll"]) / abs(c["cpu_ll"])
+        out["configs"][name] = c
+    best = out["configs"].get("headline") or out["configs"].get("c2")
+    out["value"] = best["fwd_gflops"] if best else None
+    out["sample"] = ("torch-CPU port of cigp.negative_log_likelihood (oracle/torch_cpu_ref.py), fp64, %d threads, %s, %s: "
+                     "forward at N=%d (min of up to 3 after a warm-up); per-config fwd / fwd+bwd / stages under configs"
+                     % (out["cores"], host["cpu_model"], host["blas"], best["N"] if best else 0))
+    return out
 
+
+# ---------------------------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------------------------
+def run_rank(args):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -104,97 +206,201 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N ranks, or drop WORLD_SIZE to let bench.py "
+                         "launch them itself)" % (args.gpus, world))
+    if args.dry:
+        if args.backend != "gloo":
+            raise SystemExit("bench.py: --dry is the CPU plumbing run; use it with --backend gloo")
+        dev = torch.device("cpu")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path; --dry only checks plumbing)"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    coll = {"backend": (dist.get_backend() if world > 1 else None), "ranks": (dist.get_world_size() if world > 1 else 1)}
 
-    from fidelityfusion_amd import _lib
-    from fidelityfusion_amd import functional as F
-    for kv in args.opt:   # development switches (tools/): --opt la_split=1 --opt tile32_threshold=0 ...
-        key, val = kv.split("=")
-        _lib.set_option(key, float(val), local_rank)
+    if not args.dry:
+        from fidelityfusion_amd import _lib
+        from fidelityfusion_amd import functional as F
+        for kv in args.opt:   # development switches (tools/): --opt la_split=1 --opt tile32_threshold=0 ...
+            key, val = kv.split("=")
+            _lib.set_option(key, float(val), local_rank)
+    from fidelityfusion_amd.sharding import block_cost, partition_lpt
 
-    n, D, d = args.n, args.D, args.d
-    # one independent block per rank (fidelity f = rank): same shape, different seed
-    X, Y = synthetic_xy(n, D, d, seed=rank)
-    Xd = torch.tensor(X, dtype=torch.float64, device=dev)
-    Yd = torch.tensor(Y, dtype=torch.float64, device=dev, requires_grad=args.with_grad)
-    # reference initial hyper-parameters: length_scales = 1 (kernel.py:84), signal_variance = 1, log_beta = 1 (ResGP.py:27)
-    w = torch.ones(D, dtype=torch.float64, device=dev, requires_grad=args.with_grad)
-    amp = torch.ones(1, dtype=torch.float64, device=dev, requires_grad=args.with_grad)
-    dadd = torch.tensor([np.exp(-1.0) + 1e-6], dtype=torch.float64, device=dev, requires_grad=args.with_grad)
-    joint = torch.zeros(world, dtype=torch.float64, device=dev)
-
-    def step():
-        nll = F.nlml(Xd, Yd, w, amp, diag_add=dadd, clamp=1e-30)
-        if world > 1:
-            joint.zero_()
-            joint[rank] = nll.detach()
-            dist.all_reduce(joint)      # the joint NLML: one 8*F-byte sum over xGMI
-        return nll
+    red_dev = dev if (args.backend == "nccl" and not args.dry) else torch.device("cpu")
 
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not args.dry:
+            torch.cuda.synchronize()
 
+    def params(D):
+        # reference initial hyper-parameters: length_scales = 1 (kernel.py:84), signal_variance = 1, log_beta = 1 (ResGP.py:27)
+        w = torch.ones(D, dtype=torch.float64, device=dev, requires_grad=args.with_grad)
+        amp = torch.ones(1, dtype=torch.float64, device=dev, requires_grad=args.with_grad)
+        dadd = torch.tensor([np.exp(-1.0) + 1e-6], dtype=torch.float64, device=dev, requires_grad=args.with_grad)
+        return w, amp, dadd
+
+    def make_workload(name, n=None, D=None, d=None, blocks=None):
+        """-> (step(), F_total, n, D, d, scaling): step() evaluates this rank's blocks and all-reduces the F-vector."""
+        F_fixed, n0, D0, d0, _ = WORKLOADS[name]
+        n, D, d = n or n0, D or D0, d or d0
+        if F_fixed is None:                                   # one block per rank: fidelity f = rank
+            F_total, mine, scaling = world, [rank], "weak"
+        else:
+            F_total = blocks or F_fixed
+            owner = partition_lpt([block_cost(n, d)] * F_total, world)
+            mine, scaling = [f for f in range(F_total) if owner[f] == rank], "strong"
+        joint = torch.zeros(F_total, dtype=torch.float64, device=red_dev)
+        if args.dry:
+            data = {f: synthetic_xy(n, D, d, seed=f) for f in mine}
+
+            def step():                                       # stand-in block value: plumbing only
+                joint.zero_()
+                for f in mine:
+                    joint[f] = float(np.square(data[f][1]).sum()) + f
+                if world > 1:
+                    dist.all_reduce(joint)
+                return joint
+            return step, F_total, n, D, d, scaling
+        data = {}
+        for f in mine:
+            if d <= 16:   # host recipe: the CPU baseline leg reads the very same numbers
+                X, Y = synthetic_xy(n, D, d, seed=f)
+                data[f] = (torch.tensor(X, dtype=torch.float64, device=dev), torch.tensor(Y, dtype=torch.float64, device=dev))
+            else:
+                data[f] = synthetic_xy_device(n, D, d, f, dev)
+            if args.with_grad:
+                data[f][1].requires_grad_(True)
+        w, amp, dadd = params(D)
+        nslots = max(1, min(3, len(mine)))
+
+        def step():
+            vals = {}
+            if len(mine) == 1:
+                f = mine[0]
+                vals[f] = F.nlml(data[f][0], data[f][1], w, amp, diag_add=dadd, clamp=1e-30)
+            elif mine:   # several owned blocks overlap on this GPU
+                ctx = torch.enable_grad() if args.with_grad else torch.no_grad()
+                with ctx, F.concurrent_blocks(nslots=nslots, device_index=local_rank) as cb:
+                    for i, f in enumerate(mine):
+                        with cb.slot(i):
+                            vals[f] = F.nlml(data[f][0], data[f][1], w, amp, diag_add=dadd, clamp=1e-30, **F._slot_args())
+            joint.zero_()
+            for f, v in vals.items():
+                joint[f] = v.detach()
+            if world > 1:
+                dist.all_reduce(joint)      # the joint NLML: one 8*F-byte sum over xGMI
+            return joint
+        return step, F_total, n, D, d, scaling
+
+    def timed(step, steps, warmup):
+        for _ in range(warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            joint = step()
+        fence()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t), joint.clone()
+
+    # ---- the timed workload ------------------------------------------------------------------------------------
+    step, F_total, n, D, d, scaling = make_workload(args.workload, args.n, args.D, args.d, args.blocks)
     for _ in range(args.warmup):
         step()
-    _lib.set_option("timing", 2, local_rank)     # event pairs around every trailing-update launch (no host syncs)
-    _lib.syrk_stats(reset=True, device_index=local_rank)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        nll = step()
-    fence()
-    dt = time.perf_counter() - t0
-    stats = _lib.syrk_stats(reset=True, device_index=local_rank)
-    _lib.set_option("timing", 1, local_rank)
-    step()
-    stages = _lib.last_timings(local_rank)
-    _lib.set_option("timing", 0, local_rank)
-
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax)
+    if not args.dry:
+        _lib.set_option("timing", 2, local_rank)     # event pairs around every trailing-update launch (no host syncs)
+        _lib.syrk_stats(reset=True, device_index=local_rank)
+    dt, joint = timed(step, args.steps, 0)
+    stats, stages = {"flops": 0.0, "ms": 0.0, "launches": 0}, {}
+    if not args.dry:
+        stats = _lib.syrk_stats(reset=True, device_index=local_rank)
+        if WORKLOADS[args.workload][0] is None:
+            _lib.set_option("timing", 1, local_rank)
+            step()
+            stages = _lib.last_timings(local_rank)
+        _lib.set_option("timing", 0, local_rank)
     ms_per_step = dt / args.steps * 1e3
-    flops_step = nlml_flops(n, D, d) * (3.0 if args.with_grad else 1.0)  # fwd+bwd ~ N^3
-    value = flops_step * world / (dt / args.steps) / 1e9
+    flops_step = nlml_flops(n, D, d) * (3.0 if args.with_grad else 1.0) * F_total   # fwd+bwd ~ N^3 (SURVEY 8d)
+    value = flops_step / (dt / args.steps) / 1e9
+    stock = args.n is None and args.D is None and args.d is None and args.blocks is None
+    gpu_nll = {args.workload: float(joint[0])} if args.workload in ("headline", "c2") and stock else {}
+
+    # ---- the fixed-F sharding workloads, a few steps each (default run only) ----------------------------------------
+    sharded = {}
+    if args.workload == "headline" and not args.no_sharded and not args.with_grad and (stock or args.dry):
+        del step
+        if not args.dry:
+            torch.cuda.empty_cache()
+        for name in ("cigar4", "gar8"):
+            kw = dict(n=64, d=8) if args.dry else {}
+            s_step, sF, sn, sD, sd, _ = make_workload(name, **kw)
+            sdt, sjoint = timed(s_step, 3, 1)
+            sharded[name] = {"blocks": sF, "N": sn, "D": sD, "d": sd, "ms_per_step": round(sdt / 3 * 1e3, 3),
+                             "value": round(nlml_flops(sn, sD, sd) * sF / (sdt / 3) / 1e9, 1), "unit": "GF/s", "scaling": "strong",
+                             "blocks_per_rank": -(-sF // world), "joint_nll": float(sjoint.sum()),
+                             "config": "BASELINE configs[%d]" % WORKLOADS[name][4]}
+            del s_step
+            if not args.dry:
+                torch.cuda.empty_cache()
+        if not args.dry and not args.no_cpu_baseline and world == 1:   # C2 on the GPU, for the in-run parity column
+            c_step, *_ = make_workload("c2")
+            gpu_nll["c2"] = float(c_step()[0])
 
     if rank == 0:
         achieved = stats["flops"] / (stats["ms"] * 1e-3) / 1e12 if stats["ms"] > 0 else 0.0
-        traffic, traffic_src = recorded_traffic(n)
+        traffic, traffic_src = (None, None) if args.dry else recorded_traffic(n)
+        cfg_idx = WORKLOADS[args.workload][4] if stock else None
         out = {
             "metric": "GP NLML+Cholesky throughput (NxN fp64 GF/s, %%MFMA-roofline) at N=%d" % n,
             "value": round(value, 1), "unit": "GF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "single-fidelity cigp NLML %s, ARD kernel, N=%d D=%d d=%d per GPU%s"
-                                   % ("forward+gradients" if args.with_grad else "forward", n, D, d,
-                                      " (BASELINE configs[2])" if (n, D, d) == (16384, 16, 1) else
-                                      " (BASELINE configs[1])" if (n, D, d) == (4096, 8, 1) else ""),
-                       "N": n, "D": D, "d": d, "blocks": world, "parallelism": "fidelity-shard x%d" % world},
+            "config": {"workload": "%s: %s NLML %s, ARD kernel, %d block%s of N=%d D=%d d=%d%s"
+                                   % (args.workload, "single-fidelity cigp" if F_total == world and scaling == "weak" else "per-fidelity cigp blocks,",
+                                      "forward+gradients" if args.with_grad else "forward", F_total, "" if F_total == 1 else "s", n, D, d,
+                                      " (BASELINE configs[%d])" % cfg_idx if cfg_idx is not None else ""),
+                       "N": n, "D": D, "d": d, "blocks": F_total,
+                       "parallelism": "fidelity-shard x%d (LPT partition, one %d-byte all-reduce per step)" % (world, 8 * F_total)},
+            "collective": coll,
+            "rccl_ranks": coll["ranks"] if coll["backend"] == "nccl" else 0,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "traffic_unit": "bytes/launch (PMC, recorded)", "traffic_source": traffic_src,
+                         "traffic_unit": "bytes/launch (PMC pass of this command, replayed from the committed profile)",
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": round(8.0 * stats["flops"] / max(stats["launches"], 1) / 512.0 * (1.0 + 1.0 / 16.0)),
                          "kernel": ROOFLINE_KERNEL + " (trailing SYRK update of the blocked Cholesky, K = 512)",
                          "launches": stats["launches"], "avg_launch_ms": round(stats["ms"] / max(stats["launches"], 1), 4),
                          "avg_launch_gflop": round(stats["flops"] / max(stats["launches"], 1) / 1e9, 3)},
             "whole_path_frac_of_mfma_peak": round(value / world / 1e3 / FP64_MFMA_PEAK_TFLOPS, 4),
             "stage_ms": {k: round(v, 3) for k, v in stages.items()},
-            "nll": float(nll),
+            "nll": float(joint[0]), "joint_nll": float(joint.sum()),
         }
-        if not args.no_cpu_baseline and world == 1:   # reported on rank 0 of the single-GPU run only
-            out["cpu_baseline"] = cpu_baseline(D, d, min(args.cpu_sample_n, n))
-        print(json.dumps(out))
+        if sharded:
+            out["sharded"] = sharded
+        if not args.no_cpu_baseline and world == 1 and not args.dry:   # reported on rank 0 of the single-GPU run only
+            out["cpu_baseline"] = cpu_baseline(args.cpu_budget_s, gpu_nll)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))          # before torch is imported: the parent never initialises the GPU
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -66,6 +66,7 @@ EXPORTS = {
                                     C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]),
     "ffgp_rows_in": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_int, C.c_int, _dp]),
     "ffgp_trtri_diag": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int]),
+    "ffgp_invalidate": (C.c_int, [C.c_void_p]),
     "ffgp_trsm_lower": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int]),
     "ffgp_trsm_lower_t": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int]),
     "ffgp_potrs": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int]),
@@ -117,7 +118,11 @@ def check(rc, what):
 
 def handle(device_index=None, slot=0):
     """ffgp handles of this process: one per (GPU, slot).  Slot 0 is the default; extra slots carry independent
-    GP blocks that should overlap on the same GPU (each handle owns its workspace and side stream)."""
+    GP blocks that should overlap on the same GPU (each handle owns its workspace and side stream).
+
+    Threading rule (include/ffgp.h): a handle carries mutable state (stream binding, workspaces, cached inverses), so one
+    host thread at a time per handle.  The handles here are process-wide: a second Python thread that drives the GPU path
+    concurrently must use its own slot(s) -- `functional.nlml(..., slot=k)` / `concurrent_blocks` -- not slot 0."""
     import torch
 
     if not torch.cuda.is_available():

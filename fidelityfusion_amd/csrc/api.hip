@@ -343,6 +343,15 @@ int ffgp_trtri_diag(ffgp_handle* h, const double* L, int n, int ldl) {
   return ffgp_refresh_dinv(h, L, n, ldl);
 }
 
+int ffgp_invalidate(ffgp_handle* h) {
+  if (!h) return FFGP_ERR_ARG;
+  h->dinv_L = nullptr;   // both stores are keyed on the factor's address: forget it, the next solve rebuilds them
+  h->dinv_n = 0;
+  h->sinv_L = nullptr;
+  h->sinv_n = 0;
+  return FFGP_OK;
+}
+
 int ffgp_potri(ffgp_handle* h, double* L, int n, int ldl) {
   if (!h || !L || n <= 0) return FFGP_ERR_ARG;
   FFGP_HIP(hipSetDevice(h->device));

@@ -35,6 +35,34 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def _check_xy(X, Y=None, what="x_train"):
+    """The library reads raw device pointers: every size it derives them from is checked here first (the reference fails
+    with a broadcast / solve error on the same mistakes; an unchecked mismatch would be an out-of-bounds device read)."""
+    if X.dim() != 2:
+        raise ValueError("%s must be 2-D [N, D], got shape %s" % (what, tuple(X.shape)))
+    if Y is not None:
+        if Y.dim() != 2:
+            raise ValueError("y_train must be 2-D [N, d], got shape %s" % (tuple(Y.shape),))
+        if Y.shape[0] != X.shape[0]:
+            raise ValueError("y_train has %d rows for %d training inputs" % (Y.shape[0], X.shape[0]))
+
+
+def _check_same_D(a, b, what="x_test"):
+    if b.dim() != 2 or b.shape[1] != a.shape[1]:
+        raise ValueError("%s must be [*, %d] like the training inputs, got shape %s" % (what, a.shape[1], tuple(b.shape)))
+
+
+def _weights(w, D, dev):
+    """[D] inverse length scales on the device: one value is broadcast over the input dimensions, D values are taken as
+    they are, anything else (e.g. ARDKernel(input_dim=3) on 5-D inputs) is the caller's mistake."""
+    wd = _dev(w.reshape(-1), dev)
+    if wd.numel() == 1 and D > 1:
+        wd = wd.expand(D).contiguous()
+    if wd.numel() != D:
+        raise ValueError("the kernel has %d length scales but the inputs have %d dimensions" % (wd.numel(), D))
+    return wd
+
+
 def _raise_not_pd(rc, what):
     raise torch.linalg.LinAlgError(
         "%s: The factorization could not be completed because the input is not positive-definite "
@@ -44,12 +72,18 @@ def _raise_not_pd(rc, what):
 def _problem(dev, X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, variant, pi_const, keep,
              kfun=(0, 1.0)):
     Xd, Yd = _dev(X, dev), _dev(Y, dev)
+    _check_xy(Xd, Yd)
     n, D = Xd.shape
     d = Yd.shape[1]
-    wd = _dev(w.reshape(-1), dev)
-    if wd.numel() == 1 and D > 1:
-        wd = wd.expand(D).contiguous()
+    wd = _weights(w, D, dev)
     ad = _dev(amp.reshape(-1)[:1], dev)
+    if ad.numel() != 1:
+        raise ValueError("the kernel amplitude must hold one value, got shape %s" % (tuple(amp.shape),))
+    if diag_vec is not None and tuple(diag_vec.shape) not in ((n,), (n, n)):
+        raise ValueError("y_var / diag_vec must be [%d] or [%d, %d] for %d training points, got %s"
+                         % (n, n, n, n, tuple(diag_vec.shape)))
+    if add_mat is not None and tuple(add_mat.shape) != (n, n):
+        raise ValueError("y_var / add_mat must be [%d, %d], got %s" % (n, n, tuple(add_mat.shape)))
     p = Problem()
     p.n, p.D, p.d = n, D, d
     p.X_dev, p.Y_dev, p.w_dev, p.amp_dev = _ptr(Xd), _ptr(Yd), _ptr(wd), _ptr(ad)
@@ -95,7 +129,10 @@ class _NLML(torch.autograd.Function):
         keep = []
         p, (n, D, d) = _problem(dev, X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, variant,
                                 pi_const, keep, kfun)
-        needs = [isinstance(t, torch.Tensor) and t.requires_grad for t in (Y, w, amp, diag_add, diag_vec, kparam)]
+        # ctx.needs_input_grad is all False under torch.no_grad() (evaluation of a model whose nn.Parameters still carry
+        # requires_grad = True): the gradient pipeline (TRTRI, LAUUM, A A^T, gradient tiles: 2x the forward's flops and
+        # 2-3 more N x ld workspaces) only runs when autograd will actually ask for it
+        needs = [bool(ctx.needs_input_grad[i]) for i in (1, 2, 3, 4, 5, 15)]    # Y, w, amp, diag_add, diag_vec, kparam
         out = torch.empty((), dtype=torch.float64, device=dev)
         g = None
         grads = {}
@@ -272,6 +309,7 @@ def predict(X, Y, Xs, w, amp, diag_add=None, diag_vec=None, add_mat=None, add_al
     p, (n, D, d) = _problem(dev, X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, FFGP_LL_V1,
                             PI_TRUNC, keep, kfun)
     Xsd = _dev(Xs, dev)
+    _check_same_D(keep[0], Xsd)
     nt = Xsd.shape[0]
     mean = torch.empty((nt, d), dtype=torch.float64, device=dev)
     var = torch.empty((nt, nt) if full_cov else (nt,), dtype=torch.float64, device=dev)
@@ -296,10 +334,10 @@ class _KernelMatrix(torch.autograd.Function):
         a, b = _dev(x1, dev), _dev(x2, dev)
         if a.dim() > 2:  # SE_kernel.py:29-32 flattens >2-D inputs
             a, b = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+        _check_xy(a, what="x1")
+        _check_same_D(a, b, "x2")
         D = a.shape[1]
-        wd = _dev(w.reshape(-1), dev)
-        if wd.numel() == 1 and D > 1:
-            wd = wd.expand(D).contiguous()
+        wd = _weights(w, D, dev)
         ad = _dev(amp.reshape(-1)[:1], dev)
         K = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float64, device=dev)
         check(lib.ffgp_assemble(h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], D, _ptr(wd), _ptr(ad), clamp, None, None, 0, None,
@@ -498,7 +536,7 @@ class _GaussNLLFromCov(torch.autograd.Function):
         out = torch.empty((), dtype=torch.float64, device=dev)
         g = None
         ctx.grads = {}
-        if Y.requires_grad or cov.requires_grad:
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:   # all False under torch.no_grad()
             g = Grads()
             ctx.grads["Y"] = torch.empty((n, d), dtype=torch.float64, device=dev)
             ctx.grads["cov"] = torch.empty((n, n), dtype=torch.float64, device=dev)
@@ -512,7 +550,10 @@ class _GaussNLLFromCov(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         outs = []
-        for key, (shape, dtype, device) in zip(("Y", "cov"), ctx.meta):
+        for i, (key, (shape, dtype, device)) in enumerate(zip(("Y", "cov"), ctx.meta)):
+            if not ctx.needs_input_grad[i]:
+                outs.append(None)
+                continue
             t = ctx.grads[key] * gout.to(device=ctx.grads[key].device, dtype=torch.float64)
             outs.append(t.reshape(shape).to(device=device, dtype=dtype))
         return outs[0], outs[1], None, None
@@ -634,13 +675,15 @@ class Posterior:
         self.kfun, _ = _split_kfun(kfun)
         self.clamp = clamp
         Xd, Yd = _dev(X, dev), _dev(Y, dev)
+        _check_xy(Xd, Yd)
         n, D = Xd.shape
         d = Yd.shape[1]
-        wd = _dev(w.reshape(-1), dev)
-        self.w = wd.expand(D).contiguous() if wd.numel() == 1 and D > 1 else wd
+        self.w = _weights(w, D, dev)
         self.amp = _dev(amp.reshape(-1)[:1], dev)
         self.dadd = _dev(diag_add.reshape(-1)[:1], dev)
         Xq = _dev(first_query, dev) if first_query is not None else None
+        if Xq is not None:
+            _check_same_D(Xd, Xq)
         nt = Xq.shape[0] if Xq is not None else 0
         self.cap = max(int(capacity or 0), n)
         self.ld = _pad_ld(self.cap)
@@ -689,6 +732,7 @@ class Posterior:
         (`var_add_all` lands on every entry, cigp_v10.py:44)."""
         dev, n = self.dev, self.n
         Xsd = _dev(Xs, dev)
+        _check_same_D(self.X, Xsd)
         nt = Xsd.shape[0]
         if self.alpha is None:
             self._solve_alpha()
@@ -710,6 +754,7 @@ class Posterior:
         the model's own forward under autograd when their gradients are wanted as well."""
         dev, n = self.dev, self.n
         Xsd = Xs.to(device=dev, dtype=torch.float64)
+        _check_same_D(self.X, Xsd)
         Ks = kernel_matrix(self.X[:n], Xsd, self.w, self.amp, self.clamp, kfun=self.kfun)
         if full_cov:
             Kss = kernel_matrix(Xsd, Xsd, self.w, self.amp, self.clamp, kfun=self.kfun)
@@ -724,6 +769,9 @@ class Posterior:
         block a k x k Cholesky of the Schur complement."""
         dev, n, h = self.dev, self.n, self._h()
         Xn, Yn = _dev(X_new, dev), _dev(Y_new, dev)
+        _check_same_D(self.X, Xn, "X_new")
+        if Yn.dim() != 2 or Yn.shape != (Xn.shape[0], self.d):
+            raise ValueError("Y_new must be [%d, %d], got shape %s" % (Xn.shape[0], self.d, tuple(Yn.shape)))
         k = Xn.shape[0]
         if n + k > self.cap or n + k > self.W.shape[0]:       # grow geometrically; the factor is copied once
             cap = max(n + k, 2 * self.cap)
@@ -761,13 +809,20 @@ class Posterior:
 class PosteriorCache:
     """Keeps the `Posterior` of a model while the SAME tensor objects (training inputs, targets, every parameter) come
     back with unchanged in-place version counters: in-place updates bump `_version`, `p.data = ...` moves the pointer,
-    and weak references make sure a recycled address can never alias.  Not part of a model's state (pickles empty)."""
+    and weak references make sure a recycled address can never alias.  Not part of a model's state (pickles empty).
+
+    Invalidation rule: edits that bypass the version counter -- `p.data.copy_(...)`, `.data.clamp_()`, writes through a
+    numpy array that shares the tensor's memory (`torch.from_numpy`) -- are NOT seen; call the model's
+    `clear_posterior_cache()` after such an edit (the reference refactorises on every call and needs no such rule).  The
+    cache pins one N x N fp64 factor per model (2 GB at N = 16384); `clear_posterior_cache()` releases it, and
+    `model.cache_posterior = False` turns the cache off for that model (every call refactorises, as the reference)."""
 
     def __init__(self):
         self._c = None
+        self.enabled = True
 
     def __getstate__(self):
-        return {"_c": None}
+        return {"_c": None, "enabled": self.enabled}
 
     def get(self, objs, build):
         """(posterior, fresh): the cached one if `objs` are unchanged, else `build()` (which is then cached)"""
@@ -776,7 +831,7 @@ class PosteriorCache:
         if c is not None and len(c[0]) == len(objs) and all(r() is t for r, t in zip(c[0], objs)) and c[1] == vers:
             return c[2], False
         post = build()
-        self._c = ([weakref.ref(t) for t in objs], vers, post)
+        self._c = ([weakref.ref(t) for t in objs], vers, post) if self.enabled else None
         return post, True
 
     @property
@@ -785,6 +840,23 @@ class PosteriorCache:
 
     def clear(self):
         self._c = None
+
+
+class PosteriorCacheMixin:
+    """`clear_posterior_cache()` / `cache_posterior` for the GP modules that keep a `_pcache` (see PosteriorCache)."""
+
+    def clear_posterior_cache(self):
+        self._pcache.clear()
+
+    @property
+    def cache_posterior(self):
+        return self._pcache.enabled
+
+    @cache_posterior.setter
+    def cache_posterior(self, on):
+        self._pcache.enabled = bool(on)
+        if not on:
+            self._pcache.clear()
 
 
 @torch.no_grad()

@@ -17,9 +17,14 @@ backward is closed-form (`_KronNLL`): GEMMs only, no differentiation through `ei
 
 Kept quirks: ONE kernel module is shared by the input space and every output mode (:27-29); the per-mode grids are
 0..d-1 as float columns; `forward` needs `log_likelihood` to have been called (it reads the cached `K`, `K_eigen`,
-`A`, `g`); the "variance" is diag(K) + (A-weighted squared eigenvector products) (:60-75).  One deliberate difference:
-`K_x.inverse() @ U_x` (:68) is evaluated as `U_x / lambda_x` -- the same matrix, without inverting a numerically
-singular K_x.
+`A`, `g`); the "variance" is diag(K) + (A-weighted squared eigenvector products) (:60-75).
+
+`variance_mode` (constructor keyword, attribute): "reference" (default) evaluates `K_star @ K_x.inverse() @ U_x` as the
+reference writes it (:68) -- an explicit LU inverse of the jitter-free kernel matrix (cond ~1e13 on the fixtures; the
+device's getrf/getri, a one-off O(N^3) outside the likelihood) followed by two GEMMs; "eigen" evaluates the same matrix
+as `K_star @ (U_x / lambda_x)` from the eigenpairs already cached, without inverting a numerically singular K_x.  The
+two agree to ~cond * eps; which one is "right" is moot (the expression is not a variance), the default is the
+reference's arithmetic.
 """
 import math
 
@@ -149,8 +154,12 @@ def kron_nll(y, tau, Ks):
 
 
 class HOGP_simple(nn.Module):
-    def __init__(self, kernel, noise_variance, output_shape, learnable_grid=False, learnable_map=False):
+    def __init__(self, kernel, noise_variance, output_shape, learnable_grid=False, learnable_map=False,
+                 variance_mode="reference"):
         super().__init__()
+        if variance_mode not in ("reference", "eigen"):
+            raise ValueError("variance_mode must be 'reference' or 'eigen', got %r" % (variance_mode,))
+        self.variance_mode = variance_mode
         self.noise_variance = nn.Parameter(torch.tensor([noise_variance]))
         self.K = []
         self.K_eigen = []
@@ -205,7 +214,11 @@ class HOGP_simple(nn.Module):
         diag_K = diag_K_x * diag_K_dims
         S_2 = (self.A * self.A.pow(-1 / 2)).pow(2)
         e0 = self.K_eigen[0]
-        ev_x = mode_dot(K_star, (e0.vector / e0.value.unsqueeze(0)).T.contiguous(), 1).pow(2)   # (K* K_x^-1 U_x)^2 = (K* U_x / lambda)^2
+        if self.variance_mode == "reference":   # K_star @ K_x.inverse() @ U_x, the reference's own order of operations (:68)
+            K_inv = torch.linalg.inv(self.K[0].detach() if not torch.is_grad_enabled() else self.K[0])
+            ev_x = F.matmul_nt(F.matmul_nt(K_star, K_inv.T.contiguous()), e0.vector.T.contiguous()).pow(2)
+        else:                                   # the same matrix from the cached eigenpairs: K_x^-1 U_x = U_x / lambda
+            ev_x = mode_dot(K_star, (e0.vector / e0.value.unsqueeze(0)).T.contiguous(), 1).pow(2)
         evs = [ev_x] + [self.K_eigen[i + 1].vector.pow(2) for i in range(n_dim)]
         var_diag = diag_K + multi_mode_dot(S_2, evs)
         odt = x_test.dtype if x_test.dtype.is_floating_point else torch.float64

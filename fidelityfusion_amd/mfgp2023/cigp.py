@@ -92,7 +92,7 @@ def _flat(x):
     return x.reshape(x.shape[0], -1) if x.dim() > 2 else x
 
 
-class CIGP(torch.nn.Module):
+class CIGP(F.PosteriorCacheMixin, torch.nn.Module):
     def __init__(self, gp_model_config=None):
         super().__init__()
         self.gp_model_config = _merge(default_config, gp_model_config)

@@ -12,7 +12,10 @@
  *     positive definite -- torch.linalg.cholesky raises torch.linalg.LinAlgError there); < 0 = FFGP_ERR_*;
  *   - work is enqueued on the handle's stream (ffgp_set_stream); calls that return a status derived from
  *     device data (ffgp_potrf, ffgp_nlml_fused, ffgp_predict) synchronise that stream before returning;
- *   - nothing here falls back to the CPU: without a gfx950 device ffgp_create fails.
+ *   - nothing here falls back to the CPU: without a gfx950 device ffgp_create fails;
+ *   - THREADING: a handle owns mutable state (its stream binding, workspaces, the cached inverses) that calls modify while
+ *     they run; at most ONE host thread may be inside a call on a given handle at any time.  Use one handle per thread
+ *     (handles are cheap: two streams + workspaces grown on demand), or serialise calls on a shared one.
  *
  * Parameterisation.  All of the reference's stationary kernels on this path are
  *        K_ij = amp * exp(-1/2 * max(sum_k ((x_ik - x_jk) * w_k)^2, clamp_min))
@@ -193,8 +196,17 @@ int ffgp_kernel_input_weights(ffgp_handle* h, const double* X1_dev, int n1, cons
                               const double* dK_dev, int ldk, double* Wt_dev, int ldw);
 
 /* Rebuild the handle's store of inverted 128x128 diagonal blocks for a factor L that this handle did not just
-   produce (the triangular solves and ffgp_potri consume it; ffgp_potrf leaves it up to date).               */
+   produce (the triangular solves and ffgp_potri consume it; ffgp_potrf leaves it up to date).
+   CONTRACT of the cached inverses (ffgp_trsm_lower, ffgp_trsm_lower_t, ffgp_potrs, ffgp_potri): the store -- and the
+   inverted super-blocks built on top of it -- is keyed on (L_dev, n, ldl) only.  A factor passed to those calls must be
+   unmodified since the ffgp_potrf / ffgp_potrf_rows / ffgp_trtri_diag call ON THIS HANDLE that keyed the store.  If the
+   contents at that address changed any other way (a buffer refilled by the caller, a factor written by another handle,
+   a recycled allocation), call ffgp_trtri_diag again (or ffgp_invalidate) before solving with it.              */
 int ffgp_trtri_diag(ffgp_handle* h, const double* L_dev, int n, int ldl);
+
+/* Drop the handle's cached inverses (diagonal blocks and super-blocks): the next triangular solve rebuilds them from
+   the factor it is given.  Cheap; use it whenever a factor buffer is refilled behind the handle's back.        */
+int ffgp_invalidate(ffgp_handle* h);
 
 /* B <- L^-1 B.  Replaces torch.triangular_solve(B, L, upper=False) (cigp_v10.py:36,63;
    gp_computation_pack.py:130) and `L.inverse() @ B` (base_gp/cigp.py:131; gp_computation_pack.py:108).      */

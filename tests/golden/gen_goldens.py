@@ -326,6 +326,28 @@ def main():
         for ln in (201, 401, 601):
             nums = [float(v) for v in re.findall(r"tensor\(\[?(-?\d+\.\d+)", lines[ln - 1])]
             rows[f"line{ln}"] = np.array(nums)
+        # the inputs that log was produced from: the demo's own data recipe (FidelityFusion_Models/ResGP.py:117-133, seed 1,
+        # default dtype fp32 as in the demo), fidelity 0 as the reference's data manager normalises it -- so that a test
+        # can re-run the 200 Adam steps of fidelity 0 on the drop-in and land on the logged parameters
+        _dt = torch.get_default_dtype()
+        torch.set_default_dtype(torch.float32)
+        try:
+            from FidelityFusion_Models.MF_data import MultiFidelityDataManager as _Mgr
+            torch.manual_seed(1)
+            x_all = torch.rand(500, 1) * 20
+            x_low = x_all[torch.sort(torch.randperm(500)[:300]).values]
+            x_h1 = x_all[torch.sort(torch.randperm(500)[:300]).values]
+            x_h2 = x_all[torch.sort(torch.randperm(500)[:250]).values]
+            y_low = torch.sin(x_low) - 0.5 * torch.sin(2 * x_low) + torch.rand(300, 1) * 0.1 - 0.05
+            y_h1 = torch.sin(x_h1) - 0.3 * torch.sin(2 * x_h1) + torch.rand(300, 1) * 0.1 - 0.05
+            y_h2 = torch.sin(x_h2) + torch.rand(250, 1) * 0.1 - 0.05
+            mgr_log = _Mgr([{"raw_fidelity_name": "0", "fidelity_indicator": 0, "X": x_low, "Y": y_low},
+                            {"raw_fidelity_name": "1", "fidelity_indicator": 1, "X": x_h1, "Y": y_h1},
+                            {"raw_fidelity_name": "2", "fidelity_indicator": 2, "X": x_h2, "Y": y_h2}])
+            x0n, y0n = mgr_log.get_data(0, normal=True)
+            rows["x0n"], rows["y0n"] = x0n, y0n
+        finally:
+            torch.set_default_dtype(_dt)
         save("train_log_resgp", **rows)
     except Exception as e:  # noqa
         print("train_log_resgp skipped:", repr(e))

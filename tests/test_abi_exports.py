@@ -66,3 +66,15 @@ def test_product_code_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("# oracle", ""), os.path.join(dirpath, f)
+
+
+def test_host_asan_build_walks_the_no_device_paths():
+    """`make asan` (SURVEY section 5's sanitizer row, CPU side only -- GPU ASAN is not available on the pool): the whole
+    library built with host AddressSanitizer + LeakSanitizer, device code uninstrumented, and a host driver walking the
+    create / argument-check / destroy paths"""
+    import subprocess
+    csrc = os.path.join(ROOT, "fidelityfusion_amd", "csrc")
+    p = subprocess.run(["make", "-C", csrc, "-j8", "asan"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    assert "asan_host_check:" in p.stdout and "clean" in p.stdout
+    assert "ERROR: AddressSanitizer" not in p.stderr and "LeakSanitizer" not in p.stderr

@@ -1,0 +1,81 @@
+"""bench.py's multi-rank path on CPU: `python bench.py --gpus 2 --backend gloo --dry` must launch its own two ranks (the
+parent never imports torch), deal the blocks by LPT, all-reduce the F-vector and print ONE JSON line (rank 0)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra, env_extra=None):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "gloo", "--dry", "--steps", "2", "--warmup",
+                        "1"] + list(extra), env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def _expected_joint(F_, n, D, d):
+    sys.path.insert(0, ROOT)
+    import bench
+    return sum(float(np.square(bench.synthetic_xy(n, D, d, seed=f)[1]).sum()) + f for f in range(F_))
+
+
+def test_self_launch_two_ranks_weak_and_sharded_legs():
+    out = _run("--gpus", "2", "--n", "96")
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["blocks"] == 2
+    assert out["collective"] == {"backend": "gloo", "ranks": 2}
+    for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data",
+                "roofline"):
+        assert key in out
+    assert abs(out["joint_nll"] - _expected_joint(2, 96, 16, 1)) < 1e-9 * abs(out["joint_nll"])
+    # the fixed-F legs ride along: 4 and 8 blocks over 2 ranks, values summed by the all-reduce
+    sh = out["sharded"]
+    assert sh["cigar4"]["blocks"] == 4 and sh["cigar4"]["blocks_per_rank"] == 2 and sh["cigar4"]["scaling"] == "strong"
+    assert sh["gar8"]["blocks"] == 8 and sh["gar8"]["blocks_per_rank"] == 4
+    assert abs(sh["gar8"]["joint_nll"] - _expected_joint(8, 64, 8, 8)) < 1e-9 * abs(sh["gar8"]["joint_nll"])
+
+
+def test_fixed_blocks_same_joint_value_on_1_2_3_ranks():
+    vals = []
+    for g in (1, 2, 3):
+        out = _run("--gpus", str(g), "--workload", "gar8", "--n", "80", "--d", "4")
+        assert out["scaling"] == "strong" and out["config"]["blocks"] == 8 and out["n_gpus"] == g
+        vals.append(out["joint_nll"])
+    assert abs(vals[0] - _expected_joint(8, 80, 8, 4)) < 1e-9 * abs(vals[0])
+    assert abs(vals[1] - vals[0]) < 1e-9 * abs(vals[0]) and abs(vals[2] - vals[0]) < 1e-9 * abs(vals[0])
+
+
+def test_runs_as_a_rank_under_an_external_launcher():
+    # what `python -m torch.distributed.run --nproc-per-node 1` sets up: WORLD_SIZE present -> no self-launch
+    out = _run("--gpus", "1", "--n", "64", env_extra={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1",
+                                                      "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29591"})
+    assert out["n_gpus"] == 1
+
+
+def test_world_size_mismatch_is_an_error_not_a_hang():
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29592")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+def test_parent_of_a_self_launch_never_imports_torch():
+    code = ("import sys, os; sys.argv = ['bench.py', '--gpus', '2', '--backend', 'gloo', '--dry', '--n', '64', '--steps', '1', "
+            "'--warmup', '0', '--no-sharded']\n"
+            "sys.path.insert(0, %r)\nimport bench\n"
+            "try:\n    bench.main()\nexcept SystemExit as e:\n    assert e.code == 0, e.code\n"
+            "assert 'torch' not in sys.modules, 'the launching parent imported torch'\nprint('parent clean')\n" % ROOT)
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "parent clean" in p.stdout, p.stderr[-2000:]

@@ -384,3 +384,20 @@ def test_hogp_block(golden):
     mean, var = O.hogp_forward(kf(g["Xt"], g["X"]), np.diag(kf(g["Xt"], g["Xt"])), Ks, A, gg, eig)
     close(mean, g["mean"], 1e-7)
     close(var, g["var"], 1e-6)
+
+
+@pytest.mark.parametrize("name", ["nlml_v1_cigp_ard_d1", "nlml_v1_cigp_ard_d7", "nlml_v1_cigp_ard_n64", "nlml_v1_cigp_ard_n1"])
+def test_torch_cpu_ref_matches_reference_fixture(golden, name):
+    """oracle/torch_cpu_ref.py (the CPU baseline bench.py times on the GPU box's host) against the imported reference's
+    LL and autograd gradients: the same torch operator sequence, so agreement is at rounding level."""
+    import torch
+    from oracle import torch_cpu_ref as T
+    g = golden(name)
+    t = lambda k: torch.tensor(g[k])
+    ll, gr = T.cigp_ll_and_grads(t("X"), t("Y"), t("length_scales"), t("signal_variance"), t("log_beta"))
+    assert abs(float(ll) - float(g["ll"])) <= 1e-12 * abs(float(g["ll"]))
+    for k, v in gr.items():
+        ref = g["g_" + k]
+        assert np.abs(v.numpy() - ref).max() <= 1e-10 * max(np.abs(ref).max(), 1e-300), k
+    r = T.time_cigp(t("X"), t("Y"), t("length_scales"), t("signal_variance"), t("log_beta"), repeats=1, budget_s=5.0)
+    assert r["fwd_s"] > 0 and abs(r["ll"] - float(g["ll"])) <= 1e-12 * abs(float(g["ll"]))
