@@ -62,7 +62,7 @@ def parse_args(argv=None):
     ap.add_argument("--blocks", type=int, default=None, help="override F of a fixed-F workload (development / --dry)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sharded", action="store_true", help="skip the fixed-F legs after the headline")
-    ap.add_argument("--cpu-budget-s", type=float, default=30.0, help="wall-clock bound of the CPU baseline leg")
+    ap.add_argument("--cpu-budget-s", type=float, default=40.0, help="wall-clock bound of the CPU baseline leg")
     ap.add_argument("--with-grad", action="store_true", help="time forward + closed-form gradients instead")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--dry", action="store_true", help="CPU plumbing run (needs --backend gloo): no GPU work")
@@ -161,21 +161,41 @@ def recorded_traffic(n):
 def cpu_baseline(budget_s, gpu_nll):
     """The reference's torch-CPU operator sequence (oracle/torch_cpu_ref.py: cdist -> exp -> eye adds -> linalg.cholesky
     -> solve_triangular -> V1 formula; autograd for the backward) timed on this box's host cores at C2 and C3 (SURVEY
-    8d), 1 warm-up + min of 3 where the budget allows, next to the GPU's value on the same inputs (in-run parity)."""
+    8d), 1 warm-up + min of 3 where the budget allows, next to the GPU's value on the same inputs (in-run parity).
+    Thread count: SURVEY asks for os.cpu_count(); on a 2 x 64-core SMT host that oversubscribes MKL badly (measured:
+    C2 forward 3.1 s on 256 threads), so a short sweep at N = 2048 picks the fastest of {all, physical, 64, 32, 16}
+    logical CPUs this process may use and the protocol runs with that -- the sweep is reported."""
     import torch
     from oracle import torch_cpu_ref as T
-    torch.set_num_threads(os.cpu_count() or 1)
-    host = T.host_description()
-    out = {"unit": "GF/s", "cores": int(torch.get_num_threads()), "kind": "port", "host": host, "configs": {}}
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    one = lambda k: torch.ones(k, dtype=torch.float64)
     t_leg = time.perf_counter()
+    Xs, Ys = (torch.tensor(a) for a in synthetic_xy(2048, 8, 1, seed=0))
+    sweep = {}
+    for t in sorted({avail, max(1, avail // 2), min(avail, 64), min(avail, 32), min(avail, 16)}, reverse=True):
+        torch.set_num_threads(t)
+        r = T.time_cigp(Xs, Ys, one(8), one(1), one(1), repeats=2, with_backward=False, budget_s=2.0)
+        sweep[t] = round(r["fwd_s"] * 1e3, 2)
+    threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
+    host = T.host_description()
+    host["usable_cpus"] = avail
+    out = {"unit": "GF/s", "cores": int(torch.get_num_threads()), "kind": "port", "host": host,
+           "thread_sweep_ms_at_N2048": {str(k): v for k, v in sweep.items()}, "configs": {}}
+    pred = None                                       # predicted C3 forward seconds, from C2's stages
     for name, share in (("c2", 0.25), ("headline", 1.0)):
         _, n, D, d, _ = WORKLOADS[name]
         left = budget_s - (time.perf_counter() - t_leg)
         if left < 1.0:
             break
+        if name == "headline" and pred is not None:
+            while n > 4096 and 1.3 * pred * (n / 16384.0) ** 3 > left:      # the warm-up alone would not fit: bounded sample
+                n //= 2
+            if n <= 4096:
+                break
+            name = "headline" if n == 16384 else "headline_sample_N%d" % n
         X, Y = synthetic_xy(n, D, d, seed=0)
         Xt, Yt = torch.tensor(X), torch.tensor(Y)
-        one = lambda k: torch.ones(k, dtype=torch.float64)
         r = T.time_cigp(Xt, Yt, one(D), one(1), one(1), repeats=3, with_backward=True, budget_s=left * share)
         fl = nlml_flops(n, D, d)
         c = {"N": n, "D": D, "d": d, "fwd_ms": round(r["fwd_s"] * 1e3, 2), "fwd_gflops": round(fl / r["fwd_s"] / 1e9, 1),
@@ -183,15 +203,17 @@ def cpu_baseline(budget_s, gpu_nll):
              "fwd_bwd_gflops": None if r["fwd_bwd_s"] is None else round(3.0 * fl / r["fwd_bwd_s"] / 1e9, 1),
              "stage_ms": None if r["stages_s"] is None else {k: round(v * 1e3, 2) for k, v in r["stages_s"].items()},
              "cpu_ll": r["ll"]}
+        if name == "c2" and r["stages_s"]:
+            pred = 64.0 * r["stages_s"]["potrf"] + 32.0 * r["stages_s"]["assemble"]
         if gpu_nll.get(name) is not None:    # cigp returns +LL = -nll: same inputs, same parameters
             c["gpu_ll"] = -gpu_nll[name]
             c["rel_err"] = abs(c["gpu_ll"] - c["cpu_ll"]) / abs(c["cpu_ll"])
         out["configs"][name] = c
-    best = out["configs"].get("headline") or out["configs"].get("c2")
+    best = ([v for k, v in out["configs"].items() if k.startswith("headline")] or [out["configs"].get("c2")])[0]
     out["value"] = best["fwd_gflops"] if best else None
-    out["sample"] = ("torch-CPU port of cigp.negative_log_likelihood (oracle/torch_cpu_ref.py), fp64, %d threads, %s, %s: "
-                     "forward at N=%d (min of up to 3 after a warm-up); per-config fwd / fwd+bwd / stages under configs"
-                     % (out["cores"], host["cpu_model"], host["blas"], best["N"] if best else 0))
+    out["sample"] = ("torch-CPU port of cigp.negative_log_likelihood (oracle/torch_cpu_ref.py), fp64, %d threads (fastest of the "
+                     "sweep) on %s, %s: forward at N=%d (min of up to 3 after a warm-up, bounded by --cpu-budget-s); per-config "
+                     "fwd / fwd+bwd / stages under configs" % (out["cores"], host["cpu_model"], host["blas"], best["N"] if best else 0))
     return out
 
 
@@ -319,17 +341,18 @@ def run_rank(args):
     for _ in range(args.warmup):
         step()
     if not args.dry:
-        _lib.set_option("timing", 2, local_rank)     # event pairs around every trailing-update launch (no host syncs)
-        _lib.syrk_stats(reset=True, device_index=local_rank)
+        _lib.set_option("timing", 2, local_rank, all_slots=True)   # event pairs around every trailing-update launch (no host syncs)
+        _lib.syrk_stats(reset=True, device_index=local_rank, all_slots=True)
     dt, joint = timed(step, args.steps, 0)
     stats, stages = {"flops": 0.0, "ms": 0.0, "launches": 0}, {}
     if not args.dry:
-        stats = _lib.syrk_stats(reset=True, device_index=local_rank)
+        stats = _lib.syrk_stats(reset=True, device_index=local_rank, all_slots=True)
+        _lib.set_option("timing", 0, local_rank, all_slots=True)
         if WORKLOADS[args.workload][0] is None:
             _lib.set_option("timing", 1, local_rank)
             step()
             stages = _lib.last_timings(local_rank)
-        _lib.set_option("timing", 0, local_rank)
+            _lib.set_option("timing", 0, local_rank)
     ms_per_step = dt / args.steps * 1e3
     flops_step = nlml_flops(n, D, d) * (3.0 if args.with_grad else 1.0) * F_total   # fwd+bwd ~ N^3
     value = flops_step / (dt / args.steps) / 1e9

@@ -140,8 +140,20 @@ def handle(device_index=None, slot=0):
     return h
 
 
-def set_option(key, value, device_index=None):
-    check(lib.ffgp_set_option(handle(device_index), key.encode(), float(value)), "ffgp_set_option(%s)" % key)
+def _device_handles(device_index):
+    """every handle this process holds on that GPU (slot 0 is created on demand)"""
+    h0 = handle(device_index)
+    if device_index is None:
+        import torch
+        device_index = torch.cuda.current_device()
+    with _lock:
+        return [h0] + [h for (dv, sl), h in sorted(_handles.items(), key=lambda kv: kv[0]) if dv == device_index and sl != 0]
+
+
+def set_option(key, value, device_index=None, all_slots=False):
+    """library option on the default handle of the GPU; all_slots: on every handle held there (concurrent blocks)"""
+    for h in (_device_handles(device_index) if all_slots else [handle(device_index)]):
+        check(lib.ffgp_set_option(h, key.encode(), float(value)), "ffgp_set_option(%s)" % key)
 
 
 def bind_stream(h, device_index):
@@ -160,11 +172,16 @@ def last_timings(device_index=None):
     return {names[i].decode(): float(ms[i]) for i in range(n.value)}
 
 
-def syrk_stats(reset=False, device_index=None):
-    h = handle(device_index)
-    fl, ms, ln = C.c_double(0), C.c_double(0), C.c_long(0)
-    check(lib.ffgp_syrk_stats(h, C.byref(fl), C.byref(ms), C.byref(ln), 1 if reset else 0), "ffgp_syrk_stats")
-    return {"flops": fl.value, "ms": ms.value, "launches": ln.value}
+def syrk_stats(reset=False, device_index=None, all_slots=False):
+    """launch statistics of the trailing-update SYRK (the roofline kernel); all_slots sums over every handle on the GPU"""
+    tot = {"flops": 0.0, "ms": 0.0, "launches": 0}
+    for h in (_device_handles(device_index) if all_slots else [handle(device_index)]):
+        fl, ms, ln = C.c_double(0), C.c_double(0), C.c_long(0)
+        check(lib.ffgp_syrk_stats(h, C.byref(fl), C.byref(ms), C.byref(ln), 1 if reset else 0), "ffgp_syrk_stats")
+        tot["flops"] += fl.value
+        tot["ms"] += ms.value
+        tot["launches"] += ln.value
+    return tot
 
 
 def mfma_f64_peak(device_index=None):

@@ -137,6 +137,7 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->la_split = 1;
   h->aux_prio = 1;
   h->nb_outer = 512;
+  h->diag_v2 = 1;
   const int rc = create_resources(h);
   if (rc != FFGP_OK) {   // release whatever was created before the failure
     ffgp_destroy(h);
@@ -199,6 +200,8 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->small_tile_threshold = (int)value;
   } else if (!strcmp(key, "tile32_threshold")) {
     h->tile32_threshold = (int)value;
+  } else if (!strcmp(key, "diag_v2")) {
+    h->diag_v2 = (int)value;
   } else if (!strcmp(key, "diag_dbg")) {
     h->diag_dbg = (int)value;
   } else if (!strcmp(key, "la_split")) {
@@ -388,7 +391,7 @@ int ffgp_wait(ffgp_handle* h) {
     h->h_info[1] = 0;
     FFGP_HIP(hipMemsetAsync(h->d_info + 1, 0, sizeof(int), h->stream));
   }
-  return rc;
+  return ffgp_map_info(rc);
 }
 
 int ffgp_nlml_fused_async(ffgp_handle* h, const ffgp_problem* p, double* nll_dev, const ffgp_grads* g) {
@@ -571,7 +574,7 @@ int ffgp_predict(ffgp_handle* h, const ffgp_problem* p, const double* Xs, int nt
   FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   FFGP_HIP(hipStreamSynchronize(h->stream));
   stage_collect(h);
-  return h->h_info[0];
+  return ffgp_map_info(h->h_info[0]);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -102,6 +102,7 @@ struct ffgp_handle {
   int small_tile_threshold;  // launches with fewer 128-tiles than this use the 64-tile
   int tile32_threshold;      // K-major launches with fewer 64-tiles than this use 32-row tiles
   int diag_dbg;         // timing-only ablation mask of potrf_diag128 (0 in production)
+  int diag_v2;          // 0 = barrier version of the diagonal-block kernel, 1 = pipelined (default), 2 = pipelined, helper waves off wave 0's SIMD
   int la_split;         // 1 = issue the look-ahead part of the trailing update in two launches (first 128 columns first)
   int lookahead;        // 1 = overlap panel k+1 with the trailing update of step k
   int diag_attr_set;    // dynamic-LDS attribute of potrf_diag128 set on this handle's device
@@ -165,6 +166,7 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
 int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int sync_info);
 int ffgp_ensure_dinv(ffgp_handle* h, int n);
 int ffgp_refresh_dinv(ffgp_handle* h, const double* L, int n, int ldl);
+int ffgp_map_info(int v);
 // ---- solve.hip
 int ffgp_trsm_lower_impl(ffgp_handle* h, const double* L, int n, int ldl, double* B, int nrhs, int ldb);
 int ffgp_trsm_lower_t_impl(ffgp_handle* h, const double* L, int n, int ldl, double* B, int nrhs, int ldb);

@@ -410,6 +410,361 @@ __global__ __launch_bounds__(DIAG_THREADS) void ffgp_potrf_diag128(double* __res
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// potrf_diag128_v2: the same factor + inverse as a wave-specialised PIPELINE instead of barrier-separated phases.
+//
+// The old kernel spends 8 x (3 workgroup barriers + a ~1.7 us in-register 16x16 factor + two short MFMA phases); every wave
+// waits for every other wave three times per 16 columns.  Here wave 0 never meets a barrier after the load phase:
+//
+//   wave 0   F(jj): in-register 16x16 Cholesky + inverse of the diagonal block (16 pivots)
+//            G(jj): Y = inv(L_jj) S[jj+1][jj]^T on the matrix cores (4 MFMAs); L[jj+1][jj] = Y^T goes to LDS / global;
+//                   D = S[jj+1][jj+1] - Y^T Y (4 MFMAs with a = b = the Y registers: the accumulator layout is both the
+//                   A layout of Y^T and the B layout of Y) -> the next diagonal block, already in the factor's layout
+//            ... F(jj+1) ...                       serial chain: 8 x (F + G), nothing else
+//   helpers  iteration jj, triggered by wave 0's flags in LDS (seqF: inv(L_jj) is in LDS; seqX: L[jj+1][jj] is):
+//            A1 TRSM of the block rows jj+2.. of column jj          A2 row block jj of the inverse (from T, see B3)
+//            B1 column jj+1 receives block column jj   B2 column jj+2 receives block columns 0..jj (left-looking,
+//            one block column of look-ahead -- so G(jj+1) finds S[jj+2][jj+1], S[jj+2][jj+2] complete)  -> doneU
+//            B3 T_j = sum_k L[jj+1][k] X[k][j] for the inverse's next row block (kept in registers)
+//   Helpers synchronise among themselves with a counter barrier in LDS (two per iteration); wave 0 waits for doneU of
+//   iteration jj-1 before G(jj) -- by then it has spent a whole F on its own, so it normally does not wait at all.
+//
+// The 16x16 factor itself is restructured so that no LDS-latency operation sits on the pivot-to-pivot chain: every lane
+// keeps the CURRENT pivot row for its column (rowA, rowW); the next pivot row is fetched (ds_bpermute) one step ahead,
+// before this step's update, and patched locally with this step's rank-1 term; pivot and multiplier broadcasts are DPP
+// row shares.  Finished columns are parked in place (their multiplier is masked to 0), so no select instructions
+// capture them.  Every polling loop is bounded: on a timeout the kernel raises `abort`, every wave leaves, and the host
+// sees FFGP_DIAG_WATCHDOG in the status word instead of a hung queue.
+// ------------------------------------------------------------------------------------------------------------
+#define FFGP_DIAG_WATCHDOG 0x7ffffff0
+
+// tools/diag_trace.py builds a second library with -DFFGP_DIAG_TRACE: wave 0 and helper 0 stamp the cycle counter at their
+// phase boundaries (never compiled into libffgp.so)
+#ifdef FFGP_DIAG_TRACE
+__device__ unsigned long long* ffgp_diag_trace_buf = nullptr;
+extern "C" int ffgp_debug_set_diag_trace(void* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(ffgp_diag_trace_buf), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#define D2_TRACE(slot)                                                                          \
+  do {                                                                                          \
+    if (lane == 0 && ffgp_diag_trace_buf) ffgp_diag_trace_buf[(slot)] = wall_clock64();         \
+  } while (0)
+#else
+#define D2_TRACE(slot)
+#endif
+
+struct D2Flags {      // ints in LDS, behind the block image
+  int seqF, seqX, doneU, sb, abort, nh, simd0, pad;
+};
+
+#define D2_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define D2_COMPILER_FENCE() asm volatile("" ::: "memory")
+
+__device__ __forceinline__ bool d2_wait_ge(volatile int* p, int target, volatile int* abort_flag, int* info) {
+  int spins = 0;
+  while (*p < target) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1 << 21) || *abort_flag) {   // ~1 s of polling: something upstream died
+      if (!*abort_flag) atomicExch(info, FFGP_DIAG_WATCHDOG);
+      *abort_flag = 1;
+      return false;
+    }
+  }
+  D2_COMPILER_FENCE();
+  return true;
+}
+
+// one pivot of the pipelined in-register factor (see the header comment).  lane (g = lane>>4, c = lane&15) holds rows
+// g+4r of column c of the symmetric block (v) and of the eliminated identity (w); rowA / rowW = current row J of both.
+template <int J>
+__device__ __forceinline__ void f16_step(double (&v)[4], double (&w)[4], double& rowA, double& rowW, int c, int g) {
+  double preA = 0.0, preW = 0.0;
+  if constexpr (J < 15) {   // row J+1 as it stands BEFORE this pivot's update; patched below
+    constexpr int PR1 = (J + 1) >> 2, G1 = (J + 1) & 3;
+    preA = bperm_d(v[PR1], 16 * G1 + c);
+    preW = bperm_d(w[PR1], 16 * G1 + c);
+  }
+  const double d = row_bcast_d<J>(rowA);                     // A[J][J]  (checked for positivity after the 16 steps)
+  const double y0 = __builtin_amdgcn_rcp(d);
+  const double e = __builtin_fma(-d, y0, 1.0);
+  const double f = __builtin_fma(e, e, e);                   // 1/d = y0 (1 + e + e^2)
+  const double u = rowA * y0;
+  const double t = __builtin_fma(u, f, u);                   // A[J][c] / d
+  const double uw = rowW * y0;
+  const double tw = __builtin_fma(uw, f, uw);                // W[J][c] / d
+  double colj[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) colj[r] = row_bcast_d<J>(v[r]);   // A[g+4r][J]
+  if constexpr (J < 15) {
+    const double s = row_bcast_d<(J + 1) & 15>(rowA);        // A[J][J+1] = A[J+1][J]
+    rowA = __builtin_fma(-s, t, preA);
+    rowW = __builtin_fma(-s, tw, preW);
+  }
+  const double tm = (c > J) ? t : 0.0;                       // columns <= J are parked: they keep the unscaled L column
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = __builtin_fma(-colj[r], tm, v[r]);
+  constexpr int PR = J >> 2;
+  colj[PR] = (g == (J & 3)) ? 0.0 : colj[PR];               // the pivot row of W stays
+#pragma unroll
+  for (int r = 0; r < 4; ++r) w[r] = __builtin_fma(-colj[r], tw, w[r]);
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void ffgp_potrf_diag128_v2(double* __restrict__ A, int lda, int nb, double* __restrict__ Dinv,
+                                                                 int* info, int row_base, int excl_simd, int prio) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* S = lds;
+  volatile D2Flags* fl = reinterpret_cast<volatile D2Flags*>(lds + NBLK_LOWER * BLKSZ);
+  constexpr int NT = NW * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (wave == 0) D2_TRACE(0);
+  if (tid == 0) {
+    fl->seqF = 0; fl->seqX = 0; fl->doneU = 0; fl->sb = 0; fl->abort = 0; fl->nh = 0;
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    fl->simd0 = (int)((hwid >> 4) & 3);
+  }
+  // ---- load phase (as in the barrier version): lower blocks, diagonal blocks completed symmetrically, identity padding
+  {
+    // two rounds of 8 loads per thread (all of a round in flight before its LDS stores): the kernel is held to 128 VGPRs
+    // so that it fits on a CU BESIDE a resident trailing-update workgroup (the barrier version needs 256 -- a whole CU)
+    constexpr int NLOAD = 8192 / NT, CH = NLOAD / 2;
+    const bool vec = !(lda & 1) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      d2_t lv[CH];
+#pragma unroll
+      for (int it = 0; it < CH; ++it) {
+        const int idx = tid + NT * (half * CH + it);
+        const int r = min(idx >> 6, nb - 1), c = min((idx & 63) * 2, (nb - 1) & ~1);
+        const double* src = A + (size_t)r * lda + c;
+        if (vec) {
+          lv[it] = *reinterpret_cast<const d2_t*>(src);
+        } else {
+          lv[it].x = src[0];
+          lv[it].y = (c + 1 < nb) ? src[1] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < CH; ++it) {
+        const int idx = tid + NT * (half * CH + it);
+        const int r = idx >> 6, c = (idx & 63) * 2;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int cc = c + e;
+          if (cc <= r) {
+            double x = (r == cc) ? 1.0 : 0.0;
+            if (r < nb) x = e ? lv[it].y : lv[it].x;
+            S[blk_off(r >> 4, cc >> 4) + (r & 15) * BLD + (cc & 15)] = x;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 8 * 256; idx += NT) {
+      const int jj = idx >> 8, i = (idx >> 4) & 15, c = idx & 15;
+      double* Dj = S + blk_off(jj, jj);
+      if (c > i) Dj[i * BLD + c] = Dj[c * BLD + i];
+    }
+  }
+  // helper roles: every wave but wave 0 (excl_simd: and but the waves that share wave 0's SIMD -- their MFMAs would sit
+  // in the same pipe as the pivot chain's fp64 operations)
+  int hidx = -1;
+  if (wave != 0) {
+    bool take = true;
+    if (excl_simd) {
+      unsigned hwid;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      take = ((int)((hwid >> 4) & 3) != fl->simd0);
+    }
+    if (take) {
+      int got = 0;
+      if (lane == 0) got = atomicAdd(const_cast<int*>(&fl->nh), 1);
+      hidx = __builtin_amdgcn_readfirstlane(got);
+    }
+  }
+  __syncthreads();
+  const int NH = fl->nh;
+  volatile int* ab = &fl->abort;
+  const int g = lane >> 4, c = lane & 15;
+
+  if (wave == 0) {
+    // ================================ the serial chain ================================
+    if (prio) __builtin_amdgcn_s_setprio(3);
+    D2_TRACE(1);
+    double v[4], w[4];
+    {
+      const double* D0 = S + blk_off(0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = D0[(g + 4 * r) * BLD + c];
+    }
+    for (int jj = 0; jj < 8; ++jj) {
+      // ---- F(jj)
+      // (lane coordinates made opaque per iteration: otherwise every lane-derived constant of the 16 unrolled pivots is
+      //  hoisted out of this loop and the kernel spills ~60 registers around its serial chain)
+      int cc = c, gg = g;
+      asm volatile("" : "+v"(cc), "+v"(gg));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w[r] = (gg + 4 * r == cc) ? 1.0 : 0.0;
+      double rowA = bperm_d(v[0], cc);           // row 0: lanes (0, c)
+      double rowW = (cc == 0) ? 1.0 : 0.0;
+      f16_step<0>(v, w, rowA, rowW, cc, gg);
+      f16_step<1>(v, w, rowA, rowW, cc, gg);
+      f16_step<2>(v, w, rowA, rowW, cc, gg);
+      f16_step<3>(v, w, rowA, rowW, cc, gg);
+      f16_step<4>(v, w, rowA, rowW, cc, gg);
+      f16_step<5>(v, w, rowA, rowW, cc, gg);
+      f16_step<6>(v, w, rowA, rowW, cc, gg);
+      f16_step<7>(v, w, rowA, rowW, cc, gg);
+      f16_step<8>(v, w, rowA, rowW, cc, gg);
+      f16_step<9>(v, w, rowA, rowW, cc, gg);
+      f16_step<10>(v, w, rowA, rowW, cc, gg);
+      f16_step<11>(v, w, rowA, rowW, cc, gg);
+      f16_step<12>(v, w, rowA, rowW, cc, gg);
+      f16_step<13>(v, w, rowA, rowW, cc, gg);
+      f16_step<14>(v, w, rowA, rowW, cc, gg);
+      f16_step<15>(v, w, rowA, rowW, cc, gg);
+      // the pivot of column c sits, unscaled, on the parked column's diagonal: lane (c & 3, c), register c >> 2
+      const int q = c >> 2;
+      const double dsel = (q == 0) ? v[0] : (q == 1) ? v[1] : (q == 2) ? v[2] : v[3];
+      const double dcol = bperm_d(dsel, 16 * (c & 3) + c);
+      const double rs = rsqrt_nr(dcol);          // 1 / sqrt(pivot of column c)
+      // first non-positive pivot of the block (a NaN counts): lanes 0..15 carry columns 0..15
+      const unsigned long long nonpos = __ballot(!(dcol > 0.0)) & 0xffffull;
+      const int bad = nonpos ? __ffsll((long long)nonpos) : 0;
+      double* Dj = S + blk_off(jj, jj);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = g + 4 * r;
+        const double rsi = bperm_d(rs, i);       // 1 / sqrt(pivot of column i): the row scaling of the inverse
+        const double x = (i >= c) ? w[r] * rsi : 0.0;
+        Dj[i * BLD + c] = x;                                              // inv(L_jj) for the helpers and for G
+        const int gr = jj * 16 + i, gc = jj * 16 + c;
+        if (i >= c) {
+          Dinv[(size_t)gr * NB + gc] = x;
+          if (gr < nb) A[(size_t)gr * lda + gc] = v[r] * rs;              // L_jj
+        }
+      }
+      if (bad && lane == 0 && (jj * 16 + bad) <= nb) atomicCAS(info, 0, row_base + jj * 16 + bad);
+      D2_LDS_FENCE();
+      if (lane == 0) fl->seqF = jj + 1;
+      D2_TRACE(2 + 3 * jj);
+      if (jj == 7) break;
+      // ---- G(jj): the helpers' updates of iteration jj-1 must have landed in S[jj+1][jj] and S[jj+1][jj+1]
+      if (jj > 0 && !d2_wait_ge(&fl->doneU, NH * jj, ab, info)) break;
+      D2_TRACE(3 + 3 * jj);
+      const double* Sb = S + blk_off(jj + 1, jj);
+      double* Sd = S + blk_off(jj + 1, jj + 1);
+      d4_t Y = {0.0, 0.0, 0.0, 0.0};
+      mma16<true>(Y, Dj, BLD, Sb, BLD, lane);                  // Y = inv(L_jj) S[jj+1][jj]^T
+      d4_t D;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) D[r] = Sd[(g + 4 * r) * BLD + c];
+      D2_LDS_FENCE();                                          // the reads of S[jj+1][jj] are done before it is overwritten
+      {
+        double* Xb = S + blk_off(jj + 1, jj);                  // L[jj+1][jj] = Y^T
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = g + 4 * r;                             // Y[k][c] -> X[c][k]
+          Xb[c * BLD + k] = Y[r];
+          const int gr = (jj + 1) * 16 + c;
+          if (gr < nb) A[(size_t)gr * lda + jj * 16 + k] = Y[r];
+        }
+      }
+      D2_LDS_FENCE();
+      if (lane == 0) fl->seqX = jj + 1;
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) D = __builtin_amdgcn_mfma_f64_16x16x4f64(Y[kq], Y[kq], D, 0, 0, 1);   // D -= Y^T Y
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = D[r];
+      D2_TRACE(4 + 3 * jj);
+    }
+    return;
+  }
+  if (hidx < 0) return;
+
+  // ================================ helpers ================================
+  int sb_target = 0;
+  auto helper_barrier = [&]() -> bool {
+    sb_target += NH;
+    D2_LDS_FENCE();
+    if (lane == 0) atomicAdd(const_cast<int*>(&fl->sb), 1);
+    return d2_wait_ge(&fl->sb, sb_target, ab, info);
+  };
+  d4_t T[2];                                   // T_j for the columns j = hidx, hidx + NH of the inverse's next row block
+  T[0] = (d4_t){0.0, 0.0, 0.0, 0.0};
+  T[1] = T[0];
+  for (int jj = 0; jj < 8; ++jj) {
+    if (!d2_wait_ge(&fl->seqF, jj + 1, ab, info)) return;
+    if (hidx == 0) D2_TRACE(32 + 4 * jj);
+    const double* Wj = S + blk_off(jj, jj);    // inv(L_jj)
+    // A1: L[i][jj] = S[i][jj] inv(L_jj)^T for the block rows wave 0 does not take itself
+    for (int i = jj + 2 + hidx; i < 8; i += NH) {
+      d4_t acc = {0.0, 0.0, 0.0, 0.0};
+      double* Bij = S + blk_off(i, jj);
+      mma16<true>(acc, Bij, BLD, Wj, BLD, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        Bij[(g + 4 * r) * BLD + c] = acc[r];
+        const int gr = i * 16 + g + 4 * r;
+        if (gr < nb) A[(size_t)gr * lda + jj * 16 + c] = acc[r];
+      }
+    }
+    // A2: X[jj][j] = -inv(L_jj) T_j (T from B3 of the previous iteration; accumulator layout = B-operand layout)
+    for (int s = 0; s < 2; ++s) {
+      const int j = hidx + s * NH;
+      if (j < jj) {
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Wj[c * BLD + kq * 4 + g], s ? T[1][kq] : T[0][kq], acc, 0, 0, 0);
+        double* dst = S + blk_off(jj, j);
+        double* gd = Dinv + (size_t)(jj * 16 + g) * NB + j * 16 + c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dst[(g + 4 * r) * BLD + c] = -acc[r];
+          gd[(size_t)4 * r * NB] = -acc[r];
+        }
+      }
+    }
+    if (hidx == 0) D2_TRACE(33 + 4 * jj);
+    if (jj == 7) break;
+    if (!helper_barrier()) return;
+    if (!d2_wait_ge(&fl->seqX, jj + 1, ab, info)) return;
+    // B1 / B2, dealt round-robin in priority order: (B1 i, B2 i) for i = jj+2 .. 7
+    {
+      const int nrows = 6 - jj;                // block rows jj+2 .. 7
+      for (int q = hidx; q < 2 * nrows; q += NH) {
+        const int i = jj + 2 + (q >> 1);
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+        double* dst;
+        if ((q & 1) == 0) {                    // B1: column jj+1 receives block column jj
+          mma16<true>(acc, S + blk_off(i, jj), BLD, S + blk_off(jj + 1, jj), BLD, lane);
+          dst = S + blk_off(i, jj + 1);
+        } else {                               // B2: column jj+2 receives block columns 0 .. jj
+          for (int p = 0; p <= jj; ++p) mma16<true>(acc, S + blk_off(i, p), BLD, S + blk_off(jj + 2, p), BLD, lane);
+          dst = S + blk_off(i, jj + 2);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(g + 4 * r) * BLD + c] -= acc[r];
+      }
+    }
+    D2_LDS_FENCE();
+    if (lane == 0) atomicAdd(const_cast<int*>(&fl->doneU), 1);
+    if (hidx == 0) D2_TRACE(34 + 4 * jj);
+    // B3: T_j = sum_{k=j}^{jj} L[jj+1][k] X[k][j] for the owned columns j <= jj of the inverse's row block jj+1
+    for (int s = 0; s < 2; ++s) {
+      const int j = hidx + s * NH;
+      d4_t acc = {0.0, 0.0, 0.0, 0.0};
+      if (j <= jj)
+        for (int k = j; k <= jj; ++k) mma16<false>(acc, S + blk_off(jj + 1, k), BLD, S + blk_off(k, j), BLD, lane);
+      if (s) T[1] = acc; else T[0] = acc;
+    }
+    if (hidx == 0) D2_TRACE(35 + 4 * jj);
+    if (!helper_barrier()) return;             // row block jj+1 of L is dead now: A2 of the next iteration overwrites it
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // naive reference kernels (debug / on-device cross-check only; selected with option "naive")
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ffgp_potrf_naive(double* A, int lda, int n, int* info) {
@@ -476,10 +831,20 @@ __global__ __launch_bounds__(128) void ffgp_dinv_naive(const double* L, int ldl,
 // host side
 // ------------------------------------------------------------------------------------------------------------
 static int launch_diag(ffgp_handle* h, double* Ablk, int lda, int nb, double* Dinv_blk, int row_base, int do_factor) {
-  if (!h->diag_attr_set) {   // per handle = per device (the attribute lives in the device's context)
+  if (!(h->diag_attr_set & 1)) {   // per handle = per device (the attribute lives in the device's context)
     FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
-    h->diag_attr_set = 1;
+    h->diag_attr_set |= 1;
+  }
+  if (do_factor && h->diag_v2 && !h->diag_dbg) {   // the pipelined kernel (the barrier version keeps the inverse-only entry)
+    if (!(h->diag_attr_set & 2)) {
+      FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v2<8>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+      h->diag_attr_set |= 2;
+    }
+    hipLaunchKernelGGL(ffgp_potrf_diag128_v2<8>, dim3(1), dim3(512), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk, h->d_info,
+                       row_base, h->diag_v2 == 2 ? 1 : 0, h->aux_prio);
+    return FFGP_OK;
   }
   hipLaunchKernelGGL(ffgp_potrf_diag128, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk,
                      h->d_info, row_base, do_factor, h->diag_dbg, h->aux_prio);
@@ -676,5 +1041,14 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
   if (!sync_info) return FFGP_OK;
   FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   FFGP_HIP(hipStreamSynchronize(h->stream));
-  return h->h_info[0];
+  return ffgp_map_info(h->h_info[0]);
+}
+
+// status word -> return code: a pivot index passes through; the diagonal-block kernel's watchdog is a library error
+int ffgp_map_info(int v) {
+  if (v >= FFGP_DIAG_WATCHDOG) {
+    fprintf(stderr, "[ffgp] potrf_diag128: a wave waited ~1 s for a hand-off inside the kernel and gave up (internal error)\n");
+    return FFGP_ERR_HIP;
+  }
+  return v;
 }

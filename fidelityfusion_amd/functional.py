@@ -120,7 +120,7 @@ class _NLML(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, variant, pi_const, slot=0,
-                defer=False, kfun=(0, 1.0), kparam=None):
+                defer=False, kfun=(0, 1.0), kparam=None, rec=True):
         dev = _device_of(X, Y, w, amp)
         if kparam is not None:
             kfun = (kfun[0], float(kparam.detach()))
@@ -129,10 +129,11 @@ class _NLML(torch.autograd.Function):
         keep = []
         p, (n, D, d) = _problem(dev, X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, variant,
                                 pi_const, keep, kfun)
-        # ctx.needs_input_grad is all False under torch.no_grad() (evaluation of a model whose nn.Parameters still carry
-        # requires_grad = True): the gradient pipeline (TRTRI, LAUUM, A A^T, gradient tiles: 2x the forward's flops and
-        # 2-3 more N x ld workspaces) only runs when autograd will actually ask for it
-        needs = [bool(ctx.needs_input_grad[i]) for i in (1, 2, 3, 4, 5, 15)]    # Y, w, amp, diag_add, diag_vec, kparam
+        # under torch.no_grad() nothing will ever call backward, although leaf inputs (nn.Parameters, a y with
+        # requires_grad) still report requires_grad = True: the gradient pipeline (TRTRI, LAUUM, A A^T, gradient tiles: 2x
+        # the forward's flops and 2-3 more N x ld workspaces) only runs when autograd is recording.  `rec` is the caller's
+        # grad mode, captured by the wrapper: inside forward() autograd is always off
+        needs = [rec and bool(ctx.needs_input_grad[i]) for i in (1, 2, 3, 4, 5, 15)]    # Y, w, amp, diag_add, diag_vec, kparam
         out = torch.empty((), dtype=torch.float64, device=dev)
         g = None
         grads = {}
@@ -197,7 +198,7 @@ class _NLML(torch.autograd.Function):
             return t.reshape(shape).to(device=device, dtype=dtype)
 
         return (None, fin("Y", 0), fin("w", 1), fin("amp", 2), fin("diag_add", 3), fin("diag_vec", 4), None, None, None,
-                None, None, None, None, None, None, fin("kparam", 5))
+                None, None, None, None, None, None, fin("kparam", 5), None)
 
 
 _pending = {}   # (device, slot) -> staging tensors of enqueued-but-not-waited calls (kept alive until wait)
@@ -212,7 +213,7 @@ def nlml(X, Y, w, amp, diag_add=None, diag_vec=None, add_mat=None, add_all=0.0, 
     `slot` and `defer=True`, then call `wait(slot)` (see `concurrent_blocks`)."""
     kfun, kparam = _split_kfun(kfun)
     return _NLML.apply(X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, variant, pi_const, slot,
-                       defer, kfun, kparam)
+                       defer, kfun, kparam, torch.is_grad_enabled())
 
 
 def _split_kfun(kfun):
@@ -523,7 +524,7 @@ class _GaussNLLFromCov(torch.autograd.Function):
     d/dY and the symmetric d/d(cov) -- what torch's cholesky backward gives the reference."""
 
     @staticmethod
-    def forward(ctx, Y, cov, variant, pi_const):
+    def forward(ctx, Y, cov, variant, pi_const, rec=True):
         dev = _device_of(Y, cov)
         h = _lib.handle(dev.index)
         _lib.bind_stream(h, dev.index)
@@ -536,7 +537,7 @@ class _GaussNLLFromCov(torch.autograd.Function):
         out = torch.empty((), dtype=torch.float64, device=dev)
         g = None
         ctx.grads = {}
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:   # all False under torch.no_grad()
+        if rec and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):   # rec: the caller's grad mode (off inside forward)
             g = Grads()
             ctx.grads["Y"] = torch.empty((n, d), dtype=torch.float64, device=dev)
             ctx.grads["cov"] = torch.empty((n, n), dtype=torch.float64, device=dev)
@@ -556,11 +557,11 @@ class _GaussNLLFromCov(torch.autograd.Function):
                 continue
             t = ctx.grads[key] * gout.to(device=ctx.grads[key].device, dtype=torch.float64)
             outs.append(t.reshape(shape).to(device=device, dtype=dtype))
-        return outs[0], outs[1], None, None
+        return outs[0], outs[1], None, None, None
 
 
 def gaussian_nll_from_cov(Y, cov, variant=FFGP_LL_V2, pi_const=math.pi):
-    return _GaussNLLFromCov.apply(Y, cov, variant, pi_const)
+    return _GaussNLLFromCov.apply(Y, cov, variant, pi_const, torch.is_grad_enabled())
 
 
 def gaussian_ll_v2(Y, cov):

@@ -1483,6 +1483,7 @@ def test_no_grad_evaluation_skips_the_gradient_pipeline(monkeypatch):
     X = torch.rand((200, 3), generator=gen, dtype=torch.float64).to(DEV)
     Y = torch.randn((200, 2), generator=gen, dtype=torch.float64).to(DEV)
     m = cigp(kernel.ARDKernel(3), 0.7).double().to(DEV)
+    Y.requires_grad_(True)                   # a leaf that keeps requires_grad = True under no_grad (as nn.Parameters do)
     with torch.no_grad():
         v0 = m.negative_log_likelihood(X, Y)
     assert seen == [False] and not v0.requires_grad
