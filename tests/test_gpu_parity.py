@@ -1546,7 +1546,7 @@ def test_posterior_cache_controls():
         a, _ = m(X, Y, Xs)
         m.log_beta.data.fill_(3.0)               # bypasses the version counter: the cached factor is stale
         stale, _ = m(X, Y, Xs)
-        assert float((stale - a).abs().max()) == 0.0
+        assert float((stale - a).abs().max()) < 1e-12      # (first answer rides in the factorisation, later ones are TRSM queries)
         m.clear_posterior_cache()
         b, _ = m(X, Y, Xs)
         assert float((b - a).abs().max()) > 1e-6
