@@ -14,7 +14,7 @@ import threading
 import torch  # noqa: F401  (device memory, streams)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libffgp.so")
+_SO = os.environ.get("FFGP_LIB") or os.path.join(_HERE, "libffgp.so")   # FFGP_LIB: development builds (tools/)
 
 FFGP_LL_V1, FFGP_LL_V2 = 1, 2
 FFGP_VAR_FULL, FFGP_VAR_DIAG = 0, 1

@@ -21,6 +21,9 @@
 #include "ffgp_internal.h"
 
 #define BK 16
+#ifndef FFGP_PD_SMALL
+#define FFGP_PD_SMALL 4   // register prefetch depth (k-tiles) of the latency-shape tiles
+#endif
 
 // tools/trace_gemm.py builds a second library with -DFFGP_GEMM_TRACE: every workgroup stamps s_memtime at the
 // phase boundaries of each tile (never compiled into libffgp.so)
@@ -393,7 +396,7 @@ __device__ __forceinline__ void gemm_one_tile(const GemmArgs& p, const double* _
     const size_t stepB = (OPB == OP_KMAJOR) ? (size_t)BK * 8 : (size_t)BK * p.ldb * 8;
     char* bC = reinterpret_cast<char*>(Cg) + ((size_t)m0 * p.ldc + n0) * 8;
     const size_t row4 = (size_t)p.ldc * 32;   // 4 rows of C
-    constexpr int PD = (TM == 128 && TN == 128) ? 1 : 4;
+    constexpr int PD = (TM == 128 && TN == 128) ? 1 : FFGP_PD_SMALL;
     unsigned voffA[Geo<TM>::NLD], voffB[Geo<TN>::NLD];   // per-lane byte offsets (a dozen VALU ops per tile)
     lane_byte_offsets<OPA, TM>(p.lda, tid, voffA);
     lane_byte_offsets<OPB, TN>(p.ldb, tid, voffB);

@@ -453,7 +453,7 @@ extern "C" int ffgp_debug_set_diag_trace(void* p) {
 #endif
 
 struct D2Flags {      // ints in LDS, behind the block image
-  int seqF, seqX, doneU, sb, abort, nh, simd0, pad;
+  int seqF, seqX, doneU, sb, abort, pad[3];
 };
 
 #define D2_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -491,9 +491,11 @@ __device__ __forceinline__ void f16_step(double (&v)[4], double (&w)[4], double&
   const double t = __builtin_fma(u, f, u);                   // A[J][c] / d
   const double uw = rowW * y0;
   const double tw = __builtin_fma(uw, f, uw);                // W[J][c] / d
+  // registers whose four rows (g + 4r, g = 0..3) are all <= J hold finished rows: neither block is updated there
+  constexpr int RMIN = (J + 1) >> 2;
   double colj[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) colj[r] = row_bcast_d<J>(v[r]);   // A[g+4r][J]
+  for (int r = RMIN; r < 4; ++r) colj[r] = row_bcast_d<J>(v[r]);   // A[g+4r][J]
   if constexpr (J < 15) {
     const double s = row_bcast_d<(J + 1) & 15>(rowA);        // A[J][J+1] = A[J+1][J]
     rowA = __builtin_fma(-s, t, preA);
@@ -501,16 +503,16 @@ __device__ __forceinline__ void f16_step(double (&v)[4], double (&w)[4], double&
   }
   const double tm = (c > J) ? t : 0.0;                       // columns <= J are parked: they keep the unscaled L column
 #pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = __builtin_fma(-colj[r], tm, v[r]);
+  for (int r = RMIN; r < 4; ++r) v[r] = __builtin_fma(-colj[r], tm, v[r]);
   constexpr int PR = J >> 2;
-  colj[PR] = (g == (J & 3)) ? 0.0 : colj[PR];               // the pivot row of W stays
+  if constexpr (PR >= RMIN) colj[PR] = (g == (J & 3)) ? 0.0 : colj[PR];   // the pivot row of W stays
 #pragma unroll
-  for (int r = 0; r < 4; ++r) w[r] = __builtin_fma(-colj[r], tw, w[r]);
+  for (int r = RMIN; r < 4; ++r) w[r] = __builtin_fma(-colj[r], tw, w[r]);
 }
 
 template <int NW>
 __global__ __launch_bounds__(NW * 64, NW / 2) void ffgp_potrf_diag128_v2(double* __restrict__ A, int lda, int nb, double* __restrict__ Dinv,
-                                                                 int* info, int row_base, int excl_simd, int prio) {
+                                                                 int* info, int row_base, int prio) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* S = lds;
   volatile D2Flags* fl = reinterpret_cast<volatile D2Flags*>(lds + NBLK_LOWER * BLKSZ);
@@ -518,10 +520,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void ffgp_potrf_diag128_v2(double*
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (wave == 0) D2_TRACE(0);
   if (tid == 0) {
-    fl->seqF = 0; fl->seqX = 0; fl->doneU = 0; fl->sb = 0; fl->abort = 0; fl->nh = 0;
-    unsigned hwid;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    fl->simd0 = (int)((hwid >> 4) & 3);
+    fl->seqF = 0; fl->seqX = 0; fl->doneU = 0; fl->sb = 0; fl->abort = 0;
   }
   // ---- load phase (as in the barrier version): lower blocks, diagonal blocks completed symmetrically, identity padding
   {
@@ -566,24 +565,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void ffgp_potrf_diag128_v2(double*
       if (c > i) Dj[i * BLD + c] = Dj[c * BLD + i];
     }
   }
-  // helper roles: every wave but wave 0 (excl_simd: and but the waves that share wave 0's SIMD -- their MFMAs would sit
-  // in the same pipe as the pivot chain's fp64 operations)
-  int hidx = -1;
-  if (wave != 0) {
-    bool take = true;
-    if (excl_simd) {
-      unsigned hwid;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-      take = ((int)((hwid >> 4) & 3) != fl->simd0);
-    }
-    if (take) {
-      int got = 0;
-      if (lane == 0) got = atomicAdd(const_cast<int*>(&fl->nh), 1);
-      hidx = __builtin_amdgcn_readfirstlane(got);
-    }
-  }
+  // helper roles: every wave but wave 0.  (Keeping the helpers off wave 0's SIMD -- so that no MFMA shares a pipe with
+  // the pivot chain's fp64 operations -- was measured: no difference.)
+  const int hidx = wave - 1;
+  constexpr int NH = NW - 1;
   __syncthreads();
-  const int NH = fl->nh;
   volatile int* ab = &fl->abort;
   const int g = lane >> 4, c = lane & 15;
 
@@ -623,6 +609,20 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void ffgp_potrf_diag128_v2(double*
       f16_step<13>(v, w, rowA, rowW, cc, gg);
       f16_step<14>(v, w, rowA, rowW, cc, gg);
       f16_step<15>(v, w, rowA, rowW, cc, gg);
+      // operands of G(jj) that do not depend on this block's result are fetched now, under the post-processing below:
+      // the helpers' updates of iteration jj-1 must have landed in S[jj+1][jj] and S[jj+1][jj+1]
+      double sb[4];
+      d4_t D;
+      if (jj < 7) {
+        if (jj > 0 && !d2_wait_ge(&fl->doneU, NH * jj, ab, info)) break;
+        const double* Sb = S + blk_off(jj + 1, jj);
+        const double* Sd = S + blk_off(jj + 1, jj + 1);
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) sb[kq] = Sb[c * BLD + kq * 4 + g];       // B operand of Y = inv(L_jj) S[jj+1][jj]^T
+#pragma unroll
+        for (int r = 0; r < 4; ++r) D[r] = Sd[(g + 4 * r) * BLD + c];
+      }
+      D2_TRACE(3 + 3 * jj);
       // the pivot of column c sits, unscaled, on the parked column's diagonal: lane (c & 3, c), register c >> 2
       const int q = c >> 2;
       const double dsel = (q == 0) ? v[0] : (q == 1) ? v[1] : (q == 2) ? v[2] : v[3];
@@ -649,19 +649,12 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void ffgp_potrf_diag128_v2(double*
       if (lane == 0) fl->seqF = jj + 1;
       D2_TRACE(2 + 3 * jj);
       if (jj == 7) break;
-      // ---- G(jj): the helpers' updates of iteration jj-1 must have landed in S[jj+1][jj] and S[jj+1][jj+1]
-      if (jj > 0 && !d2_wait_ge(&fl->doneU, NH * jj, ab, info)) break;
-      D2_TRACE(3 + 3 * jj);
-      const double* Sb = S + blk_off(jj + 1, jj);
-      double* Sd = S + blk_off(jj + 1, jj + 1);
+      // ---- G(jj)
       d4_t Y = {0.0, 0.0, 0.0, 0.0};
-      mma16<true>(Y, Dj, BLD, Sb, BLD, lane);                  // Y = inv(L_jj) S[jj+1][jj]^T
-      d4_t D;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) D[r] = Sd[(g + 4 * r) * BLD + c];
-      D2_LDS_FENCE();                                          // the reads of S[jj+1][jj] are done before it is overwritten
+      for (int kq = 0; kq < 4; ++kq) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(Dj[c * BLD + kq * 4 + g], sb[kq], Y, 0, 0, 0);
       {
-        double* Xb = S + blk_off(jj + 1, jj);                  // L[jj+1][jj] = Y^T
+        double* Xb = S + blk_off(jj + 1, jj);                  // L[jj+1][jj] = Y^T  (its old content sits in sb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int k = g + 4 * r;                             // Y[k][c] -> X[c][k]
@@ -680,7 +673,6 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void ffgp_potrf_diag128_v2(double*
     }
     return;
   }
-  if (hidx < 0) return;
 
   // ================================ helpers ================================
   int sb_target = 0;
@@ -843,7 +835,7 @@ static int launch_diag(ffgp_handle* h, double* Ablk, int lda, int nb, double* Di
       h->diag_attr_set |= 2;
     }
     hipLaunchKernelGGL(ffgp_potrf_diag128_v2<8>, dim3(1), dim3(512), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk, h->d_info,
-                       row_base, h->diag_v2 == 2 ? 1 : 0, h->aux_prio);
+                       row_base, h->aux_prio);
     return FFGP_OK;
   }
   hipLaunchKernelGGL(ffgp_potrf_diag128, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk,
