@@ -1,8 +1,8 @@
 """Kernel modules with the reference's names, parameters and call signature
 (`GaussianProcess/kernel.py`: LinearKernel :23-63, ARDKernel :65-105, MaternKernel :109-169, SumKernel :172-203,
 ProductKernel :205-236, SquaredExponentialKernel :239-272, RationalQuadraticKernel :275-310); the covariance itself
-is assembled by the HIP library.  Not provided: MaternKernel_scalarLengthScale (:312-347) -- its sqrt of an
-unclamped norm-expansion distance is NaN whenever rounding leaves a diagonal entry negative.
+is assembled by the HIP library.  MaternKernel_scalarLengthScale (:312-347) is provided in the reference's own arithmetic
+(norm-expansion distance, matrix product on the fp64 GEMM), NaN behaviour included -- see its docstring.
 
 Each module owns the same raw nn.Parameters as the reference (names show up in state_dict logs,
 `FidelityFusion_Models/log/ResGP/train.log:2`) and exposes `effective()` -> (w, amp, clamp): the inverse length
@@ -148,3 +148,33 @@ class ProductKernel(_Pair):
 
     def forward(self, x1, x2):
         return self.kernel1(x1, x2) * self.kernel2(x1, x2)
+
+
+class MaternKernel_scalarLengthScale(nn.Module):
+    """K = signal_variance^2 * (1 + sqrt(3 sqdist) / length_scale^2)^(-nu), sqdist = |x1|^2 + |x2|^2 - 2 x1 x2^T, all three
+    raw parameters learnable (`nu` too) -- GaussianProcess/kernel.py:312-347, formula at :346-347 (despite its name it is
+    not a Matern covariance).
+
+    The distance is the UNCLAMPED norm expansion: wherever rounding leaves it negative -- on the diagonal of
+    kernel(x, x), where the three terms cancel to +-1e-16 -- sqrt returns NaN, in the reference and here alike (which
+    entries go negative depends on the summation order of the matrix product, so the NaN PATTERN is not reproducible
+    between any two BLAS builds; the reference's own demos never use this kernel on coincident points).  Kept as the
+    reference wrote it rather than repaired: cross-covariances between distinct points are finite and pinned by a
+    fixture.  The matrix product runs on the fp64 matrix-core GEMM (forward and backward), the elementwise tail in torch
+    on the device, so autograd reaches length_scale, signal_variance, nu and the inputs as in the reference."""
+    _ffgp_device_aware = True
+
+    def __init__(self, length_scale=1.0, signal_variance=1.0, nu=2.5):
+        super().__init__()
+        self.length_scale = nn.Parameter(torch.tensor([length_scale]))
+        self.signal_variance = nn.Parameter(torch.tensor([signal_variance]))
+        self.nu = nn.Parameter(torch.tensor([nu]))
+
+    def forward(self, x1, x2):
+        dev = F._device_of(x1, x2)
+        a, b = x1.to(device=dev, dtype=torch.float64), x2.to(device=dev, dtype=torch.float64)
+        sqdist = (a * a).sum(1).reshape(-1, 1) + (b * b).sum(1) - 2.0 * F.matmul_nt(a, b)
+        ls, sv, nu = (p.to(device=dev, dtype=torch.float64) for p in (self.length_scale, self.signal_variance, self.nu))
+        K = sv.pow(2) * torch.pow(1.0 + torch.sqrt(3.0 * sqdist) / ls.pow(2), -nu)
+        odt = x1.dtype if x1.dtype.is_floating_point else torch.float64
+        return K.to(device=x1.device, dtype=odt)

@@ -97,6 +97,15 @@ def se_kernel(x1, x2, length_scale, signal_variance):
     return np.exp(sv) ** 2 * np.exp(-0.5 * sqdist_expanded(x1, x2) / np.exp(ls) ** 2)
 
 
+def matern_scalar_kernel(x1, x2, length_scale, signal_variance, nu):
+    """MaternKernel_scalarLengthScale.forward, GaussianProcess/kernel.py:346-347: sv^2 (1 + sqrt(3 sqdist) / ls^2)^-nu on
+    the unclamped norm-expansion distance (NaN where rounding leaves it negative, as in the reference)."""
+    sq = sqdist_expanded(x1, x2)
+    ls, sv, nu = (float(np.ravel(v)[0]) for v in (length_scale, signal_variance, nu))
+    with np.errstate(invalid="ignore"):
+        return sv ** 2 * np.power(1.0 + np.sqrt(3.0 * sq) / ls ** 2, -nu)
+
+
 def se_kernel_2023(x1, x2, length_scale, scale, exp_format):
     """K3: SE_kernel.forward, MFGP_ver2023May/kernel/SE_kernel.py:20-44 (inputs >2-D are flattened :29-32)."""
     ls = float(np.ravel(length_scale)[0])

@@ -844,6 +844,18 @@ def main():
     except Exception as e:  # noqa
         print("hogp2023_block skipped:", repr(e))
 
+    # ------------------------------------------------------------------ MaternKernel_scalarLengthScale (kernel.py:312-347): cross-covariance
+    # between DISTINCT point sets (on coincident points the unclamped sqrt is NaN at rounding-dependent places), values and
+    # autograd gradients w.r.t. length_scale, signal_variance, nu and both inputs
+    g9 = torch.Generator().manual_seed(424242)
+    xa = (torch.rand(41, 3, generator=g9) * 2).requires_grad_(True)
+    xb = (torch.rand(29, 3, generator=g9) * 2 + 0.05).requires_grad_(True)
+    km = rk.MaternKernel_scalarLengthScale(length_scale=1.3, signal_variance=-0.8, nu=1.7)
+    Kms = km(xa, xb)
+    Rm = torch.rand(41, 29, generator=g9)
+    (Kms * Rm).sum().backward()
+    save("k_matern_scalar", x1=xa, x2=xb, K=Kms, R=Rm, length_scale=km.length_scale, signal_variance=km.signal_variance, nu=km.nu,
+         g_length_scale=km.length_scale.grad, g_signal_variance=km.signal_variance.grad, g_nu=km.nu.grad, g_x1=xa.grad, g_x2=xb.grad)
 
     os.chdir(cwd)
 

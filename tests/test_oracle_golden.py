@@ -401,3 +401,9 @@ def test_torch_cpu_ref_matches_reference_fixture(golden, name):
         assert np.abs(v.numpy() - ref).max() <= 1e-10 * max(np.abs(ref).max(), 1e-300), k
     r = T.time_cigp(t("X"), t("Y"), t("length_scales"), t("signal_variance"), t("log_beta"), repeats=1, budget_s=5.0)
     assert r["fwd_s"] > 0 and abs(r["ll"] - float(g["ll"])) <= 1e-12 * abs(float(g["ll"]))
+
+
+def test_matern_scalar_kernel_oracle(golden):
+    g = golden("k_matern_scalar")
+    K = O.matern_scalar_kernel(g["x1"], g["x2"], g["length_scale"], g["signal_variance"], g["nu"])
+    assert np.abs(K - g["K"]).max() <= 1e-13 * np.abs(g["K"]).max()
