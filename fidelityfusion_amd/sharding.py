@@ -38,6 +38,25 @@ def _rank_world(group=None):
     return 0, 1
 
 
+def _f64(a):
+    """values of a block description as a float64 tensor (a Python float must not pass through torch's float32 default)"""
+    import numpy as np
+    if isinstance(a, torch.Tensor):
+        return a.detach().to(dtype=torch.float64, device="cpu").reshape(-1)
+    return torch.from_numpy(np.asarray(a, dtype=np.float64).reshape(-1))
+
+
+def _block_model(block, dev, kernel, cigp):
+    """cigp(ARDKernel) with the block's hyper-parameters, built in fp64 whatever torch's default dtype is"""
+    k = kernel.ARDKernel(len(block["length_scales"]))
+    m = cigp(k, 0.0).double()
+    with torch.no_grad():
+        k.length_scales.copy_(_f64(block["length_scales"]))
+        k.signal_variance.copy_(_f64(block["signal_variance"])[:1])
+        m.log_beta.copy_(_f64(block["log_beta"])[:1])
+    return m.to(dev)
+
+
 def hip_block_evaluator(device=None):
     """Default evaluator: cigp (ARD kernel) on the fused HIP path.  block = dict(X, Y, length_scales,
     signal_variance, log_beta); returns the block's +LL (what cigp.negative_log_likelihood returns) as a float."""
@@ -46,11 +65,7 @@ def hip_block_evaluator(device=None):
 
     def evaluate(block):
         dev = device or torch.device("cuda", torch.cuda.current_device())
-        k = kernel.ARDKernel(len(block["length_scales"]))
-        with torch.no_grad():
-            k.length_scales.copy_(torch.as_tensor(block["length_scales"], dtype=k.length_scales.dtype))
-            k.signal_variance.copy_(torch.as_tensor(block["signal_variance"], dtype=k.signal_variance.dtype).reshape(1))
-        m = cigp(k, float(torch.as_tensor(block["log_beta"]).reshape(-1)[0])).to(dev).double()
+        m = _block_model(block, dev, kernel, cigp)
         X = torch.as_tensor(block["X"], dtype=torch.float64, device=dev)
         Y = torch.as_tensor(block["Y"], dtype=torch.float64, device=dev)
         with torch.no_grad():
@@ -71,10 +86,7 @@ def hip_blocks_evaluator_concurrent(device=None, nslots=3):
         outs = []
         with torch.no_grad(), F.concurrent_blocks(nslots=max(1, min(nslots, len(owned))), device_index=dev.index) as cb:
             for i, block in enumerate(owned):
-                k = kernel.ARDKernel(len(block["length_scales"]))
-                k.length_scales.copy_(torch.as_tensor(block["length_scales"], dtype=k.length_scales.dtype))
-                k.signal_variance.copy_(torch.as_tensor(block["signal_variance"], dtype=k.signal_variance.dtype).reshape(1))
-                m = cigp(k, float(torch.as_tensor(block["log_beta"]).reshape(-1)[0])).to(dev).double()
+                m = _block_model(block, dev, kernel, cigp)
                 X = torch.as_tensor(block["X"], dtype=torch.float64, device=dev)
                 Y = torch.as_tensor(block["Y"], dtype=torch.float64, device=dev)
                 with cb.slot(i):

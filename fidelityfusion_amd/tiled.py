@@ -174,7 +174,7 @@ class TiledCholesky:
         X = X.to(device=self.dev, dtype=torch.float64)
         w = w.to(device=self.dev, dtype=torch.float64).reshape(-1)
         amp = amp.to(device=self.dev, dtype=torch.float64).reshape(-1)[:1]
-        dadd = float(torch.as_tensor(diag_add).reshape(-1)[0])
+        dadd = float(diag_add.detach().double().reshape(-1)[0]) if isinstance(diag_add, torch.Tensor) else float(diag_add)
         for k in lay.owned(self.rank):
             k0, wk = lay.start(k), lay.width(k)
             T = self.ops.kernel_panel(X[k0:], X[k0:k0 + wk], w, amp, clamp).contiguous()

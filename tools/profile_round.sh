@@ -8,10 +8,10 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/bench.py --steps 10 --warmup 2 > $OUT/bench_c3.json 2> $OUT/bench_c3.err
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o st --output-format csv -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $OUT/stats_bench.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o st --output-format csv -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-sharded > $OUT/stats_bench.json 2> $OUT/stats.err
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   name=$(echo $pass | cut -d' ' -f1)
-  rocprofv3 --pmc $pass -d $OUT/pmc_$name -o pmc --output-format csv -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$name.err
+  rocprofv3 --pmc $pass -d $OUT/pmc_$name -o pmc --output-format csv -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-sharded > /dev/null 2> $OUT/pmc_$name.err
 done
 cd $ROOT
 python3 tools/pmc_summary.py $OUT/pmc_summary.json $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES
