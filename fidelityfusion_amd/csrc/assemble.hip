@@ -25,6 +25,30 @@ struct AsmArgs {
   int kfun; double rinv;   // radial profile and 1/rho
 };
 
+// exp(x) for the argument range of a covariance profile (x <= 0; correct for moderate positive x too): range reduction
+// x = n ln 2 + r, |r| <= ln2 / 2, Taylor polynomial of degree 13 (truncation 4e-18 relative), v_ldexp_f64.  ~22 vector
+// instructions with every constant in SGPRs -- the library exp() inlines to ~3x that, most of it constant moves and
+// special-case handling this call site cannot reach.  Arguments below -745.2 return exactly 0 (as exp() does).
+__constant__ double ffgp_exp_coef[14] = {1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
+                                         1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0};
+struct ExpCoef {
+  double c[14];
+};
+__device__ __forceinline__ void ffgp_exp_load(ExpCoef& e) {
+#pragma unroll
+  for (int i = 0; i < 14; ++i) e.c[i] = ffgp_exp_coef[i];   // uniform addresses: scalar loads into SGPR pairs
+}
+__device__ __forceinline__ double ffgp_exp_fast(double x, const ExpCoef& e) {
+  x = fmax(x, -750.0);                                   // exp(-750) < 2^-1074: ldexp flushes it to exactly 0, like exp() does
+  const double n = __builtin_rint(x * 1.4426950408889634);
+  double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
+  r = __builtin_fma(n, -1.90821492927058770002e-10, r);
+  double p = e.c[13];
+#pragma unroll
+  for (int i = 12; i >= 0; --i) p = __builtin_fma(p, r, e.c[i]);
+  return __builtin_amdgcn_ldexp(p, (int)n);
+}
+
 __global__ __launch_bounds__(256) void ffgp_assemble_kernel(AsmArgs a) {
   __shared__ double x1s[AT][DC + 1];
   __shared__ double x2t[DC][AT + 1];
@@ -56,10 +80,13 @@ __global__ __launch_bounds__(256) void ffgp_assemble_kernel(AsmArgs a) {
       const int idx = tid + 256 * q;
       const int row = idx >> 4, dd = idx & 15;
       const int gd = d0 + dd;
-      const double wk = (gd < a.D) ? a.w[gd] : 0.0;
+      // (unconditional loads from clamped addresses, masked afterwards: guarded loads serialise on memory latency)
+      const int gdc = min(gd, a.D - 1);
+      const double wk = a.w[gdc];
       const int g1 = r0 + row, g2 = c0 + row;
-      x1s[row][dd] = (gd < a.D && g1 < a.n1) ? a.X1[(size_t)g1 * a.D + gd] * wk : 0.0;
-      x2t[dd][row] = (gd < a.D && g2 < a.n2) ? a.X2[(size_t)g2 * a.D + gd] * wk : 0.0;
+      const double l1 = a.X1[(size_t)min(g1, a.n1 - 1) * a.D + gdc], l2 = a.X2[(size_t)min(g2, a.n2 - 1) * a.D + gdc];
+      x1s[row][dd] = (gd < a.D && g1 < a.n1) ? l1 * wk : 0.0;
+      x2t[dd][row] = (gd < a.D && g2 < a.n2) ? l2 * wk : 0.0;
     }
     __syncthreads();
 #pragma unroll
@@ -82,6 +109,9 @@ __global__ __launch_bounds__(256) void ffgp_assemble_kernel(AsmArgs a) {
 
   const double amp = a.amp[0];
   const double dadd = a.diag_add ? a.diag_add[0] : 0.0;
+  ExpCoef ec;
+  ffgp_exp_load(ec);
+  const bool se = (a.kfun == FFGP_KFUN_SE);
   double tsum = 0.0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -91,7 +121,7 @@ __global__ __launch_bounds__(256) void ffgp_assemble_kernel(AsmArgs a) {
       const int col = c0 + tx + 16 * j;
       if (row < a.n1 && col < a.n2) {
         const double s = fmax(sq[i][j], a.clamp);
-        double k = amp * ffgp_kfun_val(a.kfun, a.rinv, s);
+        double k = amp * (se ? ffgp_exp_fast(-0.5 * s, ec) : ffgp_kfun_val(a.kfun, a.rinv, s));
         tsum += k;
         if (a.symmetric) {
           if (row == col) {
@@ -166,13 +196,13 @@ int ffgp_assemble_impl(ffgp_handle* h, const double* X1, int n1, const double* X
   a.ksum = nullptr;
   a.kfun = kfun;
   a.rinv = (kparam != 0.0) ? 1.0 / kparam : 1.0;
-  const int tm = (n1 + AT - 1) / AT;
-  a.tiles_n = (n2 + AT - 1) / AT;
-  const int tiles = lower_only ? tm * (tm + 1) / 2 : tm * a.tiles_n;
   if (mean_jitter != 0.0) {
     a.ksum = h->d_scal + 32;
     hipLaunchKernelGGL(ffgp_zero_scalar, dim3(1), dim3(1), 0, h->stream, a.ksum);
   }
+  const int tm = (n1 + AT - 1) / AT;
+  a.tiles_n = (n2 + AT - 1) / AT;
+  const int tiles = lower_only ? tm * (tm + 1) / 2 : tm * a.tiles_n;
   hipLaunchKernelGGL(ffgp_assemble_kernel, dim3(tiles), dim3(256), 0, h->stream, a);
   if (mean_jitter != 0.0)
     hipLaunchKernelGGL(ffgp_mean_jitter_kernel, dim3((n1 + 255) / 256), dim3(256), 0, h->stream, K, ldk, n1, a.ksum,

@@ -569,3 +569,22 @@ def test_eigh_small_backward_matches_torch():
     assert abs(outs[0][0] - outs[1][0]) <= 1e-11 * abs(outs[1][0])
     g0, g1 = outs[0][1], outs[1][1]
     assert np.abs(g0 - 0.5 * (g1 + g1.T)).max() <= 1e-9 * np.abs(g1).max()
+
+
+@pytest.mark.gpu
+def test_assembly_exp_range(ff):
+    """the assembly's own exp (range reduction + degree-13 polynomial + ldexp) against torch over the whole argument range:
+    ~1 ulp where the result is normal, exactly 0 where exp() underflows, finite in the subnormal range"""
+    import torch
+    from fidelityfusion_amd import functional as F
+    dev = "cuda:0"
+    # squared distances 0 .. 1600 between points on a line: K = exp(-s / 2) spans 1 .. e^-800
+    x = torch.linspace(0.0, 40.0, 4001, dtype=torch.float64, device=dev).reshape(-1, 1)
+    one = torch.ones(1, dtype=torch.float64, device=dev)
+    K = F.kernel_matrix(x[:1], x, one, one, clamp=1e-30)[0]
+    ref = torch.exp(-0.5 * torch.clamp((x[:, 0] - x[0, 0]) ** 2, min=1e-30))
+    normal = ref > 1e-300
+    assert float(((K - ref).abs() / ref)[normal].max()) < 4e-16
+    assert bool((K[ref == 0.0] == 0.0).all()) and int((ref == 0.0).sum()) > 100
+    sub = (~normal) & (ref > 0)
+    assert bool(torch.isfinite(K[sub]).all()) and float((K[sub] - ref[sub]).abs().max()) < 1e-300
