@@ -57,9 +57,12 @@ __global__ __launch_bounds__(256) void ffgp_grad_kernel(GradArgs a) {
     for (int q = 0; q < 4; ++q) {
       const int idx = tid + 256 * q;
       const int row = idx >> 4, dd = idx & 15, gd = d0 + dd;
-      const double wk = (gd < a.D) ? a.w[gd] : 0.0;
-      x1s[row][dd] = (gd < a.D && r0 + row < a.n) ? a.X[(size_t)(r0 + row) * a.D + gd] * wk : 0.0;
-      x2t[dd][row] = (gd < a.D && c0 + row < nc) ? Xc[(size_t)(c0 + row) * a.D + gd] * wk : 0.0;
+      // unconditional loads from clamped addresses, masked afterwards (guarded loads serialise on memory latency)
+      const int gdc = min(gd, a.D - 1);
+      const double wk = a.w[gdc];
+      const double l1 = a.X[(size_t)min(r0 + row, a.n - 1) * a.D + gdc], l2 = Xc[(size_t)min(c0 + row, nc - 1) * a.D + gdc];
+      x1s[row][dd] = (gd < a.D && r0 + row < a.n) ? l1 * wk : 0.0;
+      x2t[dd][row] = (gd < a.D && c0 + row < nc) ? l2 * wk : 0.0;
     }
     __syncthreads();
 #pragma unroll
@@ -85,6 +88,15 @@ __global__ __launch_bounds__(256) void ffgp_grad_kernel(GradArgs a) {
   const double geff_add = (a.mj_coef != 0.0) ? a.mj_coef * a.trG[0] : 0.0;
   double Wl[4][4];
   double s_amp = 0.0, s_kp = 0.0;
+  double gl[4][4];   // the tile of G: sixteen loads in flight at once (clamped addresses; entries outside the mask are not used)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int rowc = min(r0 + ty + 16 * i, a.n - 1);
+      const int colc = a.rect ? min(c0 + tx + 16 * j, nc - 1) : min(c0 + tx + 16 * j, rowc);
+      gl[i][j] = a.G[(size_t)rowc * a.ldg + colc];
+    }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = r0 + ty + 16 * i;
@@ -93,7 +105,7 @@ __global__ __launch_bounds__(256) void ffgp_grad_kernel(GradArgs a) {
       const int col = c0 + tx + 16 * j;
       double wv = 0.0;
       if (row < a.n && (a.rect ? col < nc : col <= row)) {
-        const double g = a.G[(size_t)row * a.ldg + col] + geff_add;
+        const double g = gl[i][j] + geff_add;
         const double sc = fmax(sq[i][j], a.clamp);
         const double e = ffgp_kfun_val(a.kfun, a.rinv, sc);
         const double sym = (!a.rect && col < row) ? 2.0 : 1.0;
@@ -111,9 +123,12 @@ __global__ __launch_bounds__(256) void ffgp_grad_kernel(GradArgs a) {
     for (int q = 0; q < 4; ++q) {
       const int idx = tid + 256 * q;
       const int row = idx >> 4, dd = idx & 15, gd = d0 + dd;
-      const double wk = (gd < a.D) ? a.w[gd] : 0.0;
-      x1s[row][dd] = (gd < a.D && r0 + row < a.n) ? a.X[(size_t)(r0 + row) * a.D + gd] * wk : 0.0;
-      x2t[dd][row] = (gd < a.D && c0 + row < nc) ? Xc[(size_t)(c0 + row) * a.D + gd] * wk : 0.0;
+      // unconditional loads from clamped addresses, masked afterwards (guarded loads serialise on memory latency)
+      const int gdc = min(gd, a.D - 1);
+      const double wk = a.w[gdc];
+      const double l1 = a.X[(size_t)min(r0 + row, a.n - 1) * a.D + gdc], l2 = Xc[(size_t)min(c0 + row, nc - 1) * a.D + gdc];
+      x1s[row][dd] = (gd < a.D && r0 + row < a.n) ? l1 * wk : 0.0;
+      x2t[dd][row] = (gd < a.D && c0 + row < nc) ? l2 * wk : 0.0;
     }
     __syncthreads();
     double accd[DC];
@@ -282,9 +297,11 @@ __global__ __launch_bounds__(256) void ffgp_kernel_wt_kernel(GradArgs a, double*
     for (int q = 0; q < 4; ++q) {
       const int idx = tid + 256 * q;
       const int row = idx >> 4, dd = idx & 15, gd = d0 + dd;
-      const double wk = (gd < a.D) ? a.w[gd] : 0.0;
-      x1s[row][dd] = (gd < a.D && r0 + row < a.n) ? a.X[(size_t)(r0 + row) * a.D + gd] * wk : 0.0;
-      x2t[dd][row] = (gd < a.D && c0 + row < a.n2) ? a.X2[(size_t)(c0 + row) * a.D + gd] * wk : 0.0;
+      const int gdc = min(gd, a.D - 1);
+      const double wk = a.w[gdc];
+      const double l1 = a.X[(size_t)min(r0 + row, a.n - 1) * a.D + gdc], l2 = a.X2[(size_t)min(c0 + row, a.n2 - 1) * a.D + gdc];
+      x1s[row][dd] = (gd < a.D && r0 + row < a.n) ? l1 * wk : 0.0;
+      x2t[dd][row] = (gd < a.D && c0 + row < a.n2) ? l2 * wk : 0.0;
     }
     __syncthreads();
 #pragma unroll
