@@ -67,6 +67,7 @@ EXPORTS = {
     "ffgp_rows_in": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_int, C.c_int, _dp]),
     "ffgp_trtri_diag": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int]),
     "ffgp_invalidate": (C.c_int, [C.c_void_p]),
+    "ffgp_allreduce_sum": (C.c_int, [C.c_void_p, C.c_void_p, _dp, C.c_int]),
     "ffgp_trsm_lower": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int]),
     "ffgp_trsm_lower_t": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int]),
     "ffgp_potrs": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int]),

@@ -346,6 +346,36 @@ int ffgp_trtri_diag(ffgp_handle* h, const double* L, int n, int ldl) {
   return ffgp_refresh_dinv(h, L, n, ldl);
 }
 
+// ---- RCCL, resolved at run time ------------------------------------------------------------------------------
+#include <dlfcn.h>
+typedef int (*ffgp_nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+static ffgp_nccl_allreduce_fn ffgp_resolve_allreduce() {
+  static ffgp_nccl_allreduce_fn fn = nullptr;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);   // the copy already in the process, if any (same SONAME)
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (lib) fn = reinterpret_cast<ffgp_nccl_allreduce_fn>(dlsym(lib, "ncclAllReduce"));
+    if (!fn) fprintf(stderr, "[ffgp] ffgp_allreduce_sum: cannot resolve ncclAllReduce from librccl.so.1 (%s)\n", dlerror());
+  }
+  return fn;
+}
+
+int ffgp_allreduce_sum(ffgp_handle* h, void* comm, double* buf_dev, int count) {
+  if (!h || !comm || !buf_dev || count <= 0) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  ffgp_nccl_allreduce_fn fn = ffgp_resolve_allreduce();
+  if (!fn) return FFGP_ERR_HIP;
+  const int nccl_double = 8, nccl_sum = 0;   // ncclFloat64, ncclSum (rccl.h)
+  const int rc = fn(buf_dev, buf_dev, (size_t)count, nccl_double, nccl_sum, comm, h->stream);
+  if (rc != 0) {
+    fprintf(stderr, "[ffgp] ncclAllReduce failed with %d\n", rc);
+    return FFGP_ERR_HIP;
+  }
+  return FFGP_OK;
+}
+
 int ffgp_invalidate(ffgp_handle* h) {
   if (!h) return FFGP_ERR_ARG;
   h->dinv_L = nullptr;   // both stores are keyed on the factor's address: forget it, the next solve rebuilds them

@@ -260,6 +260,15 @@ int ffgp_wait(ffgp_handle* h);
 int ffgp_predict(ffgp_handle* h, const ffgp_problem* p, const double* Xs_dev, int nt, int var_mode,
                  double var_add_all, double* mean_dev, double* var_dev, int ldv);
 
+/* ---- multi-GPU: the joint likelihood of sharded blocks --------------------------------------------------- */
+/* buf_dev[0..count) <- element-wise SUM over the ranks of `comm` (in place, fp64), enqueued on the handle's stream: the ONE
+   collective of the per-fidelity sharding -- the F-vector of per-block values, `loss += cigp_list[f].compute_loss(...)`
+   in MFGP_ver2023May/ResGP.py:235,245 (the 2024 trainers' per-fidelity loop, FidelityFusion_Models/CIGAR.py:99-134).
+   `comm` is the caller's ncclComm_t (RCCL); the library resolves ncclAllReduce from librccl.so.1 at the first call
+   (dlopen: libffgp.so has no link-time dependency on RCCL, and a process that already loaded RCCL -- torch -- shares it).
+   Returns FFGP_ERR_ARG for bad arguments, FFGP_ERR_HIP if RCCL cannot be loaded or reports an error.              */
+int ffgp_allreduce_sum(ffgp_handle* h, void* comm, double* buf_dev, int count);
+
 /* ---- instrumentation ------------------------------------------------------------------------------------ */
 /* stage timings (ms) of the last fused call when option "timing" = 1; names are static strings */
 int ffgp_last_timings(ffgp_handle* h, float* ms_out, const char** names_out, int max_stages, int* n_stages);

@@ -470,6 +470,27 @@ def test_c_abi_standalone_consumer(tmp_path):
     assert "c-abi example ok" in out.stdout
 
 
+def test_c_abi_rccl_consumer(tmp_path):
+    """examples/joint_nll_rccl.cpp: the sharded joint likelihood without Python -- blocks dealt to the node's GPUs, fused
+    NLML enqueued per GPU, ONE ffgp_allreduce_sum (RCCL, resolved by the library at run time) of the F-vector; every GPU
+    must end with the block-by-block values.  On the 1-GPU box the communicator has one rank; the call path is the same."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc) or not os.path.exists("/opt/rocm/lib/librccl.so"):
+        pytest.skip("no hipcc / RCCL development files on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "joint_nll_rccl")
+    libdir = os.path.join(root, "fidelityfusion_amd")
+    subprocess.check_call([hipcc, "-O2", "--offload-arch=gfx950", "-I", os.path.join(root, "include"), "-I", "/opt/rocm/include",
+                           os.path.join(root, "examples", "joint_nll_rccl.cpp"), "-L", libdir, "-lffgp", "-L", "/opt/rocm/lib", "-lrccl",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([exe, "8", "6", "1024", "5", "3", "2"], capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "mismatches 0" in out.stdout
+
+
 @pytest.mark.timeout(120)
 @pytest.mark.parametrize("n", [1, 2, 5, 31, 33, 64])
 def test_syevj_small_vs_lapack(n):
