@@ -34,13 +34,23 @@ import torch.nn as nn
 from . import functional as F
 
 
+EIGENSOLVER = "rocsolver"    # n > 64: "rocsolver" = torch.linalg.eigh (default); "jacobi" = the library's own block Jacobi (eigh.py: slow)
+
+
 class eigen_pairs:
     """matrices up to 64 x 64 (the per-mode kernels; tiny input sets) go to the hand-written LDS Jacobi solver
-    (`ffgp_syevj_small`, ~80 us where rocSOLVER's syevd takes 1.7 ms); larger ones to rocSOLVER"""
+    (`ffgp_syevj_small`, ~80 us where rocSOLVER's syevd takes 1.7 ms).  Larger ones -- the N x N input kernel -- go to
+    rocSOLVER through `torch.linalg.eigh`: the one vendor-library call on this path.  The library's own large-N solver
+    (`eigh.jacobi_eigh`, block Jacobi on the LDS kernel and the batched MFMA GEMM) is correct but 30x slower at N = 8192
+    (21 s against 0.67 s) and therefore opt-in: `hogp_simple.EIGENSOLVER = "jacobi"`."""
 
     def __init__(self, matrix):
         if matrix.shape[0] <= 64 and matrix.is_cuda:
             self.value, self.vector = F.eigh_small(matrix)
+        elif matrix.is_cuda and EIGENSOLVER == "jacobi":
+            from .eigh import jacobi_eigh
+            with torch.no_grad():
+                self.value, self.vector = jacobi_eigh(matrix.detach().to(torch.float64))
         else:
             self.value, self.vector = torch.linalg.eigh(matrix, UPLO="U")
 

@@ -1,0 +1,70 @@
+"""The library's own (opt-in) large-N symmetric eigensolver, fidelityfusion_amd/eigh.py, against
+LAPACK, and the HOGP block with both eigensolvers."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _kernel_matrix(n, D, ls, seed=0, kind="se"):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    X = torch.rand((n, D), generator=g, device=DEV, dtype=torch.float64)
+    d = torch.cdist(X / ls, X / ls)
+    return torch.exp(-0.5 * d * d) if kind == "se" else torch.exp(-d)
+
+
+def _check(K, ev, U, tol_rec, tol_orth=2e-10):
+    n = K.shape[0]
+    lam_ref = torch.linalg.eigvalsh(K)
+    scale = float(lam_ref.abs().max())
+    assert ev.shape == (n,) and U.shape == (n, n)
+    assert bool((ev[1:] >= ev[:-1]).all())                                          # ascending, as torch.linalg.eigh
+    assert float((U.T @ U - torch.eye(n, device=DEV, dtype=torch.float64)).abs().max()) < tol_orth
+    rec = (U * ev) @ U.T
+    assert float(torch.linalg.matrix_norm(rec - K)) <= tol_rec * float(torch.linalg.matrix_norm(K))
+    assert float((ev - lam_ref).abs().max()) <= tol_rec * scale
+
+
+@pytest.mark.parametrize("n", [70, 128, 257, 600])
+def test_block_jacobi_dense_core_vs_lapack(n):
+    from fidelityfusion_amd.eigh import jacobi_eigh
+    g = torch.Generator(device=DEV).manual_seed(n)
+    M = torch.randn((n, n), generator=g, device=DEV, dtype=torch.float64)
+    for A in (0.5 * (M + M.T), _kernel_matrix(n, 2, 0.7, seed=n)):
+        ev, U = jacobi_eigh(A)
+        _check(A, ev, U, 5e-12)
+
+
+def test_hogp_block_same_with_both_eigensolvers():
+    """HOGP_simple.log_likelihood / forward at N = 500, d = 6 x 5 with the library's block Jacobi and with rocSOLVER: loss,
+    every gradient, cached g, posterior -- the quantities are basis-independent, so they must agree although the two
+    solvers return different bases of the near-null space"""
+    from fidelityfusion_amd import hogp_simple, kernel
+    n, d1, d2 = 500, 6, 5
+    g = torch.Generator(device=DEV).manual_seed(5)
+    X = torch.rand((n, 3), generator=g, device=DEV, dtype=torch.float64)
+    Y = torch.randn((n, d1, d2), generator=g, device=DEV, dtype=torch.float64)
+    Xt = torch.rand((9, 3), generator=g, device=DEV, dtype=torch.float64)
+    res = {}
+    for solver in ("jacobi", "rocsolver"):
+        hogp_simple.EIGENSOLVER = solver
+        try:
+            m = hogp_simple.HOGP_simple(kernel.ARDKernel(3), 0.7, [d1, d2], variance_mode="eigen").double().to(DEV)
+            Yr = Y.clone().requires_grad_(True)
+            loss = m.log_likelihood(X, Yr)
+            loss.backward()
+            with torch.no_grad():
+                mu, var = m.forward(X, Xt)
+            res[solver] = (float(loss), Yr.grad.clone(), m.noise_variance.grad.clone(), m.kernel_list[0].length_scales.grad.clone(),
+                           m.g.clone(), mu.clone(), var.clone())
+        finally:
+            hogp_simple.EIGENSOLVER = "rocsolver"
+    a, b = res["jacobi"], res["rocsolver"]
+    rel = lambda x, y: float((x - y).abs().max() / y.abs().max())
+    assert abs(a[0] - b[0]) <= 1e-10 * abs(b[0])
+    assert rel(a[1], b[1]) < 1e-8 and rel(a[2], b[2]) < 1e-8 and rel(a[3], b[3]) < 1e-7
+    assert rel(a[4], b[4]) < 1e-8 and rel(a[5], b[5]) < 1e-8
+    # (the reference's "variance" expression divides by the eigenvalues of the jitter-free K_x -- ~1e-16 here -- and is a
+    #  different O(1e5) number for every basis of the near-null space: nothing to compare)
