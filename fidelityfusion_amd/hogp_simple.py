@@ -201,6 +201,7 @@ class HOGP_simple(nn.Module):
         dev = self._dev()
         y = y_train.to(device=dev, dtype=torch.float64)
         self.K.clear()
+        self._K_inv = None            # (reference variance mode: the explicit inverse is formed once per likelihood call)
         self.K.append(self._kernel(0, x_train, x_train))
         for i in range(len(self.kernel_list) - 1):
             _in = mode_dot(self.grid[i].to(device=dev, dtype=torch.float64), self.mapping_vector[i].to(device=dev, dtype=torch.float64), 0)
@@ -225,7 +226,12 @@ class HOGP_simple(nn.Module):
         S_2 = (self.A * self.A.pow(-1 / 2)).pow(2)
         e0 = self.K_eigen[0]
         if self.variance_mode == "reference":   # K_star @ K_x.inverse() @ U_x, the reference's own order of operations (:68)
-            K_inv = torch.linalg.inv(self.K[0].detach() if not torch.is_grad_enabled() else self.K[0])
+            if torch.is_grad_enabled() and self.K[0].requires_grad:
+                K_inv = torch.linalg.inv(self.K[0])
+            else:
+                if getattr(self, "_K_inv", None) is None:
+                    self._K_inv = torch.linalg.inv(self.K[0].detach())
+                K_inv = self._K_inv
             ev_x = F.matmul_nt(F.matmul_nt(K_star, K_inv.T.contiguous()), e0.vector.T.contiguous()).pow(2)
         else:                                   # the same matrix from the cached eigenpairs: K_x^-1 U_x = U_x / lambda
             ev_x = mode_dot(K_star, (e0.vector / e0.value.unsqueeze(0)).T.contiguous(), 1).pow(2)

@@ -1,0 +1,31 @@
+#!/bin/bash
+# Every number DESIGN.md quotes for the round, in one GPU call.  Usage: bash tools/round_numbers.sh <tag>
+TAG=${1:-numbers}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd $ROOT
+python3 bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench.err
+python3 bench.py --workload c2 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_c2.json 2>> $OUT/bench.err
+python3 bench.py --with-grad --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_c3_grad.json 2>> $OUT/bench.err
+python3 bench.py --workload c2 --with-grad --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_c2_grad.json 2>> $OUT/bench.err
+python3 bench.py --workload cigar4 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_cigar4.json 2>> $OUT/bench.err
+python3 bench.py --workload gar8 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_gar8.json 2>> $OUT/bench.err
+python3 bench.py --workload cigar4 --with-grad --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_cigar4_grad.json 2>> $OUT/bench.err
+python3 bench.py --n 8192 --D 8 --d 1024 --steps 10 --warmup 3 --no-cpu-baseline --no-sharded > $OUT/bench_c4_block.json 2>> $OUT/bench.err
+python3 bench.py --n 8192 --D 8 --d 4096 --steps 10 --warmup 3 --no-cpu-baseline --no-sharded > $OUT/bench_c5_block.json 2>> $OUT/bench.err
+python3 bench.py --n 32768 --steps 3 --warmup 1 --no-cpu-baseline --no-sharded > $OUT/bench_n32768.json 2>> $OUT/bench.err
+{
+for t in posterior_bench hogp_bench c4_step small_n_latency v2_bench diag_bench assemble_bench eigh_bench; do
+  echo "## tools/$t.py"; timeout 300 python3 tools/$t.py 2>&1 | grep -v amdgpu.ids | tail -12
+done
+} > $OUT/tools_output.txt
+for f in $OUT/bench_*.json; do python3 - "$f" <<'P'
+import json, sys
+try:
+    o = json.load(open(sys.argv[1]))
+    print(sys.argv[1].split('/')[-1], o["ms_per_step"], "ms", o["value"], o["unit"], "|", o["config"]["workload"][:90])
+except Exception as e:
+    print(sys.argv[1], "unreadable", e)
+P
+done
