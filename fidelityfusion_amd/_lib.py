@@ -26,6 +26,16 @@ ERRORS = {-1: "FFGP_ERR_ARG", -2: "FFGP_ERR_HIP", -3: "FFGP_ERR_ALLOC", -4: "FFG
 _dp = C.c_void_p  # device pointers travel as void*
 
 
+class KDesc(C.Structure):
+    """ffgp_kdesc: one part of a composed kernel (include/ffgp.h)"""
+    _fields_ = [("kfun", C.c_int), ("w_dev", _dp), ("amp_dev", _dp), ("clamp_min", C.c_double), ("kparam", C.c_double),
+                ("center_dev", _dp)]
+
+
+class KDescGrads(C.Structure):
+    _fields_ = [("g_w_dev", _dp), ("g_amp_dev", _dp), ("g_kparam_dev", _dp), ("g_center_dev", _dp)]
+
+
 class Problem(C.Structure):
     _fields_ = [
         ("n", C.c_int), ("D", C.c_int), ("d", C.c_int),
@@ -37,12 +47,14 @@ class Problem(C.Structure):
         ("ll_variant", C.c_int), ("pi_const", C.c_double),
         ("kfun", C.c_int), ("kparam", C.c_double),
         ("cov_dev", _dp), ("ld_cov", C.c_int),
+        ("pair", C.POINTER(KDesc)), ("pair_op", C.c_int),
     ]
 
 
 class Grads(C.Structure):
     _fields_ = [("g_w_dev", _dp), ("g_amp_dev", _dp), ("g_diag_add_dev", _dp), ("g_Y_dev", _dp),
-                ("g_diag_vec_dev", _dp), ("g_cov_dev", _dp), ("ld_gcov", C.c_int), ("g_kparam_dev", _dp)]
+                ("g_diag_vec_dev", _dp), ("g_cov_dev", _dp), ("ld_gcov", C.c_int), ("g_kparam_dev", _dp),
+                ("g_pair", C.POINTER(KDescGrads))]
 
 
 EXPORTS = {
@@ -54,6 +66,10 @@ EXPORTS = {
     "ffgp_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "ffgp_assemble": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, C.c_double, _dp, _dp,
                                 C.c_long, _dp, C.c_int, C.c_double, C.c_double, _dp, C.c_int, C.c_int, C.c_int, C.c_double]),
+    "ffgp_assemble_pair": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_int, C.c_int, C.POINTER(KDesc), C.c_int, _dp, _dp, C.c_long,
+                                     _dp, C.c_int, C.c_double, C.c_double, _dp, C.c_int, C.c_int]),
+    "ffgp_kernel_grad_pair": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_int, C.c_int, C.POINTER(KDesc), C.c_int, _dp, C.c_int,
+                                        C.POINTER(KDescGrads)]),
     "ffgp_potrf": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int]),
     "ffgp_potrf_rows": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, C.c_int]),
     "ffgp_kernel_grad": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_double,

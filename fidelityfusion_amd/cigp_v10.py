@@ -47,7 +47,7 @@ class cigp(F.PosteriorCacheMixin, nn.Module):
             with torch.no_grad():
                 w, amp, clamp = self.kernel.effective()
                 noise = self.log_beta.exp().pow(-1)
-                return F.Posterior(x_train, y_train, w, amp, noise + JITTER, clamp=clamp, kfun=_kfun(self.kernel),
+                return F.Posterior(x_train, y_train, w, amp, noise.double() + JITTER, clamp=clamp, kfun=_kfun(self.kernel),
                                    first_query=first_query, var_add_all=var_add_all)
         return self._pcache.get([x_train, y_train] + list(self.parameters()), build)
 
@@ -96,10 +96,16 @@ class cigp(F.PosteriorCacheMixin, nn.Module):
 
     def negative_log_likelihood(self, x_train, y_train):
         y_train, y_var = _split(y_train)
+        pr = self.kernel.pair() if hasattr(self.kernel, "pair") else None
+        if pr is not None:   # SumKernel(LinearKernel, MaternKernel) of the demos (:81,111,147): two descriptors, fused like a single kernel
+            return -F.nlml_pair(x_train, y_train, pr[0], pr[1], diag_add=self.log_beta.exp().pow(-1).double() + JITTER, diag_vec=y_var,
+                                variant=F.FFGP_LL_V1, pi_const=PI, **F._slot_args())
         if not hasattr(self.kernel, "effective"):
             return -self._nll_composed(x_train, y_train, y_var)
         w, amp, clamp = self.kernel.effective()
-        diag_add = self.log_beta.exp().pow(-1) + JITTER
+        # (.double() first: with an fp32 log_beta -- the reference's default dtype -- the sum would round the jitter away in fp32;
+        # the reference adds the two terms to the fp64 kernel matrix one after the other, :57-58)
+        diag_add = self.log_beta.exp().pow(-1).double() + JITTER
         nll = F.nlml(x_train, y_train, w, amp, diag_add=diag_add, diag_vec=y_var, clamp=clamp, variant=F.FFGP_LL_V1,
                      pi_const=PI, **F._slot_args(), kfun=_kfun(self.kernel))
         return -nll

@@ -23,6 +23,13 @@ int ffgp_kernel_wt_impl(ffgp_handle* h, const double* X1, int n1, const double* 
                         const double* amp, double clamp, int kfun, double kparam, const double* dK, int ldk, double* Wt,
                         int ldw);
 
+int ffgp_assemble_pair_impl(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const ffgp_kdesc* k, int op,
+                            const double* diag_add, const double* diag_vec, long diag_stride, const double* add_mat, int ld_add,
+                            double add_all, double mean_jitter, double* K, int ldk, int lower_only);
+size_t ffgp_grad_pair_partial_doubles(int n1, int n2, int D, int rect);
+int ffgp_grad_pair_impl(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const ffgp_kdesc* k, int op,
+                        const double* G, int ldg, int rect, const double* trG_dev, double mj_coef, double* partial_ws,
+                        const ffgp_kdesc_grads* g);
 int ffgp_rows_in_impl(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, unsigned char* found);
 
 int ffgp_syevj_small_impl(ffgp_handle* h, const double* M, int n, int ldm, int batch, long strideM, double* Q, int ldq,
@@ -339,6 +346,25 @@ int ffgp_kernel_grad(ffgp_handle* h, const double* X1, int n1, const double* X2,
   return ffgp_kernel_grad_impl(h, X1, n1, X2, n2, D, w, amp, clamp_min, kfun, kparam, dK, ldk, g_w, g_amp, g_kparam);
 }
 
+int ffgp_assemble_pair(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const ffgp_kdesc* k, int op,
+                       const double* diag_add, const double* diag_vec, long diag_stride, const double* add_mat, int ld_add,
+                       double add_all, double mean_jitter, double* K, int ldk, int lower_only) {
+  if (!h || !k) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  return ffgp_assemble_pair_impl(h, X1, n1, X2, n2, D, k, op, diag_add, diag_vec, diag_stride, add_mat, ld_add, add_all,
+                                 mean_jitter, K, ldk, lower_only);
+}
+
+int ffgp_kernel_grad_pair(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const ffgp_kdesc* k, int op,
+                          const double* dK, int ldk, const ffgp_kdesc_grads* g) {
+  if (!h || !k || !g) return FFGP_ERR_ARG;
+  if (n1 <= 0 || n2 <= 0) return FFGP_OK;
+  if (D <= 0 || ldk < n2) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  FFGP_CHECK(ffgp_ensure_ws(h, (ffgp_grad_pair_partial_doubles(n1, n2, D, 1) + 16) * sizeof(double)));
+  return ffgp_grad_pair_impl(h, X1, n1, X2, n2, D, k, op, dK, ldk, 1, nullptr, 0.0, h->ws, g);
+}
+
 /* (re)build the inverted 128x128 diagonal blocks of a factor (also the diag-kernel timing hook of tools/) */
 int ffgp_trtri_diag(ffgp_handle* h, const double* L, int n, int ldl) {
   if (!h || !L) return FFGP_ERR_ARG;
@@ -437,14 +463,17 @@ static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll
   if (!h || !p || !nll_dev) return FFGP_ERR_ARG;
   const bool given_cov = (p->cov_dev != nullptr);
   if (p->n <= 0 || p->d <= 0 || !p->Y_dev) return FFGP_ERR_ARG;
-  if (!given_cov && (p->D <= 0 || !p->X_dev || !p->w_dev || !p->amp_dev)) return FFGP_ERR_ARG;
+  const bool pair = (!given_cov && p->pair != nullptr);
+  if (!given_cov && (p->D <= 0 || !p->X_dev)) return FFGP_ERR_ARG;
+  if (!given_cov && !pair && (!p->w_dev || !p->amp_dev)) return FFGP_ERR_ARG;
   if (given_cov && p->ld_cov < p->n) return FFGP_ERR_ARG;
   if (p->ll_variant != FFGP_LL_V1 && p->ll_variant != FFGP_LL_V2) return FFGP_ERR_ARG;
-  if (p->kfun < FFGP_KFUN_SE || p->kfun > FFGP_KFUN_RQ) return FFGP_ERR_ARG;
+  if (!pair && (p->kfun < FFGP_KFUN_SE || p->kfun > FFGP_KFUN_RQ)) return FFGP_ERR_ARG;
   FFGP_HIP(hipSetDevice(h->device));
   const int n = p->n, D = given_cov ? 1 : p->D, d = p->d;
   const bool want_grad = g && (g->g_w_dev || g->g_amp_dev || g->g_diag_add_dev || g->g_Y_dev || g->g_diag_vec_dev || g->g_cov_dev ||
-                                g->g_kparam_dev);
+                                g->g_kparam_dev || (pair && g->g_pair));
+  if (pair && g && (g->g_w_dev || g->g_amp_dev || g->g_kparam_dev)) return FFGP_ERR_ARG;   // a pair's kernel gradients travel in g_pair
   if (given_cov && g && (g->g_w_dev || g->g_amp_dev || g->g_kparam_dev)) return FFGP_ERR_ARG;
   if (g && g->g_cov_dev && g->ld_gcov < p->n) return FFGP_ERR_ARG;
   const bool v2 = (p->ll_variant == FFGP_LL_V2);
@@ -458,7 +487,7 @@ static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll
     o_S = total; total += (size_t)n * ld;          // Sigma^-1 -> G
     o_T = total; total += n1 * n1 + 16;            // TRTRI scratch
     o_At = total; total += (size_t)d * ld;         // A^T = (Sigma^-1 Y)^T
-    o_P = total; total += ffgp_grad_partial_doubles(n, D) + 16;
+    o_P = total; total += (pair ? ffgp_grad_pair_partial_doubles(n, n, D, 0) : ffgp_grad_partial_doubles(n, D)) + 16;
     if (v2) {
       o_Ct = total; total += (size_t)d * ld;       // (L^-1 A)^T
       o_Bt = total; total += (size_t)d * ld;       // B^T = (Sigma^-1 A)^T
@@ -476,6 +505,9 @@ static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll
   if (given_cov) {
     hipLaunchKernelGGL(ffgp_copy_lower_kernel, dim3((n + 31) / 32, (n + 31) / 32), dim3(256), 0, h->stream, p->cov_dev, p->ld_cov,
                        W0, (int)ld, n);
+  } else if (pair) {
+    FFGP_CHECK(ffgp_assemble_pair_impl(h, p->X_dev, n, p->X_dev, n, D, p->pair, p->pair_op, p->diag_add_dev, p->diag_vec_dev,
+                                       p->diag_stride, p->add_mat_dev, p->ld_add, p->add_all, p->mean_jitter, W0, (int)ld, 1));
   } else {
     FFGP_CHECK(ffgp_assemble_impl(h, p->X_dev, n, p->X_dev, n, D, p->w_dev, p->amp_dev, p->clamp_min, p->diag_add_dev,
                                   p->diag_vec_dev, p->diag_stride, p->add_mat_dev, p->ld_add, p->add_all, p->mean_jitter,
@@ -532,7 +564,10 @@ static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll
     }
     FFGP_CHECK(ffgp_grad_impl(h, p->X_dev, n, D, p->w_dev, p->amp_dev, p->clamp_min, S, (int)ld, given_cov ? 0.0 : p->mean_jitter,
                               g->g_w_dev, g->g_amp_dev, g->g_diag_add_dev, g->g_diag_vec_dev, P, p->kfun, p->kparam,
-                              g->g_kparam_dev));
+                              g->g_kparam_dev));   // (a pair: only the trace / diagonal part runs here, tr G lands in d_scal[4])
+    if (pair && g->g_pair)
+      FFGP_CHECK(ffgp_grad_pair_impl(h, p->X_dev, n, p->X_dev, n, D, p->pair, p->pair_op, S, (int)ld, 0, h->d_scal + 4,
+                                     (p->mean_jitter != 0.0) ? p->mean_jitter / ((double)n * (double)n) : 0.0, P, g->g_pair));
     if (g->g_cov_dev)
       hipLaunchKernelGGL(ffgp_symmetrize_kernel, dim3((n + 31) / 32, (n + 31) / 32), dim3(256), 0, h->stream, S, (int)ld,
                          g->g_cov_dev, g->ld_gcov, n, 1.0);

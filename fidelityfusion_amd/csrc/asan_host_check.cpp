@@ -35,6 +35,12 @@ int main() {
     EXPECT(ffgp_potrf(nullptr, &x, 1, 2) < 0);
     EXPECT(ffgp_nlml_fused(nullptr, &p, &x, nullptr) < 0);
     EXPECT(ffgp_wait(nullptr) < 0);
+    ffgp_kdesc kd[2];
+    ffgp_kdesc_grads kg[2];
+    std::memset(kd, 0, sizeof kd);
+    std::memset(kg, 0, sizeof kg);
+    EXPECT(ffgp_assemble_pair(nullptr, &x, 1, &x, 1, 1, kd, FFGP_KOP_SUM, nullptr, nullptr, 0, nullptr, 0, 0.0, 0.0, &x, 2, 0) < 0);
+    EXPECT(ffgp_kernel_grad_pair(nullptr, &x, 1, &x, 1, 1, kd, FFGP_KOP_PRODUCT, &x, 2, kg) < 0);
     std::printf("asan_host_check: no device -- argument / no-device paths clean\n");
     return 0;
   }

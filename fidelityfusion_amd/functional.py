@@ -12,7 +12,7 @@ import weakref
 import torch
 
 from . import _lib
-from ._lib import FFGP_LL_V1, FFGP_LL_V2, FFGP_VAR_DIAG, FFGP_VAR_FULL, PI_TRUNC, Grads, Problem, check, lib
+from ._lib import FFGP_LL_V1, FFGP_LL_V2, FFGP_VAR_DIAG, FFGP_VAR_FULL, PI_TRUNC, Grads, KDesc, KDescGrads, Problem, check, lib
 
 NEG_INF = float("-inf")
 
@@ -75,10 +75,11 @@ def _problem(dev, X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitte
     _check_xy(Xd, Yd)
     n, D = Xd.shape
     d = Yd.shape[1]
-    wd = _weights(w, D, dev)
-    ad = _dev(amp.reshape(-1)[:1], dev)
-    if ad.numel() != 1:
-        raise ValueError("the kernel amplitude must hold one value, got shape %s" % (tuple(amp.shape),))
+    if w is not None:   # (a composed kernel carries its parts in Problem.pair instead)
+        wd = _weights(w, D, dev)
+        ad = _dev(amp.reshape(-1)[:1], dev)
+        if ad.numel() != 1:
+            raise ValueError("the kernel amplitude must hold one value, got shape %s" % (tuple(amp.shape),))
     if diag_vec is not None and tuple(diag_vec.shape) not in ((n,), (n, n)):
         raise ValueError("y_var / diag_vec must be [%d] or [%d, %d] for %d training points, got %s"
                          % (n, n, n, n, tuple(diag_vec.shape)))
@@ -86,9 +87,12 @@ def _problem(dev, X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitte
         raise ValueError("y_var / add_mat must be [%d, %d], got %s" % (n, n, tuple(add_mat.shape)))
     p = Problem()
     p.n, p.D, p.d = n, D, d
-    p.X_dev, p.Y_dev, p.w_dev, p.amp_dev = _ptr(Xd), _ptr(Yd), _ptr(wd), _ptr(ad)
+    p.X_dev, p.Y_dev = _ptr(Xd), _ptr(Yd)
+    keep += [Xd, Yd]
+    if w is not None:
+        p.w_dev, p.amp_dev = _ptr(wd), _ptr(ad)
+        keep += [wd, ad]
     p.clamp_min = clamp
-    keep += [Xd, Yd, wd, ad]
     if diag_add is not None:
         dd = _dev(diag_add.reshape(-1)[:1], dev)
         p.diag_add_dev = _ptr(dd)
@@ -400,6 +404,203 @@ def kernel_matrix(x1, x2, w, amp, clamp=NEG_INF, kfun=(0, 1.0)):
     tensor profile parameter."""
     kfun, kparam = _split_kfun(kfun)
     return _KernelMatrix.apply(x1, x2, w, amp, clamp, kfun, kparam)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# composed kernels: K = k_a (+ | x) k_b as two descriptors in one tile pass (ffgp_assemble_pair / ffgp_kernel_grad_pair and
+# ffgp_problem.pair) -- SumKernel / ProductKernel of GaussianProcess/kernel.py:172-236
+# ----------------------------------------------------------------------------------------------------------------------
+FFGP_KFUN_LINEAR = 5
+FFGP_KOP_SUM, FFGP_KOP_PRODUCT = 0, 1
+_PAIR_KEYS = ("w", "amp", "kparam", "center")
+
+
+def _pair_split(descs):
+    """two descriptor dicts {kfun, w, amp, clamp, kparam, center} -> (static meta, the 8 tensor-or-None autograd inputs)"""
+    meta, tensors = [], []
+    for dsc in descs:
+        kp = dsc.get("kparam", 1.0)
+        kp_t = kp if isinstance(kp, torch.Tensor) else None
+        meta.append((int(dsc["kfun"]), float(dsc.get("clamp", NEG_INF)), float(kp.detach()) if kp_t is not None else float(kp)))
+        tensors += [dsc["w"], dsc["amp"], kp_t, dsc.get("center")]
+    return tuple(meta), tensors
+
+
+def _pair_descs(dev, D, meta, tensors, keep):
+    arr = (KDesc * 2)()
+    for e in range(2):
+        w, amp, _, cen = tensors[4 * e:4 * e + 4]
+        wd = _weights(w, D, dev)
+        ad = _dev(amp.reshape(-1)[:1], dev)
+        arr[e].kfun, arr[e].clamp_min, arr[e].kparam = meta[e]
+        arr[e].w_dev, arr[e].amp_dev = _ptr(wd), _ptr(ad)
+        keep += [wd, ad]
+        if cen is not None and meta[e][0] == FFGP_KFUN_LINEAR:
+            cd = _weights(cen, D, dev)
+            arr[e].center_dev = _ptr(cd)
+            keep.append(cd)
+    return arr
+
+
+def _pair_grad_buffers(dev, D, needs):
+    """needs: 8 flags in the order of the tensor inputs -> (KDescGrads[2] | None, the two [w (D) | center (D) | amp | kparam] buffers)"""
+    if not any(needs):
+        return None, None
+    arr = (KDescGrads * 2)()
+    bufs = torch.empty((2, 2 * D + 2), dtype=torch.float64, device=dev)
+    step = bufs.element_size()
+    for e in range(2):
+        base = bufs[e].data_ptr()
+        nw, na, nk, nc = needs[4 * e:4 * e + 4]
+        if nw:
+            arr[e].g_w_dev = C.c_void_p(base)
+        if nc:
+            arr[e].g_center_dev = C.c_void_p(base + D * step)
+        if na:
+            arr[e].g_amp_dev = C.c_void_p(base + 2 * D * step)
+        if nk:
+            arr[e].g_kparam_dev = C.c_void_p(base + (2 * D + 1) * step)
+    return arr, bufs
+
+
+def _pair_grads_out(bufs, D, needs, metas, scale=None):
+    """the 8 gradient outputs (None where not needed) from the two buffers, reshaped to the inputs' shapes / devices"""
+    if bufs is None:
+        return [None] * 8
+    if scale is not None:
+        bufs = bufs * scale.to(device=bufs.device, dtype=torch.float64)
+    outs = []
+    for e in range(2):
+        views = (bufs[e, :D], bufs[e, 2 * D:2 * D + 1], bufs[e, 2 * D + 1:2 * D + 2], bufs[e, D:2 * D])   # w, amp, kparam, center
+        for k in range(4):
+            m = metas[4 * e + k]
+            if not needs[4 * e + k] or m is None:
+                outs.append(None)
+                continue
+            shape, dtype, device = m
+            t = views[k]
+            if k in (0, 3) and math.prod(shape) == 1 and t.numel() > 1:
+                t = t.sum().reshape(1)    # one value was broadcast over the D input dimensions
+            outs.append(t.reshape(shape).to(device=device, dtype=dtype))
+    return outs
+
+
+class _KernelPair(torch.autograd.Function):
+    """K = k_a(x1, x2) (+ | x) k_b(x1, x2) [n1, n2]; backward: every part's w / amp / kparam / center from one read of dK.
+    (Gradients w.r.t. x1 / x2 are not provided here: callers that need them use the composed per-part path.)"""
+
+    @staticmethod
+    def forward(ctx, x1, x2, op, meta, *tensors):
+        dev = _device_of(x1, x2, tensors[0])
+        h = _lib.handle(dev.index)
+        _lib.bind_stream(h, dev.index)
+        a, b = _dev(x1, dev), _dev(x2, dev)
+        _check_xy(a, what="x1")
+        _check_same_D(a, b, "x2")
+        D = a.shape[1]
+        keep = []
+        descs = _pair_descs(dev, D, meta, tensors, keep)
+        K = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float64, device=dev)
+        check(lib.ffgp_assemble_pair(h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], D, descs, op, None, None, 0, None, 0, 0.0, 0.0,
+                                     _ptr(K), b.shape[0], 0), "ffgp_assemble_pair")
+        ctx.saved = (a, b, descs, keep, op, dev)
+        ctx.metas = [(t.shape, t.dtype, t.device) if isinstance(t, torch.Tensor) else None for t in tensors]
+        odt = x1.dtype if x1.dtype.is_floating_point else torch.float64
+        return K.to(device=x1.device, dtype=odt)
+
+    @staticmethod
+    def backward(ctx, dK):
+        a, b, descs, keep, op, dev = ctx.saved
+        h = _lib.handle(dev.index)
+        _lib.bind_stream(h, dev.index)
+        dKd = _dev(dK, dev)
+        D = a.shape[1]
+        needs = [bool(f) for f in ctx.needs_input_grad[4:12]]
+        garr, bufs = _pair_grad_buffers(dev, D, needs)
+        if garr is not None:
+            check(lib.ffgp_kernel_grad_pair(h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], D, descs, op, _ptr(dKd), dKd.shape[1], garr),
+                  "ffgp_kernel_grad_pair")
+        return (None, None, None, None) + tuple(_pair_grads_out(bufs, D, needs, ctx.metas))
+
+
+def kernel_pair(x1, x2, descs, op):
+    """K = k_a (+ | x) k_b on the device from two descriptor dicts {kfun, w, amp, clamp, kparam, center} in one pass."""
+    meta, tensors = _pair_split(descs)
+    return _KernelPair.apply(x1, x2, int(op), meta, *tensors)
+
+
+class _NLMLPair(torch.autograd.Function):
+    """nlml() for a composed kernel: the pair is assembled straight into the factorisation's buffer and its gradient tile
+    reads G once (ffgp_problem.pair / ffgp_grads.g_pair)."""
+
+    @staticmethod
+    def forward(ctx, X, Y, op, meta, diag_add, diag_vec, add_mat, add_all, mean_jitter, variant, pi_const, slot, defer, rec,
+                *tensors):
+        dev = _device_of(X, Y, tensors[0])
+        h = _lib.handle(dev.index, slot)
+        _lib.bind_stream(h, dev.index)
+        keep = []
+        p, (n, D, d) = _problem(dev, X, Y, None, None, diag_add, diag_vec, add_mat, add_all, mean_jitter, NEG_INF, variant,
+                                pi_const, keep)
+        descs = _pair_descs(dev, D, meta, tensors, keep)
+        p.pair, p.pair_op = descs, int(op)
+        keep.append(descs)
+        # positions: Y 1, diag_add 4, diag_vec 5, the pair's tensors 14..21
+        need_Y, need_da, need_dv = (rec and bool(ctx.needs_input_grad[i]) for i in (1, 4, 5))
+        needs = [rec and bool(f) for f in ctx.needs_input_grad[14:22]]
+        out = torch.empty((), dtype=torch.float64, device=dev)
+        g = None
+        grads = {}
+        if need_Y or need_da or need_dv or any(needs):
+            g = Grads()
+            if need_Y:
+                grads["Y"] = torch.empty((n, d), dtype=torch.float64, device=dev)
+                g.g_Y_dev = _ptr(grads["Y"])
+            if need_da:
+                grads["diag_add"] = torch.empty((1,), dtype=torch.float64, device=dev)
+                g.g_diag_add_dev = _ptr(grads["diag_add"])
+            if need_dv:
+                grads["diag_vec"] = torch.empty((n,), dtype=torch.float64, device=dev)
+                g.g_diag_vec_dev = _ptr(grads["diag_vec"])
+            garr, bufs = _pair_grad_buffers(dev, D, needs)
+            if garr is not None:
+                g.g_pair = garr
+                grads["_pair"] = bufs
+                keep.append(garr)
+        gref = C.byref(g) if g is not None else None
+        if defer:
+            check(lib.ffgp_nlml_fused_async(h, C.byref(p), _ptr(out), gref), "ffgp_nlml_fused_async")
+            _pending.setdefault((dev.index, slot), []).append(keep)
+        else:
+            rc = check(lib.ffgp_nlml_fused(h, C.byref(p), _ptr(out), gref), "ffgp_nlml_fused")
+            if rc > 0:
+                _raise_not_pd(rc, "linalg.cholesky")
+        ctx.grads, ctx.needs, ctx.D = grads, needs, D
+        ctx.meta = [(t.shape, t.dtype, t.device) if isinstance(t, torch.Tensor) else None for t in (Y, diag_add, diag_vec)]
+        ctx.metas = [(t.shape, t.dtype, t.device) if isinstance(t, torch.Tensor) else None for t in tensors]
+        return out.to(device=Y.device, dtype=Y.dtype if Y.dtype.is_floating_point else torch.float64)
+
+    @staticmethod
+    def backward(ctx, gout):
+        def fin(key, idx):
+            if key not in ctx.grads or ctx.meta[idx] is None:
+                return None
+            shape, dtype, device = ctx.meta[idx]
+            t = ctx.grads[key] * gout.to(device=ctx.grads[key].device, dtype=torch.float64)
+            if key == "diag_vec" and len(shape) == 2:
+                t = torch.diag_embed(t)
+            return t.reshape(shape).to(device=device, dtype=dtype)
+
+        pair = _pair_grads_out(ctx.grads.get("_pair"), ctx.D, ctx.needs, ctx.metas, scale=gout)
+        return (None, fin("Y", 0), None, None, fin("diag_add", 1), fin("diag_vec", 2)) + (None,) * 8 + tuple(pair)
+
+
+def nlml_pair(X, Y, descs, op, diag_add=None, diag_vec=None, add_mat=None, add_all=0.0, mean_jitter=0.0, variant=FFGP_LL_V1,
+              pi_const=PI_TRUNC, slot=0, defer=False):
+    """nlml() for K = k_a (+ | x) k_b given as two descriptor dicts (see kernel._Pair.pair)."""
+    meta, tensors = _pair_split(descs)
+    return _NLMLPair.apply(X, Y, int(op), meta, diag_add, diag_vec, add_mat, add_all, mean_jitter, variant, pi_const, slot, defer,
+                           torch.is_grad_enabled(), *tensors)
 
 
 def kernel_on_device(kernel, x1, x2):

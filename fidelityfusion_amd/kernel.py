@@ -29,6 +29,12 @@ class _StationaryKernel(nn.Module):
         """(radial profile id, profile parameter) -- include/ffgp.h FFGP_KFUN_*; squared exponential by default."""
         return (0, 1.0)
 
+    def descriptor(self):
+        """this kernel as one part of a composed kernel (include/ffgp.h ffgp_kdesc)"""
+        w, amp, clamp = self.effective()
+        kf = self.kfun()
+        return {"kfun": kf[0], "w": w, "amp": amp, "clamp": clamp, "kparam": kf[1], "center": None}
+
     def forward(self, x1, x2):
         """Covariance matrix [n1, n2]; differentiable w.r.t. the kernel parameters (the fused likelihood in cigp /
         gp_computation_pack does not go through this call -- it assembles Sigma and its gradient in one pass)."""
@@ -115,6 +121,11 @@ class LinearKernel(nn.Module):
         self.signal_variance = nn.Parameter(torch.tensor([initial_signal_variance]))
         self.center = nn.Parameter(torch.zeros(input_dim))
 
+    def descriptor(self):
+        """K = amp * sum_k w_k^2 (x_k - c_k)(x'_k - c_k) with w = 1 / length_scales (raw, as the reference divides), amp = |sv|"""
+        return {"kfun": F.FFGP_KFUN_LINEAR, "w": 1.0 / self.length_scales, "amp": self.signal_variance.abs(), "clamp": F.NEG_INF,
+                "kparam": 1.0, "center": self.center}
+
     def forward(self, x1, x2):
         c, ls = self.center.to(x1.device), self.length_scales.to(x1.device)
         z1, z2 = (x1 - c) / ls, (x2 - c) / ls
@@ -134,20 +145,41 @@ class _Pair(nn.Module):
     def _ffgp_device_aware(self):
         return all(getattr(k, "_ffgp_device_aware", False) for k in (self.kernel1, self.kernel2))
 
-
-class SumKernel(_Pair):
-    """kernel1(x1, x2) + kernel2(x1, x2)  (kernel.py:172-203).  No fused descriptor: the GP modules evaluate the two
-    parts on the device and hand the composed Sigma to the fused factorisation (ffgp_problem.cov_dev)."""
+    def pair(self):
+        """([descriptor of kernel1, descriptor of kernel2], operator) when both parts are kernels the library evaluates
+        itself (the stationary profiles and LinearKernel) -- then kernel, Sigma extras and all gradients are ONE tile pass
+        each (ffgp_assemble_pair, ffgp_problem.pair); None for anything else (nested compositions, user modules): those
+        are evaluated part by part on the device and composed there."""
+        if FUSE_PAIRS and all(hasattr(k, "descriptor") for k in (self.kernel1, self.kernel2)):
+            return [self.kernel1.descriptor(), self.kernel2.descriptor()], self._OP
+        return None
 
     def forward(self, x1, x2):
-        return self.kernel1(x1, x2) + self.kernel2(x1, x2)
+        pr = self.pair()
+        if pr is not None and not (x1.requires_grad or x2.requires_grad) and x1.dim() == 2 and x2.dim() == 2:
+            return F.kernel_pair(x1, x2, pr[0], pr[1])
+        return self._compose(self.kernel1(x1, x2), self.kernel2(x1, x2))   # (also the path that differentiates w.r.t. the inputs)
+
+
+FUSE_PAIRS = True   # False: always compose part by part (tests compare the two paths)
+
+
+class SumKernel(_Pair):
+    """kernel1(x1, x2) + kernel2(x1, x2)  (kernel.py:172-203)."""
+    _OP = F.FFGP_KOP_SUM
+
+    @staticmethod
+    def _compose(a, b):
+        return a + b
 
 
 class ProductKernel(_Pair):
     """kernel1(x1, x2) * kernel2(x1, x2)  (kernel.py:205-236)."""
+    _OP = F.FFGP_KOP_PRODUCT
 
-    def forward(self, x1, x2):
-        return self.kernel1(x1, x2) * self.kernel2(x1, x2)
+    @staticmethod
+    def _compose(a, b):
+        return a * b
 
 
 class MaternKernel_scalarLengthScale(nn.Module):

@@ -63,8 +63,29 @@ enum {
   FFGP_KFUN_MATERN12 = 1,  /* phi = exp(-sqrt(s)/rho)                       MaternKernel nu = 0.5, GaussianProcess/kernel.py:161-162 */
   FFGP_KFUN_MATERN32 = 2,  /* phi = (1 + a) exp(-a),          a = sqrt(3s)/rho           nu = 1.5, kernel.py:163-164 */
   FFGP_KFUN_MATERN52 = 3,  /* phi = (1 + a + a^2/3) exp(-a),  a = sqrt(5s)/rho           nu = 2.5, kernel.py:165-166 */
-  FFGP_KFUN_RQ = 4         /* phi = (1 + s/(2 alpha))^(-alpha), kparam = alpha (learnable: g_kparam)  RationalQuadraticKernel, kernel.py:297-310 */
+  FFGP_KFUN_RQ = 4,        /* phi = (1 + s/(2 alpha))^(-alpha), kparam = alpha (learnable: g_kparam)  RationalQuadraticKernel, kernel.py:297-310 */
+  FFGP_KFUN_LINEAR = 5     /* not a radial profile: K = amp * sum_k w_k^2 (x_k - c_k)(x'_k - c_k)   LinearKernel, kernel.py:22-63.
+                              Only valid inside an ffgp_kdesc (the two-descriptor entry points below) */
 };
+
+/* One part of a composed kernel -- SumKernel / ProductKernel, GaussianProcess/kernel.py:172-236; the reference's demos and
+   two-fidelity models all run on SumKernel(LinearKernel, MaternKernel) (cigp_v10.py:81; two_fidelity_models/ResGP.py:25,
+   AR_autoRegression.py:31, NAR_NonlinearAR.py:23).  Two descriptors + an operator are evaluated in ONE tile pass. */
+typedef struct {
+  int kfun;                  /* FFGP_KFUN_*  (FFGP_KFUN_LINEAR allowed) */
+  const double* w_dev;       /* [D] inverse length scales */
+  const double* amp_dev;     /* [1] amplitude */
+  double clamp_min;          /* lower clamp on the squared distance (stationary parts) */
+  double kparam;             /* rho / alpha of the profile */
+  const double* center_dev;  /* [D] LinearKernel.center (FFGP_KFUN_LINEAR only; NULL = origin) */
+} ffgp_kdesc;
+typedef struct {             /* gradients w.r.t. one part's effective quantities; any pointer may be NULL */
+  double* g_w_dev;           /* [D] */
+  double* g_amp_dev;         /* [1] */
+  double* g_kparam_dev;      /* [1] (FFGP_KFUN_RQ) */
+  double* g_center_dev;      /* [D] (FFGP_KFUN_LINEAR) */
+} ffgp_kdesc_grads;
+enum { FFGP_KOP_SUM = 0, FFGP_KOP_PRODUCT = 1 };
 
 /* prediction outputs */
 enum {
@@ -97,6 +118,11 @@ typedef struct {
                              assembled (X, w, amp, the diag and add fields are ignored) -- the Gaussian_log_likelihood(y, cov) call
                              shape of gp_computation_pack.py:34-91 -- and the gradient comes back through g_cov_dev */
   int ld_cov;
+  const ffgp_kdesc* pair; /* optional: [2] descriptors of a composed kernel K = k[0] (+|x) k[1] on X_dev.  When set, w_dev / amp_dev /
+                             clamp_min / kfun / kparam above are ignored and the kernel gradients come back through
+                             ffgp_grads.g_pair; every Sigma extra (diag / matrix / all-entries / mean jitter) applies as usual.
+                             Not accepted by ffgp_predict (the modules compose the posterior from ffgp_assemble_pair pieces). */
+  int pair_op;            /* FFGP_KOP_SUM | FFGP_KOP_PRODUCT */
 } ffgp_problem;
 
 /* Gradients of the value returned by ffgp_nlml_fused with respect to the effective quantities.
@@ -110,6 +136,7 @@ typedef struct {
   double* g_cov_dev;      /* [n, n] full symmetric d(value)/d(cov) (what torch's cholesky backward returns), optional */
   int ld_gcov;
   double* g_kparam_dev;   /* [1] d(value)/d(kparam) for FFGP_KFUN_RQ (alpha is an nn.Parameter, kernel.py:295), optional */
+  const ffgp_kdesc_grads* g_pair; /* [2] gradients of the two parts when ffgp_problem.pair is set, optional */
 } ffgp_grads;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------ */
@@ -151,6 +178,18 @@ int ffgp_assemble(ffgp_handle* h, const double* X1_dev, int n1, const double* X2
                   const double* w_dev, const double* amp_dev, double clamp_min, const double* diag_add_dev,
                   const double* diag_vec_dev, long diag_stride, const double* add_mat_dev, int ld_add,
                   double add_all, double mean_jitter, double* K_dev, int ldk, int lower_only, int kfun, double kparam);
+
+/* The same for a composed kernel K = k[0] (+|x) k[1]  (k: two descriptors, op: FFGP_KOP_*): one write-only pass instead of
+   the two kernel evaluations + elementwise combine + torch.eye adds of the reference (kernel.py:172-236 under
+   cigp_v10.py:57-60).  Sigma extras as in ffgp_assemble.                                                        */
+int ffgp_assemble_pair(ffgp_handle* h, const double* X1_dev, int n1, const double* X2_dev, int n2, int D, const ffgp_kdesc* k,
+                       int op, const double* diag_add_dev, const double* diag_vec_dev, long diag_stride,
+                       const double* add_mat_dev, int ld_add, double add_all, double mean_jitter, double* K_dev, int ldk,
+                       int lower_only);
+/* Backward of that call for a dense upstream dK [n1, n2]: g[e] = d sum(dK o K) / d{w, amp, kparam, center} of part e, one
+   read of dK (autograd through Sum/ProductKernel.forward in the reference: two kernel backward chains).   */
+int ffgp_kernel_grad_pair(ffgp_handle* h, const double* X1_dev, int n1, const double* X2_dev, int n2, int D, const ffgp_kdesc* k,
+                          int op, const double* dK_dev, int ldk, const ffgp_kdesc_grads* g);
 
 /* In-place lower Cholesky, A = L L^T (strictly-upper part is not referenced and not written).
    Replaces torch.linalg.cholesky at cigp_v10.py:35,61; gp_computation_pack.py:67,105,128; gp_basic.py:80,131;

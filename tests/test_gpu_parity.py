@@ -265,6 +265,161 @@ def test_gpbasic_sum_linear_ard_golden(golden):
     assert rel(mu, g["mu"]) < 1e-8 and rel(var, g["var"]) < 1e-8
 
 
+def _pair_part(name, D):
+    from fidelityfusion_amd import kernel
+    if name == "lin":
+        k = kernel.LinearKernel(D, 1.4, 0.8)
+        with torch.no_grad():
+            k.center.copy_(torch.linspace(-0.3, 0.4, D))
+            k.length_scales.mul_(torch.linspace(0.8, 1.3, D))
+        return k
+    if name == "ard":
+        k = kernel.ARDKernel(D, 1.3, 0.7)
+        with torch.no_grad():
+            k.length_scales.mul_(torch.linspace(0.7, 1.5, D))
+        return k
+    if name == "se":
+        return kernel.SquaredExponentialKernel(1.1, 0.9)
+    if name == "rq":
+        return kernel.RationalQuadraticKernel(0.9, 1.2, 1.5)
+    nu, rho = {"m05": (0.5, 1.0), "m15": (1.5, 1.3), "m25": (2.5, 1.7)}[name]
+    return kernel.MaternKernel(D, 1.2, 0.6, nu=nu, rho=rho)
+
+
+def _pair_eval(k, fn, fuse):
+    from fidelityfusion_amd import kernel
+    for p_ in k.parameters():
+        p_.grad = None
+    old = kernel.FUSE_PAIRS
+    kernel.FUSE_PAIRS = fuse
+    try:
+        val = fn(k)
+        val.sum().backward()
+    finally:
+        kernel.FUSE_PAIRS = old
+    return val.detach().clone(), {n: p_.grad.clone() for n, p_ in k.named_parameters() if p_.grad is not None}
+
+
+@pytest.mark.parametrize("op", ["sum", "prod"])
+@pytest.mark.parametrize("a,b,D", [("lin", "m25", 5), ("ard", "rq", 5), ("lin", "lin", 3), ("m05", "se", 1), ("rq", "m15", 20),
+                                   ("m25", "lin", 20), ("se", "ard", 17)])
+def test_pair_kernel_matches_composition(a, b, D, op):
+    """the two-descriptor tile pass (ffgp_assemble_pair / ffgp_kernel_grad_pair) against the part-by-part composition
+    (kernel.py:172-236 evaluated as the reference writes it): values and every parameter's gradient, ragged sizes, D above
+    one 16-dimension chunk"""
+    from fidelityfusion_amd import kernel
+    rng = np.random.default_rng(D * 7 + len(a))
+    cls = kernel.SumKernel if op == "sum" else kernel.ProductKernel
+    k = cls(_pair_part(a, D), _pair_part(b, D)).to(DEV)
+    assert k.pair() is not None
+    x1, x2 = T(rng.standard_normal((150, D))), T(rng.standard_normal((77, D)))
+    dK = T(rng.standard_normal((150, 77)))
+    K1, g1 = _pair_eval(k, lambda m: m(x1, x2) * dK, True)
+    K2, g2 = _pair_eval(k, lambda m: m(x1, x2) * dK, False)
+    assert rel(K1, K2) < 1e-13
+    assert set(g1) == set(g2) and len(g1) >= 4
+    for n in g1:
+        assert rel(g1[n], g2[n]) < 1e-10, n
+    # symmetric call (x, x): the diagonal sits on the distance clamp of the Matern parts
+    Ks1, h1 = _pair_eval(k, lambda m: m(x1, x1) * (dK @ dK.T), True)
+    Ks2, h2 = _pair_eval(k, lambda m: m(x1, x1) * (dK @ dK.T), False)
+    assert rel(Ks1, Ks2) < 1e-13
+    for n in h1:
+        assert rel(h1[n], h2[n]) < 1e-10, n
+    # input gradients are the composed path's job: the fused forward steps aside
+    xg = x1.clone().requires_grad_(True)
+    k(xg, x2).sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()
+
+
+@pytest.mark.parametrize("op", ["sum", "prod"])
+@pytest.mark.parametrize("model", ["cigp", "cigp_yvar", "pack", "gp_basic", "gp_basic_yvar"])
+def test_pair_nlml_matches_composition(model, op):
+    """likelihoods over Sum / Product kernels through ffgp_problem.pair (assembly, Sigma extras S1-S4 incl. the mean(K) jitter,
+    gradient tile) == the composed-Sigma path (ffgp_problem.cov_dev + autograd through the parts): value and all gradients"""
+    import fidelityfusion_amd.gp_computation_pack as gp_pack
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp
+    from fidelityfusion_amd.gp_basic import GP_basic
+    rng = np.random.default_rng(11)
+    n, D, d = 203, 4, 3
+    cls = kernel.SumKernel if op == "sum" else kernel.ProductKernel
+    kern = cls(_pair_part("lin" if op == "sum" else "ard", D), _pair_part("m25" if op == "sum" else "rq", D))
+    X = T(rng.standard_normal((n, D)))
+    Y0 = rng.standard_normal((n, d))
+    A = rng.standard_normal((n, n)) * 0.05
+    yv = T(A @ A.T + 0.1 * np.eye(n))
+    if model.startswith("cigp"):
+        m = cigp(kern, 0.3).to(DEV)
+        fn = lambda Y: m.negative_log_likelihood(X, [Y, yv] if model.endswith("yvar") else Y)
+    elif model == "pack":
+        m = kern.to(DEV)
+        lb = T(np.array([0.4]), grad=True)
+        fn = lambda Y: gp_pack.negative_log_likelihood(m, lb, X, Y)
+    else:
+        m = GP_basic(kern, 0.8).to(DEV)
+        fn = lambda Y: m.log_likelihood(X, [Y, yv] if model.endswith("yvar") else Y)
+    res = []
+    for fuse in (True, False):
+        Y = T(Y0, grad=True)
+        if model == "pack":
+            lb.grad = None
+        val, gr = _pair_eval(m, lambda _m: fn(Y), fuse)
+        gr["Y"] = Y.grad.clone()
+        if model == "pack":
+            gr["log_beta"] = lb.grad.clone()
+        res.append((val, gr))
+    (v1, g1), (v2, g2) = res
+    assert rel(v1, v2) < 1e-12
+    assert set(g1) == set(g2)
+    for k_ in g1:
+        assert rel(g1[k_], g2[k_]) < 1e-8, k_
+
+
+@pytest.mark.parametrize("kind", ["ard", "sum"])
+def test_cigp_fp32_log_beta_keeps_the_jitter(kind):
+    """the reference's default dtype is fp32, so `log_beta` is an fp32 parameter: its Sigma adds f32(exp(-log_beta)) and the
+    1e-6 jitter to the fp64 kernel matrix one after the other (cigp_v10.py:57-58).  Summing the two in fp32 first would lose
+    the jitter's low bits (7e-9 on the diagonal = 1e-7 relative on the likelihood at N = 8192); compared here against the
+    reference's expression evaluated with torch on the same device"""
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp
+    rng = np.random.default_rng(4)
+    n, D = 1500, 3
+    X = T(rng.uniform(0, 1, (n, D)))
+    Y = T(np.sin(3 * rng.uniform(0, 1, (n, 1))))
+    k = kernel.ARDKernel(D) if kind == "ard" else kernel.SumKernel(kernel.LinearKernel(D), kernel.MaternKernel(D))
+    m = cigp(k, 2.0).to(DEV).float()                                       # (the test session's default dtype is fp64)
+    assert m.log_beta.dtype == torch.float32
+    with torch.no_grad():
+        got = m.negative_log_likelihood(X, Y)
+        K = m.kernel(X, X)
+        eye = torch.eye(n, device=DEV)                                     # fp32, as in the reference
+        Sigma = K + m.log_beta.exp().pow(-1) * eye + 1e-6 * eye
+        L = torch.linalg.cholesky(Sigma)
+        Gamma = torch.linalg.solve_triangular(L, Y, upper=False)
+        want = -(0.5 * (Gamma ** 2).sum() + L.diagonal().log().sum() + 0.5 * n * np.log(2 * 3.1415))
+    assert rel(got, want) < 1e-11
+
+
+def test_pair_under_no_grad_and_bad_descriptor():
+    """no_grad: no gradient pipeline; a descriptor outside the enum is refused by the library (FFGP_ERR_ARG), not run"""
+    from fidelityfusion_amd import _lib, kernel
+    from fidelityfusion_amd import functional as F
+    from fidelityfusion_amd.cigp_v10 import cigp
+    rng = np.random.default_rng(2)
+    m = cigp(kernel.SumKernel(_pair_part("lin", 3), _pair_part("m15", 3)), 0.0).to(DEV)
+    X, Y = T(rng.standard_normal((90, 3))), T(rng.standard_normal((90, 2)))
+    with torch.no_grad():
+        a = m.negative_log_likelihood(X, Y)
+    b = m.negative_log_likelihood(X, Y)
+    assert not a.requires_grad and b.requires_grad and rel(a, b) < 1e-14
+    descs, op = m.kernel.pair()
+    descs[1]["kfun"] = 9
+    with pytest.raises(_lib.FFGPError):
+        F.kernel_pair(X, X, descs, op)
+
+
 @pytest.mark.parametrize("tag,ls_,hs_", [("eq", (6,), (6,)), ("up", (6,), (9,)), ("two_mode", (3, 4), (3, 6))])
 def test_tensor_linear_golden(golden, tag, ls_, hs_):
     """gp_computation_pack.Tensor_linear (:138-159) on the fp64 GEMM, forward and both backward products"""
