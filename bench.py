@@ -66,6 +66,8 @@ def parse_args(argv=None):
     ap.add_argument("--with-grad", action="store_true", help="time forward + closed-form gradients instead")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--dry", action="store_true", help="CPU plumbing run (needs --backend gloo): no GPU work")
+    ap.add_argument("--slots", type=int, default=2, help="blocks of one rank that overlap on its GPU (fixed-F workloads)")
+    ap.add_argument("--slot-lookahead", action="store_true", help="keep every overlapped block's own look-ahead side stream")
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (development A/B runs)")
     return ap.parse_args(argv)
 
@@ -301,7 +303,7 @@ def run_rank(args):
             if args.with_grad:
                 data[f][1].requires_grad_(True)
         w, amp, dadd = params(D)
-        nslots = max(1, min(3, len(mine)))
+        nslots = max(1, min(args.slots, len(mine)))
 
         def step():
             vals = {}
@@ -310,7 +312,7 @@ def run_rank(args):
                 vals[f] = F.nlml(data[f][0], data[f][1], w, amp, diag_add=dadd, clamp=1e-30)
             elif mine:   # several owned blocks overlap on this GPU
                 ctx = torch.enable_grad() if args.with_grad else torch.no_grad()
-                with ctx, F.concurrent_blocks(nslots=nslots, device_index=local_rank) as cb:
+                with ctx, F.concurrent_blocks(nslots=nslots, device_index=local_rank, lookahead=args.slot_lookahead) as cb:
                     for i, f in enumerate(mine):
                         with cb.slot(i):
                             vals[f] = F.nlml(data[f][0], data[f][1], w, amp, diag_add=dadd, clamp=1e-30, **F._slot_args())

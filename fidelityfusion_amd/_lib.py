@@ -173,6 +173,10 @@ def set_option(key, value, device_index=None, all_slots=False):
         check(lib.ffgp_set_option(h, key.encode(), float(value)), "ffgp_set_option(%s)" % key)
 
 
+def set_option_handle(h, key, value):
+    check(lib.ffgp_set_option(h, key.encode(), float(value)), "ffgp_set_option(%s)" % key)
+
+
 def bind_stream(h, device_index):
     import torch
 

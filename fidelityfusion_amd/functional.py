@@ -247,11 +247,17 @@ class concurrent_blocks:
                     losses[f] = -m.negative_log_likelihood(x[f], y[f])
         # on exit every slot has been waited for (LinAlgError raised if any block failed)
 
-    The likelihood modules pick the active slot up from this context."""
+    The likelihood modules pick the active slot up from this context.
+
+    lookahead=False: the slots' factorisations run WITHOUT their own look-ahead side stream.  Look-ahead hides one block's
+    panel chain under its own trailing update; with several blocks in flight the other blocks' updates do that already, and
+    the side streams' high-priority kernels only get in each other's way (measured, 4 blocks of N = 8192, d = 1024 on one
+    MI355X: 27.9 ms with look-ahead in 3 slots, 23.5 ms without in 2 -- tools/c4_step.py, bench.py --workload cigar4)."""
     active = None
 
-    def __init__(self, nslots=2, device_index=None):
+    def __init__(self, nslots=2, device_index=None, lookahead=False):
         self.nslots = nslots
+        self.lookahead = bool(lookahead)
         self.device_index = torch.cuda.current_device() if device_index is None else device_index
         self.streams = [torch.cuda.Stream(self.device_index) for _ in range(nslots)]
         self.used = set()
@@ -270,6 +276,8 @@ class concurrent_blocks:
         class _Slot:
             def __enter__(self_inner):
                 cb.cur = 1 + (i % cb.nslots)          # slot 0 stays the synchronous default handle
+                if cb.cur not in cb.used:
+                    _lib.set_option_handle(_lib.handle(cb.device_index, cb.cur), "lookahead", 1.0 if cb.lookahead else 0.0)
                 cb.used.add(cb.cur)
                 self_inner.ctx = torch.cuda.stream(cb.streams[cb.cur - 1])
                 self_inner.ctx.__enter__()

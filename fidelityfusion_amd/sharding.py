@@ -74,9 +74,10 @@ def hip_block_evaluator(device=None):
     return evaluate
 
 
-def hip_blocks_evaluator_concurrent(device=None, nslots=3):
+def hip_blocks_evaluator_concurrent(device=None, nslots=2):
     """Evaluates a LIST of owned blocks, overlapping them on the GPU (functional.concurrent_blocks): one block's
-    latency-bound factorisation tail runs under another block's trailing updates (+40 % aggregate at N = 8192)."""
+    latency-bound panel chain runs under another block's trailing updates (4 blocks of N = 8192, d = 1024: 23.7 ms against
+    28.6 ms one after the other)."""
     from . import functional as F
     from . import kernel
     from .cigp_v10 import cigp
@@ -130,9 +131,10 @@ class ShardedTrainer:
     FidelityFusion_Models/ResGP.py:82-88), then the scalar all-reduce for the joint value.
     `make_model(f)` -> nn.Module with `.negative_log_likelihood(x, y)`; `data[f]` = (x, y)."""
 
-    def __init__(self, make_model, data, costs, lr=1e-2, group=None, concurrent=True):
+    def __init__(self, make_model, data, costs, lr=1e-2, group=None, concurrent=True, nslots=2, slot_lookahead=False):
         self.group = group
         self.concurrent = concurrent
+        self.nslots, self.slot_lookahead = nslots, slot_lookahead
         self.rank, self.world = _rank_world(group)
         self.owner = partition_lpt(costs, self.world)
         self.F = len(costs)
@@ -153,7 +155,7 @@ class ShardedTrainer:
         on_gpu = torch.cuda.is_available() and len(self.models) > 1 and self.concurrent
         if on_gpu:   # owned blocks overlap on the GPU; gradients were produced by the same fused calls
             from . import functional as F
-            with F.concurrent_blocks(nslots=min(3, len(self.models))) as cb:
+            with F.concurrent_blocks(nslots=min(self.nslots, len(self.models)), lookahead=self.slot_lookahead) as cb:
                 for i, (f, m) in enumerate(self.models.items()):
                     self.opts[f].zero_grad()
                     with cb.slot(i):

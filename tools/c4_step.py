@@ -16,8 +16,9 @@ dev = "cuda:0"
 F_, n, D, d = 4, int(sys.argv[1]) if len(sys.argv) > 1 else 8192, 8, int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 g = torch.Generator(device=dev).manual_seed(0)
 data = [(torch.rand((n, D), generator=g, device=dev), torch.randn((n, d), generator=g, device=dev)) for _ in range(F_)]
-for conc in (False, True):
-    tr = ShardedTrainer(lambda f: cigp(kernel.ARDKernel(D), 1.0).to(dev), data, [block_cost(n, d)] * F_, lr=1e-2, concurrent=conc)
+for conc, nslots, la in ((False, 1, True), (True, 3, True), (True, 2, False), (True, 4, False)):
+    tr = ShardedTrainer(lambda f: cigp(kernel.ARDKernel(D), 1.0).to(dev), data, [block_cost(n, d)] * F_, lr=1e-2, concurrent=conc,
+                        nslots=nslots, slot_lookahead=la)
     for _ in range(2):
         tr.step()
     torch.cuda.synchronize()
@@ -28,4 +29,4 @@ for conc in (False, True):
     ms = (time.perf_counter() - t0) / 3 * 1e3
     flops = F_ * (n ** 3 + 2.0 * n * n * d + 4.0 * n * n * D)
     print("F=%d N=%d d=%d, one training step of every block, %s: %.1f ms (%.1f TFLOP/s on N^3 + 2N^2 d + 4N^2 D per block)"
-          % (F_, n, d, "overlapped" if conc else "sequential", ms, flops / ms / 1e9))
+          % (F_, n, d, ("overlapped, %d slots, look-ahead %s" % (nslots, "on" if la else "off")) if conc else "sequential", ms, flops / ms / 1e9))

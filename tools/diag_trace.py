@@ -13,7 +13,7 @@ SO = os.path.join(ROOT, "fidelityfusion_amd", "libffgp_dtrace.so")
 
 
 def build():
-    srcs = [os.path.join(CSRC, f) for f in "gemm.hip potrf.hip assemble.hip solve.hip grad.hip join.hip eig.hip api.hip".split()]
+    srcs = [os.path.join(CSRC, f) for f in "gemm.hip potrf.hip assemble.hip pair.hip solve.hip grad.hip join.hip eig.hip api.hip".split()]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DFFGP_DIAG_TRACE", "-shared",
                            "-Wno-unused-value", "-Wno-unused-result", "-o", SO] + srcs)
 
