@@ -441,12 +441,17 @@ __global__ __launch_bounds__(DIAG_THREADS) void ffgp_potrf_diag128(double* __res
 // phase boundaries (never compiled into libffgp.so)
 #ifdef FFGP_DIAG_TRACE
 __device__ unsigned long long* ffgp_diag_trace_buf = nullptr;
+__device__ int ffgp_diag_trace_row = -1;          // -1: every launch stamps (the last one stays); else only the launch at this row
 extern "C" int ffgp_debug_set_diag_trace(void* p) {
   return hipMemcpyToSymbol(HIP_SYMBOL(ffgp_diag_trace_buf), &p, sizeof(p)) == hipSuccess ? 0 : -1;
 }
+extern "C" int ffgp_debug_set_diag_trace_row(int row) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(ffgp_diag_trace_row), &row, sizeof(row)) == hipSuccess ? 0 : -1;
+}
 #define D2_TRACE(slot)                                                                          \
   do {                                                                                          \
-    if (lane == 0 && ffgp_diag_trace_buf) ffgp_diag_trace_buf[(slot)] = wall_clock64();         \
+    if (lane == 0 && ffgp_diag_trace_buf && (ffgp_diag_trace_row < 0 || ffgp_diag_trace_row == row_base))  \
+      ffgp_diag_trace_buf[(slot)] = wall_clock64();                                             \
   } while (0)
 #else
 #define D2_TRACE(slot)

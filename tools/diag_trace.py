@@ -27,7 +27,8 @@ if __name__ == "__main__":
     h = C.c_void_p()
     assert lib.ffgp_create(0, C.byref(h)) == 0
     dev = torch.device("cuda:0")
-    n = 128
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 128           # n > 128: the launch at row `at` of a whole factorisation (in situ)
+    at = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     g = torch.Generator(device=dev).manual_seed(0)
     X = torch.rand((n, 8), generator=g, device=dev, dtype=torch.float64)
     A = torch.exp(-0.5 * torch.cdist(X, X) ** 2) + 0.37 * torch.eye(n, device=dev, dtype=torch.float64)
@@ -39,6 +40,7 @@ if __name__ == "__main__":
         buf.zero_()
         torch.cuda.synchronize()
         assert lib.ffgp_debug_set_diag_trace(C.c_void_p(buf.data_ptr())) == 0
+        assert lib.ffgp_debug_set_diag_trace_row(at if n > 128 else -1) == 0
         assert lib.ffgp_potrf(h, C.c_void_p(W.data_ptr()), n, n) == 0
         torch.cuda.synchronize()
         t = buf.cpu().numpy().astype("float64") / 100.0     # us
