@@ -106,7 +106,7 @@ static int create_resources(ffgp_handle* h) {
   int lo = 0, hi = 0;  // numerically lowest value = greatest priority
   FFGP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
   FFGP_HIP(hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, hi));
-  for (int i = 0; i < 8; ++i) FFGP_HIP(hipEventCreateWithFlags(&h->la_ev[i], hipEventDisableTiming));
+  for (int i = 0; i < 10; ++i) FFGP_HIP(hipEventCreateWithFlags(&h->la_ev[i], hipEventDisableTiming));
   FFGP_HIP(hipMalloc(&h->d_info, 16 * sizeof(int)));
   FFGP_HIP(hipMemset(h->d_info, 0, 16 * sizeof(int)));
   FFGP_HIP(hipDeviceSynchronize());   // NULL-stream memset: make it visible before any (non-blocking) stream touches it
@@ -142,6 +142,7 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->skinny_max_n = 8;
   h->super_min_n = 2048;
   h->la_split = 1;
+  h->la_carry = 1;
   h->aux_prio = 1;
   h->nb_outer = 512;
   h->diag_v2 = 1;
@@ -173,7 +174,7 @@ int ffgp_destroy(ffgp_handle* h) {
   for (int i = 0; i < 2; ++i)
     if (h->syrk_ev[i]) hipEventDestroy(h->syrk_ev[i]);
   for (hipEvent_t e : h->syrk_pool) hipEventDestroy(e);
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 10; ++i)
     if (h->la_ev[i]) hipEventDestroy(h->la_ev[i]);
   if (h->aux) hipStreamDestroy(h->aux);
   if (h->own) hipStreamDestroy(h->own);
@@ -213,6 +214,8 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->diag_dbg = (int)value;
   } else if (!strcmp(key, "la_split")) {
     h->la_split = (int)value;
+  } else if (!strcmp(key, "la_carry")) {
+    h->la_carry = (int)value;
   } else if (!strcmp(key, "lookahead")) {
     h->lookahead = (int)value;
   } else if (!strcmp(key, "polite_m")) {

@@ -96,7 +96,7 @@ struct ffgp_handle {
   hipStream_t stream;   // stream work is enqueued on (caller's, or `own`)
   hipStream_t own;      // the handle's own stream
   hipStream_t aux;      // high-priority side stream for the look-ahead panel factorisation
-  hipEvent_t la_ev[8];  // look-ahead hand-off events
+  hipEvent_t la_ev[10]; // look-ahead hand-off events ([7], [8]: carry mode's "strip Z(k) has run", main -> side stream)
   int aux_prio;         // 1 = look-ahead chain kernels run at raised wave priority
   int force_ts;         // 0 = automatic GEMM tile shape, 32 / 64 / 128 = forced (benchmarks, tests)
   int small_tile_threshold;  // launches with fewer 128-tiles than this use the 64-tile
@@ -105,6 +105,7 @@ struct ffgp_handle {
   int diag_v2;          // 0 = barrier version of the diagonal-block kernel, 1 = pipelined (default), 2 = pipelined, helper waves off wave 0's SIMD
   int la_split;         // 1 = issue the look-ahead part of the trailing update in two launches (first 128 columns first)
   int lookahead;        // 1 = overlap panel k+1 with the trailing update of step k
+  int la_carry;         // 1 = the panel's own update kernels also carry the next panel's first 128 columns (no S_a on the chain)
   int diag_attr_set;    // dynamic-LDS attribute of potrf_diag128 set on this handle's device
   int band_log2;        // GEMM tile order: band height 2^band_log2 tile rows (default 3)
   int split_rem_max;    // split tail of the 128-tile launches: quarter the last (tiles mod 256) tiles when that is <= this (0 = off)

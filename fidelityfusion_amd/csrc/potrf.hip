@@ -905,7 +905,12 @@ int ffgp_refresh_dinv(ffgp_handle* h, const double* L, int n, int ldl) {
 // diagonal factor+inverse, the TRSM of every row below as one GEMM, and the update of the panel's remaining columns
 // `gate` (nullable): event the stream waits on before the panel's first update GEMM -- the look-ahead driver lets
 // the first diagonal factor + TRSM start as soon as the panel's first 128 columns carry the trailing update
-static int factor_panel(ffgp_handle* h, double* A, int n, int mtot, int lda, int k0, int w1, hipEvent_t gate = nullptr) {
+// `carry` (> 0): every update of the panel also covers the `carry` columns to the right of it -- the first block of the NEXT
+// panel -- so that block is complete the moment this panel is and no strip update sits between two panels on the
+// dependency chain; `gate2` (nullable) is waited for together with `gate` (the main stream's earlier contribution to
+// those columns must have landed first)
+static int factor_panel(ffgp_handle* h, double* A, int n, int mtot, int lda, int k0, int w1, hipEvent_t gate = nullptr, int carry = 0,
+                        hipEvent_t gate2 = nullptr) {
   const int pend = k0 + w1;
   for (int j0 = k0; j0 < pend; j0 += NB) {
     const int jb = min(NB, n - j0);
@@ -918,9 +923,10 @@ static int factor_panel(ffgp_handle* h, double* A, int n, int mtot, int lda, int
       // TRSM as GEMM: A21 <- A21 * Dj^T (in place: one column tile, each workgroup rewrites only rows it read)
       FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, A21, lda, Dj, NB, A21, lda, mrows, jb, jb, 1.0, 0.0, 0,
                                   ALIAS_A));
-      const int wrem = pend - (j0 + jb);
+      const int wrem = pend - (j0 + jb) + carry;
       if (wrem > 0) {
         if (gate && j0 == k0) FFGP_HIP(hipStreamWaitEvent(h->stream, gate, 0));
+        if (gate2 && j0 == k0) FFGP_HIP(hipStreamWaitEvent(h->stream, gate2, 0));
         double* C = A + (size_t)(j0 + jb) * lda + (j0 + jb);
         FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 0, A21, lda, A21, lda, C, lda, mrows, wrem, jb, -1.0,
                                     1.0));
@@ -968,6 +974,59 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
                                       -1.0, 1.0));
         }
       }
+    } else if (h->la_carry) {
+      // Look-ahead, "carry" form.  Panel k's own update kernels (one per 128-column block, K = 128) also cover Z(k+1) = the
+      // first 128 columns of panel k+1, so the chain goes from the last TRSM of panel k straight into the first diagonal
+      // block of panel k+1 -- no K = 512 strip update (S_a of the form below) and no event wait between two panels.
+      // The main stream's trailing update of step k is cut into S_b (the rest of panel k+1's columns: gates the chain's
+      // first update, as below) together with S_z (Z(k+2): panel k's contribution to the strip that chain k+1 will carry
+      // into -- its right-hand neighbour, so the two are one launch) and S_ii (everything right of Z(k+2)).  Writers of any one column range
+      // are ordered: Z(k+2) <- S_ii(<= k-1), S_z(k) on the main stream, then chain k+1 (after S_z's event).
+      hipStream_t main_s = h->stream;
+      auto carry_of = [&](int pend_) { return min(NB, n - pend_); };   // columns of the next panel's first block (0 at the end)
+      FFGP_CHECK(factor_panel(h, A, n, mtot, lda, 0, min(pw(0), n), nullptr, max(0, carry_of(min(pw(0), n)))));
+      FFGP_HIP(hipEventRecord(h->la_ev[6], main_s));
+      FFGP_HIP(hipStreamWaitEvent(h->aux, h->la_ev[6], 0));
+      int it = 0;
+      hipEvent_t eb_prev = nullptr;
+      for (int k0 = 0; k0 < n; k0 += pw(k0), ++it) {
+        const int w1 = min(pw(k0), n - k0);
+        const int pend = k0 + w1;
+        const int mt = n - pend;
+        if (mt <= 0) break;
+        const int wn = min(pw(pend), mt);  // width of the next panel
+        const int q = pend + wn;           // first column of panel k+2
+        const int wz = max(0, min(NB, n - q));
+        hipEvent_t eb = h->la_ev[(it & 1) * 3], eg = h->la_ev[(it & 1) * 3 + 1];
+        const int wa = min(NB, wn);        // Z(k+1): already complete (carried by panel k)
+        // main stream, once panel k is complete: S_b(k) and S_z(k) are neighbours (columns pend+wa .. q+wz): one launch, one event
+        if (eb_prev) FFGP_HIP(hipStreamWaitEvent(main_s, eb_prev, 0));
+        hipEvent_t gate = nullptr, gate2 = nullptr;
+        if (wn - wa + wz > 0) {
+          double* Pb = A + (size_t)(pend + wa) * lda + k0;
+          double* Cb = A + (size_t)(pend + wa) * lda + (pend + wa);
+          FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, Pb, lda, Pb, lda, Cb, lda, mtot - pend - wa,
+                                      wn - wa + wz, w1, -1.0, 1.0));
+          FFGP_HIP(hipEventRecord(eg, main_s));
+          gate = eg;
+        }
+        // side stream: panel k+1, carrying Z(k+2)
+        h->stream = h->aux;
+        int rc = factor_panel(h, A, n, mtot, lda, pend, wn, gate, wz, gate2);
+        h->stream = main_s;
+        FFGP_CHECK(rc);
+        FFGP_HIP(hipEventRecord(eb, h->aux));
+        eb_prev = eb;
+        // main stream: S_ii(k), everything right of Z(k+2)
+        const int mt2 = mt - wn - wz;
+        if (mt2 > 0) {
+          double* P2 = A + (size_t)(q + wz) * lda + k0;
+          double* C2 = A + (size_t)(q + wz) * lda + (q + wz);
+          FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P2, lda, P2, lda, C2, lda, mtot - q - wz, mt2, w1, -1.0,
+                                      1.0));
+        }
+      }
+      if (eb_prev) FFGP_HIP(hipStreamWaitEvent(main_s, eb_prev, 0));
     } else {
       // Look-ahead.  The trailing update of step k is cut into S_a (the first 128 columns of panel k+1 -- all that its
       // first diagonal factor and TRSM read), S_b (the rest of panel k+1's columns) and S_ii (everything to the right).
