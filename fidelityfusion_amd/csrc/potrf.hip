@@ -464,13 +464,27 @@ struct D2Flags {      // ints in LDS, behind the block image
 #define D2_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define D2_COMPILER_FENCE() asm volatile("" ::: "memory")
 
+// The flags live in LDS and are touched with explicit DS instructions.  A `volatile` access through the generic pointer
+// compiles to flat_load / flat_store with `s_waitcnt vmcnt(0)`: every poll would first wait for all of the wave's
+// outstanding GLOBAL stores (the L / inverse blocks it has just written -- a memory round trip per hand-off).
+__device__ __forceinline__ int d2_ld(const volatile int* p) {
+  int v;
+  const unsigned off = (unsigned)(uintptr_t)p;          // low half of a generic LDS address = the LDS offset
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(off) : "memory");
+  return v;
+}
+__device__ __forceinline__ void d2_st(volatile int* p, int v) {
+  const unsigned off = (unsigned)(uintptr_t)p;
+  asm volatile("ds_write_b32 %0, %1" : : "v"(off), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ bool d2_wait_ge(volatile int* p, int target, volatile int* abort_flag, int* info) {
   int spins = 0;
-  while (*p < target) {
+  while (d2_ld(p) < target) {
     __builtin_amdgcn_s_sleep(1);
-    if (++spins > (1 << 21) || *abort_flag) {   // ~1 s of polling: something upstream died
-      if (!*abort_flag) atomicExch(info, FFGP_DIAG_WATCHDOG);
-      *abort_flag = 1;
+    if ((++spins & 63) == 0 && (spins > (1 << 21) || d2_ld(abort_flag))) {   // ~1 s of polling: something upstream died
+      if (!d2_ld(abort_flag)) atomicExch(info, FFGP_DIAG_WATCHDOG);
+      d2_st(abort_flag, 1);
       return false;
     }
   }
@@ -525,7 +539,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void ffgp_potrf_diag128_v2(double*
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (wave == 0) D2_TRACE(0);
   if (tid == 0) {
-    fl->seqF = 0; fl->seqX = 0; fl->doneU = 0; fl->sb = 0; fl->abort = 0;
+    d2_st(&fl->seqF, 0); d2_st(&fl->seqX, 0); d2_st(&fl->doneU, 0); d2_st(&fl->sb, 0); d2_st(&fl->abort, 0);
   }
   // ---- load phase (as in the barrier version): lower blocks, diagonal blocks completed symmetrically, identity padding
   {
@@ -651,7 +665,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void ffgp_potrf_diag128_v2(double*
       }
       if (bad && lane == 0 && (jj * 16 + bad) <= nb) atomicCAS(info, 0, row_base + jj * 16 + bad);
       D2_LDS_FENCE();
-      if (lane == 0) fl->seqF = jj + 1;
+      if (lane == 0) d2_st(&fl->seqF, jj + 1);
       D2_TRACE(2 + 3 * jj);
       if (jj == 7) break;
       // ---- G(jj)
@@ -669,7 +683,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void ffgp_potrf_diag128_v2(double*
         }
       }
       D2_LDS_FENCE();
-      if (lane == 0) fl->seqX = jj + 1;
+      if (lane == 0) d2_st(&fl->seqX, jj + 1);
 #pragma unroll
       for (int kq = 0; kq < 4; ++kq) D = __builtin_amdgcn_mfma_f64_16x16x4f64(Y[kq], Y[kq], D, 0, 0, 1);   // D -= Y^T Y
 #pragma unroll
