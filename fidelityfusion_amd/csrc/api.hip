@@ -142,7 +142,7 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->skinny_max_n = 8;
   h->super_min_n = 2048;
   h->la_split = 1;
-  h->la_carry = 1;
+  h->la_carry = 2;
   h->aux_prio = 1;
   h->nb_outer = 512;
   h->diag_v2 = 1;

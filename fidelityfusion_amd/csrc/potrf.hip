@@ -988,7 +988,7 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
                                       -1.0, 1.0));
         }
       }
-    } else if (h->la_carry) {
+    } else if (h->la_carry == 1 || (h->la_carry == 2 && n <= 12288)) {
       // Look-ahead, "carry" form.  Panel k's own update kernels (one per 128-column block, K = 128) also cover Z(k+1) = the
       // first 128 columns of panel k+1, so the chain goes from the last TRSM of panel k straight into the first diagonal
       // block of panel k+1 -- no K = 512 strip update (S_a of the form below) and no event wait between two panels.

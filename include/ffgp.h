@@ -148,8 +148,10 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
             "naive" (1: route factor kernels through the slow reference kernels; debugging only),
             "lookahead" (default 1: factor panel k+1 on a high-priority side stream under the trailing update of step k),
             "la_split" (default 1: the look-ahead column update covers the next panel's first 128 columns only),
-            "la_carry" (default 1: a panel's own update kernels also cover the next panel's first 128 columns, so no strip
-                        update sits between two panels on the dependency chain; 0 = the S_a / S_b / S_ii form),
+            "la_carry" (a panel's own update kernels also cover the next panel's first 128 columns, so no strip update sits
+                        between two panels on the dependency chain: 1 = always, 0 = never (the S_a / S_b / S_ii form),
+                        default 2 = for n <= 12288 -- the chain-bound sizes gain 2-5 %, at n = 16384 the trailing update's
+                        in-situ rate drops 4 % for no gain in total),
             "aux_prio" (default 1: raised wave priority for the side stream's kernels),
             "gemm_tile" (0 = automatic; 32 / 64 / 128 force the GEMM tile shape -- tests and benchmarks),
             "small_tile_threshold" (default 640: launches with fewer 128-tiles use 64-tiles),
