@@ -16,6 +16,7 @@ DEV = "cuda:0"
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 BIG = "big" in sys.argv[3:]
+LOOSE = "loose" in sys.argv[3:]   # the slots' default schedule (no look-ahead of their own): equal to 1e-11, not bit for bit
 from fidelityfusion_amd import _lib
 for kv in sys.argv[3:]:
     if "=" in kv:
@@ -44,7 +45,9 @@ for r in range(rounds):
             y.grad = None
         losses = [None] * nb
         if concurrent:
-            with F.concurrent_blocks(nslots=int(rng.integers(2, 5))) as cb:
+            # (look-ahead on in the slots as well: the sequential reference runs on the default handle with look-ahead, and
+            #  only the same kernel sequence reproduces it bit for bit)
+            with F.concurrent_blocks(nslots=int(rng.integers(2, 5)), lookahead=not LOOSE) as cb:
                 for f, m in enumerate(models):
                     with cb.slot(f):
                         losses[f] = -m.negative_log_likelihood(*blocks[f])
@@ -63,7 +66,7 @@ for r in range(rounds):
     for rep in range(4):
         got = run(True)
         for i, (a, b) in enumerate(zip(ref, got)):
-            if not np.array_equal(a, b):
+            if not (np.allclose(a, b, rtol=1e-11, atol=1e-11 * np.abs(a).max()) if LOOSE else np.array_equal(a, b)):
                 bad += 1
                 print("round %d rep %d item %d (block %d, n=%d d=%d): max abs diff %.3e" % (
                     r, rep, i, i % nb, blocks[i % nb][0].shape[0], blocks[i % nb][1].shape[1], np.abs(a - b).max()))
