@@ -259,6 +259,34 @@ def test_potrf_outer_block_sizes(ff, n, nb):
     assert relerr(np.tril(out[:n, :n]), np.linalg.cholesky(S)) < 1e-11
 
 
+@pytest.mark.parametrize("carry,lookahead", [(0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize("n,m,nb", [(1450, 5, 512), (2600, 0, 512), (1921, 70, 256), (640, 3, 128)])
+def test_potrf_lookahead_forms(ff, n, m, nb, carry, lookahead):
+    """both look-ahead forms of the blocked driver -- the carry form (a panel's updates also cover the next panel's first
+    block; the main stream's S_bz strip gates the side stream's first update) and the S_a / S_b / S_ii form -- and the plain
+    in-order driver, ragged sizes, passenger rows, panel widths down to one block: factor and rows against LAPACK, twice (a
+    missed cross-stream dependency is a race, not a deterministic error)"""
+    import scipy.linalg as sla
+    _lib, h = ff
+    rng = np.random.default_rng(n + m + nb)
+    B = rng.standard_normal((n, 48))
+    S = B @ B.T + np.diag(rng.random(n) + 0.5)
+    R = rng.standard_normal((m, n)) if m else None
+    L = np.linalg.cholesky(S)
+    _lib.lib.ffgp_set_option(h, b"la_carry", float(carry))
+    _lib.lib.ffgp_set_option(h, b"lookahead", float(lookahead))
+    try:
+        for _ in range(2):
+            rc, out, _, _ = potrf(ff, S, R, nb_outer=nb)
+            assert rc == 0
+            assert relerr(np.tril(out[:n, :n]), L) < 1e-11
+            if m:
+                assert relerr(out[n:, :n], sla.solve_triangular(L, R.T, lower=True).T) < 1e-10
+    finally:
+        _lib.lib.ffgp_set_option(h, b"la_carry", 2.0)
+        _lib.lib.ffgp_set_option(h, b"lookahead", 1.0)
+
+
 def test_potrf_naive_kernels_agree(ff):
     rng = np.random.default_rng(2)
     S = spd(200, rng)
