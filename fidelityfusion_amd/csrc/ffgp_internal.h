@@ -64,6 +64,30 @@ __device__ __forceinline__ double ffgp_kfun_dparam(int kind, double rinv, double
   return phi * (u / (1.0 + u) - log1p(u));
 }
 
+// exp(x) for the argument range of a covariance profile (x <= 0; correct for moderate positive x too): range reduction
+// x = n ln 2 + r, |r| <= ln2 / 2, Taylor polynomial of degree 13 (truncation 4e-18 relative), v_ldexp_f64.  ~22 vector
+// instructions with every constant in SGPRs -- the library exp() inlines to ~3x that, most of it constant moves and
+// special-case handling this call site cannot reach.  Arguments below -745.2 return exactly 0 (as exp() does).
+static __constant__ double ffgp_exp_coef[14] = {1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
+                                         1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0};
+struct ExpCoef {
+  double c[14];
+};
+__device__ __forceinline__ void ffgp_exp_load(ExpCoef& e) {
+#pragma unroll
+  for (int i = 0; i < 14; ++i) e.c[i] = ffgp_exp_coef[i];   // uniform addresses: scalar loads into SGPR pairs
+}
+__device__ __forceinline__ double ffgp_exp_fast(double x, const ExpCoef& e) {
+  x = fmax(x, -750.0);                                   // exp(-750) < 2^-1074: ldexp flushes it to exactly 0, like exp() does
+  const double n = __builtin_rint(x * 1.4426950408889634);
+  double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
+  r = __builtin_fma(n, -1.90821492927058770002e-10, r);
+  double p = e.c[13];
+#pragma unroll
+  for (int i = 12; i >= 0; --i) p = __builtin_fma(p, r, e.c[i]);
+  return __builtin_amdgcn_ldexp(p, (int)n);
+}
+
 // GEMM operand layouts.  "K-major": element (row, k) at P[row*ld + k]; "MN-major": at P[k*ld + row].
 enum { OP_KMAJOR = 0, OP_MNMAJOR = 1 };
 // tile scheduling modes: full rectangle / lower-triangular tiles of a symmetric update

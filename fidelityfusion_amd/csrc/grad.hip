@@ -22,158 +22,211 @@ struct GradArgs {
   double mj_coef;         // mean_jitter / n^2
   double* partial;        // [blocks][D+2]: per-block partial sums (deterministic two-stage reduction): w[D], amp, kparam
   int kfun; double rinv;  // radial profile and 1/rho
+  int ntiles, tpb;        // tiles in the sweep, tiles per workgroup (1 when D > 16)
 };
 
 __global__ __launch_bounds__(256) void ffgp_grad_kernel(GradArgs a) {
   __shared__ double x1s[AT][DC + 1];
   __shared__ double x2t[DC][AT + 1];
-  __shared__ double red[4][DC + 1];
+  __shared__ double red[4][DC + 2];
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  const int t = blockIdx.x;
-  int ti, tj;
-  if (a.rect) {
-    const int tn = (a.n2 + AT - 1) / AT;
-    ti = t / tn;
-    tj = t % tn;
-  } else {
-    int r = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-    while ((r + 1) * (r + 2) / 2 <= t) ++r;
-    while (r * (r + 1) / 2 > t) --r;
-    ti = r;
-    tj = t - r * (r + 1) / 2;
-  }
-  const int r0 = ti * AT, c0 = tj * AT;
   const double* __restrict__ Xc = a.rect ? a.X2 : a.X;   // points indexing the columns
   const int nc = a.rect ? a.n2 : a.n;
-
-  // pass 1: squared distances
-  double sq[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) sq[i][j] = 0.0;
-  for (int d0 = 0; d0 < a.D; d0 += DC) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int idx = tid + 256 * q;
-      const int row = idx >> 4, dd = idx & 15, gd = d0 + dd;
-      // unconditional loads from clamped addresses, masked afterwards (guarded loads serialise on memory latency)
-      const int gdc = min(gd, a.D - 1);
-      const double wk = a.w[gdc];
-      const double l1 = a.X[(size_t)min(r0 + row, a.n - 1) * a.D + gdc], l2 = Xc[(size_t)min(c0 + row, nc - 1) * a.D + gdc];
-      x1s[row][dd] = (gd < a.D && r0 + row < a.n) ? l1 * wk : 0.0;
-      x2t[dd][row] = (gd < a.D && c0 + row < nc) ? l2 * wk : 0.0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int dd = 0; dd < DC; ++dd) {
-      double p[4], q2[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) p[i] = x1s[ty + 16 * i][dd];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) q2[j] = x2t[dd][tx + 16 * j];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const double df = p[i] - q2[j];
-          sq[i][j] = __builtin_fma(df, df, sq[i][j]);
-        }
-    }
-    __syncthreads();
-  }
-
-  // W = Geff o K, with the symmetry weight folded in; Wl drops entries whose distance sits on the clamp
   const double amp = a.amp[0];
   const double geff_add = (a.mj_coef != 0.0) ? a.mj_coef * a.trG[0] : 0.0;
-  double Wl[4][4];
+  // D <= 16 (one dimension chunk): a workgroup walks a.tpb consecutive tiles and keeps its sums in registers -- the block
+  // reduction (18 values x 6 shuffle steps, two barriers) is paid once per workgroup instead of once per tile, and the
+  // second pass reads the chunk the first pass left in LDS instead of staging it again.  D > 16: one tile per workgroup,
+  // reduced per chunk.
+  const bool one_chunk = a.D <= DC;
+  double tot[DC];
+#pragma unroll
+  for (int dd = 0; dd < DC; ++dd) tot[dd] = 0.0;
   double s_amp = 0.0, s_kp = 0.0;
-  double gl[4][4];   // the tile of G: sixteen loads in flight at once (clamped addresses; entries outside the mask are not used)
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int rowc = min(r0 + ty + 16 * i, a.n - 1);
-      const int colc = a.rect ? min(c0 + tx + 16 * j, nc - 1) : min(c0 + tx + 16 * j, rowc);
-      gl[i][j] = a.G[(size_t)rowc * a.ldg + colc];
+  ExpCoef ec;
+  ffgp_exp_load(ec);
+  const int t_begin = blockIdx.x * a.tpb, t_end = min(t_begin + a.tpb, a.ntiles);
+  for (int t = t_begin; t < t_end; ++t) {
+    int ti, tj;
+    if (a.rect) {
+      const int tn = (a.n2 + AT - 1) / AT;
+      ti = t / tn;
+      tj = t % tn;
+    } else {
+      int r = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+      while ((r + 1) * (r + 2) / 2 <= t) ++r;
+      while (r * (r + 1) / 2 > t) --r;
+      ti = r;
+      tj = t - r * (r + 1) / 2;
     }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = r0 + ty + 16 * i;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = c0 + tx + 16 * j;
-      double wv = 0.0;
-      if (row < a.n && (a.rect ? col < nc : col <= row)) {
-        const double g = gl[i][j] + geff_add;
-        const double sc = fmax(sq[i][j], a.clamp);
-        const double e = ffgp_kfun_val(a.kfun, a.rinv, sc);
-        const double sym = (!a.rect && col < row) ? 2.0 : 1.0;
-        s_amp += sym * g * e;
-        if (a.kfun == FFGP_KFUN_RQ) s_kp += sym * g * amp * ffgp_kfun_dparam(a.kfun, a.rinv, sc, e);
-        wv = (sq[i][j] >= a.clamp) ? sym * g * amp * ffgp_kfun_m2d(a.kfun, a.rinv, sc) : 0.0;
-      }
-      Wl[i][j] = wv;
-    }
-  }
+    const int r0 = ti * AT, c0 = tj * AT;
 
-  // pass 2: per-dimension sums of W * df^2
-  for (int d0 = 0; d0 < a.D; d0 += DC) {
+    // the tile of G: sixteen loads in flight at once, under the staging below (clamped addresses; entries outside the mask
+    // are not used)
+    double gl[4][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int idx = tid + 256 * q;
-      const int row = idx >> 4, dd = idx & 15, gd = d0 + dd;
-      // unconditional loads from clamped addresses, masked afterwards (guarded loads serialise on memory latency)
-      const int gdc = min(gd, a.D - 1);
-      const double wk = a.w[gdc];
-      const double l1 = a.X[(size_t)min(r0 + row, a.n - 1) * a.D + gdc], l2 = Xc[(size_t)min(c0 + row, nc - 1) * a.D + gdc];
-      x1s[row][dd] = (gd < a.D && r0 + row < a.n) ? l1 * wk : 0.0;
-      x2t[dd][row] = (gd < a.D && c0 + row < nc) ? l2 * wk : 0.0;
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int rowc = min(r0 + ty + 16 * i, a.n - 1);
+        const int colc = a.rect ? min(c0 + tx + 16 * j, nc - 1) : min(c0 + tx + 16 * j, rowc);
+        gl[i][j] = a.G[(size_t)rowc * a.ldg + colc];
+      }
+
+    // pass 1: squared distances
+    double sq[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sq[i][j] = 0.0;
+    for (int d0 = 0; d0 < a.D; d0 += DC) {
+      if (d0 > 0) __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int idx = tid + 256 * q;
+        const int row = idx >> 4, dd = idx & 15, gd = d0 + dd;
+        // unconditional loads from clamped addresses, masked afterwards (guarded loads serialise on memory latency)
+        const int gdc = min(gd, a.D - 1);
+        const double wk = a.w[gdc];
+        const double l1 = a.X[(size_t)min(r0 + row, a.n - 1) * a.D + gdc], l2 = Xc[(size_t)min(c0 + row, nc - 1) * a.D + gdc];
+        x1s[row][dd] = (gd < a.D && r0 + row < a.n) ? l1 * wk : 0.0;
+        x2t[dd][row] = (gd < a.D && c0 + row < nc) ? l2 * wk : 0.0;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int dd = 0; dd < DC; ++dd) {
+        double p[4], q2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[i] = x1s[ty + 16 * i][dd];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q2[j] = x2t[dd][tx + 16 * j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const double df = p[i] - q2[j];
+            sq[i][j] = __builtin_fma(df, df, sq[i][j]);
+          }
+      }
     }
-    __syncthreads();
-    double accd[DC];
+
+    // W = Geff o K, with the symmetry weight folded in; Wl drops entries whose distance sits on the clamp
+    double Wl[4][4];
+    if (a.kfun == FFGP_KFUN_SE) {
+      // squared exponential: -2 phi' = phi, one evaluation with the assembly's own exp (22 instructions instead of two
+      // library calls per entry)
 #pragma unroll
-    for (int dd = 0; dd < DC; ++dd) {
-      double p[4], q2[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) p[i] = x1s[ty + 16 * i][dd];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) q2[j] = x2t[dd][tx + 16 * j];
-      double s = 0.0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
+        const int row = r0 + ty + 16 * i;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const double df = p[i] - q2[j];
-          s = __builtin_fma(Wl[i][j] * df, df, s);
+          const int col = c0 + tx + 16 * j;
+          const bool in = row < a.n && (a.rect ? col < nc : col <= row);
+          const double sym = (!a.rect && col < row) ? 2.0 : 1.0;
+          const double ge = in ? sym * (gl[i][j] + geff_add) * ffgp_exp_fast(-0.5 * fmax(sq[i][j], a.clamp), ec) : 0.0;
+          s_amp += ge;
+          Wl[i][j] = (sq[i][j] >= a.clamp) ? ge * amp : 0.0;
         }
-      accd[dd] = s;
+      }
+    } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = r0 + ty + 16 * i;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = c0 + tx + 16 * j;
+        double wv = 0.0;
+        if (row < a.n && (a.rect ? col < nc : col <= row)) {
+          const double g = gl[i][j] + geff_add;
+          const double sc = fmax(sq[i][j], a.clamp);
+          const double e = ffgp_kfun_val(a.kfun, a.rinv, sc);
+          const double sym = (!a.rect && col < row) ? 2.0 : 1.0;
+          s_amp += sym * g * e;
+          if (a.kfun == FFGP_KFUN_RQ) s_kp += sym * g * amp * ffgp_kfun_dparam(a.kfun, a.rinv, sc, e);
+          wv = (sq[i][j] >= a.clamp) ? sym * g * amp * ffgp_kfun_m2d(a.kfun, a.rinv, sc) : 0.0;
+        }
+        Wl[i][j] = wv;
+      }
     }
-    // block reduction of the DC per-dimension sums
+    }
+
+    // pass 2: per-dimension sums of W * df^2
+    for (int d0 = 0; d0 < a.D; d0 += DC) {
+      if (!one_chunk) {   // (one chunk: pass 1 left it in LDS)
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int idx = tid + 256 * q;
+          const int row = idx >> 4, dd = idx & 15, gd = d0 + dd;
+          const int gdc = min(gd, a.D - 1);
+          const double wk = a.w[gdc];
+          const double l1 = a.X[(size_t)min(r0 + row, a.n - 1) * a.D + gdc], l2 = Xc[(size_t)min(c0 + row, nc - 1) * a.D + gdc];
+          x1s[row][dd] = (gd < a.D && r0 + row < a.n) ? l1 * wk : 0.0;
+          x2t[dd][row] = (gd < a.D && c0 + row < nc) ? l2 * wk : 0.0;
+        }
+        __syncthreads();
+      }
+      double accd[DC];
+#pragma unroll
+      for (int dd = 0; dd < DC; ++dd) {
+        double p[4], q2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[i] = x1s[ty + 16 * i][dd];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q2[j] = x2t[dd][tx + 16 * j];
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const double df = p[i] - q2[j];
+            s = __builtin_fma(Wl[i][j] * df, df, s);
+          }
+        accd[dd] = s;
+      }
+      if (one_chunk) {
+#pragma unroll
+        for (int dd = 0; dd < DC; ++dd) tot[dd] += accd[dd];
+      } else {
+        // block reduction of this chunk's DC per-dimension sums (one tile per workgroup here)
+#pragma unroll
+        for (int dd = 0; dd < DC; ++dd) {
+          double v = accd[dd];
+          for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+          if ((tid & 63) == 0) red[tid >> 6][dd] = v;
+        }
+        __syncthreads();
+        if (tid < DC && d0 + tid < a.D)
+          a.partial[(size_t)blockIdx.x * (a.D + 2) + d0 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+      }
+    }
+    __syncthreads();   // every lane is done with the staged chunk before the next tile overwrites it
+  }
+  // the workgroup's sums: w-sums (one chunk), amplitude, profile parameter
+  if (one_chunk) {
 #pragma unroll
     for (int dd = 0; dd < DC; ++dd) {
-      double v = accd[dd];
+      double v = tot[dd];
       for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
       if ((tid & 63) == 0) red[tid >> 6][dd] = v;
     }
-    __syncthreads();
-    if (tid < DC && d0 + tid < a.D)
-      a.partial[(size_t)blockIdx.x * (a.D + 2) + d0 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-    __syncthreads();
   }
   {
-    double v = s_amp;
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-    if ((tid & 63) == 0) red[tid >> 6][DC] = v;
-    __syncthreads();
-    if (tid == 0) a.partial[(size_t)blockIdx.x * (a.D + 2) + a.D] = red[0][DC] + red[1][DC] + red[2][DC] + red[3][DC];
-    __syncthreads();
-    v = s_kp;
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-    if ((tid & 63) == 0) red[tid >> 6][DC] = v;
-    __syncthreads();
-    if (tid == 0) a.partial[(size_t)blockIdx.x * (a.D + 2) + a.D + 1] = red[0][DC] + red[1][DC] + red[2][DC] + red[3][DC];
+    double v = s_amp, u = s_kp;
+    for (int o = 32; o > 0; o >>= 1) {
+      v += __shfl_down(v, o);
+      u += __shfl_down(u, o);
+    }
+    if ((tid & 63) == 0) {
+      red[tid >> 6][DC] = v;
+      red[tid >> 6][DC + 1] = u;
+    }
   }
+  __syncthreads();
+  double* out = a.partial + (size_t)blockIdx.x * (a.D + 2);
+  if (one_chunk && tid < a.D) out[tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+  if (tid == 32) out[a.D] = red[0][DC] + red[1][DC] + red[2][DC] + red[3][DC];
+  if (tid == 33) out[a.D + 1] = red[0][DC + 1] + red[1][DC + 1] + red[2][DC + 1] + red[3][DC + 1];
 }
 
 // out_w[k] = -(1/w_k) * sum_b partial[b][k] ; out_amp = sum_b partial[b][D] ; out_kparam = sum_b partial[b][D+1]
@@ -221,6 +274,15 @@ __global__ __launch_bounds__(1024) void ffgp_trace_kernel(const double* __restri
 
 __global__ void ffgp_copy_scalar(const double* src, double* dst) { dst[0] = src[0]; }
 
+// tiles per workgroup of the gradient sweep: several when the sums can stay in registers (D <= 16) and there are enough
+// tiles to keep >= ~8 workgroups per CU busy
+static int ffgp_grad_tpb(int ntiles, int D) {
+  if (D > DC) return 1;
+  int tpb = 8;
+  while (tpb > 1 && ntiles / tpb < 2048) tpb >>= 1;
+  return tpb;
+}
+
 int ffgp_grad_impl(ffgp_handle* h, const double* X, int n, int D, const double* w, const double* amp, double clamp,
                    const double* G, int ldg, double mean_jitter, double* g_w, double* g_amp, double* g_diag_add,
                    double* g_diag_vec, double* partial_ws, int kfun, double kparam, double* g_kparam) {
@@ -229,8 +291,11 @@ int ffgp_grad_impl(ffgp_handle* h, const double* X, int n, int D, const double* 
   if (g_diag_add) hipLaunchKernelGGL(ffgp_copy_scalar, dim3(1), dim3(1), 0, h->stream, trG, g_diag_add);
   if (g_w || g_amp || g_kparam) {
     const int tm = (n + AT - 1) / AT;
-    const int blocks = tm * (tm + 1) / 2;
+    const int ntiles = tm * (tm + 1) / 2;
+    const int tpb = ffgp_grad_tpb(ntiles, D);
+    const int blocks = (ntiles + tpb - 1) / tpb;
     GradArgs a;
+    a.ntiles = ntiles; a.tpb = tpb;
     a.X2 = X; a.n2 = n; a.rect = 0;
     a.X = X; a.n = n; a.D = D; a.w = w; a.amp = amp; a.clamp = clamp;
     a.G = G; a.ldg = ldg; a.trG = trG;
@@ -259,9 +324,12 @@ int ffgp_kernel_grad_impl(ffgp_handle* h, const double* X1, int n1, const double
   if (n1 <= 0 || n2 <= 0) return FFGP_OK;
   if (!X1 || !X2 || !w || !amp || !dK || D <= 0 || ldk < n2) return FFGP_ERR_ARG;
   const int tm = (n1 + AT - 1) / AT, tn = (n2 + AT - 1) / AT;
-  const int blocks = tm * tn;
+  const int ntiles = tm * tn;
+  const int tpb = ffgp_grad_tpb(ntiles, D);
+  const int blocks = (ntiles + tpb - 1) / tpb;
   FFGP_CHECK(ffgp_ensure_ws(h, ((size_t)blocks * (D + 2) + 16) * sizeof(double)));
   GradArgs a;
+  a.ntiles = ntiles; a.tpb = tpb;
   a.X = X1; a.n = n1; a.X2 = X2; a.n2 = n2; a.rect = 1; a.D = D; a.w = w; a.amp = amp; a.clamp = clamp;
   a.G = dK; a.ldg = ldk; a.trG = nullptr; a.mj_coef = 0.0; a.partial = h->ws;
   a.kfun = kfun;
@@ -344,7 +412,7 @@ int ffgp_kernel_wt_impl(ffgp_handle* h, const double* X1, int n1, const double* 
   if (!X1 || !X2 || !w || !amp || !dK || !Wt || D <= 0 || ldk < n2 || ldw < n2) return FFGP_ERR_ARG;
   GradArgs a;
   a.X = X1; a.n = n1; a.X2 = X2; a.n2 = n2; a.rect = 1; a.D = D; a.w = w; a.amp = amp; a.clamp = clamp;
-  a.G = dK; a.ldg = ldk; a.trG = nullptr; a.mj_coef = 0.0; a.partial = nullptr;
+  a.G = dK; a.ldg = ldk; a.trG = nullptr; a.mj_coef = 0.0; a.partial = nullptr; a.ntiles = 0; a.tpb = 1;
   a.kfun = kfun;
   a.rinv = (kparam != 0.0) ? 1.0 / kparam : 1.0;
   const int tm = (n1 + AT - 1) / AT, tn = (n2 + AT - 1) / AT;
