@@ -68,7 +68,7 @@ __device__ __forceinline__ double ffgp_kfun_dparam(int kind, double rinv, double
 // x = n ln 2 + r, |r| <= ln2 / 2, Taylor polynomial of degree 13 (truncation 4e-18 relative), v_ldexp_f64.  ~22 vector
 // instructions with every constant in SGPRs -- the library exp() inlines to ~3x that, most of it constant moves and
 // special-case handling this call site cannot reach.  Arguments below -745.2 return exactly 0 (as exp() does).
-static __constant__ double ffgp_exp_coef[14] = {1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
+__attribute__((weak)) __constant__ double ffgp_exp_coef[14] = {1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
                                          1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0};
 struct ExpCoef {
   double c[14];
