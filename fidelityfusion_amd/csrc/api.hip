@@ -143,6 +143,7 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->super_min_n = 2048;
   h->la_split = 1;
   h->la_carry = 2;
+  h->la_min_n = 3584;
   h->aux_prio = 1;
   h->nb_outer = 512;
   h->diag_v2 = 1;
@@ -214,6 +215,8 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->diag_dbg = (int)value;
   } else if (!strcmp(key, "la_split")) {
     h->la_split = (int)value;
+  } else if (!strcmp(key, "la_min_n")) {
+    h->la_min_n = (int)value;
   } else if (!strcmp(key, "la_carry")) {
     h->la_carry = (int)value;
   } else if (!strcmp(key, "lookahead")) {

@@ -129,6 +129,8 @@ struct ffgp_handle {
   int diag_v2;          // 0 = barrier version of the diagonal-block kernel, 1 = pipelined (default), 2 = pipelined, helper waves off wave 0's SIMD
   int la_split;         // 1 = issue the look-ahead part of the trailing update in two launches (first 128 columns first)
   int lookahead;        // 1 = overlap panel k+1 with the trailing update of step k
+  int la_min_n;         // blocks up to this size are factored in order (no side stream): below ~3500 the event hand-offs of the
+                        // look-ahead cost more than the overlap returns
   int la_carry;         // the panel's own update kernels also carry the next panel's first 128 columns (no S_a on the chain):
                         // 0 = never, 1 = always, 2 = for n <= 12288 (default)
   int diag_attr_set;    // dynamic-LDS attribute of potrf_diag128 set on this handle's device

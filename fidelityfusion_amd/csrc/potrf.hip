@@ -975,7 +975,7 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
     // panel width at column k0: the wide block while more than nb_big_until columns remain (the SYRK's fixed per-tile
     // cost is amortised over a longer k loop where the chain still hides under it), nb_outer after that
     auto pw = [&](int k0) { return (h->nb_big > NB1 && n - k0 > h->nb_big_until) ? h->nb_big : NB1; };
-    if (!h->lookahead || n <= NB1) {
+    if (!h->lookahead || n <= NB1 || n <= h->la_min_n) {
       for (int k0 = 0; k0 < n; k0 += pw(k0)) {
         const int w1 = min(pw(k0), n - k0);
         const int pend = k0 + w1;  // end column of this outer panel

@@ -275,6 +275,7 @@ def test_potrf_lookahead_forms(ff, n, m, nb, carry, lookahead):
     L = np.linalg.cholesky(S)
     _lib.lib.ffgp_set_option(h, b"la_carry", float(carry))
     _lib.lib.ffgp_set_option(h, b"lookahead", float(lookahead))
+    _lib.lib.ffgp_set_option(h, b"la_min_n", 0.0)          # (by default blocks this small are factored in order)
     try:
         for _ in range(2):
             rc, out, _, _ = potrf(ff, S, R, nb_outer=nb)
@@ -285,6 +286,7 @@ def test_potrf_lookahead_forms(ff, n, m, nb, carry, lookahead):
     finally:
         _lib.lib.ffgp_set_option(h, b"la_carry", 2.0)
         _lib.lib.ffgp_set_option(h, b"lookahead", 1.0)
+        _lib.lib.ffgp_set_option(h, b"la_min_n", 3584.0)
 
 
 def test_potrf_naive_kernels_agree(ff):

@@ -25,7 +25,7 @@ for t in range(trials):
     carry = int(rng.choice([0, 1, 2]))
     la = int(rng.choice([0, 1, 1, 1]))
     nb = int(rng.choice([256, 512, 512, 768]))
-    for k, v in (("la_carry", carry), ("lookahead", la), ("nb_outer", nb)):
+    for k, v in (("la_carry", carry), ("lookahead", la), ("nb_outer", nb), ("la_min_n", int(rng.choice([0, 3584])))):
         _lib.set_option(k, v, 0)
     g = torch.Generator(device=dev).manual_seed(int(rng.integers(1 << 30)))
     X = torch.rand((n, 6), generator=g, device=dev, dtype=torch.float64)
@@ -44,6 +44,6 @@ for t in range(trials):
     worst = max(worst, err)
     if err > 1e-9:
         print("MISMATCH trial %d n=%d rows=%d carry=%d lookahead=%d nb_outer=%d: %.3e" % (t, n, rows, carry, la, nb, err))
-for k, v in (("la_carry", 2), ("lookahead", 1), ("nb_outer", 512)):
+for k, v in (("la_carry", 2), ("lookahead", 1), ("nb_outer", 512), ("la_min_n", 3584)):
     _lib.set_option(k, v, 0)
 print("potrf_fuzz: %d trials, n < %d, worst |L - L_torch| = %.3e" % (trials, nmax, worst))
