@@ -289,6 +289,17 @@ def test_potrf_lookahead_forms(ff, n, m, nb, carry, lookahead):
         _lib.lib.ffgp_set_option(h, b"la_min_n", 3584.0)
 
 
+@pytest.mark.parametrize("n", [3584, 3585])
+def test_potrf_around_the_lookahead_threshold(ff, n):
+    """default options on both sides of la_min_n: 3584 is factored in order on one stream, 3585 with the side stream"""
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, 40))
+    S = B @ B.T + np.diag(rng.random(n) + 0.5)
+    rc, out, _, _ = potrf(ff, S, rng.standard_normal((3, n)))
+    assert rc == 0
+    assert relerr(np.tril(out[:n, :n]), np.linalg.cholesky(S)) < 1e-11
+
+
 def test_potrf_naive_kernels_agree(ff):
     rng = np.random.default_rng(2)
     S = spd(200, rng)
