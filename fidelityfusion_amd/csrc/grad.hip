@@ -64,6 +64,16 @@ __global__ __launch_bounds__(256) void ffgp_grad_kernel(GradArgs a) {
     // the tile of G: sixteen loads in flight at once, under the staging below (clamped addresses; entries outside the mask
     // are not used)
     double gl[4][4];
+    // interior tile: every entry exists and (lower sweep) lies strictly below the diagonal -- no clamps, no per-entry masks
+    const bool interior = r0 + AT <= a.n && c0 + AT <= nc && (a.rect || ti != tj);
+    if (interior) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double* __restrict__ src = a.G + (size_t)(r0 + ty + 16 * i) * a.ldg + c0 + tx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gl[i][j] = src[16 * j];
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -72,6 +82,7 @@ __global__ __launch_bounds__(256) void ffgp_grad_kernel(GradArgs a) {
         const int colc = a.rect ? min(c0 + tx + 16 * j, nc - 1) : min(c0 + tx + 16 * j, rowc);
         gl[i][j] = a.G[(size_t)rowc * a.ldg + colc];
       }
+    }
 
     // pass 1: squared distances
     double sq[4][4];
@@ -112,7 +123,17 @@ __global__ __launch_bounds__(256) void ffgp_grad_kernel(GradArgs a) {
 
     // W = Geff o K, with the symmetry weight folded in; Wl drops entries whose distance sits on the clamp
     double Wl[4][4];
-    if (a.kfun == FFGP_KFUN_SE) {
+    if (a.kfun == FFGP_KFUN_SE && interior) {
+      const double sym = a.rect ? 1.0 : 2.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const double ge = sym * (gl[i][j] + geff_add) * ffgp_exp_fast(-0.5 * fmax(sq[i][j], a.clamp), ec);
+          s_amp += ge;
+          Wl[i][j] = (sq[i][j] >= a.clamp) ? ge * amp : 0.0;
+        }
+    } else if (a.kfun == FFGP_KFUN_SE) {
       // squared exponential: -2 phi' = phi, one evaluation with the assembly's own exp (22 instructions instead of two
       // library calls per entry)
 #pragma unroll
