@@ -78,6 +78,13 @@ EXPORTS = {
                                             C.c_double, _dp, C.c_int, _dp, C.c_int]),
     "ffgp_syevj_small": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, C.c_int, C.c_long, _dp, C.c_int, C.c_long, _dp, C.c_long,
                                    C.c_int]),
+    "ffgp_syevd": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, _dp, C.c_int]),
+    "ffgp_sy2sb": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, _dp, C.c_int]),
+    "ffgp_sb2st_reflector_doubles": (C.c_long, [C.c_int]),
+    "ffgp_sb2st": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp, _dp]),
+    "ffgp_stedc": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int, _dp, _dp, C.c_int]),
+    "ffgp_ormq2": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_int, C.c_int]),
+    "ffgp_ormq1": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int]),
     "ffgp_gemm_batched": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_long, _dp, C.c_int, C.c_long, _dp,
                                     C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]),
     "ffgp_rows_in": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_int, C.c_int, _dp]),

@@ -169,6 +169,7 @@ int ffgp_destroy(ffgp_handle* h) {
   if (h->sinv) hipFree(h->sinv);
   if (h->tsw) hipFree(h->tsw);
   if (h->skw) hipFree(h->skw);
+  if (h->ews) hipFree(h->ews);
   if (h->d_info) hipFree(h->d_info);
   if (h->d_scal) hipFree(h->d_scal);
   if (h->h_info) hipHostFree(h->h_info);

@@ -1,0 +1,403 @@
+// Symmetric eigensolver, stage 2: band (bandwidth 32) -> tridiagonal by bulge chasing, and the back-transformation with the
+// reflectors it produces.  (Second quarter of LAPACK's syevd underneath `torch.linalg.eigh(K)` in the HOGP block:
+// FidelityFusion_Models/two_fidelity_models/hogp_simple.py:15-19,97-100.)  CPU restatement: the tests' numpy model eigh_twostage.py (sb2st, apply_q2).
+//
+// sb2st_chase: one 64-lane wavefront per sweep.  Sweep s annihilates column s below the sub-diagonal with a reflector of
+//   length <= 32 and chases the bulge down the band in steps of 32 rows; step k touches the diagonal block D_k (two-sided) and
+//   the block B_k below it (right-apply, new reflector from its first column, left-apply).  The 32 x 32 blocks live in
+//   registers: lane = (row i, column half h), 16 columns each, so every product with the current reflector is lane-local and
+//   the one product that is not (v'^T B) goes through a 32 x 32 LDS transpose.  Sweeps are pipelined two steps apart:
+//   step k of sweep s needs steps k and k+1 of sweep s-1; a per-sweep progress counter in global memory carries that
+//   (release store after the step's last band store, acquire load before the step's first band load, agent scope: the waves
+//   of neighbouring sweeps sit on different XCDs/L2s).  Workgroup w runs sweeps w, w + G, ...: a sweep only ever waits for a
+//   lower-numbered one, which is running or finished (workgroups are dispatched in order), every wait is bounded (watchdog
+//   -> status word), so the grid always drains.
+// q2_prep: the reflectors of 32 consecutive sweeps at the same step k form a 63 x 32 staircase V; its compact-WY T comes from
+//   T^-1 = striu(V^T V) + diag(1 / tau); stored per block: V (64 x 32) and (V T)^T (32 x 64).
+// q2_apply: Z <- Q2 Z.  One workgroup per slab of 32 columns of Z walks the blocks in the order (sweep group descending,
+//   step ascending -- the only order in which overlapping blocks commute into place, see the numpy model) with a sliding 64-row
+//   window in LDS: X = V^T Zw, Zw -= W X on the fp64 matrix cores.
+#include "ffgp_internal.h"
+#include "syevd_internal.h"
+
+#define CH_DONE 0x3fffffff
+
+__device__ __forceinline__ double wsum32(double x) {   // sum over the 32 lanes of a half-wave (lanes l ^ 1 .. l ^ 16)
+  x += __shfl_xor(x, 16);
+  x += __shfl_xor(x, 8);
+  x += __shfl_xor(x, 4);
+  x += __shfl_xor(x, 2);
+  x += __shfl_xor(x, 1);
+  return x;
+}
+
+__device__ __forceinline__ void chase_wait(const int* p, int need, int* err) {
+  int it = 0;
+  while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
+    __builtin_amdgcn_s_sleep(4);
+    if (++it > (1 << 22)) {   // ~seconds: something is badly wrong; report and go on so that the grid drains
+      *err = 1;
+      break;
+    }
+  }
+}
+
+// Householder vector of x (lane i holds x_i, i < len valid, both halves hold the same values): returns v_i, sets tau and beta
+__device__ __forceinline__ double house32(double x, int i, int len, double& tau, double& beta) {
+  const double xv = (i < len) ? x : 0.0;
+  const double sigma = wsum32((i >= 1) ? xv * xv : 0.0);
+  const double alpha = __shfl(xv, 0);
+  tau = 0.0;
+  beta = alpha;
+  double scale = 0.0;
+  if (sigma != 0.0) {
+    const double nrm = sqrt(alpha * alpha + sigma);
+    beta = (alpha >= 0.0) ? -nrm : nrm;
+    tau = (beta - alpha) / beta;
+    scale = 1.0 / (alpha - beta);
+  }
+  return (i == 0) ? 1.0 : xv * scale;
+}
+
+struct ChaseArgs {
+  double* AB; int n;
+  double* d; double* e;
+  double* V2; double* tau2; int K;   // reflector (s, k): V2[(s K + k) 32 + i], tau2[s K + k]
+  int* prog;                         // [n] steps completed per sweep (CH_DONE when the sweep has ended)
+  int* err;
+};
+
+__global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
+  __shared__ double vsA[32], vsB[32], wsh[32], ush[32];
+  __shared__ double Mt[32][33];
+  const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+  const int n = p.n;
+  double* __restrict__ AB = p.AB;
+  double* vs = vsA;
+  double* v2s = vsB;
+  for (int s = blockIdx.x; s < n - 2; s += gridDim.x) {
+    int c0 = s + 1;
+    int len = min(32, n - c0);
+    if (s > 0) chase_wait(p.prog + s - 1, 2, p.err);
+    double tau, beta;
+    {
+      const double x = (i < len) ? AB[(size_t)s * SB_LDB + 1 + i] : 0.0;
+      const double v = house32(x, i, len, tau, beta);
+      if (h == 0) {
+        vs[i] = (i < len) ? v : 0.0;
+        if (i < len) AB[(size_t)s * SB_LDB + 1 + i] = (i == 0) ? beta : 0.0;
+        p.V2[((size_t)s * p.K) * 32 + i] = (i < len) ? v : 0.0;
+      }
+      if (lane == 0) {
+        p.e[s] = beta;
+        p.d[s] = AB[(size_t)s * SB_LDB];
+        p.tau2[(size_t)s * p.K] = tau;
+      }
+    }
+    int k = 0;
+    while (true) {
+      __syncthreads();   // vs complete
+      // ---- diagonal block, two-sided
+      double D[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int cc = h * 16 + q;
+        const bool ok = (i < len) && (cc < len);
+        const size_t a = (i >= cc) ? ((size_t)(c0 + cc) * SB_LDB + (i - cc)) : ((size_t)(c0 + i) * SB_LDB + (cc - i));
+        D[q] = ok ? AB[a] : 0.0;
+      }
+      double vq[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) vq[q] = vs[h * 16 + q];
+      const double vi = vs[i];
+      double pr = 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) pr = __builtin_fma(D[q], vq[q], pr);
+      pr += __shfl_xor(pr, 32);
+      const double a2 = wsum32(vi * pr);
+      const double w = tau * pr - 0.5 * tau * tau * a2 * vi;
+      if (h == 0) wsh[i] = w;
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int cc = h * 16 + q;
+        D[q] -= vi * wsh[cc] + w * vq[q];
+        if (i >= cc && i < len) AB[(size_t)(c0 + cc) * SB_LDB + (i - cc)] = D[q];
+      }
+      const int r0 = c0 + len;
+      if (r0 > n - 1) break;
+      const int nrow = min(32, n - r0);
+      // ---- block below: right-apply, new reflector, left-apply
+      double B[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int cc = h * 16 + q;
+        const bool ok = (i < nrow) && (cc < len);
+        B[q] = ok ? AB[(size_t)(c0 + cc) * SB_LDB + (len + i - cc)] : 0.0;
+      }
+      double sb = 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sb = __builtin_fma(B[q], vq[q], sb);
+      sb += __shfl_xor(sb, 32);
+      const double ts = tau * sb;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) B[q] = __builtin_fma(-ts, vq[q], B[q]);
+      double tau_n, beta_n;
+      const double x0 = __shfl(B[0], i);           // first column: lane i of half 0
+      const double v2 = house32(x0, i, nrow, tau_n, beta_n);
+      const double v2i = (i < nrow) ? v2 : 0.0;
+      if (h == 0) {
+        B[0] = (i == 0) ? beta_n : 0.0;
+        v2s[i] = v2i;
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int cc = h * 16 + q;
+        Mt[i][cc] = (cc == 0) ? 0.0 : v2i * B[q];
+      }
+      __syncthreads();
+      {
+        double u = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u += Mt[h * 16 + r][i];
+        u += __shfl_xor(u, 32);
+        if (h == 0) ush[i] = u;
+      }
+      __syncthreads();
+      const double tv = tau_n * v2i;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int cc = h * 16 + q;
+        B[q] = __builtin_fma(-tv, ush[cc], B[q]);
+        if (i < nrow && cc < len) AB[(size_t)(c0 + cc) * SB_LDB + (len + i - cc)] = B[q];
+      }
+      ++k;
+      if (h == 0) p.V2[((size_t)s * p.K + k) * 32 + i] = v2i;
+      if (lane == 0) p.tau2[(size_t)s * p.K + k] = tau_n;
+      // publish: k steps of this sweep are complete (every band store above is ordered before the flag by the release)
+      __syncthreads();
+      if (lane == 0) __hip_atomic_store(p.prog + s, k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      c0 = r0;
+      len = nrow;
+      tau = tau_n;
+      double* t_ = vs;
+      vs = v2s;
+      v2s = t_;
+      if (s > 0) chase_wait(p.prog + s - 1, k + 2, p.err);
+    }
+    __syncthreads();
+    if (lane == 0) __hip_atomic_store(p.prog + s, CH_DONE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ void sb2st_tail(const double* __restrict__ AB, int n, double* d, double* e) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    d[n - 2] = AB[(size_t)(n - 2) * SB_LDB];
+    e[n - 2] = AB[(size_t)(n - 2) * SB_LDB + 1];
+    d[n - 1] = AB[(size_t)(n - 1) * SB_LDB];
+    e[n - 1] = 0.0;
+  }
+}
+
+static inline int chase_K(int n) { return n / 32 + 1; }
+
+// AB [n, 64] band in (destroyed), d [n], e [n] out, V2 [n * K * 32], tau2 [n * K], prog [n + 1] ints (last: status word)
+int ffgp_sb2st_impl(ffgp_handle* h, double* AB, int n, double* d, double* e, double* V2, double* tau2, int* prog) {
+  if (n < 64 || n % 32) return FFGP_ERR_ARG;
+  hipStream_t st = h->stream;
+  const int K = chase_K(n);
+  FFGP_HIP(hipMemsetAsync(prog, 0, (size_t)(n + 1) * sizeof(int), st));
+  FFGP_HIP(hipMemsetAsync(V2, 0, (size_t)n * K * 32 * sizeof(double), st));
+  FFGP_HIP(hipMemsetAsync(tau2, 0, (size_t)n * K * sizeof(double), st));
+  ChaseArgs a;
+  a.AB = AB; a.n = n; a.d = d; a.e = e; a.V2 = V2; a.tau2 = tau2; a.K = K; a.prog = prog; a.err = prog + n;
+  const int grid = min(n - 2, 512);
+  hipLaunchKernelGGL(sb2st_chase, dim3(grid), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(sb2st_tail, dim3(1), dim3(64), 0, st, AB, n, d, e);
+  return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// back-transformation with the chase's reflectors
+// ---------------------------------------------------------------------------------------------------------------------
+__host__ __device__ static inline int q2_nsteps(int n, int s) { return (s <= n - 3) ? (n - 2 - s) / 32 + 1 : 0; }
+
+size_t ffgp_q2_block_doubles(int n) { return (size_t)(n / 32) * chase_K(n) * 4096; }
+
+struct PrepArgs {
+  const double* V2; const double* tau2; int n, K;
+  double* blocks;
+};
+
+__global__ __launch_bounds__(256) void q2_prep(PrepArgs p) {
+  __shared__ double Vs[64][33];
+  __shared__ double Gm[32][33];
+  __shared__ double Tm[32][33];
+  __shared__ double dinv[32];
+  const int tid = threadIdx.x;
+  const int G = blockIdx.y, k = blockIdx.x;
+  const int n = p.n;
+  const int s0 = 32 * G;
+  if (s0 > n - 3 || k >= (n - 2 - s0) / 32 + 1) return;
+  for (int idx = tid; idx < 64 * 32; idx += 256) Vs[idx >> 5][idx & 31] = 0.0;
+  __syncthreads();
+  // member t: sweep s0 + t, rows t .. t + len - 1 of the block
+  for (int idx = tid; idx < 32 * 32; idx += 256) {
+    const int t = idx >> 5, i = idx & 31;
+    const int s = s0 + t;
+    bool live = (s <= n - 3) && (k < (n - 2 - s) / 32 + 1);
+    double tau = live ? p.tau2[(size_t)s * p.K + k] : 0.0;
+    if (tau == 0.0) live = false;
+    if (live) Vs[t + i][t] = p.V2[((size_t)s * p.K + k) * 32 + i];
+    if (i == 0) dinv[t] = live ? 1.0 / tau : 1.0;
+  }
+  __syncthreads();
+  {
+    const int a = tid >> 3, b0 = (tid & 7) * 4;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int r = 0; r < 64; ++r) {
+      const double av = Vs[r][a];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = __builtin_fma(av, Vs[r][b0 + q], acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int b = b0 + q;
+      Gm[a][b] = (b > a) ? acc[q] : ((b == a) ? dinv[a] : 0.0);   // T^-1 = striu(V^T V) + diag(1 / tau)
+    }
+  }
+  __syncthreads();
+  if (tid < 32) {   // column j of T = (T^-1)^-1 by back substitution
+    const int j = tid;
+    for (int ii = 31; ii >= 0; --ii) {
+      if (ii > j) {
+        Tm[ii][j] = 0.0;
+        continue;
+      }
+      double s = (ii == j) ? 1.0 : 0.0;
+      for (int cc = ii + 1; cc <= j; ++cc) s = __builtin_fma(-Gm[ii][cc], Tm[cc][j], s);
+      Tm[ii][j] = s / Gm[ii][ii];
+    }
+  }
+  __syncthreads();
+  double* out = p.blocks + ((size_t)G * p.K + k) * 4096;
+  for (int idx = tid; idx < 64 * 32; idx += 256) {
+    const int r = idx >> 5, j = idx & 31;
+    out[idx] = Vs[r][j];
+    double s = 0.0;
+    for (int cc = 0; cc <= j; ++cc) s = __builtin_fma(Vs[r][cc], Tm[cc][j], s);
+    out[2048 + j * 64 + r] = s;     // W = V T, stored transposed ([32][64]): the apply kernel's lanes read 16 consecutive rows
+  }
+}
+
+int ffgp_q2_prep_impl(ffgp_handle* h, const double* V2, const double* tau2, int n, double* blocks) {
+  PrepArgs a;
+  a.V2 = V2; a.tau2 = tau2; a.n = n; a.K = chase_K(n); a.blocks = blocks;
+  hipLaunchKernelGGL(q2_prep, dim3(a.K, n / 32), dim3(256), 0, h->stream, a);
+  return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
+}
+
+#define ZLD 48   // LDS leading dimension of the MN-major MFMA operands (row index = k): rows 16 doubles apart, conflict-free
+
+struct ApplyArgs {
+  const double* blocks; int n, K;
+  double* Z; int ldz; int ncols;
+};
+
+// operands of one block in the MFMA lane layout, straight from global memory (L2): V for X = V^T Zw (this wave's row tile ta of
+// X), W^T for Zw -= W X (this wave's 16 rows of the window)
+__device__ __forceinline__ void q2_load_ops(const double* __restrict__ blk, int ta, int wave, int lr, int lq, double (&va)[16],
+                                            double (&wa)[8]) {
+#pragma unroll
+  for (int kq = 0; kq < 16; ++kq) va[kq] = blk[(kq * 4 + lq) * 32 + ta * 16 + lr];
+#pragma unroll
+  for (int kq = 0; kq < 8; ++kq) wa[kq] = blk[2048 + (kq * 4 + lq) * 64 + wave * 16 + lr];
+}
+
+__global__ __launch_bounds__(256) void q2_apply(ApplyArgs p) {
+  __shared__ double Zs[64 * ZLD];
+  __shared__ double Xs[32 * ZLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = p.n;
+  const int col0 = blockIdx.x * 32;
+  double* __restrict__ Zg = p.Z + col0;
+  const int lr = lane & 15, lq = lane >> 4;
+  // global <-> LDS map of the window: 256 threads, 8 per row (4 doubles each), 32 rows per pass
+  const int trow = tid >> 3, tc4 = (tid & 7) * 4;
+  const int ncv = min(32, p.ncols - col0);   // live columns of this slab
+  const int ta = wave >> 1, tnb = wave & 1;
+  for (int G = n / 32 - 1; G >= 0; --G) {
+    const int s0 = 32 * G;
+    const int nk = q2_nsteps(n, s0);
+    double va[16], wa[8];
+    q2_load_ops(p.blocks + ((size_t)G * p.K) * 4096, ta, wave, lr, lq, va, wa);
+    for (int k = 0; k < nk; ++k) {
+      const int rb = s0 + 1 + 32 * k;
+      double vn[16], wn[8];
+      if (k + 1 < nk) q2_load_ops(p.blocks + ((size_t)G * p.K + k + 1) * 4096, ta, wave, lr, lq, vn, wn);
+      // window rows rb .. rb + 63: at k = 0 all 64 are loaded, afterwards the lower half has slid up and 32 new rows come in
+      for (int pass = (k == 0 ? 0 : 1); pass < 2; ++pass) {
+        const int r = pass * 32 + trow;
+        const int gr = rb + r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Zs[r * ZLD + tc4 + q] = (gr < n && tc4 + q < ncv) ? Zg[(size_t)gr * p.ldz + tc4 + q] : 0.0;
+      }
+      __syncthreads();
+      {   // X = V^T Zw : 32 x 32, wave -> tile (ta, tnb)
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kq = 0; kq < 16; ++kq)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kq], Zs[(kq * 4 + lq) * ZLD + tnb * 16 + lr], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xs[(ta * 16 + 4 * r + lq) * ZLD + tnb * 16 + lr] = acc[r];
+      }
+      __syncthreads();
+      {   // Zw -= W X : wave -> rows 16 wave .. 16 wave + 15, both column tiles
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          d4_t acc;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = Zs[(wave * 16 + 4 * r + lq) * ZLD + tn * 16 + lr];
+#pragma unroll
+          for (int kq = 0; kq < 8; ++kq)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[kq], Xs[(kq * 4 + lq) * ZLD + tn * 16 + lr], acc, 0, 0, 1);   // -A
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Zs[(wave * 16 + 4 * r + lq) * ZLD + tn * 16 + lr] = acc[r];
+        }
+      }
+      __syncthreads();
+      // rows 0..31 of the window are final for this group (the last step writes all 64)
+      const int npass = (k == nk - 1) ? 2 : 1;
+      for (int pass = 0; pass < npass; ++pass) {
+        const int r = pass * 32 + trow;
+        const int gr = rb + r;
+        if (gr < n) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (tc4 + q < ncv) Zg[(size_t)gr * p.ldz + tc4 + q] = Zs[r * ZLD + tc4 + q];
+        }
+      }
+      if (k != nk - 1) {   // slide: rows 32..63 -> 0..31
+        double keep[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) keep[q] = Zs[(32 + trow) * ZLD + tc4 + q];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Zs[trow * ZLD + tc4 + q] = keep[q];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) va[q] = vn[q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wa[q] = wn[q];
+      }
+      __syncthreads();   // the next step's (or group's) window loads overwrite Zs
+    }
+  }
+}
+
+// Z [n, ldz] (first ncols columns) <- Q2 Z
+int ffgp_q2_apply_impl(ffgp_handle* h, const double* blocks, int n, double* Z, int ldz, int ncols) {
+  ApplyArgs a;
+  a.blocks = blocks; a.n = n; a.K = chase_K(n); a.Z = Z; a.ldz = ldz; a.ncols = ncols;
+  hipLaunchKernelGGL(q2_apply, dim3((ncols + 31) / 32), dim3(256), 0, h->stream, a);
+  return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
+}

@@ -1,0 +1,489 @@
+// Symmetric eigensolver, stage 1: dense -> band (bandwidth 32) by blocked Householder transformations.
+//
+// Replaces the first half of LAPACK's syevd underneath `torch.linalg.eigh(K)` in the HOGP block of GAR
+// (FidelityFusion_Models/two_fidelity_models/hogp_simple.py:15-19,97-100; MFGP_ver2023May/base_gp/hogp.py:20-24).
+// CPU restatement of this file, stage by stage: the tests' numpy model eigh_twostage.py (sy2sb, tsqr_hr).
+//
+// Per panel p (32 columns j0 = 32p, acting on the m = n - j0 - 32 rows below the band):
+//   1. TSQR of the m x 32 panel: leaf Householder QRs of 512 rows (one workgroup each, the block in registers, thread
+//      (column, row group)), then one QR of the stacked R factors                                   [sy2sb_leaf_qr, sy2sb_top]
+//   2. Householder reconstruction (Ballard et al. 2015): the panel's thin Q1 is never formed; its top 32 x 32 block is
+//      assembled from 32 x 32 pieces, a modified LU of [I;0] - Q1 S gives the unit-lower Y1, the sign matrix S, U and
+//      T = U Y1^-T; the rows below are Y = Q_leaf (-Q_top,i S U^-1) = [G_i; 0] - V_i (X_i G_i)      [sy2sb_top, sy2sb_form_y]
+//      -> a compact-WY reflector I - Y T Y^T of the whole panel although no workgroup ever saw more than 512 of its rows.
+//      (Cholesky-QR is not an option: kernel matrices are numerically rank deficient, the Gram step squares that.)
+//   3. Yp = A22 Y (the fp64 matrix-core GEMM, split along k), G = Y^T Yp, M = T^T G T,  W = Yp T - 1/2 Y M   [sy2sb_w]
+//   4. A22 <- A22 - [Y W] [W Y]^T  : ONE rank-64 GEMM, alpha = -1, beta = 1 (the fast form of gemm.hip)
+// The band (diagonal blocks + the S R blocks) is collected in compact storage AB[c * 64 + (r - c)].
+//
+// n must be a multiple of 64 (ffgp_syevd pads with decoupled diagonal entries: every reflector component on a padded row is
+// exactly zero, so they never mix) and n <= 8224 (two TSQR levels: 16 leaves of 512 rows).
+#include "ffgp_internal.h"
+#include "syevd_internal.h"
+
+#define QR_ROWS 512   // rows of one TSQR leaf: 8 row groups x 64 rows, one column per thread
+
+struct QrShared {
+  double v[QR_ROWS];
+  double pd[8][32];
+  double red[8];
+  double alpha;
+  double tau[32];
+  double H[32][33];   // H[c][j] = V_c^T v_j  (c < j)
+  double T[32][33];
+};
+
+// Householder QR of a (<= 512) x 32 block.  Thread (c = tid & 31, g = tid >> 5) holds a[r] = element (64 g + r, c); rows >= nrows
+// must be zero.  On exit a[] holds V below the diagonal, R on and above it (rows 0..31 of row group 0), sh.T the compact-WY T,
+// sh.tau the scalar factors.  Ends with a barrier.
+__device__ __forceinline__ void qr512(double (&a)[64], QrShared& sh, const int tid) {
+  const int c = tid & 31, g = tid >> 5;
+  for (int j = 0; j < 32; ++j) {
+    if (c == j) {
+      double ss = 0.0, al = 0.0;
+#pragma unroll
+      for (int r = 0; r < 64; ++r) {
+        const int gr = g * 64 + r;
+        ss += (gr > j) ? a[r] * a[r] : 0.0;
+        al = (gr == j) ? a[r] : al;
+      }
+      sh.red[g] = ss;
+      if (g == 0) sh.alpha = al;
+    }
+    __syncthreads();
+    double sigma = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sigma += sh.red[q];
+    const double alpha = sh.alpha;
+    double tau = 0.0, beta = alpha, scale = 0.0;
+    if (sigma != 0.0) {
+      const double nrm = sqrt(alpha * alpha + sigma);
+      beta = (alpha >= 0.0) ? -nrm : nrm;
+      tau = (beta - alpha) / beta;
+      scale = 1.0 / (alpha - beta);
+    }
+    if (c == j) {
+#pragma unroll
+      for (int r = 0; r < 64; ++r) {
+        const int gr = g * 64 + r;
+        const double vv = (gr > j) ? a[r] * scale : ((gr == j) ? 1.0 : 0.0);
+        sh.v[gr] = vv;
+        a[r] = (gr > j) ? vv : ((gr == j) ? beta : a[r]);
+      }
+      if (g == 0) sh.tau[j] = tau;
+    }
+    __syncthreads();
+    if (c != j) {   // c > j: the column's projection on v;  c < j: V_c^T v_j for the T factor (v is zero above row j)
+      double s = 0.0;
+#pragma unroll
+      for (int r = 0; r < 64; ++r) s = __builtin_fma(sh.v[g * 64 + r], a[r], s);
+      sh.pd[g][c] = s;
+    }
+    __syncthreads();
+    if (c != j) {
+      double dot = 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) dot += sh.pd[q][c];
+      if (c > j) {
+        const double f = tau * dot;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) a[r] = __builtin_fma(-f, sh.v[g * 64 + r], a[r]);
+      } else if (g == 0) {
+        sh.H[c][j] = dot;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 32) {   // T row by row: T[i][j] = -tau_j sum_{c = i}^{j-1} T[i][c] H[c][j]
+    const int i = tid;
+    for (int j = 0; j < 32; ++j) {
+      double t = 0.0;
+      if (j == i) t = sh.tau[j];
+      else if (j > i) {
+        double s = 0.0;
+        for (int cc = i; cc < j; ++cc) s = __builtin_fma(sh.T[i][cc], sh.H[cc][j], s);
+        t = -sh.tau[j] * s;
+      }
+      sh.T[i][j] = t;
+    }
+  }
+  __syncthreads();
+}
+
+struct LeafArgs {
+  double* A; int lda;     // panel origin: row r0, column j0 of the matrix
+  int m;                  // rows of the panel
+  double* Rst;            // [L][32][32]
+  double* Tst;            // [L][32][32]
+};
+
+__global__ __launch_bounds__(256) void sy2sb_leaf_qr(LeafArgs p) {
+  __shared__ QrShared sh;
+  const int tid = threadIdx.x, c = tid & 31, g = tid >> 5;
+  const int row0 = blockIdx.x * QR_ROWS;
+  const int nrows = min(QR_ROWS, p.m - row0);
+  double* __restrict__ P = p.A + (size_t)row0 * p.lda;
+  double a[64];
+#pragma unroll
+  for (int r = 0; r < 64; ++r) {
+    const int gr = g * 64 + r;
+    a[r] = (gr < nrows) ? P[(size_t)gr * p.lda + c] : 0.0;
+  }
+  qr512(a, sh, tid);
+#pragma unroll
+  for (int r = 0; r < 64; ++r) {
+    const int gr = g * 64 + r;
+    if (gr < nrows) P[(size_t)gr * p.lda + c] = a[r];
+  }
+  double* R = p.Rst + (size_t)blockIdx.x * 1024;
+  if (g == 0) {
+#pragma unroll
+    for (int r = 0; r < 32; ++r) R[r * 32 + c] = (r <= c) ? a[r] : 0.0;
+  }
+  double* T = p.Tst + (size_t)blockIdx.x * 1024;
+  for (int idx = tid; idx < 1024; idx += 256) T[idx] = sh.T[idx >> 5][idx & 31];
+}
+
+// ---- small dense helpers on 32 x 32 LDS matrices (leading dimension 33), 256 threads, 4 outputs per thread -------------
+typedef double M33[32][33];
+// C = alpha * A op(B)   (TB: B transposed)
+template <bool TB>
+__device__ __forceinline__ void mm32(M33& C, const M33& A, const M33& B, double alpha, int tid) {
+  const int i = tid >> 3, j0 = (tid & 7) * 4;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int k = 0; k < 32; ++k) {
+    const double av = A[i][k];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = __builtin_fma(av, TB ? B[j0 + q][k] : B[k][j0 + q], acc[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) C[i][j0 + q] = alpha * acc[q];
+}
+
+struct TopArgs {
+  const double* A; int lda;   // panel origin (leaf V's in place)
+  int m, L;
+  const double* Rst; const double* Tst;
+  double* Vtst;               // [512][32]  V of the top-level QR
+  double* small;              // Xt [1024] | S [32] | Uinv [1024]
+  double* Tpan;               // [32][32]   T of this panel
+  double* Y; int ldy;         // Y store, origin (r0, j0): rows 0..31 <- Y1
+  double* AB;                 // band storage origin of column j0
+  int use_tree;               // L > 1
+};
+
+// One workgroup: QR of the stacked R factors, top block of Q1, modified LU, T, U^-1.
+__global__ __launch_bounds__(256) void sy2sb_top(TopArgs p) {
+  __shared__ QrShared sh;
+  __shared__ M33 V1, Xt, Q0, Wt;
+  __shared__ double Ssign[32];
+  M33& M1 = sh.H;   // free once qr512 has built T
+  M33& M2 = sh.T;   // free once Tt has been copied
+  const int tid = threadIdx.x, c = tid & 31, g = tid >> 5;
+  double rr[32];    // column c of the panel's R factor (threads of row group 0)
+  if (p.use_tree) {
+    double a[64];
+#pragma unroll
+    for (int r = 0; r < 64; ++r) {
+      const int gr = g * 64 + r;
+      a[r] = (gr < p.L * 32) ? p.Rst[(size_t)gr * 32 + c] : 0.0;   // [L][32][32] row-major = stacked rows
+    }
+    qr512(a, sh, tid);
+#pragma unroll
+    for (int r = 0; r < 64; ++r) {
+      const int gr = g * 64 + r;
+      // explicit V of the top QR (unit diagonal, zeros above) for the leaf workgroups
+      double vv = a[r];
+      if (gr < 32) vv = (gr > c) ? a[r] : ((gr == c) ? 1.0 : 0.0);
+      p.Vtst[(size_t)gr * 32 + c] = vv;
+    }
+#pragma unroll
+    for (int r = 0; r < 32; ++r) rr[r] = (r <= c) ? a[r] : 0.0;
+    if (g == 0) {
+#pragma unroll
+      for (int r = 0; r < 32; ++r) V1[r][c] = (r > c) ? a[r] : ((r == c) ? 1.0 : 0.0);
+    }
+    for (int idx = tid; idx < 1024; idx += 256) M1[idx >> 5][idx & 31] = sh.T[idx >> 5][idx & 31];
+    __syncthreads();
+    mm32<true>(Xt, M1, V1, 1.0, tid);      // Xt = Tt V1^T
+    __syncthreads();
+    mm32<false>(Q0, V1, Xt, -1.0, tid);    // Q0 = I - V1 Xt
+    __syncthreads();
+    if (tid < 32) Q0[tid][tid] += 1.0;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 32; ++r) rr[r] = p.Rst[r * 32 + c];
+    for (int idx = tid; idx < 1024; idx += 256) {
+      const int i = idx >> 5, j = idx & 31;
+      Xt[i][j] = 0.0;
+      Q0[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+  }
+  __syncthreads();
+  // X0 = T0 V0top^T ; Wtop = (I - V0top X0) Q0
+  for (int idx = tid; idx < 1024; idx += 256) {
+    const int i = idx >> 5, j = idx & 31;
+    M1[i][j] = p.Tst[idx];
+    const double av = p.A[(size_t)i * p.lda + j];
+    V1[i][j] = (i > j) ? av : ((i == j) ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  mm32<true>(M2, M1, V1, 1.0, tid);        // X0
+  __syncthreads();
+  mm32<false>(M1, V1, M2, -1.0, tid);      // -V0top X0
+  __syncthreads();
+  if (tid < 32) M1[tid][tid] += 1.0;
+  __syncthreads();
+  mm32<false>(Wt, M1, Q0, 1.0, tid);       // top block of Q1
+  __syncthreads();
+  // modified LU of [I;0] - Q1 S (top block): signs chosen so that every pivot is >= 1 in magnitude.  V1 <- Y1 (unit lower).
+  for (int idx = tid; idx < 1024; idx += 256) V1[idx >> 5][idx & 31] = ((idx >> 5) == (idx & 31)) ? 1.0 : 0.0;
+  __syncthreads();
+  for (int j = 0; j < 32; ++j) {
+    const double wjj = Wt[j][j];
+    const double sj = (wjj >= 0.0) ? -1.0 : 1.0;
+    const double piv = 1.0 - sj * wjj;
+    if (tid < 32 && tid > j) V1[tid][j] = -sj * Wt[tid][j] / piv;
+    if (tid == 0) Ssign[j] = sj;
+    __syncthreads();
+    {
+      const int i = tid >> 3, k0 = (tid & 7) * 4;
+      if (i > j) {
+        const double l = V1[i][j];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (k0 + q > j) Wt[i][k0 + q] = __builtin_fma(-l, Wt[j][k0 + q], Wt[i][k0 + q]);
+      }
+    }
+    __syncthreads();
+  }
+  // U (upper) -> M1;  T = U Y1^-T -> M2 (row i: forward substitution over the columns);  U^-1 -> Q0 (column by column)
+  for (int idx = tid; idx < 1024; idx += 256) {
+    const int i = idx >> 5, j = idx & 31;
+    M1[i][j] = (j >= i) ? (((i == j) ? 1.0 : 0.0) - Ssign[j] * Wt[i][j]) : 0.0;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    const int i = tid;
+    for (int j = 0; j < 32; ++j) {
+      double s = M1[i][j];
+      for (int cc = 0; cc < j; ++cc) s = __builtin_fma(-M2[i][cc], V1[j][cc], s);
+      M2[i][j] = s;
+    }
+  } else if (tid >= 64 && tid < 96) {
+    const int j = tid - 64;               // column j of U^-1: back substitution
+    for (int i = 31; i >= 0; --i) {
+      if (i > j) {
+        Q0[i][j] = 0.0;
+        continue;
+      }
+      double s = (i == j) ? 1.0 : 0.0;
+      for (int cc = i + 1; cc <= j; ++cc) s = __builtin_fma(-M1[i][cc], Q0[cc][j], s);
+      Q0[i][j] = s / M1[i][i];
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 1024; idx += 256) {
+    const int i = idx >> 5, j = idx & 31;
+    p.small[idx] = Xt[i][j];
+    p.small[1024 + 32 + idx] = Q0[i][j];
+    p.Tpan[idx] = M2[i][j];
+    p.Y[(size_t)i * p.ldy + j] = V1[i][j];
+  }
+  if (tid < 32) {
+    p.small[1024 + tid] = Ssign[tid];
+    // band: row r0 + i, column j0 + c of S R, kept where i <= c: offset (32 + i - c)
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+      if (i <= c) p.AB[(size_t)c * SB_LDB + (32 + i - c)] = Ssign[i] * rr[i];
+  }
+}
+
+struct FormYArgs {
+  const double* A; int lda;   // panel origin
+  int m, L;
+  const double* Tst; const double* Vtst; const double* small;
+  double* Y; int ldy;
+  int use_tree;
+};
+
+// rows of the reconstructed Y below the top block: Y = [G_i; 0] - V_i (X_i G_i),  G_i = -(Q_top,i S) U^-1.  Two workgroups
+// per leaf (256 rows each); every workgroup rebuilds its leaf's 32 x 32 pieces.
+__global__ __launch_bounds__(256) void sy2sb_form_y(FormYArgs p) {
+  __shared__ M33 Ma, Mb, Mc, G, H;
+  const int tid = threadIdx.x;
+  const int leaf = blockIdx.x >> 1, half = blockIdx.x & 1;
+  const int row0 = leaf * QR_ROWS;
+  const int nrows = min(QR_ROWS, p.m - row0);
+  if (half * 256 >= nrows) return;
+  const double* Xt = p.small;
+  const double* Ssign = p.small + 1024;
+  const double* Uinv = p.small + 1024 + 32;
+  // Q_top,i = delta_i0 I - Vt_i Xt
+  for (int idx = tid; idx < 1024; idx += 256) {
+    const int i = idx >> 5, j = idx & 31;
+    Ma[i][j] = p.use_tree ? p.Vtst[(size_t)(leaf * 32 + i) * 32 + j] : 0.0;
+    Mb[i][j] = Xt[idx];
+  }
+  __syncthreads();
+  mm32<false>(Mc, Ma, Mb, -1.0, tid);
+  __syncthreads();
+  if (tid < 32 && leaf == 0) Mc[tid][tid] += 1.0;
+  __syncthreads();
+  for (int idx = tid; idx < 1024; idx += 256) {
+    const int i = idx >> 5, j = idx & 31;
+    Ma[i][j] = -Mc[i][j] * Ssign[j];
+    Mb[i][j] = Uinv[idx];
+  }
+  __syncthreads();
+  mm32<false>(G, Ma, Mb, 1.0, tid);        // G_i
+  // X_i = T_i V_i[:32]^T
+  const double* P = p.A + (size_t)row0 * p.lda;
+  for (int idx = tid; idx < 1024; idx += 256) {
+    const int i = idx >> 5, j = idx & 31;
+    Ma[i][j] = p.Tst[(size_t)leaf * 1024 + idx];
+    const double av = P[(size_t)i * p.lda + j];
+    Mb[i][j] = (i > j) ? av : ((i == j) ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  mm32<true>(Mc, Ma, Mb, 1.0, tid);        // X_i
+  __syncthreads();
+  mm32<false>(H, Mc, G, 1.0, tid);         // H_i = X_i G_i
+  __syncthreads();
+  const int lr = half * 256 + tid;         // row inside the leaf
+  if (lr >= nrows) return;
+  if (leaf == 0 && lr < 32) return;        // the panel's top block holds Y1 (written by sy2sb_top)
+  double vrow[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    const double av = P[(size_t)lr * p.lda + k];
+    vrow[k] = (lr < 32) ? ((lr > k) ? av : ((lr == k) ? 1.0 : 0.0)) : av;
+  }
+  double* yrow = p.Y + (size_t)(row0 + lr) * p.ldy;
+  for (int j = 0; j < 32; ++j) {
+    double s = (lr < 32) ? G[lr][j] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) s = __builtin_fma(-vrow[k], H[k][j], s);
+    yrow[j] = s;
+  }
+}
+
+struct WArgs {
+  const double* Yp;   // [m][32]  A22 Y
+  const double* Y; int ldy;
+  const double* Tpan; const double* Gm;   // [32][32] each;  Gm = Y^T Yp
+  double* VW; double* WV;                  // [m][64] each
+  int m;
+};
+
+// W = Yp T - 1/2 Y (T^T (Y^T Yp) T); the two rank-64 operands [Y W], [W Y] of the trailing update
+__global__ __launch_bounds__(256) void sy2sb_w(WArgs p) {
+  __shared__ M33 T, Gm, M1, Mh;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < 1024; idx += 256) {
+    T[idx >> 5][idx & 31] = p.Tpan[idx];
+    Gm[idx >> 5][idx & 31] = p.Gm[idx];
+  }
+  __syncthreads();
+  mm32<false>(M1, Gm, T, 1.0, tid);        // G T
+  __syncthreads();
+  {   // Mh = 1/2 T^T (G T)
+    const int i = tid >> 3, j0 = (tid & 7) * 4;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < 32; ++k) {
+      const double av = T[k][i];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = __builtin_fma(av, M1[k][j0 + q], acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Mh[i][j0 + q] = 0.5 * acc[q];
+  }
+  __syncthreads();
+  const int row = blockIdx.x * 256 + tid;
+  if (row >= p.m) return;
+  double yp[32], y[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    yp[k] = p.Yp[(size_t)row * 32 + k];
+    y[k] = p.Y[(size_t)row * p.ldy + k];
+  }
+  double* vw = p.VW + (size_t)row * 64;
+  double* wv = p.WV + (size_t)row * 64;
+  for (int j = 0; j < 32; ++j) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) s = __builtin_fma(yp[k], T[k][j], s);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) s = __builtin_fma(-y[k], Mh[k][j], s);
+    vw[32 + j] = s;
+    wv[j] = s;
+  }
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    vw[k] = y[k];
+    wv[32 + k] = y[k];
+  }
+}
+
+// diagonal 32 x 32 blocks of the reduced matrix -> band storage (lower part)
+__global__ void sy2sb_copy_diag(const double* __restrict__ A, int lda, double* __restrict__ AB, int n) {
+  const int j0 = blockIdx.x * 32;
+  for (int idx = threadIdx.x; idx < 1024; idx += blockDim.x) {
+    const int i = idx >> 5, j = idx & 31;
+    if (i >= j && j0 + i < n) AB[(size_t)(j0 + j) * SB_LDB + (i - j)] = A[(size_t)(j0 + i) * lda + j0 + j];
+  }
+}
+
+size_t ffgp_sy2sb_ws_doubles(int n) {
+  // Rst, Tst (16 leaves), Vtst, small, Yp, Gm, VW, WV
+  return (size_t)16 * 1024 * 2 + 512 * 32 + 4096 + (size_t)n * 32 + 1024 + (size_t)n * 64 * 2 + 64;
+}
+
+// A [n, n] full symmetric (destroyed), AB [n, 64] band out, Y [n, ldy] reflector store out (zero outside the staircase),
+// Tpan [n/32][1024] the panels' T factors, ws: ffgp_sy2sb_ws_doubles(n)
+int ffgp_sy2sb_impl(ffgp_handle* h, double* A, int n, int lda, double* AB, double* Y, int ldy, double* Tpan, double* ws) {
+  if (n % 64 != 0 || n < 64 || n > 16 * QR_ROWS + 32) return FFGP_ERR_ARG;
+  hipStream_t st = h->stream;
+  double* Rst = ws;
+  double* Tst = Rst + 16 * 1024;
+  double* Vtst = Tst + 16 * 1024;
+  double* small = Vtst + 512 * 32;
+  double* Yp = small + 4096;
+  double* Gm = Yp + (size_t)n * 32;
+  double* VW = Gm + 1024;
+  double* WV = VW + (size_t)n * 64;
+  FFGP_HIP(hipMemsetAsync(AB, 0, (size_t)n * SB_LDB * sizeof(double), st));
+  FFGP_HIP(hipMemsetAsync(Y, 0, (size_t)n * ldy * sizeof(double), st));
+  const int npan = n / 32 - 1;
+  for (int p = 0; p < npan; ++p) {
+    const int j0 = p * 32, r0 = j0 + 32, m = n - r0;
+    const int L = (m + QR_ROWS - 1) / QR_ROWS;
+    double* Ap = A + (size_t)r0 * lda + j0;
+    double* Ypan = Y + (size_t)r0 * ldy + j0;
+    LeafArgs la;
+    la.A = Ap; la.lda = lda; la.m = m; la.Rst = Rst; la.Tst = Tst;
+    hipLaunchKernelGGL(sy2sb_leaf_qr, dim3(L), dim3(256), 0, st, la);
+    TopArgs ta;
+    ta.A = Ap; ta.lda = lda; ta.m = m; ta.L = L; ta.Rst = Rst; ta.Tst = Tst; ta.Vtst = Vtst; ta.small = small;
+    ta.Tpan = Tpan + (size_t)p * 1024; ta.Y = Ypan; ta.ldy = ldy; ta.AB = AB + (size_t)j0 * SB_LDB; ta.use_tree = (L > 1) ? 1 : 0;
+    hipLaunchKernelGGL(sy2sb_top, dim3(1), dim3(256), 0, st, ta);
+    FormYArgs fa;
+    fa.A = Ap; fa.lda = lda; fa.m = m; fa.L = L; fa.Tst = Tst; fa.Vtst = Vtst; fa.small = small; fa.Y = Ypan; fa.ldy = ldy;
+    fa.use_tree = ta.use_tree;
+    hipLaunchKernelGGL(sy2sb_form_y, dim3(2 * L), dim3(256), 0, st, fa);
+    if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
+    double* A22 = A + (size_t)r0 * lda + r0;
+    // Yp = A22 Y   (m x m times m x 32; A22 K-major, Y stored k x n)
+    FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, A22, lda, Ypan, ldy, Yp, 32, m, 32, m, 1.0, 0.0));
+    // Gm = Y^T Yp  (32 x 32, k = m)
+    FFGP_CHECK(ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_FULL, 0, Ypan, ldy, Yp, 32, Gm, 32, 32, 32, m, 1.0, 0.0));
+    WArgs wa;
+    wa.Yp = Yp; wa.Y = Ypan; wa.ldy = ldy; wa.Tpan = ta.Tpan; wa.Gm = Gm; wa.VW = VW; wa.WV = WV; wa.m = m;
+    hipLaunchKernelGGL(sy2sb_w, dim3((m + 255) / 256), dim3(256), 0, st, wa);
+    if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
+    // A22 -= [Y W] [W Y]^T
+    FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, VW, 64, WV, 64, A22, lda, m, m, 64, -1.0, 1.0));
+  }
+  hipLaunchKernelGGL(sy2sb_copy_diag, dim3(n / 32), dim3(256), 0, st, A, lda, AB, n);
+  return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
+}

@@ -1,0 +1,23 @@
+// Internal declarations of the two-stage symmetric eigensolver (sy2sb.hip, sb2st.hip, stedc.hip, syevd.hip).
+#pragma once
+#include "ffgp_internal.h"
+
+#define SB_B 32     // bandwidth after stage 1
+#define SB_LDB 64   // band storage: element (r, c), r >= c, at AB[c * 64 + (r - c)]; 2b rows leave room for the chase's bulges
+
+// ---- stage 1 (sy2sb.hip)
+size_t ffgp_sy2sb_ws_doubles(int n);
+int ffgp_sy2sb_impl(ffgp_handle* h, double* A, int n, int lda, double* AB, double* Y, int ldy, double* Tpan, double* ws);
+// ---- stage 2 (sb2st.hip)
+int ffgp_sb2st_impl(ffgp_handle* h, double* AB, int n, double* d, double* e, double* V2, double* tau2, int* prog);
+size_t ffgp_q2_block_doubles(int n);
+int ffgp_q2_prep_impl(ffgp_handle* h, const double* V2, const double* tau2, int n, double* blocks);
+int ffgp_q2_apply_impl(ffgp_handle* h, const double* blocks, int n, double* Z, int ldz, int ncols);
+// ---- stage 3 (stedc.hip)
+size_t ffgp_stedc_ws_doubles(int n);
+int ffgp_stedc_impl(ffgp_handle* h, const double* d, const double* e, int n, double* lam, double* Z, int ldz, double* ws);
+// ---- back-transformation with the stage-1 reflectors (syevd.hip)
+size_t ffgp_q1_ws_doubles(int n, int ncols);
+int ffgp_q1_apply_impl(ffgp_handle* h, const double* Y, int ldy, int n, double* Z, int ldz, int ncols, double* ws);
+// eigensolver workspace of the handle
+int ffgp_ensure_ews(ffgp_handle* h, size_t bytes);

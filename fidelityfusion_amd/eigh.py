@@ -1,24 +1,14 @@
-"""Symmetric eigendecomposition of matrices larger than the LDS solver's 64 x 64 on the library's own kernels -- an OPT-IN
-alternative to rocSOLVER for the N x N `eigh(K_x)` of the HOGP block (FidelityFusion_Models/two_fidelity_models/
-hogp_simple.py:15-19,97-100; MFGP_ver2023May/base_gp/hogp.py:20-24).  Correct at every size, NOT competitive in speed:
+"""Symmetric eigendecomposition on the library's own kernels: `eigh(K)` is the drop-in for the `torch.linalg.eigh(K_x)` of the HOGP
+block (FidelityFusion_Models/two_fidelity_models/hogp_simple.py:15-19,97-100; MFGP_ver2023May/base_gp/hogp.py:20-24).
 
-`jacobi_eigh`: two-sided block Jacobi.  32-wide blocks paired round-robin; every 64 x 64 pair problem is solved by the
-hand-written LDS Jacobi kernel (ffgp_syevj_small, one workgroup per pair); the rotations are applied to whole block rows by
-one batched MFMA GEMM per side (ffgp_gemm_batched).  The pair solver's eigenvectors are re-ordered by centre of mass so
-that every rotation stays close to the identity (with eigenvalue-sorted columns the iteration stalls: converged diagonal
-entries keep being permuted between the two blocks).  5-9 sweeps on generic matrices, 10-19 on kernel matrices (clustered
-near-zero eigenvalues), eigenvalues / reconstruction to ~1e-12 ||B||, orthogonality ~1e-11.
-Measured (MI355X, kernel matrices, D = 8): N = 2048 1.2 s, 4096 4.2 s, 8192 21 s -- rocSOLVER's syevd: 0.05 / 0.14 / 0.67 s.
-Every step moves the whole matrix ~20 times (gather, K = 64 products, scatter, transpose) for 2 * 64 flops per element:
-memory-bound by construction.  It stays in the tree as the hand-written reference for the large-N case and as the dense
-core any future two-stage solver would need for its small problems; HOGP_simple keeps rocSOLVER as its default.
+`eigh` -> `ffgp_syevd` (csrc/sy2sb.hip, sb2st.hip, stedc.hip, syevd.hip): dense -> band (TSQR + Householder reconstruction panels,
+rank-64 updates on the fp64 matrix cores) -> tridiagonal (bulge chasing) -> divide & conquer -> two back-transformations.  The
+stage wrappers (`sy2sb`, `sb2st`, `stedc`, `ormq2`, `ormq1`) expose the pieces for tests and profiling.
 
-Also tried this round and removed: a rank-revealing Rayleigh-Ritz solver for positive semi-definite
-kernel matrices (randomized range finder on the fp64 GEMM with a trace certificate, Cholesky-QR through ffgp_potrf_rows,
-block-Jacobi Ritz step, Cholesky-QR complement).  Two findings killed it: at D = 8 the kernel matrices of the benchmark
-configurations are not numerically low rank (the range finder passes N / 2 columns before the certificate holds), and
-Gram-matrix orthogonalisation resolves only sqrt(eps) of dynamic range per deflation stage, so the certificate plateaus at
-~1e-8 ||K|| even where the rank is small.
+`jacobi_eigh` (round 2) stays as the slow, independent hand-written cross-check and as the route for n > 8192: two-sided block
+Jacobi, 32-wide blocks paired round-robin, every 64 x 64 pair problem on the LDS Jacobi kernel (ffgp_syevj_small), rotations applied
+by batched MFMA GEMMs; eigenvectors of the pair solver re-ordered by centre of mass so that every rotation stays close to the
+identity.  5-9 sweeps on generic matrices, 10-19 on kernel matrices; N = 2048 1.2 s, 4096 4.2 s, 8192 21 s.
 """
 import ctypes as C
 
@@ -44,6 +34,75 @@ def _gemm(dev, opa, opb, A, B, m, n, k, alpha=1.0, out=None, beta=0.0, lower=0):
         check(lib.ffgp_gemm(_h(dev), opa, opb, lower, 0, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(out), out.stride(0), m, n, k,
                             float(alpha), float(beta)), "ffgp_gemm")
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# two-stage solver (ffgp_syevd) and its stages
+# ----------------------------------------------------------------------------------------------------------------------
+SYEVD_MAX_N = 8192
+
+
+def eigh(K):
+    """(eigenvalues ascending [n], eigenvectors in columns [n, n]) of the symmetric matrix K (lower triangle read), fp64, on the
+    device; K is not modified.  n <= 8192 runs the two-stage solver, larger matrices the block Jacobi."""
+    if K.dim() != 2 or K.shape[0] != K.shape[1]:
+        raise ValueError("eigh expects a square matrix, got %s" % (tuple(K.shape),))
+    dev = K.device
+    n = K.shape[0]
+    A = K.detach().to(torch.float64)
+    if A.stride(1) != 1 or A.stride(0) < n:
+        A = A.contiguous()
+    if n > SYEVD_MAX_N:
+        return jacobi_eigh(A)
+    W = torch.empty(n, dtype=torch.float64, device=dev)
+    Z = torch.empty((n, n), dtype=torch.float64, device=dev)
+    if n:
+        check(lib.ffgp_syevd(_h(dev), _ptr(A), n, A.stride(0), _ptr(W), _ptr(Z), n), "ffgp_syevd")
+    return W, Z
+
+
+def sy2sb(A):
+    """stage 1 on a copy of A [n, n] (n a multiple of 64): (AB [n, 64] band storage, Y [n, n] panel reflectors)"""
+    dev, n = A.device, A.shape[0]
+    Aw = A.detach().to(torch.float64).clone().contiguous()
+    AB = torch.empty((n, 64), dtype=torch.float64, device=dev)
+    Y = torch.empty((n, n), dtype=torch.float64, device=dev)
+    check(lib.ffgp_sy2sb(_h(dev), _ptr(Aw), n, n, _ptr(AB), _ptr(Y), n), "ffgp_sy2sb")
+    return AB, Y
+
+
+def sb2st(AB):
+    """stage 2 on a copy of the band: (d [n], e [n], reflector store)"""
+    dev, n = AB.device, AB.shape[0]
+    ABw = AB.clone().contiguous()
+    d = torch.empty(n, dtype=torch.float64, device=dev)
+    e = torch.empty(n, dtype=torch.float64, device=dev)
+    refl = torch.empty(int(lib.ffgp_sb2st_reflector_doubles(n)), dtype=torch.float64, device=dev)
+    check(lib.ffgp_sb2st(_h(dev), _ptr(ABw), n, _ptr(d), _ptr(e), _ptr(refl)), "ffgp_sb2st")
+    return d, e, refl
+
+
+def stedc(d, e):
+    """stage 3: eigenpairs of the symmetric tridiagonal matrix (d, e[:n-1])"""
+    dev, n = d.device, d.shape[0]
+    W = torch.empty(n, dtype=torch.float64, device=dev)
+    Z = torch.empty((n, n), dtype=torch.float64, device=dev)
+    check(lib.ffgp_stedc(_h(dev), _ptr(d.contiguous()), _ptr(e.contiguous()), n, _ptr(W), _ptr(Z), n), "ffgp_stedc")
+    return W, Z
+
+
+def ormq2(refl, Z):
+    """Z <- Q2 Z in place (the chase's reflectors)"""
+    n = Z.shape[0]
+    check(lib.ffgp_ormq2(_h(Z.device), _ptr(refl), n, _ptr(Z), Z.stride(0), Z.shape[1]), "ffgp_ormq2")
+    return Z
+
+
+def ormq1(Y, Z):
+    """Z <- Q1 Z in place (the panels' reflectors)"""
+    n = Z.shape[0]
+    check(lib.ffgp_ormq1(_h(Z.device), _ptr(Y), Y.stride(0), n, _ptr(Z), Z.stride(0), Z.shape[1]), "ffgp_ormq1")
+    return Z
 
 
 def _syevj_small(M):

@@ -221,6 +221,33 @@ int ffgp_kernel_grad(ffgp_handle* h, const double* X1_dev, int n1, const double*
 int ffgp_syevj_small(ffgp_handle* h, const double* M_dev, int n, int ldm, int batch, long strideM, double* Q_dev, int ldq,
                      long strideQ, double* evals_dev, long strideE, int descending);
 
+/* ---- symmetric eigensolver (the N x N `torch.linalg.eigh(K_x)` of the HOGP block) ------------------------------------------------
+ * Full symmetric eigendecomposition A = Z diag(W) Z^T of a dense symmetric matrix (its LOWER triangle is read, as
+ * torch.linalg.eigh's default UPLO does), eigenvalues ascending, eigenvectors in the COLUMNS of Z -- the contract of
+ * `torch.linalg.eigh`, which the reference calls at two_fidelity_models/hogp_simple.py:15-19 (`eigen_pairs`), :97-100 (once per
+ * likelihood evaluation on the N x N input kernel) and MFGP_ver2023May/base_gp/hogp.py:20-24.  Hand-written two-stage solver:
+ * dense -> band (bandwidth 32; TSQR + Householder reconstruction per panel, rank-64 trailing updates on the fp64 matrix cores),
+ * band -> tridiagonal (bulge chasing, one wavefront per sweep, pipelined through progress counters), tridiagonal divide &
+ * conquer on the device (secular equation per root, Gu-Eisenstat vectors, merges as GEMMs), back-transformation with the
+ * chase's reflectors (blocked WY on the matrix cores) and with the panels' (256-wide block reflectors, GEMMs).
+ * n <= 8192.  A is not modified.  Synchronises the handle's stream before returning.                                          */
+int ffgp_syevd(ffgp_handle* h, const double* A_dev, int n, int lda, double* W_dev, double* Z_dev, int ldz);
+
+/* The stages of ffgp_syevd on caller-owned buffers (n a multiple of 64, 64 <= n <= 8192) -- LAPACK's dsytrd_sy2sb / dsytrd_sb2st /
+ * dstedc / dormtr split, exposed for tests, profiling and callers that want eigenvalues only:
+ *   ffgp_sy2sb   A [n, n] full symmetric, DESTROYED -> AB [n, 64] band storage (element (r, c), 0 <= r - c <= 32, at AB[c * 64 + r - c])
+ *                and Y [n, ldy]: the panels' unit-lower Householder blocks (panel p in columns 32p.., rows 32p + 32..; zero elsewhere)
+ *   ffgp_sb2st   AB (destroyed) -> d [n], e [n] (e[n-1] = 0) and the chase's reflectors (refl: ffgp_sb2st_reflector_doubles(n) doubles)
+ *   ffgp_stedc   (d, e) -> W [n] ascending, Z [n, ldz] eigenvectors of the tridiagonal matrix in columns
+ *   ffgp_ormq2   Z[:, :ncols] <- Q2 Z   (the chase's reflectors);   ffgp_ormq1   Z[:, :ncols] <- Q1 Z   (the panels')
+ * so that A = (Q1 Q2 Z) diag(W) (Q1 Q2 Z)^T.                                                                                   */
+int ffgp_sy2sb(ffgp_handle* h, double* A_dev, int n, int lda, double* AB_dev, double* Y_dev, int ldy);
+long ffgp_sb2st_reflector_doubles(int n);
+int ffgp_sb2st(ffgp_handle* h, double* AB_dev, int n, double* d_dev, double* e_dev, double* refl_dev);
+int ffgp_stedc(ffgp_handle* h, const double* d_dev, const double* e_dev, int n, double* W_dev, double* Z_dev, int ldz);
+int ffgp_ormq2(ffgp_handle* h, const double* refl_dev, int n, double* Z_dev, int ldz, int ncols);
+int ffgp_ormq1(ffgp_handle* h, const double* Y_dev, int ldy, int n, double* Z_dev, int ldz, int ncols);
+
 /* ffgp_gemm over `batch` identical problems at fixed element strides (C_b = alpha op(A_b) op(B_b) + beta C_b). */
 int ffgp_gemm_batched(ffgp_handle* h, int opa, int opb, int lower_tiles, const double* A_dev, int lda, long strideA,
                       const double* B_dev, int ldb, long strideB, double* C_dev, int ldc, long strideC, int m, int n, int k,

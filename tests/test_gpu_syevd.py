@@ -1,0 +1,134 @@
+"""The hand-written two-stage symmetric eigensolver (ffgp_syevd) through the C ABI: every stage
+against the properties that define it and against the CPU restatement's conventions (oracle/eigh_twostage.py), the whole solver
+against LAPACK (numpy.linalg.eigh) -- the routine the reference calls through torch.linalg.eigh
+(two_fidelity_models/hogp_simple.py:15-19,97-100)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _kernel_matrix(n, D, ls, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    X = torch.rand((n, D), generator=g, dtype=torch.float64)
+    d = torch.cdist(X / ls, X / ls)
+    return torch.exp(-0.5 * d * d)
+
+
+def _random_sym(n, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    M = torch.randn((n, n), generator=g, dtype=torch.float64)
+    return M + M.T
+
+
+def _band_dense(AB, b=32):
+    """dense symmetric matrix from the band storage AB[c, r - c]"""
+    AB = AB.cpu().numpy()
+    n = AB.shape[0]
+    B = np.zeros((n, n))
+    for k in range(b + 1):
+        v = AB[:n - k, k]
+        B[np.arange(k, n), np.arange(0, n - k)] = v
+        B[np.arange(0, n - k), np.arange(k, n)] = v
+    return B
+
+
+@pytest.mark.parametrize("n,kind", [(64, "rand"), (128, "rand"), (576, "kern"), (1088, "rand"), (1600, "kern")])
+def test_stage1_band_reduction(n, kind):
+    """sy2sb: the band has bandwidth 32, the eigenvalues of A, and A = Q1 B Q1^T with an orthogonal Q1 (through ormq1)"""
+    from fidelityfusion_amd import eigh as E
+    A = (_random_sym(n, n) if kind == "rand" else _kernel_matrix(n, 3, 0.6, n))
+    AB, Y = E.sy2sb(A.to(DEV))
+    assert float(AB[:, 33:].abs().max()) == 0.0
+    B = _band_dense(AB)
+    ref = np.linalg.eigvalsh(A.numpy())
+    scale = np.abs(ref).max()
+    assert np.abs(np.linalg.eigvalsh(B) - ref).max() <= 5e-14 * scale
+    Q1 = E.ormq1(Y, torch.eye(n, dtype=torch.float64, device=DEV)).cpu().numpy()
+    assert np.abs(Q1.T @ Q1 - np.eye(n)).max() <= 1e-13
+    assert np.abs(Q1 @ B @ Q1.T - A.numpy()).max() <= 2e-13 * scale
+
+
+@pytest.mark.parametrize("n", [64, 192, 640, 1216])
+def test_stage2_bulge_chasing(n):
+    """sb2st: tridiagonal with the band's eigenvalues; B = Q2 T Q2^T with an orthogonal Q2 (through ormq2)"""
+    from fidelityfusion_amd import eigh as E
+    g = np.random.default_rng(n)
+    AB = np.zeros((n, 64))
+    for k in range(33):
+        AB[:n - k, k] = g.standard_normal(n - k)
+    B = _band_dense(torch.from_numpy(AB))
+    d, e, refl = E.sb2st(torch.from_numpy(AB).to(DEV))
+    d, e = d.cpu().numpy(), e.cpu().numpy()
+    T = np.diag(d) + np.diag(e[:-1], 1) + np.diag(e[:-1], -1)
+    ref = np.linalg.eigvalsh(B)
+    scale = np.abs(ref).max()
+    assert np.abs(np.linalg.eigvalsh(T) - ref).max() <= 5e-14 * scale
+    Q2 = E.ormq2(refl, torch.eye(n, dtype=torch.float64, device=DEV)).cpu().numpy()
+    assert np.abs(Q2.T @ Q2 - np.eye(n)).max() <= 1e-13
+    assert np.abs(Q2 @ T @ Q2.T - B).max() <= 2e-13 * scale
+
+
+@pytest.mark.parametrize("n,kind", [(64, "rand"), (128, "rand"), (192, "lap"), (704, "rand"), (1024, "clustered"), (1344, "graded")])
+def test_stage3_divide_and_conquer(n, kind):
+    from fidelityfusion_amd import eigh as E
+    g = np.random.default_rng(n)
+    if kind == "rand":
+        d, e = g.standard_normal(n), g.standard_normal(n)
+    elif kind == "lap":
+        d, e = 2.0 * np.ones(n), -np.ones(n)
+    elif kind == "clustered":          # many equal eigenvalues: heavy deflation
+        d, e = np.ones(n), 1e-14 * g.standard_normal(n)
+        d[::7] = 2.0
+    else:                              # graded like a kernel matrix's tridiagonal form
+        d = np.exp(-np.arange(n) / 20.0) + 1e-17
+        e = 0.3 * np.exp(-np.arange(n) / 20.0)
+    W, Z = E.stedc(torch.from_numpy(d).to(DEV), torch.from_numpy(e).to(DEV))
+    W, Z = W.cpu().numpy(), Z.cpu().numpy()
+    T = np.diag(d) + np.diag(e[:-1], 1) + np.diag(e[:-1], -1)
+    ref = np.linalg.eigvalsh(T)
+    scale = np.abs(ref).max()
+    assert np.all(np.diff(W) >= 0)
+    assert np.abs(W - ref).max() <= 1e-14 * scale * max(1.0, np.sqrt(n) / 8)
+    assert np.abs(Z.T @ Z - np.eye(n)).max() <= 2e-13
+    assert np.abs((Z * W) @ Z.T - T).max() <= 1e-13 * scale
+
+
+@pytest.mark.parametrize("n,kind", [(1, "rand"), (7, "rand"), (64, "kern"), (65, "rand"), (130, "kern"), (257, "kern1"), (600, "rand"),
+                                    (1100, "kern"), (2048, "kern8")])
+def test_syevd_vs_lapack(n, kind):
+    """the whole solver: eigenvalues against LAPACK to 1e-13 ||A||, orthogonality, reconstruction, ascending order -- generic
+    matrices, kernel matrices with numerically singular spectra (D = 1, 3, 8), sizes that need padding"""
+    from fidelityfusion_amd import eigh as E
+    if kind == "rand":
+        A = _random_sym(n, n)
+    elif kind == "kern1":
+        A = _kernel_matrix(n, 1, 0.5, n)
+    elif kind == "kern8":
+        A = _kernel_matrix(n, 8, 1.0, n)
+    else:
+        A = _kernel_matrix(n, 3, 0.7, n)
+    W, Z = E.eigh(A.to(DEV))
+    W, Z = W.cpu().numpy(), Z.cpu().numpy()
+    ref = np.linalg.eigvalsh(A.numpy())
+    scale = max(np.abs(ref).max(), 1e-300)
+    assert W.shape == (n,) and Z.shape == (n, n)
+    assert np.all(np.diff(W) >= 0)
+    assert np.abs(W - ref).max() <= 1e-13 * scale
+    assert np.abs(Z.T @ Z - np.eye(n)).max() <= 5e-13
+    assert np.linalg.norm((Z * W) @ Z.T - A.numpy()) <= 1e-13 * np.linalg.norm(A.numpy()) * max(1.0, np.sqrt(n) / 8)
+
+
+def test_syevd_reads_the_lower_triangle_and_keeps_its_input():
+    from fidelityfusion_amd import eigh as E
+    n = 200
+    A = _random_sym(n, 3).to(DEV)
+    junk = A.clone()
+    junk[np.triu_indices(n, 1)] = 7.0
+    keep = junk.clone()
+    W, _ = E.eigh(junk)
+    assert torch.equal(junk, keep)
+    ref = torch.linalg.eigvalsh(A.cpu())
+    assert float((W.cpu() - ref).abs().max()) <= 1e-13 * float(ref.abs().max())
