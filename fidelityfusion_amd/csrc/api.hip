@@ -243,6 +243,8 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     if (v != 0 && (v < 2 * FFGP_NB || (v & (v - 1)))) return FFGP_ERR_ARG;   // 0, or a power of two >= 256
     h->super_block = v;
     h->sinv_L = nullptr;
+  } else if (!strcmp(key, "chase_pack")) {
+    h->chase_pack = (int)value;
   } else if (!strcmp(key, "skinny_max_n")) {
     h->skinny_max_n = (int)value;
   } else if (!strcmp(key, "splitk_min_k")) {

@@ -158,6 +158,7 @@ struct ffgp_handle {
   size_t skw_bytes;
   double* ews;       // workspace of the symmetric eigensolver (syevd.hip)
   size_t ews_bytes;
+  int chase_pack;    // bulge chasing: every chase_pack-th workgroup works (8 = all on one XCD; 1 = spread over the chip)
   int splitk_min_k;  // thin products (<= 64 tiles of 64 x 64) with k >= this are cut along k (0 = never)
   int skinny_max_n;  // products with at most this many output columns (<= 8) take the matrix-vector kernels (0 = never)
   int super_block;   // S (multiple of 128, power-of-two multiple): 0 = sweeps always go block by block

@@ -22,39 +22,77 @@
 
 #define CH_DONE 0x3fffffff
 
-__device__ __forceinline__ double wsum32(double x) {   // sum over the 32 lanes of a half-wave (lanes l ^ 1 .. l ^ 16)
-  x += __shfl_xor(x, 16);
-  x += __shfl_xor(x, 8);
-  x += __shfl_xor(x, 4);
-  x += __shfl_xor(x, 2);
-  x += __shfl_xor(x, 1);
-  return x;
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+  return x + __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double rdlane(double x, int l) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_readlane(lo, l);
+  hi = __builtin_amdgcn_readlane(hi, l);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 32 lanes of a half-wave, returned in all of them: four DPP steps inside each row of 16 lanes (quad swaps, half
+// mirror, mirror -- no LDS crossbar on the way), then the four row totals through scalar registers
+__device__ __forceinline__ double wsum32(double x, int lane) {
+  x = dpp_add<0xB1>(x);    // quad_perm [1,0,3,2]
+  x = dpp_add<0x4E>(x);    // quad_perm [2,3,0,1]
+  x = dpp_add<0x141>(x);   // row_half_mirror
+  x = dpp_add<0x140>(x);   // row_mirror
+  const double r0 = rdlane(x, 0), r1 = rdlane(x, 16), r2 = rdlane(x, 32), r3 = rdlane(x, 48);
+  return (lane < 32) ? r0 + r1 : r2 + r3;
+}
+__device__ __forceinline__ double swap32(double x) { return __shfl_xor(x, 32); }
 
-__device__ __forceinline__ void chase_wait(const int* p, int need, int* err) {
-  int it = 0;
-  while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
-    __builtin_amdgcn_s_sleep(4);
-    if (++it > (1 << 22)) {   // ~seconds: something is badly wrong; report and go on so that the grid drains
-      *err = 1;
+// the band lives in memory that waves on other compute units (and other XCDs) read and write while this kernel runs: every access
+// is a device-scope access (sc1: served from the coherent level, never from this CU's L1); ordering against the progress counters
+// is by waiting for the wave's outstanding memory operations (the workgroup-scope fence) around relaxed device-scope flag accesses
+__device__ __forceinline__ double ldb(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stb(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ int chase_wait(const int* p, int need, int* err) {
+  int it = 0, v;
+  while ((v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+    __builtin_amdgcn_s_sleep(1);
+    // watchdog: ~0.3 s without progress, or any other sweep already gave up -> report and go on, so that the grid always drains
+    if (++it > (1 << 19) || ((it & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+      __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v = need;
       break;
     }
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return v;
+}
+
+__device__ __forceinline__ double ch_rcp(double d) {
+  double y = __builtin_amdgcn_rcp(d);
+  y = __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
+  y = __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
+  return y;
 }
 
 // Householder vector of x (lane i holds x_i, i < len valid, both halves hold the same values): returns v_i, sets tau and beta
-__device__ __forceinline__ double house32(double x, int i, int len, double& tau, double& beta) {
+__device__ __forceinline__ double house32(double x, int i, int lane, int len, double& tau, double& beta) {
   const double xv = (i < len) ? x : 0.0;
-  const double sigma = wsum32((i >= 1) ? xv * xv : 0.0);
-  const double alpha = __shfl(xv, 0);
+  const double sigma = wsum32((i >= 1) ? xv * xv : 0.0, lane);
+  const double alpha = rdlane(xv, 0);
   tau = 0.0;
   beta = alpha;
   double scale = 0.0;
   if (sigma != 0.0) {
-    const double nrm = sqrt(alpha * alpha + sigma);
+    const double q = __builtin_fma(alpha, alpha, sigma);
+    double r = __builtin_amdgcn_rsq(q);                         // 1 / sqrt(q), two Newton steps
+    r = __builtin_fma(0.5 * r, __builtin_fma(-q * r, r, 1.0), r);
+    r = __builtin_fma(0.5 * r, __builtin_fma(-q * r, r, 1.0), r);
+    double nrm = q * r;
+    nrm = __builtin_fma(0.5 * r, __builtin_fma(-nrm, nrm, q), nrm);   // one step on the root itself
     beta = (alpha >= 0.0) ? -nrm : nrm;
-    tau = (beta - alpha) / beta;
-    scale = 1.0 / (alpha - beta);
+    tau = (beta - alpha) * ch_rcp(beta);
+    scale = ch_rcp(alpha - beta);
   }
   return (i == 0) ? 1.0 : xv * scale;
 }
@@ -65,47 +103,61 @@ struct ChaseArgs {
   double* V2; double* tau2; int K;   // reflector (s, k): V2[(s K + k) 32 + i], tau2[s K + k]
   int* prog;                         // [n] steps completed per sweep (CH_DONE when the sweep has ended)
   int* err;
+  int pack;                          // only workgroups with blockIdx % pack == 0 work (pack = 8: all of them on one XCD, one L2)
 };
 
 __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
   __shared__ double vsA[32], vsB[32], wsh[32], ush[32];
   __shared__ double Mt[32][33];
+  if (blockIdx.x % p.pack) return;
+  const int wg = blockIdx.x / p.pack, nwg = (gridDim.x + p.pack - 1) / p.pack;
   const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
   const int n = p.n;
-  double* __restrict__ AB = p.AB;
+  double* AB = p.AB;
   double* vs = vsA;
   double* v2s = vsB;
-  for (int s = blockIdx.x; s < n - 2; s += gridDim.x) {
+  for (int s = wg; s < n - 2; s += nwg) {
     int c0 = s + 1;
     int len = min(32, n - c0);
-    if (s > 0) chase_wait(p.prog + s - 1, 2, p.err);
+    int seen = (s > 0) ? 0 : CH_DONE;    // progress of sweep s - 1 as last observed
+    if (seen < 2) seen = chase_wait(p.prog + s - 1, 2, p.err);
     double tau, beta;
     {
-      const double x = (i < len) ? AB[(size_t)s * SB_LDB + 1 + i] : 0.0;
-      const double v = house32(x, i, len, tau, beta);
+      const double x = (i < len) ? ldb(AB + (size_t)s * SB_LDB + 1 + i) : 0.0;
+      const double v = house32(x, i, lane, len, tau, beta);
       if (h == 0) {
         vs[i] = (i < len) ? v : 0.0;
-        if (i < len) AB[(size_t)s * SB_LDB + 1 + i] = (i == 0) ? beta : 0.0;
+        if (i < len) stb(AB + (size_t)s * SB_LDB + 1 + i, (i == 0) ? beta : 0.0);
         p.V2[((size_t)s * p.K) * 32 + i] = (i < len) ? v : 0.0;
       }
       if (lane == 0) {
         p.e[s] = beta;
-        p.d[s] = AB[(size_t)s * SB_LDB];
+        p.d[s] = ldb(AB + (size_t)s * SB_LDB);
         p.tau2[(size_t)s * p.K] = tau;
       }
     }
     int k = 0;
     while (true) {
-      __syncthreads();   // vs complete
-      // ---- diagonal block, two-sided
-      double D[16];
+      const int r0 = c0 + len;
+      const bool more = (r0 <= n - 1);
+      const int nrow = more ? min(32, n - r0) : 0;
+      // ---- both blocks of the step are requested up front
+      double D[16], B[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int cc = h * 16 + q;
         const bool ok = (i < len) && (cc < len);
         const size_t a = (i >= cc) ? ((size_t)(c0 + cc) * SB_LDB + (i - cc)) : ((size_t)(c0 + i) * SB_LDB + (cc - i));
-        D[q] = ok ? AB[a] : 0.0;
+        D[q] = ok ? ldb(AB + a) : 0.0;
       }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int cc = h * 16 + q;
+        const bool ok = (i < nrow) && (cc < len);
+        B[q] = ok ? ldb(AB + (size_t)(c0 + cc) * SB_LDB + (len + i - cc)) : 0.0;
+      }
+      __syncthreads();   // vs complete
+      // ---- diagonal block, two-sided
       double vq[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) vq[q] = vs[h * 16 + q];
@@ -113,8 +165,8 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
       double pr = 0.0;
 #pragma unroll
       for (int q = 0; q < 16; ++q) pr = __builtin_fma(D[q], vq[q], pr);
-      pr += __shfl_xor(pr, 32);
-      const double a2 = wsum32(vi * pr);
+      pr += swap32(pr);
+      const double a2 = wsum32(vi * pr, lane);
       const double w = tau * pr - 0.5 * tau * tau * a2 * vi;
       if (h == 0) wsh[i] = w;
       __syncthreads();
@@ -122,29 +174,20 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
       for (int q = 0; q < 16; ++q) {
         const int cc = h * 16 + q;
         D[q] -= vi * wsh[cc] + w * vq[q];
-        if (i >= cc && i < len) AB[(size_t)(c0 + cc) * SB_LDB + (i - cc)] = D[q];
+        if (i >= cc && i < len) stb(AB + (size_t)(c0 + cc) * SB_LDB + (i - cc), D[q]);
       }
-      const int r0 = c0 + len;
-      if (r0 > n - 1) break;
-      const int nrow = min(32, n - r0);
+      if (!more) break;
       // ---- block below: right-apply, new reflector, left-apply
-      double B[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int cc = h * 16 + q;
-        const bool ok = (i < nrow) && (cc < len);
-        B[q] = ok ? AB[(size_t)(c0 + cc) * SB_LDB + (len + i - cc)] : 0.0;
-      }
       double sb = 0.0;
 #pragma unroll
       for (int q = 0; q < 16; ++q) sb = __builtin_fma(B[q], vq[q], sb);
-      sb += __shfl_xor(sb, 32);
+      sb += swap32(sb);
       const double ts = tau * sb;
 #pragma unroll
       for (int q = 0; q < 16; ++q) B[q] = __builtin_fma(-ts, vq[q], B[q]);
       double tau_n, beta_n;
       const double x0 = __shfl(B[0], i);           // first column: lane i of half 0
-      const double v2 = house32(x0, i, nrow, tau_n, beta_n);
+      const double v2 = house32(x0, i, lane, nrow, tau_n, beta_n);
       const double v2i = (i < nrow) ? v2 : 0.0;
       if (h == 0) {
         B[0] = (i == 0) ? beta_n : 0.0;
@@ -160,7 +203,7 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
         double u = 0.0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) u += Mt[h * 16 + r][i];
-        u += __shfl_xor(u, 32);
+        u += swap32(u);
         if (h == 0) ush[i] = u;
       }
       __syncthreads();
@@ -169,24 +212,25 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
       for (int q = 0; q < 16; ++q) {
         const int cc = h * 16 + q;
         B[q] = __builtin_fma(-tv, ush[cc], B[q]);
-        if (i < nrow && cc < len) AB[(size_t)(c0 + cc) * SB_LDB + (len + i - cc)] = B[q];
+        if (i < nrow && cc < len) stb(AB + (size_t)(c0 + cc) * SB_LDB + (len + i - cc), B[q]);
       }
       ++k;
+      // publish: k steps of this sweep are complete.  The fence waits for every band store of the wave above.
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(p.prog + s, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (h == 0) p.V2[((size_t)s * p.K + k) * 32 + i] = v2i;
       if (lane == 0) p.tau2[(size_t)s * p.K + k] = tau_n;
-      // publish: k steps of this sweep are complete (every band store above is ordered before the flag by the release)
-      __syncthreads();
-      if (lane == 0) __hip_atomic_store(p.prog + s, k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       c0 = r0;
       len = nrow;
       tau = tau_n;
       double* t_ = vs;
       vs = v2s;
       v2s = t_;
-      if (s > 0) chase_wait(p.prog + s - 1, k + 2, p.err);
+      if (seen < k + 2) seen = chase_wait(p.prog + s - 1, k + 2, p.err);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(p.prog + s, CH_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (lane == 0) __hip_atomic_store(p.prog + s, CH_DONE, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -211,7 +255,11 @@ int ffgp_sb2st_impl(ffgp_handle* h, double* AB, int n, double* d, double* e, dou
   FFGP_HIP(hipMemsetAsync(tau2, 0, (size_t)n * K * sizeof(double), st));
   ChaseArgs a;
   a.AB = AB; a.n = n; a.d = d; a.e = e; a.V2 = V2; a.tau2 = tau2; a.K = K; a.prog = prog; a.err = prog + n;
-  const int grid = min(n - 2, 512);
+  // all working wavefronts on ONE XCD (workgroups are dealt round-robin to the 8 XCDs, so every 8th one works): neighbouring
+  // sweeps then hand their blocks over through one L2 instead of through the memory side.  Purely a placement: every band access
+  // is a device-scope access wherever the wave runs.
+  a.pack = h->chase_pack > 0 ? h->chase_pack : 8;
+  const int grid = min(n - 2, 256) * a.pack;
   hipLaunchKernelGGL(sb2st_chase, dim3(grid), dim3(64), 0, st, a);
   hipLaunchKernelGGL(sb2st_tail, dim3(1), dim3(64), 0, st, AB, n, d, e);
   return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
