@@ -5,8 +5,8 @@
 // CPU restatement of this file, stage by stage: the tests' numpy model eigh_twostage.py (sy2sb, tsqr_hr).
 //
 // Per panel p (32 columns j0 = 32p, acting on the m = n - j0 - 32 rows below the band):
-//   1. TSQR of the m x 32 panel: leaf Householder QRs of 512 rows (one workgroup each, the block in registers, thread
-//      (column, row group)), then one QR of the stacked R factors                                   [sy2sb_leaf_qr, sy2sb_top]
+//   1. TSQR of the m x 32 panel: leaf Householder QRs of 512 rows (one workgroup of 1024 threads each, the block in registers, a
+//      half-wave per column), then one QR of the stacked R factors                                   [sy2sb_leaf_qr, sy2sb_top]
 //   2. Householder reconstruction (Ballard et al. 2015): the panel's thin Q1 is never formed; its top 32 x 32 block is
 //      assembled from 32 x 32 pieces, a modified LU of [I;0] - Q1 S gives the unit-lower Y1, the sign matrix S, U and
 //      T = U Y1^-T; the rows below are Y = Q_leaf (-Q_top,i S U^-1) = [G_i; 0] - V_i (X_i G_i)      [sy2sb_top, sy2sb_form_y]
@@ -21,90 +21,118 @@
 #include "ffgp_internal.h"
 #include "syevd_internal.h"
 
-#define QR_ROWS 512   // rows of one TSQR leaf: 8 row groups x 64 rows, one column per thread
+#define QR_ROWS 512   // rows of one TSQR leaf
+#define QR_THREADS 1024
+
+template <int CTRL>
+__device__ __forceinline__ double qr_dpp_add(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+  return x + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double qr_rdlane(double x, int l) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_readlane(lo, l);
+  hi = __builtin_amdgcn_readlane(hi, l);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 32 lanes of each half-wave, in all of them (DPP inside the rows of 16, row totals through scalar registers)
+__device__ __forceinline__ double qr_wsum32(double x, int lane) {
+  x = qr_dpp_add<0xB1>(x);
+  x = qr_dpp_add<0x4E>(x);
+  x = qr_dpp_add<0x141>(x);
+  x = qr_dpp_add<0x140>(x);
+  const double r0 = qr_rdlane(x, 0), r1 = qr_rdlane(x, 16), r2 = qr_rdlane(x, 32), r3 = qr_rdlane(x, 48);
+  return (lane < 32) ? r0 + r1 : r2 + r3;
+}
+__device__ __forceinline__ double qr_rcp(double d) {
+  double y = __builtin_amdgcn_rcp(d);
+  y = __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
+  y = __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
+  return y;
+}
 
 struct QrShared {
-  double v[QR_ROWS];
-  double pd[8][32];
-  double red[8];
-  double alpha;
+  double v[2][QR_ROWS];   // the current reflector, double-buffered: one barrier per column
+  double tauc[2];
   double tau[32];
   double H[32][33];   // H[c][j] = V_c^T v_j  (c < j)
   double T[32][33];
 };
 
-// Householder QR of a (<= 512) x 32 block.  Thread (c = tid & 31, g = tid >> 5) holds a[r] = element (64 g + r, c); rows >= nrows
-// must be zero.  On exit a[] holds V below the diagonal, R on and above it (rows 0..31 of row group 0), sh.T the compact-WY T,
-// sh.tau the scalar factors.  Ends with a barrier.
-__device__ __forceinline__ void qr512(double (&a)[64], QrShared& sh, const int tid) {
-  const int c = tid & 31, g = tid >> 5;
+// Householder QR of a (<= 512) x 32 block by 1024 threads: a half-wave (32 lanes) per column, lane i holds the rows i + 32 r
+// (r = 0..15) in a[r]; rows beyond the block must be zero.  Every column sum is a half-wave reduction (no LDS partial sums), the
+// reflector travels through LDS, one workgroup barrier per column.  On exit a[] holds V below the diagonal and R on / above it
+// (a[0] of lane i <= c), sh.T the compact-WY T, sh.tau the scalar factors.  Ends with a barrier.
+__device__ __forceinline__ void qr512(double (&a)[16], QrShared& sh, const int tid) {
+  const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, i = lane & 31;
+  const int c = wave * 2 + half;
   for (int j = 0; j < 32; ++j) {
-    if (c == j) {
-      double ss = 0.0, al = 0.0;
+    const int buf = j & 1;
+    if (wave == (j >> 1)) {   // the wave that holds column j: its norm, the reflector, tau
+      double ss = (i > j) ? a[0] * a[0] : 0.0;
 #pragma unroll
-      for (int r = 0; r < 64; ++r) {
-        const int gr = g * 64 + r;
-        ss += (gr > j) ? a[r] * a[r] : 0.0;
-        al = (gr == j) ? a[r] : al;
+      for (int r = 1; r < 16; ++r) ss = __builtin_fma(a[r], a[r], ss);
+      const double sigma = qr_wsum32(ss, lane);
+      const double alpha = qr_rdlane(a[0], (j & 1) * 32 + j);
+      double tau = 0.0, beta = alpha, scale = 0.0;
+      if (sigma != 0.0) {
+        const double q = __builtin_fma(alpha, alpha, sigma);
+        double rs = __builtin_amdgcn_rsq(q);
+        rs = __builtin_fma(0.5 * rs, __builtin_fma(-q * rs, rs, 1.0), rs);
+        rs = __builtin_fma(0.5 * rs, __builtin_fma(-q * rs, rs, 1.0), rs);
+        double nrm = q * rs;
+        nrm = __builtin_fma(0.5 * rs, __builtin_fma(-nrm, nrm, q), nrm);
+        beta = (alpha >= 0.0) ? -nrm : nrm;
+        tau = (beta - alpha) * qr_rcp(beta);
+        scale = qr_rcp(alpha - beta);
       }
-      sh.red[g] = ss;
-      if (g == 0) sh.alpha = al;
+      if (half == (j & 1)) {
+        const double v0 = (i > j) ? a[0] * scale : ((i == j) ? 1.0 : 0.0);
+        sh.v[buf][i] = v0;
+        a[0] = (i > j) ? v0 : ((i == j) ? beta : a[0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) {
+          a[r] *= scale;
+          sh.v[buf][i + 32 * r] = a[r];
+        }
+        if (i == 0) {
+          sh.tauc[buf] = tau;
+          sh.tau[j] = tau;
+        }
+      }
     }
     __syncthreads();
-    double sigma = 0.0;
+    double vr[16];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) sigma += sh.red[q];
-    const double alpha = sh.alpha;
-    double tau = 0.0, beta = alpha, scale = 0.0;
-    if (sigma != 0.0) {
-      const double nrm = sqrt(alpha * alpha + sigma);
-      beta = (alpha >= 0.0) ? -nrm : nrm;
-      tau = (beta - alpha) / beta;
-      scale = 1.0 / (alpha - beta);
-    }
-    if (c == j) {
-#pragma unroll
-      for (int r = 0; r < 64; ++r) {
-        const int gr = g * 64 + r;
-        const double vv = (gr > j) ? a[r] * scale : ((gr == j) ? 1.0 : 0.0);
-        sh.v[gr] = vv;
-        a[r] = (gr > j) ? vv : ((gr == j) ? beta : a[r]);
-      }
-      if (g == 0) sh.tau[j] = tau;
-    }
-    __syncthreads();
+    for (int r = 0; r < 16; ++r) vr[r] = sh.v[buf][i + 32 * r];
+    double s = 0.0;
     if (c != j) {   // c > j: the column's projection on v;  c < j: V_c^T v_j for the T factor (v is zero above row j)
-      double s = 0.0;
 #pragma unroll
-      for (int r = 0; r < 64; ++r) s = __builtin_fma(sh.v[g * 64 + r], a[r], s);
-      sh.pd[g][c] = s;
+      for (int r = 0; r < 16; ++r) s = __builtin_fma(vr[r], a[r], s);
     }
-    __syncthreads();
-    if (c != j) {
-      double dot = 0.0;
+    const double dot = qr_wsum32(s, lane);
+    if (c > j) {
+      const double f = sh.tauc[buf] * dot;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) dot += sh.pd[q][c];
-      if (c > j) {
-        const double f = tau * dot;
-#pragma unroll
-        for (int r = 0; r < 64; ++r) a[r] = __builtin_fma(-f, sh.v[g * 64 + r], a[r]);
-      } else if (g == 0) {
-        sh.H[c][j] = dot;
-      }
+      for (int r = 0; r < 16; ++r) a[r] = __builtin_fma(-f, vr[r], a[r]);
+    } else if (c < j && i == 0) {
+      sh.H[c][j] = dot;
     }
   }
   __syncthreads();
   if (tid < 32) {   // T row by row: T[i][j] = -tau_j sum_{c = i}^{j-1} T[i][c] H[c][j]
-    const int i = tid;
+    const int ti = tid;
     for (int j = 0; j < 32; ++j) {
       double t = 0.0;
-      if (j == i) t = sh.tau[j];
-      else if (j > i) {
-        double s = 0.0;
-        for (int cc = i; cc < j; ++cc) s = __builtin_fma(sh.T[i][cc], sh.H[cc][j], s);
-        t = -sh.tau[j] * s;
+      if (j == ti) t = sh.tau[j];
+      else if (j > ti) {
+        double sacc = 0.0;
+        for (int cc = ti; cc < j; ++cc) sacc = __builtin_fma(sh.T[ti][cc], sh.H[cc][j], sacc);
+        t = -sh.tau[j] * sacc;
       }
-      sh.T[i][j] = t;
+      sh.T[ti][j] = t;
     }
   }
   __syncthreads();
@@ -117,31 +145,26 @@ struct LeafArgs {
   double* Tst;            // [L][32][32]
 };
 
-__global__ __launch_bounds__(256) void sy2sb_leaf_qr(LeafArgs p) {
+__global__ __launch_bounds__(QR_THREADS) void sy2sb_leaf_qr(LeafArgs p) {
   __shared__ QrShared sh;
-  const int tid = threadIdx.x, c = tid & 31, g = tid >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, c = (tid >> 6) * 2 + (lane >> 5);
   const int row0 = blockIdx.x * QR_ROWS;
   const int nrows = min(QR_ROWS, p.m - row0);
   double* __restrict__ P = p.A + (size_t)row0 * p.lda;
-  double a[64];
+  double a[16];
 #pragma unroll
-  for (int r = 0; r < 64; ++r) {
-    const int gr = g * 64 + r;
+  for (int r = 0; r < 16; ++r) {
+    const int gr = i + 32 * r;
     a[r] = (gr < nrows) ? P[(size_t)gr * p.lda + c] : 0.0;
   }
   qr512(a, sh, tid);
 #pragma unroll
-  for (int r = 0; r < 64; ++r) {
-    const int gr = g * 64 + r;
+  for (int r = 0; r < 16; ++r) {
+    const int gr = i + 32 * r;
     if (gr < nrows) P[(size_t)gr * p.lda + c] = a[r];
   }
-  double* R = p.Rst + (size_t)blockIdx.x * 1024;
-  if (g == 0) {
-#pragma unroll
-    for (int r = 0; r < 32; ++r) R[r * 32 + c] = (r <= c) ? a[r] : 0.0;
-  }
-  double* T = p.Tst + (size_t)blockIdx.x * 1024;
-  for (int idx = tid; idx < 1024; idx += 256) T[idx] = sh.T[idx >> 5][idx & 31];
+  p.Rst[(size_t)blockIdx.x * 1024 + i * 32 + c] = (i <= c) ? a[0] : 0.0;
+  p.Tst[(size_t)blockIdx.x * 1024 + tid] = sh.T[tid >> 5][tid & 31];
 }
 
 // ---- small dense helpers on 32 x 32 LDS matrices (leading dimension 33), 256 threads, 4 outputs per thread -------------
@@ -172,72 +195,59 @@ struct TopArgs {
   int use_tree;               // L > 1
 };
 
-// One workgroup: QR of the stacked R factors, top block of Q1, modified LU, T, U^-1.
-__global__ __launch_bounds__(256) void sy2sb_top(TopArgs p) {
+// One workgroup: QR of the stacked R factors, top block of Q1, modified LU, T, U^-1.  (The QR runs on all 1024 threads, the
+// 32 x 32 algebra after it on the first 256.)
+__global__ __launch_bounds__(QR_THREADS) void sy2sb_top(TopArgs p) {
   __shared__ QrShared sh;
   __shared__ M33 V1, Xt, Q0, Wt;
   __shared__ double Ssign[32];
   M33& M1 = sh.H;   // free once qr512 has built T
   M33& M2 = sh.T;   // free once Tt has been copied
-  const int tid = threadIdx.x, c = tid & 31, g = tid >> 5;
-  double rr[32];    // column c of the panel's R factor (threads of row group 0)
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, c = (tid >> 6) * 2 + (lane >> 5);
+  const bool sm = tid < 256;   // the threads of the small-matrix phases
+  double r0v;       // R[i][c] of the panel's R factor
   if (p.use_tree) {
-    double a[64];
+    double a[16];
 #pragma unroll
-    for (int r = 0; r < 64; ++r) {
-      const int gr = g * 64 + r;
-      a[r] = (gr < p.L * 32) ? p.Rst[(size_t)gr * 32 + c] : 0.0;   // [L][32][32] row-major = stacked rows
-    }
+    for (int r = 0; r < 16; ++r) a[r] = (r < p.L) ? p.Rst[(size_t)(i + 32 * r) * 32 + c] : 0.0;   // [L][32][32] = stacked rows
     qr512(a, sh, tid);
+    // explicit V of the top QR (unit diagonal, zeros above) for the leaf workgroups
+    const double v0 = (i > c) ? a[0] : ((i == c) ? 1.0 : 0.0);
+    p.Vtst[(size_t)i * 32 + c] = v0;
 #pragma unroll
-    for (int r = 0; r < 64; ++r) {
-      const int gr = g * 64 + r;
-      // explicit V of the top QR (unit diagonal, zeros above) for the leaf workgroups
-      double vv = a[r];
-      if (gr < 32) vv = (gr > c) ? a[r] : ((gr == c) ? 1.0 : 0.0);
-      p.Vtst[(size_t)gr * 32 + c] = vv;
-    }
-#pragma unroll
-    for (int r = 0; r < 32; ++r) rr[r] = (r <= c) ? a[r] : 0.0;
-    if (g == 0) {
-#pragma unroll
-      for (int r = 0; r < 32; ++r) V1[r][c] = (r > c) ? a[r] : ((r == c) ? 1.0 : 0.0);
-    }
-    for (int idx = tid; idx < 1024; idx += 256) M1[idx >> 5][idx & 31] = sh.T[idx >> 5][idx & 31];
+    for (int r = 1; r < 16; ++r) p.Vtst[(size_t)(i + 32 * r) * 32 + c] = a[r];
+    r0v = (i <= c) ? a[0] : 0.0;
+    V1[i][c] = v0;
+    M1[tid >> 5][tid & 31] = sh.T[tid >> 5][tid & 31];
     __syncthreads();
-    mm32<true>(Xt, M1, V1, 1.0, tid);      // Xt = Tt V1^T
+    if (sm) mm32<true>(Xt, M1, V1, 1.0, tid);      // Xt = Tt V1^T
     __syncthreads();
-    mm32<false>(Q0, V1, Xt, -1.0, tid);    // Q0 = I - V1 Xt
+    if (sm) mm32<false>(Q0, V1, Xt, -1.0, tid);    // Q0 = I - V1 Xt
     __syncthreads();
     if (tid < 32) Q0[tid][tid] += 1.0;
   } else {
-#pragma unroll
-    for (int r = 0; r < 32; ++r) rr[r] = p.Rst[r * 32 + c];
-    for (int idx = tid; idx < 1024; idx += 256) {
-      const int i = idx >> 5, j = idx & 31;
-      Xt[i][j] = 0.0;
-      Q0[i][j] = (i == j) ? 1.0 : 0.0;
-    }
+    r0v = p.Rst[i * 32 + c];
+    Xt[i][c] = 0.0;
+    Q0[i][c] = (i == c) ? 1.0 : 0.0;
   }
   __syncthreads();
   // X0 = T0 V0top^T ; Wtop = (I - V0top X0) Q0
-  for (int idx = tid; idx < 1024; idx += 256) {
-    const int i = idx >> 5, j = idx & 31;
-    M1[i][j] = p.Tst[idx];
-    const double av = p.A[(size_t)i * p.lda + j];
-    V1[i][j] = (i > j) ? av : ((i == j) ? 1.0 : 0.0);
+  {
+    M1[i][c] = p.Tst[i * 32 + c];
+    const double av = p.A[(size_t)i * p.lda + c];
+    V1[i][c] = (i > c) ? av : ((i == c) ? 1.0 : 0.0);
   }
   __syncthreads();
-  mm32<true>(M2, M1, V1, 1.0, tid);        // X0
+  if (sm) mm32<true>(M2, M1, V1, 1.0, tid);        // X0
   __syncthreads();
-  mm32<false>(M1, V1, M2, -1.0, tid);      // -V0top X0
+  if (sm) mm32<false>(M1, V1, M2, -1.0, tid);      // -V0top X0
   __syncthreads();
   if (tid < 32) M1[tid][tid] += 1.0;
   __syncthreads();
-  mm32<false>(Wt, M1, Q0, 1.0, tid);       // top block of Q1
+  if (sm) mm32<false>(Wt, M1, Q0, 1.0, tid);       // top block of Q1
   __syncthreads();
   // modified LU of [I;0] - Q1 S (top block): signs chosen so that every pivot is >= 1 in magnitude.  V1 <- Y1 (unit lower).
-  for (int idx = tid; idx < 1024; idx += 256) V1[idx >> 5][idx & 31] = ((idx >> 5) == (idx & 31)) ? 1.0 : 0.0;
+  V1[i][c] = (i == c) ? 1.0 : 0.0;
   __syncthreads();
   for (int j = 0; j < 32; ++j) {
     const double wjj = Wt[j][j];
@@ -246,57 +256,42 @@ __global__ __launch_bounds__(256) void sy2sb_top(TopArgs p) {
     if (tid < 32 && tid > j) V1[tid][j] = -sj * Wt[tid][j] / piv;
     if (tid == 0) Ssign[j] = sj;
     __syncthreads();
-    {
-      const int i = tid >> 3, k0 = (tid & 7) * 4;
-      if (i > j) {
-        const double l = V1[i][j];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (k0 + q > j) Wt[i][k0 + q] = __builtin_fma(-l, Wt[j][k0 + q], Wt[i][k0 + q]);
-      }
-    }
+    if (i > j && c > j) Wt[i][c] = __builtin_fma(-V1[i][j], Wt[j][c], Wt[i][c]);   // thread (i, c): one entry each
     __syncthreads();
   }
   // U (upper) -> M1;  T = U Y1^-T -> M2 (row i: forward substitution over the columns);  U^-1 -> Q0 (column by column)
-  for (int idx = tid; idx < 1024; idx += 256) {
-    const int i = idx >> 5, j = idx & 31;
-    M1[i][j] = (j >= i) ? (((i == j) ? 1.0 : 0.0) - Ssign[j] * Wt[i][j]) : 0.0;
-  }
+  M1[i][c] = (c >= i) ? (((i == c) ? 1.0 : 0.0) - Ssign[c] * Wt[i][c]) : 0.0;
   __syncthreads();
   if (tid < 32) {
-    const int i = tid;
+    const int ti = tid;
     for (int j = 0; j < 32; ++j) {
-      double s = M1[i][j];
-      for (int cc = 0; cc < j; ++cc) s = __builtin_fma(-M2[i][cc], V1[j][cc], s);
-      M2[i][j] = s;
+      double sacc = M1[ti][j];
+      for (int cc = 0; cc < j; ++cc) sacc = __builtin_fma(-M2[ti][cc], V1[j][cc], sacc);
+      M2[ti][j] = sacc;
     }
   } else if (tid >= 64 && tid < 96) {
     const int j = tid - 64;               // column j of U^-1: back substitution
-    for (int i = 31; i >= 0; --i) {
-      if (i > j) {
-        Q0[i][j] = 0.0;
+    for (int ii = 31; ii >= 0; --ii) {
+      if (ii > j) {
+        Q0[ii][j] = 0.0;
         continue;
       }
-      double s = (i == j) ? 1.0 : 0.0;
-      for (int cc = i + 1; cc <= j; ++cc) s = __builtin_fma(-M1[i][cc], Q0[cc][j], s);
-      Q0[i][j] = s / M1[i][i];
+      double sacc = (ii == j) ? 1.0 : 0.0;
+      for (int cc = ii + 1; cc <= j; ++cc) sacc = __builtin_fma(-M1[ii][cc], Q0[cc][j], sacc);
+      Q0[ii][j] = sacc / M1[ii][ii];
     }
   }
   __syncthreads();
-  for (int idx = tid; idx < 1024; idx += 256) {
-    const int i = idx >> 5, j = idx & 31;
-    p.small[idx] = Xt[i][j];
-    p.small[1024 + 32 + idx] = Q0[i][j];
-    p.Tpan[idx] = M2[i][j];
-    p.Y[(size_t)i * p.ldy + j] = V1[i][j];
-  }
-  if (tid < 32) {
-    p.small[1024 + tid] = Ssign[tid];
+  {
+    const int idx = i * 32 + c;
+    p.small[idx] = Xt[i][c];
+    p.small[1024 + 32 + idx] = Q0[i][c];
+    p.Tpan[idx] = M2[i][c];
+    p.Y[(size_t)i * p.ldy + c] = V1[i][c];
     // band: row r0 + i, column j0 + c of S R, kept where i <= c: offset (32 + i - c)
-#pragma unroll
-    for (int i = 0; i < 32; ++i)
-      if (i <= c) p.AB[(size_t)c * SB_LDB + (32 + i - c)] = Ssign[i] * rr[i];
+    if (i <= c) p.AB[(size_t)c * SB_LDB + (32 + i - c)] = Ssign[i] * r0v;
   }
+  if (tid < 32) p.small[1024 + tid] = Ssign[tid];
 }
 
 struct FormYArgs {
@@ -462,11 +457,11 @@ int ffgp_sy2sb_impl(ffgp_handle* h, double* A, int n, int lda, double* AB, doubl
     double* Ypan = Y + (size_t)r0 * ldy + j0;
     LeafArgs la;
     la.A = Ap; la.lda = lda; la.m = m; la.Rst = Rst; la.Tst = Tst;
-    hipLaunchKernelGGL(sy2sb_leaf_qr, dim3(L), dim3(256), 0, st, la);
+    hipLaunchKernelGGL(sy2sb_leaf_qr, dim3(L), dim3(QR_THREADS), 0, st, la);
     TopArgs ta;
     ta.A = Ap; ta.lda = lda; ta.m = m; ta.L = L; ta.Rst = Rst; ta.Tst = Tst; ta.Vtst = Vtst; ta.small = small;
     ta.Tpan = Tpan + (size_t)p * 1024; ta.Y = Ypan; ta.ldy = ldy; ta.AB = AB + (size_t)j0 * SB_LDB; ta.use_tree = (L > 1) ? 1 : 0;
-    hipLaunchKernelGGL(sy2sb_top, dim3(1), dim3(256), 0, st, ta);
+    hipLaunchKernelGGL(sy2sb_top, dim3(1), dim3(QR_THREADS), 0, st, ta);
     FormYArgs fa;
     fa.A = Ap; fa.lda = lda; fa.m = m; fa.L = L; fa.Tst = Tst; fa.Vtst = Vtst; fa.small = small; fa.Y = Ypan; fa.ldy = ldy;
     fa.use_tree = ta.use_tree;
