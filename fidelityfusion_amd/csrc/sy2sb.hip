@@ -363,10 +363,64 @@ __global__ __launch_bounds__(256) void sy2sb_form_y(FormYArgs p) {
   }
 }
 
+struct RedArgs {
+  const double* P; long sP; int parts;   // partial products A22[:, chunk] Y[chunk, :], [parts][m][32]
+  const double* Y; int ldy;
+  double* Yp;                            // [m][32]  their sum
+  double* Gpart;                         // [workgroups][32][32]  Y_blk^T Yp_blk
+  int m;
+};
+
+// Yp = sum of the k-chunks' partial products (fixed order), and this workgroup's 256 rows' share of G = Y^T Yp
+__global__ __launch_bounds__(256) void sy2sb_red(RedArgs p) {
+  __shared__ double Ys[64][33], Ps[64][33];
+  const int tid = threadIdx.x;
+  const int row = blockIdx.x * 256 + tid;
+  double yp[32], y[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) yp[k] = 0.0, y[k] = 0.0;
+  if (row < p.m) {
+    for (int s = 0; s < p.parts; ++s) {
+      const double* src = p.P + (size_t)s * p.sP + (size_t)row * 32;
+#pragma unroll
+      for (int k = 0; k < 32; k += 2) {
+        const d2_t v = *reinterpret_cast<const d2_t*>(src + k);
+        yp[k] += v.x;
+        yp[k + 1] += v.y;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      p.Yp[(size_t)row * 32 + k] = yp[k];
+      y[k] = p.Y[(size_t)row * p.ldy + k];
+    }
+  }
+  const int a = tid >> 3, b0 = (tid & 7) * 4;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int chunk = 0; chunk < 4; ++chunk) {
+    __syncthreads();
+    if ((tid >> 6) == chunk) {
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        Ys[tid & 63][k] = y[k];
+        Ps[tid & 63][k] = yp[k];
+      }
+    }
+    __syncthreads();
+    for (int r = 0; r < 64; ++r) {
+      const double av = Ys[r][a];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = __builtin_fma(av, Ps[r][b0 + q], acc[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) p.Gpart[(size_t)blockIdx.x * 1024 + a * 32 + b0 + q] = acc[q];
+}
+
 struct WArgs {
   const double* Yp;   // [m][32]  A22 Y
   const double* Y; int ldy;
-  const double* Tpan; const double* Gm;   // [32][32] each;  Gm = Y^T Yp
+  const double* Tpan; const double* Gpart; int ngp;   // T [32][32]; Gpart [ngp][32][32], their sum = Y^T Yp
   double* VW; double* WV;                  // [m][64] each
   int m;
 };
@@ -377,7 +431,9 @@ __global__ __launch_bounds__(256) void sy2sb_w(WArgs p) {
   const int tid = threadIdx.x;
   for (int idx = tid; idx < 1024; idx += 256) {
     T[idx >> 5][idx & 31] = p.Tpan[idx];
-    Gm[idx >> 5][idx & 31] = p.Gm[idx];
+    double g = 0.0;
+    for (int q = 0; q < p.ngp; ++q) g += p.Gpart[(size_t)q * 1024 + idx];
+    Gm[idx >> 5][idx & 31] = g;
   }
   __syncthreads();
   mm32<false>(M1, Gm, T, 1.0, tid);        // G T
@@ -429,9 +485,11 @@ __global__ void sy2sb_copy_diag(const double* __restrict__ A, int lda, double* _
   }
 }
 
+#define AV_MAX_PARTS 16
 size_t ffgp_sy2sb_ws_doubles(int n) {
-  // Rst, Tst (16 leaves), Vtst, small, Yp, Gm, VW, WV
-  return (size_t)16 * 1024 * 2 + 512 * 32 + 4096 + (size_t)n * 32 + 1024 + (size_t)n * 64 * 2 + 64;
+  // Rst, Tst (16 leaves), Vtst, small, Yp, Gpart, VW, WV, partial products of the k-chunks
+  return (size_t)16 * 1024 * 2 + 512 * 32 + 4096 + (size_t)n * 32 + (size_t)(n / 256 + 1) * 1024 + (size_t)n * 64 * 2 +
+         (size_t)(AV_MAX_PARTS + 1) * n * 32 + 64;
 }
 
 // A [n, n] full symmetric (destroyed), AB [n, 64] band out, Y [n, ldy] reflector store out (zero outside the staircase),
@@ -444,9 +502,10 @@ int ffgp_sy2sb_impl(ffgp_handle* h, double* A, int n, int lda, double* AB, doubl
   double* Vtst = Tst + 16 * 1024;
   double* small = Vtst + 512 * 32;
   double* Yp = small + 4096;
-  double* Gm = Yp + (size_t)n * 32;
-  double* VW = Gm + 1024;
+  double* Gpart = Yp + (size_t)n * 32;
+  double* VW = Gpart + (size_t)(n / 256 + 1) * 1024;
   double* WV = VW + (size_t)n * 64;
+  double* Ppart = WV + (size_t)n * 64;
   FFGP_HIP(hipMemsetAsync(AB, 0, (size_t)n * SB_LDB * sizeof(double), st));
   FFGP_HIP(hipMemsetAsync(Y, 0, (size_t)n * ldy * sizeof(double), st));
   const int npan = n / 32 - 1;
@@ -468,12 +527,26 @@ int ffgp_sy2sb_impl(ffgp_handle* h, double* A, int n, int lda, double* AB, doubl
     hipLaunchKernelGGL(sy2sb_form_y, dim3(2 * L), dim3(256), 0, st, fa);
     if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
     double* A22 = A + (size_t)r0 * lda + r0;
-    // Yp = A22 Y   (m x m times m x 32; A22 K-major, Y stored k x n)
-    FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, A22, lda, Ypan, ldy, Yp, 32, m, 32, m, 1.0, 0.0));
-    // Gm = Y^T Yp  (32 x 32, k = m)
-    FFGP_CHECK(ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_FULL, 0, Ypan, ldy, Yp, 32, Gm, 32, 32, 32, m, 1.0, 0.0));
+    // Yp = A22 Y  (m x m times m x 32; A22 K-major, Y stored k x n), cut along k into `parts` chunks that run as ONE batched launch
+    // (enough workgroups to fill the chip whatever m is); the chunks are summed in fixed order by sy2sb_red, which also leaves
+    // the pieces of G = Y^T Yp
+    int parts = min(AV_MAX_PARTS, max(1, 1024 / ((m + 63) / 64)));
+    int kc = ((m + parts - 1) / parts + 31) & ~31;
+    parts = m / kc;                       // full chunks; a shorter tail chunk runs as its own launch
+    const int tail = m - parts * kc;
+    const long sP = (long)m * 32;
+    if (parts > 0)
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, A22, lda, Ypan, ldy, Ppart, 32, m, 32, kc, 1.0, 0.0, 0, ALIAS_NONE, parts,
+                                  (long)kc, (long)kc * ldy, sP));
+    if (tail > 0)
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, A22 + (size_t)parts * kc, lda, Ypan + (size_t)parts * kc * ldy, ldy,
+                                  Ppart + (size_t)parts * sP, 32, m, 32, tail, 1.0, 0.0));
+    RedArgs ra;
+    ra.P = Ppart; ra.sP = sP; ra.parts = parts + (tail > 0 ? 1 : 0); ra.Y = Ypan; ra.ldy = ldy; ra.Yp = Yp; ra.Gpart = Gpart; ra.m = m;
+    const int nred = (m + 255) / 256;
+    hipLaunchKernelGGL(sy2sb_red, dim3(nred), dim3(256), 0, st, ra);
     WArgs wa;
-    wa.Yp = Yp; wa.Y = Ypan; wa.ldy = ldy; wa.Tpan = ta.Tpan; wa.Gm = Gm; wa.VW = VW; wa.WV = WV; wa.m = m;
+    wa.Yp = Yp; wa.Y = Ypan; wa.ldy = ldy; wa.Tpan = ta.Tpan; wa.Gpart = Gpart; wa.ngp = nred; wa.VW = VW; wa.WV = WV; wa.m = m;
     hipLaunchKernelGGL(sy2sb_w, dim3((m + 255) / 256), dim3(256), 0, st, wa);
     if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
     // A22 -= [Y W] [W Y]^T

@@ -30,61 +30,58 @@ int ffgp_ensure_ews(ffgp_handle* h, size_t bytes) {
 // Z <- Q1 Z,  Q1 = prod_p (I - Y_p T_p Y_p^T).  Eight panels at a time form one 256-wide block reflector I - V T V^T whose T follows
 // from orthogonality alone:  T^-1 + T^-T = V^T V  =>  T^-1 = striu(V^T V) + 1/2 diag(V^T V); three GEMMs per group.
 // ---------------------------------------------------------------------------------------------------------------------
-// T (w x w, w = 32 nb) of the wide block reflector from G = V^T V alone, block column by block column:
-//   T_jj = (striu(G_jj) + diag(G_jj) / 2)^-1,    T[0:j, j] = -T[0:j, 0:j] (G[0:j, j] T_jj)
-// (the recurrence of the compact-WY accumulation, LAPACK dlarft; orthogonality of I - V T V^T fixes the diagonal blocks)
-__global__ __launch_bounds__(256) void q1_tbuild(const double* __restrict__ G, int w, double* __restrict__ T, double* __restrict__ Mg) {
+// T (256 x 256) of the wide block reflector from G = V^T V alone: U = striu(G) + diag(G) / 2 is T^-1.  Diagonal 32 x 32 blocks
+// by back substitution (one workgroup each), then three doubling levels [A B; 0 C]^-1 = [A^-1, -A^-1 B C^-1; 0, C^-1] as batched
+// GEMMs.  Groups narrower than 256 are padded with identity blocks (G arrives zeroed outside its w x w corner).
+__global__ __launch_bounds__(256) void q1_diag_inv(const double* __restrict__ G, int w, double* __restrict__ T) {
   __shared__ double Gi[32][33], Tj[32][33];
-  const int tid = threadIdx.x;
-  const int nb = w / 32;
-  for (int idx = tid; idx < w * w; idx += 256) T[idx] = 0.0;
+  const int tid = threadIdx.x, J0 = 32 * blockIdx.x;
+  const bool live = J0 < w;
+  for (int idx = tid; idx < 1024; idx += 256) Gi[idx >> 5][idx & 31] = live ? G[(size_t)(J0 + (idx >> 5)) * 256 + J0 + (idx & 31)] : 0.0;
   __syncthreads();
-  for (int j = 0; j < nb; ++j) {
-    const int J0 = 32 * j;
-    for (int idx = tid; idx < 1024; idx += 256) Gi[idx >> 5][idx & 31] = G[(size_t)(J0 + (idx >> 5)) * w + J0 + (idx & 31)];
-    __syncthreads();
-    if (tid < 32) {   // column tid of T_jj by back substitution
-      const int c = tid;
-      for (int i = 31; i >= 0; --i) {
-        if (i > c) {
-          Tj[i][c] = 0.0;
-          continue;
-        }
-        double s = (i == c) ? 1.0 : 0.0;
-        for (int k = i + 1; k <= c; ++k) s = __builtin_fma(-Gi[i][k], Tj[k][c], s);
-        Tj[i][c] = s / (0.5 * Gi[i][i]);
+  if (tid < 32) {   // column tid of T_jj by back substitution
+    const int c = tid;
+    for (int i = 31; i >= 0; --i) {
+      if (i > c || !live) {
+        Tj[i][c] = (i == c) ? 1.0 : 0.0;
+        continue;
       }
+      double s = (i == c) ? 1.0 : 0.0;
+      for (int k = i + 1; k <= c; ++k) s = __builtin_fma(-Gi[i][k], Tj[k][c], s);
+      Tj[i][c] = s / (0.5 * Gi[i][i]);
     }
-    __syncthreads();
-    for (int idx = tid; idx < 1024; idx += 256) T[(size_t)(J0 + (idx >> 5)) * w + J0 + (idx & 31)] = Tj[idx >> 5][idx & 31];
-    if (j > 0) {
-      for (int idx = tid; idx < J0 * 32; idx += 256) {   // M = G[0:J0, J] T_jj
-        const int r = idx >> 5, c = idx & 31;
-        double s = 0.0;
-        for (int k = 0; k <= c; ++k) s = __builtin_fma(G[(size_t)r * w + J0 + k], Tj[k][c], s);
-        Mg[idx] = s;
-      }
-      __syncthreads();
-      for (int idx = tid; idx < J0 * 32; idx += 256) {   // T[0:J0, J] = -T[0:J0, 0:J0] M   (T upper triangular: k >= r)
-        const int r = idx >> 5, c = idx & 31;
-        double s = 0.0;
-        for (int k = r; k < J0; ++k) s = __builtin_fma(T[(size_t)r * w + k], Mg[k * 32 + c], s);
-        T[(size_t)r * w + J0 + c] = -s;
-      }
-    }
-    __syncthreads();
   }
+  __syncthreads();
+  for (int idx = tid; idx < 1024; idx += 256) T[(size_t)(J0 + (idx >> 5)) * 256 + J0 + (idx & 31)] = Tj[idx >> 5][idx & 31];
+}
+
+static int q1_tbuild(ffgp_handle* h, const double* G, int w, double* T, double* tmp) {
+  hipStream_t st = h->stream;
+  FFGP_HIP(hipMemsetAsync(T, 0, (size_t)256 * 256 * sizeof(double), st));
+  hipLaunchKernelGGL(q1_diag_inv, dim3(8), dim3(256), 0, st, G, w, T);
+  if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
+  for (int s = 32; s < 256; s *= 2) {
+    if (s >= w) break;                          // everything beyond is identity padding
+    const int np = 256 / (2 * s);
+    const long sp = (long)2 * s * 256 + 2 * s;  // from one pair's diagonal position to the next
+    // tmp_p = A_p^-1 B_p ;  T[A rows, C cols] = -tmp_p C_p^-1
+    FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, T, 256, G + s, 256, tmp, s, s, s, s, 1.0, 0.0, 0, ALIAS_NONE, np, sp, sp,
+                                (long)s * s));
+    FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, tmp, s, T + (size_t)s * 256 + s, 256, T + s, 256, s, s, s, -1.0, 0.0, 0,
+                                ALIAS_NONE, np, (long)s * s, sp, sp));
+  }
+  return FFGP_OK;
 }
 
 #define Q1_AGG 8
-size_t ffgp_q1_ws_doubles(int n, int ncols) { return (size_t)2 * 256 * 256 + 256 * 32 + (size_t)2 * 256 * ncols + 64; }
+size_t ffgp_q1_ws_doubles(int n, int ncols) { return (size_t)3 * 256 * 256 + (size_t)2 * 256 * ncols + 64; }
 
 int ffgp_q1_apply_impl(ffgp_handle* h, const double* Y, int ldy, int n, double* Z, int ldz, int ncols, double* ws) {
   hipStream_t st = h->stream;
   double* Gm = ws;
   double* Tw = Gm + 256 * 256;
-  double* Mg = Tw + 256 * 256;
-  double* P1 = Mg + 256 * 32;
+  double* tmp = Tw + 256 * 256;
+  double* P1 = tmp + 256 * 256;
   double* P2 = P1 + (size_t)256 * ncols;
   const int npan = n / 32 - 1;
   const int ngrp = (npan + Q1_AGG - 1) / Q1_AGG;
@@ -93,12 +90,12 @@ int ffgp_q1_apply_impl(ffgp_handle* h, const double* Y, int ldy, int n, double* 
     const int w = 32 * (p1 - p0);
     const int r0 = 32 * p0 + 32, mg = n - r0;
     const double* V = Y + (size_t)r0 * ldy + 32 * p0;
-    FFGP_CHECK(ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_FULL, 0, V, ldy, V, ldy, Gm, w, w, w, mg, 1.0, 0.0));
-    hipLaunchKernelGGL(q1_tbuild, dim3(1), dim3(256), 0, st, Gm, w, Tw, Mg);
-    if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
+    if (w < 256) FFGP_HIP(hipMemsetAsync(Gm, 0, (size_t)256 * 256 * sizeof(double), st));
+    FFGP_CHECK(ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_FULL, 0, V, ldy, V, ldy, Gm, 256, w, w, mg, 1.0, 0.0));
+    FFGP_CHECK(q1_tbuild(h, Gm, w, Tw, tmp));
     double* Zr = Z + (size_t)r0 * ldz;
     FFGP_CHECK(ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_FULL, 0, V, ldy, Zr, ldz, P1, ncols, w, ncols, mg, 1.0, 0.0));
-    FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Tw, w, P1, ncols, P2, ncols, w, ncols, w, 1.0, 0.0));
+    FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Tw, 256, P1, ncols, P2, ncols, w, ncols, w, 1.0, 0.0));
     FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, V, ldy, P2, ncols, Zr, ldz, mg, ncols, w, -1.0, 1.0));
   }
   return FFGP_OK;
