@@ -8,23 +8,24 @@ Same constructor, parameters (`noise_variance`, the shared kernel, `grid`, `mapp
 What runs where: the covariance matrices come from the library's assembly (differentiable `kernel_matrix`), every
 mode product -- the O(N^2 prod(d)) part: 550 GFLOP each at N = 8192, d = 64 x 64 -- runs on the fp64 matrix-core
 GEMM (`functional.matmul_nt`, forward and backward).  Symmetric eigendecompositions: matrices up to 64 x 64 -- the
-per-mode kernels -- run on the hand-written LDS Jacobi solver (`ffgp_syevj_small`); the N x N input kernel goes to
-rocSOLVER (`torch.linalg.eigh` on the device: 0.66 s at N = 8192): a vendor-library call, not a hand-written kernel --
-the one place on this path where that is so.  (A blocked one-sided Jacobi built from the batched Gram GEMM and the LDS
-solver was written and measured: kernel matrices have condition numbers >= 1e9 and the Gram step squares them, so the
-small eigenvalues never converge -- dropped; a QR-based block Jacobi is what "next" means here.)  The likelihood's
-backward is closed-form (`_KronNLL`): GEMMs only, no differentiation through `eigh`.
+per-mode kernels -- run on the hand-written LDS Jacobi solver (`ffgp_syevj_small`); the N x N input kernel runs on the
+library's two-stage solver (`eigh.eigh` -> `ffgp_syevd`: band reduction, bulge chasing, divide & conquer, two
+back-transformations; 0.43 s at N = 8192 where rocSOLVER's syevd takes 0.67 s).  No vendor library is called anywhere on
+this path; `EIGENSOLVER = "rocsolver"` (torch.linalg.eigh) exists only as the comparator of the GPU tests, "jacobi" is the
+round-2 block Jacobi (slow, independent cross-check).  The likelihood's backward is closed-form (`_KronNLL`): GEMMs only,
+no differentiation through `eigh`.
 
 Kept quirks: ONE kernel module is shared by the input space and every output mode (:27-29); the per-mode grids are
 0..d-1 as float columns; `forward` needs `log_likelihood` to have been called (it reads the cached `K`, `K_eigen`,
 `A`, `g`); the "variance" is diag(K) + (A-weighted squared eigenvector products) (:60-75).
 
-`variance_mode` (constructor keyword, attribute): "reference" (default) evaluates `K_star @ K_x.inverse() @ U_x` as the
-reference writes it (:68) -- an explicit LU inverse of the jitter-free kernel matrix (cond ~1e13 on the fixtures; the
-device's getrf/getri, a one-off O(N^3) outside the likelihood) followed by two GEMMs; "eigen" evaluates the same matrix
-as `K_star @ (U_x / lambda_x)` from the eigenpairs already cached, without inverting a numerically singular K_x.  The
-two agree to ~cond * eps; which one is "right" is moot (the expression is not a variance), the default is the
-reference's arithmetic.
+`variance_mode` (constructor keyword, attribute): "reference" (default) evaluates `K_star @ K_x.inverse() @ U_x` in the
+reference's order of operations (:68) with an EXPLICIT inverse of the jitter-free kernel matrix followed by two GEMMs; the
+inverse is formed from the eigenpairs the likelihood call already produced, K_x^-1 = (U / lambda) U^T on the fp64 GEMM (the
+reference's `.inverse()` is LAPACK's LU; on these numerically singular matrices -- cond 5e6 ... 1e13 on the fixtures -- any
+two inverses agree to ~cond * eps, which is also what the fixtures of the reference's own LU hold this to).  "eigen"
+evaluates the same matrix as `K_star @ (U_x / lambda_x)` without forming the inverse.  Which one is "right" is moot (the
+expression is not a variance); the default keeps the reference's arithmetic shape.
 """
 import math
 
@@ -34,25 +35,44 @@ import torch.nn as nn
 from . import functional as F
 
 
-EIGENSOLVER = "rocsolver"    # n > 64: "rocsolver" = torch.linalg.eigh (default); "jacobi" = the library's own block Jacobi (eigh.py: slow)
+EIGENSOLVER = "ffgp"    # n > 64: "ffgp" = the library's two-stage solver (default); "jacobi" = its block Jacobi (slow cross-check);
+                        # "rocsolver" = torch.linalg.eigh, the comparator of the GPU tests -- never the default
 
 
 class eigen_pairs:
     """matrices up to 64 x 64 (the per-mode kernels; tiny input sets) go to the hand-written LDS Jacobi solver
-    (`ffgp_syevj_small`, ~80 us where rocSOLVER's syevd takes 1.7 ms).  Larger ones -- the N x N input kernel -- go to
-    rocSOLVER through `torch.linalg.eigh`: the one vendor-library call on this path.  The library's own large-N solver
-    (`eigh.jacobi_eigh`, block Jacobi on the LDS kernel and the batched MFMA GEMM) is correct but 30x slower at N = 8192
-    (21 s against 0.67 s) and therefore opt-in: `hogp_simple.EIGENSOLVER = "jacobi"`."""
+    (`ffgp_syevj_small`, ~80 us where rocSOLVER's syevd takes 1.7 ms), larger ones -- the N x N input kernel -- to the
+    library's two-stage solver (`ffgp_syevd`).  Reference: `eigen_pairs`, two_fidelity_models/hogp_simple.py:15-19."""
 
     def __init__(self, matrix):
         if matrix.shape[0] <= 64 and matrix.is_cuda:
             self.value, self.vector = F.eigh_small(matrix)
-        elif matrix.is_cuda and EIGENSOLVER == "jacobi":
-            from .eigh import jacobi_eigh
+        elif matrix.is_cuda and EIGENSOLVER in ("ffgp", "jacobi"):
+            from . import eigh as _eigh
             with torch.no_grad():
-                self.value, self.vector = jacobi_eigh(matrix.detach().to(torch.float64))
-        else:
+                fn = _eigh.eigh if EIGENSOLVER == "ffgp" else _eigh.jacobi_eigh
+                self.value, self.vector = fn(matrix.detach().to(torch.float64))
+        elif EIGENSOLVER == "rocsolver" or not matrix.is_cuda:
             self.value, self.vector = torch.linalg.eigh(matrix, UPLO="U")
+        else:
+            raise ValueError("unknown EIGENSOLVER %r" % (EIGENSOLVER,))
+
+
+class _InvFromEigen(torch.autograd.Function):
+    """K^-1 = (U / lambda) U^T from the eigenpairs of the symmetric K (explicit inverse on the fp64 GEMM); backward
+    d K = -K^-1 (d K^-1) K^-1"""
+
+    @staticmethod
+    def forward(ctx, K, lam, U):
+        Kinv = F.matmul_nt(U / lam.unsqueeze(0), U)
+        ctx.save_for_backward(Kinv)
+        return Kinv
+
+    @staticmethod
+    def backward(ctx, dKi):
+        (Kinv,) = ctx.saved_tensors
+        t = F.matmul_nt(Kinv, dKi.T.contiguous())          # K^-1 dKi   (K^-1 is symmetric)
+        return -F.matmul_nt(t, Kinv), None, None
 
 
 def mode_dot(t, M, mode):
@@ -227,10 +247,11 @@ class HOGP_simple(nn.Module):
         e0 = self.K_eigen[0]
         if self.variance_mode == "reference":   # K_star @ K_x.inverse() @ U_x, the reference's own order of operations (:68)
             if torch.is_grad_enabled() and self.K[0].requires_grad:
-                K_inv = torch.linalg.inv(self.K[0])
+                K_inv = _InvFromEigen.apply(self.K[0], e0.value.detach(), e0.vector.detach())
             else:
                 if getattr(self, "_K_inv", None) is None:
-                    self._K_inv = torch.linalg.inv(self.K[0].detach())
+                    with torch.no_grad():
+                        self._K_inv = _InvFromEigen.apply(self.K[0].detach(), e0.value.detach(), e0.vector.detach())
                 K_inv = self._K_inv
             ev_x = F.matmul_nt(F.matmul_nt(K_star, K_inv.T.contiguous()), e0.vector.T.contiguous()).pow(2)
         else:                                   # the same matrix from the cached eigenpairs: K_x^-1 U_x = U_x / lambda

@@ -2,8 +2,8 @@
 `fidelityfusion_amd.hogp_simple.HOGP_simple`: one kernel PER mode (`create_kernels` over the repeated config), the
 noise box, `y_var` added to A, `train_x` / `train_y` kept from the first `compute_loss` (or when `update_data`), and a
 `forward` whose "variance" is diag(K) + A x_0 (K* K_x + 1e-6 eye^2)  x_m U_m^2 exactly as written (:226-229, no
-inverse).  Covariances from the library's assembly, mode products on the fp64 GEMM, eigendecompositions by rocSOLVER
-(see hogp_simple.py)."""
+inverse).  Covariances from the library's assembly, mode products on the fp64 GEMM, eigendecompositions by the library's own
+solvers (LDS Jacobi up to 64 x 64, the two-stage `ffgp_syevd` above; see hogp_simple.py)."""
 import math
 
 import torch

@@ -1,5 +1,5 @@
-"""The library's own (opt-in) large-N symmetric eigensolver, fidelityfusion_amd/eigh.py, against
-LAPACK, and the HOGP block with both eigensolvers."""
+"""The round-2 block Jacobi (fidelityfusion_amd/eigh.py, the slow independent cross-check) against LAPACK, and the HOGP block
+ with every eigensolver: the default two-stage ffgp_syevd, the block Jacobi, and rocSOLVER as the comparator."""
 import numpy as np
 import pytest
 import torch
@@ -38,9 +38,9 @@ def test_block_jacobi_dense_core_vs_lapack(n):
 
 
 def test_hogp_block_same_with_both_eigensolvers():
-    """HOGP_simple.log_likelihood / forward at N = 500, d = 6 x 5 with the library's block Jacobi and with rocSOLVER: loss,
-    every gradient, cached g, posterior -- the quantities are basis-independent, so they must agree although the two
-    solvers return different bases of the near-null space"""
+    """HOGP_simple.log_likelihood / forward at N = 500, d = 6 x 5 with the library's two-stage solver (the default), its block
+    Jacobi and rocSOLVER (comparator): loss, every gradient, cached g, posterior -- the quantities are basis-independent, so they
+    must agree although the solvers return different bases of the near-null space"""
     from fidelityfusion_amd import hogp_simple, kernel
     n, d1, d2 = 500, 6, 5
     g = torch.Generator(device=DEV).manual_seed(5)
@@ -48,7 +48,8 @@ def test_hogp_block_same_with_both_eigensolvers():
     Y = torch.randn((n, d1, d2), generator=g, device=DEV, dtype=torch.float64)
     Xt = torch.rand((9, 3), generator=g, device=DEV, dtype=torch.float64)
     res = {}
-    for solver in ("jacobi", "rocsolver"):
+    assert hogp_simple.EIGENSOLVER == "ffgp"          # the library's own solver is the default; rocSOLVER only compares
+    for solver in ("ffgp", "jacobi", "rocsolver"):
         hogp_simple.EIGENSOLVER = solver
         try:
             m = hogp_simple.HOGP_simple(kernel.ARDKernel(3), 0.7, [d1, d2], variance_mode="eigen").double().to(DEV)
@@ -60,11 +61,13 @@ def test_hogp_block_same_with_both_eigensolvers():
             res[solver] = (float(loss), Yr.grad.clone(), m.noise_variance.grad.clone(), m.kernel_list[0].length_scales.grad.clone(),
                            m.g.clone(), mu.clone(), var.clone())
         finally:
-            hogp_simple.EIGENSOLVER = "rocsolver"
-    a, b = res["jacobi"], res["rocsolver"]
+            hogp_simple.EIGENSOLVER = "ffgp"
     rel = lambda x, y: float((x - y).abs().max() / y.abs().max())
-    assert abs(a[0] - b[0]) <= 1e-10 * abs(b[0])
-    assert rel(a[1], b[1]) < 1e-8 and rel(a[2], b[2]) < 1e-8 and rel(a[3], b[3]) < 1e-7
-    assert rel(a[4], b[4]) < 1e-8 and rel(a[5], b[5]) < 1e-8
+    b = res["rocsolver"]
+    for own in ("ffgp", "jacobi"):
+        a = res[own]
+        assert abs(a[0] - b[0]) <= 1e-10 * abs(b[0]), own
+        assert rel(a[1], b[1]) < 1e-8 and rel(a[2], b[2]) < 1e-8 and rel(a[3], b[3]) < 1e-7, own
+        assert rel(a[4], b[4]) < 1e-8 and rel(a[5], b[5]) < 1e-8, own
     # (the reference's "variance" expression divides by the eigenvalues of the jitter-free K_x -- ~1e-16 here -- and is a
     #  different O(1e5) number for every basis of the near-null space: nothing to compare)

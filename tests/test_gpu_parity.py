@@ -876,7 +876,7 @@ def test_car_chain_golden(golden):
 @pytest.mark.parametrize("where", ["cuda", "cpu"])
 def test_hogp_block_golden(golden, where):
     """H1-H2 (GAR's per-fidelity block, config 5): HOGP_simple.log_likelihood / forward on the device -- library
-    assembly, GEMM-backed mode products, rocSOLVER eigh -- against the reference: loss, all gradients, cached A / g,
+    assembly, GEMM-backed mode products, the library's own eigensolvers -- against the reference: loss, all gradients, cached A / g,
     posterior mean and variance."""
     from fidelityfusion_amd import kernel
     from fidelityfusion_amd.hogp_simple import HOGP_simple
@@ -903,7 +903,7 @@ def test_hogp_block_golden(golden, where):
     assert tuple(mean.shape) == g["mean"].shape
     assert rel(mean, g["mean"]) < 1e-7
     # variance_mode "reference" (default): K_star @ K_x.inverse() @ U_x as hogp_simple.py:68 writes it; cond(K_x) = 5e6 here, so
-    # two LU inverses (LAPACK in the fixture, the device's here) agree to ~cond * eps
+    # two explicit inverses (LAPACK's LU in the fixture, (U / lambda) U^T from the library's eigenpairs here) agree to ~cond * eps
     assert m.variance_mode == "reference"
     assert rel(var, g["var"]) < 1e-6
     m.variance_mode = "eigen"            # the opt-in: the same matrix from the cached eigenpairs, U_x / lambda_x
