@@ -11,6 +11,10 @@ Workloads (--workload):
   c2                  BASELINE configs[1]: N = 4096, D = 8, d = 1 (same sharding as headline).
   cigar4              BASELINE configs[3]: F = 4 fixed blocks of N = 8192, D = 8, d = 1024 (strong scaling).
   gar8                BASELINE configs[4]: F = 8 fixed blocks of N = 8192, D = 8, d = 4096 (strong scaling).
+  gar8_hogp           the same configuration with the blocks as the reference writes them (FidelityFusion_Models/GAR.py:76-126):
+                      HOGP_simple.log_likelihood on N = 8192, d = 64 x 64 -- eigendecomposition of the N x N input kernel by the
+                      library's own two-stage solver (ffgp_syevd) + the mode products on the fp64 GEMM ("HOGP variant
+                      reported separately").
 For the fixed-F workloads the blocks are dealt to the ranks by longest-processing-time-first
 (fidelityfusion_amd.sharding.partition_lpt -- the reference's per-fidelity loop, FidelityFusion_Models/CIGAR.py:99-134,
 GAR.py:76-126; the sum MFGP_ver2023May/ResGP.py:232-246); a rank that owns several blocks overlaps them on its GPU
@@ -47,7 +51,9 @@ WORKLOADS = {   # name: (F or None = one block per rank, N, D, d, BASELINE confi
     "c2": (None, 4096, 8, 1, 1),
     "cigar4": (4, 8192, 8, 1024, 3),
     "gar8": (8, 8192, 8, 4096, 4),
+    "gar8_hogp": (8, 8192, 8, 4096, 4),
 }
+HOGP_MODES = (64, 64)   # output shape of a gar8_hogp block (prod = d)
 
 
 def parse_args(argv=None):
@@ -138,6 +144,18 @@ def synthetic_xy_device(n, D, d, seed, dev):
 def nlml_flops(n, D, d):
     """N^3/3 (Cholesky) + N^2 d (Gamma = L^-1 Y) + 2 N^2 D (distance contractions)."""
     return n ** 3 / 3.0 + float(n) * n * d + 2.0 * n * n * D
+
+
+def hogp_flops(n, modes):
+    """One HOGP_simple.log_likelihood forward as this build executes it: the two-stage eigensolver of the N x N input kernel --
+    band reduction 2 N^3 (A V products 2/3, rank-64 updates 4/3), divide & conquer merges as dense GEMMs 8/3 N^3, the two
+    back-transformations 2 N^3 each (useful flops; the staircase blocks of the second execute twice that) -- and the mode
+    products: two mode-0 products 2 N^2 prod(d) each (T_1 = Y x_0 U^T, g = W x_0 U) plus the small per-mode ones."""
+    pd = 1.0
+    for m in modes:
+        pd *= m
+    eig = (2.0 + 8.0 / 3.0 + 2.0 + 2.0) * float(n) ** 3
+    return eig + 2.0 * 2.0 * float(n) * n * pd + 2.0 * 2.0 * float(n) * pd * sum(modes)
 
 
 def recorded_traffic(n):
@@ -293,6 +311,25 @@ def run_rank(args):
                     dist.all_reduce(joint)
                 return joint
             return step, F_total, n, D, d, scaling
+        if name == "gar8_hogp":   # the blocks as HOGP_simple (GAR's per-fidelity model): own eigensolver + mode products
+            from fidelityfusion_amd import kernel as K_
+            from fidelityfusion_amd.hogp_simple import HOGP_simple
+            modes = HOGP_MODES if d == HOGP_MODES[0] * HOGP_MODES[1] else (d, 1)
+            hdata, models = {}, {}
+            for f in mine:
+                X, Y = synthetic_xy_device(n, D, d, f, dev)
+                hdata[f] = (X, Y.reshape(n, *modes))
+                models[f] = HOGP_simple(K_.ARDKernel(D), 1.0, list(modes)).double().to(dev)
+
+            def step():
+                joint.zero_()
+                with torch.no_grad():
+                    for f in mine:
+                        joint[f] = models[f].log_likelihood(hdata[f][0], hdata[f][1]).to(joint.device)
+                if world > 1:
+                    dist.all_reduce(joint)
+                return joint
+            return step, F_total, n, D, d, scaling
         data = {}
         for f in mine:
             if d <= 16:   # host recipe: the CPU baseline leg reads the very same numbers
@@ -361,6 +398,8 @@ def run_rank(args):
             _lib.set_option("timing", 0, local_rank)
     ms_per_step = dt / args.steps * 1e3
     flops_step = nlml_flops(n, D, d) * (3.0 if args.with_grad else 1.0) * F_total   # fwd+bwd ~ N^3
+    if args.workload == "gar8_hogp":
+        flops_step = hogp_flops(n, HOGP_MODES if d == HOGP_MODES[0] * HOGP_MODES[1] else (d, 1)) * F_total
     value = flops_step / (dt / args.steps) / 1e9
     stock = args.n is None and args.D is None and args.d is None and args.blocks is None
     gpu_nll = {args.workload: float(joint[0])} if args.workload in ("headline", "c2") and stock else {}
@@ -371,14 +410,19 @@ def run_rank(args):
         del step
         if not args.dry:
             torch.cuda.empty_cache()
-        for name in ("cigar4", "gar8"):
+        for name in ("cigar4", "gar8", "gar8_hogp"):
             kw = dict(n=64, d=8) if args.dry else {}
             s_step, sF, sn, sD, sd, _ = make_workload(name, **kw)
-            sdt, sjoint = timed(s_step, 4, 3)     # (the first steps grow the workspaces of the concurrent slots)
-            sharded[name] = {"blocks": sF, "N": sn, "D": sD, "d": sd, "ms_per_step": round(sdt / 4 * 1e3, 3),
-                             "value": round(nlml_flops(sn, sD, sd) * sF / (sdt / 4) / 1e9, 1), "unit": "GF/s", "scaling": "strong",
+            hog = name == "gar8_hogp"
+            ssteps, swarm = (2, 1) if hog else (4, 3)     # (the first steps grow the workspaces of the concurrent slots)
+            sdt, sjoint = timed(s_step, ssteps, swarm)
+            sfl = hogp_flops(sn, HOGP_MODES if sd == HOGP_MODES[0] * HOGP_MODES[1] else (sd, 1)) if hog else nlml_flops(sn, sD, sd)
+            sharded[name] = {"blocks": sF, "N": sn, "D": sD, "d": sd, "ms_per_step": round(sdt / ssteps * 1e3, 3),
+                             "value": round(sfl * sF / (sdt / ssteps) / 1e9, 1), "unit": "GF/s", "scaling": "strong",
                              "blocks_per_rank": -(-sF // world), "joint_nll": float(sjoint.sum()),
-                             "config": "BASELINE configs[%d]" % WORKLOADS[name][4]}
+                             "config": "BASELINE configs[%d]" % WORKLOADS[name][4] + (
+                                 " as HOGP blocks (d = %d x %d): eigh of the N x N input kernel on ffgp_syevd + mode products; flops = "
+                                 "8.67 N^3 + 4 N^2 d per block, see hogp_flops" % HOGP_MODES if hog else "")}
             del s_step
             if not args.dry:
                 torch.cuda.empty_cache()
@@ -396,7 +440,9 @@ def run_rank(args):
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %s NLML %s, ARD kernel, %d block%s of N=%d D=%d d=%d%s"
-                                   % (args.workload, "single-fidelity cigp" if F_total == world and scaling == "weak" else "per-fidelity cigp blocks,",
+                                   % (args.workload, "single-fidelity cigp" if F_total == world and scaling == "weak" else
+                                      ("per-fidelity HOGP_simple blocks (eigh on ffgp_syevd + mode products)," if args.workload == "gar8_hogp"
+                                       else "per-fidelity cigp blocks,"),
                                       "forward+gradients" if args.with_grad else "forward", F_total, "" if F_total == 1 else "s", n, D, d,
                                       " (BASELINE configs[%d])" % cfg_idx if cfg_idx is not None else ""),
                        "N": n, "D": D, "d": d, "blocks": F_total,

@@ -42,6 +42,10 @@ def test_self_launch_two_ranks_weak_and_sharded_legs():
     assert sh["cigar4"]["blocks"] == 4 and sh["cigar4"]["blocks_per_rank"] == 2 and sh["cigar4"]["scaling"] == "strong"
     assert sh["gar8"]["blocks"] == 8 and sh["gar8"]["blocks_per_rank"] == 4
     assert abs(sh["gar8"]["joint_nll"] - _expected_joint(8, 64, 8, 8)) < 1e-9 * abs(sh["gar8"]["joint_nll"])
+    # ... and the HOGP wording of config 5 ("HOGP variant reported separately"), dealt and reduced the same way
+    hg = sh["gar8_hogp"]
+    assert hg["blocks"] == 8 and hg["blocks_per_rank"] == 4 and "HOGP" in hg["config"] and hg["value"] > 0
+    assert abs(hg["joint_nll"] - _expected_joint(8, 64, 8, 8)) < 1e-9 * abs(hg["joint_nll"])
 
 
 def test_fixed_blocks_same_joint_value_on_1_2_3_ranks():
@@ -52,6 +56,16 @@ def test_fixed_blocks_same_joint_value_on_1_2_3_ranks():
         vals.append(out["joint_nll"])
     assert abs(vals[0] - _expected_joint(8, 80, 8, 4)) < 1e-9 * abs(vals[0])
     assert abs(vals[1] - vals[0]) < 1e-9 * abs(vals[0]) and abs(vals[2] - vals[0]) < 1e-9 * abs(vals[0])
+
+
+def test_hogp_workload_flop_count_and_dry_run():
+    sys.path.insert(0, ROOT)
+    import bench
+    n = 8192
+    fl = bench.hogp_flops(n, (64, 64))
+    assert abs(fl - (26.0 / 3.0 * n ** 3 + 4.0 * n * n * 4096 + 4.0 * n * 4096 * 128)) < 1e-6 * fl
+    out = _run("--gpus", "2", "--workload", "gar8_hogp", "--n", "80", "--d", "4")
+    assert out["scaling"] == "strong" and out["config"]["blocks"] == 8 and "gar8_hogp" in out["config"]["workload"]
 
 
 def test_runs_as_a_rank_under_an_external_launcher():
