@@ -1,8 +1,10 @@
-"""The reference's own single-output demo (GaussianProcess/cigp_v10.py:73-101), with the import switched.
-python examples/cigp_demo.py        tensors and model stay on the CPU, as the reference writes them: every call copies its
-                                    inputs / parameters to the MI355X and the results back
-python examples/cigp_demo.py cuda   model.to("cuda") and device tensors: no transfers
-(16 training points: ~0.9 ms per Adam step either way -- launch and Python overhead; the first step pays ~0.45 s of set-up)"""
+"""A small drop-in tour: the reference's `cigp` module and kernel classes, imported from this package, on a 2-D test surface of
+our own (a damped ripple) -- fit the hyper-parameters by maximum likelihood, report held-out error and the calibration of the
+predictive variance.
+
+python examples/cigp_demo.py [cuda]      `cuda`: model and tensors live on the MI355X (no per-call transfers)
+"""
+import math
 import os
 import sys
 import time
@@ -10,33 +12,39 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from fidelityfusion_amd import kernel                     # reference: import kernel
-from fidelityfusion_amd.cigp_v10 import cigp              # reference: from cigp_v10 import cigp
+from fidelityfusion_amd import kernel
+from fidelityfusion_amd.cigp_v10 import cigp
 
-torch.manual_seed(1)
-xte = torch.linspace(0, 6, 100).view(-1, 1)
-yte = torch.sin(xte) + 10
-xtr = torch.rand(16, 1) * 6
-ytr = torch.sin(xtr) + torch.randn(16, 1) * 0.5 + 10
+where = "cuda" if sys.argv[1:] == ["cuda"] else "cpu"
+gen = torch.Generator().manual_seed(2026)
 
-kernel1 = kernel.SumKernel(kernel.LinearKernel(1), kernel.MaternKernel(1))   # two descriptors, one tile pass (csrc/pair.hip)
-model = cigp(kernel=kernel1, log_beta=1.0)
-if len(sys.argv) > 1 and sys.argv[1] == "cuda":
-    model = model.to("cuda")
-    xtr, ytr, xte, yte = (t.to("cuda") for t in (xtr, ytr, xte, yte))
-optimizer = torch.optim.Adam(model.parameters(), lr=1e-1)
-t0 = time.time()
-for i in range(100):
-    if i == 1:
-        t1 = time.time()        # (the first step loads the code objects and allocates the handle's workspaces)
-    optimizer.zero_grad()
-    loss = -model.negative_log_likelihood(xtr, ytr)
-    loss.backward()
-    optimizer.step()
-    if i % 20 == 0 or i == 99:
-        print("iter", i, "nll:{:.5f}".format(loss.item()))
-print("first step {:.3f} s, then {:.2f} ms per step".format(t1 - t0, (time.time() - t1) / 99 * 1e3))
+
+def ripple(x):                                   # the surface: exp(-r) cos(3 pi r) around (0.3, 0.6), shifted off zero
+    r = (x - torch.tensor([0.3, 0.6])).norm(dim=1, keepdim=True)
+    return torch.exp(-r) * torch.cos(3.0 * math.pi * r) + 2.0
+
+
+x_fit = torch.rand(160, 2, generator=gen)
+y_fit = ripple(x_fit) + 0.05 * torch.randn(160, 1, generator=gen)
+x_new = torch.rand(400, 2, generator=gen)
+y_new = ripple(x_new)
+
+gp = cigp(kernel=kernel.ARDKernel(2), log_beta=2.0).to(where)
+x_fit, y_fit, x_new, y_new = (t.to(where) for t in (x_fit, y_fit, x_new, y_new))
+opt = torch.optim.Adam(gp.parameters(), lr=5e-2)
+history, clock = [], time.perf_counter()
+for it in range(150):
+    opt.zero_grad()
+    nll = -gp.negative_log_likelihood(x_fit, y_fit)     # (the reference's function returns +LL: callers negate)
+    nll.backward()
+    opt.step()
+    history.append(float(nll))
+elapsed = time.perf_counter() - clock
+print("150 likelihood + gradient steps on %s: %.2f s;  nll %.3f -> %.3f" % (where, elapsed, history[0], history[-1]))
+print("length scales", [round(float(v), 3) for v in gp.kernel.length_scales.abs()], " noise sd %.3f" % math.exp(-0.5 * float(gp.log_beta)))
+
 with torch.no_grad():
-    ypred, ypred_var = model.forward(xtr, ytr, xte)
-rmse = float((ypred - yte).pow(2).mean().sqrt())
-print("prediction at 100 points: rmse {:.3f}, mean predictive sd {:.3f}".format(rmse, float(ypred_var.diag().clamp_min(0).sqrt().mean())))
+    mean, cov = gp.forward(x_fit, y_fit, x_new)
+    sd = cov.diagonal().clamp_min(0).sqrt().unsqueeze(1)
+    z = (y_new - mean) / sd
+print("held-out rmse %.4f;  |error| <= 2 sd on %.0f %% of 400 points" % (float((mean - y_new).pow(2).mean().sqrt()), 100.0 * float((z.abs() <= 2).float().mean())))

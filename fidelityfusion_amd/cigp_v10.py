@@ -97,7 +97,7 @@ class cigp(F.PosteriorCacheMixin, nn.Module):
     def negative_log_likelihood(self, x_train, y_train):
         y_train, y_var = _split(y_train)
         pr = self.kernel.pair() if hasattr(self.kernel, "pair") else None
-        if pr is not None:   # SumKernel(LinearKernel, MaternKernel) of the demos (:81,111,147): two descriptors, fused like a single kernel
+        if pr is not None and F.pair_inputs_plain(x_train, y_var):   # SumKernel(LinearKernel, MaternKernel) of the demos (:81,111,147): two descriptors, fused like a single kernel
             return -F.nlml_pair(x_train, y_train, pr[0], pr[1], diag_add=self.log_beta.exp().pow(-1).double() + JITTER, diag_vec=y_var,
                                 variant=F.FFGP_LL_V1, pi_const=PI, **F._slot_args())
         if not hasattr(self.kernel, "effective"):

@@ -388,15 +388,16 @@ int ffgp_trtri_diag(ffgp_handle* h, const double* L, int n, int ldl) {
 #include <dlfcn.h>
 typedef int (*ffgp_nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
 static ffgp_nccl_allreduce_fn ffgp_resolve_allreduce() {
-  static ffgp_nccl_allreduce_fn fn = nullptr;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  // resolved exactly once, whichever host thread (one per handle / GPU) gets here first: a function-local static's
+  // initialiser runs under the language's own lock
+  static const ffgp_nccl_allreduce_fn fn = [] {
+    ffgp_nccl_allreduce_fn f = nullptr;
     void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);   // the copy already in the process, if any (same SONAME)
     if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (lib) fn = reinterpret_cast<ffgp_nccl_allreduce_fn>(dlsym(lib, "ncclAllReduce"));
-    if (!fn) fprintf(stderr, "[ffgp] ffgp_allreduce_sum: cannot resolve ncclAllReduce from librccl.so.1 (%s)\n", dlerror());
-  }
+    if (lib) f = reinterpret_cast<ffgp_nccl_allreduce_fn>(dlsym(lib, "ncclAllReduce"));
+    if (!f) fprintf(stderr, "[ffgp] ffgp_allreduce_sum: cannot resolve ncclAllReduce from librccl.so.1 (%s)\n", dlerror());
+    return f;
+  }();
   return fn;
 }
 

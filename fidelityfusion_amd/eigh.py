@@ -148,8 +148,8 @@ def jacobi_eigh(B, max_sweeps=30, tol=2e-15):
     m = nb * 32
     A = torch.zeros((m, m), dtype=torch.float64, device=dev)
     A[:n, :n] = B
-    scale = float(B.diagonal().abs().max()) or 1.0
-    if m > n:   # padding: decoupled 1 x 1 blocks with distinct values far below the spectrum -- they never rotate
+    scale = float(B.abs().sum(1).max()) or 1.0      # Gershgorin: every eigenvalue of B lies in [-scale, scale]
+    if m > n:   # padding: decoupled 1 x 1 blocks with distinct values below the whole spectrum -- they never rotate
         A[n:, n:] = torch.diag(-scale * (2.0 + torch.arange(m - n, dtype=torch.float64, device=dev)))
     Vt = torch.eye(m, dtype=torch.float64, device=dev)                 # V^T: its rows are rotated like A's
     rounds = _round_robin(nb)
@@ -186,7 +186,11 @@ def jacobi_eigh(B, max_sweeps=30, tol=2e-15):
     ev = A.diagonal()[:m].clone()
     keep = torch.ones(m, dtype=torch.bool, device=dev)
     if m > n:   # drop the padding's eigenpairs: the ones whose vectors live on the padded coordinates
-        keep = Vt[:, n:].abs().amax(1) < 0.5
+        mass = Vt[:, n:].abs().amax(1)
+        keep = mass < 0.5
+        if int(keep.sum()) != n:   # should not happen (the padding sits outside B's Gershgorin interval): keep the n rows with least padding mass
+            keep = torch.zeros(m, dtype=torch.bool, device=dev)
+            keep[torch.argsort(mass)[:n]] = True
     ev, V = ev[keep], Vt[keep][:, :n].T
     order = torch.argsort(ev)
     return ev[order].contiguous(), V[:, order].contiguous()

@@ -276,7 +276,7 @@ class concurrent_blocks:
         class _Slot:
             def __enter__(self_inner):
                 cb.cur = 1 + (i % cb.nslots)          # slot 0 stays the synchronous default handle
-                if cb.cur not in cb.used:
+                if cb.cur not in cb.used:   # (restored in concurrent_blocks.__exit__: the slot handles are process-wide)
                     _lib.set_option_handle(_lib.handle(cb.device_index, cb.cur), "lookahead", 1.0 if cb.lookahead else 0.0)
                 cb.used.add(cb.cur)
                 self_inner.ctx = torch.cuda.stream(cb.streams[cb.cur - 1])
@@ -298,6 +298,8 @@ class concurrent_blocks:
                 err = e
         for s in self.streams:
             self.origin.wait_stream(s)
+        for sl in sorted(self.used):   # the library default (look-ahead on) for whoever uses that slot's handle next
+            _lib.set_option_handle(_lib.handle(self.device_index, sl), "lookahead", 1.0)
         if err is not None and exc[0] is None:
             raise err
         return False
@@ -601,6 +603,16 @@ class _NLMLPair(torch.autograd.Function):
 
         pair = _pair_grads_out(ctx.grads.get("_pair"), ctx.D, ctx.needs, ctx.metas, scale=gout)
         return (None, fin("Y", 0), None, None, fin("diag_add", 1), fin("diag_vec", 2)) + (None,) * 8 + tuple(pair)
+
+
+def pair_inputs_plain(x_train, *extras):
+    """True when the fused pair likelihood may be used: `_NLMLPair.backward` returns gradients for Y, diag_add, diag_vec and the
+    kernel parameters only, so a caller with learnable / latent inputs (x_train.requires_grad) or a gradient-carrying y_var
+    matrix must take the composed path (kernel_on_device -> add_diagonal -> gaussian_nll_from_cov), which differentiates
+    through both."""
+    if not torch.is_grad_enabled():
+        return True
+    return not any(isinstance(t, torch.Tensor) and t.requires_grad for t in (x_train,) + extras)
 
 
 def nlml_pair(X, Y, descs, op, diag_add=None, diag_vec=None, add_mat=None, add_all=0.0, mean_jitter=0.0, variant=FFGP_LL_V1,

@@ -88,7 +88,7 @@ class GP_basic(F.PosteriorCacheMixin, nn.Module):
             quad, const = _alt_terms(y_train, self._sigma_composed(x_train, y_var).to(y_train.device), Kinv_method)
             return -0.5 * ((quad.sum() if Kinv_method == "cholesky2" else quad) + const)
         pr = self.kernel.pair() if hasattr(self.kernel, "pair") else None
-        if pr is not None:   # Sum / Product of two library kernels (:170-173): two descriptors, fused like a single kernel
+        if pr is not None and F.pair_inputs_plain(x_train, y_var):   # Sum / Product of two library kernels (:170-173): two descriptors, fused like a single kernel
             ll = -F.nlml_pair(x_train, y_train, pr[0], pr[1], diag_add=self.noise_variance.pow(2), add_mat=y_var,
                               variant=F.FFGP_LL_V2, pi_const=math.pi, **F._slot_args())
             return ll.reshape(1, 1) if y_train.shape[1] == 1 else ll

@@ -97,7 +97,7 @@ def conditional_Gaussian(y, Sigma, K_s, K_ss, Kinv_method="cholesky3"):
 def negative_log_likelihood(kernel, log_beta, x_train, y_train):
     """Sigma = K + exp(-log_beta) I + 1e-6 mean(K) I ; returns +LL with pi = 3.1415 (:120-136)."""
     pr = kernel.pair() if hasattr(kernel, "pair") else None
-    if pr is not None:   # Sum / Product of two library kernels: two descriptors, one assembly pass, one gradient pass
+    if pr is not None and F.pair_inputs_plain(x_train):   # Sum / Product of two library kernels: two descriptors, one assembly pass, one gradient pass
         return -F.nlml_pair(x_train, y_train, pr[0], pr[1], diag_add=log_beta.exp().pow(-1), mean_jitter=JITTER,
                             variant=F.FFGP_LL_V1, pi_const=PI, **F._slot_args())
     if not hasattr(kernel, "effective"):   # any other composition: Sigma is built on the device, then the fused factorisation

@@ -29,7 +29,7 @@ local sums followed by one 2-scalar all-reduce.  nll = 1/2 ||Gamma||^2 + d sum l
 formula of the single-GPU path (cigp_v10.py:67-68), same constants.
 
 The arithmetic is injected (`ops`): `HipOps` drives libffgp (ffgp_assemble / ffgp_potrf_rows / ffgp_gemm /
-ffgp_trsm_lower) on this rank's GPU; tests inject `TorchOps` to prove the distributed algorithm on CPU over gloo.  No
+ffgp_trsm_lower) on this rank's GPU; the CPU tests inject a torch double of the four operations (tests/tiled_torch_ops.py) to prove the distributed algorithm over gloo.  No
 multi-GPU hardware number is claimed for this module: the pool has 1-GPU boxes.
 """
 import math
@@ -72,37 +72,6 @@ class PanelLayout:
 
     def bytes_per_rank(self, rank):
         return sum(8 * self.rows(k) * self.width(k) for k in self.owned(rank))
-
-
-class TorchOps:
-    """The four local operations on torch tensors (CPU tests; also a readable specification of HipOps)."""
-
-    def __init__(self, device="cpu"):
-        self.device = torch.device(device)
-
-    def kernel_panel(self, Xr, Xc, w, amp, clamp):
-        d = (Xr * w).unsqueeze(1) - (Xc * w).unsqueeze(0)
-        return amp * torch.exp(-0.5 * torch.clamp((d * d).sum(-1), min=clamp))
-
-    def potrf_rows(self, T, w):
-        L, info = torch.linalg.cholesky_ex(T[:w, :w])
-        if int(info) > 0:
-            return int(info)
-        T[:w, :w] = L
-        if T.shape[0] > w:
-            T[w:] = torch.linalg.solve_triangular(L, T[w:].T, upper=False).T
-        return 0
-
-    def update(self, C, A, B):
-        """C -= A B^T"""
-        C -= A @ B.T
-
-    def trsm_lower(self, Lkk, B):
-        B.copy_(torch.linalg.solve_triangular(torch.tril(Lkk), B, upper=False))
-
-    def gemm_acc(self, Z, A, G):
-        """Z += A G"""
-        Z += A @ G
 
 
 class HipOps:

@@ -402,6 +402,48 @@ def test_cigp_fp32_log_beta_keeps_the_jitter(kind):
     assert rel(got, want) < 1e-11
 
 
+@pytest.mark.parametrize("model", ["cigp", "pack", "gp_basic_yvar"])
+def test_pair_likelihood_with_learnable_inputs_takes_the_composed_path(model):
+    """a caller with latent / learnable inputs (x_train.requires_grad) or a gradient-carrying y_var: the fused pair likelihood has no
+    input gradients, so the dispatch must fall back to the composed path -- x_train.grad (and y_var.grad) equal with
+    FUSE_PAIRS on and off, and are not None"""
+    import fidelityfusion_amd.gp_computation_pack as gp_pack
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp
+    from fidelityfusion_amd.gp_basic import GP_basic
+    rng = np.random.default_rng(21)
+    n, D, d = 120, 3, 2
+    kern = kernel.SumKernel(_pair_part("lin", D), _pair_part("m25", D))
+    X0, Y = rng.standard_normal((n, D)), T(rng.standard_normal((n, d)))
+    A = rng.standard_normal((n, n)) * 0.05
+    yv0 = A @ A.T + 0.1 * np.eye(n)
+    res = []
+    for fuse in (True, False):
+        X = T(X0, grad=True)
+        yv = T(yv0, grad=True)
+        if model == "cigp":
+            m = cigp(kern, 0.3).to(DEV)
+            fn = lambda _m: _m.negative_log_likelihood(X, Y)
+        elif model == "pack":
+            m = kern.to(DEV)
+            lb = T(np.array([0.4]))
+            fn = lambda _m: gp_pack.negative_log_likelihood(_m, lb, X, Y)
+        else:
+            m = GP_basic(kern, 0.8).to(DEV)
+            fn = lambda _m: _m.log_likelihood(X, [Y, yv])
+        val, gr = _pair_eval(m, fn, fuse)
+        assert X.grad is not None and torch.isfinite(X.grad).all() and float(X.grad.abs().max()) > 0
+        gr["X"] = X.grad.clone()
+        if model == "gp_basic_yvar":
+            assert yv.grad is not None
+            gr["yvar"] = yv.grad.clone()
+        res.append((val, gr))
+    (v1, g1), (v2, g2) = res
+    assert rel(v1, v2) < 1e-12 and set(g1) == set(g2)
+    for k_ in g1:
+        assert rel(g1[k_], g2[k_]) < 1e-8, k_
+
+
 def test_pair_under_no_grad_and_bad_descriptor():
     """no_grad: no gradient pipeline; a descriptor outside the enum is refused by the library (FFGP_ERR_ARG), not run"""
     from fidelityfusion_amd import _lib, kernel

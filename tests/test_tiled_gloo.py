@@ -43,8 +43,9 @@ def _worker(rank, world, port, n, nb, use_hip, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from fidelityfusion_amd import tiled
+        from tiled_torch_ops import TorchOps
         X, Y, w, amp, dadd = _problem(n, 4, 3)
-        ops = tiled.HipOps(torch.device("cuda", 0)) if use_hip else tiled.TorchOps()
+        ops = tiled.HipOps(torch.device("cuda", 0)) if use_hip else TorchOps()
         t = lambda a: torch.tensor(np.asarray(a, dtype=np.float64))
         tc = tiled.TiledCholesky(n, nb=nb, ops=ops)
         tc.assemble(t(X), t(w), t([amp]), dadd, clamp=1e-30)
