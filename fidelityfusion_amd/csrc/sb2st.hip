@@ -345,99 +345,109 @@ int ffgp_q2_prep_impl(ffgp_handle* h, const double* V2, const double* tau2, int 
   return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
 }
 
-#define ZLD 48   // LDS leading dimension of the MN-major MFMA operands (row index = k): rows 16 doubles apart, conflict-free
-
 struct ApplyArgs {
   const double* blocks; int n, K;
   double* Z; int ldz; int ncols;
 };
 
-// operands of one block in the MFMA lane layout, straight from global memory (L2): V for X = V^T Zw (this wave's row tile ta of
-// X), W^T for Zw -= W X (this wave's 16 rows of the window)
-__device__ __forceinline__ void q2_load_ops(const double* __restrict__ blk, int ta, int wave, int lr, int lq, double (&va)[16],
-                                            double (&wa)[8]) {
-#pragma unroll
-  for (int kq = 0; kq < 16; ++kq) va[kq] = blk[(kq * 4 + lq) * 32 + ta * 16 + lr];
-#pragma unroll
-  for (int kq = 0; kq < 8; ++kq) wa[kq] = blk[2048 + (kq * 4 + lq) * 64 + wave * 16 + lr];
-}
-
-__global__ __launch_bounds__(256) void q2_apply(ApplyArgs p) {
-  __shared__ double Zs[64 * ZLD];
-  __shared__ double Xs[32 * ZLD];
+// One workgroup of 8 waves per slab of 32 columns of Z.  The 64-row window lives in LDS as two 32-row halves whose roles swap
+// from block to block (no copying when the window slides); per block X = V^T Zw (32 x 32, k = 64: each of the 8 waves one
+// 16 x 16 tile over half of k, the two halves summed when X is read) and Zw -= W X (64 x 32: one tile per wave), 16 MFMAs per
+// wave.  V and W^T come straight from global memory (L2) in the MFMA lane layout, one block ahead; the 32 new rows of the
+// window are requested before the block's arithmetic and land in LDS after it.
+#define XLD 32
+__global__ __launch_bounds__(512) void q2_apply(ApplyArgs p) {
+  __shared__ double Zs[2][32 * XLD];      // physical halves of the window
+  __shared__ double Xs[2][32 * XLD];      // the two k-halves of X
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = p.n;
   const int col0 = blockIdx.x * 32;
   double* __restrict__ Zg = p.Z + col0;
   const int lr = lane & 15, lq = lane >> 4;
-  // global <-> LDS map of the window: 256 threads, 8 per row (4 doubles each), 32 rows per pass
-  const int trow = tid >> 3, tc4 = (tid & 7) * 4;
-  const int ncv = min(32, p.ncols - col0);   // live columns of this slab
-  const int ta = wave >> 1, tnb = wave & 1;
+  const int trow = tid >> 4, tc2 = (tid & 15) * 2;   // window <-> global map: 512 threads, 32 rows x 16 column pairs
+  const int ncv = min(32, p.ncols - col0);
+  const bool cok0 = tc2 < ncv, cok1 = tc2 + 1 < ncv;
+  // X tile of this wave: rows 16 xa.., columns 16 xn.., k half xk;   Zw tile: logical rows 16 zr.. (half zr >> 1), columns 16 zn..
+  const int xa = wave & 1, xn = (wave >> 1) & 1, xk = wave >> 2;
+  const int zr = wave & 3, zn = wave >> 2;
+  auto load_ops = [&](const double* __restrict__ blk, double (&va)[8], double (&wa)[8]) {
+#pragma unroll
+    for (int kq = 0; kq < 8; ++kq) va[kq] = blk[(32 * xk + kq * 4 + lq) * 32 + xa * 16 + lr];
+#pragma unroll
+    for (int kq = 0; kq < 8; ++kq) wa[kq] = blk[2048 + (kq * 4 + lq) * 64 + zr * 16 + lr];
+  };
+  auto load_rows = [&](int grow) {   // two doubles of one row of the slab (zero beyond the matrix / the live columns)
+    d2_t v = {0.0, 0.0};
+    if (grow < n) {
+      const double* src = Zg + (size_t)grow * p.ldz + tc2;
+      if (cok1) v = *reinterpret_cast<const d2_t*>(src);
+      else if (cok0) v.x = src[0];
+    }
+    return v;
+  };
+  auto store_rows = [&](int grow, d2_t v) {
+    if (grow < n) {
+      double* dst = Zg + (size_t)grow * p.ldz + tc2;
+      if (cok1) *reinterpret_cast<d2_t*>(dst) = v;
+      else if (cok0) dst[0] = v.x;
+    }
+  };
   for (int G = n / 32 - 1; G >= 0; --G) {
     const int s0 = 32 * G;
     const int nk = q2_nsteps(n, s0);
-    double va[16], wa[8];
-    q2_load_ops(p.blocks + ((size_t)G * p.K) * 4096, ta, wave, lr, lq, va, wa);
+    double va[8], wa[8];
+    load_ops(p.blocks + ((size_t)G * p.K) * 4096, va, wa);
+    int cur = 0;   // physical half that holds the window's rows 0..31
+    {
+      const int rb = s0 + 1;
+      __syncthreads();   // the previous group's last reads of Zs are done, its last stores to Z visible to the whole workgroup
+      const d2_t a0 = load_rows(rb + trow), a1 = load_rows(rb + 32 + trow);
+      *reinterpret_cast<d2_t*>(&Zs[0][trow * XLD + tc2]) = a0;
+      *reinterpret_cast<d2_t*>(&Zs[1][trow * XLD + tc2]) = a1;
+    }
     for (int k = 0; k < nk; ++k) {
       const int rb = s0 + 1 + 32 * k;
-      double vn[16], wn[8];
-      if (k + 1 < nk) q2_load_ops(p.blocks + ((size_t)G * p.K + k + 1) * 4096, ta, wave, lr, lq, vn, wn);
-      // window rows rb .. rb + 63: at k = 0 all 64 are loaded, afterwards the lower half has slid up and 32 new rows come in
-      for (int pass = (k == 0 ? 0 : 1); pass < 2; ++pass) {
-        const int r = pass * 32 + trow;
-        const int gr = rb + r;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Zs[r * ZLD + tc4 + q] = (gr < n && tc4 + q < ncv) ? Zg[(size_t)gr * p.ldz + tc4 + q] : 0.0;
+      const bool last = (k == nk - 1);
+      double vn[8], wn[8];
+      d2_t znew = {0.0, 0.0};
+      if (!last) {
+        load_ops(p.blocks + ((size_t)G * p.K + k + 1) * 4096, vn, wn);
+        znew = load_rows(rb + 64 + trow);     // the rows that enter the window at the next step
       }
-      __syncthreads();
-      {   // X = V^T Zw : 32 x 32, wave -> tile (ta, tnb)
+      __syncthreads();   // window complete
+      {
+        const double* zh = Zs[xk ^ cur];
         d4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int kq = 0; kq < 16; ++kq)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kq], Zs[(kq * 4 + lq) * ZLD + tnb * 16 + lr], acc, 0, 0, 0);
+        for (int kq = 0; kq < 8; ++kq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kq], zh[(kq * 4 + lq) * XLD + xn * 16 + lr], acc, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Xs[(ta * 16 + 4 * r + lq) * ZLD + tnb * 16 + lr] = acc[r];
+        for (int r = 0; r < 4; ++r) Xs[xk][(xa * 16 + 4 * r + lq) * XLD + xn * 16 + lr] = acc[r];
       }
       __syncthreads();
-      {   // Zw -= W X : wave -> rows 16 wave .. 16 wave + 15, both column tiles
+      {
+        double* zh = Zs[(zr >> 1) ^ cur] + ((zr & 1) * 16) * XLD;
+        d4_t acc;
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-          d4_t acc;
+        for (int r = 0; r < 4; ++r) acc[r] = zh[(4 * r + lq) * XLD + zn * 16 + lr];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[r] = Zs[(wave * 16 + 4 * r + lq) * ZLD + tn * 16 + lr];
-#pragma unroll
-          for (int kq = 0; kq < 8; ++kq)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[kq], Xs[(kq * 4 + lq) * ZLD + tn * 16 + lr], acc, 0, 0, 1);   // -A
-#pragma unroll
-          for (int r = 0; r < 4; ++r) Zs[(wave * 16 + 4 * r + lq) * ZLD + tn * 16 + lr] = acc[r];
+        for (int kq = 0; kq < 8; ++kq) {
+          const int o = (kq * 4 + lq) * XLD + zn * 16 + lr;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[kq], Xs[0][o] + Xs[1][o], acc, 0, 0, 1);   // -A
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zh[(4 * r + lq) * XLD + zn * 16 + lr] = acc[r];
       }
       __syncthreads();
-      // rows 0..31 of the window are final for this group (the last step writes all 64)
-      const int npass = (k == nk - 1) ? 2 : 1;
-      for (int pass = 0; pass < npass; ++pass) {
-        const int r = pass * 32 + trow;
-        const int gr = rb + r;
-        if (gr < n) {
+      // rows 0..31 of the window are final for this group; their half receives the incoming rows (the last step writes both halves)
+      store_rows(rb + trow, *reinterpret_cast<const d2_t*>(&Zs[cur][trow * XLD + tc2]));
+      if (last) {
+        store_rows(rb + 32 + trow, *reinterpret_cast<const d2_t*>(&Zs[cur ^ 1][trow * XLD + tc2]));
+      } else {
+        *reinterpret_cast<d2_t*>(&Zs[cur][trow * XLD + tc2]) = znew;
+        cur ^= 1;
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (tc4 + q < ncv) Zg[(size_t)gr * p.ldz + tc4 + q] = Zs[r * ZLD + tc4 + q];
-        }
+        for (int q = 0; q < 8; ++q) va[q] = vn[q], wa[q] = wn[q];
       }
-      if (k != nk - 1) {   // slide: rows 32..63 -> 0..31
-        double keep[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) keep[q] = Zs[(32 + trow) * ZLD + tc4 + q];
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Zs[trow * ZLD + tc4 + q] = keep[q];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) va[q] = vn[q];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) wa[q] = wn[q];
-      }
-      __syncthreads();   // the next step's (or group's) window loads overwrite Zs
     }
   }
 }
@@ -446,6 +456,6 @@ __global__ __launch_bounds__(256) void q2_apply(ApplyArgs p) {
 int ffgp_q2_apply_impl(ffgp_handle* h, const double* blocks, int n, double* Z, int ldz, int ncols) {
   ApplyArgs a;
   a.blocks = blocks; a.n = n; a.K = chase_K(n); a.Z = Z; a.ldz = ldz; a.ncols = ncols;
-  hipLaunchKernelGGL(q2_apply, dim3((ncols + 31) / 32), dim3(256), 0, h->stream, a);
+  hipLaunchKernelGGL(q2_apply, dim3((ncols + 31) / 32), dim3(512), 0, h->stream, a);
   return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
 }

@@ -10,7 +10,7 @@
 //     dc_rank     sort d by counting (no assumption that the halves arrive sorted)
 //     dc_deflate  one lane per merge walks the sorted list: negligible z components and close pairs (one Givens rotation
 //                 each) are deflated exactly as LAPACK's dlaed2 does; the rotations are recorded
-//     dc_rotate   ... and applied to the columns of the old eigenvector block, one thread per row
+//     dc_rotate_s ... and folded into the rows of S (so the old eigenvector block stays block diagonal)
 //     dc_secular  one thread per root: the secular equation in the variable shifted to the nearer pole, two-pole rational
 //                 ("middle way") steps safeguarded by a bracket -- the root is returned as (origin, offset), so every
 //                 difference d_j - lambda_i is formed without cancellation
@@ -203,21 +203,23 @@ __global__ __launch_bounds__(64) void dc_deflate(DcLevel p) {
   }
 }
 
-// columns of the old eigenvector block take the deflation's rotations (in order): one thread per row
-__global__ __launch_bounds__(256) void dc_rotate(DcLevel p) {
+// The deflation's rotations act on columns of the old eigenvector block: Q_rot = Q_old R_1 R_2 ... R_r.  They are folded into S
+// instead (Q_new = Q_old (R_1 (R_2 ... (R_r S)))), last rotation first, on pairs of ROWS of S: one thread per column of S, coalesced,
+// and Q_old keeps its block-diagonal form, which halves the merge GEMMs.
+__global__ __launch_bounds__(256) void dc_rotate_s(DcLevel p) {
   int off, n1, n2;
   dc_shape(p, blockIdx.x, off, n1, n2);
   const int nn = n1 + n2;
-  const int r = blockIdx.y * 256 + threadIdx.x;
+  const int c = blockIdx.y * 256 + threadIdx.x;
   const int nr = p.nrot[blockIdx.x];
-  if (r >= nn || nr == 0) return;
-  double* row = p.Zc + (size_t)(off + r) * p.ldz + off;
-  for (int t = 0; t < nr; ++t) {
-    const int ca = p.perm[off + p.rotp[off + t]], cb = p.perm[off + p.rotj[off + t]];
-    const double c = p.rotc[off + t], s = p.rots[off + t];
-    const double a = row[ca], b = row[cb];
-    row[ca] = c * a + s * b;
-    row[cb] = -s * a + c * b;
+  if (c >= nn || nr == 0) return;
+  double* col = p.S + (size_t)off * p.lds + off + c;
+  for (int t = nr - 1; t >= 0; --t) {
+    const size_t ra = (size_t)p.perm[off + p.rotp[off + t]] * p.lds, rb = (size_t)p.perm[off + p.rotj[off + t]] * p.lds;
+    const double cs = p.rotc[off + t], sn = p.rots[off + t];
+    const double a = col[ra], b = col[rb];
+    col[ra] = cs * a - sn * b;
+    col[rb] = sn * a + cs * b;
   }
 }
 
@@ -232,81 +234,116 @@ __device__ __forceinline__ double dc_small_root(double a, double b, double c) { 
   return (fabs(r1) <= fabs(r2)) ? r1 : r2;
 }
 
+template <int CTRL>
+__device__ __forceinline__ double dc_dpp_add(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+  return x + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dc_sum8(double x) {   // sum over the 8 lanes of a root's group, in all of them
+  x = dc_dpp_add<0xB1>(x);
+  x = dc_dpp_add<0x4E>(x);
+  return dc_dpp_add<0x141>(x);
+}
+__device__ __forceinline__ double dc_rcp(double d) {
+  double y = __builtin_amdgcn_rcp(d);
+  y = __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
+  y = __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
+  return y;
+}
+
+// one root per group of 8 lanes: the poles are dealt round-robin to the lanes, the four sums of an iteration are combined inside
+// the group (DPP), every lane of the group runs the same scalar iteration
 __global__ __launch_bounds__(256) void dc_secular(DcLevel p) {
   int off, n1, n2;
   dc_shape(p, blockIdx.x, off, n1, n2);
   const int k = p.kcnt[blockIdx.x];
-  const int i = blockIdx.y * 256 + threadIdx.x;
-  if (i >= k) return;
+  const int i = blockIdx.y * 32 + (threadIdx.x >> 3);
+  const int part = threadIdx.x & 7;
+  if (blockIdx.y * 32 >= k) return;          // whole workgroup idle
+  const bool live = i < k;                   // idle groups of a live workgroup run along (DPP wants every lane) on root k - 1
+  const int ii = live ? i : k - 1;
   const double rho = p.rho[blockIdx.x];
   const double* __restrict__ dk = p.dk + off;
   const double* __restrict__ zk = p.zk + off;
   int o;
   double lo, hi;
   if (k == 1) {
-    p.org[off] = 0;
-    p.mu[off] = rho * zk[0] * zk[0];
-    p.lamn[off] = dk[0] + p.mu[off];
+    if (live && part == 0) {
+      p.org[off] = 0;
+      p.mu[off] = rho * zk[0] * zk[0];
+      p.lamn[off] = dk[0] + p.mu[off];
+    }
     return;
   }
-  if (i < k - 1) {
-    const double di = dk[i];
-    const double mid = 0.5 * (dk[i + 1] - di);
+  if (ii < k - 1) {
+    const double di = dk[ii];
+    const double mid = 0.5 * (dk[ii + 1] - di);
     double f = 0.0;
-    for (int j = 0; j < k; ++j) f += zk[j] * zk[j] / ((dk[j] - di) - mid);
-    f = 1.0 + rho * f;
+    for (int j = part; j < k; j += 8) f = __builtin_fma(zk[j] * zk[j], dc_rcp((dk[j] - di) - mid), f);
+    f = 1.0 + rho * dc_sum8(f);
     if (f >= 0.0) {
-      o = i; lo = 0.0; hi = mid;
+      o = ii; lo = 0.0; hi = mid;
     } else {
-      o = i + 1; lo = -mid; hi = 0.0;
+      o = ii + 1; lo = -mid; hi = 0.0;
     }
   } else {
-    double s = 0.0;
-    for (int j = 0; j < k; ++j) s += zk[j] * zk[j];
-    o = k - 1; lo = 0.0; hi = rho * s;
+    double sacc = 0.0;
+    for (int j = part; j < k; j += 8) sacc = __builtin_fma(zk[j], zk[j], sacc);
+    o = k - 1; lo = 0.0; hi = rho * dc_sum8(sacc);
   }
   const double dorg = dk[o];
   double mu = 0.5 * (lo + hi);
   const double sk = sqrt((double)k);
+  bool done = false;
   for (int it = 0; it < 100; ++it) {
     double psi = 0.0, phi = 0.0, dpsi = 0.0, dphi = 0.0;
-    for (int j = 0; j <= i; ++j) {
-      const double r = 1.0 / ((dk[j] - dorg) - mu);
+    for (int j = part; j < k; j += 8) {
+      const double r = dc_rcp((dk[j] - dorg) - mu);
       const double t = zk[j] * zk[j] * r;
-      psi += t;
-      dpsi = __builtin_fma(t, r, dpsi);
+      if (j <= ii) {
+        psi += t;
+        dpsi = __builtin_fma(t, r, dpsi);
+      } else {
+        phi += t;
+        dphi = __builtin_fma(t, r, dphi);
+      }
     }
-    for (int j = i + 1; j < k; ++j) {
-      const double r = 1.0 / ((dk[j] - dorg) - mu);
-      const double t = zk[j] * zk[j] * r;
-      phi += t;
-      dphi = __builtin_fma(t, r, dphi);
+    psi = dc_sum8(psi); phi = dc_sum8(phi); dpsi = dc_sum8(dpsi); dphi = dc_sum8(dphi);
+    if (!done) {
+      const double f = 1.0 + rho * (psi + phi);
+      const double err = 8.0 * DC_EPS * (1.0 + rho * (fabs(psi) + fabs(phi))) * sk;
+      if (fabs(f) <= err) {
+        done = true;
+      } else {
+        if (f > 0.0) hi = mu; else lo = mu;
+        double eta;
+        if (ii < k - 1) {
+          const double a1 = (dk[ii] - dorg) - mu, a2 = (dk[ii + 1] - dorg) - mu;   // a1 < 0 < a2
+          const double a = rho * dpsi * a1 * a1, b = rho * dphi * a2 * a2;
+          const double c = f - rho * dpsi * a1 - rho * dphi * a2;
+          eta = dc_small_root(c, -(c * (a1 + a2) + a + b), c * a1 * a2 + a * a2 + b * a1);
+        } else {
+          const double a1 = (dk[k - 1] - dorg) - mu;
+          const double a = rho * dpsi * a1 * a1;
+          const double c = f - rho * dpsi * a1;
+          eta = (c != 0.0) ? a1 + a / c : HUGE_VAL;
+        }
+        double nw = mu + eta;
+        if (!(nw > lo && nw < hi)) nw = 0.5 * (lo + hi);   // also catches NaN / inf
+        const bool stop = (nw == mu) || (hi - lo <= 2.0 * DC_EPS * fmax(fabs(lo), fabs(hi)));
+        mu = nw;
+        if (stop) done = true;
+      }
     }
-    const double f = 1.0 + rho * (psi + phi);
-    const double err = 8.0 * DC_EPS * (1.0 + rho * (fabs(psi) + fabs(phi))) * sk;
-    if (fabs(f) <= err) break;
-    if (f > 0.0) hi = mu; else lo = mu;
-    double eta;
-    if (i < k - 1) {
-      const double a1 = (dk[i] - dorg) - mu, a2 = (dk[i + 1] - dorg) - mu;   // a1 < 0 < a2
-      const double a = rho * dpsi * a1 * a1, b = rho * dphi * a2 * a2;
-      const double c = f - rho * dpsi * a1 - rho * dphi * a2;
-      eta = dc_small_root(c, -(c * (a1 + a2) + a + b), c * a1 * a2 + a * a2 + b * a1);
-    } else {
-      const double a1 = (dk[k - 1] - dorg) - mu;
-      const double a = rho * dpsi * a1 * a1;
-      const double c = f - rho * dpsi * a1;
-      eta = (c != 0.0) ? a1 + a / c : HUGE_VAL;
-    }
-    double nw = mu + eta;
-    if (!(nw > lo && nw < hi)) nw = 0.5 * (lo + hi);   // also catches NaN / inf
-    const bool stop = (nw == mu) || (hi - lo <= 2.0 * DC_EPS * fmax(fabs(lo), fabs(hi)));
-    mu = nw;
-    if (stop) break;
+    if (__all(done)) break;   // the wave leaves together (the DPP sums need all of its lanes)
   }
-  p.org[off + i] = o;
-  p.mu[off + i] = mu;
-  p.lamn[off + i] = dorg + mu;
+  if (live && part == 0) {
+    p.org[off + i] = o;
+    p.mu[off + i] = mu;
+    p.lamn[off + i] = dorg + mu;
+  }
 }
 
 // zhat_j = sign(z_j) sqrt(| prod_i (lam_i - d_j) / prod_{i != j} (d_i - d_j) | / rho)
@@ -473,23 +510,31 @@ int ffgp_stedc_impl(ffgp_handle* h, const double* d, const double* e, int n, dou
     hipLaunchKernelGGL(dc_setup, dim3(nm), dim3(256), 0, st, p);
     hipLaunchKernelGGL(dc_rank, dim3(nm, chunks), dim3(256), 0, st, p);
     hipLaunchKernelGGL(dc_deflate, dim3(nm), dim3(64), 0, st, p);
-    hipLaunchKernelGGL(dc_rotate, dim3(nm, chunks), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(dc_secular, dim3(nm, chunks), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(dc_secular, dim3(nm, (bs + 31) / 32), dim3(256), 0, st, p);
     hipLaunchKernelGGL(dc_zhat, dim3(nm, chunks), dim3(256), 0, st, p);
     hipLaunchKernelGGL(dc_norm, dim3(nm, chunks), dim3(256), 0, st, p);
     hipLaunchKernelGGL(dc_rank2, dim3(nm, chunks), dim3(256), 0, st, p);
     hipLaunchKernelGGL(dc_build_s, dim3(nm, chunks, min(bs, 256)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(dc_rotate_s, dim3(nm, chunks), dim3(256), 0, st, p);
     if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
-    // Q_new = Q_old S per merge (dense nn x nn blocks on the diagonal)
-    const int nfull = n / bs;
-    if (nfull > 0)
-      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Zcur, ldc, S, n, Zoth, ldo, bs, bs, bs, 1.0, 0.0, 0, ALIAS_NONE,
-                                  nfull, (long)bs * ldc + bs, (long)bs * n + bs, (long)bs * ldo + bs));
+    // Q_new = blockdiag(Q1, Q2) S per merge: the top n1 rows from Q1 and S's first n1 rows, the bottom n2 from Q2 and the rest
+    const int nfull = n / bs, hb = bs / 2;
+    if (nfull > 0) {
+      const long sa = (long)bs * ldc + bs, sb = (long)bs * n + bs, sc = (long)bs * ldo + bs;
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Zcur, ldc, S, n, Zoth, ldo, hb, bs, hb, 1.0, 0.0, 0, ALIAS_NONE, nfull,
+                                  sa, sb, sc));
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Zcur + (size_t)hb * ldc + hb, ldc, S + (size_t)hb * n, n,
+                                  Zoth + (size_t)hb * ldo, ldo, hb, bs, hb, 1.0, 0.0, 0, ALIAS_NONE, nfull, sa, sb, sc));
+    }
     const int rem = n - nfull * bs;
     if (rem > 0) {
       const size_t o = (size_t)nfull * bs;
+      const int r1 = min(hb, rem), r2 = rem - r1;
       FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Zcur + o * ldc + o, ldc, S + o * n + o, n, Zoth + o * ldo + o, ldo,
-                                  rem, rem, rem, 1.0, 0.0));
+                                  r1, rem, r1, 1.0, 0.0));
+      if (r2 > 0)
+        FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Zcur + (o + r1) * ldc + o + r1, ldc, S + (o + r1) * n + o, n,
+                                    Zoth + (o + r1) * ldo + o, ldo, r2, rem, r2, 1.0, 0.0));
     }
     double* tz = Zcur; Zcur = Zoth; Zoth = tz;
     int tl = ldc; ldc = ldo; ldo = tl;
