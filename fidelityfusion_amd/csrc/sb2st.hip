@@ -347,7 +347,7 @@ int ffgp_q2_prep_impl(ffgp_handle* h, const double* V2, const double* tau2, int 
 
 struct ApplyArgs {
   const double* blocks; int n, K;
-  double* Z; int ldz; int ncols;
+  double* Z; int ldz; int ncols; int dbg;
 };
 
 // One workgroup of 8 waves per slab of 32 columns of Z.  The 64-row window lives in LDS as two 32-row halves whose roles swap
@@ -355,7 +355,11 @@ struct ApplyArgs {
 // 16 x 16 tile over half of k, the two halves summed when X is read) and Zw -= W X (64 x 32: one tile per wave), 16 MFMAs per
 // wave.  V and W^T come straight from global memory (L2) in the MFMA lane layout, one block ahead; the 32 new rows of the
 // window are requested before the block's arithmetic and land in LDS after it.
-#define XLD 32
+#define XLD 48   // rows 16 doubles apart modulo the bank row: the four rows an MFMA operand read touches fall on disjoint banks
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global load of the wave
+// (loads and stores share one counter on this ISA), which would serialise the operand / window prefetches with the arithmetic
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __global__ __launch_bounds__(512) void q2_apply(ApplyArgs p) {
   __shared__ double Zs[2][32 * XLD];      // physical halves of the window
   __shared__ double Xs[2][32 * XLD];      // the two k-halves of X
@@ -411,39 +415,54 @@ __global__ __launch_bounds__(512) void q2_apply(ApplyArgs p) {
       double vn[8], wn[8];
       d2_t znew = {0.0, 0.0};
       if (!last) {
-        load_ops(p.blocks + ((size_t)G * p.K + k + 1) * 4096, vn, wn);
-        znew = load_rows(rb + 64 + trow);     // the rows that enter the window at the next step
+        if (!(p.dbg & 1)) load_ops(p.blocks + ((size_t)G * p.K + k + 1) * 4096, vn, wn);
+        else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) vn[q] = va[q], wn[q] = wa[q];
+        }
+        if (!(p.dbg & 2)) znew = load_rows(rb + 64 + trow);     // the rows that enter the window at the next step
       }
-      __syncthreads();   // window complete
+      lds_barrier();   // window complete
       {
         const double* zh = Zs[xk ^ cur];
+        double zb[8];
+#pragma unroll
+        for (int kq = 0; kq < 8; ++kq) zb[kq] = zh[(kq * 4 + lq) * XLD + xn * 16 + lr];   // all operand reads first, then the MFMA chain
         d4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int kq = 0; kq < 8; ++kq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kq], zh[(kq * 4 + lq) * XLD + xn * 16 + lr], acc, 0, 0, 0);
+        for (int kq = 0; kq < 8; ++kq) if (!(p.dbg & 4)) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kq], zb[kq], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) Xs[xk][(xa * 16 + 4 * r + lq) * XLD + xn * 16 + lr] = acc[r];
       }
-      __syncthreads();
+      lds_barrier();
       {
         double* zh = Zs[(zr >> 1) ^ cur] + ((zr & 1) * 16) * XLD;
         d4_t acc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = zh[(4 * r + lq) * XLD + zn * 16 + lr];
+        double xb[8];
 #pragma unroll
         for (int kq = 0; kq < 8; ++kq) {
           const int o = (kq * 4 + lq) * XLD + zn * 16 + lr;
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[kq], Xs[0][o] + Xs[1][o], acc, 0, 0, 1);   // -A
+          xb[kq] = Xs[0][o] + Xs[1][o];
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = zh[(4 * r + lq) * XLD + zn * 16 + lr];
+#pragma unroll
+        for (int kq = 0; kq < 8; ++kq) if (!(p.dbg & 4)) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[kq], xb[kq], acc, 0, 0, 1);   // -A
 #pragma unroll
         for (int r = 0; r < 4; ++r) zh[(4 * r + lq) * XLD + zn * 16 + lr] = acc[r];
       }
-      __syncthreads();
-      // rows 0..31 of the window are final for this group; their half receives the incoming rows (the last step writes both halves)
-      store_rows(rb + trow, *reinterpret_cast<const d2_t*>(&Zs[cur][trow * XLD + tc2]));
+      lds_barrier();
+      // rows 0..31 of the window are final for this group; their half receives the incoming rows (the last step writes both
+      // halves).  The LDS write of the incoming rows comes BEFORE the global stores: waiting for the incoming rows' load must
+      // not also wait for stores issued a moment ago (loads and stores share one counter).
+      const d2_t fin = *reinterpret_cast<const d2_t*>(&Zs[cur][trow * XLD + tc2]);
       if (last) {
-        store_rows(rb + 32 + trow, *reinterpret_cast<const d2_t*>(&Zs[cur ^ 1][trow * XLD + tc2]));
+        const d2_t fin2 = *reinterpret_cast<const d2_t*>(&Zs[cur ^ 1][trow * XLD + tc2]);
+        store_rows(rb + trow, fin);
+        store_rows(rb + 32 + trow, fin2);
       } else {
         *reinterpret_cast<d2_t*>(&Zs[cur][trow * XLD + tc2]) = znew;
+        if (!(p.dbg & 8)) store_rows(rb + trow, fin);
         cur ^= 1;
 #pragma unroll
         for (int q = 0; q < 8; ++q) va[q] = vn[q], wa[q] = wn[q];
@@ -455,7 +474,7 @@ __global__ __launch_bounds__(512) void q2_apply(ApplyArgs p) {
 // Z [n, ldz] (first ncols columns) <- Q2 Z
 int ffgp_q2_apply_impl(ffgp_handle* h, const double* blocks, int n, double* Z, int ldz, int ncols) {
   ApplyArgs a;
-  a.blocks = blocks; a.n = n; a.K = chase_K(n); a.Z = Z; a.ldz = ldz; a.ncols = ncols;
+  a.blocks = blocks; a.n = n; a.K = chase_K(n); a.Z = Z; a.ldz = ldz; a.ncols = ncols; a.dbg = h->diag_dbg;
   hipLaunchKernelGGL(q2_apply, dim3((ncols + 31) / 32), dim3(512), 0, h->stream, a);
   return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
 }

@@ -371,109 +371,109 @@ struct RedArgs {
   int m;
 };
 
-// Yp = sum of the k-chunks' partial products (fixed order), and this workgroup's 256 rows' share of G = Y^T Yp
-__global__ __launch_bounds__(256) void sy2sb_red(RedArgs p) {
-  __shared__ double Ys[64][33], Ps[64][33];
-  const int tid = threadIdx.x;
-  const int row = blockIdx.x * 256 + tid;
-  double yp[32], y[32];
-#pragma unroll
-  for (int k = 0; k < 32; ++k) yp[k] = 0.0, y[k] = 0.0;
+// Yp = sum of the k-chunks' partial products (fixed order), and this workgroup's 128 rows' share of G = Y^T Yp.
+// 1024 threads: 8 per row (4 columns each).
+__global__ __launch_bounds__(1024) void sy2sb_red(RedArgs p) {
+  __shared__ double Ys[128][33], Ps[128][33];
+  const int tid = threadIdx.x, lrow = tid >> 3, c4 = (tid & 7) * 4;
+  const int row = blockIdx.x * 128 + lrow;
+  double yp[4] = {0.0, 0.0, 0.0, 0.0}, y[4] = {0.0, 0.0, 0.0, 0.0};
   if (row < p.m) {
     for (int s = 0; s < p.parts; ++s) {
-      const double* src = p.P + (size_t)s * p.sP + (size_t)row * 32;
+      const d4_t v = *reinterpret_cast<const d4_t*>(p.P + (size_t)s * p.sP + (size_t)row * 32 + c4);
 #pragma unroll
-      for (int k = 0; k < 32; k += 2) {
-        const d2_t v = *reinterpret_cast<const d2_t*>(src + k);
-        yp[k] += v.x;
-        yp[k + 1] += v.y;
-      }
+      for (int q = 0; q < 4; ++q) yp[q] += v[q];
     }
+    d4_t o;
 #pragma unroll
-    for (int k = 0; k < 32; ++k) {
-      p.Yp[(size_t)row * 32 + k] = yp[k];
-      y[k] = p.Y[(size_t)row * p.ldy + k];
+    for (int q = 0; q < 4; ++q) {
+      o[q] = yp[q];
+      y[q] = p.Y[(size_t)row * p.ldy + c4 + q];
     }
-  }
-  const int a = tid >> 3, b0 = (tid & 7) * 4;
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int chunk = 0; chunk < 4; ++chunk) {
-    __syncthreads();
-    if ((tid >> 6) == chunk) {
-#pragma unroll
-      for (int k = 0; k < 32; ++k) {
-        Ys[tid & 63][k] = y[k];
-        Ps[tid & 63][k] = yp[k];
-      }
-    }
-    __syncthreads();
-    for (int r = 0; r < 64; ++r) {
-      const double av = Ys[r][a];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = __builtin_fma(av, Ps[r][b0 + q], acc[q]);
-    }
+    *reinterpret_cast<d4_t*>(p.Yp + (size_t)row * 32 + c4) = o;
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) p.Gpart[(size_t)blockIdx.x * 1024 + a * 32 + b0 + q] = acc[q];
+  for (int q = 0; q < 4; ++q) {
+    Ys[lrow][c4 + q] = y[q];
+    Ps[lrow][c4 + q] = yp[q];
+  }
+  __syncthreads();
+  {   // 1024 outputs, one per thread, k = 128 rows
+    const int a = tid >> 5, b = tid & 31;
+    double acc = 0.0;
+#pragma unroll 8
+    for (int r = 0; r < 128; ++r) acc = __builtin_fma(Ys[r][a], Ps[r][b], acc);
+    p.Gpart[(size_t)blockIdx.x * 1024 + tid] = acc;
+  }
+}
+
+struct MArgs {
+  const double* Tpan; const double* Gpart; int ngp;   // T [32][32]; Gpart [ngp][32][32], their sum = G = Y^T Yp
+  double* Mh;                                         // [32][32]  1/2 T^T G T
+};
+
+// one workgroup: G = sum of the pieces, Mh = 1/2 T^T (G T)
+__global__ __launch_bounds__(1024) void sy2sb_m(MArgs p) {
+  __shared__ M33 T, G, M1;
+  const int tid = threadIdx.x, i = tid >> 5, j = tid & 31;
+  double g = 0.0;
+  for (int q = 0; q < p.ngp; ++q) g += p.Gpart[(size_t)q * 1024 + tid];
+  G[i][j] = g;
+  T[i][j] = p.Tpan[tid];
+  __syncthreads();
+  double acc = 0.0;
+  for (int k = 0; k < 32; ++k) acc = __builtin_fma(G[i][k], T[k][j], acc);
+  M1[i][j] = acc;
+  __syncthreads();
+  acc = 0.0;
+  for (int k = 0; k < 32; ++k) acc = __builtin_fma(T[k][i], M1[k][j], acc);
+  p.Mh[tid] = 0.5 * acc;
 }
 
 struct WArgs {
   const double* Yp;   // [m][32]  A22 Y
   const double* Y; int ldy;
-  const double* Tpan; const double* Gpart; int ngp;   // T [32][32]; Gpart [ngp][32][32], their sum = Y^T Yp
+  const double* Tpan; const double* Mh;    // [32][32] each
   double* VW; double* WV;                  // [m][64] each
   int m;
 };
 
-// W = Yp T - 1/2 Y (T^T (Y^T Yp) T); the two rank-64 operands [Y W], [W Y] of the trailing update
+// W = Yp T - Y Mh; the two rank-64 operands [Y W], [W Y] of the trailing update.  256 threads: 8 per row (4 columns each).
 __global__ __launch_bounds__(256) void sy2sb_w(WArgs p) {
-  __shared__ M33 T, Gm, M1, Mh;
-  const int tid = threadIdx.x;
+  __shared__ M33 T, Mh;
+  __shared__ double Ys[32][33], Ps[32][33];
+  const int tid = threadIdx.x, lrow = tid >> 3, c4 = (tid & 7) * 4;
   for (int idx = tid; idx < 1024; idx += 256) {
     T[idx >> 5][idx & 31] = p.Tpan[idx];
-    double g = 0.0;
-    for (int q = 0; q < p.ngp; ++q) g += p.Gpart[(size_t)q * 1024 + idx];
-    Gm[idx >> 5][idx & 31] = g;
+    Mh[idx >> 5][idx & 31] = p.Mh[idx];
+  }
+  const int row = blockIdx.x * 32 + lrow;
+  const bool ok = row < p.m;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    Ys[lrow][c4 + q] = ok ? p.Y[(size_t)row * p.ldy + c4 + q] : 0.0;
+    Ps[lrow][c4 + q] = ok ? p.Yp[(size_t)row * 32 + c4 + q] : 0.0;
   }
   __syncthreads();
-  mm32<false>(M1, Gm, T, 1.0, tid);        // G T
-  __syncthreads();
-  {   // Mh = 1/2 T^T (G T)
-    const int i = tid >> 3, j0 = (tid & 7) * 4;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int k = 0; k < 32; ++k) {
-      const double av = T[k][i];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = __builtin_fma(av, M1[k][j0 + q], acc[q]);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) Mh[i][j0 + q] = 0.5 * acc[q];
-  }
-  __syncthreads();
-  const int row = blockIdx.x * 256 + tid;
-  if (row >= p.m) return;
-  double yp[32], y[32];
-#pragma unroll
+  if (!ok) return;
+  double w[4] = {0.0, 0.0, 0.0, 0.0};
   for (int k = 0; k < 32; ++k) {
-    yp[k] = p.Yp[(size_t)row * 32 + k];
-    y[k] = p.Y[(size_t)row * p.ldy + k];
+    const double a = Ps[lrow][k], b = Ys[lrow][k];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = __builtin_fma(a, T[k][c4 + q], __builtin_fma(-b, Mh[k][c4 + q], w[q]));
+  }
+  d4_t wv, yv;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    wv[q] = w[q];
+    yv[q] = Ys[lrow][c4 + q];
   }
   double* vw = p.VW + (size_t)row * 64;
-  double* wv = p.WV + (size_t)row * 64;
-  for (int j = 0; j < 32; ++j) {
-    double s = 0.0;
-#pragma unroll
-    for (int k = 0; k < 32; ++k) s = __builtin_fma(yp[k], T[k][j], s);
-#pragma unroll
-    for (int k = 0; k < 32; ++k) s = __builtin_fma(-y[k], Mh[k][j], s);
-    vw[32 + j] = s;
-    wv[j] = s;
-  }
-#pragma unroll
-  for (int k = 0; k < 32; ++k) {
-    vw[k] = y[k];
-    wv[32 + k] = y[k];
-  }
+  double* wvp = p.WV + (size_t)row * 64;
+  *reinterpret_cast<d4_t*>(vw + c4) = yv;
+  *reinterpret_cast<d4_t*>(vw + 32 + c4) = wv;
+  *reinterpret_cast<d4_t*>(wvp + c4) = wv;
+  *reinterpret_cast<d4_t*>(wvp + 32 + c4) = yv;
 }
 
 // diagonal 32 x 32 blocks of the reduced matrix -> band storage (lower part)
@@ -487,8 +487,8 @@ __global__ void sy2sb_copy_diag(const double* __restrict__ A, int lda, double* _
 
 #define AV_MAX_PARTS 16
 size_t ffgp_sy2sb_ws_doubles(int n) {
-  // Rst, Tst (16 leaves), Vtst, small, Yp, Gpart, VW, WV, partial products of the k-chunks
-  return (size_t)16 * 1024 * 2 + 512 * 32 + 4096 + (size_t)n * 32 + (size_t)(n / 256 + 1) * 1024 + (size_t)n * 64 * 2 +
+  // Rst, Tst (16 leaves), Vtst, small (+ Mh), Yp, Gpart, VW, WV, partial products of the k-chunks
+  return (size_t)16 * 1024 * 2 + 512 * 32 + 4096 + (size_t)n * 32 + (size_t)(n / 128 + 1) * 1024 + (size_t)n * 64 * 2 +
          (size_t)(AV_MAX_PARTS + 1) * n * 32 + 64;
 }
 
@@ -503,7 +503,8 @@ int ffgp_sy2sb_impl(ffgp_handle* h, double* A, int n, int lda, double* AB, doubl
   double* small = Vtst + 512 * 32;
   double* Yp = small + 4096;
   double* Gpart = Yp + (size_t)n * 32;
-  double* VW = Gpart + (size_t)(n / 256 + 1) * 1024;
+  double* VW = Gpart + (size_t)(n / 128 + 1) * 1024;
+  double* Mh = small + 3072;   // (small holds Xt | S | U^-1 in its first 2080 doubles)
   double* WV = VW + (size_t)n * 64;
   double* Ppart = WV + (size_t)n * 64;
   FFGP_HIP(hipMemsetAsync(AB, 0, (size_t)n * SB_LDB * sizeof(double), st));
@@ -543,11 +544,14 @@ int ffgp_sy2sb_impl(ffgp_handle* h, double* A, int n, int lda, double* AB, doubl
                                   Ppart + (size_t)parts * sP, 32, m, 32, tail, 1.0, 0.0));
     RedArgs ra;
     ra.P = Ppart; ra.sP = sP; ra.parts = parts + (tail > 0 ? 1 : 0); ra.Y = Ypan; ra.ldy = ldy; ra.Yp = Yp; ra.Gpart = Gpart; ra.m = m;
-    const int nred = (m + 255) / 256;
-    hipLaunchKernelGGL(sy2sb_red, dim3(nred), dim3(256), 0, st, ra);
+    const int nred = (m + 127) / 128;
+    hipLaunchKernelGGL(sy2sb_red, dim3(nred), dim3(1024), 0, st, ra);
+    MArgs ma;
+    ma.Tpan = ta.Tpan; ma.Gpart = Gpart; ma.ngp = nred; ma.Mh = Mh;
+    hipLaunchKernelGGL(sy2sb_m, dim3(1), dim3(1024), 0, st, ma);
     WArgs wa;
-    wa.Yp = Yp; wa.Y = Ypan; wa.ldy = ldy; wa.Tpan = ta.Tpan; wa.Gpart = Gpart; wa.ngp = nred; wa.VW = VW; wa.WV = WV; wa.m = m;
-    hipLaunchKernelGGL(sy2sb_w, dim3((m + 255) / 256), dim3(256), 0, st, wa);
+    wa.Yp = Yp; wa.Y = Ypan; wa.ldy = ldy; wa.Tpan = ta.Tpan; wa.Mh = Mh; wa.VW = VW; wa.WV = WV; wa.m = m;
+    hipLaunchKernelGGL(sy2sb_w, dim3((m + 31) / 32), dim3(256), 0, st, wa);
     if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
     // A22 -= [Y W] [W Y]^T
     FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, VW, 64, WV, 64, A22, lda, m, m, 64, -1.0, 1.0));
