@@ -170,6 +170,8 @@ int ffgp_destroy(ffgp_handle* h) {
   if (h->tsw) hipFree(h->tsw);
   if (h->skw) hipFree(h->skw);
   if (h->ews) hipFree(h->ews);
+  for (int i = 0; i < 12; ++i)
+    if (h->eig_ev[i]) hipEventDestroy(h->eig_ev[i]);
   if (h->d_info) hipFree(h->d_info);
   if (h->d_scal) hipFree(h->d_scal);
   if (h->h_info) hipHostFree(h->h_info);
@@ -243,6 +245,8 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     if (v != 0 && (v < 2 * FFGP_NB || (v & (v - 1)))) return FFGP_ERR_ARG;   // 0, or a power of two >= 256
     h->super_block = v;
     h->sinv_L = nullptr;
+  } else if (!strcmp(key, "eig_overlap")) {
+    h->eig_overlap = (int)value;
   } else if (!strcmp(key, "chase_pack")) {
     h->chase_pack = (int)value;
   } else if (!strcmp(key, "skinny_max_n")) {

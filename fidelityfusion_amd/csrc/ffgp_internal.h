@@ -158,6 +158,8 @@ struct ffgp_handle {
   size_t skw_bytes;
   double* ews;       // workspace of the symmetric eigensolver (syevd.hip)
   size_t ews_bytes;
+  hipEvent_t eig_ev[12];   // hand-offs between the chase (side stream) and the back-transformation (main stream) of ffgp_syevd
+  int eig_overlap;   // ffgp_syevd: 1 = chase on the side stream with the Q2^T accumulation behind it (see syevd.hip), 0 = stage after stage
   int chase_pack;    // bulge chasing: every chase_pack-th workgroup works (8 = all on one XCD; 1 = spread over the chip)
   int splitk_min_k;  // thin products (<= 64 tiles of 64 x 64) with k >= this are cut along k (0 = never)
   int skinny_max_n;  // products with at most this many output columns (<= 8) take the matrix-vector kernels (0 = never)

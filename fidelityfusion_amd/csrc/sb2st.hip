@@ -104,6 +104,7 @@ struct ChaseArgs {
   int* prog;                         // [n] steps completed per sweep (CH_DONE when the sweep has ended)
   int* err;
   int pack;                          // only workgroups with blockIdx % pack == 0 work (pack = 8: all of them on one XCD, one L2)
+  int s_begin, s_end;                // sweeps of this launch (the chase may be cut into several launches: prog carries over)
 };
 
 __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
   double* AB = p.AB;
   double* vs = vsA;
   double* v2s = vsB;
-  for (int s = wg; s < n - 2; s += nwg) {
+  for (int s = p.s_begin + wg; s < p.s_end; s += nwg) {
     int c0 = s + 1;
     int len = min(32, n - c0);
     int seen = (s > 0) ? 0 : CH_DONE;    // progress of sweep s - 1 as last observed
@@ -245,24 +246,43 @@ __global__ void sb2st_tail(const double* __restrict__ AB, int n, double* d, doub
 
 static inline int chase_K(int n) { return n / 32 + 1; }
 
-// AB [n, 64] band in (destroyed), d [n], e [n] out, V2 [n * K * 32], tau2 [n * K], prog [n + 1] ints (last: status word)
-int ffgp_sb2st_impl(ffgp_handle* h, double* AB, int n, double* d, double* e, double* V2, double* tau2, int* prog) {
+// AB [n, 64] band in (destroyed), d [n], e [n] out, V2 [n * K * 32], tau2 [n * K], prog [n + 1] ints (last: status word).
+// init clears the stores; chunk runs the sweeps [s_begin, s_end) (sweeps of later launches find their predecessors' counters at
+// CH_DONE); finish writes the last two diagonal entries.  All on stream st.
+int ffgp_sb2st_init(ffgp_handle* h, hipStream_t st, int n, double* V2, double* tau2, int* prog) {
   if (n < 64 || n % 32) return FFGP_ERR_ARG;
-  hipStream_t st = h->stream;
   const int K = chase_K(n);
   FFGP_HIP(hipMemsetAsync(prog, 0, (size_t)(n + 1) * sizeof(int), st));
   FFGP_HIP(hipMemsetAsync(V2, 0, (size_t)n * K * 32 * sizeof(double), st));
   FFGP_HIP(hipMemsetAsync(tau2, 0, (size_t)n * K * sizeof(double), st));
+  return FFGP_OK;
+}
+
+int ffgp_sb2st_chunk(ffgp_handle* h, hipStream_t st, double* AB, int n, double* d, double* e, double* V2, double* tau2, int* prog, int s_begin,
+                     int s_end) {
+  s_end = min(s_end, n - 2);
+  if (s_begin >= s_end) return FFGP_OK;
   ChaseArgs a;
-  a.AB = AB; a.n = n; a.d = d; a.e = e; a.V2 = V2; a.tau2 = tau2; a.K = K; a.prog = prog; a.err = prog + n;
+  a.AB = AB; a.n = n; a.d = d; a.e = e; a.V2 = V2; a.tau2 = tau2; a.K = chase_K(n); a.prog = prog; a.err = prog + n;
+  a.s_begin = s_begin; a.s_end = s_end;
   // all working wavefronts on ONE XCD (workgroups are dealt round-robin to the 8 XCDs, so every 8th one works): neighbouring
   // sweeps then hand their blocks over through one L2 instead of through the memory side.  Purely a placement: every band access
   // is a device-scope access wherever the wave runs.
   a.pack = h->chase_pack > 0 ? h->chase_pack : 8;
-  const int grid = min(n - 2, 256) * a.pack;
+  const int grid = min(s_end - s_begin, 256) * a.pack;
   hipLaunchKernelGGL(sb2st_chase, dim3(grid), dim3(64), 0, st, a);
+  return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
+}
+
+int ffgp_sb2st_finish(ffgp_handle* h, hipStream_t st, const double* AB, int n, double* d, double* e) {
   hipLaunchKernelGGL(sb2st_tail, dim3(1), dim3(64), 0, st, AB, n, d, e);
   return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
+}
+
+int ffgp_sb2st_impl(ffgp_handle* h, double* AB, int n, double* d, double* e, double* V2, double* tau2, int* prog) {
+  FFGP_CHECK(ffgp_sb2st_init(h, h->stream, n, V2, tau2, prog));
+  FFGP_CHECK(ffgp_sb2st_chunk(h, h->stream, AB, n, d, e, V2, tau2, prog, 0, n - 2));
+  return ffgp_sb2st_finish(h, h->stream, AB, n, d, e);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -275,6 +295,8 @@ size_t ffgp_q2_block_doubles(int n) { return (size_t)(n / 32) * chase_K(n) * 409
 struct PrepArgs {
   const double* V2; const double* tau2; int n, K;
   double* blocks;
+  int G0;      // first sweep group of this launch (blockIdx.y counts from it)
+  int trans;   // 1: W = V T^T (the block of Q2^T), 0: W = V T
 };
 
 __global__ __launch_bounds__(256) void q2_prep(PrepArgs p) {
@@ -283,7 +305,7 @@ __global__ __launch_bounds__(256) void q2_prep(PrepArgs p) {
   __shared__ double Tm[32][33];
   __shared__ double dinv[32];
   const int tid = threadIdx.x;
-  const int G = blockIdx.y, k = blockIdx.x;
+  const int G = p.G0 + blockIdx.y, k = blockIdx.x;
   const int n = p.n;
   const int s0 = 32 * G;
   if (s0 > n - 3 || k >= (n - 2 - s0) / 32 + 1) return;
@@ -333,47 +355,65 @@ __global__ __launch_bounds__(256) void q2_prep(PrepArgs p) {
     const int r = idx >> 5, j = idx & 31;
     out[idx] = Vs[r][j];
     double s = 0.0;
-    for (int cc = 0; cc <= j; ++cc) s = __builtin_fma(Vs[r][cc], Tm[cc][j], s);
+    if (p.trans) {
+      for (int cc = j; cc < 32; ++cc) s = __builtin_fma(Vs[r][cc], Tm[j][cc], s);
+    } else {
+      for (int cc = 0; cc <= j; ++cc) s = __builtin_fma(Vs[r][cc], Tm[cc][j], s);
+    }
     out[2048 + j * 64 + r] = s;     // W = V T, stored transposed ([32][64]): the apply kernel's lanes read 16 consecutive rows
   }
 }
 
-int ffgp_q2_prep_impl(ffgp_handle* h, const double* V2, const double* tau2, int n, double* blocks) {
+int ffgp_q2_prep_impl(ffgp_handle* h, const double* V2, const double* tau2, int n, double* blocks, int G0, int G1, int trans) {
+  if (G1 <= G0) return FFGP_OK;
   PrepArgs a;
-  a.V2 = V2; a.tau2 = tau2; a.n = n; a.K = chase_K(n); a.blocks = blocks;
-  hipLaunchKernelGGL(q2_prep, dim3(a.K, n / 32), dim3(256), 0, h->stream, a);
+  a.V2 = V2; a.tau2 = tau2; a.n = n; a.K = chase_K(n); a.blocks = blocks; a.G0 = G0; a.trans = trans;
+  hipLaunchKernelGGL(q2_prep, dim3(a.K, G1 - G0), dim3(256), 0, h->stream, a);
   return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
 }
 
 struct ApplyArgs {
   const double* blocks; int n, K;
   double* Z; int ldz; int ncols; int dbg;
+  int G0, G1;   // sweep groups of this launch
+  int skip8;    // 1: workgroups with blockIdx % 8 == 0 (the XCD the chase runs on) leave at once, the others share the slabs
 };
 
-// One workgroup of 8 waves per slab of 32 columns of Z.  The 64-row window lives in LDS as two 32-row halves whose roles swap
-// from block to block (no copying when the window slides); per block X = V^T Zw (32 x 32, k = 64: each of the 8 waves one
-// 16 x 16 tile over half of k, the two halves summed when X is read) and Zw -= W X (64 x 32: one tile per wave), 16 MFMAs per
-// wave.  V and W^T come straight from global memory (L2) in the MFMA lane layout, one block ahead; the 32 new rows of the
-// window are requested before the block's arithmetic and land in LDS after it.
-#define XLD 48   // rows 16 doubles apart modulo the bank row: the four rows an MFMA operand read touches fall on disjoint banks
+// One workgroup of 4 waves per slab of 16 columns of Z; several workgroups share a CU (16 KB of LDS, <= 128 VGPRs), so one
+// slab's barriers and memory latencies are filled with another slab's arithmetic.  The 64-row window lives in LDS as two 32-row
+// halves whose roles swap from block to block (no copying when the window slides); per block X = V^T Zw (32 x 16, k = 64: wave
+// (xa, xk) one 16 x 16 tile over half of k, the two halves summed when X is read) and Zw -= W X (64 x 16: one tile per wave),
+// 16 MFMAs per wave.  V and W^T come straight from global memory (L2) in the MFMA lane layout, one block ahead -- every wave
+// loads a different quarter of them; the 32 new rows of the window are requested before the block's arithmetic and land in LDS
+// after it.
+#define XLD 16   // 4 consecutive rows of 16 doubles: the 64 lanes of an operand read cover 64 consecutive doubles, no conflicts
 // workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global load of the wave
 // (loads and stores share one counter on this ISA), which would serialise the operand / window prefetches with the arithmetic
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__global__ __launch_bounds__(512) void q2_apply(ApplyArgs p) {
+// FWD = false: Z <- Q2 Z (groups descending, steps ascending, window slides down);  FWD = true: Z <- Q2^T Z with blocks prepared as
+// V, (V T^T)^T (groups ascending -- the order the chase produces them --, steps descending, window slides up)
+template <bool FWD>
+__global__ __launch_bounds__(256, 4) void q2_apply(ApplyArgs p) {
   __shared__ double Zs[2][32 * XLD];      // physical halves of the window
   __shared__ double Xs[2][32 * XLD];      // the two k-halves of X
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = p.n;
-  const int col0 = blockIdx.x * 32;
+  int slab = blockIdx.x;
+  if (p.skip8) {
+    if ((blockIdx.x & 7) == 0) return;
+    slab = blockIdx.x - (blockIdx.x >> 3) - 1;
+  }
+  const int col0 = slab * 16;
+  if (col0 >= p.ncols) return;
   double* __restrict__ Zg = p.Z + col0;
   const int lr = lane & 15, lq = lane >> 4;
-  const int trow = tid >> 4, tc2 = (tid & 15) * 2;   // window <-> global map: 512 threads, 32 rows x 16 column pairs
-  const int ncv = min(32, p.ncols - col0);
+  const int trow = tid >> 3, tc2 = (tid & 7) * 2;   // window <-> global map: 256 threads, 32 rows x 8 column pairs
+  const int ncv = min(16, p.ncols - col0);
   const bool cok0 = tc2 < ncv, cok1 = tc2 + 1 < ncv;
-  // X tile of this wave: rows 16 xa.., columns 16 xn.., k half xk;   Zw tile: logical rows 16 zr.. (half zr >> 1), columns 16 zn..
-  const int xa = wave & 1, xn = (wave >> 1) & 1, xk = wave >> 2;
-  const int zr = wave & 3, zn = wave >> 2;
+  // X tile of this wave: rows 16 xa.., k half xk;   Zw tile: logical rows 16 zr.. (half zr >> 1)
+  const int xa = wave & 1, xk = wave >> 1;
+  const int zr = wave;
   auto load_ops = [&](const double* __restrict__ blk, double (&va)[8], double (&wa)[8]) {
 #pragma unroll
     for (int kq = 0; kq < 8; ++kq) va[kq] = blk[(32 * xk + kq * 4 + lq) * 32 + xa * 16 + lr];
@@ -396,43 +436,44 @@ __global__ __launch_bounds__(512) void q2_apply(ApplyArgs p) {
       else if (cok0) dst[0] = v.x;
     }
   };
-  for (int G = n / 32 - 1; G >= 0; --G) {
+  for (int gi = 0; gi < p.G1 - p.G0; ++gi) {
+    const int G = FWD ? p.G0 + gi : p.G1 - 1 - gi;
     const int s0 = 32 * G;
     const int nk = q2_nsteps(n, s0);
+    if (nk == 0) continue;
+    const int kfirst = FWD ? nk - 1 : 0, kstep = FWD ? -1 : 1;
     double va[8], wa[8];
-    load_ops(p.blocks + ((size_t)G * p.K) * 4096, va, wa);
+    load_ops(p.blocks + ((size_t)G * p.K + kfirst) * 4096, va, wa);
     int cur = 0;   // physical half that holds the window's rows 0..31
     {
-      const int rb = s0 + 1;
+      const int rb = s0 + 1 + 32 * kfirst;
       __syncthreads();   // the previous group's last reads of Zs are done, its last stores to Z visible to the whole workgroup
       const d2_t a0 = load_rows(rb + trow), a1 = load_rows(rb + 32 + trow);
       *reinterpret_cast<d2_t*>(&Zs[0][trow * XLD + tc2]) = a0;
       *reinterpret_cast<d2_t*>(&Zs[1][trow * XLD + tc2]) = a1;
     }
-    for (int k = 0; k < nk; ++k) {
+    for (int ki = 0; ki < nk; ++ki) {
+      const int k = kfirst + kstep * ki;
       const int rb = s0 + 1 + 32 * k;
-      const bool last = (k == nk - 1);
+      const bool last = (ki == nk - 1);
       double vn[8], wn[8];
       d2_t znew = {0.0, 0.0};
       if (!last) {
-        if (!(p.dbg & 1)) load_ops(p.blocks + ((size_t)G * p.K + k + 1) * 4096, vn, wn);
-        else {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) vn[q] = va[q], wn[q] = wa[q];
-        }
-        if (!(p.dbg & 2)) znew = load_rows(rb + 64 + trow);     // the rows that enter the window at the next step
+        load_ops(p.blocks + ((size_t)G * p.K + k + kstep) * 4096, vn, wn);
+        // the rows that enter the window at the next step: below it when it slides down, above it when it slides up
+        znew = load_rows(FWD ? rb - 32 + trow : rb + 64 + trow);
       }
       lds_barrier();   // window complete
       {
         const double* zh = Zs[xk ^ cur];
         double zb[8];
 #pragma unroll
-        for (int kq = 0; kq < 8; ++kq) zb[kq] = zh[(kq * 4 + lq) * XLD + xn * 16 + lr];   // all operand reads first, then the MFMA chain
+        for (int kq = 0; kq < 8; ++kq) zb[kq] = zh[(kq * 4 + lq) * XLD + lr];   // all operand reads first, then the MFMA chain
         d4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int kq = 0; kq < 8; ++kq) if (!(p.dbg & 4)) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kq], zb[kq], acc, 0, 0, 0);
+        for (int kq = 0; kq < 8; ++kq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kq], zb[kq], acc, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Xs[xk][(xa * 16 + 4 * r + lq) * XLD + xn * 16 + lr] = acc[r];
+        for (int r = 0; r < 4; ++r) Xs[xk][(xa * 16 + 4 * r + lq) * XLD + lr] = acc[r];
       }
       lds_barrier();
       {
@@ -441,28 +482,31 @@ __global__ __launch_bounds__(512) void q2_apply(ApplyArgs p) {
         double xb[8];
 #pragma unroll
         for (int kq = 0; kq < 8; ++kq) {
-          const int o = (kq * 4 + lq) * XLD + zn * 16 + lr;
+          const int o = (kq * 4 + lq) * XLD + lr;
           xb[kq] = Xs[0][o] + Xs[1][o];
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = zh[(4 * r + lq) * XLD + zn * 16 + lr];
+        for (int r = 0; r < 4; ++r) acc[r] = zh[(4 * r + lq) * XLD + lr];
 #pragma unroll
-        for (int kq = 0; kq < 8; ++kq) if (!(p.dbg & 4)) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[kq], xb[kq], acc, 0, 0, 1);   // -A
+        for (int kq = 0; kq < 8; ++kq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[kq], xb[kq], acc, 0, 0, 1);   // -A
 #pragma unroll
-        for (int r = 0; r < 4; ++r) zh[(4 * r + lq) * XLD + zn * 16 + lr] = acc[r];
+        for (int r = 0; r < 4; ++r) zh[(4 * r + lq) * XLD + lr] = acc[r];
       }
       lds_barrier();
-      // rows 0..31 of the window are final for this group; their half receives the incoming rows (the last step writes both
-      // halves).  The LDS write of the incoming rows comes BEFORE the global stores: waiting for the incoming rows' load must
-      // not also wait for stores issued a moment ago (loads and stores share one counter).
-      const d2_t fin = *reinterpret_cast<const d2_t*>(&Zs[cur][trow * XLD + tc2]);
+      // the half the window leaves behind (its first 32 rows when it slides down, its last 32 when it slides up) is final for
+      // this group; that half receives the incoming rows (the last step writes both halves).  The LDS write of the incoming rows
+      // comes BEFORE the global stores: waiting for the incoming rows' load must not also wait for stores issued a moment ago
+      // (loads and stores share one counter).
+      const int hout = FWD ? (cur ^ 1) : cur;          // physical half that leaves
+      const int rout = FWD ? rb + 32 : rb;
+      const d2_t fin = *reinterpret_cast<const d2_t*>(&Zs[hout][trow * XLD + tc2]);
       if (last) {
-        const d2_t fin2 = *reinterpret_cast<const d2_t*>(&Zs[cur ^ 1][trow * XLD + tc2]);
-        store_rows(rb + trow, fin);
-        store_rows(rb + 32 + trow, fin2);
+        const d2_t fin2 = *reinterpret_cast<const d2_t*>(&Zs[hout ^ 1][trow * XLD + tc2]);
+        store_rows(rout + trow, fin);
+        store_rows((FWD ? rb : rb + 32) + trow, fin2);
       } else {
-        *reinterpret_cast<d2_t*>(&Zs[cur][trow * XLD + tc2]) = znew;
-        if (!(p.dbg & 8)) store_rows(rb + trow, fin);
+        *reinterpret_cast<d2_t*>(&Zs[hout][trow * XLD + tc2]) = znew;
+        store_rows(rout + trow, fin);
         cur ^= 1;
 #pragma unroll
         for (int q = 0; q < 8; ++q) va[q] = vn[q], wa[q] = wn[q];
@@ -471,10 +515,16 @@ __global__ __launch_bounds__(512) void q2_apply(ApplyArgs p) {
   }
 }
 
-// Z [n, ldz] (first ncols columns) <- Q2 Z
-int ffgp_q2_apply_impl(ffgp_handle* h, const double* blocks, int n, double* Z, int ldz, int ncols) {
+// Z [n, ldz] (first ncols columns) <- Q2 Z (fwd = 0; blocks prepared with trans = 0) or Q2^T Z (fwd = 1; trans = 1), the sweep
+// groups [G0, G1) only.  skip8: leave the XCD the chase runs on alone.
+int ffgp_q2_apply_impl(ffgp_handle* h, const double* blocks, int n, double* Z, int ldz, int ncols, int G0, int G1, int fwd, int skip8) {
+  if (G1 <= G0) return FFGP_OK;
   ApplyArgs a;
   a.blocks = blocks; a.n = n; a.K = chase_K(n); a.Z = Z; a.ldz = ldz; a.ncols = ncols; a.dbg = h->diag_dbg;
-  hipLaunchKernelGGL(q2_apply, dim3((ncols + 31) / 32), dim3(512), 0, h->stream, a);
+  a.G0 = G0; a.G1 = G1; a.skip8 = skip8;
+  const int nslab = (ncols + 15) / 16;
+  const int grid = skip8 ? nslab + (nslab + 6) / 7 + 1 : nslab;
+  if (fwd) hipLaunchKernelGGL(q2_apply<true>, dim3(grid), dim3(256), 0, h->stream, a);
+  else hipLaunchKernelGGL(q2_apply<false>, dim3(grid), dim3(256), 0, h->stream, a);
   return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
 }

@@ -76,7 +76,9 @@ static int q1_tbuild(ffgp_handle* h, const double* G, int w, double* T, double* 
 #define Q1_AGG 8
 size_t ffgp_q1_ws_doubles(int n, int ncols) { return (size_t)3 * 256 * 256 + (size_t)2 * 256 * ncols + 64; }
 
-int ffgp_q1_apply_impl(ffgp_handle* h, const double* Y, int ldy, int n, double* Z, int ldz, int ncols, double* ws) {
+// trans = 0: Z <- Q1 Z (groups last to first);  trans = 1: Z <- Q1^T Z (groups first to last, every block reflector transposed:
+// (I - V T V^T)^T = I - V T^T V^T)
+int ffgp_q1_apply_impl(ffgp_handle* h, const double* Y, int ldy, int n, double* Z, int ldz, int ncols, double* ws, int trans) {
   hipStream_t st = h->stream;
   double* Gm = ws;
   double* Tw = Gm + 256 * 256;
@@ -85,7 +87,8 @@ int ffgp_q1_apply_impl(ffgp_handle* h, const double* Y, int ldy, int n, double* 
   double* P2 = P1 + (size_t)256 * ncols;
   const int npan = n / 32 - 1;
   const int ngrp = (npan + Q1_AGG - 1) / Q1_AGG;
-  for (int g = ngrp - 1; g >= 0; --g) {
+  for (int gi = 0; gi < ngrp; ++gi) {
+    const int g = trans ? gi : ngrp - 1 - gi;
     const int p0 = g * Q1_AGG, p1 = min(npan, p0 + Q1_AGG);
     const int w = 32 * (p1 - p0);
     const int r0 = 32 * p0 + 32, mg = n - r0;
@@ -95,10 +98,15 @@ int ffgp_q1_apply_impl(ffgp_handle* h, const double* Y, int ldy, int n, double* 
     FFGP_CHECK(q1_tbuild(h, Gm, w, Tw, tmp));
     double* Zr = Z + (size_t)r0 * ldz;
     FFGP_CHECK(ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_FULL, 0, V, ldy, Zr, ldz, P1, ncols, w, ncols, mg, 1.0, 0.0));
-    FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Tw, 256, P1, ncols, P2, ncols, w, ncols, w, 1.0, 0.0));
+    FFGP_CHECK(ffgp_gemm_launch(h, trans ? OP_MNMAJOR : OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Tw, 256, P1, ncols, P2, ncols, w, ncols, w, 1.0, 0.0));
     FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, V, ldy, P2, ncols, Zr, ldz, mg, ncols, w, -1.0, 1.0));
   }
   return FFGP_OK;
+}
+
+__global__ __launch_bounds__(256) void syevd_identity(double* __restrict__ M, int n) {
+  const int r = blockIdx.x;
+  for (int j = threadIdx.x; j < n; j += 256) M[(size_t)r * n + j] = (j == r) ? 1.0 : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -206,15 +214,54 @@ extern "C" int ffgp_syevd(ffgp_handle* h, const double* A_dev, int n, int lda, d
   hipLaunchKernelGGL(syevd_pad, dim3(np), dim3(256), 0, st, A_dev, n, lda, s.Ap, np, s.scal);
   if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
   FFGP_CHECK(ffgp_sy2sb_impl(h, s.Ap, np, np, s.AB, s.Y, np, s.Tpan, s.ws1));
-  FFGP_CHECK(ffgp_sb2st_impl(h, s.AB, np, s.d, s.e, s.V2, s.tau2, s.prog));
-  FFGP_CHECK(ffgp_stedc_impl(h, s.d, s.e, np, s.lam, s.Zt, np, s.ws3));
   const int ncols = (n + 31) / 32 * 32;   // the padding's eigenpairs are the last columns: never transformed
-  FFGP_CHECK(ffgp_q2_prep_impl(h, s.V2, s.tau2, np, s.blocks));
-  FFGP_CHECK(ffgp_q2_apply_impl(h, s.blocks, np, s.Zt, np, ncols));
-  FFGP_CHECK(ffgp_q1_apply_impl(h, s.Y, np, np, s.Zt, np, ncols, s.ws4));
+  const int ngroups = np / 32;
+  if (!h->eig_overlap) {
+    // one stage after the other on the handle's stream
+    FFGP_CHECK(ffgp_sb2st_impl(h, s.AB, np, s.d, s.e, s.V2, s.tau2, s.prog));
+    FFGP_CHECK(ffgp_stedc_impl(h, s.d, s.e, np, s.lam, s.Zt, np, s.ws3));
+    FFGP_CHECK(ffgp_q2_prep_impl(h, s.V2, s.tau2, np, s.blocks, 0, ngroups, 0));
+    FFGP_CHECK(ffgp_q2_apply_impl(h, s.blocks, np, s.Zt, np, ncols, 0, ngroups, 0, 0));
+    FFGP_CHECK(ffgp_q1_apply_impl(h, s.Y, np, np, s.Zt, np, ncols, s.ws4, 0));
+    FFGP_HIP(hipMemcpy2DAsync(Z_dev, (size_t)ldz * sizeof(double), s.Zt, (size_t)np * sizeof(double), (size_t)n * sizeof(double), n,
+                              hipMemcpyDeviceToDevice, st));
+  } else {
+    // Two queues side by side.  The bulge chase (latency-bound, all of it on one XCD) runs on the handle's side stream, cut into a
+    // few launches; behind every launch the main stream prepares and applies that launch's reflectors -- in the order they were
+    // produced, which is the order of Q2^T -- to M, which starts as the identity; those kernels keep off the chase's XCD.  When
+    // the chase ends M = Q2^T is complete up to the last launch's blocks; then the tridiagonal problem, ONE GEMM
+    // Z_B = Q2 Z_T = M^T Z_T, and the stage-1 back-transformation.
+    hipStream_t side = h->aux;
+    double* M = s.Ap;                       // the dense matrix is no longer needed
+    double* ZB = s.blocks;                  // (free again once the last blocks have been applied)
+    if (!h->eig_ev[0])
+      for (int i = 0; i < 12; ++i) FFGP_HIP(hipEventCreateWithFlags(&h->eig_ev[i], hipEventDisableTiming));
+    FFGP_HIP(hipEventRecord(h->eig_ev[0], st));
+    FFGP_HIP(hipStreamWaitEvent(side, h->eig_ev[0], 0));
+    FFGP_CHECK(ffgp_sb2st_init(h, side, np, s.V2, s.tau2, s.prog));
+    const int gchunk = max(4, (ngroups + 7) / 8);
+    const int nchunk = (ngroups + gchunk - 1) / gchunk;     // <= 8
+    for (int c = 0; c < nchunk; ++c) {
+      FFGP_CHECK(ffgp_sb2st_chunk(h, side, s.AB, np, s.d, s.e, s.V2, s.tau2, s.prog, 32 * c * gchunk, 32 * (c + 1) * gchunk));
+      FFGP_HIP(hipEventRecord(h->eig_ev[1 + c], side));
+    }
+    FFGP_CHECK(ffgp_sb2st_finish(h, side, s.AB, np, s.d, s.e));
+    FFGP_HIP(hipEventRecord(h->eig_ev[10], side));
+    hipLaunchKernelGGL(syevd_identity, dim3(np), dim3(256), 0, st, M, np);
+    for (int c = 0; c < nchunk; ++c) {
+      FFGP_HIP(hipStreamWaitEvent(st, h->eig_ev[1 + c], 0));
+      const int G0 = c * gchunk, G1 = min(ngroups, (c + 1) * gchunk);
+      FFGP_CHECK(ffgp_q2_prep_impl(h, s.V2, s.tau2, np, s.blocks, G0, G1, 1));
+      FFGP_CHECK(ffgp_q2_apply_impl(h, s.blocks, np, M, np, np, G0, G1, 1, c + 1 < nchunk ? 1 : 0));   // M <- (Q2 part)^T M
+    }
+    FFGP_HIP(hipStreamWaitEvent(st, h->eig_ev[10], 0));
+    FFGP_CHECK(ffgp_stedc_impl(h, s.d, s.e, np, s.lam, s.Zt, np, s.ws3));
+    FFGP_CHECK(ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_FULL, 0, M, np, s.Zt, np, ZB, np, np, ncols, np, 1.0, 0.0));
+    FFGP_CHECK(ffgp_q1_apply_impl(h, s.Y, np, np, ZB, np, ncols, s.ws4, 0));
+    FFGP_HIP(hipMemcpy2DAsync(Z_dev, (size_t)ldz * sizeof(double), ZB, (size_t)np * sizeof(double), (size_t)n * sizeof(double), n,
+                              hipMemcpyDeviceToDevice, st));
+  }
   FFGP_HIP(hipMemcpyAsync(W_dev, s.lam, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
-  FFGP_HIP(hipMemcpy2DAsync(Z_dev, (size_t)ldz * sizeof(double), s.Zt, (size_t)np * sizeof(double), (size_t)n * sizeof(double), n,
-                            hipMemcpyDeviceToDevice, st));
   return syevd_check_watchdog(h, s.prog, np);
 }
 
@@ -251,13 +298,13 @@ extern "C" int ffgp_ormq2(ffgp_handle* h, const double* refl_dev, int n, double*
   FFGP_HIP(hipSetDevice(h->device));
   const int K = n / 32 + 1;
   FFGP_CHECK(ffgp_ensure_ews(h, ffgp_q2_block_doubles(n) * sizeof(double)));
-  FFGP_CHECK(ffgp_q2_prep_impl(h, refl_dev, refl_dev + (size_t)n * K * 32, n, h->ews));
-  return ffgp_q2_apply_impl(h, h->ews, n, Z_dev, ldz, ncols);
+  FFGP_CHECK(ffgp_q2_prep_impl(h, refl_dev, refl_dev + (size_t)n * K * 32, n, h->ews, 0, n / 32, 0));
+  return ffgp_q2_apply_impl(h, h->ews, n, Z_dev, ldz, ncols, 0, n / 32, 0, 0);
 }
 
 extern "C" int ffgp_ormq1(ffgp_handle* h, const double* Y_dev, int ldy, int n, double* Z_dev, int ldz, int ncols) {
   if (!h || !Y_dev || !Z_dev || n % 64 || n < 64 || ldz < ncols || ncols < 1 || ldy < n) return FFGP_ERR_ARG;
   FFGP_HIP(hipSetDevice(h->device));
   FFGP_CHECK(ffgp_ensure_ews(h, ffgp_q1_ws_doubles(n, ncols) * sizeof(double)));
-  return ffgp_q1_apply_impl(h, Y_dev, ldy, n, Z_dev, ldz, ncols, h->ews);
+  return ffgp_q1_apply_impl(h, Y_dev, ldy, n, Z_dev, ldz, ncols, h->ews, 0);
 }

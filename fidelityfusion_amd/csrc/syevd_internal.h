@@ -10,14 +10,18 @@ size_t ffgp_sy2sb_ws_doubles(int n);
 int ffgp_sy2sb_impl(ffgp_handle* h, double* A, int n, int lda, double* AB, double* Y, int ldy, double* Tpan, double* ws);
 // ---- stage 2 (sb2st.hip)
 int ffgp_sb2st_impl(ffgp_handle* h, double* AB, int n, double* d, double* e, double* V2, double* tau2, int* prog);
+int ffgp_sb2st_init(ffgp_handle* h, hipStream_t st, int n, double* V2, double* tau2, int* prog);
+int ffgp_sb2st_chunk(ffgp_handle* h, hipStream_t st, double* AB, int n, double* d, double* e, double* V2, double* tau2, int* prog, int s_begin,
+                     int s_end);
+int ffgp_sb2st_finish(ffgp_handle* h, hipStream_t st, const double* AB, int n, double* d, double* e);
 size_t ffgp_q2_block_doubles(int n);
-int ffgp_q2_prep_impl(ffgp_handle* h, const double* V2, const double* tau2, int n, double* blocks);
-int ffgp_q2_apply_impl(ffgp_handle* h, const double* blocks, int n, double* Z, int ldz, int ncols);
+int ffgp_q2_prep_impl(ffgp_handle* h, const double* V2, const double* tau2, int n, double* blocks, int G0, int G1, int trans);
+int ffgp_q2_apply_impl(ffgp_handle* h, const double* blocks, int n, double* Z, int ldz, int ncols, int G0, int G1, int fwd, int skip8);
 // ---- stage 3 (stedc.hip)
 size_t ffgp_stedc_ws_doubles(int n);
 int ffgp_stedc_impl(ffgp_handle* h, const double* d, const double* e, int n, double* lam, double* Z, int ldz, double* ws);
 // ---- back-transformation with the stage-1 reflectors (syevd.hip)
 size_t ffgp_q1_ws_doubles(int n, int ncols);
-int ffgp_q1_apply_impl(ffgp_handle* h, const double* Y, int ldy, int n, double* Z, int ldz, int ncols, double* ws);
+int ffgp_q1_apply_impl(ffgp_handle* h, const double* Y, int ldy, int n, double* Z, int ldz, int ncols, double* ws, int trans);
 // eigensolver workspace of the handle
 int ffgp_ensure_ews(ffgp_handle* h, size_t bytes);

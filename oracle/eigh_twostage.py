@@ -245,6 +245,32 @@ def apply_q2(refl, n, b, Z, g=None):
     return Z
 
 
+def apply_q2_t(refl, n, b, Z, g):
+    """Z <- Q2^T Z, the forward order the device uses while the chase is still running: sweep groups ASCENDING (as they are
+    produced), steps DESCENDING inside a group, every block transposed:  (I - V T V^T)^T = I - V T^T V^T."""
+    Z = np.array(Z, dtype=np.float64)
+    if not refl:
+        return Z
+    smax = max(s for s, _ in refl.keys())
+    for S0 in range(0, smax + 1, g):
+        kmax = max(k for (s, k) in refl.keys() if S0 <= s < S0 + g)
+        for k in range(kmax, -1, -1):
+            members = [(s, refl[(s, k)]) for s in range(S0, min(S0 + g, smax + 1)) if (s, k) in refl]
+            if not members:
+                continue
+            rlo = min(r0 for _, (r0, v, tau) in members)
+            rhi = max(r0 + v.size for _, (r0, v, tau) in members)
+            V = np.zeros((rhi - rlo, len(members)))
+            dinv = np.ones(len(members))
+            for i, (s, (r0, v, tau)) in enumerate(members):
+                if tau != 0.0:
+                    V[r0 - rlo:r0 - rlo + v.size, i] = v
+                    dinv[i] = 1.0 / tau
+            Tm = np.linalg.inv(np.triu(V.T @ V, 1) + np.diag(dinv))
+            Z[rlo:rhi] -= (V @ Tm.T) @ (V.T @ Z[rlo:rhi])
+    return Z
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # stage 3: tridiagonal divide and conquer
 # ----------------------------------------------------------------------------------------------------------------------
