@@ -265,10 +265,11 @@ int ffgp_sb2st_chunk(ffgp_handle* h, hipStream_t st, double* AB, int n, double* 
   ChaseArgs a;
   a.AB = AB; a.n = n; a.d = d; a.e = e; a.V2 = V2; a.tau2 = tau2; a.K = chase_K(n); a.prog = prog; a.err = prog + n;
   a.s_begin = s_begin; a.s_end = s_end;
-  // all working wavefronts on ONE XCD (workgroups are dealt round-robin to the 8 XCDs, so every 8th one works): neighbouring
-  // sweeps then hand their blocks over through one L2 instead of through the memory side.  Purely a placement: every band access
-  // is a device-scope access wherever the wave runs.
-  a.pack = h->chase_pack > 0 ? h->chase_pack : 8;
+  // placement of the working wavefronts: every pack-th workgroup works (workgroups are dealt round-robin to the 8 XCDs, so pack = 8
+  // puts all of them on one XCD and one L2, pack = 1 one wave on every CU of the chip).  Measured at N = 8192 (tools/chase_dbg.py):
+  // pack 8: 119 ms, 4: 88, 2: 80, 1: 82 -- the waves get in each other's way on a shared SIMD more than the memory-side
+  // hand-over between XCDs costs.  Purely a placement: every band access is a device-scope access wherever the wave runs.
+  a.pack = h->chase_pack > 0 ? h->chase_pack : 2;
   const int grid = min(s_end - s_begin, 256) * a.pack;
   hipLaunchKernelGGL(sb2st_chase, dim3(grid), dim3(64), 0, st, a);
   return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
