@@ -51,6 +51,15 @@ class Problem(C.Structure):
     ]
 
 
+class Links(C.Structure):
+    """ffgp_links: elementwise maps raw parameter -> effective quantity (include/ffgp.h FFGP_LINK_*)"""
+    _fields_ = [("w_link", C.c_int), ("w_c", C.c_double), ("w_broadcast", C.c_int), ("amp_link", C.c_int), ("amp_c", C.c_double),
+                ("dadd_link", C.c_int), ("dadd_c", C.c_double), ("out_scale", C.c_double)]
+
+
+LINK_ID, LINK_INV_ABS_EPS, LINK_EXP_NEG, LINK_INV, LINK_ABS, LINK_EXP_SQ, LINK_SQUARE = range(7)
+
+
 class Grads(C.Structure):
     _fields_ = [("g_w_dev", _dp), ("g_amp_dev", _dp), ("g_diag_add_dev", _dp), ("g_Y_dev", _dp),
                 ("g_diag_vec_dev", _dp), ("g_cov_dev", _dp), ("ld_gcov", C.c_int), ("g_kparam_dev", _dp),
@@ -97,6 +106,7 @@ EXPORTS = {
     "ffgp_nll_reduce": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, C.c_int, _dp, C.c_int, C.c_int, C.c_double, _dp]),
     "ffgp_potri": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int]),
     "ffgp_nlml_fused": (C.c_int, [C.c_void_p, C.POINTER(Problem), _dp, C.POINTER(Grads)]),
+    "ffgp_nlml_fused_raw": (C.c_int, [C.c_void_p, C.POINTER(Problem), C.POINTER(Links), _dp, C.POINTER(Grads)]),
     "ffgp_nlml_fused_async": (C.c_int, [C.c_void_p, C.POINTER(Problem), _dp, C.POINTER(Grads)]),
     "ffgp_wait": (C.c_int, [C.c_void_p]),
     "ffgp_predict": (C.c_int, [C.c_void_p, C.POINTER(Problem), _dp, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int]),

@@ -96,6 +96,11 @@ class cigp(F.PosteriorCacheMixin, nn.Module):
 
     def negative_log_likelihood(self, x_train, y_train):
         y_train, y_var = _split(y_train)
+        lk = F.raw_path(self.kernel, x_train, y_train, self.log_beta) if (y_var is None or F.raw_ok(y_var)) else None
+        if lk is not None:
+            # everything already on the GPU in fp64: ONE library call on the raw parameters (abs / reciprocal / exp maps inside)
+            return F.nlml_raw(x_train, y_train, lk, self.log_beta, F._lib.LINK_EXP_NEG, JITTER, diag_vec=y_var, variant=F.FFGP_LL_V1,
+                              pi_const=PI, sign=-1.0)
         pr = self.kernel.pair() if hasattr(self.kernel, "pair") else None
         if pr is not None and F.pair_inputs_plain(x_train, y_var):   # SumKernel(LinearKernel, MaternKernel) of the demos (:81,111,147): two descriptors, fused like a single kernel
             return -F.nlml_pair(x_train, y_train, pr[0], pr[1], diag_add=self.log_beta.exp().pow(-1).double() + JITTER, diag_vec=y_var,

@@ -170,6 +170,7 @@ int ffgp_destroy(ffgp_handle* h) {
   if (h->tsw) hipFree(h->tsw);
   if (h->skw) hipFree(h->skw);
   if (h->ews) hipFree(h->ews);
+  if (h->d_link) hipFree(h->d_link);
   for (int i = 0; i < 12; ++i)
     if (h->eig_ev[i]) hipEventDestroy(h->eig_ev[i]);
   if (h->d_info) hipFree(h->d_info);
@@ -245,6 +246,10 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     if (v != 0 && (v < 2 * FFGP_NB || (v & (v - 1)))) return FFGP_ERR_ARG;   // 0, or a power of two >= 256
     h->super_block = v;
     h->sinv_L = nullptr;
+  } else if (!strcmp(key, "small_max_n")) {
+    h->small_max_n = (int)value;
+  } else if (!strcmp(key, "small_fused")) {
+    h->small_off = (value == 0.0) ? 1 : 0;
   } else if (!strcmp(key, "eig_overlap")) {
     h->eig_overlap = (int)value;
   } else if (!strcmp(key, "chase_pack")) {
@@ -447,6 +452,59 @@ int ffgp_potri(ffgp_handle* h, double* L, int n, int ldl) {
 // ------------------------------------------------------------------------------------------------------------
 // fused NLML (+ gradients)
 // ------------------------------------------------------------------------------------------------------------
+// ---- raw parameters: elementwise links around the fused call ----------------------------------------------------------------
+__device__ __forceinline__ double ffgp_link_val(int kind, double p, double c) {
+  switch (kind) {
+    case FFGP_LINK_INV_ABS_EPS: return 1.0 / (fabs(p) + c);
+    case FFGP_LINK_EXP_NEG: return exp(-p) + c;
+    case FFGP_LINK_INV: return 1.0 / p + c;
+    case FFGP_LINK_ABS: return fabs(p);
+    case FFGP_LINK_EXP_SQ: { const double e = exp(p); return e * e; }
+    case FFGP_LINK_SQUARE: return p * p + c;
+    default: return p;
+  }
+}
+__device__ __forceinline__ double ffgp_link_der(int kind, double p, double c) {
+  switch (kind) {
+    case FFGP_LINK_INV_ABS_EPS: { const double a = fabs(p) + c; return ((p > 0.0) ? -1.0 : ((p < 0.0) ? 1.0 : 0.0)) / (a * a); }
+    case FFGP_LINK_EXP_NEG: return -exp(-p);
+    case FFGP_LINK_INV: return -1.0 / (p * p);
+    case FFGP_LINK_ABS: return (p > 0.0) ? 1.0 : ((p < 0.0) ? -1.0 : 0.0);
+    case FFGP_LINK_EXP_SQ: { const double e = exp(p); return 2.0 * e * e; }
+    case FFGP_LINK_SQUARE: return 2.0 * p;
+    default: return 1.0;
+  }
+}
+// eff = [w (D) | amp | dadd]
+__global__ void ffgp_link_fwd(ffgp_links l, int D, const double* __restrict__ rw, const double* __restrict__ ramp,
+                              const double* __restrict__ rdadd, double* __restrict__ eff) {
+  const int t = threadIdx.x;
+  if (t < D) eff[t] = ffgp_link_val(l.w_link, rw[l.w_broadcast ? 0 : t], l.w_c);
+  if (t == 0) {
+    eff[D] = ffgp_link_val(l.amp_link, ramp[0], l.amp_c);
+    if (rdadd) eff[D + 1] = ffgp_link_val(l.dadd_link, rdadd[0], l.dadd_c);
+  }
+}
+// geff = [g_w (D) | g_amp | g_dadd] -> gradients with respect to the raw parameters (any output pointer may be null)
+__global__ void ffgp_link_bwd(ffgp_links l, int D, const double* __restrict__ rw, const double* __restrict__ ramp,
+                              const double* __restrict__ rdadd, const double* __restrict__ geff, double* __restrict__ g_rw,
+                              double* __restrict__ g_ramp, double* __restrict__ g_rdadd, double sc) {
+  const int t = threadIdx.x;
+  if (g_rw) {
+    if (!l.w_broadcast) {
+      if (t < D) g_rw[t] = sc * geff[t] * ffgp_link_der(l.w_link, rw[t], l.w_c);
+    } else if (t == 0) {
+      double s = 0.0;
+      for (int k = 0; k < D; ++k) s += geff[k];
+      g_rw[0] = sc * s * ffgp_link_der(l.w_link, rw[0], l.w_c);
+    }
+  }
+  if (t == 0) {
+    if (g_ramp) g_ramp[0] = sc * geff[D] * ffgp_link_der(l.amp_link, ramp[0], l.amp_c);
+    if (g_rdadd && rdadd) g_rdadd[0] = sc * geff[D + 1] * ffgp_link_der(l.dadd_link, rdadd[0], l.dadd_c);
+  }
+}
+
 static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll_dev, const ffgp_grads* g);
 
 // info[1] is sticky: the first failing pivot of any fused call enqueued since the last ffgp_wait
@@ -473,6 +531,64 @@ int ffgp_nlml_fused_async(ffgp_handle* h, const ffgp_problem* p, double* nll_dev
 
 int ffgp_nlml_fused(ffgp_handle* h, const ffgp_problem* p, double* nll_dev, const ffgp_grads* g) {
   FFGP_CHECK(nlml_fused_enqueue(h, p, nll_dev, g));
+  return ffgp_wait(h);
+}
+
+__global__ void ffgp_scale_outputs(double sc, double* __restrict__ nll, double* __restrict__ gY, long nY, double* __restrict__ gv, long nv,
+                                   double* __restrict__ gk) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t == 0) {
+    nll[0] *= sc;
+    if (gk) gk[0] *= sc;
+  }
+  if (gY && t < nY) gY[t] *= sc;
+  if (gv && t < nv) gv[t] *= sc;
+}
+
+int ffgp_nlml_fused_raw(ffgp_handle* h, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g) {
+  if (!h || !p || !l || !nll_dev) return FFGP_ERR_ARG;
+  if (p->cov_dev || p->pair || !p->w_dev || !p->amp_dev || p->D <= 0 || p->D > 128) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  if (p->n <= 0 || p->d <= 0 || !p->X_dev || !p->Y_dev || (p->ll_variant != FFGP_LL_V1 && p->ll_variant != FFGP_LL_V2)) return FFGP_ERR_ARG;
+  if (ffgp_small_ok(h, p, g)) {   // one kernel: links, likelihood, gradients, chain rule, output scale
+    h->n_stages = 0;
+    FFGP_CHECK(ffgp_small_enqueue(h, p, l, nll_dev, g));
+    hipLaunchKernelGGL(ffgp_sticky_info_kernel, dim3(1), dim3(1), 0, h->stream, h->d_info);
+    FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    return ffgp_wait(h);
+  }
+  if (!h->d_link) FFGP_HIP(hipMalloc(&h->d_link, 512 * sizeof(double)));
+  const int D = p->D;
+  double* eff = h->d_link;
+  double* geff = h->d_link + 256;
+  hipLaunchKernelGGL(ffgp_link_fwd, dim3(1), dim3(128), 0, h->stream, *l, D, p->w_dev, p->amp_dev, p->diag_add_dev, eff);
+  ffgp_problem q = *p;
+  q.w_dev = eff;
+  q.amp_dev = eff + D;
+  if (p->diag_add_dev) q.diag_add_dev = eff + D + 1;
+  ffgp_grads gq;
+  const ffgp_grads* gp = nullptr;
+  bool chain = false;
+  if (g) {
+    gq = *g;
+    if (g->g_w_dev) gq.g_w_dev = geff;
+    if (g->g_amp_dev) gq.g_amp_dev = geff + D;
+    if (g->g_diag_add_dev) gq.g_diag_add_dev = geff + D + 1;
+    chain = g->g_w_dev || g->g_amp_dev || g->g_diag_add_dev;
+    gp = &gq;
+  }
+  FFGP_CHECK(nlml_fused_enqueue(h, &q, nll_dev, gp));
+  const double sc = (l->out_scale == 0.0) ? 1.0 : l->out_scale;
+  if (chain)
+    hipLaunchKernelGGL(ffgp_link_bwd, dim3(1), dim3(128), 0, h->stream, *l, D, p->w_dev, p->amp_dev, p->diag_add_dev, geff, g->g_w_dev,
+                       g->g_amp_dev, g->g_diag_add_dev, sc);
+  if (sc != 1.0) {
+    const long nY = (g && g->g_Y_dev) ? (long)p->n * p->d : 0, nv = (g && g->g_diag_vec_dev) ? p->n : 0;
+    const long tot = nY > nv ? nY : nv;
+    hipLaunchKernelGGL(ffgp_scale_outputs, dim3((unsigned)((tot > 0 ? tot : 1) + 255) / 256), dim3(256), 0, h->stream, sc, nll_dev,
+                       g ? g->g_Y_dev : nullptr, nY, g ? g->g_diag_vec_dev : nullptr, nv, g ? g->g_kparam_dev : nullptr);
+  }
+  if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
   return ffgp_wait(h);
 }
 
@@ -512,6 +628,13 @@ static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll
   }
   if (v2 && !want_grad) {
     o_A = total; total += (size_t)n * ffgp_round_up(d, 2) + 16;
+  }
+  if (ffgp_small_ok(h, p, g)) {   // the sizes of the reference's own demos: one workgroup, one launch (small.hip)
+    h->n_stages = 0;
+    FFGP_CHECK(ffgp_small_enqueue(h, p, nullptr, nll_dev, g));
+    hipLaunchKernelGGL(ffgp_sticky_info_kernel, dim3(1), dim3(1), 0, h->stream, h->d_info);
+    FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    return FFGP_OK;
   }
   FFGP_CHECK(ffgp_ensure_ws(h, total * sizeof(double)));
   double* W0 = h->ws;

@@ -159,6 +159,9 @@ struct ffgp_handle {
   double* ews;       // workspace of the symmetric eigensolver (syevd.hip)
   size_t ews_bytes;
   hipEvent_t eig_ev[12];   // hand-offs between the chase (side stream) and the back-transformation (main stream) of ffgp_syevd
+  int small_max_n;   // largest n that takes the one-kernel path (0 = the measured default, 40)
+  int small_off;     // 1: never take the one-kernel path of small.hip (option "small_fused" = 0)
+  double* d_link;    // effective parameters / their gradients of ffgp_nlml_fused_raw (2 x 256 doubles)
   int eig_overlap;   // ffgp_syevd: 1 = chase on the side stream with the Q2^T accumulation behind it (see syevd.hip), 0 = stage after stage
   int chase_pack;    // bulge chasing: every chase_pack-th workgroup works (8 = all on one XCD; 1 = spread over the chip)
   int splitk_min_k;  // thin products (<= 64 tiles of 64 x 64) with k >= this are cut along k (0 = never)
@@ -203,5 +206,8 @@ int ffgp_map_info(int v);
 // ---- solve.hip
 int ffgp_trsm_lower_impl(ffgp_handle* h, const double* L, int n, int ldl, double* B, int nrhs, int ldb);
 int ffgp_trsm_lower_t_impl(ffgp_handle* h, const double* L, int n, int ldl, double* B, int nrhs, int ldb);
+// ---- small.hip
+bool ffgp_small_ok(const ffgp_handle* h, const ffgp_problem* p, const ffgp_grads* g);
+int ffgp_small_enqueue(ffgp_handle* h, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g);
 // ---- workspace
 int ffgp_ensure_ws(ffgp_handle* h, size_t bytes);

@@ -205,6 +205,143 @@ class _NLML(torch.autograd.Function):
                 None, None, None, None, None, None, fin("kparam", 5), None)
 
 
+class _NLMLRaw(torch.autograd.Function):
+    """sign * nll on the modules' RAW parameters (ffgp_nlml_fused_raw): the raw -> effective maps and their chain rule run inside the
+    library call, so one training step is ONE autograd node and one library call instead of a dozen elementwise torch kernels
+    with their autograd nodes -- the whole cost of a step at the sizes the reference's demos run (N = 16 ... 300).
+    Everything must already live on one GPU in fp64 (see `raw_ok`).  Gradients: Y, raw w, raw amp, raw diag_add, diag_vec, kparam."""
+
+    @staticmethod
+    def forward(ctx, X, Y, rw, ramp, rdadd, diag_vec, add_mat, kparam, links, add_all, mean_jitter, clamp, variant, pi_const, kfun_id,
+                sign, rec, kp_const):
+        dev = X.device
+        h = _lib.handle(dev.index, 0)
+        _lib.bind_stream(h, dev.index)
+        n, D = X.shape
+        d = Y.shape[1]
+        p = Problem()
+        p.n, p.D, p.d = n, D, d
+        p.X_dev, p.Y_dev, p.w_dev, p.amp_dev = X.data_ptr(), Y.data_ptr(), rw.data_ptr(), ramp.data_ptr()
+        p.clamp_min = clamp
+        if rdadd is not None:
+            p.diag_add_dev = rdadd.data_ptr()
+        if diag_vec is not None:
+            p.diag_stride = diag_vec.shape[1] + 1 if diag_vec.dim() == 2 else 1
+            p.diag_vec_dev = diag_vec.data_ptr()
+        if add_mat is not None:
+            p.add_mat_dev, p.ld_add = add_mat.data_ptr(), add_mat.shape[1]
+        p.add_all, p.mean_jitter, p.ll_variant, p.pi_const = add_all, mean_jitter, variant, pi_const
+        p.kfun, p.kparam = kfun_id, (float(kparam) if kparam is not None else kp_const)
+        need = ctx.needs_input_grad
+        nY, nw, na, nd, nv, nk = (rec and bool(need[i]) for i in (1, 2, 3, 4, 5, 7))
+        Dw = rw.numel()
+        out = torch.empty((), dtype=torch.float64, device=dev)
+        g = None
+        buf = None
+        oY = Dw + 3
+        ov = oY + (n * d if nY else 0)
+        if nY or nw or na or nd or nv or nk:
+            # ONE buffer for every gradient [raw w | raw amp | raw diag_add | kparam | Y (n d) | diag_vec (n)]: one scaling launch in backward
+            g = Grads()
+            buf = torch.empty((ov + (n if nv else 0),), dtype=torch.float64, device=dev)
+            base = buf.data_ptr()
+            if nw:
+                g.g_w_dev = base
+            if na:
+                g.g_amp_dev = base + 8 * Dw
+            if nd:
+                g.g_diag_add_dev = base + 8 * (Dw + 1)
+            if nk:
+                g.g_kparam_dev = base + 8 * (Dw + 2)
+            if nY:
+                g.g_Y_dev = base + 8 * oY
+            if nv:
+                g.g_diag_vec_dev = base + 8 * ov
+        links.out_scale = sign          # the sign (+LL for the reference's `negative_log_likelihood`) is applied inside the call
+        rc = check(lib.ffgp_nlml_fused_raw(h, C.byref(p), C.byref(links), out.data_ptr(), C.byref(g) if g is not None else None),
+                   "ffgp_nlml_fused_raw")
+        if rc > 0:
+            _raise_not_pd(rc, "linalg.cholesky")
+        ctx.pack = (buf, Dw, n, d, oY, ov, (nw, na, nd, nk, nY, nv), rw.shape, ramp.shape, None if rdadd is None else rdadd.shape,
+                    None if diag_vec is None else diag_vec.shape, None if kparam is None else kparam.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        buf, Dw, n, d, oY, ov, (nw, na, nd, nk, nY, nv), sw, sa, sd, sv, sk = ctx.pack
+        gw = ga = gd = gk = gYo = gvo = None
+        if buf is not None:
+            sc = buf * gout
+            if nw:
+                gw = sc[:Dw].view(sw)
+            if na:
+                ga = sc[Dw:Dw + 1].view(sa)
+            if nd:
+                gd = sc[Dw + 1:Dw + 2].view(sd)
+            if nk:
+                gk = sc[Dw + 2:Dw + 3].view(sk)
+            if nY:
+                gYo = sc[oY:oY + n * d].view(n, d)
+            if nv:
+                gvo = sc[ov:ov + n]
+                if len(sv) == 2:
+                    gvo = torch.diag_embed(gvo)
+        return (None, gYo, gw, ga, gd, gvo, None, gk) + (None,) * 10
+
+
+def raw_ok(*tensors):
+    """the raw-parameter fast path needs every tensor resident on ONE GPU in fp64, contiguous, no concurrent-block context, and
+    inputs that carry no gradient of their own (the fused call has no input gradients)"""
+    if concurrent_blocks.active is not None:
+        return False
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+            return False
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            return False
+    return dev is not None
+
+
+def nlml_raw(X, Y, lk, rdadd, dadd_link, dadd_c, diag_vec=None, add_mat=None, add_all=0.0, mean_jitter=0.0, variant=FFGP_LL_V1,
+             pi_const=PI_TRUNC, sign=1.0):
+    """sign * nll through ffgp_nlml_fused_raw.  lk: the kernel's `links()` dict (raw tensors, link ids, clamp, kfun)."""
+    if X.dim() != 2 or Y.dim() != 2 or X.shape[0] != Y.shape[0]:
+        _check_xy(X, Y)
+    if torch.is_grad_enabled() and (X.requires_grad or (add_mat is not None and add_mat.requires_grad)):
+        raise ValueError("nlml_raw has no input gradients")
+    L = _lib.Links()
+    L.w_link, L.w_c, L.w_broadcast = lk["w_link"], lk["w_c"], 1 if lk["w"].numel() == 1 and X.shape[1] > 1 else 0
+    L.amp_link, L.amp_c = lk["amp_link"], 0.0
+    L.dadd_link, L.dadd_c = dadd_link, dadd_c
+    kparam = lk.get("kparam")
+    kt = kparam if isinstance(kparam, torch.Tensor) else None
+    return _NLMLRaw.apply(X, Y, lk["w"], lk["amp"], rdadd, diag_vec, add_mat, kt, L, float(add_all), float(mean_jitter), lk["clamp"],
+                          variant, pi_const, lk["kfun"], float(sign), torch.is_grad_enabled(),
+                          1.0 if (kparam is None or kt is not None) else float(kparam))
+
+
+def raw_path(kernel, x_train, y_train, *others):
+    """the kernel's `links()` when the raw-parameter fast path applies to this call, else None"""
+    lk = kernel.links() if hasattr(kernel, "links") else None
+    if lk is None:
+        return None
+    kp = lk.get("kparam")
+    if not raw_ok(x_train, y_train, lk["w"], lk["amp"], kp if isinstance(kp, torch.Tensor) else None, *others):
+        return None
+    if x_train.dim() != 2 or y_train.dim() != 2 or x_train.shape[0] != y_train.shape[0] or x_train.shape[1] > 128:
+        return None
+    if lk["w"].numel() not in (1, x_train.shape[1]) or lk["amp"].numel() != 1:
+        return None
+    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in (x_train,) + others[1:]):
+        return None   # (others[0] is the noise parameter; the rest -- y_var matrices -- must carry no gradient of their own ... except diag_vec)
+    return lk
+
+
 _pending = {}   # (device, slot) -> staging tensors of enqueued-but-not-waited calls (kept alive until wait)
 
 

@@ -14,6 +14,7 @@ returns back to the raw parameters (abs/exp chain rule included).
 import torch
 import torch.nn as nn
 
+from . import _lib
 from . import functional as F
 
 EPS = 1e-9
@@ -28,6 +29,10 @@ class _StationaryKernel(nn.Module):
     def kfun(self):
         """(radial profile id, profile parameter) -- include/ffgp.h FFGP_KFUN_*; squared exponential by default."""
         return (0, 1.0)
+
+    def links(self):
+        """the raw parameters and the elementwise maps to (w, amp) as the library's link ids (functional.nlml_raw), or None"""
+        return None
 
     def descriptor(self):
         """this kernel as one part of a composed kernel (include/ffgp.h ffgp_kdesc)"""
@@ -55,6 +60,10 @@ class ARDKernel(_StationaryKernel):
     def effective(self):
         return 1.0 / (self.length_scales.abs() + self.eps), self.signal_variance.abs(), 1e-30
 
+    def links(self):
+        return {"w": self.length_scales, "w_link": _lib.LINK_INV_ABS_EPS, "w_c": float(self.eps), "amp": self.signal_variance,
+                "amp_link": _lib.LINK_ABS, "clamp": 1e-30, "kfun": 0}
+
 
 class SquaredExponentialKernel(_StationaryKernel):
     """K = exp(signal_variance)^2 * exp(-1/2 * sqdist / exp(length_scale)^2), scalar length scale, both raw
@@ -67,6 +76,10 @@ class SquaredExponentialKernel(_StationaryKernel):
 
     def effective(self):
         return torch.exp(-self.length_scale), self.signal_variance.exp().pow(2), F.NEG_INF
+
+    def links(self):
+        return {"w": self.length_scale, "w_link": _lib.LINK_EXP_NEG, "w_c": 0.0, "amp": self.signal_variance,
+                "amp_link": _lib.LINK_EXP_SQ, "clamp": F.NEG_INF, "kfun": 0}
 
 
 class MaternKernel(_StationaryKernel):
@@ -85,6 +98,12 @@ class MaternKernel(_StationaryKernel):
 
     def effective(self):
         return 1.0 / (self.length_scales.abs() + self.eps), self.signal_variance.abs(), 1e-30
+
+    def links(self):
+        if self.nu not in self._KFUN:
+            return None
+        return {"w": self.length_scales, "w_link": _lib.LINK_INV_ABS_EPS, "w_c": float(self.eps), "amp": self.signal_variance,
+                "amp_link": _lib.LINK_ABS, "clamp": 1e-30, "kfun": self._KFUN[self.nu], "kparam": float(self.rho)}
 
     def kfun(self):
         if self.nu not in self._KFUN:   # the reference returns None for any other nu (kernel.py:161-166)

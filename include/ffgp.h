@@ -316,6 +316,32 @@ int ffgp_gemm(ffgp_handle* h, int opa, int opb, int lower_tiles, int tri, const 
    CIGP.compute_loss (MFGP_ver2023May/base_gp/cigp.py:99-136).  Returns 0, or the failing pivot index.       */
 int ffgp_nlml_fused(ffgp_handle* h, const ffgp_problem* p, double* nll_dev, const ffgp_grads* g);
 
+/* The same call on RAW parameters: w_dev / amp_dev / diag_add_dev of the problem hold the module's own parameters and `links` names
+   the elementwise maps to the effective quantities (the O(D) maps the reference's modules apply in torch: `abs() + eps` and the
+   reciprocal of ARDKernel / MaternKernel, kernel.py:98,157; `exp` of SquaredExponentialKernel, :262-266; `exp(-log_beta)` of cigp,
+   cigp_v10.py:57; `noise_variance ** 2` of GP_basic, gp_basic.py:63).  The maps and their chain rule run as two tiny kernels
+   around the fused call, so a training step needs ONE library call instead of a dozen elementwise torch kernels and their
+   autograd nodes -- which is what a step costs at the sizes the reference's own demos run (N = 16 ... 300).  Gradients in `g`
+   come back with respect to the RAW parameters; with w_broadcast the single raw length scale feeds all D dimensions and g_w_dev
+   receives ONE value.  D <= 128.                                                                                              */
+enum {
+  FFGP_LINK_ID = 0,           /* e = p                                                             */
+  FFGP_LINK_INV_ABS_EPS = 1,  /* e = 1 / (|p| + c)                                                 */
+  FFGP_LINK_EXP_NEG = 2,      /* e = exp(-p) + c                                                   */
+  FFGP_LINK_INV = 3,          /* e = 1 / p + c                                                     */
+  FFGP_LINK_ABS = 4,          /* e = |p|                                                           */
+  FFGP_LINK_EXP_SQ = 5,       /* e = exp(p)^2                                                      */
+  FFGP_LINK_SQUARE = 6        /* e = p^2 + c                                                       */
+};
+typedef struct {
+  int w_link; double w_c; int w_broadcast;
+  int amp_link; double amp_c;
+  int dadd_link; double dadd_c;
+  double out_scale;   /* the value and every gradient are multiplied by this (0 is read as 1): -1 turns the nll into the +LL the
+                         reference's `negative_log_likelihood` returns (cigp_v10.py:69) without another elementwise kernel */
+} ffgp_links;
+int ffgp_nlml_fused_raw(ffgp_handle* h, const ffgp_problem* p, const ffgp_links* links, double* nll_dev, const ffgp_grads* g);
+
 /* Same, enqueue only: returns as soon as the work is on the handle's stream (nll/gradients are valid after
    ffgp_wait).  With one handle + stream per block, independent GP blocks (the fidelities of one model, the seeds
    of an experiment sweep) overlap on one GPU: one block's latency-bound factorisation tail runs under another

@@ -444,6 +444,58 @@ def test_pair_likelihood_with_learnable_inputs_takes_the_composed_path(model):
         assert rel(g1[k_], g2[k_]) < 1e-8, k_
 
 
+@pytest.mark.parametrize("kind", ["ard", "se", "m15", "m25_rho"])
+@pytest.mark.parametrize("yvar", [False, True])
+def test_raw_parameter_path_matches_effective_path(kind, yvar, monkeypatch):
+    """cigp.negative_log_likelihood with everything resident on the GPU in fp64 takes ffgp_nlml_fused_raw (the abs / reciprocal /
+    exp maps and their chain rule inside the library call); value and every gradient -- raw kernel parameters, log_beta, Y, y_var --
+    must equal the path through the torch-side maps"""
+    from fidelityfusion_amd import functional as F
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp
+    rng = np.random.default_rng(31)
+    n, D, d = 97, 3, 2
+    X, Y0 = T(rng.uniform(0, 1, (n, D))), rng.standard_normal((n, d))
+    A = rng.standard_normal((n, n)) * 0.05
+    yv0 = A @ A.T + 0.1 * np.eye(n)
+    if kind == "ard":
+        k = kernel.ARDKernel(D)
+        with torch.no_grad():
+            k.length_scales.copy_(torch.tensor([0.7, -1.3, 2.0]))
+            k.signal_variance.fill_(-1.7)
+    elif kind == "se":
+        k = kernel.SquaredExponentialKernel(0.3, 0.2)
+    elif kind == "m15":
+        k = kernel.MaternKernel(D, nu=1.5)
+    else:
+        k = kernel.MaternKernel(D, nu=2.5, rho=1.7)
+    m = cigp(k, 0.4).double().to(DEV)
+    res = []
+    used = []
+    real = F.nlml_raw
+    for fast in (True, False):
+        if fast:
+            monkeypatch.setattr(F, "nlml_raw", lambda *a, **kw: (used.append(1), real(*a, **kw))[1])
+        else:
+            monkeypatch.setattr(F, "raw_path", lambda *a, **kw: None)
+        for p_ in m.parameters():
+            p_.grad = None
+        Y = T(Y0, grad=True)
+        yv = T(yv0, grad=True)
+        val = m.negative_log_likelihood(X, [Y, yv] if yvar else Y)
+        val.backward()
+        gr = {n_: p_.grad.clone() for n_, p_ in m.named_parameters()}
+        gr["Y"] = Y.grad.clone()
+        if yvar:
+            gr["yvar"] = yv.grad.clone()
+        res.append((val.detach().clone(), gr))
+    assert used, "the raw-parameter path was not taken"
+    (v1, g1), (v2, g2) = res
+    assert rel(v1, v2) < 1e-13 and set(g1) == set(g2)
+    for k_ in g1:
+        assert rel(g1[k_], g2[k_]) < 1e-10, k_
+
+
 def test_pair_under_no_grad_and_bad_descriptor():
     """no_grad: no gradient pipeline; a descriptor outside the enum is refused by the library (FFGP_ERR_ARG), not run"""
     from fidelityfusion_amd import _lib, kernel
@@ -1675,6 +1727,11 @@ def test_no_grad_evaluation_skips_the_gradient_pipeline(monkeypatch):
         def ffgp_nlml_fused(self, h, p, out, g):
             seen.append(g is not None)
             return real(h, p, out, g)
+
+        def ffgp_nlml_fused_raw(self, h, p, l, out, g):   # (the raw-parameter path of GPU-resident fp64 modules)
+            seen.append(g is not None)
+            return real_raw(h, p, l, out, g)
+    real_raw = F.lib.ffgp_nlml_fused_raw
     monkeypatch.setattr(F, "lib", _Spy())
     gen = torch.Generator().manual_seed(3)
     X = torch.rand((200, 3), generator=gen, dtype=torch.float64).to(DEV)

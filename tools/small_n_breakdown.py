@@ -76,3 +76,34 @@ def raw_fwd_sync():
 
 print("n=%d  module step %.3f ms | F.nlml+backward %.3f | parameter plumbing %.3f | C call fwd+grad sync %.3f, async (pipelined) %.3f | C fwd only sync %.3f"
       % (n, timed(step), timed(wrapper_only), timed(effective_only), timed(raw_sync), timed(raw_async), timed(raw_fwd_sync)))
+
+
+def fwd_nograd():
+    with torch.no_grad():
+        m.negative_log_likelihood(X, Y)
+
+
+def fwd_grad():
+    m.negative_log_likelihood(X, Y)
+
+
+val = m.negative_log_likelihood(X, Y)
+
+
+def bwd_only():
+    for p_ in m.parameters():
+        p_.grad = None
+    val.backward(retain_graph=True)
+
+
+def zero_only():
+    for p_ in m.parameters():
+        p_.grad = None
+
+
+def empty3():
+    torch.empty((), device=dev); torch.empty((5,), device=dev); torch.empty((n, 1), device=dev)
+
+
+print("      module (raw-parameter path): forward no_grad %.3f | forward recording %.3f | backward only %.3f | zeroing grads %.4f | 3 x torch.empty %.4f"
+      % (timed(fwd_nograd), timed(fwd_grad), timed(bwd_only), timed(zero_only), timed(empty3)))
