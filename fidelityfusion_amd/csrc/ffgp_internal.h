@@ -159,6 +159,10 @@ struct ffgp_handle {
   double* ews;       // workspace of the symmetric eigensolver (syevd.hip)
   size_t ews_bytes;
   hipEvent_t eig_ev[12];   // hand-offs between the chase (side stream) and the back-transformation (main stream) of ffgp_syevd
+  hipStream_t aux2;     // third stream: the head of the triangular inverse under the factorisation's tail (nlml_fused_enqueue)
+  hipEvent_t tri_ev[2]; // [0] factor columns < tri_hook_col are final (recorded by ffgp_potrf_impl on the side stream); [1] head done
+  int tri_hook_col, tri_hook_fired;
+  int trtri_overlap;    // option (default 1)
   int small_max_n;   // largest n that takes the one-kernel path (0 = the measured default, 40)
   int small_off;     // 1: never take the one-kernel path of small.hip (option "small_fused" = 0)
   double* d_link;    // effective parameters / their gradients of ffgp_nlml_fused_raw (2 x 256 doubles)
@@ -206,6 +210,8 @@ int ffgp_map_info(int v);
 // ---- solve.hip
 int ffgp_trsm_lower_impl(ffgp_handle* h, const double* L, int n, int ldl, double* B, int nrhs, int ldb);
 int ffgp_trsm_lower_t_impl(ffgp_handle* h, const double* L, int n, int ldl, double* B, int nrhs, int ldb);
+int ffgp_trtri_head(ffgp_handle* h, const double* L, int n, int ldl, double* X, int ldx, double* T, double* Ttop, int n1);
+int ffgp_trtri_tail(ffgp_handle* h, const double* L, int n, int ldl, double* X, int ldx, double* T, const double* Ttop, int n1);
 // ---- small.hip
 bool ffgp_small_ok(const ffgp_handle* h, const ffgp_problem* p, const ffgp_grads* g);
 int ffgp_small_enqueue(ffgp_handle* h, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g);

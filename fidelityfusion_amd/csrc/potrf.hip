@@ -1031,6 +1031,10 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
         FFGP_CHECK(rc);
         FFGP_HIP(hipEventRecord(eb, h->aux));
         eb_prev = eb;
+        if (h->tri_hook_col > 0 && pend + wn == h->tri_hook_col) {   // the factor's columns < tri_hook_col are final from here on
+          FFGP_HIP(hipEventRecord(h->tri_ev[0], h->aux));
+          h->tri_hook_fired = 1;
+        }
         // main stream: S_ii(k), everything right of Z(k+2)
         const int mt2 = mt - wn - wz;
         if (mt2 > 0) {
@@ -1090,6 +1094,10 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
         FFGP_CHECK(rc);
         FFGP_HIP(hipEventRecord(eb, h->aux));
         eb_prev = eb;
+        if (h->tri_hook_col > 0 && pend + wn == h->tri_hook_col) {   // the factor's columns < tri_hook_col are final from here on
+          FFGP_HIP(hipEventRecord(h->tri_ev[0], h->aux));
+          h->tri_hook_fired = 1;
+        }
         // main stream: S_ii(k), the rest of the trailing matrix
         const int mt2 = mt - wn;
         ei_prev = nullptr;

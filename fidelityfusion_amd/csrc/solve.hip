@@ -230,11 +230,7 @@ __global__ void ffgp_copy_dinv_kernel(const double* __restrict__ dinv, double* _
 // Bottom-up by doubling: at level s every aligned pair of inverted s x s diagonal blocks is merged,
 //   inv([[L11,0],[L21,L22]]) = [[X11,0],[-X22 (L21 X11), X22]],
 // all full pairs of a level in ONE batched launch per product (2 launches per level instead of 2 per pair).
-int ffgp_trtri_impl(ffgp_handle* h, const double* L, int n, int ldl, double* X, int ldx, double* T) {
-  FFGP_CHECK(ensure_dinv_for(h, L, n, ldl));
-  FFGP_HIP(hipMemsetAsync(X, 0, (size_t)n * ldx * sizeof(double), h->stream));
-  const int nblk = (n + NB - 1) / NB;
-  hipLaunchKernelGGL(ffgp_copy_dinv_kernel, dim3(NB * NB / 256, nblk), dim3(256), 0, h->stream, h->dinv, X, ldx, n);
+static int trtri_levels(ffgp_handle* h, const double* L, int n, int ldl, double* X, int ldx, double* T) {
   for (long s = NB; s < n; s *= 2) {
     const int full = (int)(n / (2 * s));          // pairs with both halves complete
     const long strideL = 2 * s * (long)ldl + 2 * s, strideX = 2 * s * (long)ldx + 2 * s;
@@ -263,6 +259,39 @@ int ffgp_trtri_impl(ffgp_handle* h, const double* L, int n, int ldl, double* X, 
     }
   }
   return FFGP_OK;
+}
+
+int ffgp_trtri_impl(ffgp_handle* h, const double* L, int n, int ldl, double* X, int ldx, double* T) {
+  FFGP_CHECK(ensure_dinv_for(h, L, n, ldl));
+  FFGP_HIP(hipMemsetAsync(X, 0, (size_t)n * ldx * sizeof(double), h->stream));
+  const int nblk = (n + NB - 1) / NB;
+  hipLaunchKernelGGL(ffgp_copy_dinv_kernel, dim3(NB * NB / 256, nblk), dim3(256), 0, h->stream, h->dinv, X, ldx, n);
+  return trtri_levels(h, L, n, ldl, X, ldx, T);
+}
+
+// The same inverse in two parts, split at column n1 (a power-of-two multiple of 128, n1 < n <= 2 n1 -- the top level's own split):
+//   head: everything that only needs the factor's first n1 columns -- X11 = L11^-1 and Ttop = L21 X11 (3/4 of the flops when
+//         n = 2 n1).  Those columns are final long before the factorisation ends, so the head runs on a third stream UNDER the
+//         factorisation's chain-bound tail (nlml_fused_enqueue);
+//   tail: X22 = L22^-1 and X21 = -X22 Ttop, after the factorisation.
+// The head reads the store of inverted diagonal blocks while the factorisation is still appending to it: blocks < n1 / 128 only.
+int ffgp_trtri_head(ffgp_handle* h, const double* L, int n, int ldl, double* X, int ldx, double* T, double* Ttop, int n1) {
+  FFGP_HIP(hipMemsetAsync(X, 0, (size_t)n * ldx * sizeof(double), h->stream));
+  hipLaunchKernelGGL(ffgp_copy_dinv_kernel, dim3(NB * NB / 256, n1 / NB), dim3(256), 0, h->stream, h->dinv, X, ldx, n1);
+  FFGP_CHECK(trtri_levels(h, L, n1, ldl, X, ldx, T));
+  const int n2 = n - n1;
+  return ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, L + (size_t)n1 * ldl, ldl, X, ldx, Ttop, n1, n2, n1, n1, 1.0, 0.0, TRI_LO_J);
+}
+
+int ffgp_trtri_tail(ffgp_handle* h, const double* L, int n, int ldl, double* X, int ldx, double* T, const double* Ttop, int n1) {
+  FFGP_CHECK(ensure_dinv_for(h, L, n, ldl));
+  const int n2 = n - n1;
+  double* X22 = X + (size_t)n1 * ldx + n1;
+  hipLaunchKernelGGL(ffgp_copy_dinv_kernel, dim3(NB * NB / 256, (n2 + NB - 1) / NB), dim3(256), 0, h->stream,
+                     h->dinv + (size_t)(n1 / NB) * NB * NB, X22, ldx, n2);
+  FFGP_CHECK(trtri_levels(h, L + (size_t)n1 * ldl + n1, n2, ldl, X22, ldx, T));
+  return ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, X22, ldx, Ttop, n1, X + (size_t)n1 * ldx, ldx, n2, n1, n2, -1.0, 0.0,
+                          TRI_HI_I);
 }
 
 // S (lower triangle, n x n, lds) <- X^T X  for lower-triangular X  (= Sigma^-1 when X = L^-1)
