@@ -173,6 +173,8 @@ int ffgp_destroy(ffgp_handle* h) {
   if (h->ews) hipFree(h->ews);
   if (h->d_link) hipFree(h->d_link);
   if (h->aux2) hipStreamDestroy(h->aux2);
+  for (int i = 0; i < 4; ++i)
+    if (h->sb_ev[i]) hipEventDestroy(h->sb_ev[i]);
   for (int i = 0; i < 2; ++i)
     if (h->tri_ev[i]) hipEventDestroy(h->tri_ev[i]);
   for (int i = 0; i < 12; ++i)
@@ -250,6 +252,8 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     if (v != 0 && (v < 2 * FFGP_NB || (v & (v - 1)))) return FFGP_ERR_ARG;   // 0, or a power of two >= 256
     h->super_block = v;
     h->sinv_L = nullptr;
+  } else if (!strcmp(key, "sb_lookahead")) {
+    h->sb_lookahead = (int)value;
   } else if (!strcmp(key, "trtri_overlap")) {
     h->trtri_overlap = (int)value;
   } else if (!strcmp(key, "small_max_n")) {

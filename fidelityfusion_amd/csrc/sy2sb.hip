@@ -510,23 +510,35 @@ int ffgp_sy2sb_impl(ffgp_handle* h, double* A, int n, int lda, double* AB, doubl
   FFGP_HIP(hipMemsetAsync(AB, 0, (size_t)n * SB_LDB * sizeof(double), st));
   FFGP_HIP(hipMemsetAsync(Y, 0, (size_t)n * ldy * sizeof(double), st));
   const int npan = n / 32 - 1;
-  for (int p = 0; p < npan; ++p) {
+  // the panel factorisation (three small launches on <= 16 CUs) of panel p + 1 only needs panel p's update of ITS 32 columns: that
+  // strip is updated first, then the QR chain runs on the side stream under the rest of the update
+  const bool la = h->sb_lookahead != 0;
+  hipStream_t side = h->aux;
+  if (la && !h->sb_ev[0])
+    for (int i = 0; i < 4; ++i) FFGP_HIP(hipEventCreateWithFlags(&h->sb_ev[i], hipEventDisableTiming));
+  auto panel_qr = [&](int p, hipStream_t q) -> int {
     const int j0 = p * 32, r0 = j0 + 32, m = n - r0;
     const int L = (m + QR_ROWS - 1) / QR_ROWS;
     double* Ap = A + (size_t)r0 * lda + j0;
     double* Ypan = Y + (size_t)r0 * ldy + j0;
-    LeafArgs la;
-    la.A = Ap; la.lda = lda; la.m = m; la.Rst = Rst; la.Tst = Tst;
-    hipLaunchKernelGGL(sy2sb_leaf_qr, dim3(L), dim3(QR_THREADS), 0, st, la);
+    LeafArgs la_;
+    la_.A = Ap; la_.lda = lda; la_.m = m; la_.Rst = Rst; la_.Tst = Tst;
+    hipLaunchKernelGGL(sy2sb_leaf_qr, dim3(L), dim3(QR_THREADS), 0, q, la_);
     TopArgs ta;
     ta.A = Ap; ta.lda = lda; ta.m = m; ta.L = L; ta.Rst = Rst; ta.Tst = Tst; ta.Vtst = Vtst; ta.small = small;
     ta.Tpan = Tpan + (size_t)p * 1024; ta.Y = Ypan; ta.ldy = ldy; ta.AB = AB + (size_t)j0 * SB_LDB; ta.use_tree = (L > 1) ? 1 : 0;
-    hipLaunchKernelGGL(sy2sb_top, dim3(1), dim3(QR_THREADS), 0, st, ta);
+    hipLaunchKernelGGL(sy2sb_top, dim3(1), dim3(QR_THREADS), 0, q, ta);
     FormYArgs fa;
     fa.A = Ap; fa.lda = lda; fa.m = m; fa.L = L; fa.Tst = Tst; fa.Vtst = Vtst; fa.small = small; fa.Y = Ypan; fa.ldy = ldy;
     fa.use_tree = ta.use_tree;
-    hipLaunchKernelGGL(sy2sb_form_y, dim3(2 * L), dim3(256), 0, st, fa);
-    if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
+    hipLaunchKernelGGL(sy2sb_form_y, dim3(2 * L), dim3(256), 0, q, fa);
+    return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
+  };
+  if (npan > 0) FFGP_CHECK(panel_qr(0, st));
+  for (int p = 0; p < npan; ++p) {
+    const int j0 = p * 32, r0 = j0 + 32, m = n - r0;
+    double* Ypan = Y + (size_t)r0 * ldy + j0;
+    double* Tp = Tpan + (size_t)p * 1024;
     double* A22 = A + (size_t)r0 * lda + r0;
     // Yp = A22 Y  (m x m times m x 32; A22 K-major, Y stored k x n), cut along k into `parts` chunks that run as ONE batched launch
     // (enough workgroups to fill the chip whatever m is); the chunks are summed in fixed order by sy2sb_red, which also leaves
@@ -547,14 +559,27 @@ int ffgp_sy2sb_impl(ffgp_handle* h, double* A, int n, int lda, double* AB, doubl
     const int nred = (m + 127) / 128;
     hipLaunchKernelGGL(sy2sb_red, dim3(nred), dim3(1024), 0, st, ra);
     MArgs ma;
-    ma.Tpan = ta.Tpan; ma.Gpart = Gpart; ma.ngp = nred; ma.Mh = Mh;
+    ma.Tpan = Tp; ma.Gpart = Gpart; ma.ngp = nred; ma.Mh = Mh;
     hipLaunchKernelGGL(sy2sb_m, dim3(1), dim3(1024), 0, st, ma);
     WArgs wa;
-    wa.Yp = Yp; wa.Y = Ypan; wa.ldy = ldy; wa.Tpan = ta.Tpan; wa.Mh = Mh; wa.VW = VW; wa.WV = WV; wa.m = m;
+    wa.Yp = Yp; wa.Y = Ypan; wa.ldy = ldy; wa.Tpan = Tp; wa.Mh = Mh; wa.VW = VW; wa.WV = WV; wa.m = m;
     hipLaunchKernelGGL(sy2sb_w, dim3((m + 31) / 32), dim3(256), 0, st, wa);
     if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
     // A22 -= [Y W] [W Y]^T
-    FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, VW, 64, WV, 64, A22, lda, m, m, 64, -1.0, 1.0));
+    const bool next = (p + 1 < npan);
+    if (la && next && m > 64) {
+      hipEvent_t ea = h->sb_ev[(p & 1) * 2], eq = h->sb_ev[(p & 1) * 2 + 1];
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, VW, 64, WV, 64, A22, lda, m, 32, 64, -1.0, 1.0));   // the next panel's columns
+      FFGP_HIP(hipEventRecord(ea, st));
+      FFGP_HIP(hipStreamWaitEvent(side, ea, 0));
+      FFGP_CHECK(panel_qr(p + 1, side));
+      FFGP_HIP(hipEventRecord(eq, side));
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, VW, 64, WV + 32 * 64, 64, A22 + 32, lda, m, m - 32, 64, -1.0, 1.0));
+      FFGP_HIP(hipStreamWaitEvent(st, eq, 0));
+    } else {
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, VW, 64, WV, 64, A22, lda, m, m, 64, -1.0, 1.0));
+      if (next) FFGP_CHECK(panel_qr(p + 1, st));
+    }
   }
   hipLaunchKernelGGL(sy2sb_copy_diag, dim3(n / 32), dim3(256), 0, st, A, lda, AB, n);
   return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
