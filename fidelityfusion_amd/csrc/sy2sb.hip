@@ -17,7 +17,8 @@
 // The band (diagonal blocks + the S R blocks) is collected in compact storage AB[c * 64 + (r - c)].
 //
 // n must be a multiple of 64 (ffgp_syevd pads with decoupled diagonal entries: every reflector component on a padded row is
-// exactly zero, so they never mix) and n <= 8224 (two TSQR levels: 16 leaves of 512 rows).
+// exactly zero, so they never mix).  Up to 16 leaves of 512 rows the TSQR has two levels; longer panels (n > 8224) get a middle level
+// (the leaf kernel again, on stacks of 16 R factors), n <= 131072.
 #include "ffgp_internal.h"
 #include "syevd_internal.h"
 
@@ -186,7 +187,9 @@ __device__ __forceinline__ void mm32(M33& C, const M33& A, const M33& B, double 
 struct TopArgs {
   const double* A; int lda;   // panel origin (leaf V's in place)
   int m, L;
-  const double* Rst; const double* Tst;
+  const double* Rst; const double* Tst;   // Rst: the R stack the top QR factors ([L][32][32]);  Tst: T of the panel's first leaf
+  const double* Vmid0; const double* Tmid0;   // three levels: first 32 rows of the first middle QR's V (in place in the leaves' R stack), its T
+  int three;
   double* Vtst;               // [512][32]  V of the top-level QR
   double* small;              // Xt [1024] | S [32] | Uinv [1024]
   double* Tpan;               // [32][32]   T of this panel
@@ -244,6 +247,22 @@ __global__ __launch_bounds__(QR_THREADS) void sy2sb_top(TopArgs p) {
   __syncthreads();
   if (tid < 32) M1[tid][tid] += 1.0;
   __syncthreads();
+  if (p.three) {   // a middle TSQR level sits between the leaves and the top: one more 32 x 32 factor I - Vm0 Xm0 behind leaf 0
+    M2[i][c] = p.Tmid0[i * 32 + c];
+    const double av = p.Vmid0[i * 32 + c];
+    V1[i][c] = (i > c) ? av : ((i == c) ? 1.0 : 0.0);
+    __syncthreads();
+    if (sm) mm32<true>(Wt, M2, V1, 1.0, tid);      // Xm0 = Tm0 Vm0^T
+    __syncthreads();
+    if (sm) mm32<false>(M2, V1, Wt, -1.0, tid);    // -Vm0 Xm0
+    __syncthreads();
+    if (tid < 32) M2[tid][tid] += 1.0;
+    __syncthreads();
+    if (sm) mm32<false>(Wt, M1, M2, 1.0, tid);
+    __syncthreads();
+    M1[i][c] = Wt[i][c];
+    __syncthreads();
+  }
   if (sm) mm32<false>(Wt, M1, Q0, 1.0, tid);       // top block of Q1
   __syncthreads();
   // modified LU of [I;0] - Q1 S (top block): signs chosen so that every pivot is >= 1 in magnitude.  V1 <- Y1 (unit lower).
@@ -298,6 +317,8 @@ struct FormYArgs {
   const double* A; int lda;   // panel origin
   int m, L;
   const double* Tst; const double* Vtst; const double* small;
+  const double* Vmid; const double* Tmid;   // three levels: the middle QRs' V (in place in the leaves' R stack, [L * 32][32]) and T ([groups][32][32])
+  int three;
   double* Y; int ldy;
   int use_tree;
 };
@@ -314,17 +335,45 @@ __global__ __launch_bounds__(256) void sy2sb_form_y(FormYArgs p) {
   const double* Xt = p.small;
   const double* Ssign = p.small + 1024;
   const double* Uinv = p.small + 1024 + 32;
-  // Q_top,i = delta_i0 I - Vt_i Xt
+  // the 32 x 32 factor behind this leaf's thin Q:  Q_top,g = delta_g0 I - Vt_g Xt  (g = the leaf itself with two levels, its group of
+  // 16 with three), times, with three levels, the middle factor  delta_l0 I - Vmid_g[block l] Xmid_g
+  const int g = p.three ? (leaf >> 4) : leaf, l = leaf & 15;
   for (int idx = tid; idx < 1024; idx += 256) {
     const int i = idx >> 5, j = idx & 31;
-    Ma[i][j] = p.use_tree ? p.Vtst[(size_t)(leaf * 32 + i) * 32 + j] : 0.0;
+    Ma[i][j] = p.use_tree ? p.Vtst[(size_t)(g * 32 + i) * 32 + j] : 0.0;
     Mb[i][j] = Xt[idx];
   }
   __syncthreads();
   mm32<false>(Mc, Ma, Mb, -1.0, tid);
   __syncthreads();
-  if (tid < 32 && leaf == 0) Mc[tid][tid] += 1.0;
+  if (tid < 32 && g == 0) Mc[tid][tid] += 1.0;
   __syncthreads();
+  if (p.three) {
+    const double* Vg = p.Vmid + (size_t)g * 16 * 1024;           // the group's stacked block (512 x 32), V in place
+    for (int idx = tid; idx < 1024; idx += 256) {
+      const int i = idx >> 5, j = idx & 31;
+      Ma[i][j] = p.Tmid[(size_t)g * 1024 + idx];
+      const double av = Vg[idx];
+      Mb[i][j] = (i > j) ? av : ((i == j) ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    mm32<true>(G, Ma, Mb, 1.0, tid);                             // Xmid_g = Tmid_g Vmid_g[:32]^T
+    __syncthreads();
+    for (int idx = tid; idx < 1024; idx += 256) {
+      const int i = idx >> 5, j = idx & 31;
+      const double av = Vg[(size_t)l * 1024 + idx];
+      Ma[i][j] = (l == 0) ? ((i > j) ? av : ((i == j) ? 1.0 : 0.0)) : av;
+    }
+    __syncthreads();
+    mm32<false>(H, Ma, G, -1.0, tid);                            // -Vmid_g[block l] Xmid_g
+    __syncthreads();
+    if (tid < 32 && l == 0) H[tid][tid] += 1.0;
+    __syncthreads();
+    mm32<false>(G, H, Mc, 1.0, tid);                             // middle factor times top factor
+    __syncthreads();
+    for (int idx = tid; idx < 1024; idx += 256) Mc[idx >> 5][idx & 31] = G[idx >> 5][idx & 31];
+    __syncthreads();
+  }
   for (int idx = tid; idx < 1024; idx += 256) {
     const int i = idx >> 5, j = idx & 31;
     Ma[i][j] = -Mc[i][j] * Ssign[j];
@@ -486,20 +535,25 @@ __global__ void sy2sb_copy_diag(const double* __restrict__ A, int lda, double* _
 }
 
 #define AV_MAX_PARTS 16
+static inline int sy2sb_max_leaves(int n) { return max(16, (n + QR_ROWS - 1) / QR_ROWS); }
 size_t ffgp_sy2sb_ws_doubles(int n) {
-  // Rst, Tst (16 leaves), Vtst, small (+ Mh), Yp, Gpart, VW, WV, partial products of the k-chunks
-  return (size_t)16 * 1024 * 2 + 512 * 32 + 4096 + (size_t)n * 32 + (size_t)(n / 128 + 1) * 1024 + (size_t)n * 64 * 2 +
+  // Rst, Tst (all leaves), Rst2, Tst2 (middle level), Vtst, small (+ Mh), Yp, Gpart, VW, WV, partial products of the k-chunks
+  return (size_t)sy2sb_max_leaves(n) * 1024 * 2 + (size_t)16 * 1024 * 2 + 512 * 32 + 4096 + (size_t)n * 32 + (size_t)(n / 128 + 1) * 1024 +
+         (size_t)n * 64 * 2 +
          (size_t)(AV_MAX_PARTS + 1) * n * 32 + 64;
 }
 
 // A [n, n] full symmetric (destroyed), AB [n, 64] band out, Y [n, ldy] reflector store out (zero outside the staircase),
 // Tpan [n/32][1024] the panels' T factors, ws: ffgp_sy2sb_ws_doubles(n)
 int ffgp_sy2sb_impl(ffgp_handle* h, double* A, int n, int lda, double* AB, double* Y, int ldy, double* Tpan, double* ws) {
-  if (n % 64 != 0 || n < 64 || n > 16 * QR_ROWS + 32) return FFGP_ERR_ARG;
+  if (n % 64 != 0 || n < 64 || n > 16 * 16 * QR_ROWS) return FFGP_ERR_ARG;
   hipStream_t st = h->stream;
+  const int Lmax = sy2sb_max_leaves(n);
   double* Rst = ws;
-  double* Tst = Rst + 16 * 1024;
-  double* Vtst = Tst + 16 * 1024;
+  double* Tst = Rst + (size_t)Lmax * 1024;
+  double* Rst2 = Tst + (size_t)Lmax * 1024;
+  double* Tst2 = Rst2 + 16 * 1024;
+  double* Vtst = Tst2 + 16 * 1024;
   double* small = Vtst + 512 * 32;
   double* Yp = small + 4096;
   double* Gpart = Yp + (size_t)n * 32;
@@ -524,12 +578,22 @@ int ffgp_sy2sb_impl(ffgp_handle* h, double* A, int n, int lda, double* AB, doubl
     LeafArgs la_;
     la_.A = Ap; la_.lda = lda; la_.m = m; la_.Rst = Rst; la_.Tst = Tst;
     hipLaunchKernelGGL(sy2sb_leaf_qr, dim3(L), dim3(QR_THREADS), 0, q, la_);
+    // more than 16 leaves (m > 8192): a middle level -- the same kernel factors the leaves' R factors, 16 (= 512 rows) at a time
+    const int three = (L > 16) ? 1 : 0;
+    const int L2 = (L + 15) / 16;
+    if (three) {
+      LeafArgs lm;
+      lm.A = Rst; lm.lda = 32; lm.m = L * 32; lm.Rst = Rst2; lm.Tst = Tst2;
+      hipLaunchKernelGGL(sy2sb_leaf_qr, dim3(L2), dim3(QR_THREADS), 0, q, lm);
+    }
     TopArgs ta;
-    ta.A = Ap; ta.lda = lda; ta.m = m; ta.L = L; ta.Rst = Rst; ta.Tst = Tst; ta.Vtst = Vtst; ta.small = small;
+    ta.A = Ap; ta.lda = lda; ta.m = m; ta.L = three ? L2 : L; ta.Rst = three ? Rst2 : Rst; ta.Tst = Tst; ta.Vtst = Vtst; ta.small = small;
+    ta.Vmid0 = Rst; ta.Tmid0 = Tst2; ta.three = three;
     ta.Tpan = Tpan + (size_t)p * 1024; ta.Y = Ypan; ta.ldy = ldy; ta.AB = AB + (size_t)j0 * SB_LDB; ta.use_tree = (L > 1) ? 1 : 0;
     hipLaunchKernelGGL(sy2sb_top, dim3(1), dim3(QR_THREADS), 0, q, ta);
     FormYArgs fa;
     fa.A = Ap; fa.lda = lda; fa.m = m; fa.L = L; fa.Tst = Tst; fa.Vtst = Vtst; fa.small = small; fa.Y = Ypan; fa.ldy = ldy;
+    fa.Vmid = Rst; fa.Tmid = Tst2; fa.three = three;
     fa.use_tree = ta.use_tree;
     hipLaunchKernelGGL(sy2sb_form_y, dim3(2 * L), dim3(256), 0, q, fa);
     return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;

@@ -8,6 +8,8 @@
 int ffgp_syevj_small_impl(ffgp_handle* h, const double* M, int n, int ldm, int batch, long strideM, double* Q, int ldq, long strideQ,
                           double* evals, long strideE, int descending);
 
+#define FFGP_SYEVD_MAX_N 32768
+
 int ffgp_ensure_ews(ffgp_handle* h, size_t bytes) {
   if (bytes <= h->ews_bytes) return FFGP_OK;
   if (h->ews) {
@@ -199,7 +201,7 @@ static int syevd_check_watchdog(ffgp_handle* h, const int* prog, int np) {
 
 extern "C" int ffgp_syevd(ffgp_handle* h, const double* A_dev, int n, int lda, double* W_dev, double* Z_dev, int ldz) {
   if (!h || !A_dev || !W_dev || !Z_dev || n < 1 || lda < n || ldz < n) return FFGP_ERR_ARG;
-  if ((n + 63) / 64 * 64 > 8224) return FFGP_ERR_ARG;
+  if (n > FFGP_SYEVD_MAX_N) return FFGP_ERR_ARG;   // (workspace ~ 10 n^2 doubles: 86 GB at the limit)
   FFGP_HIP(hipSetDevice(h->device));
   hipStream_t st = h->stream;
   if (n <= 64) {   // one LDS Jacobi problem
@@ -265,9 +267,9 @@ extern "C" int ffgp_syevd(ffgp_handle* h, const double* A_dev, int n, int lda, d
   return syevd_check_watchdog(h, s.prog, np);
 }
 
-// ---- stage entry points (n a multiple of 64, 64 <= n <= 8224; all buffers caller-owned device memory) ----------------------
+// ---- stage entry points (n a multiple of 64, 64 <= n <= 32768; all buffers caller-owned device memory) ----------------------
 extern "C" int ffgp_sy2sb(ffgp_handle* h, double* A_dev, int n, int lda, double* AB_dev, double* Y_dev, int ldy) {
-  if (!h || !A_dev || !AB_dev || !Y_dev || n % 64 || n < 64 || n > 8224 || lda < n || ldy < n) return FFGP_ERR_ARG;
+  if (!h || !A_dev || !AB_dev || !Y_dev || n % 64 || n < 64 || n > FFGP_SYEVD_MAX_N || lda < n || ldy < n) return FFGP_ERR_ARG;
   FFGP_HIP(hipSetDevice(h->device));
   const size_t need = ffgp_sy2sb_ws_doubles(n) + (size_t)(n / 32) * 1024;
   FFGP_CHECK(ffgp_ensure_ews(h, need * sizeof(double)));

@@ -5,7 +5,7 @@ block (FidelityFusion_Models/two_fidelity_models/hogp_simple.py:15-19,97-100; MF
 rank-64 updates on the fp64 matrix cores) -> tridiagonal (bulge chasing) -> divide & conquer -> two back-transformations.  The
 stage wrappers (`sy2sb`, `sb2st`, `stedc`, `ormq2`, `ormq1`) expose the pieces for tests and profiling.
 
-`jacobi_eigh` (round 2) stays as the slow, independent hand-written cross-check and as the route for n > 8192: two-sided block
+`jacobi_eigh` (round 2) stays as the slow, independent hand-written cross-check and as the route for n > 32768: two-sided block
 Jacobi, 32-wide blocks paired round-robin, every 64 x 64 pair problem on the LDS Jacobi kernel (ffgp_syevj_small), rotations applied
 by batched MFMA GEMMs; eigenvectors of the pair solver re-ordered by centre of mass so that every rotation stays close to the
 identity.  5-9 sweeps on generic matrices, 10-19 on kernel matrices; N = 2048 1.2 s, 4096 4.2 s, 8192 21 s.
@@ -39,12 +39,12 @@ def _gemm(dev, opa, opb, A, B, m, n, k, alpha=1.0, out=None, beta=0.0, lower=0):
 # ----------------------------------------------------------------------------------------------------------------------
 # two-stage solver (ffgp_syevd) and its stages
 # ----------------------------------------------------------------------------------------------------------------------
-SYEVD_MAX_N = 8192
+SYEVD_MAX_N = 32768
 
 
 def eigh(K):
     """(eigenvalues ascending [n], eigenvectors in columns [n, n]) of the symmetric matrix K (lower triangle read), fp64, on the
-    device; K is not modified.  n <= 8192 runs the two-stage solver, larger matrices the block Jacobi."""
+    device; K is not modified.  n <= 32768 runs the two-stage solver, larger matrices the block Jacobi."""
     if K.dim() != 2 or K.shape[0] != K.shape[1]:
         raise ValueError("eigh expects a square matrix, got %s" % (tuple(K.shape),))
     dev = K.device

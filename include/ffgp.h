@@ -230,10 +230,10 @@ int ffgp_syevj_small(ffgp_handle* h, const double* M_dev, int n, int ldm, int ba
  * band -> tridiagonal (bulge chasing, one wavefront per sweep, pipelined through progress counters), tridiagonal divide &
  * conquer on the device (secular equation per root, Gu-Eisenstat vectors, merges as GEMMs), back-transformation with the
  * chase's reflectors (blocked WY on the matrix cores) and with the panels' (256-wide block reflectors, GEMMs).
- * n <= 8192.  A is not modified.  Synchronises the handle's stream before returning.                                          */
+ * n <= 32768 (workspace ~ 10 n^2 doubles).  A is not modified.  Synchronises the handle's stream before returning.                                       */
 int ffgp_syevd(ffgp_handle* h, const double* A_dev, int n, int lda, double* W_dev, double* Z_dev, int ldz);
 
-/* The stages of ffgp_syevd on caller-owned buffers (n a multiple of 64, 64 <= n <= 8192) -- LAPACK's dsytrd_sy2sb / dsytrd_sb2st /
+/* The stages of ffgp_syevd on caller-owned buffers (n a multiple of 64, 64 <= n <= 32768) -- LAPACK's dsytrd_sy2sb / dsytrd_sb2st /
  * dstedc / dormtr split, exposed for tests, profiling and callers that want eigenvalues only:
  *   ffgp_sy2sb   A [n, n] full symmetric, DESTROYED -> AB [n, 64] band storage (element (r, c), 0 <= r - c <= 32, at AB[c * 64 + r - c])
  *                and Y [n, ldy]: the panels' unit-lower Householder blocks (panel p in columns 32p.., rows 32p + 32..; zero elsewhere)

@@ -125,6 +125,68 @@ def tsqr_hr(P, leaf=512):
     return Y, T, S[:, None] * R
 
 
+def tsqr_hr3(P, leaf=512, fan=16):
+    """tsqr_hr with a middle level for panels of more than fan leaves (device: n > 8224): the leaves' R factors are stacked `fan`
+    at a time and factored again (the leaf kernel on the stack), the middle R factors go to the top QR.  Thin Q1 rows of leaf i in
+    group g (position l):  Q_i . Mid_{g,l} . Top_g,  Mid_{g,l} = E_l - Vmid_g[block l] Xmid_g,  Top_g = E_g - Vtop[block g] Xtop."""
+    P = np.asarray(P, dtype=np.float64)
+    m, b = P.shape
+    starts = list(range(0, m, leaf))
+    if len(starts) > 1 and m - starts[-1] < b:
+        starts.pop()
+    bounds = starts + [m]
+    L = len(starts)
+    if L <= fan:
+        return tsqr_hr(P, leaf)
+    leaves, Rst = [], []
+    for i in range(L):
+        Vi, Ti, Ri = householder_qr_vt(P[bounds[i]:bounds[i + 1]])
+        leaves.append((Vi, Ti))
+        Rst.append(Ri)
+    groups = [list(range(g0, min(g0 + fan, L))) for g0 in range(0, L, fan)]
+    mids, Rmid = [], []
+    for grp in groups:
+        Vm, Tm, Rm = householder_qr_vt(np.vstack([Rst[i] for i in grp]))
+        mids.append((Vm, Tm))
+        Rmid.append(Rm)
+    Vt, Tt, R = householder_qr_vt(np.vstack(Rmid))
+    Xt = Tt @ Vt[:b].T
+    eye = np.eye(b)
+    top = [(eye if g == 0 else 0.0) - Vt[g * b:(g + 1) * b] @ Xt for g in range(len(groups))]
+    X = [Ti @ Vi[:b].T for (Vi, Ti) in leaves]
+    Qfac = []                                                # b x b factor behind every leaf's thin Q_i
+    for g, grp in enumerate(groups):
+        Vm, Tm = mids[g]
+        Xm = Tm @ Vm[:b].T
+        for l, i in enumerate(grp):
+            mid = (eye if l == 0 else 0.0) - Vm[l * b:(l + 1) * b] @ Xm
+            Qfac.append(mid @ top[g])
+    Wt = (eye - leaves[0][0][:b] @ X[0]) @ Qfac[0]
+    S = np.zeros(b)
+    Y1 = np.eye(b)
+    U = np.zeros((b, b))
+    for j in range(b):
+        S[j] = -1.0 if Wt[j, j] >= 0 else 1.0
+        piv = 1.0 - S[j] * Wt[j, j]
+        lcol = -S[j] * Wt[j + 1:, j] / piv
+        Y1[j + 1:, j] = lcol
+        Wt[j + 1:, j + 1:] -= np.outer(lcol, Wt[j, j + 1:])
+    for j in range(b):
+        U[j, j:] = -S[j:] * Wt[j, j:]
+        U[j, j] += 1.0
+    T = U @ np.linalg.inv(Y1).T
+    Uinv = np.linalg.inv(U)
+    Y = np.zeros((m, b))
+    for i in range(L):
+        Gi = -(Qfac[i] * S[None, :]) @ Uinv
+        Vi = leaves[i][0]
+        blk = -(Vi @ (X[i] @ Gi))
+        blk[:b] += Gi
+        Y[bounds[i]:bounds[i + 1]] = blk
+    Y[:b] = Y1
+    return Y, T, S[:, None] * R
+
+
 def sy2sb(A, b, leaf=512, panel_qr=tsqr_hr):
     """dense symmetric A [n, n] (n a multiple of b) -> (B dense with bandwidth b, panels = [(row0, Y, T)]) with
     B = Q1^T A Q1,  Q1 = prod_p (I - Y_p T_p Y_p^T) (panel p acts on rows row0..n-1)."""

@@ -132,3 +132,21 @@ def test_syevd_reads_the_lower_triangle_and_keeps_its_input():
     assert torch.equal(junk, keep)
     ref = torch.linalg.eigvalsh(A.cpu())
     assert float((W.cpu() - ref).abs().max()) <= 1e-13 * float(ref.abs().max())
+
+
+def test_syevd_three_level_tsqr_above_8192():
+    """n > 8224: the panels have more than 16 leaves of 512 rows, so the TSQR gets its middle level (the leaf kernel on stacks of 16 R
+    factors).  Comparator at this size: rocSOLVER on the same device (LAPACK on the host would take minutes)"""
+    from fidelityfusion_amd import eigh as E
+    n = 8500
+    g = torch.Generator(device=DEV).manual_seed(1)
+    X = torch.rand((n, 6), generator=g, device=DEV, dtype=torch.float64)
+    d = torch.cdist(X, X)
+    K = torch.exp(-0.5 * d * d)
+    del d
+    W, Z = E.eigh(K)
+    ref = torch.linalg.eigvalsh(K)
+    scale = float(ref.abs().max())
+    assert float((W - ref).abs().max()) <= 1e-13 * scale
+    assert float((Z.T @ Z - torch.eye(n, device=DEV, dtype=torch.float64)).abs().max()) <= 5e-13
+    assert float(torch.linalg.matrix_norm((Z * W) @ Z.T - K)) <= 2e-13 * float(torch.linalg.matrix_norm(K))

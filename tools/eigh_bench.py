@@ -8,7 +8,7 @@ import torch
 from fidelityfusion_amd import eigh as E
 
 dev = "cuda:0"
-sizes = [1024, 2048, 4096] + ([8192] if "full" in sys.argv else [])
+sizes = [1024, 2048, 4096] + ([8192] if "full" in sys.argv else []) + ([16384] if "big" in sys.argv else [])
 for n in sizes:
     D, ls = 8, 1.0
     g = torch.Generator(device=dev).manual_seed(0)
