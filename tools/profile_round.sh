@@ -18,5 +18,11 @@ python3 tools/pmc_summary.py $OUT/pmc_summary.json $OUT/pmc_FETCH_SIZE $OUT/pmc_
 cp $OUT/stats/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null || find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 find $OUT -name "*counter_collection.csv" -delete
 find $OUT -name "*kernel_trace.csv" -delete
+# the symmetric eigensolver at N = 8192 (two calls of ffgp_syevd)
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $OUT/stats_syevd -o st --output-format csv -- python3 $ROOT/tools/eigh_prof.py 8192 > $OUT/stats_syevd.log 2> $OUT/stats_syevd.err
+cd $ROOT
+find $OUT/stats_syevd -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_syevd.csv \;
+find $OUT -name "*kernel_trace.csv" -delete
 tail -1 $OUT/bench_c3.json | cut -c1-400
 head -8 $OUT/kernel_stats.csv | cut -c1-160
