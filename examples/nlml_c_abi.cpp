@@ -1,6 +1,7 @@
 // Stand-alone consumer of the C ABI (no Python, no torch): builds a synthetic GP block on the device, runs the fused
 // NLML + gradients through include/ffgp.h and prints the value, the stage timings and a gradient check against a
-// central finite difference of the value w.r.t. one inverse length scale.
+// central finite difference of the value w.r.t. one inverse length scale; then the symmetric eigensolver (ffgp_syevd) on a kernel
+// matrix of the same points, checked on the host.
 //
 //   hipcc -O2 --offload-arch=gfx950 -I include examples/nlml_c_abi.cpp -L fidelityfusion_amd -lffgp \
 //         -Wl,-rpath,$PWD/fidelityfusion_amd -o /tmp/nlml_c_abi && /tmp/nlml_c_abi 4096 8 2
@@ -109,11 +110,55 @@ int main(int argc, char** argv) {
   const double fd = (vp - vm) / (2 * eps);
   const double relerr = fabs(fd - gw[kk]) / fmax(fabs(fd), 1e-300);
   printf("d nll / d w[%d]: closed form %.8e, finite difference %.8e, rel. diff %.2e\n", kk, gw[kk], fd, relerr);
-  ffgp_destroy(h);
   if (!(relerr < 1e-5)) {
     fprintf(stderr, "gradient check failed\n");
+    ffgp_destroy(h);
     return 6;
   }
+  // The eigensolver of the HOGP block through the same ABI: K = exp(-1/2 |x - x'|^2) on the first m points (m not a multiple of 64:
+  // the library pads), A = Z diag(W) Z^T checked through trace(K) = sum(W), ||K z_last - w_last z_last|| and ||z_last|| = 1.
+  {
+    const int m = n < 1000 ? n : 1000;
+    std::vector<double> K((size_t)m * m), W(m), Z((size_t)m * m);
+    for (int i = 0; i < m; ++i)
+      for (int j = 0; j < m; ++j) {
+        double s2 = 0.0;
+        for (int k = 0; k < D; ++k) {
+          const double df = X[(size_t)i * D + k] - X[(size_t)j * D + k];
+          s2 += df * df;
+        }
+        K[(size_t)i * m + j] = exp(-0.5 * s2);
+      }
+    double *dK, *dWv, *dZ;
+    HIPCHK(hipMalloc(&dK, K.size() * 8));
+    HIPCHK(hipMalloc(&dWv, m * 8));
+    HIPCHK(hipMalloc(&dZ, Z.size() * 8));
+    HIPCHK(hipMemcpy(dK, K.data(), K.size() * 8, hipMemcpyHostToDevice));
+    rc = ffgp_syevd(h, dK, m, m, dWv, dZ, m);
+    if (rc != 0) {
+      fprintf(stderr, "ffgp_syevd returned %d\n", rc);
+      return 7;
+    }
+    HIPCHK(hipMemcpy(W.data(), dWv, m * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(Z.data(), dZ, Z.size() * 8, hipMemcpyDeviceToHost));
+    double tr = 0.0, sw = 0.0, res = 0.0, nz = 0.0;
+    for (int i = 0; i < m; ++i) tr += K[(size_t)i * m + i], sw += W[i];
+    for (int i = 0; i < m; ++i) {          // the eigenvector of the largest eigenvalue is the last column
+      double s = 0.0;
+      for (int j = 0; j < m; ++j) s += K[(size_t)i * m + j] * Z[(size_t)j * m + m - 1];
+      const double r = s - W[m - 1] * Z[(size_t)i * m + m - 1];
+      res += r * r;
+      nz += Z[(size_t)i * m + m - 1] * Z[(size_t)i * m + m - 1];
+    }
+    printf("ffgp_syevd m=%d: lambda_max %.8f, |trace - sum(W)| %.1e, |K z - w z| %.1e, |z|^2 - 1 %.1e\n", m, W[m - 1], fabs(tr - sw),
+           sqrt(res), fabs(nz - 1.0));
+    (void)hipFree(dK); (void)hipFree(dWv); (void)hipFree(dZ);
+    if (!(fabs(tr - sw) < 1e-9 * tr && sqrt(res) < 1e-10 * W[m - 1] && fabs(nz - 1.0) < 1e-12)) {
+      fprintf(stderr, "eigensolver check failed\n");
+      return 8;
+    }
+  }
+  ffgp_destroy(h);
   printf("c-abi example ok\n");
   return 0;
 }
