@@ -338,7 +338,7 @@ def raw_path(kernel, x_train, y_train, *others):
     if lk["w"].numel() not in (1, x_train.shape[1]) or lk["amp"].numel() != 1:
         return None
     if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in (x_train,) + others[1:]):
-        return None   # (others[0] is the noise parameter; the rest -- y_var matrices -- must carry no gradient of their own ... except diag_vec)
+        return None   # (others[0] is the noise parameter; inputs and full y_var matrices have no gradient on the fused path)
     return lk
 
 

@@ -87,12 +87,18 @@ class GP_basic(F.PosteriorCacheMixin, nn.Module):
             from .gp_computation_pack import _alt_terms
             quad, const = _alt_terms(y_train, self._sigma_composed(x_train, y_var).to(y_train.device), Kinv_method)
             return -0.5 * ((quad.sum() if Kinv_method == "cholesky2" else quad) + const)
+        lk = F.raw_path(self.kernel, x_train, y_train, self.noise_variance, y_var)
+        if lk is not None:   # everything already on the GPU in fp64: ONE library call on the raw parameters (noise_variance ** 2 inside)
+            ll = F.nlml_raw(x_train, y_train, lk, self.noise_variance, F._lib.LINK_SQUARE, 0.0, add_mat=y_var, variant=F.FFGP_LL_V2,
+                            pi_const=math.pi, sign=-1.0)
+            return ll.reshape(1, 1) if y_train.shape[1] == 1 else ll
         pr = self.kernel.pair() if hasattr(self.kernel, "pair") else None
         if pr is not None and F.pair_inputs_plain(x_train, y_var):   # Sum / Product of two library kernels (:170-173): two descriptors, fused like a single kernel
             ll = -F.nlml_pair(x_train, y_train, pr[0], pr[1], diag_add=self.noise_variance.pow(2), add_mat=y_var,
                               variant=F.FFGP_LL_V2, pi_const=math.pi, **F._slot_args())
             return ll.reshape(1, 1) if y_train.shape[1] == 1 else ll
-        if not hasattr(self.kernel, "effective"):
+        if not hasattr(self.kernel, "effective") or not F.pair_inputs_plain(x_train, y_var):
+            # (also: learnable inputs or a gradient-carrying y_var -- the fused call has no gradients for them)
             ll = -F.gaussian_nll_from_cov(y_train, self._sigma_composed(x_train, y_var), F.FFGP_LL_V2, math.pi)
             return ll.reshape(1, 1) if y_train.shape[1] == 1 else ll
         w, amp, clamp = self.kernel.effective()

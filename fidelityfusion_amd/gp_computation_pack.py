@@ -96,6 +96,10 @@ def conditional_Gaussian(y, Sigma, K_s, K_ss, Kinv_method="cholesky3"):
 
 def negative_log_likelihood(kernel, log_beta, x_train, y_train):
     """Sigma = K + exp(-log_beta) I + 1e-6 mean(K) I ; returns +LL with pi = 3.1415 (:120-136)."""
+    lk = F.raw_path(kernel, x_train, y_train, log_beta)
+    if lk is not None:   # everything already on the GPU in fp64: ONE library call on the raw parameters (exp(-log_beta) inside)
+        return F.nlml_raw(x_train, y_train, lk, log_beta, F._lib.LINK_EXP_NEG, 0.0, mean_jitter=JITTER, variant=F.FFGP_LL_V1,
+                          pi_const=PI, sign=-1.0)
     pr = kernel.pair() if hasattr(kernel, "pair") else None
     if pr is not None and F.pair_inputs_plain(x_train):   # Sum / Product of two library kernels: two descriptors, one assembly pass, one gradient pass
         return -F.nlml_pair(x_train, y_train, pr[0], pr[1], diag_add=log_beta.exp().pow(-1), mean_jitter=JITTER,

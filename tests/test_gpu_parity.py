@@ -496,6 +496,48 @@ def test_raw_parameter_path_matches_effective_path(kind, yvar, monkeypatch):
         assert rel(g1[k_], g2[k_]) < 1e-10, k_
 
 
+@pytest.mark.parametrize("model", ["pack", "gp_basic", "gp_basic_yvar"])
+def test_raw_parameter_path_other_modules(model, monkeypatch):
+    """gp_computation_pack.negative_log_likelihood (mean(K) jitter) and GP_basic.log_likelihood (noise_variance ** 2, full y_var, the
+    V2 form) through ffgp_nlml_fused_raw against the torch-side maps: value, shape and every gradient"""
+    import fidelityfusion_amd.gp_computation_pack as gp_pack
+    from fidelityfusion_amd import functional as F
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.gp_basic import GP_basic
+    rng = np.random.default_rng(41)
+    n, D, d = 83, 4, 1 if model != "pack" else 3
+    X, Y0 = T(rng.uniform(0, 1, (n, D))), rng.standard_normal((n, d))
+    A = rng.standard_normal((n, n)) * 0.05
+    yv = T(A @ A.T + 0.1 * np.eye(n))
+    k = kernel.ARDKernel(D).double().to(DEV)
+    lb = T(np.array([0.4]), grad=True)
+    gb = GP_basic(k, 0.8).double().to(DEV)
+    res, used, real = [], [], F.nlml_raw
+    for fast in (True, False):
+        if fast:
+            monkeypatch.setattr(F, "nlml_raw", lambda *a, **kw: (used.append(1), real(*a, **kw))[1])
+        else:
+            monkeypatch.setattr(F, "raw_path", lambda *a, **kw: None)
+        for p_ in list(gb.parameters()) + [lb]:
+            p_.grad = None
+        Y = T(Y0, grad=True)
+        if model == "pack":
+            val = gp_pack.negative_log_likelihood(k, lb, X, Y)
+        else:
+            val = gb.log_likelihood(X, [Y, yv] if model.endswith("yvar") else Y)
+        val.sum().backward()
+        gr = {n_: p_.grad.clone() for n_, p_ in gb.named_parameters() if p_.grad is not None}
+        gr["Y"] = Y.grad.clone()
+        if model == "pack":
+            gr["log_beta"] = lb.grad.clone()
+        res.append((val.detach().clone(), gr))
+    assert used, "the raw-parameter path was not taken"
+    (v1, g1), (v2, g2) = res
+    assert v1.shape == v2.shape and rel(v1, v2) < 1e-13 and set(g1) == set(g2)
+    for k_ in g1:
+        assert rel(g1[k_], g2[k_]) < 1e-10, k_
+
+
 def test_pair_under_no_grad_and_bad_descriptor():
     """no_grad: no gradient pipeline; a descriptor outside the enum is refused by the library (FFGP_ERR_ARG), not run"""
     from fidelityfusion_amd import _lib, kernel
