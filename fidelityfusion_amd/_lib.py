@@ -36,6 +36,11 @@ class KDescGrads(C.Structure):
     _fields_ = [("g_w_dev", _dp), ("g_amp_dev", _dp), ("g_kparam_dev", _dp), ("g_center_dev", _dp)]
 
 
+class KTree(C.Structure):
+    """ffgp_ktree: a nested composition of 2-4 leaves in canonical form (include/ffgp.h)"""
+    _fields_ = [("n_leaves", C.c_int), ("shape", C.c_int), ("op", C.c_int * 3), ("leaf", C.POINTER(KDesc))]
+
+
 class Problem(C.Structure):
     _fields_ = [
         ("n", C.c_int), ("D", C.c_int), ("d", C.c_int),
@@ -47,7 +52,7 @@ class Problem(C.Structure):
         ("ll_variant", C.c_int), ("pi_const", C.c_double),
         ("kfun", C.c_int), ("kparam", C.c_double),
         ("cov_dev", _dp), ("ld_cov", C.c_int),
-        ("pair", C.POINTER(KDesc)), ("pair_op", C.c_int),
+        ("pair", C.POINTER(KDesc)), ("pair_op", C.c_int), ("tree", C.POINTER(KTree)),
     ]
 
 
@@ -79,6 +84,12 @@ EXPORTS = {
                                      _dp, C.c_int, C.c_double, C.c_double, _dp, C.c_int, C.c_int]),
     "ffgp_kernel_grad_pair": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_int, C.c_int, C.POINTER(KDesc), C.c_int, _dp, C.c_int,
                                         C.POINTER(KDescGrads)]),
+    "ffgp_assemble_tree": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_int, C.c_int, C.POINTER(KTree), _dp, _dp, C.c_long,
+                                     _dp, C.c_int, C.c_double, C.c_double, _dp, C.c_int, C.c_int]),
+    "ffgp_kernel_grad_tree": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_int, C.c_int, C.POINTER(KTree), _dp, C.c_int,
+                                        C.POINTER(KDescGrads)]),
+    "ffgp_kernel_input_weights_tree": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_int, C.c_int, C.POINTER(KTree), _dp, C.c_int, _dp,
+                                                 C.c_int, C.c_long]),
     "ffgp_potrf": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int]),
     "ffgp_potrf_rows": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int, C.c_int]),
     "ffgp_kernel_grad": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_double,

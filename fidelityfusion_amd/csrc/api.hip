@@ -23,13 +23,15 @@ int ffgp_kernel_wt_impl(ffgp_handle* h, const double* X1, int n1, const double* 
                         const double* amp, double clamp, int kfun, double kparam, const double* dK, int ldk, double* Wt,
                         int ldw);
 
-int ffgp_assemble_pair_impl(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const ffgp_kdesc* k, int op,
+int ffgp_assemble_pair_impl(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const ffgp_ktree* t,
                             const double* diag_add, const double* diag_vec, long diag_stride, const double* add_mat, int ld_add,
                             double add_all, double mean_jitter, double* K, int ldk, int lower_only);
-size_t ffgp_grad_pair_partial_doubles(int n1, int n2, int D, int rect);
-int ffgp_grad_pair_impl(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const ffgp_kdesc* k, int op,
+size_t ffgp_grad_pair_partial_doubles(int n1, int n2, int D, int rect, int nl);
+int ffgp_grad_pair_impl(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const ffgp_ktree* t,
                         const double* G, int ldg, int rect, const double* trG_dev, double mj_coef, double* partial_ws,
                         const ffgp_kdesc_grads* g);
+int ffgp_pair_wt_impl(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const ffgp_ktree* t, const double* dK,
+                      int ldk, double* Wt, int ldw, long leaf_stride);
 int ffgp_rows_in_impl(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, unsigned char* found);
 
 int ffgp_syevj_small_impl(ffgp_handle* h, const double* M, int n, int ldm, int batch, long strideM, double* Q, int ldq,
@@ -381,19 +383,42 @@ int ffgp_assemble_pair(ffgp_handle* h, const double* X1, int n1, const double* X
                        const double* diag_add, const double* diag_vec, long diag_stride, const double* add_mat, int ld_add,
                        double add_all, double mean_jitter, double* K, int ldk, int lower_only) {
   if (!h || !k) return FFGP_ERR_ARG;
+  const ffgp_ktree t = {2, FFGP_TREE_CHAIN, {op, 0, 0}, k};
+  return ffgp_assemble_tree(h, X1, n1, X2, n2, D, &t, diag_add, diag_vec, diag_stride, add_mat, ld_add, add_all, mean_jitter, K, ldk,
+                            lower_only);
+}
+
+int ffgp_assemble_tree(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const ffgp_ktree* t,
+                       const double* diag_add, const double* diag_vec, long diag_stride, const double* add_mat, int ld_add,
+                       double add_all, double mean_jitter, double* K, int ldk, int lower_only) {
+  if (!h || !t) return FFGP_ERR_ARG;
   FFGP_HIP(hipSetDevice(h->device));
-  return ffgp_assemble_pair_impl(h, X1, n1, X2, n2, D, k, op, diag_add, diag_vec, diag_stride, add_mat, ld_add, add_all,
+  return ffgp_assemble_pair_impl(h, X1, n1, X2, n2, D, t, diag_add, diag_vec, diag_stride, add_mat, ld_add, add_all,
                                  mean_jitter, K, ldk, lower_only);
 }
 
 int ffgp_kernel_grad_pair(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const ffgp_kdesc* k, int op,
                           const double* dK, int ldk, const ffgp_kdesc_grads* g) {
   if (!h || !k || !g) return FFGP_ERR_ARG;
+  const ffgp_ktree t = {2, FFGP_TREE_CHAIN, {op, 0, 0}, k};
+  return ffgp_kernel_grad_tree(h, X1, n1, X2, n2, D, &t, dK, ldk, g);
+}
+
+int ffgp_kernel_grad_tree(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const ffgp_ktree* t,
+                          const double* dK, int ldk, const ffgp_kdesc_grads* g) {
+  if (!h || !t || !g || t->n_leaves < 2 || t->n_leaves > 4) return FFGP_ERR_ARG;
   if (n1 <= 0 || n2 <= 0) return FFGP_OK;
   if (D <= 0 || ldk < n2) return FFGP_ERR_ARG;
   FFGP_HIP(hipSetDevice(h->device));
-  FFGP_CHECK(ffgp_ensure_ws(h, (ffgp_grad_pair_partial_doubles(n1, n2, D, 1) + 16) * sizeof(double)));
-  return ffgp_grad_pair_impl(h, X1, n1, X2, n2, D, k, op, dK, ldk, 1, nullptr, 0.0, h->ws, g);
+  FFGP_CHECK(ffgp_ensure_ws(h, (ffgp_grad_pair_partial_doubles(n1, n2, D, 1, t->n_leaves) + 16) * sizeof(double)));
+  return ffgp_grad_pair_impl(h, X1, n1, X2, n2, D, t, dK, ldk, 1, nullptr, 0.0, h->ws, g);
+}
+
+int ffgp_kernel_input_weights_tree(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const ffgp_ktree* t,
+                                   const double* dK, int ldk, double* Wt, int ldw, long leaf_stride) {
+  if (!h || !t) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  return ffgp_pair_wt_impl(h, X1, n1, X2, n2, D, t, dK, ldk, Wt, ldw, leaf_stride);
 }
 
 /* (re)build the inverted 128x128 diagonal blocks of a factor (also the diag-kernel timing hook of tools/) */
@@ -557,7 +582,7 @@ __global__ void ffgp_scale_outputs(double sc, double* __restrict__ nll, double* 
 
 int ffgp_nlml_fused_raw(ffgp_handle* h, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g) {
   if (!h || !p || !l || !nll_dev) return FFGP_ERR_ARG;
-  if (p->cov_dev || p->pair || !p->w_dev || !p->amp_dev || p->D <= 0 || p->D > 128) return FFGP_ERR_ARG;
+  if (p->cov_dev || p->pair || p->tree || !p->w_dev || !p->amp_dev || p->D <= 0 || p->D > 128) return FFGP_ERR_ARG;
   FFGP_HIP(hipSetDevice(h->device));
   if (p->n <= 0 || p->d <= 0 || !p->X_dev || !p->Y_dev || (p->ll_variant != FFGP_LL_V1 && p->ll_variant != FFGP_LL_V2)) return FFGP_ERR_ARG;
   if (ffgp_small_ok(h, p, g)) {   // one kernel: links, likelihood, gradients, chain rule, output scale
@@ -606,7 +631,10 @@ static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll
   if (!h || !p || !nll_dev) return FFGP_ERR_ARG;
   const bool given_cov = (p->cov_dev != nullptr);
   if (p->n <= 0 || p->d <= 0 || !p->Y_dev) return FFGP_ERR_ARG;
-  const bool pair = (!given_cov && p->pair != nullptr);
+  const bool pair = (!given_cov && (p->pair != nullptr || p->tree != nullptr));
+  const ffgp_ktree pair2 = {2, FFGP_TREE_CHAIN, {p->pair_op, 0, 0}, p->pair};
+  const ffgp_ktree* tree = p->tree ? p->tree : &pair2;
+  if (pair && (tree->n_leaves < 2 || tree->n_leaves > 4 || !tree->leaf)) return FFGP_ERR_ARG;
   if (!given_cov && (p->D <= 0 || !p->X_dev)) return FFGP_ERR_ARG;
   if (!given_cov && !pair && (!p->w_dev || !p->amp_dev)) return FFGP_ERR_ARG;
   if (given_cov && p->ld_cov < p->n) return FFGP_ERR_ARG;
@@ -630,7 +658,7 @@ static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll
     o_S = total; total += (size_t)n * ld;          // Sigma^-1 -> G
     o_T = total; total += 2 * (n1 * n1 + 16);      // TRTRI scratch + the top level's L21 X11 when the inverse is split
     o_At = total; total += (size_t)d * ld;         // A^T = (Sigma^-1 Y)^T
-    o_P = total; total += (pair ? ffgp_grad_pair_partial_doubles(n, n, D, 0) : ffgp_grad_partial_doubles(n, D)) + 16;
+    o_P = total; total += (pair ? ffgp_grad_pair_partial_doubles(n, n, D, 0, tree->n_leaves) : ffgp_grad_partial_doubles(n, D)) + 16;
     if (v2) {
       o_Ct = total; total += (size_t)d * ld;       // (L^-1 A)^T
       o_Bt = total; total += (size_t)d * ld;       // B^T = (Sigma^-1 A)^T
@@ -656,7 +684,7 @@ static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll
     hipLaunchKernelGGL(ffgp_copy_lower_kernel, dim3((n + 31) / 32, (n + 31) / 32), dim3(256), 0, h->stream, p->cov_dev, p->ld_cov,
                        W0, (int)ld, n);
   } else if (pair) {
-    FFGP_CHECK(ffgp_assemble_pair_impl(h, p->X_dev, n, p->X_dev, n, D, p->pair, p->pair_op, p->diag_add_dev, p->diag_vec_dev,
+    FFGP_CHECK(ffgp_assemble_pair_impl(h, p->X_dev, n, p->X_dev, n, D, tree, p->diag_add_dev, p->diag_vec_dev,
                                        p->diag_stride, p->add_mat_dev, p->ld_add, p->add_all, p->mean_jitter, W0, (int)ld, 1));
   } else {
     FFGP_CHECK(ffgp_assemble_impl(h, p->X_dev, n, p->X_dev, n, D, p->w_dev, p->amp_dev, p->clamp_min, p->diag_add_dev,
@@ -747,7 +775,7 @@ static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll
                               g->g_w_dev, g->g_amp_dev, g->g_diag_add_dev, g->g_diag_vec_dev, P, p->kfun, p->kparam,
                               g->g_kparam_dev));   // (a pair: only the trace / diagonal part runs here, tr G lands in d_scal[4])
     if (pair && g->g_pair)
-      FFGP_CHECK(ffgp_grad_pair_impl(h, p->X_dev, n, p->X_dev, n, D, p->pair, p->pair_op, S, (int)ld, 0, h->d_scal + 4,
+      FFGP_CHECK(ffgp_grad_pair_impl(h, p->X_dev, n, p->X_dev, n, D, tree, S, (int)ld, 0, h->d_scal + 4,
                                      (p->mean_jitter != 0.0) ? p->mean_jitter / ((double)n * (double)n) : 0.0, P, g->g_pair));
     if (g->g_cov_dev)
       hipLaunchKernelGGL(ffgp_symmetrize_kernel, dim3((n + 31) / 32, (n + 31) / 32), dim3(256), 0, h->stream, S, (int)ld,

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(SM_T) void ffgp_small_nlml_kernel(SmallArgs a) {
 // does the one-kernel path cover this call?
 bool ffgp_small_ok(const ffgp_handle* h, const ffgp_problem* p, const ffgp_grads* g) {
   if (h->small_off) return false;
-  if (p->n > (h->small_max_n > 0 ? h->small_max_n : SM_MAX_FAST_N) || p->n > SM_N || p->D > SM_D || p->d > SM_Y || p->cov_dev || p->pair)
+  if (p->n > (h->small_max_n > 0 ? h->small_max_n : SM_MAX_FAST_N) || p->n > SM_N || p->D > SM_D || p->d > SM_Y || p->cov_dev || p->pair || p->tree)
     return false;
   if (p->kfun < FFGP_KFUN_SE || p->kfun > FFGP_KFUN_RQ) return false;
   if (g && (g->g_cov_dev || g->g_pair)) return false;

@@ -554,16 +554,31 @@ def kernel_matrix(x1, x2, w, amp, clamp=NEG_INF, kfun=(0, 1.0)):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-# composed kernels: K = k_a (+ | x) k_b as two descriptors in one tile pass (ffgp_assemble_pair / ffgp_kernel_grad_pair and
-# ffgp_problem.pair) -- SumKernel / ProductKernel of GaussianProcess/kernel.py:172-236
+# composed kernels: K = k_a (+ | x) k_b -- and nested compositions of up to four leaves -- as descriptors evaluated in one tile
+# pass (ffgp_assemble_tree / ffgp_kernel_grad_tree / ffgp_kernel_input_weights_tree and ffgp_problem.tree) -- SumKernel /
+# ProductKernel of GaussianProcess/kernel.py:172-236
 # ----------------------------------------------------------------------------------------------------------------------
 FFGP_KFUN_LINEAR = 5
 FFGP_KOP_SUM, FFGP_KOP_PRODUCT = 0, 1
+FFGP_TREE_CHAIN, FFGP_TREE_BALANCED = 0, 1
 _PAIR_KEYS = ("w", "amp", "kparam", "center")
 
 
+def _tree_spec(op, nl):
+    """`op`: one FFGP_KOP_* for two leaves, or (shape, (op0, op1[, op2])) for the canonical nested forms of include/ffgp.h"""
+    if isinstance(op, int):
+        if nl != 2:
+            raise ValueError("a single operator composes exactly two kernels")
+        return FFGP_TREE_CHAIN, (op,)
+    shape, ops = op
+    ops = tuple(int(o) for o in ops)
+    if not 2 <= nl <= 4 or len(ops) != nl - 1 or any(o not in (FFGP_KOP_SUM, FFGP_KOP_PRODUCT) for o in ops):
+        raise ValueError("a composed kernel takes 2-4 leaves and one operator per node")
+    return int(shape), ops
+
+
 def _pair_split(descs):
-    """two descriptor dicts {kfun, w, amp, clamp, kparam, center} -> (static meta, the 8 tensor-or-None autograd inputs)"""
+    """descriptor dicts {kfun, w, amp, clamp, kparam, center} -> (static meta, the 4 tensor-or-None autograd inputs of each)"""
     meta, tensors = [], []
     for dsc in descs:
         kp = dsc.get("kparam", 1.0)
@@ -573,30 +588,42 @@ def _pair_split(descs):
     return tuple(meta), tensors
 
 
-def _pair_descs(dev, D, meta, tensors, keep):
-    arr = (KDesc * 2)()
-    for e in range(2):
+def _pair_descs(dev, D, meta, tensors, keep, op):
+    """-> KTree (by value; its leaf array and the staged device tensors -- (w, amp, center | None) per leaf, first entry of
+    `keep` -- are appended to `keep`)"""
+    nl = len(meta)
+    shape, ops = _tree_spec(op, nl)
+    arr = (KDesc * nl)()
+    staged = []
+    keep.append(staged)
+    for e in range(nl):
         w, amp, _, cen = tensors[4 * e:4 * e + 4]
         wd = _weights(w, D, dev)
         ad = _dev(amp.reshape(-1)[:1], dev)
         arr[e].kfun, arr[e].clamp_min, arr[e].kparam = meta[e]
         arr[e].w_dev, arr[e].amp_dev = _ptr(wd), _ptr(ad)
-        keep += [wd, ad]
+        cd = None
         if cen is not None and meta[e][0] == FFGP_KFUN_LINEAR:
             cd = _weights(cen, D, dev)
             arr[e].center_dev = _ptr(cd)
-            keep.append(cd)
-    return arr
+        staged.append((wd, ad, cd))
+    t = _lib.KTree()
+    t.n_leaves, t.shape, t.leaf = nl, shape, arr
+    for i, o in enumerate(ops):
+        t.op[i] = o
+    keep.append(arr)
+    return t
 
 
 def _pair_grad_buffers(dev, D, needs):
-    """needs: 8 flags in the order of the tensor inputs -> (KDescGrads[2] | None, the two [w (D) | center (D) | amp | kparam] buffers)"""
+    """needs: 4 flags per leaf in the order of the tensor inputs -> (KDescGrads[nl] | None, the [nl, w (D) | center (D) | amp | kparam] buffer)"""
     if not any(needs):
         return None, None
-    arr = (KDescGrads * 2)()
-    bufs = torch.empty((2, 2 * D + 2), dtype=torch.float64, device=dev)
+    nl = len(needs) // 4
+    arr = (KDescGrads * nl)()
+    bufs = torch.empty((nl, 2 * D + 2), dtype=torch.float64, device=dev)
     step = bufs.element_size()
-    for e in range(2):
+    for e in range(nl):
         base = bufs[e].data_ptr()
         nw, na, nk, nc = needs[4 * e:4 * e + 4]
         if nw:
@@ -611,13 +638,13 @@ def _pair_grad_buffers(dev, D, needs):
 
 
 def _pair_grads_out(bufs, D, needs, metas, scale=None):
-    """the 8 gradient outputs (None where not needed) from the two buffers, reshaped to the inputs' shapes / devices"""
+    """the 4 gradient outputs per leaf (None where not needed) from the buffer, reshaped to the inputs' shapes / devices"""
     if bufs is None:
-        return [None] * 8
+        return [None] * len(needs)
     if scale is not None:
         bufs = bufs * scale.to(device=bufs.device, dtype=torch.float64)
     outs = []
-    for e in range(2):
+    for e in range(len(needs) // 4):
         views = (bufs[e, :D], bufs[e, 2 * D:2 * D + 1], bufs[e, 2 * D + 1:2 * D + 2], bufs[e, D:2 * D])   # w, amp, kparam, center
         for k in range(4):
             m = metas[4 * e + k]
@@ -633,8 +660,9 @@ def _pair_grads_out(bufs, D, needs, metas, scale=None):
 
 
 class _KernelPair(torch.autograd.Function):
-    """K = k_a(x1, x2) (+ | x) k_b(x1, x2) [n1, n2]; backward: every part's w / amp / kparam / center from one read of dK.
-    (Gradients w.r.t. x1 / x2 are not provided here: callers that need them use the composed per-part path.)"""
+    """K = the composed kernel of x1, x2 [n1, n2]; backward: every leaf's w / amp / kparam / center from one read of dK, and --
+    when x1 / x2 carry gradients -- every leaf's input-weight matrix from a second pass (ffgp_kernel_input_weights_tree) followed
+    by two thin matrix-core products per leaf."""
 
     @staticmethod
     def forward(ctx, x1, x2, op, meta, *tensors):
@@ -646,39 +674,77 @@ class _KernelPair(torch.autograd.Function):
         _check_same_D(a, b, "x2")
         D = a.shape[1]
         keep = []
-        descs = _pair_descs(dev, D, meta, tensors, keep)
+        tree = _pair_descs(dev, D, meta, tensors, keep, op)
         K = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float64, device=dev)
-        check(lib.ffgp_assemble_pair(h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], D, descs, op, None, None, 0, None, 0, 0.0, 0.0,
-                                     _ptr(K), b.shape[0], 0), "ffgp_assemble_pair")
-        ctx.saved = (a, b, descs, keep, op, dev)
+        check(lib.ffgp_assemble_tree(h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], D, C.byref(tree), None, None, 0, None, 0, 0.0, 0.0,
+                                     _ptr(K), b.shape[0], 0), "ffgp_assemble_tree")
+        ctx.saved = (a, b, tree, keep, dev, meta)
+        ctx.staged = keep[0]
         ctx.metas = [(t.shape, t.dtype, t.device) if isinstance(t, torch.Tensor) else None for t in tensors]
+        ctx.xmeta = [(t.shape, t.dtype, t.device) for t in (x1, x2)]
         odt = x1.dtype if x1.dtype.is_floating_point else torch.float64
         return K.to(device=x1.device, dtype=odt)
 
     @staticmethod
     def backward(ctx, dK):
-        a, b, descs, keep, op, dev = ctx.saved
+        a, b, tree, keep, dev, meta = ctx.saved
+        staged = ctx.staged
         h = _lib.handle(dev.index)
         _lib.bind_stream(h, dev.index)
         dKd = _dev(dK, dev)
         D = a.shape[1]
-        needs = [bool(f) for f in ctx.needs_input_grad[4:12]]
+        nl = len(meta)
+        n1, n2 = a.shape[0], b.shape[0]
+        needs = [bool(f) for f in ctx.needs_input_grad[4:4 + 4 * nl]]
         garr, bufs = _pair_grad_buffers(dev, D, needs)
         if garr is not None:
-            check(lib.ffgp_kernel_grad_pair(h, _ptr(a), a.shape[0], _ptr(b), b.shape[0], D, descs, op, _ptr(dKd), dKd.shape[1], garr),
-                  "ffgp_kernel_grad_pair")
-        return (None, None, None, None) + tuple(_pair_grads_out(bufs, D, needs, ctx.metas))
+            check(lib.ffgp_kernel_grad_tree(h, _ptr(a), n1, _ptr(b), n2, D, C.byref(tree), _ptr(dKd), dKd.shape[1], garr),
+                  "ffgp_kernel_grad_tree")
+        gx1 = gx2 = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            Wt = torch.empty((nl, n1, n2), dtype=torch.float64, device=dev)
+            check(lib.ffgp_kernel_input_weights_tree(h, _ptr(a), n1, _ptr(b), n2, D, C.byref(tree), _ptr(dKd), dKd.shape[1], _ptr(Wt),
+                                                     n2, n1 * n2), "ffgp_kernel_input_weights_tree")
+            one = lambda t: torch.cat([t, torch.ones((t.shape[0], 1), dtype=torch.float64, device=dev)], 1)
+            for e in range(nl):
+                wd, _, cen = staged[e]
+                w2 = (wd * wd).reshape(1, D)
+                if meta[e][0] == FFGP_KFUN_LINEAR:
+                    cen = cen.reshape(1, D) if cen is not None else None
+                    if ctx.needs_input_grad[0]:      # dK/dp = amp w^2 (q - c)
+                        t = w2 * _gemm(dev, 0, 1, Wt[e], (b - cen) if cen is not None else b, n1, D, n2, 1.0)
+                        gx1 = t if gx1 is None else gx1 + t
+                    if ctx.needs_input_grad[1]:
+                        t = w2 * _gemm(dev, 1, 1, Wt[e], (a - cen) if cen is not None else a, n2, D, n1, 1.0)
+                        gx2 = t if gx2 is None else gx2 + t
+                else:
+                    if ctx.needs_input_grad[0]:
+                        P = _gemm(dev, 0, 1, Wt[e], one(b), n1, D + 1, n2, 1.0)          # [Wt X2 | rowsum(Wt)]
+                        t = -w2 * (P[:, D:] * a - P[:, :D])
+                        gx1 = t if gx1 is None else gx1 + t
+                    if ctx.needs_input_grad[1]:
+                        P = _gemm(dev, 1, 1, Wt[e], one(a), n2, D + 1, n1, 1.0)          # [Wt^T X1 | colsum(Wt)]
+                        t = w2 * (P[:, :D] - P[:, D:] * b)
+                        gx2 = t if gx2 is None else gx2 + t
+            if gx1 is not None:
+                shp, dt, dv = ctx.xmeta[0]
+                gx1 = gx1.reshape(shp).to(device=dv, dtype=dt)
+            if gx2 is not None:
+                shp, dt, dv = ctx.xmeta[1]
+                gx2 = gx2.reshape(shp).to(device=dv, dtype=dt)
+        return (gx1, gx2, None, None) + tuple(_pair_grads_out(bufs, D, needs, ctx.metas))
 
 
 def kernel_pair(x1, x2, descs, op):
-    """K = k_a (+ | x) k_b on the device from two descriptor dicts {kfun, w, amp, clamp, kparam, center} in one pass."""
+    """The composed kernel on the device from descriptor dicts {kfun, w, amp, clamp, kparam, center} in one pass.
+    op: FFGP_KOP_* for two descriptors, or (shape, ops) for a nested composition of three / four (see `_tree_spec`)."""
     meta, tensors = _pair_split(descs)
-    return _KernelPair.apply(x1, x2, int(op), meta, *tensors)
+    return _KernelPair.apply(x1, x2, op, meta, *tensors)
 
 
 class _NLMLPair(torch.autograd.Function):
-    """nlml() for a composed kernel: the pair is assembled straight into the factorisation's buffer and its gradient tile
-    reads G once (ffgp_problem.pair / ffgp_grads.g_pair)."""
+    """nlml() for a composed kernel: the composition is assembled straight into the factorisation's buffer and its gradient tile
+    reads G once (ffgp_problem.tree / ffgp_grads.g_pair)."""
 
     @staticmethod
     def forward(ctx, X, Y, op, meta, diag_add, diag_vec, add_mat, add_all, mean_jitter, variant, pi_const, slot, defer, rec,
@@ -689,12 +755,12 @@ class _NLMLPair(torch.autograd.Function):
         keep = []
         p, (n, D, d) = _problem(dev, X, Y, None, None, diag_add, diag_vec, add_mat, add_all, mean_jitter, NEG_INF, variant,
                                 pi_const, keep)
-        descs = _pair_descs(dev, D, meta, tensors, keep)
-        p.pair, p.pair_op = descs, int(op)
-        keep.append(descs)
-        # positions: Y 1, diag_add 4, diag_vec 5, the pair's tensors 14..21
+        tree = _pair_descs(dev, D, meta, tensors, keep, op)
+        p.tree = C.pointer(tree)
+        keep.append(tree)
+        # positions: Y 1, diag_add 4, diag_vec 5, the leaves' tensors 14 ...
         need_Y, need_da, need_dv = (rec and bool(ctx.needs_input_grad[i]) for i in (1, 4, 5))
-        needs = [rec and bool(f) for f in ctx.needs_input_grad[14:22]]
+        needs = [rec and bool(f) for f in ctx.needs_input_grad[14:14 + 4 * len(meta)]]
         out = torch.empty((), dtype=torch.float64, device=dev)
         g = None
         grads = {}
@@ -754,9 +820,10 @@ def pair_inputs_plain(x_train, *extras):
 
 def nlml_pair(X, Y, descs, op, diag_add=None, diag_vec=None, add_mat=None, add_all=0.0, mean_jitter=0.0, variant=FFGP_LL_V1,
               pi_const=PI_TRUNC, slot=0, defer=False):
-    """nlml() for K = k_a (+ | x) k_b given as two descriptor dicts (see kernel._Pair.pair)."""
+    """nlml() for a composed kernel given as descriptor dicts and `op` (see kernel._Pair.pair and `kernel_pair`)."""
     meta, tensors = _pair_split(descs)
-    return _NLMLPair.apply(X, Y, int(op), meta, diag_add, diag_vec, add_mat, add_all, mean_jitter, variant, pi_const, slot, defer,
+    _tree_spec(op, len(meta))
+    return _NLMLPair.apply(X, Y, op, meta, diag_add, diag_vec, add_mat, add_all, mean_jitter, variant, pi_const, slot, defer,
                            torch.is_grad_enabled(), *tensors)
 
 

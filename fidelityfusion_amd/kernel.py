@@ -165,19 +165,50 @@ class _Pair(nn.Module):
         return all(getattr(k, "_ffgp_device_aware", False) for k in (self.kernel1, self.kernel2))
 
     def pair(self):
-        """([descriptor of kernel1, descriptor of kernel2], operator) when both parts are kernels the library evaluates
-        itself (the stationary profiles and LinearKernel) -- then kernel, Sigma extras and all gradients are ONE tile pass
-        each (ffgp_assemble_pair, ffgp_problem.pair); None for anything else (nested compositions, user modules): those
-        are evaluated part by part on the device and composed there."""
-        if FUSE_PAIRS and all(hasattr(k, "descriptor") for k in (self.kernel1, self.kernel2)):
-            return [self.kernel1.descriptor(), self.kernel2.descriptor()], self._OP
-        return None
+        """(leaf descriptors, operator spec) when every leaf of this composition is a kernel the library evaluates itself (the
+        stationary profiles and LinearKernel) and there are at most four of them -- then kernel, Sigma extras and all gradients
+        are ONE tile pass each (ffgp_assemble_tree, ffgp_problem.tree).  Two leaves: spec = FFGP_KOP_*; nested Sum / Product
+        objects (the reference composes arbitrary modules, kernel.py:172-236): spec = (shape, ops) of the canonical forms in
+        include/ffgp.h, reached by swapping the operands of commutative nodes.  None for anything else (more leaves, user
+        modules): those are evaluated part by part on the device and composed there."""
+        if not FUSE_PAIRS:
+            return None
+        flat = _flatten(self)
+        if flat is None:
+            return None
+        leaves, form = flat
+        descs = [k.descriptor() for k in leaves]
+        if len(descs) == 2:
+            return descs, form[1][0]
+        return descs, form
 
     def forward(self, x1, x2):
         pr = self.pair()
-        if pr is not None and not (x1.requires_grad or x2.requires_grad) and x1.dim() == 2 and x2.dim() == 2:
-            return F.kernel_pair(x1, x2, pr[0], pr[1])
-        return self._compose(self.kernel1(x1, x2), self.kernel2(x1, x2))   # (also the path that differentiates w.r.t. the inputs)
+        if pr is not None and x1.dim() == 2 and x2.dim() == 2:
+            return F.kernel_pair(x1, x2, pr[0], pr[1])   # (input gradients: ffgp_kernel_input_weights_tree in its backward)
+        return self._compose(self.kernel1(x1, x2), self.kernel2(x1, x2))
+
+
+def _flatten(k):
+    """a composition as (leaf modules in canonical order, (shape, ops)) -- include/ffgp.h ffgp_ktree -- or None"""
+    if not isinstance(k, _Pair):
+        return ([k], None) if hasattr(k, "descriptor") else None
+    L, R = _flatten(k.kernel1), _flatten(k.kernel2)
+    if L is None or R is None:
+        return None
+    (ll, lf), (rl, rf) = L, R
+    if len(ll) < len(rl):      # a + b == b + a and a * b == b * a bit for bit: put the deeper operand first
+        (ll, lf), (rl, rf) = (rl, rf), (ll, lf)
+    n1, n2, op = len(ll), len(rl), k._OP
+    if (n1, n2) == (1, 1):
+        return ll + rl, (F.FFGP_TREE_CHAIN, (op,))
+    if (n1, n2) == (2, 1):
+        return ll + rl, (F.FFGP_TREE_CHAIN, (lf[1][0], op))
+    if (n1, n2) == (2, 2):
+        return ll + rl, (F.FFGP_TREE_BALANCED, (lf[1][0], rf[1][0], op))
+    if (n1, n2) == (3, 1):
+        return ll + rl, (F.FFGP_TREE_CHAIN, (lf[1][0], lf[1][1], op))
+    return None
 
 
 FUSE_PAIRS = True   # False: always compose part by part (tests compare the two paths)

@@ -87,6 +87,21 @@ typedef struct {             /* gradients w.r.t. one part's effective quantities
 } ffgp_kdesc_grads;
 enum { FFGP_KOP_SUM = 0, FFGP_KOP_PRODUCT = 1 };
 
+/* A nested composition -- SumKernel / ProductKernel objects whose parts are themselves Sum / Product kernels (kernel.py:172-236
+   compose arbitrary modules) -- with up to four leaves, evaluated in the same single tile pass.  Every binary tree with <= 4
+   leaves is, up to the operand order of its (commutative, hence bit-identical) nodes, one of
+       n_leaves = 2:  l0 op[0] l1
+       n_leaves = 3:  (l0 op[0] l1) op[1] l2
+       n_leaves = 4:  FFGP_TREE_CHAIN     ((l0 op[0] l1) op[1] l2) op[2] l3
+                      FFGP_TREE_BALANCED  (l0 op[0] l1) op[2] (l2 op[1] l3)                                              */
+enum { FFGP_TREE_CHAIN = 0, FFGP_TREE_BALANCED = 1 };
+typedef struct {
+  int n_leaves;              /* 2, 3 or 4 */
+  int shape;                 /* FFGP_TREE_* (n_leaves = 4 only) */
+  int op[3];                 /* FFGP_KOP_* of the n_leaves - 1 nodes, as numbered above */
+  const ffgp_kdesc* leaf;    /* [n_leaves] */
+} ffgp_ktree;
+
 /* prediction outputs */
 enum {
   FFGP_VAR_FULL = 0, /* cov[Nt,Nt] = K** - V^T V + var_add_all              (cigp_v10.py:41-44; gp_computation_pack.py:108-110) */
@@ -123,6 +138,8 @@ typedef struct {
                              ffgp_grads.g_pair; every Sigma extra (diag / matrix / all-entries / mean jitter) applies as usual.
                              Not accepted by ffgp_predict (the modules compose the posterior from ffgp_assemble_pair pieces). */
   int pair_op;            /* FFGP_KOP_SUM | FFGP_KOP_PRODUCT */
+  const ffgp_ktree* tree; /* optional: a nested composition of 2-4 leaves in place of `pair` (same rules; ffgp_grads.g_pair then holds
+                             n_leaves entries) */
 } ffgp_problem;
 
 /* Gradients of the value returned by ffgp_nlml_fused with respect to the effective quantities.
@@ -136,7 +153,7 @@ typedef struct {
   double* g_cov_dev;      /* [n, n] full symmetric d(value)/d(cov) (what torch's cholesky backward returns), optional */
   int ld_gcov;
   double* g_kparam_dev;   /* [1] d(value)/d(kparam) for FFGP_KFUN_RQ (alpha is an nn.Parameter, kernel.py:295), optional */
-  const ffgp_kdesc_grads* g_pair; /* [2] gradients of the two parts when ffgp_problem.pair is set, optional */
+  const ffgp_kdesc_grads* g_pair; /* [2] gradients of the two parts when ffgp_problem.pair is set ([n_leaves] for .tree), optional */
 } ffgp_grads;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------ */
@@ -196,6 +213,20 @@ int ffgp_assemble_pair(ffgp_handle* h, const double* X1_dev, int n1, const doubl
    read of dK (autograd through Sum/ProductKernel.forward in the reference: two kernel backward chains).   */
 int ffgp_kernel_grad_pair(ffgp_handle* h, const double* X1_dev, int n1, const double* X2_dev, int n2, int D, const ffgp_kdesc* k,
                           int op, const double* dK_dev, int ldk, const ffgp_kdesc_grads* g);
+
+/* The same three calls for a nested composition (ffgp_ktree).  ffgp_kernel_input_weights_tree: for an upstream dK [n1, n2], leaf
+   e's weight matrix lands at Wt_dev + e * leaf_stride (each [n1, ldw]):
+       stationary leaf  Wt_e = dK o (d root / d leaf_e) o amp_e (-2 phi'_e):  dX1 = -w_e^2 o (rowsum(Wt_e) o X1 - Wt_e X2)
+       linear leaf      Wt_e = dK o (d root / d leaf_e) o amp_e:              dX1 =  w_e^2 o (Wt_e (X2 - c_e))
+   (autograd through Sum/ProductKernel.forward w.r.t. the inputs in the reference -- the acquisition loops of
+   Bayesian_optimization/acq.py on the demo kernel SumKernel(LinearKernel, MaternKernel)).                         */
+int ffgp_assemble_tree(ffgp_handle* h, const double* X1_dev, int n1, const double* X2_dev, int n2, int D, const ffgp_ktree* t,
+                       const double* diag_add_dev, const double* diag_vec_dev, long diag_stride, const double* add_mat_dev,
+                       int ld_add, double add_all, double mean_jitter, double* K_dev, int ldk, int lower_only);
+int ffgp_kernel_grad_tree(ffgp_handle* h, const double* X1_dev, int n1, const double* X2_dev, int n2, int D, const ffgp_ktree* t,
+                          const double* dK_dev, int ldk, const ffgp_kdesc_grads* g);
+int ffgp_kernel_input_weights_tree(ffgp_handle* h, const double* X1_dev, int n1, const double* X2_dev, int n2, int D,
+                                   const ffgp_ktree* t, const double* dK_dev, int ldk, double* Wt_dev, int ldw, long leaf_stride);
 
 /* In-place lower Cholesky, A = L L^T (strictly-upper part is not referenced and not written).
    Replaces torch.linalg.cholesky at cigp_v10.py:35,61; gp_computation_pack.py:67,105,128; gp_basic.py:80,131;

@@ -436,7 +436,9 @@ def composed_ll_and_grads(X, Y, parts, combine, sigma_fn, dsigma_scalar, variant
     kernel is the sum / product of `parts` = [(K_fn(X)->K, grads_fn(X, Gw)->dict), ...]; sigma_fn(K) -> Sigma.
     Returns LL, [grads per part], d LL / d Sigma (symmetric), d LL / dY."""
     Ks = [kf(X) for kf, _ in parts]
-    K = Ks[0] + Ks[1] if combine == "sum" else Ks[0] * Ks[1]
+    if isinstance(combine, str):
+        combine = (combine, 0, 1)
+    K = tree_value(combine, Ks)
     S = sigma_fn(K)
     Y = np.asarray(Y, dtype=np.float64)
     d = Y.shape[1]
@@ -447,11 +449,49 @@ def composed_ll_and_grads(X, Y, parts, combine, sigma_fn, dsigma_scalar, variant
     else:
         ll, dS, dY = ll_v2_grads(Y, S)
     dK = dS + dsigma_scalar(dS, K)      # chain through any K-dependent diagonal term (pack's mean(K) jitter)
-    out = []
-    for i, (_, gf) in enumerate(parts):
-        Gw = dK if combine == "sum" else dK * Ks[1 - i]
-        out.append(gf(X, Gw))
-    return ll, out, dS, dY
+    ups = [None] * len(parts)
+    tree_upstreams(combine, Ks, dK, ups)
+    return ll, [gf(X, ups[i]) for i, (_, gf) in enumerate(parts)], dS, dY
+
+
+def tree_value(expr, Ks):
+    """A nested Sum / Product composition (SumKernel / ProductKernel objects holding each other, kernel.py:172-236) as an expression:
+    an int names a leaf's matrix in Ks, ("sum" | "prod", left, right) a node."""
+    if isinstance(expr, int):
+        return Ks[expr]
+    op, a, b = expr
+    va, vb = tree_value(a, Ks), tree_value(b, Ks)
+    return va + vb if op == "sum" else va * vb
+
+
+def tree_upstreams(expr, Ks, G, out):
+    """reverse sweep of tree_value: out[leaf] = d sum(G o root) / d leaf matrix (what autograd hands every leaf kernel)"""
+    if isinstance(expr, int):
+        out[expr] = G if out[expr] is None else out[expr] + G
+        return
+    op, a, b = expr
+    if op == "sum":
+        tree_upstreams(a, Ks, G, out)
+        tree_upstreams(b, Ks, G, out)
+    else:
+        tree_upstreams(a, Ks, G * tree_value(b, Ks), out)
+        tree_upstreams(b, Ks, G * tree_value(a, Ks), out)
+
+
+def se_kernel_grads(X, length_scale, signal_variance, Gw):
+    """SquaredExponentialKernel (raw parameters are logs, kernel.py:258-272): d sum(Gw o K) / d{length_scale, signal_variance}"""
+    ls, sv = float(np.ravel(length_scale)[0]), float(np.ravel(signal_variance)[0])
+    sq = sqdist_expanded(X, X)
+    K = np.exp(sv) ** 2 * np.exp(-0.5 * sq / np.exp(ls) ** 2)
+    return {"signal_variance": 2.0 * (Gw * K).sum(), "length_scale": (Gw * K * sq).sum() / np.exp(ls) ** 2}
+
+
+def linear_input_grads(x1, x2, length_scales, signal_variance, center, Gw):
+    """d sum(Gw o K_lin(x1, x2)) / dx1, / dx2 (autograd through kernel.py:45-63)"""
+    ls = np.asarray(length_scales, dtype=np.float64)
+    c = np.asarray(center, dtype=np.float64)
+    a = abs(float(np.ravel(signal_variance)[0]))
+    return a * (Gw @ (np.asarray(x2) - c)) / ls ** 2, a * (Gw.T @ (np.asarray(x1) - c)) / ls ** 2
 
 
 def ard_input_grads(x1, x2, length_scales, signal_variance, Gw, nu=None, rho=1.0):

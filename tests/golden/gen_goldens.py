@@ -857,6 +857,91 @@ def main():
     save("k_matern_scalar", x1=xa, x2=xb, K=Kms, R=Rm, length_scale=km.length_scale, signal_variance=km.signal_variance, nu=km.nu,
          g_length_scale=km.length_scale.grad, g_signal_variance=km.signal_variance.grad, g_nu=km.nu.grad, g_x1=xa.grad, g_x2=xb.grad)
 
+    # ------------------------------------------------------------------ nested Sum / Product compositions (kernel.py:172-236 compose
+    # arbitrary modules) and input gradients through a composed kernel (the acquisition loops differentiate the posterior w.r.t.
+    # the query points): three leaves under cigp, four leaves (balanced / chain) under gp_computation_pack and GP_basic
+    g10 = torch.Generator().manual_seed(777001)
+
+    def rnd10(*shape, lo=0.5, hi=1.5):
+        return torch.rand(*shape, generator=g10) * (hi - lo) + lo
+
+    def set_(p, v):
+        with torch.no_grad():
+            p.copy_(v if isinstance(v, torch.Tensor) else torch.tensor([v]))
+
+    D, n, d = 3, 96, 2
+    # (a) the demo pair SumKernel(LinearKernel, MaternKernel): kernel value and gradients w.r.t. BOTH inputs for an upstream dK
+    kp = rk.SumKernel(rk.LinearKernel(D), rk.MaternKernel(D))
+    set_(kp.kernel1.length_scales, rnd10(D, lo=1.0, hi=2.0))
+    set_(kp.kernel1.center, rnd10(D, lo=-0.2, hi=0.2))
+    set_(kp.kernel1.signal_variance, 0.4)
+    set_(kp.kernel2.length_scales, rnd10(D) * torch.tensor([1.0, -1.0, 1.0]))
+    set_(kp.kernel2.signal_variance, -1.3)
+    xa = (torch.rand(37, D, generator=g10) * 2 - 0.5).requires_grad_(True)
+    xb = (torch.rand(26, D, generator=g10) * 2 - 0.5).requires_grad_(True)
+    Kp = kp(xa, xb)
+    Rp = torch.rand(37, 26, generator=g10) - 0.3
+    (Kp * Rp).sum().backward()
+    save("pair_sum_linear_matern_xgrad", x1=xa, x2=xb, K=Kp, R=Rp, g_x1=xa.grad, g_x2=xb.grad, **params_of(kp), **grads_of(kp))
+
+    # (b) three leaves: SumKernel(ProductKernel(ARDKernel, RationalQuadraticKernel), LinearKernel) under cigp -- likelihood, every
+    # gradient, the posterior and the gradient of (sum(mean) + trace(var)) w.r.t. the query points
+    k3 = rk.SumKernel(rk.ProductKernel(rk.ARDKernel(D), rk.RationalQuadraticKernel(length_scale=0.9, signal_variance=1.1, alpha=1.4)),
+                      rk.LinearKernel(D))
+    set_(k3.kernel1.kernel1.length_scales, rnd10(D) * torch.tensor([1.0, 1.0, -1.0]))
+    set_(k3.kernel1.kernel1.signal_variance, -1.2)
+    set_(k3.kernel2.length_scales, rnd10(D, lo=1.0, hi=2.0))
+    set_(k3.kernel2.center, rnd10(D, lo=-0.2, hi=0.2))
+    set_(k3.kernel2.signal_variance, 0.35)
+    X, Y = make_xy(g10, n, D, d)
+    Y = Y.clone().requires_grad_(True)
+    m3 = RCIGP(k3, log_beta=1.1)
+    ll = m3.negative_log_likelihood(X, Y)
+    ll.backward()
+    Xs = torch.rand(19, D, generator=g10).requires_grad_(True)
+    mean, var = m3(X, Y.detach(), Xs)
+    gXs, = torch.autograd.grad(mean.sum() + var.diagonal().sum(), Xs)
+    save("cigp_nested3", X=X, Y=Y, Xs=Xs, ll=ll, g_Y=Y.grad, mean=mean, var=var, g_Xs=gXs, **params_of(m3), **grads_of(m3))
+
+    # (c) four leaves, balanced: SumKernel(ProductKernel(ARD, Matern nu=1.5), ProductKernel(Linear, SquaredExponential)) under
+    # gp_computation_pack.negative_log_likelihood (mean(K) jitter)
+    k4 = rk.SumKernel(rk.ProductKernel(rk.ARDKernel(D), rk.MaternKernel(D, nu=1.5)),
+                      rk.ProductKernel(rk.LinearKernel(D), rk.SquaredExponentialKernel(length_scale=0.2, signal_variance=-0.1)))
+    set_(k4.kernel1.kernel1.length_scales, rnd10(D))
+    set_(k4.kernel1.kernel1.signal_variance, 1.3)
+    set_(k4.kernel1.kernel2.length_scales, rnd10(D, lo=1.0, hi=2.5) * torch.tensor([-1.0, 1.0, 1.0]))
+    set_(k4.kernel1.kernel2.signal_variance, 0.8)
+    set_(k4.kernel2.kernel1.length_scales, rnd10(D, lo=1.0, hi=2.0))
+    set_(k4.kernel2.kernel1.center, rnd10(D, lo=-0.3, hi=0.3))
+    set_(k4.kernel2.kernel1.signal_variance, -0.6)
+    X, Y = make_xy(g10, n, D, 1)
+    Y = Y.clone().requires_grad_(True)
+    log_beta = torch.nn.Parameter(torch.tensor([1.3]))
+    ll = rpack.negative_log_likelihood(k4, log_beta, X, Y)
+    ll.backward()
+    save("pack_nested4_balanced", X=X, Y=Y, ll=ll, g_Y=Y.grad, log_beta=log_beta, g_log_beta=log_beta.grad, **params_of(k4),
+         **grads_of(k4))
+
+    # (d) four leaves, chain with the deep operand on the RIGHT: ProductKernel(RQ, SumKernel(ARD, SumKernel(Linear, Matern nu=2.5)))
+    # under GP_basic (V2 likelihood), plus the conditional-Gaussian forward
+    kc = rk.ProductKernel(rk.RationalQuadraticKernel(length_scale=1.2, signal_variance=0.9, alpha=2.1),
+                          rk.SumKernel(rk.ARDKernel(D), rk.SumKernel(rk.LinearKernel(D), rk.MaternKernel(D))))
+    set_(kc.kernel2.kernel1.length_scales, rnd10(D))
+    set_(kc.kernel2.kernel1.signal_variance, 0.7)
+    set_(kc.kernel2.kernel2.kernel1.length_scales, rnd10(D, lo=1.0, hi=2.0))
+    set_(kc.kernel2.kernel2.kernel1.signal_variance, 0.25)
+    set_(kc.kernel2.kernel2.kernel2.length_scales, rnd10(D) * torch.tensor([1.0, -1.0, -1.0]))
+    set_(kc.kernel2.kernel2.kernel2.signal_variance, 1.1)
+    X, Y = make_xy(g10, n, D, d)
+    Y = Y.clone().requires_grad_(True)
+    mb = RGPB(kc, noise_variance=0.45)
+    ll = mb.log_likelihood(X, Y)
+    ll.sum().backward()
+    Xs2 = torch.rand(15, D, generator=g10)
+    with torch.no_grad():
+        mu, var = mb(X, Y.detach(), Xs2)
+    save("gpbasic_nested4_chain", X=X, Y=Y, Xs=Xs2, ll=ll, g_Y=Y.grad, mu=mu, var=var, **params_of(mb), **grads_of(mb))
+
     os.chdir(cwd)
 
 

@@ -326,10 +326,136 @@ def test_pair_kernel_matches_composition(a, b, D, op):
     assert rel(Ks1, Ks2) < 1e-13
     for n in h1:
         assert rel(h1[n], h2[n]) < 1e-10, n
-    # input gradients are the composed path's job: the fused forward steps aside
-    xg = x1.clone().requires_grad_(True)
-    k(xg, x2).sum().backward()
-    assert xg.grad is not None and torch.isfinite(xg.grad).all()
+    # input gradients: one more tile pass (ffgp_kernel_input_weights_tree) + thin products, against autograd through the parts
+    res = []
+    for fuse in (True, False):
+        xa, xb = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+        _pair_eval(k, lambda m: m(xa, xb) * dK, fuse)
+        xs = x1.clone().requires_grad_(True)
+        _pair_eval(k, lambda m: m(xs, xs) * (dK @ dK.T), fuse)
+        res.append((xa.grad, xb.grad, xs.grad))
+    for u, v in zip(*res):
+        assert rel(u, v) < 1e-10
+
+
+def _nested(shape, D):
+    """compositions of three / four library kernels in every canonical form and with the deep operand on either side"""
+    from fidelityfusion_amd import kernel
+    S, P, part = kernel.SumKernel, kernel.ProductKernel, lambda nm: _pair_part(nm, D)
+    return {"s(p(ard,rq),lin)": lambda: S(P(part("ard"), part("rq")), part("lin")),
+            "p(m25,s(lin,se))": lambda: P(part("m25"), S(part("lin"), part("se"))),
+            "s(p(ard,m15),p(lin,se))": lambda: S(P(part("ard"), part("m15")), P(part("lin"), part("se"))),
+            "p(s(lin,m05),s(rq,ard))": lambda: P(S(part("lin"), part("m05")), S(part("rq"), part("ard"))),
+            "p(rq,s(ard,s(lin,m25)))": lambda: P(part("rq"), S(part("ard"), S(part("lin"), part("m25")))),
+            "s(p(s(lin,ard),m15),se)": lambda: S(P(S(part("lin"), part("ard")), part("m15")), part("se")),
+            "s(s(s(lin,lin),m25),rq)": lambda: S(S(S(part("lin"), part("lin")), part("m25")), part("rq"))}[shape]()
+
+
+@pytest.mark.parametrize("shape,D", [("s(p(ard,rq),lin)", 5), ("p(m25,s(lin,se))", 3), ("s(p(ard,m15),p(lin,se))", 5),
+                                     ("p(s(lin,m05),s(rq,ard))", 20), ("p(rq,s(ard,s(lin,m25)))", 4), ("s(p(s(lin,ard),m15),se)", 17),
+                                     ("s(s(s(lin,lin),m25),rq)", 2)])
+def test_nested_kernel_matches_composition(shape, D):
+    """nested Sum / Product objects (<= 4 leaves) through the single tile pass (ffgp_assemble_tree / ffgp_kernel_grad_tree /
+    ffgp_kernel_input_weights_tree) against the part-by-part composition as the reference evaluates it (kernel.py:172-236):
+    values bit-close, every parameter's gradient, both inputs' gradients, rectangular and symmetric calls"""
+    from fidelityfusion_amd import functional as F
+    rng = np.random.default_rng(D * 11 + len(shape))
+    k = _nested(shape, D).to(DEV)
+    pr = k.pair()
+    assert pr is not None and len(pr[0]) in (3, 4) and isinstance(pr[1], tuple)
+    x1, x2 = T(rng.standard_normal((131, D)) * 0.7), T(rng.standard_normal((70, D)) * 0.7)
+    dK = T(rng.standard_normal((131, 70)))
+    calls = {"rect": lambda m, a, b: m(a, b) * dK, "sym": lambda m, a, b: m(a, a) * (dK @ dK.T)}
+    for name, fn in calls.items():
+        res = []
+        for fuse in (True, False):
+            xa, xb = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+            val, gr = _pair_eval(k, lambda m: fn(m, xa, xb), fuse)
+            res.append((val, gr, xa.grad, xb.grad if name == "rect" else None))
+        (v1, g1, a1, b1), (v2, g2, a2, b2) = res
+        assert rel(v1, v2) < 1e-13, name
+        assert set(g1) == set(g2) and len(g1) >= 6
+        for n in g1:
+            assert rel(g1[n], g2[n]) < 1e-10, (name, n)
+        assert rel(a1, a2) < 1e-10 and (b1 is None or rel(b1, b2) < 1e-10), name
+    # more than four leaves: no fused form, the composition still evaluates (fused sub-trees inside)
+    from fidelityfusion_amd import kernel
+    big = kernel.SumKernel(_nested("s(p(ard,m15),p(lin,se))", D), _nested("s(p(ard,rq),lin)", D)).to(DEV)
+    assert big.pair() is None and big.kernel1.pair() is not None
+    assert rel(big(x1, x2), big.kernel1(x1, x2) + big.kernel2(x1, x2)) < 1e-14
+    with pytest.raises(ValueError):
+        F.kernel_pair(x1, x2, pr[0], F.FFGP_KOP_SUM)      # one operator for three / four descriptors
+
+
+def test_nested_goldens(golden):
+    """the reference's own numbers for nested compositions: cigp over Sum(Product(ARD, RQ), Linear) incl. the posterior and its
+    gradient w.r.t. the query points; gp_computation_pack over Sum(Product(ARD, Matern), Product(Linear, SE)) (mean(K) jitter);
+    GP_basic over Product(RQ, Sum(ARD, Sum(Linear, Matern))) (V2) -- all through ffgp_problem.tree"""
+    import fidelityfusion_amd.gp_computation_pack as gp_pack
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp
+    from fidelityfusion_amd.gp_basic import GP_basic
+    S, P = kernel.SumKernel, kernel.ProductKernel
+    g = golden("cigp_nested3")
+    m = cigp(S(P(kernel.ARDKernel(3), kernel.RationalQuadraticKernel()), kernel.LinearKernel(3)), 0.0)
+    want = _load_params(m, g)
+    m = m.to(DEV)
+    assert isinstance(m.kernel.pair()[1], tuple)
+    Y = T(g["Y"], grad=True)
+    ll = m.negative_log_likelihood(T(g["X"]), Y)
+    assert rel(ll, g["ll"]) < 1e-11
+    ll.backward()
+    assert rel(Y.grad, g["g_Y"]) < 1e-8
+    _check_param_grads(m, want)
+    Xs = T(g["Xs"], grad=True)
+    mean, var = m(T(g["X"]), Y.detach(), Xs)
+    assert rel(mean, g["mean"]) < 1e-8 and rel(var, g["var"]) < 1e-8
+    gXs, = torch.autograd.grad(mean.sum() + var.diagonal().sum(), Xs)
+    assert rel(gXs, g["g_Xs"]) < 1e-7
+
+    g = golden("pack_nested4_balanced")
+    k = S(P(kernel.ARDKernel(3), kernel.MaternKernel(3, nu=1.5)), P(kernel.LinearKernel(3), kernel.SquaredExponentialKernel()))
+    want = _load_params(k, g)
+    k = k.to(DEV)
+    assert k.pair()[1][0] == 1 and len(k.pair()[0]) == 4      # balanced
+    lb = T(g["log_beta"], grad=True)
+    Y = T(g["Y"], grad=True)
+    ll = gp_pack.negative_log_likelihood(k, lb, T(g["X"]), Y)
+    assert rel(ll, g["ll"]) < 1e-11
+    ll.backward()
+    assert rel(Y.grad, g["g_Y"]) < 1e-8 and rel(lb.grad, g["g_log_beta"]) < 1e-8
+    _check_param_grads(k, want)
+
+    g = golden("gpbasic_nested4_chain")
+    m = GP_basic(P(kernel.RationalQuadraticKernel(), S(kernel.ARDKernel(3), S(kernel.LinearKernel(3), kernel.MaternKernel(3)))), 0.1)
+    want = _load_params(m, g)
+    m = m.to(DEV)
+    assert m.kernel.pair()[1][0] == 0 and len(m.kernel.pair()[0]) == 4     # chain, deep operand swapped to the left
+    Y = T(g["Y"], grad=True)
+    ll = m.log_likelihood(T(g["X"]), Y)
+    assert tuple(ll.shape) == g["ll"].shape and rel(ll, g["ll"]) < 1e-11
+    ll.sum().backward()
+    assert rel(Y.grad, g["g_Y"]) < 1e-8
+    _check_param_grads(m, want)
+    with torch.no_grad():
+        mu, var = m(T(g["X"]), Y.detach(), T(g["Xs"]))
+    assert rel(mu, g["mu"]) < 1e-8 and rel(var, g["var"]) < 1e-8
+
+
+def test_pair_input_gradients_golden(golden):
+    """SumKernel(LinearKernel, MaternKernel)(x1, x2) -- the demo kernel -- differentiated w.r.t. both inputs by the fused pass,
+    against the reference's autograd"""
+    from fidelityfusion_amd import kernel
+    g = golden("pair_sum_linear_matern_xgrad")
+    k = kernel.SumKernel(kernel.LinearKernel(3), kernel.MaternKernel(3))
+    want = _load_params(k, g)
+    k = k.to(DEV)
+    x1, x2 = T(g["x1"], grad=True), T(g["x2"], grad=True)
+    K = k(x1, x2)
+    assert type(K.grad_fn).__name__.startswith("_KernelPair") and rel(K, g["K"]) < 1e-12
+    (K * T(g["R"])).sum().backward()
+    assert rel(x1.grad, g["g_x1"]) < 1e-9 and rel(x2.grad, g["g_x2"]) < 1e-9
+    _check_param_grads(k, want)
 
 
 @pytest.mark.parametrize("op", ["sum", "prod"])
@@ -554,6 +680,25 @@ def test_pair_under_no_grad_and_bad_descriptor():
     descs[1]["kfun"] = 9
     with pytest.raises(_lib.FFGPError):
         F.kernel_pair(X, X, descs, op)
+    # the plain two-descriptor C entry points (kept beside the tree form) and the tree validation
+    import ctypes as C
+    descs, op = m.kernel.pair()
+    keep = []
+    tree = F._pair_descs(X.device, 3, *F._pair_split(descs), keep, op)
+    h = _lib.handle(0)
+    K2, K3 = torch.empty(90, 90, device=DEV, dtype=torch.float64), torch.empty(90, 90, device=DEV, dtype=torch.float64)
+    args = (None, None, 0, None, 0, 0.0, 0.0)
+    assert _lib.lib.ffgp_assemble_pair(h, X.data_ptr(), 90, X.data_ptr(), 90, 3, tree.leaf, op, *args, K2.data_ptr(), 90, 0) == 0
+    assert _lib.lib.ffgp_assemble_tree(h, X.data_ptr(), 90, X.data_ptr(), 90, 3, C.byref(tree), *args, K3.data_ptr(), 90, 0) == 0
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        assert torch.equal(K2, K3) and rel(K2, m.kernel(X, X)) < 1e-14
+    for nl, shape, op0 in ((1, 0, 0), (5, 0, 0), (4, 2, 0), (2, 0, 7)):
+        bad = _lib.KTree()
+        bad.n_leaves, bad.shape, bad.leaf = nl, shape, tree.leaf
+        bad.op[0] = op0
+        rc = _lib.lib.ffgp_assemble_tree(h, X.data_ptr(), 90, X.data_ptr(), 90, 3, C.byref(bad), *args, K3.data_ptr(), 90, 0)
+        assert rc == -1, (nl, shape, op0)      # FFGP_ERR_ARG
 
 
 @pytest.mark.parametrize("tag,ls_,hs_", [("eq", (6,), (6,)), ("up", (6,), (9,)), ("two_mode", (3, 4), (3, 6))])

@@ -269,6 +269,81 @@ def test_cigp_sum_linear_matern(golden):
     close(var, g["var"], 1e-8)
 
 
+def _se_part(p):
+    return (lambda X: O.se_kernel(X, X, p["length_scale"], p["signal_variance"]),
+            lambda X, Gw: O.se_kernel_grads(X, p["length_scale"], p["signal_variance"], Gw))
+
+
+def _check_parts(g, prefixes, outs, tol=1e-8):
+    for pre, o in zip(prefixes, outs):
+        _, gr = _pg(g, pre)
+        assert gr, pre
+        for k in gr:
+            close(o[k], gr[k], tol)
+
+
+def test_nested_compositions(golden):
+    """nested Sum / Product kernels (kernel.py:172-236 compose arbitrary modules): three leaves under cigp, four leaves balanced
+    under gp_computation_pack (mean(K) jitter chain), four leaves as a right-deep chain under GP_basic (V2)"""
+    g = golden("cigp_nested3")      # Sum(Product(ARD, RQ), Linear)
+    pre = ["kernel__kernel1__kernel1__", "kernel__kernel1__kernel2__", "kernel__kernel2__"]
+    ps = [_pg(g, q)[0] for q in pre]
+    lb = g["p__log_beta"]
+    expr = ("sum", ("prod", 0, 1), 2)
+    ll, outs, dS, dY = O.composed_ll_and_grads(g["X"], g["Y"], [_ard_part(ps[0]), _rq_part(ps[1]), _lin_part(ps[2])], expr,
+                                               lambda K: O.sigma_cigp(K, lb), lambda dS, K: 0.0)
+    close(ll, g["ll"])
+    close(dY, g["g_Y"], 1e-8)
+    close(-np.exp(-lb[0]) * np.trace(dS), g["g__log_beta"], 1e-8)
+    _check_parts(g, pre, outs)
+    kf = lambda a, b: (O.ard_kernel(a, b, ps[0]["length_scales"], ps[0]["signal_variance"]) *
+                       O.rq_kernel(a, b, ps[1]["length_scale"], ps[1]["signal_variance"], ps[1]["alpha"]) +
+                       O.linear_kernel(a, b, ps[2]["length_scales"], ps[2]["signal_variance"], ps[2]["center"]))
+    mean, var = O.cigp_forward(g["X"], g["Y"], g["Xs"], kf, lb)
+    close(mean, g["mean"], 1e-8)
+    close(var, g["var"], 1e-8)
+
+    g = golden("pack_nested4_balanced")      # Sum(Product(ARD, Matern 1.5), Product(Linear, SE))
+    pre = ["kernel1__kernel1__", "kernel1__kernel2__", "kernel2__kernel1__", "kernel2__kernel2__"]
+    ps = [_pg(g, q)[0] for q in pre]
+    lb, n = g["log_beta"], g["X"].shape[0]
+    expr = ("sum", ("prod", 0, 1), ("prod", 2, 3))
+    ll, outs, dS, dY = O.composed_ll_and_grads(
+        g["X"], g["Y"], [_ard_part(ps[0]), _ard_part(ps[1], nu=1.5), _lin_part(ps[2]), _se_part(ps[3])], expr,
+        lambda K: O.sigma_pack(K, lb), lambda dS, K: O.JITTER * np.trace(dS) / (n * n))
+    close(ll, g["ll"])
+    close(dY, g["g_Y"], 1e-8)
+    close(-np.exp(-lb[0]) * np.trace(dS), g["g_log_beta"], 1e-8)
+    _check_parts(g, pre, outs)
+
+    g = golden("gpbasic_nested4_chain")      # Product(RQ, Sum(ARD, Sum(Linear, Matern 2.5)))
+    pre = ["kernel__kernel1__", "kernel__kernel2__kernel1__", "kernel__kernel2__kernel2__kernel1__", "kernel__kernel2__kernel2__kernel2__"]
+    ps = [_pg(g, q)[0] for q in pre]
+    nv = g["p__noise_variance"]
+    expr = ("prod", 0, ("sum", 1, ("sum", 2, 3)))
+    ll, outs, dS, dY = O.composed_ll_and_grads(
+        g["X"], g["Y"], [_rq_part(ps[0]), _ard_part(ps[1]), _lin_part(ps[2]), _ard_part(ps[3], nu=2.5)], expr,
+        lambda K: O.sigma_basic(K, nv), lambda dS, K: 0.0, variant="v2")
+    close(ll, g["ll"])
+    close(dY, g["g_Y"], 1e-8)
+    close(2.0 * nv[0] * np.trace(dS), g["g__noise_variance"], 1e-8)
+    _check_parts(g, pre, outs)
+
+
+def test_pair_input_gradients(golden):
+    """gradients of SumKernel(LinearKernel, MaternKernel)(x1, x2) w.r.t. both inputs for an upstream dK"""
+    g = golden("pair_sum_linear_matern_xgrad")
+    p1, _ = _pg(g, "kernel1__")
+    p2, _ = _pg(g, "kernel2__")
+    K = (O.linear_kernel(g["x1"], g["x2"], p1["length_scales"], p1["signal_variance"], p1["center"]) +
+         O.matern_kernel(g["x1"], g["x2"], p2["length_scales"], p2["signal_variance"], 2.5, 1.0))
+    close(K, g["K"], 1e-12)
+    a1, a2 = O.linear_input_grads(g["x1"], g["x2"], p1["length_scales"], p1["signal_variance"], p1["center"], g["R"])
+    b1, b2 = O.ard_input_grads(g["x1"], g["x2"], p2["length_scales"], p2["signal_variance"], g["R"], nu=2.5)
+    close(a1 + b1, g["g_x1"], 1e-9)
+    close(a2 + b2, g["g_x2"], 1e-9)
+
+
 def test_cigp_rq_yvar(golden):
     g = golden("cigp_rq_yvar")
     p, gr = _pg(g, "kernel__")
