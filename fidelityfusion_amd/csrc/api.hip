@@ -153,6 +153,9 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->nb_outer = 512;
   h->diag_v2 = 1;
   h->trtri_overlap = 1;
+  h->asm_mm = 1;
+  h->asm_mm_min = 6144;
+  h->asm_mm_grid = 768;
   const int rc = create_resources(h);
   if (rc != FFGP_OK) {   // release whatever was created before the failure
     ffgp_destroy(h);
@@ -183,6 +186,7 @@ int ffgp_destroy(ffgp_handle* h) {
     if (h->eig_ev[i]) hipEventDestroy(h->eig_ev[i]);
   if (h->d_info) hipFree(h->d_info);
   if (h->d_scal) hipFree(h->d_scal);
+  if (h->d_asm) hipFree(h->d_asm);
   if (h->h_info) hipHostFree(h->h_info);
   if (h->h_scal) hipHostFree(h->h_scal);
   for (int i = 0; i <= FFGP_MAX_STAGES; ++i)
@@ -254,6 +258,13 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     if (v != 0 && (v < 2 * FFGP_NB || (v & (v - 1)))) return FFGP_ERR_ARG;   // 0, or a power of two >= 256
     h->super_block = v;
     h->sinv_L = nullptr;
+  } else if (!strcmp(key, "asm_mm")) {
+    h->asm_mm = (int)value;
+  } else if (!strcmp(key, "asm_mm_grid")) {
+    if (value < 1) return FFGP_ERR_ARG;
+    h->asm_mm_grid = (int)value;
+  } else if (!strcmp(key, "asm_mm_min")) {
+    h->asm_mm_min = (int)value;
   } else if (!strcmp(key, "sb_lookahead")) {
     h->sb_lookahead = (int)value;
   } else if (!strcmp(key, "trtri_overlap")) {

@@ -176,6 +176,11 @@ struct ffgp_handle {
   int super_min_n;   // factors smaller than this keep the 128-block sweep
   int* d_info;       // device status word(s)
   double* d_scal;    // small device scalar scratch (64 doubles)
+  double* d_asm;     // assembly on the matrix cores: shifted + scaled inputs and their squared norms (n (D + 1) doubles)
+  size_t asm_bytes;
+  int asm_mm;        // option "asm_mm" (default 1): interior squared-exponential tiles through the MFMA chain
+  int asm_mm_grid;   // option "asm_mm_grid" (default 768 = 3 per CU): persistent workgroups of the matrix-core assembly
+  int asm_mm_min;    // option "asm_mm_min" (default 6144): geometric-mean size below which the difference kernel runs alone
   int* h_info;       // pinned host mirror
   double* h_scal;    // pinned host mirror
   // timing

@@ -188,7 +188,13 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
             "skinny_max_n" (default 8: products with at most this many output columns run on the matrix-vector kernels; 0 = never),
             "splitk_min_k" (default 1024: products with <= 64 tiles of 64 x 64 and k >= this are cut along k; 0 = never),
             "band_log2" (default 3: the GEMM tile order walks bands of 2^k tile rows, column-major inside a band),
-            "diag_dbg" (timing-only ablation mask of the diagonal-block kernel; results are wrong when non-zero)       */
+            "diag_dbg" (timing-only ablation mask of the diagonal-block kernel; results are wrong when non-zero),
+            "asm_mm" / "asm_mm_min" / "asm_mm_grid" (default 1 / 6144 / 768: squared-exponential assemblies whose geometric-mean size
+                        is at least asm_mm_min evaluate their interior 64 x 64 tiles on the matrix cores -- norm expansion, guarded
+                        per 32 x 32 block by a fall-back to the difference form wherever a distance is below 1e-6 of the
+                        squared norms -- with asm_mm_grid persistent workgroups; 0 = the difference kernel alone),
+            "trtri_overlap", "small_fused", "small_max_n", "chase_pack", "eig_overlap", "sb_lookahead" (round-3 experiment
+                        switches)                                                                  */
 int ffgp_set_option(ffgp_handle* h, const char* key, double value);
 const char* ffgp_version(void);
 

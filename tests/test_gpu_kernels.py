@@ -633,6 +633,81 @@ def test_eigh_small_backward_matches_torch():
     assert np.abs(g0 - 0.5 * (g1 + g1.T)).max() <= 1e-9 * np.abs(g1).max()
 
 
+def _asm_call(_lib, h, x1d, n1, x2d, n2, D, wd, ad, clamp, dd, dvd, add_all, mj, lower, opts):
+    for k, v in opts.items():
+        assert _lib.lib.ffgp_set_option(h, k.encode(), float(v)) == 0
+    K = torch.full((n1, n2), 555.0, dtype=torch.float64, device="cuda:0")
+    try:
+        rc = _lib.lib.ffgp_assemble(h, ptr(x1d), n1, ptr(x2d), n2, D, ptr(wd), ptr(ad), clamp, ptr(dd) if dd is not None else None,
+                                    ptr(dvd) if dvd is not None else None, 1, None, 0, add_all, mj, ptr(K), n2, lower, 0, 1.0)
+        assert rc == 0
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib.ffgp_set_option(h, b"asm_mm", 1.0)
+        _lib.lib.ffgp_set_option(h, b"asm_mm_min", 6144.0)
+        _lib.lib.ffgp_set_option(h, b"asm_mm_grid", 768.0)
+    return K
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n1,n2,D,lower,extras", [(640, 640, 16, 1, True), (640, 640, 16, 0, False), (709, 709, 5, 1, True), (710, 710, 5, 1, True), (1210, 840, 9, 0, False),
+                                                   (1000, 1000, 20, 0, True), (448, 448, 37, 1, False), (384, 333, 16, 0, False),
+                                                   (517, 1100, 3, 0, False), (2048, 2048, 128, 1, False)])
+def test_assemble_matrix_core_path(ff, n1, n2, D, lower, extras):
+    """interior squared-exponential tiles through the MFMA chain (norm expansion, operands in lane layout, persistent waves,
+    deferred stores) against the difference kernel: the diagonal tiles and every Sigma extra must agree exactly, interior entries
+    to the expansion's error eps * (|x_i|^2 + |x_j|^2); lower / full / rectangular sweeps, ragged edges, one to eight k-chunks,
+    the mean(K) jitter's tile sums, several persistent grid sizes"""
+    _lib, h = ff
+    rng = np.random.default_rng(n1 * 3 + n2 + D)
+    x1 = rng.random((n1, D)) * 2 + 5.0                      # (an offset: the kernel shifts by the first point)
+    sym = (n1 == n2)
+    x2 = x1 if sym else rng.random((n2, D)) * 2 + 5.0
+    w = (rng.random(D) + 0.3) / np.sqrt(D / 4.0)
+    x1d, wd, ad = dev(x1), dev(w), dev(np.array([1.3]))
+    x2d = x1d if sym else dev(x2)
+    dd = dev(np.array([0.37])) if extras else None
+    dvd = dev(rng.random(n1)) if extras else None
+    add_all, mj = (0.125, 1e-3) if extras else (0.0, 0.0)
+    clamp = 1e-30 if D != 5 else float("-inf")
+    ref = _asm_call(_lib, h, x1d, n1, x2d, n2, D, wd, ad, clamp, dd, dvd, add_all, mj, lower, {"asm_mm": 0})
+    for grid in (768, 5, 100000):
+        got = _asm_call(_lib, h, x1d, n1, x2d, n2, D, wd, ad, clamp, dd, dvd, add_all, mj, lower, {"asm_mm_min": 128, "asm_mm_grid": grid})
+        # scaled inputs are O(1) after the shift: the expansion's error in the distance is a few eps * |x|^2 ~ 1e-14
+        assert float((got - ref).abs().max()) < 3e-14 * 1.3, grid
+        if lower:
+            assert bool((got[torch.ones_like(got, dtype=torch.bool).triu(1)] == 555.0).all())
+        if sym:
+            for t in range(0, n1, 64):       # diagonal tiles: difference form in both launches -- the same bits but for the jitter's sum
+                blk = (slice(t, t + 64), slice(t, t + 64))
+                tol = 0.0 if mj == 0.0 else 1e-15
+                assert float((got[blk] - ref[blk]).abs().max()) <= tol
+    # the matrix-core launch really ran (and is not the same arithmetic): some interior entry differs in the last bits --
+    # except with an odd leading dimension, where its 16-byte stores are not possible and the difference kernel runs alone
+    assert torch.equal(got, ref) == (n2 % 2 == 1)
+
+
+@pytest.mark.gpu
+def test_assemble_matrix_core_near_coincident_points(ff):
+    """points that nearly coincide with another far-away row: the expansion would lose their distance (1e-18 against |x|^2 ~ 1);
+    the wave flags the tile and the second launch recomputes it in the difference form -- bit-identical to the difference kernel --
+    while unflagged tiles keep the matrix-core result"""
+    _lib, h = ff
+    rng = np.random.default_rng(77)
+    n, D = 1024, 8
+    x = rng.random((n, D)) * 2
+    x[900:910] = x[100:110] + 1e-9 * rng.standard_normal((10, D))       # tile (14, 1)
+    x[700] = x[3]                                                       # exact duplicate: tile (10, 0)
+    xd, wd, ad = dev(x), dev(np.ones(D)), dev(np.array([1.0]))
+    ref = _asm_call(_lib, h, xd, n, xd, n, D, wd, ad, 1e-30, None, None, 0.0, 0.0, 1, {"asm_mm": 0})
+    got = _asm_call(_lib, h, xd, n, xd, n, D, wd, ad, 1e-30, None, None, 0.0, 0.0, 1, {"asm_mm_min": 128})
+    for (ti, tj) in ((14, 1), (10, 0)):
+        blk = (slice(64 * ti, 64 * ti + 64), slice(64 * tj, 64 * tj + 64))
+        assert torch.equal(got[blk], ref[blk]), (ti, tj)
+    assert float(got[700, 3]) == 1.0 and abs(float(got[905, 105]) - 1.0) < 1e-16
+    assert float((got - ref).abs().max()) < 1e-14 and not torch.equal(got, ref)
+
+
 @pytest.mark.gpu
 def test_assembly_exp_range(ff):
     """the assembly's own exp (range reduction + degree-13 polynomial + ldexp) against torch over the whole argument range:

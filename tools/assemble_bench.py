@@ -11,6 +11,9 @@ dev = torch.device("cuda:0")
 h = _lib.handle(0)
 _lib.bind_stream(h, 0)
 p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+for kv in os.environ.get("FFGP_ASM_OPTS", "").split(","):     # e.g. FFGP_ASM_OPTS=asm_mm=0  or  asm_mm_grid=512
+    if kv:
+        _lib.check(_lib.lib.ffgp_set_option(h, kv.split("=")[0].encode(), float(kv.split("=")[1])), "ffgp_set_option")
 for nbytes in (1 << 31,):
     t = torch.empty(nbytes // 8, device=dev, dtype=torch.float64)
     ts = []
@@ -20,7 +23,7 @@ for nbytes in (1 << 31,):
         ts.append(e0.elapsed_time(e1))
     print("torch fill_ of %d MB: %.3f ms = %.2f TB/s written" % (nbytes >> 20, min(ts), nbytes / min(ts) / 1e9), flush=True)
     del t
-for (n, D, lower, pad) in [(16384, 16, 1, 0), (16384, 16, 0, 0), (8192, 8, 1, 0)]:
+for (n, D, lower, pad) in [(16384, 16, 1, 0), (16384, 16, 0, 0), (8192, 8, 1, 0)] + [(int(v), 8, 1, 0) for v in os.environ.get('FFGP_ASM_SIZES', '').split(',') if v]:
     g = torch.Generator(device=dev).manual_seed(0)
     X = torch.rand((n, D), generator=g, device=dev, dtype=torch.float64)
     w = torch.rand((D,), generator=g, device=dev, dtype=torch.float64) + 0.5
