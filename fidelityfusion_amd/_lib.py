@@ -118,6 +118,7 @@ EXPORTS = {
     "ffgp_potri": (C.c_int, [C.c_void_p, _dp, C.c_int, C.c_int]),
     "ffgp_nlml_fused": (C.c_int, [C.c_void_p, C.POINTER(Problem), _dp, C.POINTER(Grads)]),
     "ffgp_nlml_fused_raw": (C.c_int, [C.c_void_p, C.POINTER(Problem), C.POINTER(Links), _dp, C.POINTER(Grads)]),
+    "ffgp_nlml_fused_raw_async": (C.c_int, [C.c_void_p, C.POINTER(Problem), C.POINTER(Links), _dp, C.POINTER(Grads)]),
     "ffgp_nlml_fused_async": (C.c_int, [C.c_void_p, C.POINTER(Problem), _dp, C.POINTER(Grads)]),
     "ffgp_wait": (C.c_int, [C.c_void_p]),
     "ffgp_predict": (C.c_int, [C.c_void_p, C.POINTER(Problem), _dp, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int]),

@@ -553,6 +553,7 @@ int ffgp_assemble_impl(ffgp_handle* h, const double* X1, int n1, const double* X
       h->asm_bytes = 0;
       FFGP_HIP(hipMalloc(&h->d_asm, need));
       h->asm_bytes = need;
+      ++h->alloc_epoch;
     }
     AsmMM m;
     const int nflags = tm * a.tiles_n;

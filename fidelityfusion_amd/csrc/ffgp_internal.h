@@ -176,6 +176,10 @@ struct ffgp_handle {
   int super_min_n;   // factors smaller than this keep the 128-block sweep
   int* d_info;       // device status word(s)
   double* d_scal;    // small device scalar scratch (64 doubles)
+  // launch-bound sizes: the raw-parameter likelihood call replayed as a captured graph (api.hip, nlml_fused_raw_enqueue)
+  unsigned long alloc_epoch;   // bumped whenever one of the handle's device buffers is re-allocated (captured pointers go stale)
+  int raw_graph_max_n;         // option "raw_graph_max_n" (default 0 = never capture: measured no faster, see api.hip)
+  struct RawGraph* rawg;
   double* d_asm;     // assembly on the matrix cores: shifted + scaled inputs and their squared norms (n (D + 1) doubles)
   size_t asm_bytes;
   int asm_mm;        // option "asm_mm" (default 1): interior squared-exponential tiles through the MFMA chain
@@ -224,3 +228,6 @@ bool ffgp_small_ok(const ffgp_handle* h, const ffgp_problem* p, const ffgp_grads
 int ffgp_small_enqueue(ffgp_handle* h, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g);
 // ---- workspace
 int ffgp_ensure_ws(ffgp_handle* h, size_t bytes);
+// zero `bytes` (a multiple of 4) on the handle's stream with a kernel: small fills on the captured (graph) path go through this
+// instead of hipMemsetAsync, whose graph nodes replayed wrong values on this ROCm build; large ones keep the runtime's fill
+int ffgp_zero_async(ffgp_handle* h, void* ptr, size_t bytes);

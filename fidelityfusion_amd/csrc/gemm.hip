@@ -594,6 +594,7 @@ static int ensure_skw(ffgp_handle* h, size_t bytes) {
   const size_t want = (bytes + gran - 1) / gran * gran;
   if (hipMalloc(&h->skw, want) != hipSuccess) return FFGP_ERR_ALLOC;
   h->skw_bytes = want;
+  ++h->alloc_epoch;
   return FFGP_OK;
 }
 

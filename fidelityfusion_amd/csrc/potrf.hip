@@ -884,6 +884,7 @@ int ffgp_ensure_dinv(ffgp_handle* h, int n) {
     }
     h->dinv = fresh;
     h->dinv_bytes = want;
+    ++h->alloc_epoch;
   }
   return FFGP_OK;
 }
@@ -962,7 +963,7 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
     return FFGP_ERR_ARG;
   }
   FFGP_CHECK(ffgp_ensure_dinv(h, n));
-  FFGP_HIP(hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+  FFGP_CHECK(ffgp_zero_async(h, h->d_info, sizeof(int)));
   h->dinv_L = nullptr;
   h->sinv_L = nullptr;   // super-block inverses belong to the factor that is about to be overwritten
 

@@ -57,6 +57,7 @@ static int ensure_sinv_for(ffgp_handle* h, const double* L, int n, int ldl) {
     }
     h->sinv = fresh;
     h->sinv_bytes = want;
+    ++h->alloc_epoch;
   }
   double* Xc = h->sinv;
   double* T = h->sinv + (h->sinv_bytes / sizeof(double) - ((size_t)n * S / 4 + (size_t)S * S));   // scratch at the end of the buffer
@@ -110,6 +111,7 @@ static int ensure_tsw(ffgp_handle* h, size_t bytes) {
   const size_t want = (bytes + gran - 1) / gran * gran;
   if (hipMalloc(&h->tsw, want) != hipSuccess) return FFGP_ERR_ALLOC;
   h->tsw_bytes = want;
+  ++h->alloc_epoch;
   return FFGP_OK;
 }
 
@@ -263,7 +265,7 @@ static int trtri_levels(ffgp_handle* h, const double* L, int n, int ldl, double*
 
 int ffgp_trtri_impl(ffgp_handle* h, const double* L, int n, int ldl, double* X, int ldx, double* T) {
   FFGP_CHECK(ensure_dinv_for(h, L, n, ldl));
-  FFGP_HIP(hipMemsetAsync(X, 0, (size_t)n * ldx * sizeof(double), h->stream));
+  FFGP_CHECK(ffgp_zero_async(h, X, (size_t)n * ldx * sizeof(double)));
   const int nblk = (n + NB - 1) / NB;
   hipLaunchKernelGGL(ffgp_copy_dinv_kernel, dim3(NB * NB / 256, nblk), dim3(256), 0, h->stream, h->dinv, X, ldx, n);
   return trtri_levels(h, L, n, ldl, X, ldx, T);
@@ -276,7 +278,7 @@ int ffgp_trtri_impl(ffgp_handle* h, const double* L, int n, int ldl, double* X, 
 //   tail: X22 = L22^-1 and X21 = -X22 Ttop, after the factorisation.
 // The head reads the store of inverted diagonal blocks while the factorisation is still appending to it: blocks < n1 / 128 only.
 int ffgp_trtri_head(ffgp_handle* h, const double* L, int n, int ldl, double* X, int ldx, double* T, double* Ttop, int n1) {
-  FFGP_HIP(hipMemsetAsync(X, 0, (size_t)n * ldx * sizeof(double), h->stream));
+  FFGP_CHECK(ffgp_zero_async(h, X, (size_t)n * ldx * sizeof(double)));
   hipLaunchKernelGGL(ffgp_copy_dinv_kernel, dim3(NB * NB / 256, n1 / NB), dim3(256), 0, h->stream, h->dinv, X, ldx, n1);
   FFGP_CHECK(trtri_levels(h, L, n1, ldl, X, ldx, T));
   const int n2 = n - n1;

@@ -205,6 +205,25 @@ class _NLML(torch.autograd.Function):
                 None, None, None, None, None, None, fin("kparam", 5), None)
 
 
+DEFER_RAW_ERRORS = True
+"""A training step through the raw-parameter path (`nlml_raw`: everything GPU-resident, gradients requested) is ENQUEUED and its
+status collected in backward(): the host builds the backward pass while the GPU factors, which is most of a step at the sizes the
+reference's demos run.  Consequence: a Sigma that is not positive definite raises torch.linalg.LinAlgError from `loss.backward()`
+-- or from the next likelihood call on that device if backward() is never reached -- instead of from the likelihood call itself
+(the value is NaN meanwhile).  Calls under torch.no_grad(), CPU-resident tensors and every other path raise at the call, as
+torch.linalg.cholesky does.  False: always raise at the call."""
+
+_raw_pending = {}   # device index -> handle with an enqueued, not yet collected raw-parameter call
+
+
+def _settle_raw(dev_index):
+    h = _raw_pending.pop(dev_index, None)
+    if h is not None:
+        rc = check(lib.ffgp_wait(h), "ffgp_wait")
+        if rc > 0:
+            _raise_not_pd(rc, "linalg.cholesky")
+
+
 class _NLMLRaw(torch.autograd.Function):
     """sign * nll on the modules' RAW parameters (ffgp_nlml_fused_raw): the raw -> effective maps and their chain rule run inside the
     library call, so one training step is ONE autograd node and one library call instead of a dozen elementwise torch kernels
@@ -215,6 +234,8 @@ class _NLMLRaw(torch.autograd.Function):
     def forward(ctx, X, Y, rw, ramp, rdadd, diag_vec, add_mat, kparam, links, add_all, mean_jitter, clamp, variant, pi_const, kfun_id,
                 sign, rec, kp_const):
         dev = X.device
+        if dev.index in _raw_pending:
+            _settle_raw(dev.index)      # an earlier step never reached backward(): its status is due now
         h = _lib.handle(dev.index, 0)
         _lib.bind_stream(h, dev.index)
         n, D = X.shape
@@ -258,10 +279,16 @@ class _NLMLRaw(torch.autograd.Function):
             if nv:
                 g.g_diag_vec_dev = base + 8 * ov
         links.out_scale = sign          # the sign (+LL for the reference's `negative_log_likelihood`) is applied inside the call
-        rc = check(lib.ffgp_nlml_fused_raw(h, C.byref(p), C.byref(links), out.data_ptr(), C.byref(g) if g is not None else None),
-                   "ffgp_nlml_fused_raw")
-        if rc > 0:
-            _raise_not_pd(rc, "linalg.cholesky")
+        if g is not None and DEFER_RAW_ERRORS:
+            check(lib.ffgp_nlml_fused_raw_async(h, C.byref(p), C.byref(links), out.data_ptr(), C.byref(g)), "ffgp_nlml_fused_raw_async")
+            _raw_pending[dev.index] = h
+            ctx.dev_index = dev.index
+        else:
+            rc = check(lib.ffgp_nlml_fused_raw(h, C.byref(p), C.byref(links), out.data_ptr(), C.byref(g) if g is not None else None),
+                       "ffgp_nlml_fused_raw")
+            if rc > 0:
+                _raise_not_pd(rc, "linalg.cholesky")
+            ctx.dev_index = None
         ctx.pack = (buf, Dw, n, d, oY, ov, (nw, na, nd, nk, nY, nv), rw.shape, ramp.shape, None if rdadd is None else rdadd.shape,
                     None if diag_vec is None else diag_vec.shape, None if kparam is None else kparam.shape)
         return out
@@ -269,6 +296,8 @@ class _NLMLRaw(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         buf, Dw, n, d, oY, ov, (nw, na, nd, nk, nY, nv), sw, sa, sd, sv, sk = ctx.pack
+        if ctx.dev_index is not None:
+            _settle_raw(ctx.dev_index)
         gw = ga = gd = gk = gYo = gvo = None
         if buf is not None:
             sc = buf * gout

@@ -378,6 +378,9 @@ typedef struct {
                          reference's `negative_log_likelihood` returns (cigp_v10.py:69) without another elementwise kernel */
 } ffgp_links;
 int ffgp_nlml_fused_raw(ffgp_handle* h, const ffgp_problem* p, const ffgp_links* links, double* nll_dev, const ffgp_grads* g);
+/* the same call enqueued only: the status (a not-PD Sigma) is collected by the next ffgp_wait on this handle -- the Python modules
+   issue a training step's likelihood this way and collect in backward(), so the host prepares the backward pass while the GPU works */
+int ffgp_nlml_fused_raw_async(ffgp_handle* h, const ffgp_problem* p, const ffgp_links* links, double* nll_dev, const ffgp_grads* g);
 
 /* Same, enqueue only: returns as soon as the work is on the handle's stream (nll/gradients are valid after
    ffgp_wait).  With one handle + stream per block, independent GP blocks (the fidelities of one model, the seeds

@@ -664,6 +664,71 @@ def test_raw_parameter_path_other_modules(model, monkeypatch):
         assert rel(g1[k_], g2[k_]) < 1e-10, k_
 
 
+def test_raw_path_defers_not_pd_to_backward():
+    """a training step on GPU-resident tensors is enqueued and collected in backward(): a Sigma that is not positive definite raises
+    LinAlgError from loss.backward() (or from the next likelihood call if backward never runs); with DEFER_RAW_ERRORS off, and under
+    no_grad, the call itself raises as torch.linalg.cholesky does"""
+    from fidelityfusion_amd import functional as F
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp
+    rng = np.random.default_rng(5)
+    X, Y = T(rng.uniform(0, 1, (70, 2))), T(rng.standard_normal((70, 1)))
+    yv = -3.0 * torch.eye(70, device=DEV, dtype=torch.float64)
+    m = cigp(kernel.ARDKernel(2), 0.5).double().to(DEV)
+    assert F.raw_path(m.kernel, X, Y, m.log_beta) is not None
+    loss = m.negative_log_likelihood(X, [Y, yv])            # enqueued: no error yet
+    with pytest.raises(torch.linalg.LinAlgError):
+        loss.backward()
+    loss = m.negative_log_likelihood(X, [Y, yv])            # never reaches backward ...
+    with pytest.raises(torch.linalg.LinAlgError):
+        m.negative_log_likelihood(X, Y)                     # ... so the next call on the device reports it
+    ok = m.negative_log_likelihood(X, Y)                    # and the handle is clean afterwards
+    ok.backward()
+    assert torch.isfinite(ok) and torch.isfinite(m.log_beta.grad).all()
+    with torch.no_grad(), pytest.raises(torch.linalg.LinAlgError):
+        m.negative_log_likelihood(X, [Y, yv])
+    F.DEFER_RAW_ERRORS = False
+    try:
+        with pytest.raises(torch.linalg.LinAlgError):
+            m.negative_log_likelihood(X, [Y, yv])
+    finally:
+        F.DEFER_RAW_ERRORS = True
+
+
+def test_raw_graph_replay():
+    """option raw_graph_max_n: the third identical raw-parameter call replays a captured graph (off by default -- no faster on this
+    runtime); values and gradients are bit-identical, a changed input or option drops the graph"""
+    from fidelityfusion_amd import _lib, kernel
+    from fidelityfusion_amd.cigp_v10 import cigp
+    rng = np.random.default_rng(6)
+    X, Y = T(rng.uniform(0, 1, (150, 3))), T(rng.standard_normal((150, 2)))
+    m = cigp(kernel.ARDKernel(3), 0.8).double().to(DEV)
+    h = _lib.handle(0)
+
+    def step(x):
+        for p_ in m.parameters():
+            p_.grad = None
+        v = m.negative_log_likelihood(x, Y)
+        v.backward()
+        return v.detach().clone(), [p_.grad.clone() for p_ in m.parameters()]
+
+    ref = step(X)
+    X2 = X.clone() * 0.9
+    ref2 = step(X2)
+    assert _lib.lib.ffgp_set_option(h, b"raw_graph_max_n", 1024.0) == 0
+    try:
+        for i in range(4):                       # plain, capture + launch, replay, replay
+            v, gr = step(X)
+            assert torch.equal(v, ref[0]) and all(torch.equal(a, b) for a, b in zip(gr, ref[1])), i
+        v, gr = step(X2)                         # other inputs: the graph is dropped, not replayed on them
+        assert torch.equal(v, ref2[0]) and all(torch.equal(a, b) for a, b in zip(gr, ref2[1]))
+        for i in range(3):
+            v, gr = step(X)
+            assert torch.equal(v, ref[0]) and all(torch.equal(a, b) for a, b in zip(gr, ref[1])), i
+    finally:
+        _lib.lib.ffgp_set_option(h, b"raw_graph_max_n", 0.0)
+
+
 def test_pair_under_no_grad_and_bad_descriptor():
     """no_grad: no gradient pipeline; a descriptor outside the enum is refused by the library (FFGP_ERR_ARG), not run"""
     from fidelityfusion_amd import _lib, kernel
@@ -1918,7 +1983,11 @@ def test_no_grad_evaluation_skips_the_gradient_pipeline(monkeypatch):
         def ffgp_nlml_fused_raw(self, h, p, l, out, g):   # (the raw-parameter path of GPU-resident fp64 modules)
             seen.append(g is not None)
             return real_raw(h, p, l, out, g)
-    real_raw = F.lib.ffgp_nlml_fused_raw
+
+        def ffgp_nlml_fused_raw_async(self, h, p, l, out, g):   # (... enqueued when gradients are requested)
+            seen.append(g is not None)
+            return real_raw_async(h, p, l, out, g)
+    real_raw, real_raw_async = F.lib.ffgp_nlml_fused_raw, F.lib.ffgp_nlml_fused_raw_async
     monkeypatch.setattr(F, "lib", _Spy())
     gen = torch.Generator().manual_seed(3)
     X = torch.rand((200, 3), generator=gen, dtype=torch.float64).to(DEV)
