@@ -45,8 +45,11 @@ class cigp(F.PosteriorCacheMixin, nn.Module):
         (acquisition loops, serving) cost one TRSM sweep here instead of N^3/3."""
         def build():
             with torch.no_grad():
-                w, amp, clamp = self.kernel.effective()
                 noise = self.log_beta.exp().pow(-1)
+                if not hasattr(self.kernel, "effective"):      # SumKernel / ProductKernel over library kernels: descriptor tree
+                    return F.Posterior(x_train, y_train, None, None, noise.double() + JITTER, first_query=first_query,
+                                       var_add_all=var_add_all, tree=self.kernel.pair())
+                w, amp, clamp = self.kernel.effective()
                 return F.Posterior(x_train, y_train, w, amp, noise.double() + JITTER, clamp=clamp, kfun=_kfun(self.kernel),
                                    first_query=first_query, var_add_all=var_add_all)
         return self._pcache.get([x_train, y_train] + list(self.parameters()), build)
@@ -54,7 +57,8 @@ class cigp(F.PosteriorCacheMixin, nn.Module):
     def forward(self, x_train, y_train, x_test):
         y_train, _ = _split(y_train)
         odt = y_train.dtype if y_train.dtype.is_floating_point else torch.float64
-        fused = hasattr(self.kernel, "effective")
+        # one (w, amp, profile) kernel, or a composition of library kernels the tile pass evaluates (the demos' SumKernel(Linear, Matern))
+        fused = hasattr(self.kernel, "effective") or (hasattr(self.kernel, "fusable") and self.kernel.fusable())
         if fused and torch.is_grad_enabled() and not (x_train.requires_grad or y_train.requires_grad
                                                       or any(p.requires_grad for p in self.parameters())):
             # autograd on, model frozen (`model.requires_grad_(False)`): only the query points can want gradients -- the
@@ -83,7 +87,8 @@ class cigp(F.PosteriorCacheMixin, nn.Module):
         K_ss = F.kernel_on_device(self.kernel, x_test, x_test)
         # a trainable model queried again and again with unchanged parameters (an acquisition loop that never froze it):
         # the factor of Sigma is the cached one, only the backward formulas run -- gradients still reach the parameters and y
-        post = self._cached_posterior(x_train, y_train)[0] if hasattr(self.kernel, "effective") else None
+        fused = hasattr(self.kernel, "effective") or (hasattr(self.kernel, "fusable") and self.kernel.fusable())
+        post = self._cached_posterior(x_train, y_train)[0] if fused else None
         mean, var = F.conditional_gaussian(y_train, Sigma, K_s, K_ss, factor=post)
         var = var + noise.to(var.device)
         odt = y_train.dtype if y_train.dtype.is_floating_point else torch.float64

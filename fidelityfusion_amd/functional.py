@@ -1118,14 +1118,15 @@ class Posterior:
         predict(Xs)      assembly of K_s, one TRSM sweep on the cached factor (N^2 nt), two thin GEMMs
         append(X, Y)     L21 = (L^-1 K_nk)^T, L22 = chol(S_kk - L21 L21^T): O(N^2 k) instead of O(N^3 / 3)
 
-    Parameters are the library's effective ones (w, amp, diag_add, clamp, kfun), frozen at construction."""
+    Parameters are the library's effective ones (w, amp, diag_add, clamp, kfun), frozen at construction -- or, for a composed
+    kernel (SumKernel / ProductKernel over library kernels, `kernel._Pair.pair()`), `tree = (descriptors, operator spec)`."""
 
     def __init__(self, X, Y, w, amp, diag_add, clamp=NEG_INF, kfun=(0, 1.0), capacity=None, first_query=None,
-                 var_add_all=0.0):
+                 var_add_all=0.0, tree=None):
         """first_query (optional [nt, D]): its K_s^T rides, with Y^T, as passenger rows of the factorisation itself, so
         the first answer (`self.first` = (mean, covariance)) costs what the fused one-shot posterior costs; the rows
         below the factor are scratch afterwards (later appends overwrite them)."""
-        dev = _device_of(X, Y, w, amp)
+        dev = _device_of(X, Y, w if tree is None else tree[0][0]["w"])
         self.dev = dev
         self.kfun, _ = _split_kfun(kfun)
         self.clamp = clamp
@@ -1133,8 +1134,17 @@ class Posterior:
         _check_xy(Xd, Yd)
         n, D = Xd.shape
         d = Yd.shape[1]
-        self.w = _weights(w, D, dev)
-        self.amp = _dev(amp.reshape(-1)[:1], dev)
+        self.tree = None
+        if tree is not None:
+            # frozen copies of the leaves' effective quantities on the device; the ctypes tree lives as long as this object
+            descs = [{k: (_dev(v.detach(), dev).clone() if isinstance(v, torch.Tensor) else v) for k, v in dsc.items()} for dsc in tree[0]]
+            meta, tensors = _pair_split(descs)
+            self._tree_keep = []
+            self.tree = (descs, tree[1], _pair_descs(dev, D, meta, tensors, self._tree_keep, tree[1]))
+            self.w = self.amp = None
+        else:
+            self.w = _weights(w, D, dev)
+            self.amp = _dev(amp.reshape(-1)[:1], dev)
         self.dadd = _dev(diag_add.reshape(-1)[:1], dev)
         Xq = _dev(first_query, dev) if first_query is not None else None
         if Xq is not None:
@@ -1172,6 +1182,11 @@ class Posterior:
         return h
 
     def _assemble(self, A, B, out, ld, lower, diag):
+        if self.tree is not None:
+            check(lib.ffgp_assemble_tree(self._h(), _ptr(A), A.shape[0], _ptr(B), B.shape[0], self.D, C.byref(self.tree[2]),
+                                         _ptr(self.dadd) if diag else None, None, 0, None, 0, 0.0, 0.0, _ptr(out), ld, lower),
+                  "ffgp_assemble_tree")
+            return
         check(lib.ffgp_assemble(self._h(), _ptr(A), A.shape[0], _ptr(B), B.shape[0], self.D, _ptr(self.w), _ptr(self.amp),
                                 self.clamp, _ptr(self.dadd) if diag else None, None, 0, None, 0, 0.0, 0.0, _ptr(out), ld, lower,
                                 int(self.kfun[0]), float(self.kfun[1])), "ffgp_assemble")
@@ -1199,9 +1214,17 @@ class Posterior:
             var = torch.empty((nt, nt), dtype=torch.float64, device=dev)
             self._assemble(Xsd, Xsd, var, nt, lower=0, diag=False)
             var = var - _gemm(dev, 1, 1, Ks, Ks, nt, nt, n, 1.0) + var_add_all
+        elif self.tree is not None:
+            var = self._kernel(Xsd, Xsd).diagonal() - (Ks * Ks).sum(0) + var_add_all
         else:
             var = float(self.amp) - (Ks * Ks).sum(0) + var_add_all      # phi(0) = 1 for every radial profile
         return mean, var
+
+    def _kernel(self, a, b):
+        """the frozen kernel as a differentiable call (w.r.t. a, b)"""
+        if self.tree is not None:
+            return kernel_pair(a, b, self.tree[0], self.tree[1])
+        return kernel_matrix(a, b, self.w, self.amp, self.clamp, kfun=self.kfun)
 
     def predict_diff(self, Xs, full_cov=True, var_add_all=0.0):
         """`predict` with autograd w.r.t. the query points: K_s and K_ss come from the differentiable kernel call, the
@@ -1210,9 +1233,11 @@ class Posterior:
         dev, n = self.dev, self.n
         Xsd = Xs.to(device=dev, dtype=torch.float64)
         _check_same_D(self.X, Xsd)
-        Ks = kernel_matrix(self.X[:n], Xsd, self.w, self.amp, self.clamp, kfun=self.kfun)
+        Ks = self._kernel(self.X[:n], Xsd)
         if full_cov:
-            Kss = kernel_matrix(Xsd, Xsd, self.w, self.amp, self.clamp, kfun=self.kfun)
+            Kss = self._kernel(Xsd, Xsd)
+        elif self.tree is not None:
+            Kss = self._kernel(Xsd, Xsd).diagonal()
         else:
             Kss = self.amp.expand(Xsd.shape[0])                  # phi(0) = 1 for every radial profile
         mean, var = _PosteriorQuery.apply(self, Ks, Kss, full_cov)

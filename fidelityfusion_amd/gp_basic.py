@@ -36,8 +36,16 @@ class GP_basic(F.PosteriorCacheMixin, nn.Module):
     def forward(self, x_train, y_train, x_test, Kinv_method="cholesky3"):
         _check_method(Kinv_method, (), _METHODS_FWD)   # three spellings of the same posterior (:66-88)
         y_train, y_var = _split(y_train)
-        if not hasattr(self.kernel, "effective") or torch.is_grad_enabled():   # autograd on: differentiable composition
-            return self._forward_composed(x_train, y_train, y_var, x_test)
+        tree = hasattr(self.kernel, "fusable") and self.kernel.fusable()   # Sum / Product over library kernels: descriptor tree
+        if not (hasattr(self.kernel, "effective") or (tree and y_var is None)) or torch.is_grad_enabled():
+            return self._forward_composed(x_train, y_train, y_var, x_test)      # autograd on: differentiable composition
+        if tree:
+            def build():
+                return F.Posterior(x_train, y_train, None, None, self.noise_variance.pow(2), first_query=x_test, tree=self.kernel.pair())
+            post, fresh = self._pcache.get([x_train, y_train] + list(self.parameters()), build)
+            mu, var = post.first if fresh else post.predict(x_test, full_cov=True)
+            odt = y_train.dtype if y_train.dtype.is_floating_point else torch.float64
+            return mu.to(device=y_train.device, dtype=odt).squeeze(), var.to(device=y_train.device, dtype=odt)
         w, amp, clamp = self.kernel.effective()
         if y_var is not None:
             mu, var = F.predict(x_train, y_train, x_test, w, amp, diag_add=self.noise_variance.pow(2), add_mat=y_var,
@@ -65,11 +73,14 @@ class GP_basic(F.PosteriorCacheMixin, nn.Module):
         K_s = F.kernel_on_device(self.kernel, x_train, x_test)
         K_ss = F.kernel_on_device(self.kernel, x_test, x_test)
         post = None
-        if y_var is None and hasattr(self.kernel, "effective"):
+        tree = hasattr(self.kernel, "fusable") and self.kernel.fusable()
+        if y_var is None and (hasattr(self.kernel, "effective") or tree):
             # asked again with unchanged parameters (an acquisition loop): the factor of Sigma is the cached one and only the
             # closed-form backward runs; gradients reach the parameters and y as before
             def build():
                 with torch.no_grad():
+                    if tree:
+                        return F.Posterior(x_train, y_train, None, None, self.noise_variance.pow(2), tree=self.kernel.pair())
                     w, amp, clamp = self.kernel.effective()
                     return F.Posterior(x_train, y_train, w, amp, self.noise_variance.pow(2), clamp=clamp, kfun=_kfun(self.kernel))
             post, _ = self._pcache.get([x_train, y_train] + list(self.parameters()), build)

@@ -182,6 +182,10 @@ class _Pair(nn.Module):
             return descs, form[1][0]
         return descs, form
 
+    def fusable(self):
+        """`pair()` would return descriptors (checked on the module structure alone: no tensor is touched)"""
+        return FUSE_PAIRS and _flatten(self) is not None
+
     def forward(self, x1, x2):
         pr = self.pair()
         if pr is not None and x1.dim() == 2 and x2.dim() == 2:

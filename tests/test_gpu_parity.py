@@ -442,6 +442,67 @@ def test_nested_goldens(golden):
     assert rel(mu, g["mu"]) < 1e-8 and rel(var, g["var"]) < 1e-8
 
 
+def test_composed_kernel_posterior_is_cached(golden):
+    """a trained model over SumKernel / ProductKernel compositions keeps its factor between predictions (F.Posterior with a
+    descriptor tree): first query riding in the factorisation, later queries one TRSM sweep, the frozen-model query differentiable
+    w.r.t. the query points, appended points -- all against the reference's numbers (`cigp_nested3`, `gpbasic_nested4_chain`)"""
+    from fidelityfusion_amd import functional as F
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp
+    from fidelityfusion_amd.gp_basic import GP_basic
+    S, P = kernel.SumKernel, kernel.ProductKernel
+    g = golden("cigp_nested3")
+    m = cigp(S(P(kernel.ARDKernel(3), kernel.RationalQuadraticKernel()), kernel.LinearKernel(3)), 0.0)
+    _load_params(m, g)
+    m = m.to(DEV)
+    X, Y, Xs = T(g["X"]), T(g["Y"]), T(g["Xs"])
+    calls = []
+    real = F.lib.ffgp_potrf_rows
+
+    class _Spy:
+        def __getattr__(self, name):
+            return getattr(F._lib.lib, name)
+
+        def ffgp_potrf_rows(self, *a):
+            calls.append(1)
+            return real(*a)
+    F.lib, keep = _Spy(), F.lib
+    try:
+        with torch.no_grad():
+            m1, v1 = m(X, Y, Xs)                  # factorises (K_s^T rides along)
+            m2, v2 = m(X, Y, Xs[:7])              # cached factor
+            m3, v3 = m(X, Y, Xs)
+        assert len(calls) == 1 and isinstance(m._pcache.posterior, F.Posterior) and m._pcache.posterior.tree is not None
+        assert rel(m1, g["mean"]) < 1e-8 and rel(v1, g["var"]) < 1e-8 and rel(m3, m1) < 1e-11 and rel(v3, v1) < 1e-9
+        assert rel(m2, g["mean"][:7]) < 1e-8 and rel(v2, g["var"][:7, :7]) < 1e-8
+        mq, vq = m._pcache.posterior.predict(Xs, full_cov=False)
+        assert rel(vq + float(m.log_beta.detach().exp().pow(-1)), np.diag(g["var"])) < 1e-8
+        # frozen model, autograd on: only the query points carry gradients; the factor stays the cached one
+        m.requires_grad_(False)
+        xq = Xs.clone().requires_grad_(True)
+        mean, var = m(X, Y, xq)
+        gx, = torch.autograd.grad(mean.sum() + var.diagonal().sum(), xq)
+        assert rel(gx, g["g_Xs"]) < 1e-7 and len(calls) == 1      # (freezing bumps no version counter: still the first factor)
+    finally:
+        F.lib = keep
+    # appended points: the extended factor answers like a fresh one
+    post = F.Posterior(X[:80], Y[:80], None, None, torch.tensor([0.3]), tree=m.kernel.pair())
+    post.append(X[80:], Y[80:])
+    full = F.Posterior(X, Y, None, None, torch.tensor([0.3]), tree=m.kernel.pair())
+    a, b = post.predict(Xs), full.predict(Xs)
+    assert rel(a[0], b[0]) < 1e-10 and rel(a[1], b[1]) < 1e-9
+
+    g = golden("gpbasic_nested4_chain")
+    mb = GP_basic(P(kernel.RationalQuadraticKernel(), S(kernel.ARDKernel(3), S(kernel.LinearKernel(3), kernel.MaternKernel(3)))), 0.1)
+    _load_params(mb, g)
+    mb = mb.to(DEV)
+    with torch.no_grad():
+        mu1, c1 = mb(T(g["X"]), T(g["Y"]), T(g["Xs"]))
+        mu2, c2 = mb(T(g["X"]), T(g["Y"]), T(g["Xs"]))
+    assert rel(mu1, g["mu"]) < 1e-8 and rel(c1, g["var"]) < 1e-8 and rel(mu2, g["mu"]) < 1e-8 and rel(c2, g["var"]) < 1e-8
+    assert mb._pcache.posterior is not None and mb._pcache.posterior.tree is not None
+
+
 def test_pair_input_gradients_golden(golden):
     """SumKernel(LinearKernel, MaternKernel)(x1, x2) -- the demo kernel -- differentiated w.r.t. both inputs by the fused pass,
     against the reference's autograd"""
