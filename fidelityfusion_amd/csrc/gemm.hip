@@ -609,6 +609,10 @@ struct SkinnyArgs {
   const double* B;
   double* C;
   int m, n, k, lda, ldb, ldc, opb;
+  int kc;            // k range per blockIdx.y (gridDim.y parts, partial results sP doubles apart; kc >= k: one part)
+  long sP;
+  int klo;           // 1: row r of op(A) is structurally zero for k < r (a lower-triangular factor read as op(A)^T ...): the k loop starts there
+  int ldcj;          // stride between the (<= 8) output columns: 1 for C[m x n], ldc of the caller for the transposed use
   double alpha, beta;
 };
 
@@ -622,13 +626,14 @@ __global__ __launch_bounds__(256) void ffgp_skinny_kmajor(SkinnyArgs p) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p.m) return;
   const double* __restrict__ a = p.A + (size_t)row * p.lda;
+  const int kbeg = blockIdx.y * p.kc, kend = min(p.k, kbeg + p.kc);     // (kc is even)
   double acc[NC];
 #pragma unroll
   for (int j = 0; j < NC; ++j) acc[j] = 0.0;
 #pragma unroll 4
-  for (int k0 = lane * 2; k0 < p.k; k0 += 128) {
+  for (int k0 = max(kbeg, p.klo ? (row & ~127) : 0) + lane * 2; k0 < kend; k0 += 128) {
     const double a0 = a[k0];
-    const bool two = k0 + 1 < p.k;
+    const bool two = k0 + 1 < kend;
     const double a1 = two ? a[k0 + 1] : 0.0;
 #pragma unroll
     for (int j = 0; j < NC; ++j)
@@ -644,7 +649,7 @@ __global__ __launch_bounds__(256) void ffgp_skinny_kmajor(SkinnyArgs p) {
 #pragma unroll
     for (int j = 0; j < NC; ++j)
       if (j < p.n) {
-        double* dst = p.C + (size_t)row * p.ldc + j;
+        double* dst = p.C + blockIdx.y * p.sP + (size_t)row * p.ldc + (size_t)j * p.ldcj;
         *dst = (p.beta != 0.0) ? p.alpha * acc[j] + p.beta * *dst : p.alpha * acc[j];
       }
   }
@@ -655,8 +660,10 @@ __global__ __launch_bounds__(512) void ffgp_skinny_mnmajor(SkinnyArgs p) {
   __shared__ double red[8][NC][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int row = blockIdx.x * 64 + lane;
-  const int kchunk = (p.k + 7) / 8;
-  const int kb = w * kchunk, ke = min(p.k, kb + kchunk);
+  const int kbeg = blockIdx.y * p.kc, kend = min(p.k, kbeg + p.kc);
+  const int k00 = max(kbeg, p.klo ? (int)blockIdx.x * 64 : 0);           // (klo: the workgroup's first row)
+  const int kchunk = (max(kend - k00, 0) + 7) / 8;
+  const int kb = k00 + w * kchunk, ke = min(kend, kb + kchunk);
   double acc[NC];
 #pragma unroll
   for (int j = 0; j < NC; ++j) acc[j] = 0.0;
@@ -680,18 +687,18 @@ __global__ __launch_bounds__(512) void ffgp_skinny_mnmajor(SkinnyArgs p) {
         double s = 0.0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) s += red[q][j][lane];
-        double* dst = p.C + (size_t)row * p.ldc + j;
+        double* dst = p.C + blockIdx.y * p.sP + (size_t)row * p.ldc + (size_t)j * p.ldcj;
         *dst = (p.beta != 0.0) ? p.alpha * s + p.beta * *dst : p.alpha * s;
       }
   }
 }
 
 template <int NC>
-static void launch_skinny(ffgp_handle* h, int opa, const SkinnyArgs& a) {
+static void launch_skinny(ffgp_handle* h, int opa, const SkinnyArgs& a, int parts = 1) {
   if (opa == OP_KMAJOR)
-    hipLaunchKernelGGL(ffgp_skinny_kmajor<NC>, dim3((a.m + 3) / 4), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL(ffgp_skinny_kmajor<NC>, dim3((a.m + 3) / 4, parts), dim3(256), 0, h->stream, a);
   else
-    hipLaunchKernelGGL(ffgp_skinny_mnmajor<NC>, dim3((a.m + 63) / 64), dim3(512), 0, h->stream, a);
+    hipLaunchKernelGGL(ffgp_skinny_mnmajor<NC>, dim3((a.m + 63) / 64, parts), dim3(512), 0, h->stream, a);
 }
 
 // alias: 0 = C aliases neither operand; ALIAS_A = C is A's buffer (row-wise in place: needs ONE column tile so
@@ -708,6 +715,48 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   if (mode == TILES_LOWER && m < n) return FFGP_ERR_ARG;
   if (alias == ALIAS_A && (n > 128 || mode != TILES_FULL)) return FFGP_ERR_ARG;
   if (alias == ALIAS_B && (m > 128 || mode != TILES_FULL)) return FFGP_ERR_ARG;
+  // few output ROWS (single-output GPs: A^T = Gamma^T L^-1, 1 x n): the transposed matrix-vector product -- C^T = op(B)^T op(A)^T
+  // reads B once with the rows of C^T across the lanes; on the 64 x 64 tile the launch above cost 0.21 ms at n = k = 4096
+  // (0.6 TB/s of B) inside every training step of a d = 1 model
+  if (h->skinny_max_n > 0 && m <= h->skinny_max_n && m <= 8 && n > 8 && alias == 0 && batch <= 1 && (tri == 0 || tri == TRI_LO_J) &&
+      mode == TILES_FULL && !syrk_tag && h->stream != h->aux) {
+    SkinnyArgs sk = {};
+    sk.A = B; sk.B = A; sk.C = C;
+    sk.m = n; sk.n = m; sk.k = k;
+    sk.lda = ldb; sk.ldb = lda; sk.ldc = 1; sk.ldcj = ldc;
+    sk.klo = (tri == TRI_LO_J) ? 1 : 0;      // op(B)(k, c) = 0 for k < c: row c of the transposed operand starts at k = c
+    sk.opb = (opa == OP_KMAJOR) ? OP_KMAJOR : OP_MNMAJOR;   // op(A)^T (k x m): element (kk, j) at A[j * lda + kk] for a K-major A
+    sk.alpha = alpha; sk.beta = beta;
+    sk.kc = k + 1; sk.sP = 0;
+    const int opa_t = (opb == OP_MNMAJOR) ? OP_MNMAJOR : OP_KMAJOR;   // op(B)^T (n x k): row c, column kk at B[kk * ldb + c] for an MN-major B
+    // lanes-across-rows launches have n / 64 workgroups: cut k as well until the chip is full (partials + a fixed-order reduction)
+    int parts = 1;
+    if (opa_t == OP_MNMAJOR) {
+      const int wg = (n + 63) / 64;
+      parts = max(1, min(min((512 + wg - 1) / wg, k / 256), 16));
+    }
+    if (parts >= 2) {
+      const int ldp = (n + 1) & ~1;
+      const long sP = (long)m * ldp;
+      FFGP_CHECK(ensure_skw(h, (size_t)parts * sP * sizeof(double)));
+      sk.C = h->skw;
+      sk.ldcj = ldp;
+      sk.kc = ((k + parts - 1) / parts + 1) & ~1;
+      sk.sP = sP;
+      sk.beta = 0.0;
+      parts = (k + sk.kc - 1) / sk.kc;
+    }
+    if (m == 1) launch_skinny<1>(h, opa_t, sk, parts);
+    else if (m == 2) launch_skinny<2>(h, opa_t, sk, parts);
+    else if (m <= 4) launch_skinny<4>(h, opa_t, sk, parts);
+    else launch_skinny<8>(h, opa_t, sk, parts);
+    if (parts >= 2) {
+      const long total = (long)m * n;
+      hipLaunchKernelGGL(ffgp_splitk_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->skw, sk.ldcj, sk.sP, parts, C,
+                         ldc, m, n, beta);
+    }
+    return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
+  }
   if (h->splitk_min_k > 0 && alias == 0 && batch <= 1 && tri == 0 && mode == TILES_FULL && !syrk_tag && k >= h->splitk_min_k &&
       h->stream != h->aux) {
     const int t64 = ((m + 63) / 64) * ((n + 63) / 64);
@@ -744,6 +793,9 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
     sk.A = A; sk.B = B; sk.C = C;
     sk.m = m; sk.n = n; sk.k = k;
     sk.lda = lda; sk.ldb = ldb; sk.ldc = ldc; sk.opb = opb;
+    sk.ldcj = 1;
+    sk.klo = 0;
+    sk.kc = k + 1; sk.sP = 0;
     sk.alpha = alpha; sk.beta = beta;
     if (n == 1) launch_skinny<1>(h, opa, sk);
     else if (n == 2) launch_skinny<2>(h, opa, sk);

@@ -143,6 +143,28 @@ def test_gemm_split_tail(ff, case):
 
 
 @pytest.mark.parametrize("opa,opb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("m,n,k", [(1, 4096, 4096), (1, 1000, 333), (3, 517, 2100), (8, 129, 64), (5, 9, 7), (2, 70, 5000)])
+def test_gemm_few_output_rows(ff, opa, opb, m, n, k):
+    """C[m x n] with m <= 8 (A^T = Gamma^T L^-1 of a single-output GP) runs as the transposed matrix-vector product: every
+    operand layout, alpha / beta, padded leading dimensions left untouched, beta == 0 never reads C"""
+    rng = np.random.default_rng(m + 5 * n + k + opa * 2 + opb)
+    A = rng.standard_normal((m, k))
+    B = rng.standard_normal((k, n))
+    C0 = rng.standard_normal((m, n))
+    scale = (np.abs(A) @ np.abs(B)).max()
+    out = run_gemm(ff, opa, opb, 0, 0, A, B, C0, -1.0, 1.0, pad=(2, 4, 6))
+    assert np.abs(out - (C0 - A @ B)).max() <= 1e-14 * scale * np.sqrt(k)
+    out = run_gemm(ff, opa, opb, 0, 0, A, B, np.full((m, n), np.nan), 2.0, 0.0)
+    assert np.abs(out - 2.0 * A @ B).max() <= 2e-14 * scale * np.sqrt(k)
+    out2 = run_gemm(ff, opa, opb, 0, 0, A, B, np.full((m, n), np.nan), 2.0, 0.0)
+    assert np.array_equal(out, out2)
+    # TRI_LO_J: op(B)(k, j) = 0 for k < j (the inverse factor L^-1 of the likelihood's backward): the k loop may start at j
+    Bl = np.tril(B)
+    out = run_gemm(ff, opa, opb, 0, 2, A, Bl, np.full((m, n), np.nan), 1.0, 0.0, pad=(0, 2, 0))
+    assert np.abs(out - A @ Bl).max() <= 1e-14 * scale * np.sqrt(k)
+
+
+@pytest.mark.parametrize("opa,opb", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("m,n,k", [(256, 1, 16384), (256, 256, 8192), (70, 33, 5000), (64, 64, 2048 + 17), (1, 1, 4096), (130, 512, 3000)])
 def test_gemm_split_k(ff, opa, opb, m, n, k):
     """thin products with a long k are cut along k (batched partial products + a fixed-order reduction): values, beta,

@@ -17,10 +17,11 @@ python3 bench.py --n 8192 --D 8 --d 4096 --steps 10 --warmup 3 --no-cpu-baseline
 python3 bench.py --n 32768 --steps 3 --warmup 1 --no-cpu-baseline --no-sharded > $OUT/bench_n32768.json 2>> $OUT/bench.err
 python3 bench.py --workload gar8_hogp --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_gar8_hogp.json 2>> $OUT/bench.err
 {
-for t in posterior_bench hogp_bench c4_step small_n_latency small_kernel_bench v2_bench diag_bench assemble_bench chase_dbg; do
+for t in posterior_bench hogp_bench c4_step small_n_latency small_kernel_bench v2_bench diag_bench assemble_bench chase_dbg step_stages raw_graph_bench; do
   echo "## tools/$t.py"; timeout 300 python3 tools/$t.py 2>&1 | grep -v amdgpu.ids | tail -12
 done
 echo "## tools/eigh_bench.py full big"; timeout 600 python3 tools/eigh_bench.py full big 2>&1 | grep -v amdgpu.ids | tail -12
+echo "## tools/pair_bench.py 16384 16"; timeout 300 python3 tools/pair_bench.py 16384 16 2>&1 | grep -v amdgpu.ids | tail -8
 echo "## tools/small_n_breakdown.py 128 400"; timeout 300 python3 tools/small_n_breakdown.py 128 400 2>&1 | grep -v amdgpu.ids | tail -4
 } > $OUT/tools_output.txt
 for f in $OUT/bench_*.json; do python3 - "$f" <<'P'
