@@ -196,6 +196,7 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->diag_v2 = 1;
   h->trtri_overlap = 1;
   h->raw_graph_max_n = 0;
+  h->small2_off = 1;
   h->asm_mm = 1;
   h->asm_mm_min = 6144;
   h->asm_mm_grid = 768;
@@ -325,6 +326,8 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->trtri_overlap = (int)value;
   } else if (!strcmp(key, "small_max_n")) {
     h->small_max_n = (int)value;
+  } else if (!strcmp(key, "small_finish")) {
+    h->small2_off = (value == 0.0) ? 1 : 0;
   } else if (!strcmp(key, "small_fused")) {
     h->small_off = (value == 0.0) ? 1 : 0;
   } else if (!strcmp(key, "eig_overlap")) {
@@ -772,6 +775,33 @@ static int nlml_fused_raw_enqueue(ffgp_handle* h, const ffgp_problem* p, const f
   return FFGP_OK;
 }
 
+// 40 < n <= 128 (one diagonal block): assemble and factor with the blocked path's kernels, then ONE finishing kernel (small.hip,
+// FROM_FACTOR) for everything else -- links of the raw-parameter call included.  p holds the raw parameters when l is given.
+static int small2_enqueue(ffgp_handle* h, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g) {
+  FFGP_HIP(hipSetDevice(h->device));
+  const int n = p->n, D = p->D;
+  const size_t ld = ffgp_round_up(n, 16);
+  FFGP_CHECK(ffgp_ensure_ws(h, (size_t)(n + 16) * ld * sizeof(double)));
+  h->n_stages = 0;
+  const double* w = p->w_dev;
+  const double* amp = p->amp_dev;
+  const double* dadd = p->diag_add_dev;
+  if (l) {
+    if (!h->d_link) FFGP_HIP(hipMalloc(&h->d_link, 512 * sizeof(double)));
+    hipLaunchKernelGGL(ffgp_link_fwd, dim3(1), dim3(128), 0, h->stream, *l, D, p->w_dev, p->amp_dev, p->diag_add_dev, h->d_link);
+    w = h->d_link;
+    amp = h->d_link + D;
+    if (dadd) dadd = h->d_link + D + 1;
+  }
+  FFGP_CHECK(ffgp_assemble_impl(h, p->X_dev, n, p->X_dev, n, D, w, amp, p->clamp_min, dadd, p->diag_vec_dev, p->diag_stride, p->add_mat_dev,
+                                p->ld_add, p->add_all, p->mean_jitter, h->ws, (int)ld, 1, p->kfun, p->kparam));
+  FFGP_CHECK(ffgp_potrf_impl(h, h->ws, n, n, (int)ld, 0));
+  FFGP_CHECK(ffgp_small_enqueue(h, p, l, nll_dev, g, h->dinv));
+  hipLaunchKernelGGL(ffgp_sticky_info_kernel, dim3(1), dim3(1), 0, h->stream, h->d_info);
+  FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  return FFGP_OK;
+}
+
 static int nlml_fused_raw_plain(ffgp_handle* h, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g) {
   if (!h || !p || !l || !nll_dev) return FFGP_ERR_ARG;
   if (p->cov_dev || p->pair || p->tree || !p->w_dev || !p->amp_dev || p->D <= 0 || p->D > 128) return FFGP_ERR_ARG;
@@ -784,6 +814,7 @@ static int nlml_fused_raw_plain(ffgp_handle* h, const ffgp_problem* p, const ffg
     FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     return FFGP_OK;
   }
+  if (ffgp_small2_ok(h, p, g)) return small2_enqueue(h, p, l, nll_dev, g);
   if (!h->d_link) FFGP_HIP(hipMalloc(&h->d_link, 512 * sizeof(double)));
   const int D = p->D;
   double* eff = h->d_link;
@@ -866,6 +897,7 @@ static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll
     FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     return FFGP_OK;
   }
+  if (ffgp_small2_ok(h, p, g)) return small2_enqueue(h, p, nullptr, nll_dev, g);
   FFGP_CHECK(ffgp_ensure_ws(h, total * sizeof(double)));
   double* W0 = h->ws;
   double* Gt = W0 + (size_t)n * ld;  // passenger rows: Gamma^T (d x n)

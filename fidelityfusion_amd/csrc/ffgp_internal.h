@@ -177,6 +177,8 @@ struct ffgp_handle {
   int* d_info;       // device status word(s)
   double* d_scal;    // small device scalar scratch (64 doubles)
   // launch-bound sizes: the raw-parameter likelihood call replayed as a captured graph (api.hip, nlml_fused_raw_enqueue)
+  int small2_off;              // option "small_finish" (default 0 = off): 1 = 40 < n <= 128 runs assembly + the blocked diagonal-block
+                               // factorisation + ONE finishing kernel (7 launches instead of 21); measured +-5-10 % per training step
   unsigned long alloc_epoch;   // bumped whenever one of the handle's device buffers is re-allocated (captured pointers go stale)
   int raw_graph_max_n;         // option "raw_graph_max_n" (default 0 = never capture: measured no faster, see api.hip)
   struct RawGraph* rawg;
@@ -225,7 +227,9 @@ int ffgp_trtri_head(ffgp_handle* h, const double* L, int n, int ldl, double* X, 
 int ffgp_trtri_tail(ffgp_handle* h, const double* L, int n, int ldl, double* X, int ldx, double* T, const double* Ttop, int n1);
 // ---- small.hip
 bool ffgp_small_ok(const ffgp_handle* h, const ffgp_problem* p, const ffgp_grads* g);
-int ffgp_small_enqueue(ffgp_handle* h, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g);
+int ffgp_small_enqueue(ffgp_handle* h, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g,
+                       const double* dinv = nullptr);
+bool ffgp_small2_ok(const ffgp_handle* h, const ffgp_problem* p, const ffgp_grads* g);
 // ---- workspace
 int ffgp_ensure_ws(ffgp_handle* h, size_t bytes);
 // zero `bytes` (a multiple of 4) on the handle's stream with a kernel: small fills on the captured (graph) path go through this

@@ -16,6 +16,7 @@
 #define SM_D 16
 #define SM_Y 16
 #define SM_T 256    // threads (1024 were measured: the 16-wave barriers cost more than the extra waves hide)
+#define SM_T2 1024  // threads of the finishing launch (FROM_FACTOR)
 #define SM_TG 16    // the trailing update's thread grid is SM_TG x SM_TG
 #define SM_MAX_FAST_N 40   // above this the blocked path of api.hip (whole chip, MFMA kernels) is faster: tools/small_kernel_bench.py
 
@@ -31,6 +32,7 @@ struct SmallArgs {
   double* g_w; double* g_amp; double* g_dadd; double* g_Y; double* g_diag_vec; double* g_kparam;
   int want_grad;
   int* info;
+  const double* dinv;   // FROM_FACTOR: L^-1 as the blocked factorisation left it (one 128 x 128 block, lower part valid)
 };
 
 __device__ __forceinline__ double sm_link_val(int kind, double p, double c) {
@@ -64,7 +66,8 @@ __device__ __forceinline__ void sm_unpk(int e, int& i, int& j) {
   j = e - i * (i + 1) / 2;
 }
 
-// sum over the workgroup, result in every thread; red: SM_T / 64 doubles of LDS
+// sum over the workgroup, result in every thread; red: T / 64 doubles of LDS
+template <int T>
 __device__ __forceinline__ double sm_bsum(double v, double* red, int tid) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   __syncthreads();
@@ -72,11 +75,17 @@ __device__ __forceinline__ double sm_bsum(double v, double* red, int tid) {
   __syncthreads();
   double t = 0.0;
 #pragma unroll
-  for (int q = 0; q < SM_T / 64; ++q) t += red[q];
+  for (int q = 0; q < T / 64; ++q) t += red[q];
   return t;
 }
 
-__global__ __launch_bounds__(SM_T) void ffgp_small_nlml_kernel(SmallArgs a) {
+// FROM_FACTOR = false: everything here (n <= 40 by default).  FROM_FACTOR = true (40 < n <= 128): Sigma was assembled and factored by
+// the blocked path's own kernels -- the diagonal-block kernel leaves L^-1 of a single block in the handle's store -- and this launch
+// does the rest of the call (Gamma, A, value, Sigma^-1, G, every gradient, links, output scale): 7 launches per call instead of 21.
+// (the finishing launch has no column-by-column phases, i.e. few barriers: 1024 threads hide the LDS latency that one wave per SIMD cannot)
+template <bool FROM_FACTOR>
+__global__ __launch_bounds__(FROM_FACTOR ? SM_T2 : SM_T) void ffgp_small_nlml_kernel(SmallArgs a) {
+  constexpr int T = FROM_FACTOR ? SM_T2 : SM_T;
   extern __shared__ double sm[];
   double* Sp = sm;                          // packed lower [n (n + 1) / 2]
   double* Xs = Sp + SM_N * (SM_N + 1) / 2;  // [n][17] scaled inputs
@@ -102,93 +111,105 @@ __global__ __launch_bounds__(SM_T) void ffgp_small_nlml_kernel(SmallArgs a) {
     sc[1] = a.dadd ? (a.has_links ? sm_link_val(a.l.dadd_link, a.dadd[0], a.l.dadd_c) : a.dadd[0]) : 0.0;
   }
   __syncthreads();
-  for (int idx = tid; idx < n * D; idx += SM_T) {
+  for (int idx = tid; idx < n * D; idx += T) {
     const int i = idx / D, k = idx - i * D;
     Xs[i * (SM_D + 1) + k] = a.X[idx] * wv[k];
   }
-  for (int idx = tid; idx < n * d; idx += SM_T) Ym[idx] = a.Y[idx];
+  for (int idx = tid; idx < n * d; idx += T) Ym[idx] = a.Y[idx];
   __syncthreads();
   const double amp = sc[0], dadd = sc[1];
 
-  // ---- Sigma (lower, packed) and sum(K) over the full matrix
-  double ksum = 0.0;
-  for (int e = tid; e < npair; e += SM_T) {
-    int i, j;
-    sm_unpk(e, i, j);
-    double sq = 0.0;
-    for (int k = 0; k < D; ++k) {
-      const double df = Xs[i * (SM_D + 1) + k] - Xs[j * (SM_D + 1) + k];
-      sq = __builtin_fma(df, df, sq);
-    }
-    double kv = amp * ffgp_kfun_val(a.kfun, a.rinv, fmax(sq, a.clamp));
-    ksum += (i == j) ? kv : 2.0 * kv;
-    if (i == j) {
-      kv += dadd;
-      if (a.diag_vec) kv += a.diag_vec[(size_t)i * a.diag_stride];
-    }
-    if (a.add_mat) kv += a.add_mat[(size_t)i * a.ld_add + j];
-    Sp[e] = kv + a.add_all;
-  }
-  if (a.mean_jitter != 0.0) {
-    const double tot = sm_bsum(ksum, red, tid);
-    const double add = a.mean_jitter * tot / ((double)n * (double)n);
-    __syncthreads();
-    if (tid < n) Sp[sm_pk(tid, tid)] += add;
-  }
-  __syncthreads();
-
-  // ---- Cholesky, right-looking; thread (ti, tk) of a 16 x 16 grid updates rows j+1+ti (+16..) x columns j+1+tk (+16..), k <= i
-  const int ti = tid / SM_TG, tk = tid % SM_TG;
   double logdet = 0.0;
-  int bad = 0;
-  for (int j = 0; j < n; ++j) {
-    __syncthreads();                       // the previous column's trailing update is complete
-    const double djj = Sp[sm_pk(j, j)];    // (the diagonal of L is never stored: the inverse below only needs 1 / L_jj)
-    if (!(djj > 0.0) && bad == 0) bad = j + 1;
-    const double ljj = sqrt(djj), inv = 1.0 / ljj;
-    logdet += log(ljj);
-    for (int i = j + 1 + tid; i < n; i += SM_T) {
-      const double l = Sp[sm_pk(i, j)] * inv;
-      Sp[sm_pk(i, j)] = l;
-      rowb[i] = l;
+  if constexpr (FROM_FACTOR) {
+    for (int e = tid; e < npair; e += T) {
+      int i, j;
+      sm_unpk(e, i, j);
+      const double v = a.dinv[i * 128 + j];
+      Sp[e] = v;
+      if (i == j) logdet -= log(v);          // (every thread needs the total below: summed over the workgroup)
     }
-    if (tid == 0) dinv[j] = inv;
+    logdet = sm_bsum<T>(logdet, red, tid);
     __syncthreads();
-    for (int i = j + 1 + ti; i < n; i += SM_TG) {
-      const double li = rowb[i];
-      const int base = i * (i + 1) / 2;
-#pragma unroll 4
-      for (int k = j + 1 + tk; k <= i; k += SM_TG) Sp[base + k] = __builtin_fma(-li, rowb[k], Sp[base + k]);
-    }
-  }
-  __syncthreads();
-  if (tid == 0) a.info[0] = bad;
-
-  // ---- L^-1 in place, row by row: X[i][j] = -(1 / L_ii) sum_{k = j}^{i-1} L[i][k] X[k][j]; 4 lanes share one j
-  {
-    const int jq = tid >> 2, kp = tid & 3;          // SM_T / 4 columns per pass: one pass
-    for (int i = 0; i < n; ++i) {
-      const int base = i * (i + 1) / 2;
-      for (int k = tid; k < i; k += SM_T) rowb[k] = Sp[base + k];
-      __syncthreads();
-      for (int j0 = 0; j0 < i; j0 += SM_T / 4) {
-        const int j = j0 + jq;
-        double s = 0.0;
-        if (j < i) {
-#pragma unroll 4
-          for (int k = j + kp; k < i; k += 4) s = __builtin_fma(rowb[k], Sp[sm_pk(k, j)], s);
-        }
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        if (j < i && kp == 0) Sp[base + j] = -dinv[i] * s;
+  } else {
+  // ---- Sigma (lower, packed) and sum(K) over the full matrix
+    double ksum = 0.0;
+    for (int e = tid; e < npair; e += T) {
+      int i, j;
+      sm_unpk(e, i, j);
+      double sq = 0.0;
+      for (int k = 0; k < D; ++k) {
+        const double df = Xs[i * (SM_D + 1) + k] - Xs[j * (SM_D + 1) + k];
+        sq = __builtin_fma(df, df, sq);
       }
-      if (tid == 0) Sp[base + i] = dinv[i];
-      __syncthreads();
+      double kv = amp * ffgp_kfun_val(a.kfun, a.rinv, fmax(sq, a.clamp));
+      ksum += (i == j) ? kv : 2.0 * kv;
+      if (i == j) {
+        kv += dadd;
+        if (a.diag_vec) kv += a.diag_vec[(size_t)i * a.diag_stride];
+      }
+      if (a.add_mat) kv += a.add_mat[(size_t)i * a.ld_add + j];
+      Sp[e] = kv + a.add_all;
     }
-  }
+    if (a.mean_jitter != 0.0) {
+      const double tot = sm_bsum<T>(ksum, red, tid);
+      const double add = a.mean_jitter * tot / ((double)n * (double)n);
+      __syncthreads();
+      if (tid < n) Sp[sm_pk(tid, tid)] += add;
+    }
+    __syncthreads();
 
+    // ---- Cholesky, right-looking; thread (ti, tk) of a 16 x 16 grid updates rows j+1+ti (+16..) x columns j+1+tk (+16..), k <= i
+    const int ti = tid / SM_TG, tk = tid % SM_TG;
+    int bad = 0;
+    for (int j = 0; j < n; ++j) {
+      __syncthreads();                       // the previous column's trailing update is complete
+      const double djj = Sp[sm_pk(j, j)];    // (the diagonal of L is never stored: the inverse below only needs 1 / L_jj)
+      if (!(djj > 0.0) && bad == 0) bad = j + 1;
+      const double ljj = sqrt(djj), inv = 1.0 / ljj;
+      logdet += log(ljj);
+      for (int i = j + 1 + tid; i < n; i += T) {
+        const double l = Sp[sm_pk(i, j)] * inv;
+        Sp[sm_pk(i, j)] = l;
+        rowb[i] = l;
+      }
+      if (tid == 0) dinv[j] = inv;
+      __syncthreads();
+      for (int i = j + 1 + ti; i < n; i += SM_TG) {
+        const double li = rowb[i];
+        const int base = i * (i + 1) / 2;
+#pragma unroll 4
+        for (int k = j + 1 + tk; k <= i; k += SM_TG) Sp[base + k] = __builtin_fma(-li, rowb[k], Sp[base + k]);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) a.info[0] = bad;
+
+    // ---- L^-1 in place, row by row: X[i][j] = -(1 / L_ii) sum_{k = j}^{i-1} L[i][k] X[k][j]; 4 lanes share one j
+    {
+      const int jq = tid >> 2, kp = tid & 3;          // T / 4 columns per pass: one pass
+      for (int i = 0; i < n; ++i) {
+        const int base = i * (i + 1) / 2;
+        for (int k = tid; k < i; k += T) rowb[k] = Sp[base + k];
+        __syncthreads();
+        for (int j0 = 0; j0 < i; j0 += T / 4) {
+          const int j = j0 + jq;
+          double s = 0.0;
+          if (j < i) {
+#pragma unroll 4
+            for (int k = j + kp; k < i; k += 4) s = __builtin_fma(rowb[k], Sp[sm_pk(k, j)], s);
+          }
+          s += __shfl_xor(s, 1);
+          s += __shfl_xor(s, 2);
+          if (j < i && kp == 0) Sp[base + j] = -dinv[i] * s;
+        }
+        if (tid == 0) Sp[base + i] = dinv[i];
+        __syncthreads();
+      }
+    }
+
+}
   // ---- Gamma = L^-1 Y, A = L^-T Gamma
-  for (int idx = tid; idx < n * d; idx += SM_T) {
+  for (int idx = tid; idx < n * d; idx += T) {
     const int i = idx / d, c = idx - i * d;
     const int base = i * (i + 1) / 2;
     double s = 0.0;
@@ -198,7 +219,7 @@ __global__ __launch_bounds__(SM_T) void ffgp_small_nlml_kernel(SmallArgs a) {
   __syncthreads();
   const bool needA = a.v2 || a.want_grad;
   if (needA) {
-    for (int idx = tid; idx < n * d; idx += SM_T) {
+    for (int idx = tid; idx < n * d; idx += T) {
       const int i = idx / d, c = idx - i * d;
       double s = 0.0;
       for (int k = i; k < n; ++k) s = __builtin_fma(Sp[sm_pk(k, i)], Gam[k * d + c], s);
@@ -210,8 +231,8 @@ __global__ __launch_bounds__(SM_T) void ffgp_small_nlml_kernel(SmallArgs a) {
   {
     const double* M = a.v2 ? Am : Gam;
     double ss = 0.0;
-    for (int idx = tid; idx < n * d; idx += SM_T) ss = __builtin_fma(M[idx], M[idx], ss);
-    ss = sm_bsum(ss, red, tid);
+    for (int idx = tid; idx < n * d; idx += T) ss = __builtin_fma(M[idx], M[idx], ss);
+    ss = sm_bsum<T>(ss, red, tid);
     const double oscale = (a.has_links && a.l.out_scale != 0.0) ? a.l.out_scale : 1.0;
     if (tid == 0) a.nll[0] = oscale * (0.5 * ss + (double)d * logdet + 0.5 * (double)n * (double)d * log(2.0 * a.pi_const));
   }
@@ -219,11 +240,11 @@ __global__ __launch_bounds__(SM_T) void ffgp_small_nlml_kernel(SmallArgs a) {
 
   // ---- Sigma^-1 = L^-T L^-1 (lower): every entry from the rows below it, all of them read before any is written
   {
-    constexpr int NV = (SM_N * (SM_N + 1) / 2 + SM_T - 1) / SM_T;
+    constexpr int NV = (SM_N * (SM_N + 1) / 2 + T - 1) / T;
     double vals[NV];
 #pragma unroll
     for (int c = 0; c < NV; ++c) {
-      const int e = tid + SM_T * c;
+      const int e = tid + T * c;
       double sacc = 0.0;
       if (e < npair) {
         int i, j;
@@ -236,13 +257,13 @@ __global__ __launch_bounds__(SM_T) void ffgp_small_nlml_kernel(SmallArgs a) {
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < NV; ++c) {
-      const int e = tid + SM_T * c;
+      const int e = tid + T * c;
       if (e < npair) Sp[e] = vals[c];
     }
     __syncthreads();
   }
   if (a.v2) {   // B = Sigma^-1 A
-    for (int idx = tid; idx < n * d; idx += SM_T) {
+    for (int idx = tid; idx < n * d; idx += T) {
       const int i = idx / d, c = idx - i * d;
       double s = 0.0;
       for (int k = 0; k < n; ++k) s = __builtin_fma((k <= i) ? Sp[sm_pk(i, k)] : Sp[sm_pk(k, i)], Am[k * d + c], s);
@@ -252,7 +273,7 @@ __global__ __launch_bounds__(SM_T) void ffgp_small_nlml_kernel(SmallArgs a) {
   }
   // ---- G = d/2 Sigma^-1 - 1/2 A A^T   (V2: - 1/2 (A B^T + B A^T)), in place; trace and diagonal
   double tr = 0.0;
-  for (int e = tid; e < npair; e += SM_T) {
+  for (int e = tid; e < npair; e += T) {
     int i, j;
     sm_unpk(e, i, j);
     double s = 0.0;
@@ -265,13 +286,13 @@ __global__ __launch_bounds__(SM_T) void ffgp_small_nlml_kernel(SmallArgs a) {
     Sp[e] = gv;
     if (i == j) tr += gv;
   }
-  const double trG = sm_bsum(tr, red, tid);
+  const double trG = sm_bsum<T>(tr, red, tid);
   __syncthreads();
   const double oscale = (a.has_links && a.l.out_scale != 0.0) ? a.l.out_scale : 1.0;
   if (a.g_diag_vec && tid < n) a.g_diag_vec[tid] = oscale * Sp[sm_pk(tid, tid)];
   if (a.g_Y) {
     const double* M = a.v2 ? Bm : Am;
-    for (int idx = tid; idx < n * d; idx += SM_T) a.g_Y[idx] = oscale * M[idx];
+    for (int idx = tid; idx < n * d; idx += T) a.g_Y[idx] = oscale * M[idx];
   }
   // ---- kernel-parameter gradients: the reductions of grad.hip over the lower triangle (off-diagonal entries count twice)
   const double geff_add = (a.mean_jitter != 0.0) ? a.mean_jitter / ((double)n * (double)n) * trG : 0.0;
@@ -279,7 +300,7 @@ __global__ __launch_bounds__(SM_T) void ffgp_small_nlml_kernel(SmallArgs a) {
 #pragma unroll
   for (int k = 0; k < SM_D; ++k) tot[k] = 0.0;
   if (a.g_w || a.g_amp || a.g_kparam) {
-    for (int e = tid; e < npair; e += SM_T) {
+    for (int e = tid; e < npair; e += T) {
       int i, j;
       sm_unpk(e, i, j);
       double df[SM_D], sq = 0.0;
@@ -298,19 +319,19 @@ __global__ __launch_bounds__(SM_T) void ffgp_small_nlml_kernel(SmallArgs a) {
       for (int k = 0; k < SM_D; ++k) tot[k] = __builtin_fma(wl * df[k], df[k], tot[k]);
     }
   }
-  s_amp = sm_bsum(s_amp, red, tid);
-  s_kp = sm_bsum(s_kp, red, tid);
+  s_amp = sm_bsum<T>(s_amp, red, tid);
+  s_kp = sm_bsum<T>(s_kp, red, tid);
   double gw_eff = 0.0;       // thread k < D ends up with the effective-w gradient of dimension k
 #pragma unroll
   for (int k = 0; k < SM_D; ++k) {
-    const double t = sm_bsum(tot[k], red, tid);
+    const double t = sm_bsum<T>(tot[k], red, tid);
     if (tid == k && k < D) gw_eff = -t / wv[k];
   }
   // ---- chain to the raw parameters (identity links otherwise), output scale
   if (a.g_w) {
     if (a.has_links && a.l.w_broadcast) {
       double v = (tid < D) ? gw_eff : 0.0;
-      v = sm_bsum(v, red, tid);
+      v = sm_bsum<T>(v, red, tid);
       if (tid == 0) a.g_w[0] = oscale * v * sm_link_der(a.l.w_link, a.w[0], a.l.w_c);
     } else if (tid < D) {
       a.g_w[tid] = oscale * gw_eff * (a.has_links ? sm_link_der(a.l.w_link, a.w[tid], a.l.w_c) : 1.0);
@@ -323,7 +344,18 @@ __global__ __launch_bounds__(SM_T) void ffgp_small_nlml_kernel(SmallArgs a) {
   }
 }
 
-#define SM_LDS_DOUBLES (SM_N * (SM_N + 1) / 2 + SM_N * (SM_D + 1) + 4 * SM_N * SM_Y + 2 * SM_N + SM_D + 8 + SM_T / 64)
+#define SM_LDS_DOUBLES (SM_N * (SM_N + 1) / 2 + SM_N * (SM_D + 1) + 4 * SM_N * SM_Y + 2 * SM_N + SM_D + 8 + SM_T2 / 64)
+
+// does the "blocked factorisation + one finishing kernel" path cover this call?  (one diagonal block: 40 < n <= 128; option
+// "small_finish", off by default: tools/small_finish_bench.py measured a training step at n = 64 / 80 / 96 / 112 / 128 at
+// 0.196 / 0.202 / 0.209 / 0.220 / 0.234 ms with it against 0.216 / 0.219 / 0.219 / 0.222 / 0.227 ms on the 21-launch path -- the
+// single-workgroup finishing kernel takes about as long as the launches it saves)
+bool ffgp_small2_ok(const ffgp_handle* h, const ffgp_problem* p, const ffgp_grads* g) {
+  if (h->small_off || h->small2_off || p->n > SM_N || p->D > SM_D || p->d > SM_Y || p->cov_dev || p->pair || p->tree) return false;
+  if (p->kfun < FFGP_KFUN_SE || p->kfun > FFGP_KFUN_RQ) return false;
+  if (g && (g->g_cov_dev || g->g_pair)) return false;
+  return !h->use_naive && h->timing == 0;
+}
 
 // does the one-kernel path cover this call?
 bool ffgp_small_ok(const ffgp_handle* h, const ffgp_problem* p, const ffgp_grads* g) {
@@ -336,10 +368,12 @@ bool ffgp_small_ok(const ffgp_handle* h, const ffgp_problem* p, const ffgp_grads
 }
 
 // enqueue the kernel; the caller finishes like the blocked path (sticky info, D2H of the status word)
-int ffgp_small_enqueue(ffgp_handle* h, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g) {
+int ffgp_small_enqueue(ffgp_handle* h, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g, const double* dinv) {
   static bool attr_set[64] = {false};
   if (h->device >= 0 && h->device < 64 && !attr_set[h->device]) {
-    FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_small_nlml_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_small_nlml_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 SM_LDS_DOUBLES * (int)sizeof(double)));
+    FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_small_nlml_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  SM_LDS_DOUBLES * (int)sizeof(double)));
     attr_set[h->device] = true;
   }
@@ -357,6 +391,8 @@ int ffgp_small_enqueue(ffgp_handle* h, const ffgp_problem* p, const ffgp_links* 
   a.g_Y = g ? g->g_Y_dev : nullptr; a.g_diag_vec = g ? g->g_diag_vec_dev : nullptr; a.g_kparam = g ? g->g_kparam_dev : nullptr;
   a.want_grad = (a.g_w || a.g_amp || a.g_dadd || a.g_Y || a.g_diag_vec || a.g_kparam) ? 1 : 0;
   a.info = h->d_info;
-  hipLaunchKernelGGL(ffgp_small_nlml_kernel, dim3(1), dim3(SM_T), SM_LDS_DOUBLES * sizeof(double), h->stream, a);
+  a.dinv = dinv;
+  if (dinv) hipLaunchKernelGGL(ffgp_small_nlml_kernel<true>, dim3(1), dim3(SM_T2), SM_LDS_DOUBLES * sizeof(double), h->stream, a);
+  else hipLaunchKernelGGL(ffgp_small_nlml_kernel<false>, dim3(1), dim3(SM_T), SM_LDS_DOUBLES * sizeof(double), h->stream, a);
   return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
 }

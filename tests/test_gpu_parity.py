@@ -725,6 +725,83 @@ def test_raw_parameter_path_other_modules(model, monkeypatch):
         assert rel(g1[k_], g2[k_]) < 1e-10, k_
 
 
+@pytest.mark.parametrize("n,D,d", [(41, 2, 1), (64, 5, 3), (100, 16, 16), (128, 3, 2), (127, 1, 1)])
+@pytest.mark.parametrize("model", ["cigp", "cigp_yvar", "pack", "gp_basic", "gp_basic_yvar", "cigp_matern", "cigp_rq", "cigp_cpu"])
+def test_small_problem_paths_agree(model, n, D, d):
+    """40 < n <= 128: assembly + the blocked diagonal-block factorisation + ONE finishing kernel (small.hip, FROM_FACTOR; option
+    small_finish, off by default) against the fully blocked path and against the one-kernel path forced up to n = 128: value and every
+    gradient, V1 / V2, diagonal and full y_var, the mean(K) jitter, Matern / RQ profiles, raw-parameter and effective-parameter
+    calls (GPU- / CPU-resident modules)"""
+    import fidelityfusion_amd.gp_computation_pack as gp_pack
+    from fidelityfusion_amd import _lib, kernel
+    from fidelityfusion_amd.cigp_v10 import cigp
+    from fidelityfusion_amd.gp_basic import GP_basic
+    rng = np.random.default_rng(n * 3 + D + d)
+    where = "cpu" if model.endswith("cpu") else DEV
+    X = torch.tensor(rng.uniform(0, 1, (n, D)), device=where)
+    Y0 = rng.standard_normal((n, d))
+    A = rng.standard_normal((n, n)) * 0.05
+    yv = torch.tensor(A @ A.T + 0.1 * np.eye(n), device=where)
+    kern = {"cigp_matern": lambda: kernel.MaternKernel(D, 0.9, 1.2, nu=1.5), "cigp_rq": lambda: kernel.RationalQuadraticKernel(0.8, 1.1, 1.6)}.get(
+        model, lambda: kernel.ARDKernel(D, 0.7, 1.3))()
+    kern = kern.double().to(where)
+    lb = torch.tensor([0.6], device=where, dtype=torch.float64, requires_grad=True)
+    mc = cigp(kern, 0.6).double().to(where)
+    gb = GP_basic(kern, 0.7).double().to(where)
+    if model in ("gp_basic", "gp_basic_yvar") and d != 1:
+        pytest.skip("GP_basic's likelihood is per output column")
+    h = _lib.handle(0)
+
+    def run():
+        for p_ in list(mc.parameters()) + list(gb.parameters()) + [lb]:
+            p_.grad = None
+        Y = torch.tensor(Y0, device=where, requires_grad=True)
+        if model == "pack":
+            v = gp_pack.negative_log_likelihood(kern, lb, X, Y)
+            mod = [lb] + list(kern.parameters())
+        elif model.startswith("gp_basic"):
+            v = gb.log_likelihood(X, [Y, yv] if model.endswith("yvar") else Y)
+            mod = list(gb.parameters())
+        else:
+            v = mc.negative_log_likelihood(X, [Y, yv] if model.endswith("yvar") else Y)
+            mod = list(mc.parameters())
+        v.sum().backward()
+        return v.detach().clone().cpu(), [Y.grad.clone().cpu()] + [p_.grad.clone().cpu() for p_ in mod]
+
+    outs = {}
+    for name, opts in (("finish", {"small_finish": 1}), ("blocked", {"small_finish": 0}), ("one_kernel", {"small_max_n": 128})):
+        for k_, v_ in opts.items():
+            assert _lib.lib.ffgp_set_option(h, k_.encode(), float(v_)) == 0
+        try:
+            outs[name] = run()
+        finally:
+            _lib.lib.ffgp_set_option(h, b"small_finish", 0.0)
+            _lib.lib.ffgp_set_option(h, b"small_max_n", 0.0)
+    for other in ("blocked", "one_kernel"):
+        va, ga = outs["finish"]
+        vb, gb_ = outs[other]
+        assert rel(va, vb) < 1e-12, other
+        for x, y in zip(ga, gb_):
+            assert rel(x, y) < 1e-9, other
+
+
+def test_small_finish_reports_not_pd():
+    """the finishing-kernel path keeps the factorisation's status: a Sigma that is not positive definite raises"""
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp
+    rng = np.random.default_rng(9)
+    X, Y = torch.tensor(rng.uniform(0, 1, (90, 2))), torch.tensor(rng.standard_normal((90, 1)))
+    from fidelityfusion_amd import _lib
+    m = cigp(kernel.ARDKernel(2), 0.5).double()            # CPU-resident: the effective-parameter call, raised at the call
+    _lib.lib.ffgp_set_option(_lib.handle(0), b"small_finish", 1.0)
+    try:
+        with pytest.raises(torch.linalg.LinAlgError):
+            m.negative_log_likelihood(X, [Y, -3.0 * torch.eye(90, dtype=torch.float64)])
+        assert torch.isfinite(m.negative_log_likelihood(X, Y))
+    finally:
+        _lib.lib.ffgp_set_option(_lib.handle(0), b"small_finish", 0.0)
+
+
 def test_raw_path_defers_not_pd_to_backward():
     """a training step on GPU-resident tensors is enqueued and collected in backward(): a Sigma that is not positive definite raises
     LinAlgError from loss.backward() (or from the next likelihood call if backward never runs); with DEFER_RAW_ERRORS off, and under
