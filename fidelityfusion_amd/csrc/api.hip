@@ -197,6 +197,7 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->trtri_overlap = 1;
   h->raw_graph_max_n = 0;
   h->small2_off = 1;
+  h->q2_wave4 = 1;
   h->asm_mm = 1;
   h->asm_mm_min = 6144;
   h->asm_mm_grid = 768;
@@ -326,6 +327,8 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->trtri_overlap = (int)value;
   } else if (!strcmp(key, "small_max_n")) {
     h->small_max_n = (int)value;
+  } else if (!strcmp(key, "q2_wave4")) {
+    h->q2_wave4 = (int)value;
   } else if (!strcmp(key, "small_finish")) {
     h->small2_off = (value == 0.0) ? 1 : 0;
   } else if (!strcmp(key, "small_fused")) {

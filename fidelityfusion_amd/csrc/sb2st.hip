@@ -298,6 +298,7 @@ struct PrepArgs {
   double* blocks;
   int G0;      // first sweep group of this launch (blockIdx.y counts from it)
   int trans;   // 1: W = V T^T (the block of Q2^T), 0: W = V T
+  int lanes;   // 1: both factors in the MFMA lane order of q2_apply_wave4 (pairs of k-steps per lane: 16-byte operand loads)
 };
 
 __global__ __launch_bounds__(256) void q2_prep(PrepArgs p) {
@@ -354,14 +355,17 @@ __global__ __launch_bounds__(256) void q2_prep(PrepArgs p) {
   double* out = p.blocks + ((size_t)G * p.K + k) * 4096;
   for (int idx = tid; idx < 64 * 32; idx += 256) {
     const int r = idx >> 5, j = idx & 31;
-    out[idx] = Vs[r][j];
+    // lane order: A-operand element (row m = 16 t + lr, k = 4 kq + lq) of tile t sits at ((t * nkp + kq / 2) * 64 + 16 lq + lr) * 2 + kq % 2
+    if (p.lanes) out[(((j >> 4) * 8 + (r >> 3)) * 64 + 16 * (r & 3) + (j & 15)) * 2 + ((r >> 2) & 1)] = Vs[r][j];   // V^T: m = reflector j, k = row r
+    else out[idx] = Vs[r][j];
     double s = 0.0;
     if (p.trans) {
       for (int cc = j; cc < 32; ++cc) s = __builtin_fma(Vs[r][cc], Tm[j][cc], s);
     } else {
       for (int cc = 0; cc <= j; ++cc) s = __builtin_fma(Vs[r][cc], Tm[cc][j], s);
     }
-    out[2048 + j * 64 + r] = s;     // W = V T, stored transposed ([32][64]): the apply kernel's lanes read 16 consecutive rows
+    if (p.lanes) out[2048 + (((r >> 4) * 4 + (j >> 3)) * 64 + 16 * (j & 3) + (r & 15)) * 2 + ((j >> 2) & 1)] = s;   // W: m = row r, k = reflector j
+    else out[2048 + j * 64 + r] = s;     // W = V T, stored transposed ([32][64]): the apply kernel's lanes read 16 consecutive rows
   }
 }
 
@@ -369,6 +373,8 @@ int ffgp_q2_prep_impl(ffgp_handle* h, const double* V2, const double* tau2, int 
   if (G1 <= G0) return FFGP_OK;
   PrepArgs a;
   a.V2 = V2; a.tau2 = tau2; a.n = n; a.K = chase_K(n); a.blocks = blocks; a.G0 = G0; a.trans = trans;
+  a.lanes = (!trans && h->q2_wave4) ? 1 : 0;
+  h->q2_blocks_lanes = a.lanes;     // (the apply launch must read the blocks the way they were written)
   hipLaunchKernelGGL(q2_prep, dim3(a.K, G1 - G0), dim3(256), 0, h->stream, a);
   return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
 }
@@ -516,6 +522,202 @@ __global__ __launch_bounds__(256, 4) void q2_apply(ApplyArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Z <- Q2 Z, four sweep groups per pass over Z (round 3, second half).  The kernel above streams the whole slab through its
+// window once per sweep group: n / 32 passes over Z, 8 flops per byte of HBM traffic -- at N = 8192 it ran at 14 TFLOP/s, bound
+// by that traffic and by three barriers per 63 x 32 block.  Blocks of different groups commute when their rows are disjoint,
+// and block (G, k) covers the row bands G + k and G + k + 1 (32 rows each), so four consecutive groups can travel down the slab
+// TOGETHER as a wavefront: wave w of the workgroup owns group Gtop - w and runs two steps behind wave w - 1, which puts it three
+// bands higher -- never on the same rows -- and satisfies every ordering constraint of the sequential order (group G + 1's steps
+// k - 2 .. k precede step k of group G).  The window is a ring of 12 bands in LDS (the 11 live ones + the one arriving); per time
+// step every wave applies one whole block to its two bands (X = V^T Zw and Zw -= W X, 64 MFMAs, X turned around through a
+// wave-private LDS tile), then one band leaves for global memory and one arrives: two barriers per FOUR blocks, a quarter of the
+// HBM traffic.
+// ---------------------------------------------------------------------------------------------------------------------
+#define Q2W_RING 12
+#define Q2W_LDS_DOUBLES(NC) ((NC) * (Q2W_RING * 32 * XLD + 4 * 32 * XLD))
+
+// NC = 1: slabs of 16 columns, 64 KB of LDS, two workgroups per CU.  NC = 2: slabs of 32 columns (two 16-column tiles, stored one
+// after the other so that operand reads stay conflict-free), 128 KB, one workgroup per CU -- every block's V and W^T are fetched
+// once per 32 columns instead of once per 16: the operand stream (n^3 / 6 doubles per 16 columns of Z) is what bounds NC = 1.
+template <int NC>
+__global__ __launch_bounds__(256, NC == 1 ? 2 : 1) void q2_apply_wave4(ApplyArgs p) {
+  extern __shared__ double q2w_sm[];
+  constexpr int TILE = 32 * XLD;                            // one band of one column tile
+  double* ring = q2w_sm;                                    // [Q2W_RING][NC][32][XLD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* xs = q2w_sm + Q2W_RING * NC * TILE + wave * NC * TILE;   // this wave's X tiles [NC][32][XLD]
+  const int n = p.n;
+  const int col0 = blockIdx.x * 16 * NC;
+  if (col0 >= p.ncols) return;
+  double* __restrict__ Zg = p.Z + col0;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int trow = tid >> 3, tc2 = (tid & 7) * 2;          // band <-> global map: 256 threads, 32 rows x 8 column pairs (per tile)
+  bool cok0[NC], cok1[NC];
+#pragma unroll
+  for (int ct = 0; ct < NC; ++ct) {
+    cok0[ct] = col0 + 16 * ct + tc2 < p.ncols;
+    cok1[ct] = col0 + 16 * ct + tc2 + 1 < p.ncols;
+  }
+  auto load_band = [&](int b, d2_t (&v)[NC]) {             // two doubles per tile of one row of band b (rows 32 b + 1 .. 32 b + 32)
+    const int grow = 32 * b + 1 + trow;
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) {
+      v[ct] = d2_t{0.0, 0.0};
+      if (b >= 0 && grow < n) {
+        const double* src = Zg + (size_t)grow * p.ldz + 16 * ct + tc2;
+        if (cok1[ct]) v[ct] = *reinterpret_cast<const d2_t*>(src);
+        else if (cok0[ct]) v[ct].x = src[0];
+      }
+    }
+  };
+  auto store_band = [&](int b, const d2_t (&v)[NC]) {
+    const int grow = 32 * b + 1 + trow;
+    if (b < 0 || grow >= n) return;
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) {
+      double* dst = Zg + (size_t)grow * p.ldz + 16 * ct + tc2;
+      if (cok1[ct]) *reinterpret_cast<d2_t*>(dst) = v[ct];
+      else if (cok0[ct]) dst[0] = v[ct].x;
+    }
+  };
+  auto slot = [&](int b) { return ring + (((b % Q2W_RING) + Q2W_RING) % Q2W_RING) * NC * TILE; };
+  auto put_band = [&](int b, const d2_t (&v)[NC]) {
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) *reinterpret_cast<d2_t*>(slot(b) + ct * TILE + trow * XLD + tc2) = v[ct];
+  };
+  auto get_band = [&](int b, d2_t (&v)[NC]) {
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) v[ct] = *reinterpret_cast<const d2_t*>(slot(b) + ct * TILE + trow * XLD + tc2);
+  };
+
+  for (int Gtop = p.G1 - 1; Gtop >= p.G0; Gtop -= 4) {
+    const int Gw = Gtop - wave;
+    const int nkw = (Gw >= p.G0) ? q2_nsteps(n, 32 * Gw) : 0;
+    int T = 0;
+    for (int w = 0; w < 4; ++w) {
+      const int g = Gtop - w;
+      const int nk = (g >= p.G0) ? q2_nsteps(n, 32 * g) : 0;
+      if (nk > 0) T = max(T, nk + 2 * w);
+    }
+    if (T == 0) continue;
+    __syncthreads();       // the previous pass's stores are visible to the whole workgroup, its LDS reads are done
+    // the window at t = 0: bands Gtop - 9 .. Gtop + 1
+    for (int b = Gtop - 9; b <= Gtop + 1; ++b) {
+      d2_t v[NC];
+      load_band(b, v);
+      put_band(b, v);
+    }
+    // this wave's operands of its first block: V (64 x 32) as 2 x 16 A-operands, W^T (32 x 64) as 4 x 8
+    double va[2][16], wa[4][8];
+    auto load_v = [&](int k) {
+      const d2_t* __restrict__ blk = reinterpret_cast<const d2_t*>(p.blocks + ((size_t)Gw * p.K + k) * 4096);
+#pragma unroll
+      for (int xa = 0; xa < 2; ++xa)
+#pragma unroll
+        for (int kp = 0; kp < 8; ++kp)
+          if (xa == 0 ? kp < 6 : kp >= 2) {
+            const d2_t v = blk[(xa * 8 + kp) * 64 + lane];
+            va[xa][2 * kp] = v.x;
+            va[xa][2 * kp + 1] = v.y;
+          }
+    };
+    auto load_w = [&](int k) {
+      const d2_t* __restrict__ blk = reinterpret_cast<const d2_t*>(p.blocks + ((size_t)Gw * p.K + k) * 4096 + 2048);
+#pragma unroll
+      for (int zr = 0; zr < 4; ++zr)
+#pragma unroll
+        for (int kp = 0; kp < 4; ++kp)
+          if (zr < 3 || kp >= 2) {          // (W = V T: rows 48-63 only carry reflectors 17-31)
+            const d2_t v = blk[(zr * 4 + kp) * 64 + lane];
+            wa[zr][2 * kp] = v.x;
+            wa[zr][2 * kp + 1] = v.y;
+          }
+    };
+    if (nkw > 0) {
+      load_v(0);
+      load_w(0);
+    }
+    for (int t = 0; t < T; ++t) {
+      const int b0 = Gtop + t;
+      d2_t znew[NC];
+      load_band(b0 + 2, znew);                             // the band that arrives for the next step
+      lds_barrier();                                       // window complete
+      const int k = t - 2 * wave;
+      if (k >= 0 && k < nkw) {
+        const int bw = b0 - 3 * wave;                      // this wave's bands: bw, bw + 1
+        double* z0 = slot(bw);
+        double* z1 = slot(bw + 1);
+        // X = V^T Zw  (32 x 16 per tile, k = 64 window rows)
+        d4_t ax[NC][2];
+#pragma unroll
+        for (int ct = 0; ct < NC; ++ct) ax[ct][0] = ax[ct][1] = d4_t{0.0, 0.0, 0.0, 0.0};
+        // (V is a staircase: reflector j lives on window rows j .. j + 31, so reflectors 0-15 never see rows 48-63 and
+        // reflectors 16-31 never see rows 0-15: 12 of the 16 k-steps each)
+#pragma unroll
+        for (int kq = 0; kq < 16; ++kq)
+#pragma unroll
+          for (int ct = 0; ct < NC; ++ct) {
+            const double zb = (kq < 8 ? z0 : z1)[ct * TILE + ((kq & 7) * 4 + lq) * XLD + lr];
+            if (kq < 12) ax[ct][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[0][kq], zb, ax[ct][0], 0, 0, 0);
+            if (kq >= 4) ax[ct][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[1][kq], zb, ax[ct][1], 0, 0, 0);
+          }
+        if (k + 1 < nkw) load_v(k + 1);                    // (V's registers are free: the next block's travel under the second product)
+#pragma unroll
+        for (int ct = 0; ct < NC; ++ct)
+#pragma unroll
+          for (int xa = 0; xa < 2; ++xa)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xs[ct * TILE + (xa * 16 + 4 * r + lq) * XLD + lr] = ax[ct][xa][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private tiles: written and read by this wave only
+        double xb[NC][8];
+#pragma unroll
+        for (int ct = 0; ct < NC; ++ct)
+#pragma unroll
+          for (int kq = 0; kq < 8; ++kq) xb[ct][kq] = xs[ct * TILE + (kq * 4 + lq) * XLD + lr];
+        // Zw -= W X  (64 x 16 per tile, k = 32 reflectors): two row tiles at a time, so that two accumulator chains interleave
+#pragma unroll
+        for (int zp = 0; zp < 2; ++zp)
+#pragma unroll
+          for (int ct = 0; ct < NC; ++ct) {
+            double* zh = (zp == 0 ? z0 : z1) + ct * TILE;
+            d4_t acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              acc0[r] = zh[(4 * r + lq) * XLD + lr];
+              acc1[r] = zh[(16 + 4 * r + lq) * XLD + lr];
+            }
+#pragma unroll
+            for (int kq = 0; kq < 8; ++kq) {
+              acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[2 * zp][kq], xb[ct][kq], acc0, 0, 0, 1);   // -A
+              if (zp == 0 || kq >= 4) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[2 * zp + 1][kq], xb[ct][kq], acc1, 0, 0, 1);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              zh[(4 * r + lq) * XLD + lr] = acc0[r];
+              zh[(16 + 4 * r + lq) * XLD + lr] = acc1[r];
+            }
+          }
+        if (k + 1 < nkw) load_w(k + 1);
+      }
+      lds_barrier();                                       // every wave is done with its bands
+      // band b0 - 9 is final for this pass; its slot is NOT the arriving band's (the ring has one spare slot), so the arriving
+      // rows go to LDS first and the store follows (a wait for the next load must not also wait for this store)
+      d2_t fin[NC];
+      get_band(b0 - 9, fin);
+      put_band(b0 + 2, znew);
+      store_band(b0 - 9, fin);
+    }
+    lds_barrier();
+    // what is still in the window after the last step: bands (Gtop + T) - 9 .. (Gtop + T) + 1
+    for (int b = Gtop + T - 9; b <= Gtop + T + 1; ++b) {
+      d2_t v[NC];
+      get_band(b, v);
+      store_band(b, v);
+    }
+  }
+}
+
 // Z [n, ldz] (first ncols columns) <- Q2 Z (fwd = 0; blocks prepared with trans = 0) or Q2^T Z (fwd = 1; trans = 1), the sweep
 // groups [G0, G1) only.  skip8: leave the XCD the chase runs on alone.
 int ffgp_q2_apply_impl(ffgp_handle* h, const double* blocks, int n, double* Z, int ldz, int ncols, int G0, int G1, int fwd, int skip8) {
@@ -524,6 +726,23 @@ int ffgp_q2_apply_impl(ffgp_handle* h, const double* blocks, int n, double* Z, i
   a.blocks = blocks; a.n = n; a.K = chase_K(n); a.Z = Z; a.ldz = ldz; a.ncols = ncols; a.dbg = h->diag_dbg;
   a.G0 = G0; a.G1 = G1; a.skip8 = skip8;
   const int nslab = (ncols + 15) / 16;
+  if (!fwd && h->q2_blocks_lanes) {
+    if (skip8) return FFGP_ERR_ARG;
+    static bool attr_set[64] = {false};
+    if (h->device >= 0 && h->device < 64 && !attr_set[h->device]) {
+      FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(q2_apply_wave4<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   Q2W_LDS_DOUBLES(1) * (int)sizeof(double)));
+      FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(q2_apply_wave4<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   Q2W_LDS_DOUBLES(2) * (int)sizeof(double)));
+      attr_set[h->device] = true;
+    }
+    // 16-column slabs (two workgroups per CU) measured faster than 32-column ones at every size: N = 8192 51.9 / 57.4 ms,
+    // N = 16384 401 / 424 ms (the old kernel: 80.4 / 712); option value 2 selects the wide form
+    const bool wide = (h->q2_wave4 == 2);
+    if (wide) hipLaunchKernelGGL(q2_apply_wave4<2>, dim3((ncols + 31) / 32), dim3(256), Q2W_LDS_DOUBLES(2) * sizeof(double), h->stream, a);
+    else hipLaunchKernelGGL(q2_apply_wave4<1>, dim3(nslab), dim3(256), Q2W_LDS_DOUBLES(1) * sizeof(double), h->stream, a);
+    return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
+  }
   const int grid = skip8 ? nslab + (nslab + 6) / 7 + 1 : nslab;
   if (fwd) hipLaunchKernelGGL(q2_apply<true>, dim3(grid), dim3(256), 0, h->stream, a);
   else hipLaunchKernelGGL(q2_apply<false>, dim3(grid), dim3(256), 0, h->stream, a);

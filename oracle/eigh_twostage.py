@@ -307,6 +307,50 @@ def apply_q2(refl, n, b, Z, g=None):
     return Z
 
 
+def apply_q2_wavefront(refl, n, b, Z, g, lanes=4, lag=2):
+    """Z <- Q2 Z in the order of the device's four-groups-per-pass kernel (sb2st.hip, q2_apply_wave4): `lanes` consecutive sweep
+    groups travel down the rows together, group Gtop - w running `lag` steps behind group Gtop - w + 1 -- which keeps the blocks
+    applied at the same time on disjoint rows (block (G, k) covers the row bands G + k and G + k + 1) and every pair of overlapping
+    blocks in the order of `apply_q2`.  Blocks of one time step are applied in an arbitrary order here (reversed, on purpose)."""
+    Z = np.array(Z, dtype=np.float64)
+    if not refl:
+        return Z
+    smax = max(s for s, _ in refl.keys())
+    ngroups = smax // g + 1
+
+    def block(G, k):
+        members = [(s, refl[(s, k)]) for s in range(G * g, min(G * g + g, smax + 1)) if (s, k) in refl]
+        if not members:
+            return None
+        rlo = min(r0 for _, (r0, v, tau) in members)
+        rhi = max(r0 + v.size for _, (r0, v, tau) in members)
+        V = np.zeros((rhi - rlo, len(members)))
+        dinv = np.ones(len(members))
+        for i, (s, (r0, v, tau)) in enumerate(members):
+            if tau != 0.0:
+                V[r0 - rlo:r0 - rlo + v.size, i] = v
+                dinv[i] = 1.0 / tau
+        return rlo, rhi, V, np.linalg.inv(np.triu(V.T @ V, 1) + np.diag(dinv))
+
+    for Gtop in range(ngroups - 1, -1, -lanes):
+        nsteps = [max([k for (s, k) in refl.keys() if (Gtop - w) * g <= s < (Gtop - w) * g + g], default=-1) + 1 if Gtop - w >= 0 else 0
+                  for w in range(lanes)]
+        T = max([nk + lag * w for w, nk in enumerate(nsteps) if nk > 0], default=0)
+        for t in range(T):
+            rows = []
+            for w in reversed(range(lanes)):
+                k = t - lag * w
+                if 0 <= k < nsteps[w]:
+                    blk = block(Gtop - w, k)
+                    if blk is None:
+                        continue
+                    rlo, rhi, V, Tm = blk
+                    assert all(rhi <= a or rlo >= b_ for a, b_ in rows), "blocks of one time step overlap"
+                    rows.append((rlo, rhi))
+                    Z[rlo:rhi] -= (V @ Tm) @ (V.T @ Z[rlo:rhi])
+    return Z
+
+
 def apply_q2_t(refl, n, b, Z, g):
     """Z <- Q2^T Z, the forward order the device uses while the chase is still running: sweep groups ASCENDING (as they are
     produced), steps DESCENDING inside a group, every block transposed:  (I - V T V^T)^T = I - V T^T V^T."""

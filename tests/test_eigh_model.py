@@ -33,6 +33,7 @@ def test_stages_and_block_orderings():
     X = rng.standard_normal((n, 5))
     for g in (4, 16):
         assert np.abs(E.apply_q2(refl, n, b, np.eye(n), g) - Q2).max() < 1e-14        # (group descending, step ascending)
+        assert np.abs(E.apply_q2_wavefront(refl, n, b, np.eye(n), g) - Q2).max() < 1e-14   # (four groups per pass, two steps apart)
         assert np.abs(E.apply_q2_t(refl, n, b, X, g) - Q2.T @ X).max() < 1e-13         # (group ascending, step descending, T^T)
     lam, Z = E.stedc(d, e, leaf=16)
     assert np.abs(lam - np.linalg.eigvalsh(T)).max() < 1e-12 * np.abs(ref).max()

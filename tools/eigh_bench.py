@@ -6,6 +6,10 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from fidelityfusion_amd import eigh as E
+from fidelityfusion_amd import _lib as _opt_lib
+for _kv in os.environ.get("FFGP_EIGH_OPTS", "").split(","):     # e.g. FFGP_EIGH_OPTS=q2_wave4=0
+    if _kv:
+        _opt_lib.check(_opt_lib.lib.ffgp_set_option(_opt_lib.handle(0), _kv.split("=")[0].encode(), float(_kv.split("=")[1])), "ffgp_set_option")
 
 dev = "cuda:0"
 sizes = [1024, 2048, 4096] + ([8192] if "full" in sys.argv else []) + ([16384] if "big" in sys.argv else [])
