@@ -38,7 +38,7 @@ for it in range(150):
     nll = -gp.negative_log_likelihood(x_fit, y_fit)     # (the reference's function returns +LL: callers negate)
     nll.backward()
     opt.step()
-    history.append(float(nll))
+    history.append(float(nll.detach()))
 elapsed = time.perf_counter() - clock
 print("150 likelihood + gradient steps on %s: %.2f s;  nll %.3f -> %.3f" % (where, elapsed, history[0], history[-1]))
 print("length scales", [round(float(v), 3) for v in gp.kernel.length_scales.abs()], " noise sd %.3f" % math.exp(-0.5 * float(gp.log_beta)))
