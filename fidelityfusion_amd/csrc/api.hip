@@ -662,6 +662,25 @@ int ffgp_nlml_fused_raw_async(ffgp_handle* h, const ffgp_problem* p, const ffgp_
   return nlml_fused_raw_enqueue(h, p, l, nll_dev, g);
 }
 
+int ffgp_nlml_fused_small_batch_async(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_links* l, double* nll_dev,
+                                      const ffgp_grads* g) {
+  if (!h || !p || !nll_dev || F <= 0) return FFGP_ERR_ARG;
+  for (int f = 0; f < F; ++f)
+    if (!ffgp_small_batch_ok(p + f, g ? g + f : nullptr)) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  h->n_stages = 0;
+  FFGP_CHECK(ffgp_zero_async(h, h->d_info, sizeof(int)));
+  FFGP_CHECK(ffgp_small_batch_enqueue(h, F, p, l, nll_dev, g));
+  hipLaunchKernelGGL(ffgp_sticky_info_kernel, dim3(1), dim3(1), 0, h->stream, h->d_info);
+  FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  return FFGP_OK;
+}
+
+int ffgp_nlml_fused_small_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g) {
+  FFGP_CHECK(ffgp_nlml_fused_small_batch_async(h, F, p, l, nll_dev, g));
+  return ffgp_wait(h);
+}
+
 // ---- launch-bound sizes: the whole call as one captured graph ---------------------------------------------------------------
 // At N = 128 a likelihood + gradient call is 21 launches of 2-30 us kernels: the host's launch cost (~5 us each) and the gaps
 // between dependent kernels are most of it.  When the SAME call (same inputs, sizes, links, options -- a training loop) arrives

@@ -232,6 +232,8 @@ bool ffgp_small_ok(const ffgp_handle* h, const ffgp_problem* p, const ffgp_grads
 int ffgp_small_enqueue(ffgp_handle* h, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g,
                        const double* dinv = nullptr);
 bool ffgp_small2_ok(const ffgp_handle* h, const ffgp_problem* p, const ffgp_grads* g);
+bool ffgp_small_batch_ok(const ffgp_problem* p, const ffgp_grads* g);
+int ffgp_small_batch_enqueue(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g);
 // ---- workspace
 int ffgp_ensure_ws(ffgp_handle* h, size_t bytes);
 // zero `bytes` (a multiple of 4) on the handle's stream with a kernel: small fills on the captured (graph) path go through this

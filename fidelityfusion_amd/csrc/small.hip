@@ -32,6 +32,7 @@ struct SmallArgs {
   double* g_w; double* g_amp; double* g_dadd; double* g_Y; double* g_diag_vec; double* g_kparam;
   int want_grad;
   int* info;
+  int info_max;         // 1: batch member (atomicMax into the shared status word instead of a plain store)
   const double* dinv;   // FROM_FACTOR: L^-1 as the blocked factorisation left it (one 128 x 128 block, lower part valid)
 };
 
@@ -84,7 +85,7 @@ __device__ __forceinline__ double sm_bsum(double v, double* red, int tid) {
 // does the rest of the call (Gamma, A, value, Sigma^-1, G, every gradient, links, output scale): 7 launches per call instead of 21.
 // (the finishing launch has no column-by-column phases, i.e. few barriers: 1024 threads hide the LDS latency that one wave per SIMD cannot)
 template <bool FROM_FACTOR>
-__global__ __launch_bounds__(FROM_FACTOR ? SM_T2 : SM_T) void ffgp_small_nlml_kernel(SmallArgs a) {
+__device__ __forceinline__ void sm_body(const SmallArgs& a) {
   constexpr int T = FROM_FACTOR ? SM_T2 : SM_T;
   extern __shared__ double sm[];
   double* Sp = sm;                          // packed lower [n (n + 1) / 2]
@@ -182,7 +183,13 @@ __global__ __launch_bounds__(FROM_FACTOR ? SM_T2 : SM_T) void ffgp_small_nlml_ke
       }
     }
     __syncthreads();
-    if (tid == 0) a.info[0] = bad;
+    if (tid == 0) {
+    if (a.info_max) {
+      if (bad) atomicMax(a.info, bad);     // one status word for a whole batch: any failing problem reports
+    } else {
+      a.info[0] = bad;
+    }
+  }
 
     // ---- L^-1 in place, row by row: X[i][j] = -(1 / L_ii) sum_{k = j}^{i-1} L[i][k] X[k][j]; 4 lanes share one j
     {
@@ -344,6 +351,21 @@ __global__ __launch_bounds__(FROM_FACTOR ? SM_T2 : SM_T) void ffgp_small_nlml_ke
   }
 }
 
+template <bool FROM_FACTOR>
+__global__ __launch_bounds__(FROM_FACTOR ? SM_T2 : SM_T) void ffgp_small_nlml_kernel(SmallArgs a) {
+  sm_body<FROM_FACTOR>(a);
+}
+
+// F independent problems in one launch (the per-fidelity / per-seed loops of Experiments/GAR_Aligned/exp_aligned.py:58-126 run
+// models of this size one after the other): workgroup f does problem f, each on its own CU
+#define SM_BATCH 8
+struct SmallBatch {
+  SmallArgs a[SM_BATCH];
+};
+__global__ __launch_bounds__(SM_T) void ffgp_small_batch_kernel(SmallBatch b) {
+  sm_body<false>(b.a[blockIdx.x]);
+}
+
 #define SM_LDS_DOUBLES (SM_N * (SM_N + 1) / 2 + SM_N * (SM_D + 1) + 4 * SM_N * SM_Y + 2 * SM_N + SM_D + 8 + SM_T2 / 64)
 
 // does the "blocked factorisation + one finishing kernel" path cover this call?  (one diagonal block: 40 < n <= 128; option
@@ -368,16 +390,34 @@ bool ffgp_small_ok(const ffgp_handle* h, const ffgp_problem* p, const ffgp_grads
 }
 
 // enqueue the kernel; the caller finishes like the blocked path (sticky info, D2H of the status word)
-int ffgp_small_enqueue(ffgp_handle* h, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g, const double* dinv) {
+static void sm_fill(SmallArgs& a, ffgp_handle* h, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g,
+                    const double* dinv);
+
+static int sm_attr(ffgp_handle* h) {
   static bool attr_set[64] = {false};
   if (h->device >= 0 && h->device < 64 && !attr_set[h->device]) {
     FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_small_nlml_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  SM_LDS_DOUBLES * (int)sizeof(double)));
     FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_small_nlml_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  SM_LDS_DOUBLES * (int)sizeof(double)));
+    FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_small_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 SM_LDS_DOUBLES * (int)sizeof(double)));
     attr_set[h->device] = true;
   }
+  return FFGP_OK;
+}
+
+int ffgp_small_enqueue(ffgp_handle* h, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g, const double* dinv) {
+  FFGP_CHECK(sm_attr(h));
   SmallArgs a;
+  sm_fill(a, h, p, l, nll_dev, g, dinv);
+  if (dinv) hipLaunchKernelGGL(ffgp_small_nlml_kernel<true>, dim3(1), dim3(SM_T2), SM_LDS_DOUBLES * sizeof(double), h->stream, a);
+  else hipLaunchKernelGGL(ffgp_small_nlml_kernel<false>, dim3(1), dim3(SM_T), SM_LDS_DOUBLES * sizeof(double), h->stream, a);
+  return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
+}
+
+static void sm_fill(SmallArgs& a, ffgp_handle* h, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g,
+                    const double* dinv) {
   a.n = p->n; a.D = p->D; a.d = p->d;
   a.X = p->X_dev; a.Y = p->Y_dev; a.w = p->w_dev; a.amp = p->amp_dev; a.dadd = p->diag_add_dev;
   a.has_links = l ? 1 : 0;
@@ -391,8 +431,32 @@ int ffgp_small_enqueue(ffgp_handle* h, const ffgp_problem* p, const ffgp_links* 
   a.g_Y = g ? g->g_Y_dev : nullptr; a.g_diag_vec = g ? g->g_diag_vec_dev : nullptr; a.g_kparam = g ? g->g_kparam_dev : nullptr;
   a.want_grad = (a.g_w || a.g_amp || a.g_dadd || a.g_Y || a.g_diag_vec || a.g_kparam) ? 1 : 0;
   a.info = h->d_info;
+  a.info_max = 0;
   a.dinv = dinv;
-  if (dinv) hipLaunchKernelGGL(ffgp_small_nlml_kernel<true>, dim3(1), dim3(SM_T2), SM_LDS_DOUBLES * sizeof(double), h->stream, a);
-  else hipLaunchKernelGGL(ffgp_small_nlml_kernel<false>, dim3(1), dim3(SM_T), SM_LDS_DOUBLES * sizeof(double), h->stream, a);
+}
+
+// F problems (each must pass ffgp_small_batch_ok) in ceil(F / 8) launches; the caller zeroes the status word first and finishes
+// like the other paths (sticky info, D2H of the status word)
+int ffgp_small_batch_enqueue(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g) {
+  FFGP_CHECK(sm_attr(h));
+  for (int f0 = 0; f0 < F; f0 += SM_BATCH) {
+    SmallBatch b;
+    const int nb = (F - f0 < SM_BATCH) ? F - f0 : SM_BATCH;
+    for (int f = 0; f < nb; ++f) {
+      sm_fill(b.a[f], h, p + f0 + f, l ? l + f0 + f : nullptr, nll_dev + f0 + f, g ? g + f0 + f : nullptr, nullptr);
+      b.a[f].info_max = 1;
+    }
+    for (int f = nb; f < SM_BATCH; ++f) b.a[f] = b.a[0];
+    hipLaunchKernelGGL(ffgp_small_batch_kernel, dim3(nb), dim3(SM_T), SM_LDS_DOUBLES * sizeof(double), h->stream, b);
+  }
   return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
+}
+
+bool ffgp_small_batch_ok(const ffgp_problem* p, const ffgp_grads* g) {
+  if (p->n <= 0 || p->n > SM_N || p->D <= 0 || p->D > SM_D || p->d <= 0 || p->d > SM_Y || p->cov_dev || p->pair || p->tree) return false;
+  if (!p->X_dev || !p->Y_dev || !p->w_dev || !p->amp_dev) return false;
+  if (p->kfun < FFGP_KFUN_SE || p->kfun > FFGP_KFUN_RQ) return false;
+  if (p->ll_variant != FFGP_LL_V1 && p->ll_variant != FFGP_LL_V2) return false;
+  if (g && (g->g_cov_dev || g->g_pair)) return false;
+  return true;
 }

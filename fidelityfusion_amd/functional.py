@@ -318,6 +318,137 @@ class _NLMLRaw(torch.autograd.Function):
         return (None, gYo, gw, ga, gd, gvo, None, gk) + (None,) * 10
 
 
+class _NLMLRawMany(torch.autograd.Function):
+    """F independent small problems in one library call (ffgp_nlml_fused_small_batch): values [F]; gradients for every problem's
+    Y, raw w, raw amp, raw diag_add, diag_vec.  Inputs per problem: X, Y, rw, ramp, rdadd, diag_vec (6 tensors, None allowed for the
+    last two); `metas[f]` = (links, mean_jitter, clamp, variant, pi_const, kfun_id, kparam, sign)."""
+
+    @staticmethod
+    def forward(ctx, metas, rec, *tensors):
+        nF = len(metas)
+        dev = tensors[0].device
+        if dev.index in _raw_pending:
+            _settle_raw(dev.index)
+        h = _lib.handle(dev.index, 0)
+        _lib.bind_stream(h, dev.index)
+        P = (Problem * nF)()
+        L = (_lib.Links * nF)()
+        G = (Grads * nF)()
+        out = torch.empty((nF,), dtype=torch.float64, device=dev)
+        layout, total = [], 0
+        any_grad = False
+        for f in range(nF):
+            X, Y, rw, ramp, rdadd, dvec = tensors[6 * f:6 * f + 6]
+            links, mean_jitter, clamp, variant, pi_const, kfun_id, kparam, sign = metas[f]
+            n, D = X.shape
+            d = Y.shape[1]
+            p = P[f]
+            p.n, p.D, p.d = n, D, d
+            p.X_dev, p.Y_dev, p.w_dev, p.amp_dev = X.data_ptr(), Y.data_ptr(), rw.data_ptr(), ramp.data_ptr()
+            p.clamp_min = clamp
+            if rdadd is not None:
+                p.diag_add_dev = rdadd.data_ptr()
+            if dvec is not None:
+                p.diag_stride = dvec.shape[1] + 1 if dvec.dim() == 2 else 1
+                p.diag_vec_dev = dvec.data_ptr()
+            p.mean_jitter, p.ll_variant, p.pi_const, p.kfun, p.kparam = mean_jitter, variant, pi_const, kfun_id, kparam
+            L[f] = links
+            L[f].out_scale = sign
+            need = ctx.needs_input_grad[2 + 6 * f:2 + 6 * f + 6]
+            nY, nw, na, nd, nv = (rec and bool(need[i]) for i in (1, 2, 3, 4, 5))
+            Dw = rw.numel()
+            seg = (total, Dw, n, d, (nw, na, nd, nY, nv), rw.shape, ramp.shape, None if rdadd is None else rdadd.shape,
+                   None if dvec is None else dvec.shape)
+            layout.append(seg)
+            total += Dw + 3 + n * d + n
+            any_grad = any_grad or nY or nw or na or nd or nv
+        buf = torch.empty((total,), dtype=torch.float64, device=dev) if any_grad else None
+        if buf is not None:
+            base = buf.data_ptr()
+            for f, (off, Dw, n, d, (nw, na, nd, nY, nv), *_r) in enumerate(layout):
+                g = G[f]
+                b = base + 8 * off
+                if nw:
+                    g.g_w_dev = b
+                if na:
+                    g.g_amp_dev = b + 8 * Dw
+                if nd:
+                    g.g_diag_add_dev = b + 8 * (Dw + 1)
+                if nY:
+                    g.g_Y_dev = b + 8 * (Dw + 3)
+                if nv:
+                    g.g_diag_vec_dev = b + 8 * (Dw + 3 + n * d)
+        if buf is not None and DEFER_RAW_ERRORS:
+            check(lib.ffgp_nlml_fused_small_batch_async(h, nF, P, L, out.data_ptr(), G), "ffgp_nlml_fused_small_batch_async")
+            _raw_pending[dev.index] = h
+            ctx.dev_index = dev.index
+        else:
+            rc = check(lib.ffgp_nlml_fused_small_batch(h, nF, P, L, out.data_ptr(), G if buf is not None else None),
+                       "ffgp_nlml_fused_small_batch")
+            if rc > 0:
+                _raise_not_pd(rc, "linalg.cholesky")
+            ctx.dev_index = None
+        ctx.pack = (buf, layout)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        buf, layout = ctx.pack
+        if ctx.dev_index is not None:
+            _settle_raw(ctx.dev_index)
+        grads = []
+        for f, (off, Dw, n, d, (nw, na, nd, nY, nv), sw, sa, sd, sv) in enumerate(layout):
+            gX = gY = gw = ga = gd = gv = None
+            if buf is not None:
+                sc = buf[off:off + Dw + 3 + n * d + n] * gout[f]
+                if nw:
+                    gw = sc[:Dw].view(sw)
+                if na:
+                    ga = sc[Dw:Dw + 1].view(sa)
+                if nd:
+                    gd = sc[Dw + 1:Dw + 2].view(sd)
+                if nY:
+                    gY = sc[Dw + 3:Dw + 3 + n * d].view(n, d)
+                if nv:
+                    gv = sc[Dw + 3 + n * d:]
+                    if len(sv) == 2:
+                        gv = torch.diag_embed(gv)
+            grads += [gX, gY, gw, ga, gd, gv]
+        return (None, None) + tuple(grads)
+
+
+SMALL_BATCH_MAX_N, SMALL_BATCH_MAX_D, SMALL_BATCH_MAX_d = 128, 16, 16
+
+
+def nlml_raw_many(items):
+    """items: list of dicts {X, Y, lk (kernel.links()), rdadd, dadd_link, dadd_c, diag_vec, mean_jitter, variant, pi_const, sign} -- F
+    independent small problems (n <= 128, D <= 16, d <= 16) evaluated by ONE library call; returns the tensor [F] of sign * nll."""
+    metas, tensors = [], []
+    for it in items:
+        lk = it["lk"]
+        L = _lib.Links()
+        L.w_link, L.w_c, L.w_broadcast = lk["w_link"], lk["w_c"], 1 if lk["w"].numel() == 1 and it["X"].shape[1] > 1 else 0
+        L.amp_link, L.amp_c = lk["amp_link"], 0.0
+        L.dadd_link, L.dadd_c = it["dadd_link"], it["dadd_c"]
+        kp = lk.get("kparam")
+        if isinstance(kp, torch.Tensor):
+            raise ValueError("nlml_raw_many: learnable profile parameters (RationalQuadraticKernel.alpha) take the single-problem call")
+        metas.append((L, float(it.get("mean_jitter", 0.0)), lk["clamp"], it.get("variant", FFGP_LL_V1), it.get("pi_const", PI_TRUNC),
+                      lk["kfun"], 1.0 if kp is None else float(kp), float(it.get("sign", 1.0))))
+        tensors += [it["X"], it["Y"], lk["w"], lk["amp"], it["rdadd"], it.get("diag_vec")]
+    return _NLMLRawMany.apply(tuple(metas), torch.is_grad_enabled(), *tensors)
+
+
+def raw_many_ok(kernel, x_train, y_train, *others):
+    """`raw_path` + the size limits of the batched small-problem call"""
+    lk = raw_path(kernel, x_train, y_train, *others)
+    if lk is None or isinstance(lk.get("kparam"), torch.Tensor):
+        return None
+    if x_train.shape[0] > SMALL_BATCH_MAX_N or x_train.shape[1] > SMALL_BATCH_MAX_D or y_train.shape[1] > SMALL_BATCH_MAX_d:
+        return None
+    return lk
+
+
 def raw_ok(*tensors):
     """the raw-parameter fast path needs every tensor resident on ONE GPU in fp64, contiguous, no concurrent-block context, and
     inputs that carry no gradient of their own (the fused call has no input gradients)"""

@@ -382,6 +382,17 @@ int ffgp_nlml_fused_raw(ffgp_handle* h, const ffgp_problem* p, const ffgp_links*
    issue a training step's likelihood this way and collect in backward(), so the host prepares the backward pass while the GPU works */
 int ffgp_nlml_fused_raw_async(ffgp_handle* h, const ffgp_problem* p, const ffgp_links* links, double* nll_dev, const ffgp_grads* g);
 
+/* F independent SMALL problems (n <= 128, D <= 16, d <= 16, one radial-profile kernel each, no caller-built covariance) in one
+   launch per eight problems -- one workgroup each, everything in LDS: the per-fidelity / per-seed loops of the reference's
+   experiments (Experiments/GAR_Aligned/exp_aligned.py:58-126; every model there has N = 16 ... 128) call cigp.negative_log_likelihood
+   for one such model after the other.  p, g: arrays of F; links: array of F (raw parameters, as ffgp_nlml_fused_raw) or NULL
+   (effective parameters); problem f's value lands in nll_dev[f].  The status is shared: a Sigma that is not positive definite in
+   ANY member is reported (as that member's leading minor).  The _async form only enqueues (status: next ffgp_wait).             */
+int ffgp_nlml_fused_small_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_links* links, double* nll_dev,
+                                const ffgp_grads* g);
+int ffgp_nlml_fused_small_batch_async(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_links* links, double* nll_dev,
+                                      const ffgp_grads* g);
+
 /* Same, enqueue only: returns as soon as the work is on the handle's stream (nll/gradients are valid after
    ffgp_wait).  With one handle + stream per block, independent GP blocks (the fidelities of one model, the seeds
    of an experiment sweep) overlap on one GPU: one block's latency-bound factorisation tail runs under another

@@ -785,6 +785,65 @@ def test_small_problem_paths_agree(model, n, D, d):
             assert rel(x, y) < 1e-9, other
 
 
+def test_small_problems_batched_call():
+    """cigp_v10.negative_log_likelihood_many: F independent small models in one library call (ffgp_nlml_fused_small_batch) against
+    the individual calls -- values, every gradient, different sizes / kernels / a diagonal y_var in one batch, more than eight
+    members (two launches), a member that is not positive definite, and the fall-back for a member that is too large"""
+    from fidelityfusion_amd import functional as F
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp, negative_log_likelihood_many
+    rng = np.random.default_rng(12)
+    specs = [(20, 2, 1, "ard"), (64, 3, 2, "m25"), (128, 5, 1, "ard"), (33, 1, 3, "se"), (97, 16, 16, "m05"), (40, 2, 1, "ard"), (41, 2, 1, "ard"),
+             (77, 4, 2, "m15"), (16, 2, 1, "ard"), (100, 3, 1, "se")]
+    models, xs, ys = [], [], []
+    for i, (n, D, d, kn) in enumerate(specs):
+        k = _pair_part(kn, D)
+        models.append(cigp(k, 0.3 + 0.1 * i).double().to(DEV))
+        xs.append(T(rng.uniform(0, 1, (n, D))))
+        Y = T(rng.standard_normal((n, d)), grad=True)
+        ys.append([Y, T(np.diag(rng.uniform(0.01, 0.1, n)))] if i % 3 == 1 else Y)
+    calls = []
+    real = F.lib.ffgp_nlml_fused_small_batch_async
+
+    class _Spy:
+        def __getattr__(self, name):
+            return getattr(F._lib.lib, name)
+
+        def ffgp_nlml_fused_small_batch_async(self, h, nF, *a):
+            calls.append(nF)
+            return real(h, nF, *a)
+    F.lib, keep = _Spy(), F.lib
+    try:
+        vals = negative_log_likelihood_many(models, xs, ys)
+        assert calls == [len(specs)] and vals.shape == (len(specs),)
+        (vals * T(np.linspace(0.5, 1.5, len(specs)))).sum().backward()
+    finally:
+        F.lib = keep
+    got = [(v.detach().clone(), [p_.grad.clone() for p_ in m.parameters()], (y[0] if isinstance(y, list) else y).grad.clone())
+           for v, m, y in zip(vals, models, ys)]
+    for i, (m, x, y) in enumerate(zip(models, xs, ys)):
+        for p_ in m.parameters():
+            p_.grad = None
+        Yt = y[0] if isinstance(y, list) else y
+        Yt.grad = None
+        v = m.negative_log_likelihood(x, y)
+        (v * (0.5 + i / (len(specs) - 1.0))).backward()
+        assert rel(got[i][0], v) < 1e-13, i
+        for a, b in zip(got[i][1], [p_.grad for p_ in m.parameters()]):
+            assert rel(a, b) < 1e-10, i
+        assert rel(got[i][2], Yt.grad) < 1e-10, i
+    # a member whose Sigma is not positive definite: reported (from backward, like the single deferred call)
+    bad_y = [ys[0].detach(), -3.0 * torch.eye(20, device=DEV, dtype=torch.float64)]
+    out = negative_log_likelihood_many(models[:3], xs[:3], [bad_y, ys[1], ys[2]])
+    with pytest.raises(torch.linalg.LinAlgError):
+        out.sum().backward()
+    # a member that is too large: the individual calls
+    big = cigp(kernel.ARDKernel(2), 0.5).double().to(DEV)
+    xb, yb = T(rng.uniform(0, 1, (200, 2))), T(rng.standard_normal((200, 1)))
+    mixed = negative_log_likelihood_many([models[0], big], [xs[0], xb], [ys[0], yb])
+    assert rel(mixed[1], big.negative_log_likelihood(xb, yb)) < 1e-13 and rel(mixed[0], got[0][0]) < 1e-13
+
+
 def test_small_finish_reports_not_pd():
     """the finishing-kernel path keeps the factorisation's status: a Sigma that is not positive definite raises"""
     from fidelityfusion_amd import kernel
