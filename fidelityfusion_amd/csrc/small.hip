@@ -159,57 +159,73 @@ __device__ __forceinline__ void sm_body(const SmallArgs& a) {
     }
     __syncthreads();
 
-    // ---- Cholesky, right-looking; thread (ti, tk) of a 16 x 16 grid updates rows j+1+ti (+16..) x columns j+1+tk (+16..), k <= i
+    // ---- Cholesky, right-looking; thread (ti, tk) of a 16 x 16 grid updates rows j+1+ti (+16..) x columns j+1+tk (+16..), k <= i.
+    // ONE barrier per column: column j stays unscaled while its step runs (the update multiplies by 1 / d_jj itself) and is
+    // scaled to L during step j + 1, when nobody reads it any more; 1 / L_jj by rsq + two Newton steps, the log-determinant
+    // from the stored reciprocals afterwards.
     const int ti = tid / SM_TG, tk = tid % SM_TG;
     int bad = 0;
+    double inv_prev = 0.0;
     for (int j = 0; j < n; ++j) {
       __syncthreads();                       // the previous column's trailing update is complete
+      if (j > 0)
+        for (int i = j + tid; i < n; i += T) Sp[sm_pk(i, j - 1)] *= inv_prev;     // column j - 1 becomes L's
       const double djj = Sp[sm_pk(j, j)];    // (the diagonal of L is never stored: the inverse below only needs 1 / L_jj)
       if (!(djj > 0.0) && bad == 0) bad = j + 1;
-      const double ljj = sqrt(djj), inv = 1.0 / ljj;
-      logdet += log(ljj);
-      for (int i = j + 1 + tid; i < n; i += T) {
-        const double l = Sp[sm_pk(i, j)] * inv;
-        Sp[sm_pk(i, j)] = l;
-        rowb[i] = l;
-      }
-      if (tid == 0) dinv[j] = inv;
-      __syncthreads();
+      double r = __builtin_amdgcn_rsq(djj);                       // 1 / sqrt(d_jj)
+      r = __builtin_fma(0.5 * r, __builtin_fma(-djj * r, r, 1.0), r);
+      r = __builtin_fma(0.5 * r, __builtin_fma(-djj * r, r, 1.0), r);
+      const double inv2 = r * r;
+      if (tid == 0) dinv[j] = r;
+      inv_prev = r;
       for (int i = j + 1 + ti; i < n; i += SM_TG) {
-        const double li = rowb[i];
         const int base = i * (i + 1) / 2;
+        const double li = Sp[base + j] * inv2;
 #pragma unroll 4
-        for (int k = j + 1 + tk; k <= i; k += SM_TG) Sp[base + k] = __builtin_fma(-li, rowb[k], Sp[base + k]);
+        for (int k = j + 1 + tk; k <= i; k += SM_TG) Sp[base + k] = __builtin_fma(-li, Sp[sm_pk(k, j)], Sp[base + k]);
       }
     }
     __syncthreads();
     if (tid == 0) {
-    if (a.info_max) {
-      if (bad) atomicMax(a.info, bad);     // one status word for a whole batch: any failing problem reports
-    } else {
-      a.info[0] = bad;
+      if (a.info_max) {
+        if (bad) atomicMax(a.info, bad);     // one status word for a whole batch: any failing problem reports
+      } else {
+        a.info[0] = bad;
+      }
     }
-  }
+    {
+      double ld = 0.0;
+      for (int j = tid; j < n; j += T) ld -= log(dinv[j]);
+      logdet = sm_bsum<T>(ld, red, tid);
+    }
 
-    // ---- L^-1 in place, row by row: X[i][j] = -(1 / L_ii) sum_{k = j}^{i-1} L[i][k] X[k][j]; 4 lanes share one j
+    // ---- L^-1 in place, row by row: X[i][j] = -(1 / L_ii) sum_{k = j}^{i-1} L[i][k] X[k][j]; 4 lanes share one j.  Row i of L is
+    // copied aside first (its entries are overwritten by X's while other lanes still need them); the copy of row i + 1 is made
+    // during row i's arithmetic into the other of two buffers: one barrier per row.
     {
       const int jq = tid >> 2, kp = tid & 3;          // T / 4 columns per pass: one pass
+      double* rb[2] = {rowb, Gam};                    // (Gamma's storage is free until the inverse is complete)
+      __syncthreads();
       for (int i = 0; i < n; ++i) {
         const int base = i * (i + 1) / 2;
-        for (int k = tid; k < i; k += T) rowb[k] = Sp[base + k];
-        __syncthreads();
+        const double* rw = rb[i & 1];
         for (int j0 = 0; j0 < i; j0 += T / 4) {
           const int j = j0 + jq;
           double s = 0.0;
           if (j < i) {
 #pragma unroll 4
-            for (int k = j + kp; k < i; k += 4) s = __builtin_fma(rowb[k], Sp[sm_pk(k, j)], s);
+            for (int k = j + kp; k < i; k += 4) s = __builtin_fma(rw[k], Sp[sm_pk(k, j)], s);
           }
           s += __shfl_xor(s, 1);
           s += __shfl_xor(s, 2);
           if (j < i && kp == 0) Sp[base + j] = -dinv[i] * s;
         }
         if (tid == 0) Sp[base + i] = dinv[i];
+        if (i + 1 < n) {
+          double* nx = rb[(i + 1) & 1];
+          const int nb = (i + 1) * (i + 2) / 2;
+          for (int k = tid; k <= i; k += T) nx[k] = Sp[nb + k];
+        }
         __syncthreads();
       }
     }
