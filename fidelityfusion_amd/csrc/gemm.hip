@@ -733,7 +733,7 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
     int parts = 1;
     if (opa_t == OP_MNMAJOR) {
       const int wg = (n + 63) / 64;
-      parts = max(1, min(min((512 + wg - 1) / wg, k / 256), 16));
+      parts = max(1, min(min((2048 + wg - 1) / wg, k / 256), 16));
     }
     if (parts >= 2) {
       const int ldp = (n + 1) & ~1;
