@@ -193,6 +193,13 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
                         is at least asm_mm_min evaluate their interior 64 x 64 tiles on the matrix cores -- norm expansion, guarded
                         per 32 x 32 block by a fall-back to the difference form wherever a distance is below 1e-6 of the
                         squared norms -- with asm_mm_grid persistent workgroups; 0 = the difference kernel alone),
+            "q2_wave4" (default 1: ffgp_syevd / ffgp_ormq2 apply Q2 with four sweep groups per pass over Z; 2 = the same on
+                        32-column slabs; 0 = one group per pass -- blocks are prepared in the matching layout by ffgp_sb2st),
+            "small_finish" (default 0; 1: 40 < n <= 128 runs assembly + blocked factorisation + ONE finishing kernel, 7 launches
+                        instead of 21 -- measured +-5-10 % per training step),
+            "raw_graph_max_n" (default 0; > 0: ffgp_nlml_fused_raw calls with n <= this are captured into a hipGraph on their
+                        second identical occurrence and replayed afterwards -- measured no faster on ROCm 7.2),
+            "diag_v2" (default 1: pipelined diagonal-block kernel; 0 = the barrier version, 2 = helper waves off wave 0's SIMD),
             "trtri_overlap", "small_fused", "small_max_n", "chase_pack", "eig_overlap", "sb_lookahead" (round-3 experiment
                         switches)                                                                  */
 int ffgp_set_option(ffgp_handle* h, const char* key, double value);
