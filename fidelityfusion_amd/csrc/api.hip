@@ -327,6 +327,8 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->trtri_overlap = (int)value;
   } else if (!strcmp(key, "small_max_n")) {
     h->small_max_n = (int)value;
+  } else if (!strcmp(key, "sb_av_gemm")) {
+    h->sb_av_gemm = (int)value;
   } else if (!strcmp(key, "q2_wave4")) {
     h->q2_wave4 = (int)value;
   } else if (!strcmp(key, "small_finish")) {

@@ -177,6 +177,7 @@ struct ffgp_handle {
   int* d_info;       // device status word(s)
   double* d_scal;    // small device scalar scratch (64 doubles)
   // launch-bound sizes: the raw-parameter likelihood call replayed as a captured graph (api.hip, nlml_fused_raw_enqueue)
+  int sb_av_gemm;              // option "sb_av_gemm" (default 0): 1 = the band reduction's A Y product on the general GEMM again
   int q2_blocks_lanes;         // how the last q2_prep wrote its blocks (1: lane order for q2_apply_wave4)
   int q2_wave4;                // option "q2_wave4" (default 1): Z <- Q2 Z with four sweep groups per pass over Z (sb2st.hip)
   int small2_off;              // option "small_finish" (default 0 = off): 1 = 40 < n <= 128 runs assembly + the blocked diagonal-block

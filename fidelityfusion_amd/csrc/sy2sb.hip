@@ -412,6 +412,89 @@ __global__ __launch_bounds__(256) void sy2sb_form_y(FormYArgs p) {
   }
 }
 
+// Yp-partials = A22[:, chunk] Y[chunk, :]: m x m times m x 32, the one place of the band reduction that reads the trailing matrix
+// without writing it.  On the general GEMM (64 x 64 tiles, half of every tile's 64 columns empty, k chunks of a few hundred) it
+// read A at 0.85 TB/s -- 54 of the 104 ms of sy2sb at N = 8192.  Here a workgroup owns 128 rows and one k chunk: the A tile of a
+// k step (128 x 16) arrives by 16-byte loads, one step ahead in registers, goes through LDS into the MFMA lane layout, and every
+// wave multiplies its 32 rows by the chunk of Y (16 x 32, also in LDS): 16 MFMAs per wave and step.
+struct AvArgs {
+  const double* A; int lda;      // A22, m x m row-major
+  const double* Y; int ldy;      // Y, m x 32
+  double* P; long sP;            // partials [parts][m][32]
+  int m, kc;                     // chunk length (multiple of 16); chunk c covers k in [c kc, min(m, (c + 1) kc))
+};
+
+__global__ __launch_bounds__(256, 4) void sy2sb_av(AvArgs p) {
+  __shared__ double As[128][17];
+  __shared__ double Ys[16][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  const int r0 = blockIdx.x * 128;
+  const int k0 = blockIdx.y * p.kc, k1 = min(p.m, k0 + p.kc);
+  if (k0 >= k1) return;
+  // staging maps: A tile 128 x 16 -- thread t takes row t / 2, eight doubles at column 8 (t % 2); Y chunk 16 x 32 -- two doubles per thread
+  const int arow = tid >> 1, acol = (tid & 1) * 8;
+  const double* __restrict__ ap = p.A + (size_t)min(r0 + arow, p.m - 1) * p.lda + acol;
+  const int yk = tid >> 4, yc = (tid & 15) * 2;
+  const double* __restrict__ yp = p.Y + yc;
+  struct Tile { d4_t a0, a1; d2_t y; };
+  auto fetch = [&](int k, Tile& t) {
+    t.a0 = *reinterpret_cast<const d4_t*>(ap + k);
+    t.a1 = *reinterpret_cast<const d4_t*>(ap + k + 4);
+    t.y = *reinterpret_cast<const d2_t*>(yp + (size_t)(k + yk) * p.ldy);
+  };
+  d4_t acc[2][2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = d4_t{0.0, 0.0, 0.0, 0.0};
+  auto step = [&](const Tile& t) {
+    __syncthreads();                       // the previous step's operand reads are done
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      As[arow][acol + q] = t.a0[q];
+      As[arow][acol + 4 + q] = t.a1[q];
+    }
+    Ys[yk][yc] = t.y.x;
+    Ys[yk][yc + 1] = t.y.y;
+    __syncthreads();
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      double av[2], bv[2];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) av[rt] = As[32 * wave + 16 * rt + lr][4 * s4 + lq];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) bv[ct] = Ys[4 * s4 + lq][16 * ct + lr];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[rt], bv[ct], acc[rt][ct], 0, 0, 0);
+    }
+  };
+  // two tiles in flight: the loads of steps k + 16 and k + 32 travel under the products of step k
+  Tile ta, tb;
+  fetch(k0, ta);
+  if (k0 + 16 < k1) fetch(k0 + 16, tb);
+  for (int k = k0; k < k1; k += 32) {
+    step(ta);
+    if (k + 32 < k1) fetch(k + 32, ta);
+    if (k + 16 < k1) {
+      step(tb);
+      if (k + 48 < k1) fetch(k + 48, tb);
+    }
+  }
+  double* __restrict__ out = p.P + (size_t)blockIdx.y * p.sP;
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = r0 + 32 * wave + 16 * rt + 4 * r + lq;
+      if (row < p.m) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) out[(size_t)row * 32 + 16 * ct + lr] = acc[rt][ct][r];
+      }
+    }
+}
+
 struct RedArgs {
   const double* P; long sP; int parts;   // partial products A22[:, chunk] Y[chunk, :], [parts][m][32]
   const double* Y; int ldy;
@@ -607,17 +690,23 @@ int ffgp_sy2sb_impl(ffgp_handle* h, double* A, int n, int lda, double* AB, doubl
     // Yp = A22 Y  (m x m times m x 32; A22 K-major, Y stored k x n), cut along k into `parts` chunks that run as ONE batched launch
     // (enough workgroups to fill the chip whatever m is); the chunks are summed in fixed order by sy2sb_red, which also leaves
     // the pieces of G = Y^T Yp
-    int parts = min(AV_MAX_PARTS, max(1, 1024 / ((m + 63) / 64)));
+    int parts = min(AV_MAX_PARTS, max(1, (h->sb_av_gemm ? 1024 : 2048) / ((m + 63) / 64)));
     int kc = ((m + parts - 1) / parts + 31) & ~31;
     parts = m / kc;                       // full chunks; a shorter tail chunk runs as its own launch
     const int tail = m - parts * kc;
     const long sP = (long)m * 32;
-    if (parts > 0)
-      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, A22, lda, Ypan, ldy, Ppart, 32, m, 32, kc, 1.0, 0.0, 0, ALIAS_NONE, parts,
-                                  (long)kc, (long)kc * ldy, sP));
-    if (tail > 0)
-      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, A22 + (size_t)parts * kc, lda, Ypan + (size_t)parts * kc * ldy, ldy,
-                                  Ppart + (size_t)parts * sP, 32, m, 32, tail, 1.0, 0.0));
+    if (h->sb_av_gemm) {                  // (the general GEMM, kept for comparison: option "sb_av_gemm")
+      if (parts > 0)
+        FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, A22, lda, Ypan, ldy, Ppart, 32, m, 32, kc, 1.0, 0.0, 0, ALIAS_NONE, parts,
+                                    (long)kc, (long)kc * ldy, sP));
+      if (tail > 0)
+        FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, A22 + (size_t)parts * kc, lda, Ypan + (size_t)parts * kc * ldy, ldy,
+                                    Ppart + (size_t)parts * sP, 32, m, 32, tail, 1.0, 0.0));
+    } else {
+      AvArgs av;
+      av.A = A22; av.lda = lda; av.Y = Ypan; av.ldy = ldy; av.P = Ppart; av.sP = sP; av.m = m; av.kc = kc;
+      hipLaunchKernelGGL(sy2sb_av, dim3((m + 127) / 128, parts + (tail > 0 ? 1 : 0)), dim3(256), 0, st, av);
+    }
     RedArgs ra;
     ra.P = Ppart; ra.sP = sP; ra.parts = parts + (tail > 0 ? 1 : 0); ra.Y = Ypan; ra.ldy = ldy; ra.Yp = Yp; ra.Gpart = Gpart; ra.m = m;
     const int nred = (m + 127) / 128;

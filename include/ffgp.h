@@ -199,6 +199,8 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
                         instead of 21 -- measured +-5-10 % per training step),
             "raw_graph_max_n" (default 0; > 0: ffgp_nlml_fused_raw calls with n <= this are captured into a hipGraph on their
                         second identical occurrence and replayed afterwards -- measured no faster on ROCm 7.2),
+            "sb_av_gemm" (default 0: the band reduction forms A * Y with its own 128-row kernel; 1 = the general GEMM -- measured
+                        sy2sb 104 -> 91 ms at n = 8192, equal below n = 4096),
             "diag_v2" (default 1: pipelined diagonal-block kernel; 0 = the barrier version, 2 = helper waves off wave 0's SIMD),
             "trtri_overlap", "small_fused", "small_max_n", "chase_pack", "eig_overlap", "sb_lookahead" (round-3 experiment
                         switches)                                                                  */
