@@ -123,18 +123,18 @@ __device__ __forceinline__ void qr512(double (&a)[16], QrShared& sh, const int t
     }
   }
   __syncthreads();
-  if (tid < 32) {   // T row by row: T[i][j] = -tau_j sum_{c = i}^{j-1} T[i][c] H[c][j]
-    const int ti = tid;
-    for (int j = 0; j < 32; ++j) {
-      double t = 0.0;
-      if (j == ti) t = sh.tau[j];
-      else if (j > ti) {
-        double sacc = 0.0;
-        for (int cc = ti; cc < j; ++cc) sacc = __builtin_fma(sh.T[ti][cc], sh.H[cc][j], sacc);
-        t = -sh.tau[j] * sacc;
-      }
-      sh.T[ti][j] = t;
+  {   // T row by row: T[t][j] = -tau_j sum_{cc = t}^{j-1} T[t][cc] H[cc][j].  The rows are independent recurrences: row t runs on
+      // half-wave t with T[t][cc] in lane cc, every step one product per lane and a half-wave sum -- no barrier, no serial inner loop
+    const int t = c;
+    double trow = (i == t) ? sh.tau[t] : 0.0;
+#pragma unroll 4
+    for (int j = 1; j < 32; ++j) {
+      const double hv = sh.H[i][j];                       // (only read into the sum where i < j: the part the loop above wrote)
+      const double prod = (i >= t && i < j) ? trow * hv : 0.0;
+      const double ssum = qr_wsum32(prod, lane);
+      if (i == j && j > t) trow = -sh.tau[j] * ssum;
     }
+    sh.T[t][i] = trow;
   }
   __syncthreads();
 }
@@ -281,24 +281,23 @@ __global__ __launch_bounds__(QR_THREADS) void sy2sb_top(TopArgs p) {
   // U (upper) -> M1;  T = U Y1^-T -> M2 (row i: forward substitution over the columns);  U^-1 -> Q0 (column by column)
   M1[i][c] = (c >= i) ? (((i == c) ? 1.0 : 0.0) - Ssign[c] * Wt[i][c]) : 0.0;
   __syncthreads();
-  if (tid < 32) {
-    const int ti = tid;
+  {   // both triangular solves as independent half-wave recurrences (value of entry cc in lane cc, one half-wave sum per step):
+      // row c of T = U Y1^-T (forward over the columns) and column c of U^-1 (backward over the rows)
+    const double urow = M1[c][i];
+    const double dii = M1[i][i];
+    double m2 = 0.0, q = 0.0;
+#pragma unroll 4
     for (int j = 0; j < 32; ++j) {
-      double sacc = M1[ti][j];
-      for (int cc = 0; cc < j; ++cc) sacc = __builtin_fma(-M2[ti][cc], V1[j][cc], sacc);
-      M2[ti][j] = sacc;
+      const int ii = 31 - j;
+      const double yv = V1[j][i];
+      const double uv = M1[ii][i];
+      const double s1 = qr_wsum32((i < j) ? m2 * yv : 0.0, lane);
+      const double s2 = qr_wsum32((i > ii && i <= c) ? uv * q : 0.0, lane);
+      if (i == j) m2 = urow - s1;
+      if (i == ii) q = (ii > c) ? 0.0 : (((ii == c) ? 1.0 : 0.0) - s2) / dii;
     }
-  } else if (tid >= 64 && tid < 96) {
-    const int j = tid - 64;               // column j of U^-1: back substitution
-    for (int ii = 31; ii >= 0; --ii) {
-      if (ii > j) {
-        Q0[ii][j] = 0.0;
-        continue;
-      }
-      double sacc = (ii == j) ? 1.0 : 0.0;
-      for (int cc = ii + 1; cc <= j; ++cc) sacc = __builtin_fma(-M1[ii][cc], Q0[cc][j], sacc);
-      Q0[ii][j] = sacc / M1[ii][ii];
-    }
+    M2[c][i] = m2;
+    Q0[i][c] = q;
   }
   __syncthreads();
   {
