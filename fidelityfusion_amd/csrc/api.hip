@@ -198,6 +198,7 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->raw_graph_max_n = 0;
   h->small2_off = 1;
   h->q2_wave4 = 1;
+  h->sb_qr4 = 0;
   h->asm_mm = 1;
   h->asm_mm_min = 6144;
   h->asm_mm_grid = 768;
@@ -329,6 +330,8 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->small_max_n = (int)value;
   } else if (!strcmp(key, "sb_av_gemm")) {
     h->sb_av_gemm = (int)value;
+  } else if (!strcmp(key, "sb_qr4")) {
+    h->sb_qr4 = (int)value;
   } else if (!strcmp(key, "q2_wave4")) {
     h->q2_wave4 = (int)value;
   } else if (!strcmp(key, "small_finish")) {

@@ -23,6 +23,18 @@
 #include "syevd_internal.h"
 
 #define QR_ROWS 512   // rows of one TSQR leaf
+#ifdef FFGP_QR_STAMPS   // development probe (tools/native/qr_phases.hip): 100 MHz clock stamps of workgroup 0, thread 0
+__device__ unsigned long long ffgp_qr_stamp[64];
+#define QR_STAMP(k)                                                              \
+  do {                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+    __builtin_amdgcn_s_waitcnt(0);                                               \
+    if (blockIdx.x == 0 && threadIdx.x == 0) ffgp_qr_stamp[k] = wall_clock64();  \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+  } while (0)
+#else
+#define QR_STAMP(k)
+#endif
 #define QR_THREADS 1024
 
 template <int CTRL>
@@ -166,6 +178,168 @@ __global__ __launch_bounds__(QR_THREADS) void sy2sb_leaf_qr(LeafArgs p) {
   }
   p.Rst[(size_t)blockIdx.x * 1024 + i * 32 + c] = (i <= c) ? a[0] : 0.0;
   p.Tst[(size_t)blockIdx.x * 1024 + tid] = sh.T[tid >> 5][tid & 31];
+}
+
+// ---- the same QR on 256 threads (option "sb_qr4", off by default) ----------------------------------------------------------------
+// A half-wave holds FOUR columns (4 hw .. 4 hw + 3; lane i the rows i + 32 r in a[q][r]).  Against qr512: the reflector is read
+// from LDS once per wave and used for four columns, and nobody waits for the owner's norm: the owner publishes the RAW column below
+// the diagonal (zeros at and above it) plus row j of the block, and every half-wave derives sigma, tau and the scale itself, next to
+// its own four dot products --
+//   v = [1; s x],  v^T a_c = a_jc + s x^T a_c,   a_c <- a_c - tau (v^T a_c) v,   H[c][j] = v^T V_c by the same expression (c < j).
+// One barrier per column.  Measured (N = 8192, kernel trace): 58.9 us per panel against 54.4 us for the 1024-thread kernel -- NOT
+// faster.  tools/native/qr_phases.hip (clock stamps, workgroup 0): load 4.2, 32 columns 37.6 (1.16 per column: LDS 0.12, dots 0.16,
+// five half-wave sums 0.36, scalars 0.16, updates 0.32, publish 0.12, barrier 0.16), T build 11.5 (four rows per half-wave, one
+// after the other), store 3.8 us.  What it does do: a workgroup of one wave per SIMD finds room beside a running GEMM, so under
+// "sb_lookahead" the leaves end before the trailing update instead of 60 us after it -- and still the stage is no faster (85.2 ms),
+// because they take 127 us there and sy2sb_top (1024 threads) runs at the update's tail.
+#define QR4_THREADS 256
+struct Qr4Shared {
+  double x[2][QR_ROWS];    // raw column j below the diagonal, double-buffered
+  double rowj[2][32];      // row j of the block after reflector j - 1
+  double tau[32];
+  double H[32][33];
+  double T[32][33];
+};
+
+__device__ __forceinline__ void qr512x4(double (&a)[4][16], Qr4Shared& sh, const int tid) {
+  const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, i = lane & 31;
+  const int hw = wave * 2 + half;
+  if (hw == 0) {
+    sh.x[0][i] = (i > 0) ? a[0][0] : 0.0;
+#pragma unroll
+    for (int r = 1; r < 16; ++r) sh.x[0][i + 32 * r] = a[0][r];
+  }
+  if (i == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sh.rowj[0][4 * hw + q] = a[q][0];
+  }
+  __syncthreads();
+  for (int jb = 0; jb < 8; ++jb) {
+#pragma unroll
+    for (int jq = 0; jq < 4; ++jq) {
+      const int j = 4 * jb + jq, buf = j & 1;
+      if (jq == 0) QR_STAMP(8 + jb);                 // start of every block of four columns
+      if (j == 16) QR_STAMP(20);
+      double xr[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xr[r] = sh.x[buf][i + 32 * r];
+      const double alpha = sh.rowj[buf][j];
+      double arow[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) arow[q] = sh.rowj[buf][4 * hw + q];
+      if (j == 16) QR_STAMP(21);                     // reflector and row j are in registers
+      double ss = 0.0, d[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        ss = __builtin_fma(xr[r], xr[r], ss);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] = __builtin_fma(xr[r], a[q][r], d[q]);
+      }
+      if (j == 16) QR_STAMP(22);                     // five dot products per lane
+      const double sigma = qr_wsum32(ss, lane);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[q] = qr_wsum32(d[q], lane);
+      if (j == 16) QR_STAMP(23);                     // five half-wave sums
+      double tau = 0.0, beta = alpha, scale = 0.0;
+      if (sigma != 0.0) {
+        const double qq = __builtin_fma(alpha, alpha, sigma);
+        double rs = __builtin_amdgcn_rsq(qq);
+        rs = __builtin_fma(0.5 * rs, __builtin_fma(-qq * rs, rs, 1.0), rs);
+        rs = __builtin_fma(0.5 * rs, __builtin_fma(-qq * rs, rs, 1.0), rs);
+        double nrm = qq * rs;
+        nrm = __builtin_fma(0.5 * rs, __builtin_fma(-nrm, nrm, qq), nrm);
+        beta = (alpha >= 0.0) ? -nrm : nrm;
+        tau = (beta - alpha) * qr_rcp(beta);
+        scale = qr_rcp(alpha - beta);
+      }
+      if (j == 16) QR_STAMP(24);                     // beta, tau, scale
+      const int nb = buf ^ 1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = 4 * hw + q;
+        const double w = __builtin_fma(scale, d[q], arow[q]);     // v^T a_c  (c > j)  =  v^T V_c  (c < j)
+        if (c > j) {
+          const double f = tau * w, g = f * scale;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) a[q][r] = __builtin_fma(-g, xr[r], a[q][r]);
+          if (i == j) a[q][0] -= f;
+        } else if (c < j) {
+          if (i == 0) sh.H[c][j] = w;
+        }
+      }
+      if (j == 16) QR_STAMP(25);                     // four column updates
+      if (hw == jb) {          // the owner: V below the diagonal, beta on it
+        a[jq][0] = (i > j) ? xr[0] * scale : ((i == j) ? beta : a[jq][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) a[jq][r] = xr[r] * scale;
+        if (i == 0) sh.tau[j] = tau;
+      }
+      if (j < 31) {            // publish column j + 1 (raw, below its diagonal) and row j + 1
+        const int nq = (jq + 1) & 3;      // (a compile-time index once the jq loop is unrolled)
+        const int nhw = (j + 1) >> 2;
+        if (hw == nhw) {
+          sh.x[nb][i] = (i > j + 1) ? a[nq][0] : 0.0;
+#pragma unroll
+          for (int r = 1; r < 16; ++r) sh.x[nb][i + 32 * r] = a[nq][r];
+        }
+        if (i == j + 1) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sh.rowj[nb][4 * hw + q] = a[q][0];
+        }
+      }
+      if (j == 16) QR_STAMP(26);                     // next column published
+      __syncthreads();
+      if (j == 16) QR_STAMP(27);                     // barrier
+    }
+  }
+  QR_STAMP(16);
+  // T: row t on a half-wave, four rows each (see qr512)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int t = 4 * hw + q;
+    double trow = (i == t) ? sh.tau[t] : 0.0;
+#pragma unroll 4
+    for (int j = 1; j < 32; ++j) {
+      const double hv = sh.H[i][j];
+      const double ssum = qr_wsum32((i >= t && i < j) ? trow * hv : 0.0, lane);
+      if (i == j && j > t) trow = -sh.tau[j] * ssum;
+    }
+    sh.T[t][i] = trow;
+  }
+  __syncthreads();
+}
+
+// leaf QR on qr512x4: every lane moves 32 bytes (its four columns) per row
+__global__ __launch_bounds__(QR4_THREADS) void sy2sb_leaf_qr4(LeafArgs p) {
+  __shared__ Qr4Shared sh;
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, hw = (tid >> 6) * 2 + (lane >> 5);
+  const int row0 = blockIdx.x * QR_ROWS;
+  const int nrows = min(QR_ROWS, p.m - row0);
+  double* __restrict__ P = p.A + (size_t)row0 * p.lda + 4 * hw;
+  QR_STAMP(0);
+  double a[4][16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int gr = i + 32 * r;
+    d4_t v = d4_t{0.0, 0.0, 0.0, 0.0};
+    if (gr < nrows) v = *reinterpret_cast<const d4_t*>(P + (size_t)gr * p.lda);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q][r] = v[q];
+  }
+  QR_STAMP(1);
+  qr512x4(a, sh, tid);
+  QR_STAMP(2);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int gr = i + 32 * r;
+    if (gr < nrows) *reinterpret_cast<d4_t*>(P + (size_t)gr * p.lda) = d4_t{a[0][r], a[1][r], a[2][r], a[3][r]};
+  }
+  d4_t rv;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) rv[q] = (i <= 4 * hw + q) ? a[q][0] : 0.0;
+  *reinterpret_cast<d4_t*>(p.Rst + (size_t)blockIdx.x * 1024 + i * 32 + 4 * hw) = rv;
+  for (int idx = tid; idx < 1024; idx += QR4_THREADS) p.Tst[(size_t)blockIdx.x * 1024 + idx] = sh.T[idx >> 5][idx & 31];
+  QR_STAMP(3);
 }
 
 // ---- small dense helpers on 32 x 32 LDS matrices (leading dimension 33), 256 threads, 4 outputs per thread -------------
@@ -412,10 +586,11 @@ __global__ __launch_bounds__(256) void sy2sb_form_y(FormYArgs p) {
 }
 
 // Yp-partials = A22[:, chunk] Y[chunk, :]: m x m times m x 32, the one place of the band reduction that reads the trailing matrix
-// without writing it.  On the general GEMM (64 x 64 tiles, half of every tile's 64 columns empty, k chunks of a few hundred) it
-// read A at 0.85 TB/s -- 54 of the 104 ms of sy2sb at N = 8192.  Here a workgroup owns 128 rows and one k chunk: the A tile of a
-// k step (128 x 16) arrives by 16-byte loads, one step ahead in registers, goes through LDS into the MFMA lane layout, and every
-// wave multiplies its 32 rows by the chunk of Y (16 x 32, also in LDS): 16 MFMAs per wave and step.
+// without writing it.  On the general GEMM (64 x 64 tiles, half of every tile's 64 columns empty) this took two launches of 39 us per
+// panel at N = 8192 (kernel trace), about 20 of the stage's 104 ms.  Here a workgroup owns 128 rows and one k chunk: the A tile of a
+// k step (128 x 16) arrives by 16-byte loads, goes through LDS into the MFMA lane layout, and every wave multiplies its 32 rows by
+// the chunk of Y (16 x 32, also in LDS): 16 MFMAs per wave and step.  Traced: 48 us per panel, 12.2 ms of the stage (about 3.7 TB/s
+// on the average trailing matrix).  Two tiles in flight instead of one measured the same: not bound by load latency.
 struct AvArgs {
   const double* A; int lda;      // A22, m x m row-major
   const double* Y; int ldy;      // Y, m x 32
@@ -659,14 +834,16 @@ int ffgp_sy2sb_impl(ffgp_handle* h, double* A, int n, int lda, double* AB, doubl
     double* Ypan = Y + (size_t)r0 * ldy + j0;
     LeafArgs la_;
     la_.A = Ap; la_.lda = lda; la_.m = m; la_.Rst = Rst; la_.Tst = Tst;
-    hipLaunchKernelGGL(sy2sb_leaf_qr, dim3(L), dim3(QR_THREADS), 0, q, la_);
+    if (h->sb_qr4) hipLaunchKernelGGL(sy2sb_leaf_qr4, dim3(L), dim3(QR4_THREADS), 0, q, la_);
+    else hipLaunchKernelGGL(sy2sb_leaf_qr, dim3(L), dim3(QR_THREADS), 0, q, la_);
     // more than 16 leaves (m > 8192): a middle level -- the same kernel factors the leaves' R factors, 16 (= 512 rows) at a time
     const int three = (L > 16) ? 1 : 0;
     const int L2 = (L + 15) / 16;
     if (three) {
       LeafArgs lm;
       lm.A = Rst; lm.lda = 32; lm.m = L * 32; lm.Rst = Rst2; lm.Tst = Tst2;
-      hipLaunchKernelGGL(sy2sb_leaf_qr, dim3(L2), dim3(QR_THREADS), 0, q, lm);
+      if (h->sb_qr4) hipLaunchKernelGGL(sy2sb_leaf_qr4, dim3(L2), dim3(QR4_THREADS), 0, q, lm);
+      else hipLaunchKernelGGL(sy2sb_leaf_qr, dim3(L2), dim3(QR_THREADS), 0, q, lm);
     }
     TopArgs ta;
     ta.A = Ap; ta.lda = lda; ta.m = m; ta.L = three ? L2 : L; ta.Rst = three ? Rst2 : Rst; ta.Tst = Tst; ta.Vtst = Vtst; ta.small = small;

@@ -201,6 +201,9 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
                         second identical occurrence and replayed afterwards -- measured no faster on ROCm 7.2),
             "sb_av_gemm" (default 0: the band reduction forms A * Y with its own 128-row kernel; 1 = the general GEMM -- measured
                         sy2sb 104 -> 91 ms at n = 8192, equal below n = 4096),
+            "sb_qr4" (default 0; 1: the band reduction's leaf QRs on 256-thread workgroups, four columns per half-wave -- 58.9 us per
+                        panel against 54.4 us on 1024 threads at n = 8192; with "sb_lookahead" the only form whose leaves overlap
+                        the trailing update, stage time equal either way),
             "diag_v2" (default 1: pipelined diagonal-block kernel; 0 = the barrier version, 2 = helper waves off wave 0's SIMD),
             "trtri_overlap", "small_fused", "small_max_n", "chase_pack", "eig_overlap", "sb_lookahead" (round-3 experiment
                         switches)                                                                  */

@@ -51,6 +51,32 @@ def test_stage1_band_reduction(n, kind):
     assert np.abs(Q1 @ B @ Q1.T - A.numpy()).max() <= 2e-13 * scale
 
 
+@pytest.mark.parametrize("opts", [{"sb_av_gemm": 1}, {"sb_qr4": 1}, {"sb_lookahead": 1}, {"sb_qr4": 1, "sb_lookahead": 1}],
+                         ids=lambda o: "+".join(sorted(o)))
+def test_stage1_band_reduction_alternative_kernels(opts):
+    """the band reduction's off-by-default forms (A Y on the general GEMM; leaf QRs on 256-thread workgroups; the next panel's QR
+    chain on the side stream) meet the same properties -- four leaves per panel at first, the last one ragged"""
+    from fidelityfusion_amd import _lib
+    from fidelityfusion_amd import eigh as E
+    n = 1600
+    A = _kernel_matrix(n, 3, 0.6, n)
+    for k, v in opts.items():
+        _lib.set_option(k, v)
+    try:
+        AB, Y = E.sy2sb(A.to(DEV))
+        Q1 = E.ormq1(Y, torch.eye(n, dtype=torch.float64, device=DEV)).cpu().numpy()
+    finally:
+        for k in opts:
+            _lib.set_option(k, 0)
+    assert float(AB[:, 33:].abs().max()) == 0.0
+    B = _band_dense(AB)
+    ref = np.linalg.eigvalsh(A.numpy())
+    scale = np.abs(ref).max()
+    assert np.abs(np.linalg.eigvalsh(B) - ref).max() <= 5e-14 * scale
+    assert np.abs(Q1.T @ Q1 - np.eye(n)).max() <= 1e-13
+    assert np.abs(Q1 @ B @ Q1.T - A.numpy()).max() <= 2e-13 * scale
+
+
 @pytest.mark.parametrize("n", [64, 192, 640, 1216])
 def test_stage2_bulge_chasing(n):
     """sb2st: tridiagonal with the band's eigenvalues; B = Q2 T Q2^T with an orthogonal Q2 (through ormq2)"""
@@ -134,9 +160,12 @@ def test_syevd_reads_the_lower_triangle_and_keeps_its_input():
     assert float((W.cpu() - ref).abs().max()) <= 1e-13 * float(ref.abs().max())
 
 
-def test_syevd_three_level_tsqr_above_8192():
+@pytest.mark.parametrize("qr4", [0, 1])
+def test_syevd_three_level_tsqr_above_8192(qr4):
     """n > 8224: the panels have more than 16 leaves of 512 rows, so the TSQR gets its middle level (the leaf kernel on stacks of 16 R
-    factors).  Comparator at this size: rocSOLVER on the same device (LAPACK on the host would take minutes)"""
+    factors; qr4: the 256-thread leaf kernel in both places).  Comparator at this size: rocSOLVER on the same device (LAPACK on the
+    host would take minutes)"""
+    from fidelityfusion_amd import _lib
     from fidelityfusion_amd import eigh as E
     n = 8500
     g = torch.Generator(device=DEV).manual_seed(1)
@@ -144,7 +173,11 @@ def test_syevd_three_level_tsqr_above_8192():
     d = torch.cdist(X, X)
     K = torch.exp(-0.5 * d * d)
     del d
-    W, Z = E.eigh(K)
+    _lib.set_option("sb_qr4", qr4)
+    try:
+        W, Z = E.eigh(K)
+    finally:
+        _lib.set_option("sb_qr4", 0)
     ref = torch.linalg.eigvalsh(K)
     scale = float(ref.abs().max())
     assert float((W - ref).abs().max()) <= 1e-13 * scale
