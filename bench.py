@@ -355,11 +355,15 @@ def run_rank(args):
                 hdata[f] = (X, Y.reshape(n, *modes))
                 models[f] = HOGP_simple(K_.ARDKernel(D), 1.0, list(modes)).double().to(dev)
 
+            hslots = max(1, min(args.slots, len(mine)))
+
             def step():
                 joint.zero_()
-                with torch.no_grad():
-                    for f in mine:
-                        joint[f] = models[f].log_likelihood(hdata[f][0], hdata[f][1]).to(joint.device)
+                with torch.no_grad():   # blocks overlap from `--slots` host threads (ffgp_syevd waits for its chase on the host)
+                    vals = F.threaded_blocks([(lambda f=f: models[f].log_likelihood(hdata[f][0], hdata[f][1])) for f in mine],
+                                             nslots=hslots, device_index=local_rank)
+                for f, v in zip(mine, vals):
+                    joint[f] = v.to(joint.device)
                 if world > 1:
                     dist.all_reduce(joint)
                 return joint

@@ -164,8 +164,34 @@ def check(rc, what):
     return rc
 
 
-def handle(device_index=None, slot=0):
-    """ffgp handles of this process: one per (GPU, slot).  Slot 0 is the default; extra slots carry independent
+_tls = threading.local()
+
+
+class thread_slot:
+    """Inside the block, every library call THIS host thread makes without naming a slot goes to handle slot `k` of its GPU
+    (`handle(device_index)` resolves to it): how a worker thread of `functional.threaded_blocks` keeps a whole block -- its
+    eigensolver, GEMMs, assemblies -- on the thread's own handle and stream.  Other threads are not affected."""
+
+    def __init__(self, k):
+        self.k = int(k)
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "slot", 0)
+        _tls.slot = self.k
+        return self
+
+    def __exit__(self, *exc):
+        _tls.slot = self.prev
+
+
+def current_slot():
+    """the calling thread's handle slot: 0 outside a `thread_slot` block"""
+    return getattr(_tls, "slot", 0)
+
+
+def handle(device_index=None, slot=None):
+    """ffgp handles of this process: one per (GPU, slot).  Slot 0 is the default (slot=None: the calling thread's current
+    slot, 0 outside a `thread_slot` block); extra slots carry independent
     GP blocks that should overlap on the same GPU (each handle owns its workspace and side stream).
 
     Threading rule (include/ffgp.h): a handle carries mutable state (stream binding, workspaces, cached inverses), so one
@@ -178,6 +204,8 @@ def handle(device_index=None, slot=0):
                         "and the package has no CPU path")
     if device_index is None:
         device_index = torch.cuda.current_device()
+    if slot is None:
+        slot = current_slot()
     with _lock:
         h = _handles.get((device_index, slot))
         if h is None:

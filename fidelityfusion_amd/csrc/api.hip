@@ -224,6 +224,7 @@ int ffgp_destroy(ffgp_handle* h) {
   if (h->ews) hipFree(h->ews);
   if (h->d_link) hipFree(h->d_link);
   if (h->aux2) hipStreamDestroy(h->aux2);
+  if (h->ev_switch) hipEventDestroy(h->ev_switch);
   for (int i = 0; i < 4; ++i)
     if (h->sb_ev[i]) hipEventDestroy(h->sb_ev[i]);
   for (int i = 0; i < 2; ++i)
@@ -256,7 +257,18 @@ int ffgp_destroy(ffgp_handle* h) {
 
 int ffgp_set_stream(ffgp_handle* h, void* s) {
   if (!h) return FFGP_ERR_ARG;
-  h->stream = s ? reinterpret_cast<hipStream_t>(s) : h->own;
+  hipStream_t ns = s ? reinterpret_cast<hipStream_t>(s) : h->own;
+  if (ns == h->stream) return FFGP_OK;
+  // Work enqueued through this handle on the stream it leaves may still be running on the handle's workspaces (the asynchronous
+  // entry points return before it has): the stream it moves to waits for that work.  Costs nothing while the stream stays the same.
+  FFGP_HIP(hipSetDevice(h->device));
+  if (!h->ev_switch) FFGP_HIP(hipEventCreateWithFlags(&h->ev_switch, hipEventDisableTiming));
+  if (hipEventRecord(h->ev_switch, h->stream) == hipSuccess) {
+    FFGP_HIP(hipStreamWaitEvent(ns, h->ev_switch, 0));
+  } else {
+    (void)hipGetLastError();   // (the old stream no longer exists: nothing of it can be running)
+  }
+  h->stream = ns;
   return FFGP_OK;
 }
 

@@ -163,6 +163,7 @@ struct ffgp_handle {
   hipEvent_t tri_ev[2]; // [0] factor columns < tri_hook_col are final (recorded by ffgp_potrf_impl on the side stream); [1] head done
   int tri_hook_col, tri_hook_fired;
   int trtri_overlap;    // option (default 1)
+  hipEvent_t ev_switch; // ffgp_set_stream: recorded on the stream the handle leaves, waited for by the one it moves to
   hipEvent_t sb_ev[4];  // sy2sb: hand-offs between the trailing update (main stream) and the next panel's QR chain (side stream)
   int sb_lookahead;     // option (default 0: measured 103 -> 108 ms at N = 8192 -- the event hand-offs cost more than the QR chain hides)
   int small_max_n;   // largest n that takes the one-kernel path (0 = the measured default, 40)

@@ -554,6 +554,9 @@ __global__ __launch_bounds__(256) void sy2sb_form_y(FormYArgs p) {
   }
   __syncthreads();
   mm32<false>(G, Ma, Mb, 1.0, tid);        // G_i
+  __syncthreads();                         // every wave is done reading Ma, Mb before they are refilled (without this barrier a wave
+                                           // that fell behind -- another kernel's waves on the CU are enough -- multiplied the NEW contents:
+                                           // 256 rows of Y wrong in a few columns, found by running two band reductions at once)
   // X_i = T_i V_i[:32]^T
   const double* P = p.A + (size_t)row0 * p.lda;
   for (int idx = tid; idx < 1024; idx += 256) {

@@ -452,7 +452,7 @@ def raw_many_ok(kernel, x_train, y_train, *others):
 def raw_ok(*tensors):
     """the raw-parameter fast path needs every tensor resident on ONE GPU in fp64, contiguous, no concurrent-block context, and
     inputs that carry no gradient of their own (the fused call has no input gradients)"""
-    if concurrent_blocks.active is not None:
+    if concurrent_blocks.active is not None or _lib.current_slot() != 0:   # (the raw path lives on handle 0 of its GPU)
         return False
     dev = None
     for t in tensors:
@@ -506,12 +506,15 @@ _pending = {}   # (device, slot) -> staging tensors of enqueued-but-not-waited c
 
 
 def nlml(X, Y, w, amp, diag_add=None, diag_vec=None, add_mat=None, add_all=0.0, mean_jitter=0.0, clamp=NEG_INF,
-         variant=FFGP_LL_V1, pi_const=PI_TRUNC, slot=0, defer=False, kfun=(0, 1.0)):
+         variant=FFGP_LL_V1, pi_const=PI_TRUNC, slot=None, defer=False, kfun=(0, 1.0)):
     """Negative log marginal likelihood of one GP block through the fused HIP path (assemble -> blocked Cholesky
     with Y^T riding as passenger rows -> reductions -> closed-form gradients).
 
     slot / defer: independent blocks can overlap on one GPU -- issue each under its own torch stream with its own
-    `slot` and `defer=True`, then call `wait(slot)` (see `concurrent_blocks`)."""
+    `slot` and `defer=True`, then call `wait(slot)` (see `concurrent_blocks`).  slot=None: the calling thread's slot (0, or the
+    one a `threaded_blocks` worker runs under) -- resolved here, so that backward, which runs on autograd's thread, uses the same."""
+    if slot is None:
+        slot = _lib.current_slot()
     kfun, kparam = _split_kfun(kfun)
     return _NLML.apply(X, Y, w, amp, diag_add, diag_vec, add_mat, add_all, mean_jitter, clamp, variant, pi_const, slot,
                        defer, kfun, kparam, torch.is_grad_enabled())
@@ -524,8 +527,10 @@ def _split_kfun(kfun):
     return (int(kfun[0]), float(kfun[1])), None
 
 
-def wait(slot=0, device_index=None):
+def wait(slot=None, device_index=None):
     """Collect a deferred call: synchronises that slot's stream, raises LinAlgError if its Sigma was not PD."""
+    if slot is None:
+        slot = _lib.current_slot()
     if device_index is None:
         device_index = torch.cuda.current_device()
     h = _lib.handle(device_index, slot)
@@ -602,11 +607,56 @@ class concurrent_blocks:
         return False
 
 
+def threaded_blocks(fns, nslots=2, device_index=None):
+    """Run independent blocks -- callables without arguments -- concurrently on one GPU from `nslots` host threads and return
+    their results in order.  Worker k runs blocks k, k + nslots, ... on its own stream with handle slot 1 + k as the thread's
+    current slot (`_lib.thread_slot`), so everything a block calls lands on that handle.
+
+    This is the form of `concurrent_blocks` for blocks whose library calls wait on the host: `ffgp_syevd` synchronises after its
+    bulge chasing (the watchdog word), so a single thread cannot put a second HOGP block under the first one's 80 ms of
+    latency-bound chase -- two threads can (ctypes drops the GIL inside the library; one thread per handle is the library's
+    threading rule, include/ffgp.h).  The caller's stream is waited for before the workers start and waits for theirs at the
+    end; the first exception of any block is raised after every worker has finished.  Grad mode is the caller's."""
+    import threading
+    fns = list(fns)
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    nslots = max(1, min(int(nslots), len(fns)))
+    results, errors = [None] * len(fns), []
+    if nslots <= 1:
+        return [fn() for fn in fns]
+    origin = torch.cuda.current_stream(device_index)
+    streams = [torch.cuda.Stream(device_index) for _ in range(nslots)]
+    for st in streams:
+        st.wait_stream(origin)
+    grad = torch.is_grad_enabled()
+
+    def work(k):
+        try:
+            torch.cuda.set_device(device_index)
+            with torch.cuda.stream(streams[k]), _lib.thread_slot(1 + k), torch.set_grad_enabled(grad):
+                for i in range(k, len(fns), nslots):
+                    results[i] = fns[i]()
+        except BaseException as e:   # noqa: BLE001  (re-raised in the caller's thread)
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,), name="ffgp-block-%d" % k) for k in range(nslots)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for st in streams:
+        origin.wait_stream(st)
+    if errors:
+        raise errors[0]
+    return results
+
+
 def _slot_args():
     cb = concurrent_blocks.active
     if cb is not None and cb.cur is not None:
         return dict(slot=cb.cur, defer=True)
-    return dict(slot=0, defer=False)
+    return dict(slot=_lib.current_slot(), defer=False)
 
 
 @torch.no_grad()
@@ -979,8 +1029,10 @@ def pair_inputs_plain(x_train, *extras):
 
 
 def nlml_pair(X, Y, descs, op, diag_add=None, diag_vec=None, add_mat=None, add_all=0.0, mean_jitter=0.0, variant=FFGP_LL_V1,
-              pi_const=PI_TRUNC, slot=0, defer=False):
+              pi_const=PI_TRUNC, slot=None, defer=False):
     """nlml() for a composed kernel given as descriptor dicts and `op` (see kernel._Pair.pair and `kernel_pair`)."""
+    if slot is None:
+        slot = _lib.current_slot()
     meta, tensors = _pair_split(descs)
     _tree_spec(op, len(meta))
     return _NLMLPair.apply(X, Y, op, meta, diag_add, diag_vec, add_mat, add_all, mean_jitter, variant, pi_const, slot, defer,

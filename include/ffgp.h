@@ -159,7 +159,9 @@ typedef struct {
 /* ---- lifetime ------------------------------------------------------------------------------------------ */
 int ffgp_create(int device, ffgp_handle** out);
 int ffgp_destroy(ffgp_handle* h);
-int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL restores the handle's own stream */
+int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL restores the handle's own stream.  When the stream
+                                                           changes, the new one is made to wait (event) for the work this handle
+                                                           enqueued on the old one: the handle's workspaces are shared by both */
 /* options: "timing" (0/1: record per-stage hipEvents; 2: also an event pair around every trailing-update launch),
             "nb_outer" (trailing-update block, multiple of 128; default 512),
             "naive" (1: route factor kernels through the slow reference kernels; debugging only),

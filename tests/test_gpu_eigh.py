@@ -71,3 +71,57 @@ def test_hogp_block_same_with_both_eigensolvers():
         assert rel(a[4], b[4]) < 1e-8 and rel(a[5], b[5]) < 1e-8, own
     # (the reference's "variance" expression divides by the eigenvalues of the jitter-free K_x -- ~1e-16 here -- and is a
     #  different O(1e5) number for every basis of the near-null space: nothing to compare)
+
+
+def test_hogp_blocks_from_host_threads_match_one_after_another():
+    """functional.threaded_blocks: HOGP blocks driven from two host threads (own handle slot, own stream each -- ffgp_syevd waits
+    for its bulge chasing on the host, so one thread cannot overlap two blocks) return exactly what the same blocks return one
+    after another, forward values and the cached posterior pieces; the default handle is untouched by the workers' slots."""
+    from fidelityfusion_amd import _lib
+    from fidelityfusion_amd import functional as F
+    from fidelityfusion_amd import kernel as K_
+    from fidelityfusion_amd.hogp_simple import HOGP_simple
+    n, D, modes = 448, 3, (6, 5)
+    blocks = []
+    for f in range(5):
+        g = torch.Generator(device=DEV).manual_seed(100 + f)
+        X = torch.rand((n, D), generator=g, device=DEV, dtype=torch.float64)
+        Y = torch.randn((n,) + modes, generator=g, device=DEV, dtype=torch.float64)
+        torch.manual_seed(f)
+        blocks.append((HOGP_simple(K_.ARDKernel(D), 1.0, list(modes)).double().to(DEV), X, Y))
+    with torch.no_grad():
+        ref = [m.log_likelihood(X, Y).clone() for m, X, Y in blocks]
+        ref_g = [m.g.clone() for m, _, _ in blocks]
+        seen = []
+
+        def run(i):
+            m, X, Y = blocks[i]
+            seen.append(getattr(_lib._tls, "slot", 0))
+            return m.log_likelihood(X, Y)
+        got = F.threaded_blocks([(lambda i=i: run(i)) for i in range(5)], nslots=2)
+    torch.cuda.synchronize()
+    assert sorted(set(seen)) == [1, 2] and getattr(_lib._tls, "slot", 0) == 0
+    for f in range(5):
+        assert torch.equal(got[f], ref[f])
+        assert torch.equal(blocks[f][0].g, ref_g[f])
+
+
+def test_threaded_blocks_raise_in_the_caller_and_keep_grad_mode():
+    from fidelityfusion_amd import functional as F
+    X = torch.rand((64, 2), device=DEV, dtype=torch.float64)
+    w = torch.ones(2, device=DEV, dtype=torch.float64)
+    amp = torch.ones(1, device=DEV, dtype=torch.float64)
+    Y = torch.ones((64, 1), device=DEV, dtype=torch.float64)
+
+    def bad():   # a covariance that is not positive definite: the raise must arrive in the calling thread
+        return F.nlml(X, Y, w, amp, diag_add=torch.tensor([-5.0], device=DEV, dtype=torch.float64), clamp=1e-30)
+
+    def good():
+        assert not torch.is_grad_enabled()
+        return F.nlml(X, Y, w, amp, diag_add=torch.tensor([0.1], device=DEV, dtype=torch.float64), clamp=1e-30)
+    with torch.no_grad():
+        with pytest.raises(torch.linalg.LinAlgError):
+            F.threaded_blocks([good, bad, good], nslots=2)
+        vals = F.threaded_blocks([good, good, good], nslots=3)
+        one = good()
+    assert all(torch.equal(v, one) for v in vals)

@@ -183,3 +183,33 @@ def test_syevd_three_level_tsqr_above_8192(qr4):
     assert float((W - ref).abs().max()) <= 1e-13 * scale
     assert float((Z.T @ Z - torch.eye(n, device=DEV, dtype=torch.float64)).abs().max()) <= 5e-13
     assert float(torch.linalg.matrix_norm((Z * W) @ Z.T - K)) <= 2e-13 * float(torch.linalg.matrix_norm(K))
+
+
+def test_solver_is_unchanged_by_a_second_solver_running_beside_it():
+    """Two host threads, each with its own handle and stream (functional.threaded_blocks), run band reductions and whole eigh calls at a
+    size where the kernels of the two really share the chip: every result must equal, bit for bit, what the same call returns alone.
+    (A missing barrier in sy2sb_form_y passed every single-stream test of the round and failed here in most repeats: a wave delayed by
+    the other solver's waves read LDS operands that a faster wave had already refilled.)"""
+    from fidelityfusion_amd import eigh as E
+    from fidelityfusion_amd import functional as F
+    n, nb = 8192, 4
+    Ks = []
+    for f in range(nb):
+        g = torch.Generator(device=DEV).manual_seed(40 + f)
+        X = torch.rand((n, 8), generator=g, device=DEV, dtype=torch.float64)
+        d = torch.cdist(X, X)
+        Ks.append(torch.exp(-0.5 * d * d))
+        del d
+    with torch.no_grad():
+        for name, fn, reps in (("sy2sb", E.sy2sb, 4), ("eigh", E.eigh, 2)):
+            ref = [fn(K) for K in Ks]
+            torch.cuda.synchronize()
+            for rep in range(reps):
+                got = F.threaded_blocks([(lambda K=K: fn(K)) for K in Ks], nslots=2)
+                torch.cuda.synchronize()
+                for f in range(nb):
+                    for j, (a, b) in enumerate(zip(ref[f], got[f])):
+                        assert torch.equal(a, b), "%s, repeat %d, matrix %d, output %d: %d entries differ, max %.2e" % (
+                            name, rep, f, j, int((a != b).sum()), float((a - b).abs().max()))
+                del got
+            del ref
