@@ -18,7 +18,9 @@ Workloads (--workload):
 For the fixed-F workloads the blocks are dealt to the ranks by longest-processing-time-first
 (fidelityfusion_amd.sharding.partition_lpt -- the reference's per-fidelity loop, FidelityFusion_Models/CIGAR.py:99-134,
 GAR.py:76-126; the sum MFGP_ver2023May/ResGP.py:232-246); a rank that owns several blocks overlaps them on its GPU
-(functional.concurrent_blocks); one all-reduce(SUM) of the F-vector per step.  The default run also times both fixed-F
+(functional.concurrent_blocks from one host thread; the HOGP blocks, whose eigensolver waits on the host after its bulge chasing,
+from `--hogp-slots` host threads with a handle and a stream each: functional.threaded_blocks); one all-reduce(SUM) of the F-vector
+per step.  The default run also times both fixed-F
 workloads for a few steps after the headline and reports them under "sharded", so that one `--gpus N` sweep carries the
 GAR-8 / CIGAR-4 curve next to the headline.
 
@@ -74,6 +76,8 @@ def parse_args(argv=None):
     ap.add_argument("--dry", action="store_true", help="CPU plumbing run (needs --backend gloo): no GPU work")
     ap.add_argument("--slots", type=int, default=2, help="blocks of one rank that overlap on its GPU (fixed-F workloads)")
     ap.add_argument("--slot-lookahead", action="store_true", help="keep every overlapped block's own look-ahead side stream")
+    ap.add_argument("--hogp-slots", type=int, default=4, help="host threads that drive the HOGP blocks of one rank (gar8_hogp): "
+                    "1 = one block after another (2.46 s/step), 2: 1.89, 3: 1.67, 4: 1.54, 6: 1.77, 8: 1.57 s/step on one MI355X")
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (development A/B runs)")
     return ap.parse_args(argv)
 
@@ -355,11 +359,11 @@ def run_rank(args):
                 hdata[f] = (X, Y.reshape(n, *modes))
                 models[f] = HOGP_simple(K_.ARDKernel(D), 1.0, list(modes)).double().to(dev)
 
-            hslots = max(1, min(args.slots, len(mine)))
+            hslots = max(1, min(args.hogp_slots, len(mine)))
 
             def step():
                 joint.zero_()
-                with torch.no_grad():   # blocks overlap from `--slots` host threads (ffgp_syevd waits for its chase on the host)
+                with torch.no_grad():   # blocks overlap from `--hogp-slots` host threads (ffgp_syevd waits for its chase on the host)
                     vals = F.threaded_blocks([(lambda f=f: models[f].log_likelihood(hdata[f][0], hdata[f][1])) for f in mine],
                                              nslots=hslots, device_index=local_rank)
                 for f, v in zip(mine, vals):
@@ -458,6 +462,7 @@ def run_rank(args):
             sharded[name] = {"blocks": sF, "N": sn, "D": sD, "d": sd, "ms_per_step": round(sdt / ssteps * 1e3, 3),
                              "value": round(sfl * sF / (sdt / ssteps) / 1e9, 1), "unit": "GF/s", "scaling": "strong",
                              "blocks_per_rank": -(-sF // world), "joint_nll": float(sjoint.sum()),
+                             "blocks_in_flight_per_rank": min(args.hogp_slots if hog else args.slots, -(-sF // world)),
                              "config": "BASELINE configs[%d]" % WORKLOADS[name][4] + (
                                  " as HOGP blocks (d = %d x %d): eigh of the N x N input kernel on ffgp_syevd + mode products; flops = "
                                  "8.67 N^3 + 4 N^2 d per block, see hogp_flops" % HOGP_MODES if hog else "")}
@@ -489,6 +494,8 @@ def run_rank(args):
                                       "forward+gradients" if args.with_grad else "forward", F_total, "" if F_total == 1 else "s", n, D, d,
                                       " (BASELINE configs[%d])" % cfg_idx if cfg_idx is not None else ""),
                        "N": n, "D": D, "d": d, "blocks": F_total,
+                       "blocks_in_flight_per_rank": (min(args.hogp_slots if args.workload == "gar8_hogp" else args.slots, -(-F_total // world))
+                                                     if scaling == "strong" else 1),
                        "parallelism": "fidelity-shard x%d (LPT partition, one %d-byte all-reduce per step)" % (world, 8 * F_total)},
             "collective": coll,
             "rccl_ranks": coll["ranks"] if coll["backend"] == "nccl" else 0,
