@@ -213,3 +213,53 @@ def test_solver_is_unchanged_by_a_second_solver_running_beside_it():
                             name, rep, f, j, int((a != b).sum()), float((a - b).abs().max()))
                 del got
             del ref
+
+
+def test_eigensolver_and_likelihood_chains_side_by_side():
+    """Different kinds of work sharing the chip: one host thread runs eigh at N = 4096 and 8192, the other a stream of NLML forwards --
+    blocked factorisations at N = 4096 and 1500, the finishing-kernel size 100, the one-kernel size 32, a Sum(Linear, Matern) kernel
+    -- each on its own handle and stream.  Every result must equal the solo result bit for bit, repeat after repeat."""
+    from fidelityfusion_amd import eigh as E
+    from fidelityfusion_amd import functional as F
+    from fidelityfusion_amd import kernel as K_
+    from fidelityfusion_amd.cigp_v10 import cigp
+    Ks = []
+    for n in (8192, 4096):
+        g = torch.Generator(device=DEV).manual_seed(n)
+        X = torch.rand((n, 8), generator=g, device=DEV, dtype=torch.float64)
+        d = torch.cdist(X, X)
+        Ks.append(torch.exp(-0.5 * d * d))
+        del d
+    gp = []
+    for f, (n, D, d) in enumerate([(4096, 8, 1), (1500, 5, 3), (100, 3, 2), (32, 2, 1), (2048, 4, 2)]):
+        g = torch.Generator(device=DEV).manual_seed(7 + f)
+        X = torch.rand((n, D), generator=g, device=DEV, dtype=torch.float64)
+        Y = torch.randn((n, d), generator=g, device=DEV, dtype=torch.float64)
+        torch.manual_seed(f)
+        kern = K_.SumKernel(K_.LinearKernel(D), K_.MaternKernel(D)) if f == 4 else K_.ARDKernel(D)
+        gp.append((cigp(kern, 0.5).double().to(DEV), X, Y))
+
+    def solver():
+        return [E.eigh(K) for K in Ks]
+
+    def likelihoods():
+        out = []
+        for _ in range(6):
+            out += [m.negative_log_likelihood(X, Y) for m, X, Y in gp]
+        return torch.stack([o.reshape(()) for o in out])
+    from fidelityfusion_amd import _lib
+    with torch.no_grad():
+        # the solo results through the same code path as the workers: under their handle slots (off slot 0 the likelihood modules do not
+        # take the raw-parameter route, which agrees with this one to rounding only), one after the other
+        with _lib.thread_slot(1):
+            ref_e = solver()
+        torch.cuda.synchronize()
+        with _lib.thread_slot(2):
+            ref_l = likelihoods()
+        torch.cuda.synchronize()
+        for rep in range(3):
+            got_e, got_l = F.threaded_blocks([solver, likelihoods], nslots=2)
+            torch.cuda.synchronize()
+            assert torch.equal(got_l, ref_l), "repeat %d: likelihood values differ by up to %.2e" % (rep, float((got_l - ref_l).abs().max()))
+            for (w0, z0), (w1, z1) in zip(ref_e, got_e):
+                assert torch.equal(w0, w1) and torch.equal(z0, z1), "repeat %d: eigenpairs differ" % rep
