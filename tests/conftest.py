@@ -27,3 +27,48 @@ def golden():
         return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
 
     return load
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _gpu_noise():
+    """FFGP_TEST_NOISE=1: the whole GPU suite runs while a background host thread keeps the chip busy with eigensolver and GEMM work on
+    its own handle slot and stream.  Kernels whose workgroups are only correct when their waves run undisturbed (a missing barrier: two
+    found so far, both invisible on an idle GPU) then fail the tests they already have.  Off by default: the suite's timing-sensitive
+    comparisons and the round-end run stay as they are."""
+    if not os.environ.get("FFGP_TEST_NOISE"):
+        yield
+        return
+    import threading
+    import torch
+    if not torch.cuda.is_available():
+        yield
+        return
+    from fidelityfusion_amd import _lib
+    from fidelityfusion_amd import eigh as E
+    from fidelityfusion_amd import functional as F
+    stop = threading.Event()
+    count = [0]
+
+    def noise():
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda:0")
+        st = torch.cuda.Stream(0)
+        with torch.cuda.stream(st), _lib.thread_slot(7), torch.no_grad():
+            g = torch.Generator(device=dev).manual_seed(99)
+            X = torch.rand((2048, 6), generator=g, device=dev, dtype=torch.float64)
+            d = torch.cdist(X, X)
+            K = torch.exp(-0.5 * d * d)
+            B = torch.randn((3072, 2048), generator=g, device=dev, dtype=torch.float64)
+            while not stop.is_set():
+                E.eigh(K)                      # 1024-thread QR workgroups, the chase, divide & conquer, both back-transformations
+                for _ in range(4):
+                    F.matmul_nt(B, B)          # 128 x 128 GEMM tiles on every CU
+                st.synchronize()
+                count[0] += 1
+
+    t = threading.Thread(target=noise, name="ffgp-test-noise", daemon=True)
+    t.start()
+    yield
+    stop.set()
+    t.join(timeout=60)
+    print("\n[ffgp] background noise thread ran %d rounds during the session" % count[0])
