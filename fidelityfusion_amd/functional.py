@@ -607,6 +607,16 @@ class concurrent_blocks:
         return False
 
 
+_block_streams = {}   # (device, worker slot) -> the torch stream threaded_blocks' worker of that slot always runs on
+
+
+def _block_stream(device_index, k):
+    st = _block_streams.get((device_index, k))
+    if st is None:
+        st = _block_streams[(device_index, k)] = torch.cuda.Stream(device_index)
+    return st
+
+
 def threaded_blocks(fns, nslots=2, device_index=None):
     """Run independent blocks -- callables without arguments -- concurrently on one GPU from `nslots` host threads and return
     their results in order.  Worker k runs blocks k, k + nslots, ... on its own stream with handle slot 1 + k as the thread's
@@ -626,7 +636,9 @@ def threaded_blocks(fns, nslots=2, device_index=None):
     if nslots <= 1:
         return [fn() for fn in fns]
     origin = torch.cuda.current_stream(device_index)
-    streams = [torch.cuda.Stream(device_index) for _ in range(nslots)]
+    # one stream per worker slot for the life of the process: the caching allocator pools memory per stream (fresh streams would send
+    # every step's temporaries back to hipMalloc) and the slot's handle stays bound to one stream
+    streams = [_block_stream(device_index, k) for k in range(nslots)]
     for st in streams:
         st.wait_stream(origin)
     grad = torch.is_grad_enabled()
