@@ -11,7 +11,8 @@ import threading
 # Several blocks in flight on one GPU (functional.threaded_blocks, concurrent_blocks) need their streams on DIFFERENT hardware queues:
 # streams that share one run their kernels in order.  ROCm maps all streams of a process onto GPU_MAX_HW_QUEUES queues, 4 by default;
 # with a handle's own streams next to the workers' that is not enough -- measured on gar8_hogp (four worker streams): 1.81 s/step
-# with 4 queues, 1.53 with 8, 1.50 with 16; headline, cigar4 and gar8 unchanged.  A default only: an explicit setting wins, and it
+# with 4 queues, 1.53 with 8, 1.50 with 16; headline unchanged, cigar4 (with gradients) and gar8 0.4-0.8 % slower with 8 in three
+# alternations each.  A default only: an explicit setting wins, and it
 # takes effect only if HIP has not been initialised in this process yet (set it in the environment to be sure).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
