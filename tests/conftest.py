@@ -59,10 +59,20 @@ def _gpu_noise():
             d = torch.cdist(X, X)
             K = torch.exp(-0.5 * d * d)
             B = torch.randn((3072, 2048), generator=g, device=dev, dtype=torch.float64)
-            while not stop.is_set():
-                E.eigh(K)                      # 1024-thread QR workgroups, the chase, divide & conquer, both back-transformations
-                for _ in range(4):
-                    F.matmul_nt(B, B)          # 128 x 128 GEMM tiles on every CU
+            Y = torch.randn((2048, 3), generator=g, device=dev, dtype=torch.float64)
+            w = torch.ones(6, device=dev, dtype=torch.float64)
+            amp = torch.ones(1, device=dev, dtype=torch.float64)
+            dadd = torch.full((1,), 0.05, device=dev, dtype=torch.float64)
+            while not stop.is_set():           # three kinds of neighbour in rotation: which kernels share a CU decides what gets disturbed
+                kind = count[0] % 3
+                if kind == 0:
+                    E.eigh(K)                  # 1024-thread QR workgroups, the chase, divide & conquer, both back-transformations
+                elif kind == 1:
+                    for _ in range(6):
+                        F.matmul_nt(B, B)      # 128 x 128 GEMM tiles on every CU
+                else:
+                    for _ in range(8):
+                        F.nlml(X, Y, w, amp, diag_add=dadd, clamp=1e-30)   # assembly, the blocked factorisation's chain, reductions
                 st.synchronize()
                 count[0] += 1
 
