@@ -327,6 +327,7 @@ __global__ __launch_bounds__(256) void q2_prep(PrepArgs p) {
   {
     const int a = tid >> 3, b0 = (tid & 7) * 4;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 8   // (fully unrolled, the 320 LDS loads of this loop were hoisted into 512 registers + 124 spilled ones: one wave per SIMD)
     for (int r = 0; r < 64; ++r) {
       const double av = Vs[r][a];
 #pragma unroll
@@ -339,31 +340,48 @@ __global__ __launch_bounds__(256) void q2_prep(PrepArgs p) {
     }
   }
   __syncthreads();
-  if (tid < 32) {   // column j of T = (T^-1)^-1 by back substitution
-    const int j = tid;
+  {   // T = (T^-1)^-1 by back substitution.  Its columns are independent recurrences: half-wave hw takes the columns hw, hw + 8, hw + 16,
+      // hw + 24 with entry cc of a column in lane cc -- per step one product per lane and a half-wave sum (syevd_internal.h), the four
+      // columns inside the step loop so that their sums overlap.  (As a loop of 32 threads with a serial inner sum this was the longest
+      // phase of the kernel, the other 224 threads waiting at the barrier.)
+    const int lane = tid & 63, i = tid & 31, hw = tid >> 5;
+    const double dii = Gm[i][i];
+    double q[4] = {0.0, 0.0, 0.0, 0.0};
     for (int ii = 31; ii >= 0; --ii) {
-      if (ii > j) {
-        Tm[ii][j] = 0.0;
-        continue;
+      const double gv = Gm[ii][i];          // row ii of T^-1 (zero left of the diagonal)
+      double sm[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int j = hw + 8 * c;
+        sm[c] = qr_wsum32((i > ii && i <= j) ? gv * q[c] : 0.0, lane);
       }
-      double s = (ii == j) ? 1.0 : 0.0;
-      for (int cc = ii + 1; cc <= j; ++cc) s = __builtin_fma(-Gm[ii][cc], Tm[cc][j], s);
-      Tm[ii][j] = s / Gm[ii][ii];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int j = hw + 8 * c;
+        if (i == ii) q[c] = (ii > j) ? 0.0 : (((ii == j) ? 1.0 : 0.0) - sm[c]) / dii;
+      }
     }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Tm[i][hw + 8 * c] = q[c];
   }
   __syncthreads();
   double* out = p.blocks + ((size_t)G * p.K + k) * 4096;
-  for (int idx = tid; idx < 64 * 32; idx += 256) {
-    const int r = idx >> 5, j = idx & 31;
+  // W = V T (or V T^T): a thread's column j is the same in all of its eight rows, so that column (row) of T lives in registers, and
+  // because T is upper triangular its exact zeros do the masking: every sum is a fixed 32 terms.  (With variable-length inner loops the
+  // compiler unrolled all eight rows into 256 VGPRs + 500 bytes of scratch per lane, one wave per SIMD.)
+  const int j = tid & 31;
+  double tcol[32];
+#pragma unroll
+  for (int cc = 0; cc < 32; ++cc) tcol[cc] = p.trans ? Tm[j][cc] : Tm[cc][j];
+#pragma unroll 1
+  for (int it = 0; it < 8; ++it) {
+    const int r = (tid >> 5) + 8 * it, idx = 32 * r + j;
     // lane order: A-operand element (row m = 16 t + lr, k = 4 kq + lq) of tile t sits at ((t * nkp + kq / 2) * 64 + 16 lq + lr) * 2 + kq % 2
     if (p.lanes) out[(((j >> 4) * 8 + (r >> 3)) * 64 + 16 * (r & 3) + (j & 15)) * 2 + ((r >> 2) & 1)] = Vs[r][j];   // V^T: m = reflector j, k = row r
     else out[idx] = Vs[r][j];
     double s = 0.0;
-    if (p.trans) {
-      for (int cc = j; cc < 32; ++cc) s = __builtin_fma(Vs[r][cc], Tm[j][cc], s);
-    } else {
-      for (int cc = 0; cc <= j; ++cc) s = __builtin_fma(Vs[r][cc], Tm[cc][j], s);
-    }
+#pragma unroll
+    for (int cc = 0; cc < 32; ++cc) s = __builtin_fma(Vs[r][cc], tcol[cc], s);
     if (p.lanes) out[2048 + (((r >> 4) * 4 + (j >> 3)) * 64 + 16 * (j & 3) + (r & 15)) * 2 + ((j >> 2) & 1)] = s;   // W: m = row r, k = reflector j
     else out[2048 + j * 64 + r] = s;     // W = V T, stored transposed ([32][64]): the apply kernel's lanes read 16 consecutive rows
   }

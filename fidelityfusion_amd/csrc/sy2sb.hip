@@ -37,28 +37,7 @@ __device__ unsigned long long ffgp_qr_stamp[64];
 #endif
 #define QR_THREADS 1024
 
-template <int CTRL>
-__device__ __forceinline__ double qr_dpp_add(double x) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
-  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
-  return x + __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double qr_rdlane(double x, int l) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_readlane(lo, l);
-  hi = __builtin_amdgcn_readlane(hi, l);
-  return __hiloint2double(hi, lo);
-}
-// sum over the 32 lanes of each half-wave, in all of them (DPP inside the rows of 16, row totals through scalar registers)
-__device__ __forceinline__ double qr_wsum32(double x, int lane) {
-  x = qr_dpp_add<0xB1>(x);
-  x = qr_dpp_add<0x4E>(x);
-  x = qr_dpp_add<0x141>(x);
-  x = qr_dpp_add<0x140>(x);
-  const double r0 = qr_rdlane(x, 0), r1 = qr_rdlane(x, 16), r2 = qr_rdlane(x, 32), r3 = qr_rdlane(x, 48);
-  return (lane < 32) ? r0 + r1 : r2 + r3;
-}
+// (qr_dpp_add, qr_rdlane, qr_wsum32: syevd_internal.h)
 __device__ __forceinline__ double qr_rcp(double d) {
   double y = __builtin_amdgcn_rcp(d);
   y = __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);

@@ -25,3 +25,31 @@ size_t ffgp_q1_ws_doubles(int n, int ncols);
 int ffgp_q1_apply_impl(ffgp_handle* h, const double* Y, int ldy, int n, double* Z, int ldz, int ncols, double* ws, int trans);
 // eigensolver workspace of the handle
 int ffgp_ensure_ews(ffgp_handle* h, size_t bytes);
+
+// ---- half-wave sums (sy2sb.hip: column norms and projections of the panel QRs, T-factor and triangular recurrences; sb2st.hip: the
+// T factors of q2_prep).  A recurrence x_j = f(sum_{i < j} a_ji x_i) over 32 unknowns runs on one half-wave with x_i in lane i: one
+// product per lane and one of these sums per step, no barrier -- in place of a 32-thread loop with a serial inner sum.
+#ifdef __HIPCC__
+template <int CTRL>
+__device__ __forceinline__ double qr_dpp_add(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+  return x + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double qr_rdlane(double x, int l) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_readlane(lo, l);
+  hi = __builtin_amdgcn_readlane(hi, l);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 32 lanes of each half-wave, in all of them (DPP inside the rows of 16, row totals through scalar registers)
+__device__ __forceinline__ double qr_wsum32(double x, int lane) {
+  x = qr_dpp_add<0xB1>(x);
+  x = qr_dpp_add<0x4E>(x);
+  x = qr_dpp_add<0x141>(x);
+  x = qr_dpp_add<0x140>(x);
+  const double r0 = qr_rdlane(x, 0), r1 = qr_rdlane(x, 16), r2 = qr_rdlane(x, 32), r3 = qr_rdlane(x, 48);
+  return (lane < 32) ? r0 + r1 : r2 + r3;
+}
+#endif
