@@ -25,7 +25,10 @@ struct GradArgs {
   int ntiles, tpb;        // tiles in the sweep, tiles per workgroup (1 when D > 16)
 };
 
-__global__ __launch_bounds__(256) void ffgp_grad_kernel(GradArgs a) {
+// ONE: D <= 16, a single dimension chunk (see below).  A template parameter rather than a run-time flag: each version keeps only the
+// accumulators it uses (running totals, or one chunk's sums), which is what lets two workgroups share a CU.
+template <bool ONE>
+__global__ __launch_bounds__(256, ONE ? 2 : 1) void ffgp_grad_kernel(GradArgs a) {   // (D > 16 spills 309 registers under the two-wave bound)
   __shared__ double x1s[AT][DC + 1];
   __shared__ double x2t[DC][AT + 1];
   __shared__ double red[4][DC + 2];
@@ -38,7 +41,7 @@ __global__ __launch_bounds__(256) void ffgp_grad_kernel(GradArgs a) {
   // reduction (18 values x 6 shuffle steps, two barriers) is paid once per workgroup instead of once per tile, and the
   // second pass reads the chunk the first pass left in LDS instead of staging it again.  D > 16: one tile per workgroup,
   // reduced per chunk.
-  const bool one_chunk = a.D <= DC;
+  constexpr bool one_chunk = ONE;
   double tot[DC];
 #pragma unroll
   for (int dd = 0; dd < DC; ++dd) tot[dd] = 0.0;
@@ -118,6 +121,7 @@ __global__ __launch_bounds__(256) void ffgp_grad_kernel(GradArgs a) {
             const double df = p[i] - q2[j];
             sq[i][j] = __builtin_fma(df, df, sq[i][j]);
           }
+        if (ONE && (dd & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (else all 128 LDS loads of the unrolled loop are hoisted: 278 registers)
       }
     }
 
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(256) void ffgp_grad_kernel(GradArgs a) {
         }
         __syncthreads();
       }
-      double accd[DC];
+      double accd[ONE ? 1 : DC];
 #pragma unroll
       for (int dd = 0; dd < DC; ++dd) {
         double p[4], q2[4];
@@ -203,12 +207,11 @@ __global__ __launch_bounds__(256) void ffgp_grad_kernel(GradArgs a) {
             const double df = p[i] - q2[j];
             s = __builtin_fma(Wl[i][j] * df, df, s);
           }
-        accd[dd] = s;
+        if constexpr (ONE) tot[dd] += s;
+        else accd[dd] = s;
+        if (ONE && (dd & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
-      if (one_chunk) {
-#pragma unroll
-        for (int dd = 0; dd < DC; ++dd) tot[dd] += accd[dd];
-      } else {
+      if constexpr (!ONE) {
         // block reduction of this chunk's DC per-dimension sums (one tile per workgroup here)
 #pragma unroll
         for (int dd = 0; dd < DC; ++dd) {
@@ -324,7 +327,8 @@ int ffgp_grad_impl(ffgp_handle* h, const double* X, int n, int D, const double* 
     a.partial = partial_ws;
     a.kfun = kfun;
     a.rinv = (kparam != 0.0) ? 1.0 / kparam : 1.0;
-    hipLaunchKernelGGL(ffgp_grad_kernel, dim3(blocks), dim3(256), 0, h->stream, a);
+    if (D <= DC) hipLaunchKernelGGL(ffgp_grad_kernel<true>, dim3(blocks), dim3(256), 0, h->stream, a);
+    else hipLaunchKernelGGL(ffgp_grad_kernel<false>, dim3(blocks), dim3(256), 0, h->stream, a);
     hipLaunchKernelGGL(ffgp_grad_finish, dim3(D + 2), dim3(256), 0, h->stream, partial_ws, blocks, D, w, g_w, g_amp, g_kparam);
   }
   if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
@@ -355,7 +359,8 @@ int ffgp_kernel_grad_impl(ffgp_handle* h, const double* X1, int n1, const double
   a.G = dK; a.ldg = ldk; a.trG = nullptr; a.mj_coef = 0.0; a.partial = h->ws;
   a.kfun = kfun;
   a.rinv = (kparam != 0.0) ? 1.0 / kparam : 1.0;
-  hipLaunchKernelGGL(ffgp_grad_kernel, dim3(blocks), dim3(256), 0, h->stream, a);
+  if (D <= DC) hipLaunchKernelGGL(ffgp_grad_kernel<true>, dim3(blocks), dim3(256), 0, h->stream, a);
+  else hipLaunchKernelGGL(ffgp_grad_kernel<false>, dim3(blocks), dim3(256), 0, h->stream, a);
   hipLaunchKernelGGL(ffgp_grad_finish, dim3(D + 2), dim3(256), 0, h->stream, h->ws, blocks, D, w, g_w, g_amp, g_kparam);
   if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
   return FFGP_OK;
