@@ -10,7 +10,7 @@ mode product -- the O(N^2 prod(d)) part: 550 GFLOP each at N = 8192, d = 64 x 64
 GEMM (`functional.matmul_nt`, forward and backward).  Symmetric eigendecompositions: matrices up to 64 x 64 -- the
 per-mode kernels -- run on the hand-written LDS Jacobi solver (`ffgp_syevj_small`); the N x N input kernel runs on the
 library's two-stage solver (`eigh.eigh` -> `ffgp_syevd`: band reduction, bulge chasing, divide & conquer, two
-back-transformations; 0.27 s at N = 8192 where rocSOLVER's syevd takes 0.67 s).  No vendor library is called anywhere on
+back-transformations; 0.26 s at N = 8192 where rocSOLVER's syevd takes 0.66 s).  No vendor library is called anywhere on
 this path; `EIGENSOLVER = "rocsolver"` (torch.linalg.eigh) exists only as the comparator of the GPU tests, "jacobi" is the
 round-2 block Jacobi (slow, independent cross-check).  The likelihood's backward is closed-form (`_KronNLL`): GEMMs only,
 no differentiation through `eigh`.

@@ -11,7 +11,7 @@ python3 bench.py --with-grad --steps 10 --warmup 3 --no-cpu-baseline > $OUT/benc
 python3 bench.py --workload c2 --with-grad --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_c2_grad.json 2>> $OUT/bench.err
 python3 bench.py --workload cigar4 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_cigar4.json 2>> $OUT/bench.err
 python3 bench.py --workload gar8 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_gar8.json 2>> $OUT/bench.err
-python3 bench.py --workload cigar4 --with-grad --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_cigar4_grad.json 2>> $OUT/bench.err
+python3 bench.py --workload cigar4 --with-grad --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_cigar4_grad.json 2>> $OUT/bench.err
 python3 bench.py --n 8192 --D 8 --d 1024 --steps 10 --warmup 3 --no-cpu-baseline --no-sharded > $OUT/bench_c4_block.json 2>> $OUT/bench.err
 python3 bench.py --n 8192 --D 8 --d 4096 --steps 10 --warmup 3 --no-cpu-baseline --no-sharded > $OUT/bench_c5_block.json 2>> $OUT/bench.err
 python3 bench.py --n 32768 --steps 3 --warmup 1 --no-cpu-baseline --no-sharded > $OUT/bench_n32768.json 2>> $OUT/bench.err
