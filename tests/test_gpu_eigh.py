@@ -125,3 +125,30 @@ def test_threaded_blocks_raise_in_the_caller_and_keep_grad_mode():
         vals = F.threaded_blocks([good, good, good], nslots=3)
         one = good()
     assert all(torch.equal(v, one) for v in vals)
+
+
+def test_threaded_blocks_forward_with_gradients_then_backward_in_the_caller():
+    """Likelihood blocks evaluated with gradients enabled in worker threads, backward() called afterwards from the calling thread
+    (the documented order): every loss and every parameter gradient equals the one-after-another run.  The slot a block ran under is
+    resolved in its worker thread and carried into backward, which runs on autograd's thread."""
+    from oracle import gp_oracle as O
+    from fidelityfusion_amd import functional as F
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp
+    data = []
+    for f, (n, D, d) in enumerate([(900, 4, 3), (1300, 6, 1), (700, 3, 8), (1100, 5, 2), (300, 2, 1)]):
+        X, Y = O.synthetic_xy(n, D, d, seed=30 + f)
+        data.append((torch.tensor(X, device=DEV), torch.tensor(Y, device=DEV), D))
+
+    def run(threaded):
+        models = [cigp(kernel.ARDKernel(D), 0.7).to(DEV) for (_, _, D) in data]
+        fns = [(lambda m=m, X=X, Y=Y: -m.negative_log_likelihood(X, Y)) for m, (X, Y, _) in zip(models, data)]
+        losses = F.threaded_blocks(fns, nslots=3) if threaded else [fn() for fn in fns]
+        torch.stack([l.reshape(()) for l in losses]).sum().backward()
+        return ([l.detach().clone() for l in losses], [m.kernel.length_scales.grad.clone() for m in models],
+                [m.log_beta.grad.clone() for m in models])
+    l0, g0, b0 = run(False)
+    for _ in range(4):
+        l1, g1, b1 = run(True)
+        for a, b in zip(l0 + g0 + b0, l1 + g1 + b1):
+            assert float((a - b).abs().max()) <= 1e-12 * float(a.abs().max()), (a, b)
