@@ -21,6 +21,20 @@
 #include "syevd_internal.h"
 
 #define CH_DONE 0x3fffffff
+#ifdef FFGP_CH_STAMPS   // development probe (tools/native/chase_phases.hip): 100 MHz clock stamps of one steady-state step, lane 0
+__device__ unsigned long long ffgp_ch_stamp[16];
+#define CH_STAMP(idx, waitmem, kk)                                                               \
+  do {                                                                                           \
+    if (s == FFGP_CH_STAMP_S && ((kk) == FFGP_CH_STAMP_K || (kk) == FFGP_CH_STAMP_K + 1)) {       \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+      if (waitmem) __builtin_amdgcn_s_waitcnt(0);                                                \
+      if (lane == 0) ffgp_ch_stamp[((kk) - FFGP_CH_STAMP_K) * 8 + (idx)] = wall_clock64();        \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+    }                                                                                            \
+  } while (0)
+#else
+#define CH_STAMP(idx, waitmem, kk)
+#endif
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_add(double x) {
@@ -142,6 +156,7 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
       const int r0 = c0 + len;
       const bool more = (r0 <= n - 1);
       const int nrow = more ? min(32, n - r0) : 0;
+      CH_STAMP(0, 0, k);    // the predecessor's counter has been seen
       // ---- both blocks of the step are requested up front
       double D[16], B[16];
 #pragma unroll
@@ -157,6 +172,7 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
         const bool ok = (i < nrow) && (cc < len);
         B[q] = ok ? ldb(AB + (size_t)(c0 + cc) * SB_LDB + (len + i - cc)) : 0.0;
       }
+      CH_STAMP(1, 1, k);    // both blocks have arrived
       __syncthreads();   // vs complete
       // ---- diagonal block, two-sided
       double vq[16];
@@ -177,6 +193,7 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
         D[q] -= vi * wsh[cc] + w * vq[q];
         if (i >= cc && i < len) stb(AB + (size_t)(c0 + cc) * SB_LDB + (i - cc), D[q]);
       }
+      CH_STAMP(2, 0, k);    // diagonal block updated, its stores issued
       if (!more) break;
       // ---- block below: right-apply, new reflector, left-apply
       double sb = 0.0;
@@ -215,9 +232,11 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
         B[q] = __builtin_fma(-tv, ush[cc], B[q]);
         if (i < nrow && cc < len) stb(AB + (size_t)(c0 + cc) * SB_LDB + (len + i - cc), B[q]);
       }
+      CH_STAMP(3, 0, k);    // block below updated, its stores issued
       ++k;
       // publish: k steps of this sweep are complete.  The fence waits for every band store of the wave above.
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      CH_STAMP(4, 0, k - 1);    // every band store of the step has completed
       if (lane == 0) __hip_atomic_store(p.prog + s, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (h == 0) p.V2[((size_t)s * p.K + k) * 32 + i] = v2i;
       if (lane == 0) p.tau2[(size_t)s * p.K + k] = tau_n;
@@ -227,6 +246,7 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
       double* t_ = vs;
       vs = v2s;
       v2s = t_;
+      CH_STAMP(5, 0, k - 1);    // counter published, reflector stored
       if (seen < k + 2) seen = chase_wait(p.prog + s - 1, k + 2, p.err);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
