@@ -192,6 +192,41 @@ class thread_slot:
         _tls.slot = self.prev
 
 
+block_streams = {}   # (device, worker slot) -> the torch stream `functional.threaded_blocks`' worker of that slot always runs on
+_reserving = threading.Lock()
+
+
+def block_stream(device_index, k):
+    import torch
+
+    st = block_streams.get((device_index, k))
+    if st is None:
+        st = block_streams[(device_index, k)] = torch.cuda.Stream(device_index)
+    return st
+
+
+def reserve_block_streams(device_index=None, n=4):
+    """Create the worker streams of `functional.threaded_blocks` and put one tiny kernel on each, so that they claim their hardware
+    queues before other multi-stream work of the process does.  ROCm binds a stream to one of GPU_MAX_HW_QUEUES hardware queues when
+    the stream is first used, and streams on one queue run in order: worker streams that first appeared AFTER a `concurrent_blocks`
+    workload (two more handles, each with its own streams) shared queues -- the same eight HOGP blocks then took 1.68 instead of
+    1.45 s per step on one box, and the earlier workloads are not affected either way (docs/concurrency.md).  Runs by itself when the
+    first handle of a GPU is created; idempotent."""
+    import torch
+
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    with _reserving:
+        fresh = [k for k in range(n) if (device_index, k) not in block_streams]
+        if not fresh:
+            return
+        x = torch.zeros(64, device=torch.device("cuda", device_index))
+        for k in fresh:
+            with torch.cuda.stream(block_stream(device_index, k)):
+                x.add_(1.0)
+        torch.cuda.synchronize(device_index)
+
+
 def current_slot():
     """the calling thread's handle slot: 0 outside a `thread_slot` block"""
     return getattr(_tls, "slot", 0)
@@ -214,13 +249,17 @@ def handle(device_index=None, slot=None):
         device_index = torch.cuda.current_device()
     if slot is None:
         slot = current_slot()
+    first_on_device = False
     with _lock:
         h = _handles.get((device_index, slot))
         if h is None:
+            first_on_device = not any(d == device_index for (d, _) in _handles)
             out = C.c_void_p()
             check(lib.ffgp_create(int(device_index), C.byref(out)), "ffgp_create")
             h = out
             _handles[(device_index, slot)] = h
+    if first_on_device:   # (outside the lock: it launches kernels)
+        reserve_block_streams(device_index)
     return h
 
 

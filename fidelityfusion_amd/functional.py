@@ -607,14 +607,7 @@ class concurrent_blocks:
         return False
 
 
-_block_streams = {}   # (device, worker slot) -> the torch stream threaded_blocks' worker of that slot always runs on
-
-
-def _block_stream(device_index, k):
-    st = _block_streams.get((device_index, k))
-    if st is None:
-        st = _block_streams[(device_index, k)] = torch.cuda.Stream(device_index)
-    return st
+reserve_block_streams = _lib.reserve_block_streams   # (runs by itself with the first handle of a GPU; see there)
 
 
 def threaded_blocks(fns, nslots=2, device_index=None):
@@ -638,7 +631,7 @@ def threaded_blocks(fns, nslots=2, device_index=None):
     origin = torch.cuda.current_stream(device_index)
     # one stream per worker slot for the life of the process: the caching allocator pools memory per stream (fresh streams would send
     # every step's temporaries back to hipMalloc) and the slot's handle stays bound to one stream
-    streams = [_block_stream(device_index, k) for k in range(nslots)]
+    streams = [_lib.block_stream(device_index, k) for k in range(nslots)]
     for st in streams:
         st.wait_stream(origin)
     grad = torch.is_grad_enabled()
