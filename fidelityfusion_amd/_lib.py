@@ -265,7 +265,7 @@ def handle(device_index=None, slot=None):
 
 def _device_handles(device_index):
     """every handle this process holds on that GPU (slot 0 is created on demand)"""
-    h0 = handle(device_index)
+    h0 = handle(device_index, 0)
     if device_index is None:
         import torch
         device_index = torch.cuda.current_device()

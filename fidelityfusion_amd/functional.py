@@ -7,6 +7,7 @@ whatever the input dtype.
 """
 import ctypes as C
 import math
+import threading
 import weakref
 
 import torch
@@ -619,15 +620,40 @@ def threaded_blocks(fns, nslots=2, device_index=None):
     bulge chasing (the watchdog word), so a single thread cannot put a second HOGP block under the first one's 80 ms of
     latency-bound chase -- two threads can (ctypes drops the GIL inside the library; one thread per handle is the library's
     threading rule, include/ffgp.h).  The caller's stream is waited for before the workers start and waits for theirs at the
-    end; the first exception of any block is raised after every worker has finished.  Grad mode is the caller's."""
-    import threading
+    end; the first exception of any block is raised after every worker has finished.  Grad mode is the caller's.  Tensors among the
+    results (also inside lists / tuples / dicts) are marked as used by the caller's stream (`record_stream`): they were allocated on
+    a worker's.  One call at a time per GPU (the worker slots are process-wide: a second caller waits); a call from INSIDE a worker
+    runs its blocks inline on that worker's slot."""
     fns = list(fns)
     if device_index is None:
         device_index = torch.cuda.current_device()
     nslots = max(1, min(int(nslots), len(fns)))
     results, errors = [None] * len(fns), []
-    if nslots <= 1:
+    if nslots <= 1 or _lib.current_slot() != 0:
         return [fn() for fn in fns]
+    with _threaded_locks_guard:
+        gate = _threaded_locks.setdefault(device_index, threading.Lock())
+    with gate:
+        return _threaded_blocks_run(fns, nslots, device_index, results, errors)
+
+
+_threaded_locks = {}
+_threaded_locks_guard = threading.Lock()
+
+
+def _mark_used_on(obj, stream):
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            _mark_used_on(o, stream)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            _mark_used_on(o, stream)
+
+
+def _threaded_blocks_run(fns, nslots, device_index, results, errors):
     origin = torch.cuda.current_stream(device_index)
     # one stream per worker slot for the life of the process: the caching allocator pools memory per stream (fresh streams would send
     # every step's temporaries back to hipMalloc) and the slot's handle stays bound to one stream
@@ -654,6 +680,7 @@ def threaded_blocks(fns, nslots=2, device_index=None):
         origin.wait_stream(st)
     if errors:
         raise errors[0]
+    _mark_used_on(results, origin)
     return results
 
 

@@ -124,7 +124,12 @@ def test_threaded_blocks_raise_in_the_caller_and_keep_grad_mode():
             F.threaded_blocks([good, bad, good], nslots=2)
         vals = F.threaded_blocks([good, good, good], nslots=3)
         one = good()
+        # a call from inside a worker runs inline on that worker's slot (the worker slots are not re-entrant)
+        from fidelityfusion_amd import _lib
+        inner = F.threaded_blocks([lambda: (_lib.current_slot(), F.threaded_blocks([good, lambda: _lib.current_slot()], nslots=2)),
+                                   lambda: (_lib.current_slot(), None)], nslots=2)
     assert all(torch.equal(v, one) for v in vals)
+    assert inner[0][0] == 1 and inner[1][0] == 2 and inner[0][1][1] == 1 and torch.equal(inner[0][1][0], one)
 
 
 def test_threaded_blocks_forward_with_gradients_then_backward_in_the_caller():
