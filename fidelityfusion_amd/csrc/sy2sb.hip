@@ -362,11 +362,14 @@ __global__ __launch_bounds__(QR_THREADS) void sy2sb_top(TopArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, c = (tid >> 6) * 2 + (lane >> 5);
   const bool sm = tid < 256;   // the threads of the small-matrix phases
   double r0v;       // R[i][c] of the panel's R factor
+  QR_STAMP(30);
   if (p.use_tree) {
     double a[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = (r < p.L) ? p.Rst[(size_t)(i + 32 * r) * 32 + c] : 0.0;   // [L][32][32] = stacked rows
+    QR_STAMP(31);
     qr512(a, sh, tid);
+    QR_STAMP(32);
     // explicit V of the top QR (unit diagonal, zeros above) for the leaf workgroups
     const double v0 = (i > c) ? a[0] : ((i == c) ? 1.0 : 0.0);
     p.Vtst[(size_t)i * 32 + c] = v0;
@@ -387,6 +390,7 @@ __global__ __launch_bounds__(QR_THREADS) void sy2sb_top(TopArgs p) {
     Q0[i][c] = (i == c) ? 1.0 : 0.0;
   }
   __syncthreads();
+  QR_STAMP(33);
   // X0 = T0 V0top^T ; Wtop = (I - V0top X0) Q0
   {
     M1[i][c] = p.Tst[i * 32 + c];
@@ -418,6 +422,7 @@ __global__ __launch_bounds__(QR_THREADS) void sy2sb_top(TopArgs p) {
   }
   if (sm) mm32<false>(Wt, M1, Q0, 1.0, tid);       // top block of Q1
   __syncthreads();
+  QR_STAMP(34);
   // modified LU of [I;0] - Q1 S (top block): signs chosen so that every pivot is >= 1 in magnitude.  V1 <- Y1 (unit lower).
   V1[i][c] = (i == c) ? 1.0 : 0.0;
   __syncthreads();
@@ -431,6 +436,7 @@ __global__ __launch_bounds__(QR_THREADS) void sy2sb_top(TopArgs p) {
     if (i > j && c > j) Wt[i][c] = __builtin_fma(-V1[i][j], Wt[j][c], Wt[i][c]);   // thread (i, c): one entry each
     __syncthreads();
   }
+  QR_STAMP(35);
   // U (upper) -> M1;  T = U Y1^-T -> M2 (row i: forward substitution over the columns);  U^-1 -> Q0 (column by column)
   M1[i][c] = (c >= i) ? (((i == c) ? 1.0 : 0.0) - Ssign[c] * Wt[i][c]) : 0.0;
   __syncthreads();
@@ -453,6 +459,7 @@ __global__ __launch_bounds__(QR_THREADS) void sy2sb_top(TopArgs p) {
     Q0[i][c] = q;
   }
   __syncthreads();
+  QR_STAMP(36);
   {
     const int idx = i * 32 + c;
     p.small[idx] = Xt[i][c];
@@ -463,6 +470,7 @@ __global__ __launch_bounds__(QR_THREADS) void sy2sb_top(TopArgs p) {
     if (i <= c) p.AB[(size_t)c * SB_LDB + (32 + i - c)] = Ssign[i] * r0v;
   }
   if (tid < 32) p.small[1024 + tid] = Ssign[tid];
+  QR_STAMP(37);
 }
 
 struct FormYArgs {

@@ -8,6 +8,7 @@
 //  with equal names the loader binds both registrations to one handle -- the library's code object then runs)
 #define sy2sb_leaf_qr4 probe_leaf_qr4
 #define sy2sb_leaf_qr probe_leaf_qr
+#define sy2sb_top probe_top
 #include "../../fidelityfusion_amd/csrc/sy2sb.hip"
 #include <cstdio>
 #include <cstdlib>
@@ -63,5 +64,28 @@ int main() {
   printf(" us;  T build %.2f us\n", us(16, 2));
   printf("  column 16:  LDS reads %.2f  dots %.2f  sums %.2f  scalars %.2f  updates %.2f  publish %.2f  barrier %.2f us\n", us(20, 21), us(21, 22),
          us(22, 23), us(23, 24), us(24, 25), us(25, 26), us(26, 27));
+  // the top kernel of the same panel: QR of the 16 stacked R factors, then the reconstruction algebra (one workgroup)
+  double *Vtst, *small, *Tpan, *Yp, *ABp;
+  CK(hipMalloc(&Vtst, 512 * 32 * sizeof(double)));
+  CK(hipMalloc(&small, 4096 * sizeof(double)));
+  CK(hipMalloc(&Tpan, 1024 * sizeof(double)));
+  CK(hipMalloc(&Yp, (size_t)32 * 32 * sizeof(double)));
+  CK(hipMalloc(&ABp, (size_t)32 * SB_LDB * sizeof(double)));
+  CK(hipMemcpy2D(A, (size_t)n * sizeof(double), hA.data(), 32 * sizeof(double), 32 * sizeof(double), m, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(probe_leaf_qr, dim3(L), dim3(QR_THREADS), 0, 0, la);
+  TopArgs ta;
+  ta.A = A; ta.lda = n; ta.m = m; ta.L = L; ta.Rst = Rst; ta.Tst = Tst; ta.Vtst = Vtst; ta.small = small;
+  ta.Vmid0 = Rst; ta.Tmid0 = Tst; ta.three = 0; ta.Tpan = Tpan; ta.Y = Yp; ta.ldy = 32; ta.AB = ABp; ta.use_tree = 1;
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL(probe_top, dim3(1), dim3(QR_THREADS), 0, 0, ta);
+  CK(hipGetLastError());
+  CK(hipEventRecord(e1, 0));
+  CK(hipDeviceSynchronize());
+  float tms;
+  CK(hipEventElapsedTime(&tms, e0, e1));
+  CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(ffgp_qr_stamp), sizeof(st)));
+  printf("sy2sb_top: %.1f us (events).  load %.2f  QR of the R stack %.2f  V / Xt / Q0 %.2f  X0, W, top block of Q1 %.2f  modified LU %.2f  "
+         "U, T, U^-1 %.2f  stores %.2f us\n", tms * 1e3, us(30, 31), us(31, 32), us(32, 33), us(33, 34), us(34, 35), us(35, 36), us(36, 37));
   return 0;
 }
