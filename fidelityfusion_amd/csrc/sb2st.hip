@@ -51,14 +51,7 @@ __device__ __forceinline__ double rdlane(double x, int l) {
 }
 // sum over the 32 lanes of a half-wave, returned in all of them: four DPP steps inside each row of 16 lanes (quad swaps, half
 // mirror, mirror -- no LDS crossbar on the way), then the four row totals through scalar registers
-__device__ __forceinline__ double wsum32(double x, int lane) {
-  x = dpp_add<0xB1>(x);    // quad_perm [1,0,3,2]
-  x = dpp_add<0x4E>(x);    // quad_perm [2,3,0,1]
-  x = dpp_add<0x141>(x);   // row_half_mirror
-  x = dpp_add<0x140>(x);   // row_mirror
-  const double r0 = rdlane(x, 0), r1 = rdlane(x, 16), r2 = rdlane(x, 32), r3 = rdlane(x, 48);
-  return (lane < 32) ? r0 + r1 : r2 + r3;
-}
+__device__ __forceinline__ double wsum32(double x, int lane) { return qr_wsum32(x, lane); }   // (syevd_internal.h)
 __device__ __forceinline__ double swap32(double x) { return __shfl_xor(x, 32); }
 
 // the band lives in memory that waves on other compute units (and other XCDs) read and write while this kernel runs: every access

@@ -43,13 +43,19 @@ __device__ __forceinline__ double qr_rdlane(double x, int l) {
   hi = __builtin_amdgcn_readlane(hi, l);
   return __hiloint2double(hi, lo);
 }
-// sum over the 32 lanes of each half-wave, in all of them (DPP inside the rows of 16, row totals through scalar registers)
+// sum over the 32 lanes of each half-wave, in all of them (DPP inside the rows of 16, then the two rows of a half exchanged)
 __device__ __forceinline__ double qr_wsum32(double x, int lane) {
   x = qr_dpp_add<0xB1>(x);
   x = qr_dpp_add<0x4E>(x);
   x = qr_dpp_add<0x141>(x);
   x = qr_dpp_add<0x140>(x);
-  const double r0 = qr_rdlane(x, 0), r1 = qr_rdlane(x, 16), r2 = qr_rdlane(x, 32), r3 = qr_rdlane(x, 48);
-  return (lane < 32) ? r0 + r1 : r2 + r3;
+  // every lane now holds the total of its row of 16; rows 0 + 1 and 2 + 3 through v_permlane16_swap (gfx950): of two copies of x one
+  // ends up with the even rows' totals in both rows of a pair, the other with the odd rows' -- five instructions where the route
+  // through scalar registers (eight readlanes, two adds, a select) took twelve, and bit-identical to it (tools/native/wsum_check.hip)
+  (void)lane;
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
 }
 #endif
