@@ -52,7 +52,14 @@ __device__ __forceinline__ double rdlane(double x, int l) {
 // sum over the 32 lanes of a half-wave, returned in all of them: four DPP steps inside each row of 16 lanes (quad swaps, half
 // mirror, mirror -- no LDS crossbar on the way), then the four row totals through scalar registers
 __device__ __forceinline__ double wsum32(double x, int lane) { return qr_wsum32(x, lane); }   // (syevd_internal.h)
-__device__ __forceinline__ double swap32(double x) { return __shfl_xor(x, 32); }
+// x + (the value 32 lanes away), in every lane: both halves exchanged in registers by v_permlane32_swap (gfx950) -- through
+// __shfl_xor it was an LDS crossbar round trip, three of them on every step's critical path (bit-identical: tools/native/wsum_check.hip)
+__device__ __forceinline__ double halves_sum(double x) {
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
 
 // the band lives in memory that waves on other compute units (and other XCDs) read and write while this kernel runs: every access
 // is a device-scope access (sc1: served from the coherent level, never from this CU's L1); ordering against the progress counters
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
       double pr = 0.0;
 #pragma unroll
       for (int q = 0; q < 16; ++q) pr = __builtin_fma(D[q], vq[q], pr);
-      pr += swap32(pr);
+      pr = halves_sum(pr);
       const double a2 = wsum32(vi * pr, lane);
       const double w = tau * pr - 0.5 * tau * tau * a2 * vi;
       if (h == 0) wsh[i] = w;
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
       double sb = 0.0;
 #pragma unroll
       for (int q = 0; q < 16; ++q) sb = __builtin_fma(B[q], vq[q], sb);
-      sb += swap32(sb);
+      sb = halves_sum(sb);
       const double ts = tau * sb;
 #pragma unroll
       for (int q = 0; q < 16; ++q) B[q] = __builtin_fma(-ts, vq[q], B[q]);
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
         double u = 0.0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) u += Mt[h * 16 + r][i];
-        u += swap32(u);
+        u = halves_sum(u);
         if (h == 0) ush[i] = u;
       }
       __syncthreads();
