@@ -195,6 +195,7 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->nb_outer = 512;
   h->diag_v2 = 1;
   h->trtri_overlap = 1;
+  h->trtri_fill = 0;
   h->raw_graph_max_n = 0;
   h->small2_off = 1;
   h->q2_wave4 = 1;
@@ -336,6 +337,8 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->asm_mm_min = (int)value;
   } else if (!strcmp(key, "sb_lookahead")) {
     h->sb_lookahead = (int)value;
+  } else if (!strcmp(key, "trtri_fill")) {
+    h->trtri_fill = (int)value;
   } else if (!strcmp(key, "trtri_overlap")) {
     h->trtri_overlap = (int)value;
   } else if (!strcmp(key, "small_max_n")) {

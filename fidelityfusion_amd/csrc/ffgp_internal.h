@@ -163,6 +163,7 @@ struct ffgp_handle {
   hipEvent_t tri_ev[2]; // [0] factor columns < tri_hook_col are final (recorded by ffgp_potrf_impl on the side stream); [1] head done
   int tri_hook_col, tri_hook_fired;
   int trtri_overlap;    // option (default 1)
+  int trtri_fill;       // option "trtri_fill" (default 0): 1 = zero the whole inverse buffer before the head of the triangular inverse; 0 = only the diagonal blocks' upper parts; 2 = NaN-fill it (test)
   hipEvent_t ev_switch; // ffgp_set_stream: recorded on the stream the handle leaves, waited for by the one it moves to
   hipEvent_t sb_ev[4];  // sy2sb: hand-offs between the trailing update (main stream) and the next panel's QR chain (side stream)
   int sb_lookahead;     // option (default 0: measured 103 -> 108 ms at N = 8192 -- the event hand-offs cost more than the QR chain hides)

@@ -217,7 +217,8 @@ __global__ void ffgp_copy_block_kernel(const double* __restrict__ src, int lds_,
 }
 
 // batched copy of the inverted diagonal blocks into X's diagonal
-__global__ void ffgp_copy_dinv_kernel(const double* __restrict__ dinv, double* __restrict__ X, int ldx, int n) {
+// (full: also write zeros above the diagonal of every block -- for callers that do not zero X first)
+__global__ void ffgp_copy_dinv_kernel(const double* __restrict__ dinv, double* __restrict__ X, int ldx, int n, int full) {
   const int b = blockIdx.y;
   const int r0 = b * NB;
   const int nb = min(NB, n - r0);
@@ -225,6 +226,7 @@ __global__ void ffgp_copy_dinv_kernel(const double* __restrict__ dinv, double* _
   if (idx < NB * NB) {
     const int r = idx >> 7, c = idx & 127;
     if (r < nb && c <= r) X[(size_t)(r0 + r) * ldx + r0 + c] = dinv[(size_t)b * NB * NB + idx];
+    else if (full && r < nb && c < nb) X[(size_t)(r0 + r) * ldx + r0 + c] = 0.0;
   }
 }
 
@@ -267,7 +269,7 @@ int ffgp_trtri_impl(ffgp_handle* h, const double* L, int n, int ldl, double* X, 
   FFGP_CHECK(ensure_dinv_for(h, L, n, ldl));
   FFGP_CHECK(ffgp_zero_async(h, X, (size_t)n * ldx * sizeof(double)));
   const int nblk = (n + NB - 1) / NB;
-  hipLaunchKernelGGL(ffgp_copy_dinv_kernel, dim3(NB * NB / 256, nblk), dim3(256), 0, h->stream, h->dinv, X, ldx, n);
+  hipLaunchKernelGGL(ffgp_copy_dinv_kernel, dim3(NB * NB / 256, nblk), dim3(256), 0, h->stream, h->dinv, X, ldx, n, 0);
   return trtri_levels(h, L, n, ldl, X, ldx, T);
 }
 
@@ -278,8 +280,14 @@ int ffgp_trtri_impl(ffgp_handle* h, const double* L, int n, int ldl, double* X, 
 //   tail: X22 = L22^-1 and X21 = -X22 Ttop, after the factorisation.
 // The head reads the store of inverted diagonal blocks while the factorisation is still appending to it: blocks < n1 / 128 only.
 int ffgp_trtri_head(ffgp_handle* h, const double* L, int n, int ldl, double* X, int ldx, double* T, double* Ttop, int n1) {
-  FFGP_CHECK(ffgp_zero_async(h, X, (size_t)n * ldx * sizeof(double)));
-  hipLaunchKernelGGL(ffgp_copy_dinv_kernel, dim3(NB * NB / 256, n1 / NB), dim3(256), 0, h->stream, h->dinv, X, ldx, n1);
+  // Every consumer of this X (the levels below, the tail, LAUUM, the gradient tiles) reads it tile-wise in the lower triangle with
+  // triangular hints: tiles wholly above the diagonal are never touched, so only the diagonal blocks' own upper parts need zeros --
+  // written by the copy kernel -- instead of a 2 GB fill per step at N = 16384 (option "trtri_fill" = 1 restores the fill; = 2 fills with
+  // NaN instead, the test that nothing reads up there: loss and gradients stay bit-identical).  C3 with gradients 78.03 -> 77.82 ms.
+  const int fill = h->trtri_fill;
+  if (fill == 1) FFGP_CHECK(ffgp_zero_async(h, X, (size_t)n * ldx * sizeof(double)));
+  if (fill == 2) FFGP_HIP(hipMemsetAsync(X, 0xFF, (size_t)n * ldx * sizeof(double), h->stream));   // test mode: NaN everywhere -- a consumer that read above the diagonal would show it
+  hipLaunchKernelGGL(ffgp_copy_dinv_kernel, dim3(NB * NB / 256, n1 / NB), dim3(256), 0, h->stream, h->dinv, X, ldx, n1, fill == 1 ? 0 : 1);
   FFGP_CHECK(trtri_levels(h, L, n1, ldl, X, ldx, T));
   const int n2 = n - n1;
   return ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, L + (size_t)n1 * ldl, ldl, X, ldx, Ttop, n1, n2, n1, n1, 1.0, 0.0, TRI_LO_J);
@@ -290,7 +298,7 @@ int ffgp_trtri_tail(ffgp_handle* h, const double* L, int n, int ldl, double* X, 
   const int n2 = n - n1;
   double* X22 = X + (size_t)n1 * ldx + n1;
   hipLaunchKernelGGL(ffgp_copy_dinv_kernel, dim3(NB * NB / 256, (n2 + NB - 1) / NB), dim3(256), 0, h->stream,
-                     h->dinv + (size_t)(n1 / NB) * NB * NB, X22, ldx, n2);
+                     h->dinv + (size_t)(n1 / NB) * NB * NB, X22, ldx, n2, h->trtri_fill == 1 ? 0 : 1);
   FFGP_CHECK(trtri_levels(h, L + (size_t)n1 * ldl + n1, n2, ldl, X22, ldx, T));
   return ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, X22, ldx, Ttop, n1, X + (size_t)n1 * ldx, ldx, n2, n1, n2, -1.0, 0.0,
                           TRI_HI_I);

@@ -201,6 +201,9 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
                         instead of 21 -- measured +-5-10 % per training step),
             "raw_graph_max_n" (default 0; > 0: ffgp_nlml_fused_raw calls with n <= this are captured into a hipGraph on their
                         second identical occurrence and replayed afterwards -- measured no faster on ROCm 7.2),
+            "trtri_fill" (default 0: the gradient path's triangular inverse, when its head runs under the factorisation, zeroes only the
+                        diagonal blocks' upper parts of its N x N buffer -- every consumer reads it tile-wise below the diagonal;
+                        1 = zero-fill the whole buffer first (2 GB per step at N = 16384; +0.2 ms); 2 = fill it with NaN, a test mode),
             "sb_av_gemm" (default 0: the band reduction forms A * Y with its own 128-row kernel; 1 = the general GEMM -- measured
                         sy2sb 104 -> 91 ms at n = 8192, equal below n = 4096),
             "sb_qr4" (default 0; 1: the band reduction's leaf QRs on 256-thread workgroups, four columns per half-wave -- 58.9 us per

@@ -2293,3 +2293,35 @@ def test_matern_scalar_length_scale_golden(golden, where):
     dg = Kxx.diagonal()
     ok = torch.isfinite(dg)
     assert (dg[ok] - float(g["signal_variance"][0]) ** 2).abs().max() < 1e-6 if ok.any() else True
+
+
+def test_triangular_inverse_head_never_reads_above_the_diagonal():
+    """The gradient path no longer zero-fills the N x N buffer of L^-1 when the inverse's head runs under the factorisation (only the
+    diagonal blocks' upper parts are zeroed).  Option trtri_fill = 2 fills that buffer with NaN first: loss and every gradient must
+    still equal, bit for bit, the run with the whole buffer zeroed (trtri_fill = 1) and the default -- at a ragged size and at a power of two."""
+    from fidelityfusion_amd import _lib
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp
+    for n, D in ((5000, 4), (8192, 6)):
+        g = torch.Generator(device=DEV).manual_seed(n)
+        X = torch.rand((n, D), generator=g, device=DEV, dtype=torch.float64)
+        Y = torch.randn((n, 2), generator=g, device=DEV, dtype=torch.float64)
+        outs = {}
+        try:
+            for mode in (1, 2, 0):
+                _lib.set_option("trtri_fill", mode)
+                torch.manual_seed(0)
+                m = cigp(kernel.ARDKernel(D), 1.0).double().to(DEV)
+                Yg = Y.clone().requires_grad_(True)
+                for _ in range(2):        # (the second step meets whatever the first one left in the buffer)
+                    for p_ in m.parameters():
+                        p_.grad = None
+                    Yg.grad = None
+                    v = m.negative_log_likelihood(X, Yg)
+                    v.backward()
+                outs[mode] = [v.detach().clone(), Yg.grad.clone()] + [p_.grad.clone() for p_ in m.parameters()]
+        finally:
+            _lib.set_option("trtri_fill", 0)
+        for mode in (2, 0):
+            for a, b in zip(outs[1], outs[mode]):
+                assert bool(torch.isfinite(b).all()) and torch.equal(a, b), (n, mode)
