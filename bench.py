@@ -44,7 +44,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before any child starts or torch loads: see fidelityfusion_amd/_lib.py
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")   # before any child starts or torch loads: see fidelityfusion_amd/_lib.py
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (vendor spec; 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz)
 ROOFLINE_KERNEL = "ffgp_gemm_f64<0, 0, 1, 1, 128, 128>"   # trailing SYRK update of the blocked Cholesky
@@ -78,7 +78,7 @@ def parse_args(argv=None):
     ap.add_argument("--slots", type=int, default=2, help="blocks of one rank that overlap on its GPU (fixed-F workloads)")
     ap.add_argument("--slot-lookahead", action="store_true", help="keep every overlapped block's own look-ahead side stream")
     ap.add_argument("--hogp-slots", type=int, default=4, help="host threads that drive the HOGP blocks of one rank (gar8_hogp): "
-                    "1 = one block after another (2.46 s/step), 2: 1.87, 3: 1.66, 4: 1.54, 8: 1.58 s/step on one MI355X (8 hardware queues)")
+                    "1 = one block after another (2.46 s/step), 2: 1.87, 3: 1.66, 4: 1.54, 8: 1.58 s/step on one MI355X (sweep taken with 8 hardware queues; the default of 6 measures the same)")
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (development A/B runs)")
     return ap.parse_args(argv)
 

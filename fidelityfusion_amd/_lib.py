@@ -10,11 +10,12 @@ import threading
 
 # Several blocks in flight on one GPU (functional.threaded_blocks, concurrent_blocks) need their streams on DIFFERENT hardware queues:
 # streams that share one run their kernels in order.  ROCm maps all streams of a process onto GPU_MAX_HW_QUEUES queues, 4 by default;
-# with a handle's own streams next to the workers' that is not enough -- measured on gar8_hogp (four worker streams): 1.81 s/step
-# with 4 queues, 1.53 with 8, 1.50 with 16; headline unchanged, cigar4 (with gradients) and gar8 0.4-0.8 % slower with 8 in three
-# alternations each.  A default only: an explicit setting wins, and it
-# takes effect only if HIP has not been initialised in this process yet (set it in the environment to be sure).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# with a handle's own streams next to the workers' that is not enough -- gar8_hogp (four worker streams, reserved first): 1.75 / 1.77 s
+# per step with 4 queues, 1.46 / 1.49 with 6, 1.47 / 1.51 with 8 (alternating on one box); 16 double cigar4.  6 costs the other
+# workloads nothing measurable (cigar4 with gradients 59.0-59.4 ms, gar8 74.1-74.4 with 4 and with 6; 8: gar8 74.4-74.6).  A default
+# only: an explicit setting wins, and it takes effect only if HIP has not been initialised in this process yet (set it in the
+# environment to be sure).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
 
 # PyTorch-ROCm ships its own libamdhip64; libffgp.so names the same SONAME.  torch must be imported BEFORE the
 # library is dlopen'ed so that both bind to the ONE runtime already in the process -- loaded the other way round the
