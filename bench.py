@@ -44,7 +44,6 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")   # before any child starts or torch loads: see fidelityfusion_amd/_lib.py
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (vendor spec; 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz)
 ROOFLINE_KERNEL = "ffgp_gemm_f64<0, 0, 1, 1, 128, 128>"   # trailing SYRK update of the blocked Cholesky
@@ -151,6 +150,16 @@ def nlml_flops(n, D, d):
     return n ** 3 / 3.0 + float(n) * n * d + 2.0 * n * n * D
 
 
+def hogp_flops_canonical(n, modes):
+    """The same block priced with a canonical LAPACK-style syevd count -- tridiagonalisation 4/3 N^3, divide & conquer ~4/3 N^3 as
+    GEMMs, ONE back-transformation 2 N^3 (= 4 2/3 N^3) -- plus the mode products: comparable with a rocSOLVER / LAPACK figure,
+    unlike `hogp_flops` (what this build executes: two-stage overhead and the second back-transformation included)."""
+    pd = 1.0
+    for m in modes:
+        pd *= m
+    return (4.0 / 3.0 + 4.0 / 3.0 + 2.0) * float(n) ** 3 + 2.0 * 2.0 * float(n) * n * pd + 2.0 * 2.0 * float(n) * pd * sum(modes)
+
+
 def hogp_flops(n, modes):
     """One HOGP_simple.log_likelihood forward as this build executes it: the two-stage eigensolver of the N x N input kernel --
     band reduction 2 N^3 (A V products 2/3, rank-64 updates 4/3), divide & conquer merges as dense GEMMs 8/3 N^3, the two
@@ -183,7 +192,83 @@ def recorded_traffic(n):
     return byt, os.path.relpath(files[-1], ROOT)
 
 
-def cpu_baseline(budget_s, gpu_nll):
+PARITY_POINTS = {"c2": 256, "headline": 64}    # posterior query points of the in-run parity columns
+
+
+def parity_points(D, nt):
+    """deterministic query points of the parity columns (same numbers on the GPU and in the CPU leg)"""
+    import numpy as np
+    return np.random.default_rng(4242).random((nt, D))
+
+
+def rel_err(a, b):
+    """max |a - b| / max |b| (the tests' measure)"""
+    import numpy as np
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(float(np.abs(b).max()), 1e-300))
+
+
+def gpu_parity_values(dev, names):
+    """OUTSIDE the timed region: the drop-in `cigp` module (reference: GaussianProcess/cigp_v10.py:24-69) at the reference's initial
+    parameters on the C2 / C3 inputs -- +LL, the gradients `loss.backward()` leaves on the raw parameters and on Y
+    (FidelityFusion_Models/ResGP.py:84-88), and the posterior mean / full covariance at PARITY_POINTS query points.  The CPU leg
+    computes the same quantities with the reference's torch-CPU operator sequence and reports the relative errors."""
+    import torch
+    from fidelityfusion_amd import kernel as K_
+    from fidelityfusion_amd.cigp_v10 import cigp
+    out = {}
+    for name in names:
+        _, n, D, d, _ = WORKLOADS[name]
+        X, Y = synthetic_xy(n, D, d, seed=0)
+        Xt = torch.tensor(X, dtype=torch.float64, device=dev)
+        Yt = torch.tensor(Y, dtype=torch.float64, device=dev, requires_grad=True)
+        Xs = torch.tensor(parity_points(D, PARITY_POINTS[name]), dtype=torch.float64, device=dev)
+        m = cigp(K_.ARDKernel(D), 1.0).double().to(dev)     # length_scales = 1, signal_variance = 1, log_beta = 1
+        ll = m.negative_log_likelihood(Xt, Yt)
+        ll.backward()
+        with torch.no_grad():
+            mean, var = m(Xt, Yt.detach(), Xs)
+        out[name] = {"ll": float(ll),
+                     "grads": {"length_scales": m.kernel.length_scales.grad.cpu().numpy(),
+                               "signal_variance": m.kernel.signal_variance.grad.cpu().numpy(),
+                               "log_beta": m.log_beta.grad.cpu().numpy(), "Y": Yt.grad.cpu().numpy()},
+                     "mean": mean.cpu().numpy(), "var": var.cpu().numpy()}
+        del m, Xt, Yt, mean, var
+        torch.cuda.empty_cache()
+    return out
+
+
+def vendor_potrf_ms(dev, sizes=(4096, 16384), reps=3):
+    """The reference's own GPU path, stated beside the headline and never on the product path: the 2023 API moves its tensors with
+    `.cuda()` (MFGP_ver2023May/mfgp_demo.py:88-94), so `torch.linalg.cholesky` there is the vendor solver on this very GPU.  Single
+    host thread, idle GPU, the library's own factorisation (ffgp_potrf via functional.cholesky) on the same matrix next to it;
+    min of `reps` after a warm-up, whole call including the vendor path's host synchronisation (tools/potrf_vs_vendor.py sweeps more sizes)."""
+    import torch
+    from fidelityfusion_amd import functional as F
+    out = {}
+    for n in sizes:
+        X = torch.tensor(synthetic_xy(n, 8, 1, seed=1)[0], dtype=torch.float64, device=dev)
+        S = torch.exp(-0.5 * torch.cdist(X, X) ** 2)
+        S.diagonal().add_(0.368)
+
+        def t(fn):
+            fn()
+            torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                best = min(best, time.perf_counter() - t0)
+            return round(best * 1e3, 3)
+
+        out[str(n)] = {"vendor_potrf_ms": t(lambda: torch.linalg.cholesky(S)), "ffgp_potrf_ms": t(lambda: F.cholesky(S))}
+        del X, S
+        torch.cuda.empty_cache()
+    return out
+
+
+def cpu_baseline(budget_s, gpu_ref):
     """The reference's torch-CPU operator sequence (oracle/torch_cpu_ref.py: cdist -> exp -> eye adds -> linalg.cholesky
     -> solve_triangular -> V1 formula; autograd for the backward) timed on this box's host cores at C2 and C3 (SURVEY
     8d), 1 warm-up + min of 3 where the budget allows, next to the GPU's value on the same inputs (in-run parity).
@@ -242,7 +327,8 @@ def cpu_baseline(budget_s, gpu_nll):
         Xt, Yt = torch.tensor(X), torch.tensor(Y)
         use = threads if name == "c2" else threads_big     # C2 keeps the whole-forward winner, the Cholesky-bound sizes the potrf winner
         torch.set_num_threads(use)
-        r = T.time_cigp(Xt, Yt, one(D), one(1), one(1), repeats=3, with_backward=True, budget_s=left * share)
+        kept = {}
+        r = T.time_cigp(Xt, Yt, one(D), one(1), one(1), repeats=3, with_backward=True, budget_s=left * share, keep=kept)
         fl = nlml_flops(n, D, d)
         c = {"N": n, "D": D, "d": d, "fwd_ms": round(r["fwd_s"] * 1e3, 2), "fwd_gflops": round(fl / r["fwd_s"] / 1e9, 1),
              "fwd_bwd_ms": None if r["fwd_bwd_s"] is None else round(r["fwd_bwd_s"] * 1e3, 2),
@@ -262,9 +348,20 @@ def cpu_baseline(budget_s, gpu_nll):
                 torch.set_num_threads(use)
         if name == "c2" and r["stages_s"]:
             pred = 64.0 * r["stages_s"]["potrf"] + 32.0 * r["stages_s"]["assemble"]
-        if gpu_nll.get(name) is not None:    # cigp returns +LL = -nll: same inputs, same parameters
-            c["gpu_ll"] = -gpu_nll[name]
+        g = gpu_ref.get(name)
+        if g is not None:    # same inputs, same parameters: the in-run parity columns (north_star's gate is 1e-4 relative)
+            c["gpu_ll"] = g["ll"]
             c["rel_err"] = abs(c["gpu_ll"] - c["cpu_ll"]) / abs(c["cpu_ll"])
+            if "grads" in kept and "grads" in g:     # the autograd backward the reference really runs (ResGP.py:84-88)
+                c["rel_err_grad"] = {k: rel_err(g["grads"][k], v.numpy()) for k, v in kept["grads"].items()}
+            if "mean" in g and "L" in kept:          # cigp.forward (cigp_v10.py:24-48) on the CPU leg's own factor
+                with torch.no_grad():
+                    Xq = torch.tensor(parity_points(D, PARITY_POINTS[name]))
+                    mean_c, var_c = T.cigp_forward(Xt, Yt, Xq, one(D), one(1), one(1), L=kept["L"])
+                c["posterior_points"] = int(Xq.shape[0])
+                c["rel_err_mean"] = rel_err(g["mean"], mean_c.numpy())
+                c["rel_err_var"] = rel_err(g["var"], var_c.numpy())
+        del kept
         out["configs"][name] = c
     best = ([v for k, v in out["configs"].items() if k.startswith("headline")] or [out["configs"].get("c2")])[0]
     out["value"] = best["fwd_gflops"] if best else None
@@ -295,8 +392,15 @@ def run_rank(args):
             raise SystemExit("bench.py: --dry is the CPU plumbing run; use it with --backend gloo")
         dev = torch.device("cpu")
     else:
+        from fidelityfusion_amd import _lib
+        _lib.configure_queues(reserve_worker_streams=0)      # GPU_MAX_HW_QUEUES: before this process first touches the GPU
+        ndev = torch.cuda.device_count()                      # (counting devices does not initialise HIP on this image)
+        if ndev < max(args.gpus, local_rank + 1):
+            raise SystemExit("bench.py: --gpus %d (LOCAL_RANK %d) but only %d GPU%s visible to this process -- check "
+                             "HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES or lower --gpus" % (args.gpus, local_rank, ndev, "" if ndev == 1 else "s"))
         assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path; --dry only checks plumbing)"
         torch.cuda.set_device(local_rank)
+        _lib.configure_queues(max_hw_queues=None, device_index=local_rank)   # the worker streams claim their hardware queues first
         dev = torch.device("cuda", local_rank)
     if world > 1:
         if args.backend == "nccl":
@@ -427,7 +531,9 @@ def run_rank(args):
                 key, val = kv.split("=")
                 _lib.set_option(key, float(val), local_rank, all_slots=True)
     if not args.dry:
-        _lib.set_option("timing", 2, local_rank, all_slots=True)   # event pairs around every trailing-update launch (no host syncs)
+        # event pairs around every trailing-update launch, on the stream the kernel runs on, inside the timed region (no host
+        # syncs): the contract's live roofline measurement; costs ~0.1 ms of the 29 ms step by A/B (tools/ab_forward.py)
+        _lib.set_option("timing", 2, local_rank, all_slots=True)
         _lib.syrk_stats(reset=True, device_index=local_rank, all_slots=True)
     dt, joint = timed(step, args.steps, 0)
     stats, stages = {"flops": 0.0, "ms": 0.0, "launches": 0}, {}
@@ -445,7 +551,7 @@ def run_rank(args):
         flops_step = hogp_flops(n, HOGP_MODES if d == HOGP_MODES[0] * HOGP_MODES[1] else (d, 1)) * F_total
     value = flops_step / (dt / args.steps) / 1e9
     stock = args.n is None and args.D is None and args.d is None and args.blocks is None
-    gpu_nll = {args.workload: float(joint[0])} if args.workload in ("headline", "c2") and stock else {}
+    gpu_ref, vendor = {}, None
 
     # ---- the fixed-F sharding workloads, a few steps each (default run only) ----------------------------------------
     sharded = {}
@@ -462,18 +568,29 @@ def run_rank(args):
             sfl = hogp_flops(sn, HOGP_MODES if sd == HOGP_MODES[0] * HOGP_MODES[1] else (sd, 1)) if hog else nlml_flops(sn, sD, sd)
             sharded[name] = {"blocks": sF, "N": sn, "D": sD, "d": sd, "ms_per_step": round(sdt / ssteps * 1e3, 3),
                              "value": round(sfl * sF / (sdt / ssteps) / 1e9, 1), "unit": "GF/s", "scaling": "strong",
-                             "blocks_per_rank": -(-sF // world), "joint_nll": float(sjoint.sum()),
+                             "blocks_per_rank": -(-sF // world),
                              "blocks_in_flight_per_rank": min(args.hogp_slots if hog else args.slots, -(-sF // world)),
                              "config": "BASELINE configs[%d]" % WORKLOADS[name][4] + (
-                                 " as HOGP blocks (d = %d x %d): eigh of the N x N input kernel on ffgp_syevd + mode products; flops = "
-                                 "8.67 N^3 + 4 N^2 d per block, see hogp_flops" % HOGP_MODES if hog else "")}
+                                 " as HOGP blocks (d = %d x %d): eigh of the N x N input kernel on ffgp_syevd + mode products; PRIMARY "
+                                 "figure: ms_per_step; `value` prices the executed flops (8.67 N^3 + 4 N^2 d per block, hogp_flops), "
+                                 "`value_canonical_syevd` a LAPACK-style count (4.67 N^3 + 4 N^2 d)" % HOGP_MODES if hog else "")}
+            if hog:    # HOGP_simple.log_likelihood returns +NLL / (N prod d) per block (hogp_simple.py:92-117): not a joint NLL
+                sharded[name]["sum_block_loss"] = float(sjoint.sum())
+                sharded[name]["primary"] = "ms_per_step"
+                sharded[name]["value_canonical_syevd"] = round(
+                    hogp_flops_canonical(sn, HOGP_MODES if sd == HOGP_MODES[0] * HOGP_MODES[1] else (sd, 1)) * sF / (sdt / ssteps) / 1e9, 1)
+            else:
+                sharded[name]["joint_nll"] = float(sjoint.sum())
             del s_step
             if not args.dry:
                 torch.cuda.empty_cache()
-        if not args.dry and not args.no_cpu_baseline and world == 1:   # C2 on the GPU, for the in-run parity column
-            c_step, *_ = make_workload("c2")
-            gpu_nll["c2"] = float(c_step()[0])
 
+    if not args.dry and not args.no_cpu_baseline and world == 1 and stock and args.workload in ("headline", "c2"):
+        # after every timed leg: the GPU side of the parity columns, and the vendor factorisation as a stated side number
+        gpu_ref = gpu_parity_values(dev, ("c2", "headline") if args.workload == "headline" else ("c2",))
+        if args.workload in gpu_ref and abs(gpu_ref[args.workload]["ll"] + float(joint[0])) > 1e-9 * abs(float(joint[0])):
+            raise SystemExit("bench.py: the timed step's value %r and the drop-in module's %r differ" % (float(joint[0]), gpu_ref[args.workload]["ll"]))
+        vendor = vendor_potrf_ms(dev)
     if rank == 0:
         achieved = stats["flops"] / (stats["ms"] * 1e-3) / 1e12 if stats["ms"] > 0 else 0.0
         traffic, traffic_src, traffic_err = None, None, None
@@ -512,10 +629,19 @@ def run_rank(args):
             "stage_ms": {k: round(v, 3) for k, v in stages.items()},
             "nll": float(joint[0]), "joint_nll": float(joint.sum()),
         }
+        if args.workload == "gar8_hogp":   # blocks return +NLL / (N prod d) each (hogp_simple.py:92-117); s/step is the primary figure
+            out["sum_block_loss"] = out.pop("joint_nll")
+            out.pop("nll")
+            out["primary"] = "ms_per_step"
+            out["value_canonical_syevd"] = round(hogp_flops_canonical(n, HOGP_MODES if d == HOGP_MODES[0] * HOGP_MODES[1] else (d, 1))
+                                                 * F_total / (dt / args.steps) / 1e9, 1)
         if sharded:
             out["sharded"] = sharded
+        if vendor is not None:
+            out["vendor_potrf_ms"] = dict(vendor, note="torch.linalg.cholesky on this GPU (the reference's own .cuda() path, MFGP_ver2023May/"
+                                          "mfgp_demo.py:88-94) vs ffgp_potrf on the same matrix; outside the timed region, never on the product path")
         if not args.no_cpu_baseline and world == 1 and not args.dry:   # reported on rank 0 of the single-GPU run only
-            out["cpu_baseline"] = cpu_baseline(args.cpu_budget_s, gpu_nll)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_budget_s, gpu_ref)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -8,14 +8,9 @@ import ctypes as C
 import os
 import threading
 
-# Several blocks in flight on one GPU (functional.threaded_blocks, concurrent_blocks) need their streams on DIFFERENT hardware queues:
-# streams that share one run their kernels in order.  ROCm maps all streams of a process onto GPU_MAX_HW_QUEUES queues, 4 by default;
-# with a handle's own streams next to the workers' that is not enough -- gar8_hogp (four worker streams, reserved first): 1.75 / 1.77 s
-# per step with 4 queues, 1.46 / 1.49 with 6, 1.47 / 1.51 with 8 (alternating on one box); 16 double cigar4.  6 costs the other
-# workloads nothing measurable (cigar4 with gradients 59.0-59.4 ms, gar8 74.1-74.4 with 4 and with 6; 8: gar8 74.4-74.6).  A default
-# only: an explicit setting wins, and it takes effect only if HIP has not been initialised in this process yet (set it in the
-# environment to be sure).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+import logging
+
+log = logging.getLogger("fidelityfusion_amd")
 
 # PyTorch-ROCm ships its own libamdhip64; libffgp.so names the same SONAME.  torch must be imported BEFORE the
 # library is dlopen'ed so that both bind to the ONE runtime already in the process -- loaded the other way round the
@@ -194,16 +189,49 @@ class thread_slot:
 
 
 block_streams = {}   # (device, worker slot) -> the torch stream `functional.threaded_blocks`' worker of that slot always runs on
-_reserving = threading.Lock()
+_reserving = threading.RLock()
+DEFAULT_HW_QUEUES = 6
+
+
+def configure_queues(max_hw_queues=DEFAULT_HW_QUEUES, reserve_worker_streams=4, device_index=None):
+    """Explicit, logged set-up for SEVERAL BLOCKS IN FLIGHT on one GPU (`functional.threaded_blocks`, `concurrent_blocks`); nothing
+    in the package calls it at import and a single-block user never needs it.  Call it once, before the process first touches the
+    GPU (bench.py does, ahead of its sharded legs).
+
+    1. Streams that share a hardware queue run their kernels in order.  ROCm maps all streams of a process onto GPU_MAX_HW_QUEUES
+       queues, 4 by default; with a handle's own streams next to the workers' that is not enough -- gar8_hogp (four worker streams):
+       1.75 / 1.77 s per step with 4 queues, 1.46 / 1.49 with 6, 1.47 / 1.51 with 8; 16 double cigar4; 6 costs the other workloads
+       nothing measurable (docs/concurrency.md).  The variable is process-wide (every HIP user of the process sees it) and only read
+       when HIP initialises: an explicit setting in the environment wins, and a process whose HIP is already up gets a warning
+       instead of a silent no-op.  `max_hw_queues=None` leaves the environment alone.
+    2. `reserve_worker_streams` > 0 (and a GPU is present): `reserve_block_streams` -- the worker streams claim their hardware
+       queues first.
+    Returns the value of GPU_MAX_HW_QUEUES in effect for this process (None: ROCm's default)."""
+    import torch
+
+    if max_hw_queues is not None:
+        cur = os.environ.get("GPU_MAX_HW_QUEUES")
+        if cur is not None:
+            log.info("GPU_MAX_HW_QUEUES=%s is set in the environment: kept (asked for %d)", cur, max_hw_queues)
+        elif torch.cuda.is_initialized():
+            log.warning("configure_queues(%d) called after HIP was initialised: GPU_MAX_HW_QUEUES cannot change any more; "
+                        "blocks in flight will share ROCm's default 4 hardware queues", max_hw_queues)
+        else:
+            os.environ["GPU_MAX_HW_QUEUES"] = str(int(max_hw_queues))
+            log.info("GPU_MAX_HW_QUEUES=%d set for this process (several blocks in flight per GPU)", max_hw_queues)
+    if reserve_worker_streams and torch.cuda.is_available():
+        reserve_block_streams(device_index, reserve_worker_streams)
+    return os.environ.get("GPU_MAX_HW_QUEUES")
 
 
 def block_stream(device_index, k):
     import torch
 
-    st = block_streams.get((device_index, k))
-    if st is None:
-        st = block_streams[(device_index, k)] = torch.cuda.Stream(device_index)
-    return st
+    with _reserving:
+        st = block_streams.get((device_index, k))
+        if st is None:
+            st = block_streams[(device_index, k)] = torch.cuda.Stream(device_index)
+        return st
 
 
 def reserve_block_streams(device_index=None, n=4):
@@ -211,8 +239,8 @@ def reserve_block_streams(device_index=None, n=4):
     queues before other multi-stream work of the process does.  ROCm binds a stream to one of GPU_MAX_HW_QUEUES hardware queues when
     the stream is first used, and streams on one queue run in order: worker streams that first appeared AFTER a `concurrent_blocks`
     workload (two more handles, each with its own streams) shared queues -- the same eight HOGP blocks then took 1.68 instead of
-    1.45 s per step on one box, and the earlier workloads are not affected either way (docs/concurrency.md).  Runs by itself when the
-    first handle of a GPU is created; idempotent."""
+    1.45 s per step on one box, and the earlier workloads are not affected either way (docs/concurrency.md).  Called by
+    `configure_queues` and by the first `threaded_blocks` of a GPU; idempotent; waits only for its own streams."""
     import torch
 
     if device_index is None:
@@ -222,10 +250,13 @@ def reserve_block_streams(device_index=None, n=4):
         if not fresh:
             return
         x = torch.zeros(64, device=torch.device("cuda", device_index))
+        torch.cuda.current_stream(device_index).synchronize()
         for k in fresh:
-            with torch.cuda.stream(block_stream(device_index, k)):
+            st = block_stream(device_index, k)
+            with torch.cuda.stream(st):
                 x.add_(1.0)
-        torch.cuda.synchronize(device_index)
+            st.synchronize()
+        log.info("reserved %d worker streams on cuda:%d", len(fresh), device_index)
 
 
 def current_slot():
@@ -250,17 +281,13 @@ def handle(device_index=None, slot=None):
         device_index = torch.cuda.current_device()
     if slot is None:
         slot = current_slot()
-    first_on_device = False
     with _lock:
         h = _handles.get((device_index, slot))
         if h is None:
-            first_on_device = not any(d == device_index for (d, _) in _handles)
             out = C.c_void_p()
             check(lib.ffgp_create(int(device_index), C.byref(out)), "ffgp_create")
             h = out
             _handles[(device_index, slot)] = h
-    if first_on_device:   # (outside the lock: it launches kernels)
-        reserve_block_streams(device_index)
     return h
 
 

@@ -234,8 +234,11 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
       }
       CH_STAMP(3, 0, k);    // block below updated, its stores issued
       ++k;
-      // publish: k steps of this sweep are complete.  The fence waits for every band store of the wave above.
+      // publish: k steps of this sweep are complete.  Every band store above is an sc1 (write-through) store of THIS wave; the
+      // explicit wait drains them to the coherent level before the counter moves (a workgroup-scope fence alone compiles to
+      // lgkmcnt(0) only: the counter could overtake the band).  tools/check_isa.py asserts the vmcnt(0) in front of both stores.
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       CH_STAMP(4, 0, k - 1);    // every band store of the step has completed
       if (lane == 0) __hip_atomic_store(p.prog + s, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (h == 0) p.V2[((size_t)s * p.K + k) * 32 + i] = v2i;
@@ -250,6 +253,7 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
       if (seen < k + 2) seen = chase_wait(p.prog + s - 1, k + 2, p.err);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_store(p.prog + s, CH_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
   }

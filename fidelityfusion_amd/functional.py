@@ -206,19 +206,22 @@ class _NLML(torch.autograd.Function):
                 None, None, None, None, None, None, fin("kparam", 5), None)
 
 
-DEFER_RAW_ERRORS = True
-"""A training step through the raw-parameter path (`nlml_raw`: everything GPU-resident, gradients requested) is ENQUEUED and its
-status collected in backward(): the host builds the backward pass while the GPU factors, which is most of a step at the sizes the
-reference's demos run.  Consequence: a Sigma that is not positive definite raises torch.linalg.LinAlgError from `loss.backward()`
--- or from the next likelihood call on that device if backward() is never reached -- instead of from the likelihood call itself
-(the value is NaN meanwhile).  Calls under torch.no_grad(), CPU-resident tensors and every other path raise at the call, as
-torch.linalg.cholesky does.  False: always raise at the call."""
+DEFER_RAW_ERRORS = False
+"""Opt-in.  False (default): a Sigma that is not positive definite raises torch.linalg.LinAlgError from the likelihood call
+itself, as `torch.linalg.cholesky` does inside the reference's `negative_log_likelihood` (GaussianProcess/cigp_v10.py:61).
+True: a training step through the raw-parameter path (`nlml_raw`: everything GPU-resident, gradients requested) is ENQUEUED and
+its status collected in backward(), so the host builds the backward pass while the GPU factors (0.33 -> 0.25 ms per step at
+N = 128).  The error then surfaces from `loss.backward()` -- or from the next likelihood call on that device if backward() is
+never reached -- and the value is NaN meanwhile; a loss that is evaluated with gradients enabled and never back-propagated only
+raises at the next call.  Calls under torch.no_grad(), CPU-resident tensors and every other path always raise at the call."""
 
-_raw_pending = {}   # device index -> handle with an enqueued, not yet collected raw-parameter call
+_raw_pending = {}   # device index -> handle with an enqueued, not yet collected raw-parameter call (only with DEFER_RAW_ERRORS)
+_raw_pending_lock = threading.Lock()
 
 
 def _settle_raw(dev_index):
-    h = _raw_pending.pop(dev_index, None)
+    with _raw_pending_lock:
+        h = _raw_pending.pop(dev_index, None)
     if h is not None:
         rc = check(lib.ffgp_wait(h), "ffgp_wait")
         if rc > 0:
@@ -235,8 +238,8 @@ class _NLMLRaw(torch.autograd.Function):
     def forward(ctx, X, Y, rw, ramp, rdadd, diag_vec, add_mat, kparam, links, add_all, mean_jitter, clamp, variant, pi_const, kfun_id,
                 sign, rec, kp_const):
         dev = X.device
-        if dev.index in _raw_pending:
-            _settle_raw(dev.index)      # an earlier step never reached backward(): its status is due now
+        if _raw_pending:
+            _settle_raw(dev.index)      # an earlier (deferred) step never reached backward(): its status is due now
         h = _lib.handle(dev.index, 0)
         _lib.bind_stream(h, dev.index)
         n, D = X.shape
@@ -282,7 +285,8 @@ class _NLMLRaw(torch.autograd.Function):
         links.out_scale = sign          # the sign (+LL for the reference's `negative_log_likelihood`) is applied inside the call
         if g is not None and DEFER_RAW_ERRORS:
             check(lib.ffgp_nlml_fused_raw_async(h, C.byref(p), C.byref(links), out.data_ptr(), C.byref(g)), "ffgp_nlml_fused_raw_async")
-            _raw_pending[dev.index] = h
+            with _raw_pending_lock:
+                _raw_pending[dev.index] = h
             ctx.dev_index = dev.index
         else:
             rc = check(lib.ffgp_nlml_fused_raw(h, C.byref(p), C.byref(links), out.data_ptr(), C.byref(g) if g is not None else None),
@@ -381,7 +385,8 @@ class _NLMLRawMany(torch.autograd.Function):
                     g.g_diag_vec_dev = b + 8 * (Dw + 3 + n * d)
         if buf is not None and DEFER_RAW_ERRORS:
             check(lib.ffgp_nlml_fused_small_batch_async(h, nF, P, L, out.data_ptr(), G), "ffgp_nlml_fused_small_batch_async")
-            _raw_pending[dev.index] = h
+            with _raw_pending_lock:
+                _raw_pending[dev.index] = h
             ctx.dev_index = dev.index
         else:
             rc = check(lib.ffgp_nlml_fused_small_batch(h, nF, P, L, out.data_ptr(), G if buf is not None else None),
@@ -608,7 +613,8 @@ class concurrent_blocks:
         return False
 
 
-reserve_block_streams = _lib.reserve_block_streams   # (runs by itself with the first handle of a GPU; see there)
+reserve_block_streams = _lib.reserve_block_streams   # (explicitly via _lib.configure_queues(), or by the first threaded_blocks of a GPU)
+configure_queues = _lib.configure_queues
 
 
 def threaded_blocks(fns, nslots=2, device_index=None):
@@ -655,6 +661,7 @@ def _mark_used_on(obj, stream):
 
 def _threaded_blocks_run(fns, nslots, device_index, results, errors):
     origin = torch.cuda.current_stream(device_index)
+    _lib.reserve_block_streams(device_index, max(4, nslots))      # (idempotent; best done up front: _lib.configure_queues)
     # one stream per worker slot for the life of the process: the caching allocator pools memory per stream (fresh streams would send
     # every step's temporaries back to hipMalloc) and the slot's handle stays bound to one stream
     streams = [_lib.block_stream(device_index, k) for k in range(nslots)]

@@ -10,8 +10,8 @@ mode product -- the O(N^2 prod(d)) part: 550 GFLOP each at N = 8192, d = 64 x 64
 GEMM (`functional.matmul_nt`, forward and backward).  Symmetric eigendecompositions: matrices up to 64 x 64 -- the
 per-mode kernels -- run on the hand-written LDS Jacobi solver (`ffgp_syevj_small`); the N x N input kernel runs on the
 library's two-stage solver (`eigh.eigh` -> `ffgp_syevd`: band reduction, bulge chasing, divide & conquer, two
-back-transformations; 0.26 s at N = 8192 where rocSOLVER's syevd takes 0.66 s).  No vendor library is called anywhere on
-this path; `EIGENSOLVER = "rocsolver"` (torch.linalg.eigh) exists only as the comparator of the GPU tests, "jacobi" is the
+back-transformations; 0.26 s at N = 8192 where rocSOLVER's syevd takes 0.66 s).  No vendor library is called anywhere in
+this module (the GPU tests substitute their own `eigen_pairs` built on torch.linalg.eigh as the comparator); "jacobi" is the
 round-2 block Jacobi (slow, independent cross-check).  The likelihood's backward is closed-form (`_KronNLL`): GEMMs only,
 no differentiation through `eigh`.
 
@@ -35,25 +35,29 @@ import torch.nn as nn
 from . import functional as F
 
 
-EIGENSOLVER = "ffgp"    # n > 64: "ffgp" = the library's two-stage solver (default); "jacobi" = its block Jacobi (slow cross-check);
-                        # "rocsolver" = torch.linalg.eigh, the comparator of the GPU tests -- never the default
+EIGENSOLVER = "ffgp"    # n > 64: "ffgp" = the library's two-stage solver (default); "jacobi" = its block Jacobi (slow cross-check)
 
 
 class eigen_pairs:
     """matrices up to 64 x 64 (the per-mode kernels; tiny input sets) go to the hand-written LDS Jacobi solver
-    (`ffgp_syevj_small`, ~80 us where rocSOLVER's syevd takes 1.7 ms), larger ones -- the N x N input kernel -- to the
-    library's two-stage solver (`ffgp_syevd`).  Reference: `eigen_pairs`, two_fidelity_models/hogp_simple.py:15-19."""
+    (`ffgp_syevj_small`), larger ones -- the N x N input kernel -- to the library's two-stage solver (`ffgp_syevd`).
+    Reference: `eigen_pairs`, two_fidelity_models/hogp_simple.py:15-19.
+
+    There is no vendor or CPU route: the matrix must live on the MI355X.  The pairs of an n > 64 matrix are computed on a
+    DETACHED copy (`value`, `vector` carry no autograd history): the likelihood's gradient is the closed form of `_KronNLL`, which
+    never differentiates through eigenvectors, and `forward()`'s variance expression treats the cached pairs as constants, as the
+    reference's cached `K_eigen` of the last likelihood call are used there (:60-75)."""
 
     def __init__(self, matrix):
-        if matrix.shape[0] <= 64 and matrix.is_cuda:
+        if not matrix.is_cuda:
+            raise F._lib.FFGPError("eigen_pairs: the matrix must be on the GPU (fidelityfusion_amd has no CPU path)")
+        if matrix.shape[0] <= 64:
             self.value, self.vector = F.eigh_small(matrix)
-        elif matrix.is_cuda and EIGENSOLVER in ("ffgp", "jacobi"):
+        elif EIGENSOLVER in ("ffgp", "jacobi"):
             from . import eigh as _eigh
             with torch.no_grad():
                 fn = _eigh.eigh if EIGENSOLVER == "ffgp" else _eigh.jacobi_eigh
                 self.value, self.vector = fn(matrix.detach().to(torch.float64))
-        elif EIGENSOLVER == "rocsolver" or not matrix.is_cuda:
-            self.value, self.vector = torch.linalg.eigh(matrix, UPLO="U")
         else:
             raise ValueError("unknown EIGENSOLVER %r" % (EIGENSOLVER,))
 

@@ -38,6 +38,13 @@ def _rank_world(group=None):
     return 0, 1
 
 
+def _has_group():
+    """Collectives are issued whenever a process group exists -- also a ONE-rank group, where they are arithmetically a no-op: a
+    1-rank `nccl` group on a single-GPU box then drives RCCL through exactly the calls the 8-GPU run makes (tests/test_sharding_gloo.py,
+    `-m gpu`), so that the first multi-GPU run is not the first time those code paths execute.  Without a process group: none."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def _f64(a):
     """values of a block description as a float64 tensor (a Python float must not pass through torch's float32 default)"""
     import numpy as np
@@ -115,7 +122,7 @@ def joint_ll(blocks, evaluator=None, group=None, reduce_device=None):
         vals = [evaluator(blocks[f]) for f in mine]
     for f, v in zip(mine, vals):
         vec[f] = v
-    if world > 1:
+    if _has_group():
         dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
     return vec, float(vec.sum())
 
@@ -168,7 +175,7 @@ class ShardedTrainer:
             losses[f].backward()
             self.opts[f].step()
             vec[f] = losses[f].detach().to(dev)
-        if self.world > 1:
+        if _has_group():
             dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.group)
         return vec
 
@@ -180,7 +187,7 @@ class ShardedTrainer:
             for f, m in self.models.items():
                 mean, var = m(self.data[f][0], self.data[f][1], x_test)
                 local[f] = (mean.cpu(), var.cpu())
-        if self.world == 1:
+        if not _has_group():
             return local
         out = [None] * self.world
         dist.all_gather_object(out, local, group=self.group)

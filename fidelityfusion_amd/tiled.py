@@ -123,6 +123,10 @@ class TiledCholesky:
     def __init__(self, n, nb=512, group=None, ops=None, comm_device=None):
         self.group = group
         self.rank, self.world = _rank_world(group)
+        # collectives are issued whenever a process group exists, also a ONE-rank group (arithmetically a no-op there): a 1-rank
+        # `nccl` group on a single-GPU box runs the panel broadcast / reduce-to-owner / status all-reduce through RCCL exactly as
+        # the multi-GPU run will (tests/test_tiled_gloo.py, `-m gpu`)
+        self.comm = dist.is_available() and dist.is_initialized()
         self.layout = PanelLayout(n, nb, self.world)
         self.ops = ops if ops is not None else HipOps()
         if isinstance(self.ops, HipOps) and n % 2:
@@ -130,8 +134,8 @@ class TiledCholesky:
         self.dev = self.ops.device
         # collectives run on the compute device with RCCL ("nccl"), through host staging with gloo
         if comm_device is None:
-            use_dev = self.world > 1 and dist.get_backend(group) == "nccl"
-            comm_device = self.dev if (use_dev or self.world == 1) else torch.device("cpu")
+            use_dev = self.comm and dist.get_backend(group) == "nccl"
+            comm_device = self.dev if (use_dev or not self.comm) else torch.device("cpu")
         self.comm_dev = torch.device(comm_device)
         self.panels = {}
         self.info = 0
@@ -163,9 +167,9 @@ class TiledCholesky:
     def _post_broadcast(self, k, buf):
         """post the broadcast of panel k into `buf` ([rows(k), nb] on comm_dev); returns (work, view)"""
         lay = self.layout
-        view = buf[:lay.rows(k), :lay.width(k)]
-        if self.world == 1:
+        if not self.comm:
             return None, self.panels[k]
+        view = buf[:lay.rows(k), :lay.width(k)]
         src = lay.owner(k)
         if self.rank == src:
             if self.panels[k].device == view.device:
@@ -179,7 +183,7 @@ class TiledCholesky:
     def _landed(self, work, view, k):
         if work is not None:
             work.wait()
-        if self.world == 1 or self.layout.owner(k) == self.rank:
+        if not self.comm or self.layout.owner(k) == self.rank:
             return self.panels[k]          # the owner reads its own copy
         return view if view.device == self.dev else view.to(self.dev)
 
@@ -202,14 +206,14 @@ class TiledCholesky:
         K = lay.npanels
         mine = set(lay.owned(self.rank))
         # contiguous [rows, nb] staging: the broadcast views must be dense, so each buffer is re-viewed per panel
-        bufs = [torch.empty((lay.rows(0) * lay.nb,), dtype=torch.float64, device=self.comm_dev) for _ in range(2 if self.world > 1 else 0)]
+        bufs = [torch.empty((lay.rows(0) * lay.nb,), dtype=torch.float64, device=self.comm_dev) for _ in range(2 if self.comm else 0)]
 
         def staging(k):
-            return bufs[k & 1][:lay.rows(k) * lay.width(k)].view(lay.rows(k), lay.width(k)) if self.world > 1 else None
+            return bufs[k & 1][:lay.rows(k) * lay.width(k)].view(lay.rows(k), lay.width(k)) if self.comm else None
 
         if 0 in mine:
             self._factor_panel(0)
-        work, view = self._post_broadcast(0, staging(0)) if self.world > 1 else (None, None)
+        work, view = self._post_broadcast(0, staging(0)) if self.comm else (None, None)
         for k in range(K):
             P = self._landed(work, view, k)
             nxt = k + 1
@@ -217,11 +221,11 @@ class TiledCholesky:
                 if nxt in mine:                      # look-ahead: the next panel first, so its broadcast can start
                     self._update_panel(nxt, k, P)
                     self._factor_panel(nxt)
-                work, view = self._post_broadcast(nxt, staging(nxt)) if self.world > 1 else (None, None)
+                work, view = self._post_broadcast(nxt, staging(nxt)) if self.comm else (None, None)
             for j in sorted(mine):
                 if j > nxt:
                     self._update_panel(j, k, P)
-        if self.world > 1:
+        if self.comm:
             st = torch.tensor([self.info if self.info else 2 ** 31 - 1], dtype=torch.int64, device=self.comm_dev)
             dist.all_reduce(st, op=dist.ReduceOp.MIN, group=self.group)     # the FIRST failing pivot over all ranks
             self.info = 0 if int(st) == 2 ** 31 - 1 else int(st)
@@ -241,7 +245,7 @@ class TiledCholesky:
             k0, wk = lay.start(k), lay.width(k)
             own = lay.owner(k)
             zk = Z[k0:k0 + wk]
-            if self.world > 1:
+            if self.comm:
                 zc = zk.to(self.comm_dev).contiguous()
                 root = dist.get_global_rank(self.group, own) if self.group is not None else own
                 dist.reduce(zc, dst=root, op=dist.ReduceOp.SUM, group=self.group)
@@ -256,7 +260,7 @@ class TiledCholesky:
                 if T.shape[0] > wk:
                     self.ops.gemm_acc(Z[k0 + wk:], T[wk:], G)
         pair = torch.stack([quad, logdet]).to(self.comm_dev)
-        if self.world > 1:
+        if self.comm:
             dist.all_reduce(pair, op=dist.ReduceOp.SUM, group=self.group)
         return float(0.5 * pair[0] + d * pair[1] + 0.5 * n * d * math.log(2.0 * pi_const))
 
@@ -269,9 +273,11 @@ class TiledCholesky:
             blk = torch.zeros((lay.rows(k), wk), dtype=torch.float64)
             if lay.owner(k) == self.rank:
                 blk.copy_(self.panels[k].cpu())
-            if self.world > 1:
+            if self.comm:
                 root = dist.get_global_rank(self.group, lay.owner(k)) if self.group is not None else lay.owner(k)
-                dist.broadcast(blk, src=root, group=self.group)
+                wire = blk.to(self.comm_dev)                    # (RCCL moves device buffers only)
+                dist.broadcast(wire, src=root, group=self.group)
+                blk = wire.cpu()
             L[k0:, k0:k0 + wk] = blk
         return torch.tril(L)
 

@@ -23,9 +23,11 @@ JITTER = 1e-6       # GaussianProcess/cigp_v10.py:13
 PI_TRUNC = 3.1415   # GaussianProcess/cigp_v10.py:15
 
 
-def cigp_ll(X, Y, length_scales, signal_variance, log_beta, stages=None):
+def cigp_ll(X, Y, length_scales, signal_variance, log_beta, stages=None, keep=None):
     """+LL (what cigp.negative_log_likelihood returns, cigp_v10.py:69) as a differentiable torch-CPU scalar.
-    stages: optional dict that receives per-stage wall seconds (assemble / potrf / trsm)."""
+    stages: optional dict that receives per-stage wall seconds (assemble / potrf / trsm).
+    keep: optional dict that receives the factor `L` (detached) -- `cigp_forward` re-derives the very same Sigma and factor
+    (cigp_v10.py:31-35 against :57-61, no y_var), so a posterior check can reuse it instead of a second dpotrf."""
     t0 = time.perf_counter()
     ell = torch.abs(length_scales) + EPS                                     # kernel.py:98
     sq = torch.cdist(X / ell, X / ell, p=2) ** 2                             # kernel.py:100-104
@@ -42,7 +44,31 @@ def cigp_ll(X, Y, length_scales, signal_variance, log_beta, stages=None):
         + 0.5 * n * torch.log(2 * torch.tensor(PI_TRUNC, dtype=X.dtype)) * d  # cigp_v10.py:67-68
     if stages is not None:
         stages.update(assemble=t1 - t0, potrf=t2 - t1, trsm=t3 - t2)
+    if keep is not None:
+        keep["L"] = L.detach()
     return -nll                                                              # cigp_v10.py:69
+
+
+def ard_kernel(x1, x2, length_scales, signal_variance):
+    """GaussianProcess/kernel.py:98-105"""
+    ell = torch.abs(length_scales) + EPS
+    return torch.abs(signal_variance) * torch.exp(-0.5 * torch.cdist(x1 / ell, x2 / ell, p=2) ** 2)
+
+
+def cigp_forward(X, Y, Xs, length_scales, signal_variance, log_beta, L=None):
+    """(mean, var) of cigp.forward, GaussianProcess/cigp_v10.py:24-48: the noise scalar is added to EVERY entry of the full
+    covariance (:44) and y_var is ignored.  L: the factor of Sigma when the caller already holds it (same Sigma as the
+    likelihood's when there is no y_var)."""
+    if L is None:
+        n = X.shape[0]
+        eye = torch.eye(n, dtype=X.dtype)
+        Sigma = ard_kernel(X, X, length_scales, signal_variance) + log_beta.exp().pow(-1) * eye + JITTER * eye   # :31-32
+        L = torch.linalg.cholesky(Sigma)                                                                         # :35
+    kx = ard_kernel(X, Xs, length_scales, signal_variance)                                                       # :34
+    LinvKx = torch.linalg.solve_triangular(L, kx, upper=False)                                                   # :36
+    mean = kx.t() @ torch.cholesky_solve(Y, L)                                                                   # :39
+    var = ard_kernel(Xs, Xs, length_scales, signal_variance) - LinvKx.t() @ LinvKx                               # :41
+    return mean, var + log_beta.exp().pow(-1)                                                                    # :44
 
 
 def cigp_ll_and_grads(X, Y, length_scales, signal_variance, log_beta):
@@ -56,9 +82,11 @@ def cigp_ll_and_grads(X, Y, length_scales, signal_variance, log_beta):
     return ll.detach(), {"length_scales": ls.grad, "signal_variance": sv.grad, "log_beta": lb.grad, "Y": Yr.grad}
 
 
-def time_cigp(X, Y, length_scales, signal_variance, log_beta, repeats=3, with_backward=True, budget_s=None):
+def time_cigp(X, Y, length_scales, signal_variance, log_beta, repeats=3, with_backward=True, budget_s=None, keep=None):
     """1 warm-up + min of `repeats` of the forward, and (optionally) of forward + backward.  budget_s bounds the
-    total wall time: measurements that would not fit are skipped (None).  Returns a dict of seconds and the LL."""
+    total wall time: measurements that would not fit are skipped (None).  Returns a dict of seconds and the LL.
+    keep: optional dict that receives the factor `L` of the warm-up run and, when a backward ran, `grads` (the autograd
+    gradients of +LL: length_scales, signal_variance, log_beta, Y) -- the parity columns of bench.py."""
     out = {"fwd_s": None, "fwd_bwd_s": None, "stages_s": None, "ll": None}
     t_start = time.perf_counter()
 
@@ -67,7 +95,7 @@ def time_cigp(X, Y, length_scales, signal_variance, log_beta, repeats=3, with_ba
 
     with torch.no_grad():
         t0 = time.perf_counter()
-        ll = cigp_ll(X, Y, length_scales, signal_variance, log_beta)          # warm-up (also the value)
+        ll = cigp_ll(X, Y, length_scales, signal_variance, log_beta, keep=keep)   # warm-up (also the value)
         first = time.perf_counter() - t0
         out["ll"] = float(ll)
         best, st_best = first, None
@@ -88,8 +116,10 @@ def time_cigp(X, Y, length_scales, signal_variance, log_beta, repeats=3, with_ba
             if left() is not None and left() < need:
                 break
             t0 = time.perf_counter()
-            cigp_ll_and_grads(X, Y, length_scales, signal_variance, log_beta)
+            _, gr = cigp_ll_and_grads(X, Y, length_scales, signal_variance, log_beta)
             runs.append(time.perf_counter() - t0)
+            if keep is not None:
+                keep["grads"] = gr
         out["fwd_bwd_s"] = min(runs[1:]) if len(runs) > 1 else (runs[0] if runs else None)
     return out
 

@@ -12,6 +12,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "noisy: (GPU) the test runs beside a background load on the same GPU by default -- multi-stream "
+                            "launches, the eigensolver's hand-offs, the full-size properties; FFGP_TEST_NOISE=0 switches it off, =1 runs "
+                            "EVERY GPU test that way")
     # the HIP library is built in-tree (git-ignored); build it once if a fresh checkout has not done so yet
     so = os.path.join(ROOT, "fidelityfusion_amd", "libffgp.so")
     if not os.path.exists(so):
@@ -29,49 +32,53 @@ def golden():
     return load
 
 
-@pytest.fixture(scope="session", autouse=True)
-def _gpu_noise():
-    """FFGP_TEST_NOISE=1: the whole GPU suite runs while a background host thread keeps the chip busy with eigensolver and GEMM work on
-    its own handle slot and stream.  Kernels whose workgroups are only correct when their waves run undisturbed (a missing barrier: two
-    found so far, both invisible on an idle GPU) then fail the tests they already have.  Off by default: the suite's timing-sensitive
-    comparisons and the round-end run stay as they are."""
-    if not os.environ.get("FFGP_TEST_NOISE"):
-        yield
-        return
-    import threading
-    import time
-    import torch
-    if not torch.cuda.is_available():
-        yield
-        return
-    from fidelityfusion_amd import _lib
-    from fidelityfusion_amd import eigh as E
-    from fidelityfusion_amd import functional as F
-    stop = threading.Event()
-    count = [0]
-    # torch.linalg's vendor routines are the REFERENCES of many tests, and on this image they are not safe beside GPU work from
-    # another host thread: torch.linalg.cholesky of a 1500 x 1500 SPD matrix returned wrong factors (up to 4e-2 relative) in 2 of 250
-    # calls next to a plain torch.matmul loop on another stream, in 8-84 of 250 next to this library's eigh / nlml, while the
-    # library's own results on the same inputs never moved (docs/experiments.md).  So the load pauses while a comparator runs: every
-    # round of the load and every wrapped vendor call take the same lock.
-    vendor = threading.Lock()
-    import functools
-    patched = []
-    for name in ("cholesky", "cholesky_ex", "eigh", "eigvalsh", "solve_triangular", "inv", "solve", "slogdet", "det", "qr", "svd", "lstsq"):
-        real = getattr(torch.linalg, name, None)
-        if real is None:
-            continue
+class _Noise:
+    """A background host thread that keeps the chip busy with eigensolver, GEMM and likelihood work on its own handle slot and stream.
+    Kernels whose workgroups are only correct when their waves run undisturbed (a missing barrier, a hand-off without a drain: three
+    found so far, all invisible on an idle GPU) then fail the tests they already have.
 
-        def quiet(*a, _real=real, **kw):
-            with vendor:
-                out = _real(*a, **kw)
-                torch.cuda.synchronize()
-                return out
-        functools.update_wrapper(quiet, real)
-        setattr(torch.linalg, name, quiet)
-        patched.append((name, real))
+    torch.linalg's vendor routines are the REFERENCES of many tests, and on this image they are not safe beside GPU work from
+    another host thread: torch.linalg.cholesky of a 1500 x 1500 SPD matrix returned wrong factors (up to 4e-2 relative) in 2 of 250
+    calls next to a plain torch.matmul loop on another stream, in 8-84 of 250 next to this library's eigh / nlml, while the
+    library's own results on the same inputs never moved (docs/experiments.md).  So the load pauses while a comparator runs: every
+    round of the load and every wrapped vendor call take the same lock."""
 
-    def noise():
+    def __init__(self):
+        import threading
+        self.stop = threading.Event()
+        self.run = threading.Event()        # set: the load is on; clear: parked
+        self.parked = threading.Event()
+        self.vendor = threading.Lock()
+        self.count = 0
+        self.patched = []
+        self.thread = None
+
+    def start(self):
+        import functools
+        import threading
+        import torch
+        for name in ("cholesky", "cholesky_ex", "eigh", "eigvalsh", "solve_triangular", "inv", "solve", "slogdet", "det", "qr", "svd", "lstsq"):
+            real = getattr(torch.linalg, name, None)
+            if real is None:
+                continue
+
+            def quiet(*a, _real=real, **kw):
+                with self.vendor:
+                    out = _real(*a, **kw)
+                    torch.cuda.synchronize()
+                    return out
+            functools.update_wrapper(quiet, real)
+            setattr(torch.linalg, name, quiet)
+            self.patched.append((name, real))
+        self.thread = threading.Thread(target=self._loop, name="ffgp-test-noise", daemon=True)
+        self.thread.start()
+
+    def _loop(self):
+        import time
+        import torch
+        from fidelityfusion_amd import _lib
+        from fidelityfusion_amd import eigh as E
+        from fidelityfusion_amd import functional as F
         torch.cuda.set_device(0)
         dev = torch.device("cuda:0")
         st = torch.cuda.Stream(0)
@@ -85,9 +92,14 @@ def _gpu_noise():
             w = torch.ones(6, device=dev, dtype=torch.float64)
             amp = torch.ones(1, device=dev, dtype=torch.float64)
             dadd = torch.full((1,), 0.05, device=dev, dtype=torch.float64)
-            while not stop.is_set():           # three kinds of neighbour in rotation: which kernels share a CU decides what gets disturbed
-                kind = count[0] % 3
-                with vendor:
+            while not self.stop.is_set():      # three kinds of neighbour in rotation: which kernels share a CU decides what gets disturbed
+                if not self.run.is_set():
+                    self.parked.set()
+                    self.run.wait(0.05)
+                    continue
+                self.parked.clear()
+                kind = self.count % 3
+                with self.vendor:
                     if kind == 0:
                         E.eigh(K)                  # 1024-thread QR workgroups, the chase, divide & conquer, both back-transformations
                     elif kind == 1:
@@ -97,14 +109,68 @@ def _gpu_noise():
                         for _ in range(8):
                             F.nlml(X, Y, w, amp, diag_add=dadd, clamp=1e-30)   # assembly, the blocked factorisation's chain, reductions
                     st.synchronize()
-                count[0] += 1
+                self.count += 1
                 time.sleep(0.002)              # (outside the lock: a comparator that is waiting gets its turn -- Python's locks are not fair)
 
-    t = threading.Thread(target=noise, name="ffgp-test-noise", daemon=True)
-    t.start()
+    def on(self):
+        if self.thread is None:
+            self.start()
+        self.parked.clear()
+        self.run.set()
+
+    def off(self):
+        self.run.clear()
+        self.parked.wait(30)
+
+    def end(self):
+        import torch
+        self.stop.set()
+        self.run.set()
+        if self.thread is not None:
+            self.thread.join(timeout=60)
+        for name, real in self.patched:
+            setattr(torch.linalg, name, real)
+
+
+_noise = None
+
+
+def _noise_mode():
+    """FFGP_TEST_NOISE: unset / "marked" (default) = the tests marked `noisy` run beside the load (the regime three of the five
+    BASELINE configs run in: several blocks in flight on one GPU); "1" = the WHOLE GPU suite does; "0" = nothing does."""
+    v = os.environ.get("FFGP_TEST_NOISE", "marked")
+    return {"1": "all", "0": "off"}.get(v, "marked")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _gpu_noise_session():
+    global _noise
     yield
-    stop.set()
-    t.join(timeout=60)
-    for name, real in patched:
-        setattr(torch.linalg, name, real)
-    print("\n[ffgp] background noise thread ran %d rounds during the session" % count[0])
+    if _noise is not None:
+        _noise.end()
+        print("\n[ffgp] background noise thread ran %d rounds during the session" % _noise.count)
+        _noise = None
+
+
+@pytest.fixture(autouse=True)
+def _gpu_noise(request):
+    """the co-running load around one test: every test when FFGP_TEST_NOISE=1, by default the tests marked `noisy`"""
+    global _noise
+    mode = _noise_mode()
+    want = mode == "all" or (mode == "marked" and request.node.get_closest_marker("noisy") is not None)
+    if want and request.node.get_closest_marker("gpu") is None:
+        want = False
+    if want:
+        import torch
+        want = torch.cuda.is_available()
+    if not want:
+        yield
+        return
+    if _noise is None:
+        _noise = _Noise()
+    _noise.on()
+    try:
+        yield
+    finally:
+        if mode != "all":
+            _noise.off()

@@ -45,7 +45,8 @@ def test_self_launch_two_ranks_weak_and_sharded_legs():
     # ... and the HOGP wording of config 5 ("HOGP variant reported separately"), dealt and reduced the same way
     hg = sh["gar8_hogp"]
     assert hg["blocks"] == 8 and hg["blocks_per_rank"] == 4 and "HOGP" in hg["config"] and hg["value"] > 0
-    assert abs(hg["joint_nll"] - _expected_joint(8, 64, 8, 8)) < 1e-9 * abs(hg["joint_nll"])
+    assert abs(hg["sum_block_loss"] - _expected_joint(8, 64, 8, 8)) < 1e-9 * abs(hg["sum_block_loss"])
+    assert hg["primary"] == "ms_per_step" and hg["value_canonical_syevd"] < hg["value"]
 
 
 def test_fixed_blocks_same_joint_value_on_1_2_3_ranks():
@@ -93,3 +94,28 @@ def test_parent_of_a_self_launch_never_imports_torch():
         env.pop(k, None)
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "parent clean" in p.stdout, p.stderr[-2000:]
+
+
+def test_more_ranks_than_visible_gpus_fails_fast_with_a_message():
+    """`bench.py --gpus 2` on a box that shows fewer than 2 devices (here: none) must end at once with a message that names the
+    count, not hang in a rendezvous or die in torch.cuda.set_device"""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert p.returncode != 0
+    assert "GPU" in p.stderr and "visible" in p.stderr and "--gpus 2" in p.stderr, p.stderr[-1500:]
+
+
+def test_importing_the_package_leaves_the_environment_alone():
+    """the hardware-queue default is an explicit, logged call (`_lib.configure_queues`), not an import side effect"""
+    code = ("import os\nos.environ.pop('GPU_MAX_HW_QUEUES', None)\nimport sys\nsys.path.insert(0, %r)\n"
+            "import fidelityfusion_amd\nfrom fidelityfusion_amd import _lib, functional\n"
+            "assert 'GPU_MAX_HW_QUEUES' not in os.environ\n"
+            "import logging\nlogging.basicConfig(level=logging.INFO)\n"
+            "assert _lib.configure_queues() == '6' and os.environ['GPU_MAX_HW_QUEUES'] == '6'\n"
+            "os.environ['GPU_MAX_HW_QUEUES'] = '5'\nassert _lib.configure_queues(8) == '5'\nprint('ok')\n" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0 and "ok" in p.stdout, p.stderr[-1500:]
+    assert "GPU_MAX_HW_QUEUES=6 set for this process" in p.stderr

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.noisy]   # (noisy: beside a background load by default, tests/conftest.py)
 DEV = "cuda:0"
 
 

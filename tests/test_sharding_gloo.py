@@ -190,3 +190,41 @@ def test_sharded_trainer_two_ranks_matches_single_process():
             assert np.allclose(post[f][0], ref_post[f][0], rtol=1e-10, atol=1e-12)
             assert np.allclose(post[f][1], ref_post[f][1], rtol=1e-10, atol=1e-12)
     assert sorted(owned[0] + owned[1]) == [0, 1, 2, 3] and owned[0] and owned[1]
+
+
+def _worker_nccl_one_rank(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        g = dict(np.load(GOLDEN))
+        F = int(g["F"])
+        blocks = [dict(X=g[f"X{f}"], Y=g[f"Y{f}"], length_scales=g[f"length_scales{f}"],
+                       signal_variance=g[f"signal_variance{f}"], log_beta=g[f"log_beta{f}"]) for f in range(F)]
+        vec, total = sharding.joint_ll(blocks)                 # F-vector on the GPU, all-reduced by RCCL (1 rank)
+        assert vec.is_cuda and dist.get_backend() == "nccl"
+        trace, post, owned = _trainer_run(steps=2)             # ShardedTrainer.step's all-reduce + gather_posteriors' all-gather
+        q.put((vec.cpu().tolist(), total, trace, owned))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_joint_ll_and_trainer_one_rank_nccl_group_run_rccl():
+    """`sharding.joint_ll` / `ShardedTrainer` with a 1-rank `nccl` process group on the 1-GPU box -- the
+    collectives go through RCCL (reference site they replace: MFGP_ver2023May/ResGP.py:232-246), values as the fixture's"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_nccl_one_rank, args=(_free_port(), q))
+    p.start()
+    vec, total, trace, owned = q.get(timeout=240)
+    p.join(60)
+    assert p.exitcode == 0
+    g = dict(np.load(GOLDEN))
+    F = int(g["F"])
+    assert np.allclose(vec, [float(g[f"ll{f}"]) for f in range(F)], rtol=1e-9, atol=0.0)
+    assert abs(total - float(g["ll_sum"])) < 1e-9 * abs(float(g["ll_sum"]))
+    assert owned == [0, 1, 2, 3] and len(trace) == 2 and np.isfinite(trace).all()

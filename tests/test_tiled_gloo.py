@@ -135,3 +135,49 @@ def test_tiled_cholesky_hip_ops_single_rank_matches_fused_path():
 def test_tiled_cholesky_hip_ops_two_gloo_ranks_share_the_gpu():
     """two ranks (gloo, host-staged broadcasts) running the HIP operations on the box's one GPU reproduce dense LAPACK"""
     _check(_run(2, 1000, _NB, use_hip=True), 1000, 2)
+
+
+def _worker_nccl_one_rank(port, out):
+    """a ONE-rank `nccl` process group on the box's GPU: every collective of the tiled factorisation (asynchronous panel broadcast,
+    reduce-to-owner of the substitution's partial sums, status MIN / value SUM all-reduces) goes through RCCL"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from fidelityfusion_amd import functional as F
+        from fidelityfusion_amd import tiled
+        from oracle import gp_oracle as O
+        n, D, d = 2500, 5, 3
+        X, Y = O.synthetic_xy(n, D, d, seed=8)
+        Xd, Yd = torch.tensor(X, device=dev), torch.tensor(Y, device=dev)
+        w, amp, dadd = torch.full((D,), 1.1, dtype=torch.float64, device=dev), torch.tensor([0.9], dtype=torch.float64, device=dev), 0.4
+        ref = float(F.nlml(Xd, Yd, w, amp, diag_add=torch.tensor([dadd], dtype=torch.float64, device=dev), clamp=1e-30))
+        tc = tiled.TiledCholesky(n, nb=512, ops=tiled.HipOps(dev))
+        assert tc.comm and tc.comm_dev.type == "cuda" and dist.get_backend() == "nccl"
+        tc.assemble(Xd, w, amp, dadd, clamp=1e-30)
+        rc = tc.factor()
+        got = tc.nll_v1(Yd)
+        L = tc.gather_dense_factor()
+        bad = tiled.TiledCholesky(n, nb=512, ops=tiled.HipOps(dev))
+        S = torch.eye(n, dtype=torch.float64)
+        S[1500, 1500] = -1.0
+        rc_bad = bad.load_dense(S).factor()
+        out.put((rc, got, ref, float(L.abs().max()), rc_bad))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_tiled_cholesky_hip_ops_one_rank_nccl_group_runs_rccl():
+    """the RCCL path of tiled.py executes on the 1-GPU box (1-rank communicator): same value as the fused path"""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    p = ctx.Process(target=_worker_nccl_one_rank, args=(_free_port(), q))
+    p.start()
+    p.join(240)
+    assert p.exitcode == 0
+    rc, got, ref, lmax, rc_bad = q.get()
+    assert rc == 0 and abs(got - ref) <= 1e-11 * abs(ref) and lmax > 0
+    assert rc_bad == 1501

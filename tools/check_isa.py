@@ -1,0 +1,53 @@
+"""Build-time checks on the generated gfx950 ISA (no GPU needed: hipcc cross-compiles).
+
+check_chase_publish(): in `sb2st_chase` every store of a sweep's progress counter must be preceded by an explicit
+`s_waitcnt vmcnt(0)` with no vector-memory instruction in between -- the band stores of the step are write-through (sc1)
+stores of the same wave and have to be complete before the counter a wave on another XCD polls moves (a workgroup-scope
+release fence compiles to `lgkmcnt(0)` only).  Used by tests/test_isa_checks.py; `python tools/check_isa.py` prints the result.
+"""
+import os
+import re
+import subprocess
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "fidelityfusion_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def device_asm(src, extra=()):
+    """gfx950 assembly text of one translation unit of the library."""
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only",
+                               "-Wno-unused-value", "-Wno-unused-result", "-Wno-unused-command-line-argument", *extra,
+                               "-o", out, os.path.join(CSRC, src)])
+        return open(out).read()
+
+
+def function_body(asm, mangled_substr):
+    """Instruction lines of the first function whose label contains `mangled_substr`."""
+    lines = asm.splitlines()
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*%s\w*:" % re.escape(mangled_substr), l))
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    return lines[start:end + 1]
+
+
+def check_chase_publish(asm=None):
+    body = function_body(asm or device_asm("sb2st.hip"), "sb2st_chase")
+    waits = [i for i, l in enumerate(body) if l.strip() == "s_waitcnt vmcnt(0)" and i > 0 and "ASMSTART" in body[i - 1]]
+    found = []
+    for w in waits:
+        for j in range(w + 1, min(w + 40, len(body))):
+            ins = body[j].strip()
+            if re.match(r"global_store_dword\s+v\d+, v\d+, s\[\d+:\d+\] sc1", ins):
+                found.append((w, j))
+                break
+            if re.match(r"(global|buffer|flat)_(load|store|atomic)", ins):
+                raise AssertionError("vector-memory instruction between the drain and the counter store: " + ins)
+    assert len(found) >= 2, "expected a drained counter store per step and one at the end of a sweep, found %d" % len(found)
+    return found
+
+
+if __name__ == "__main__":
+    print("sb2st_chase: counter stores behind an explicit vmcnt(0):", check_chase_publish())
