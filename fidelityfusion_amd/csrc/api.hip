@@ -193,7 +193,7 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->la_min_n = 3584;
   h->aux_prio = 1;
   h->nb_outer = 512;
-  h->diag_v2 = 1;
+  h->diag_v2 = 4;
   h->trtri_overlap = 1;
   h->trtri_fill = 0;
   h->raw_graph_max_n = 0;

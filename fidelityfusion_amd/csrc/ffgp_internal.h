@@ -126,7 +126,7 @@ struct ffgp_handle {
   int small_tile_threshold;  // launches with fewer 128-tiles than this use the 64-tile
   int tile32_threshold;      // K-major launches with fewer 64-tiles than this use 32-row tiles
   int diag_dbg;         // timing-only ablation mask of potrf_diag128 (0 in production)
-  int diag_v2;          // 0 = barrier version of the diagonal-block kernel, 1 = pipelined (default), 2 = pipelined, helper waves off wave 0's SIMD
+  int diag_v2;          // diagonal-block kernel: 4 = round-4 kernel (default: owner-computes helpers, wave 0's SIMD partner steps aside), 1 = round-3 pipeline with the DP-ALU DPP pivot step, 3 = round-3 pipeline as it was, 0 = barrier version
   int la_split;         // 1 = issue the look-ahead part of the trailing update in two launches (first 128 columns first)
   int lookahead;        // 1 = overlap panel k+1 with the trailing update of step k
   int la_min_n;         // blocks up to this size are factored in order (no side stream): below ~3500 the event hand-offs of the

@@ -15,6 +15,7 @@
 // global index (first failure wins) and the factorisation continues with a unit pivot so that no NaN/Inf
 // propagates into later kernels' control flow.
 #include "ffgp_internal.h"
+#include "f16_steps.h"
 
 #define NB FFGP_NB
 // LDS image of the 128x128 diagonal block: only the 36 lower 16x16 blocks, each [16][17] doubles (the pad makes
@@ -31,30 +32,6 @@
 #define DIAG_WAVES (DIAG_THREADS / 64)
 
 __device__ __forceinline__ int blk_off(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * BLKSZ; }
-
-__device__ __forceinline__ double readlane_d(double x, int l) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_readlane(lo, l);
-  hi = __builtin_amdgcn_readlane(hi, l);
-  return __hiloint2double(hi, lo);
-}
-
-// value of x held by lane (16*(lane>>4) + J): DPP row broadcast inside each row of 16 lanes
-template <int J>
-__device__ __forceinline__ double row_bcast_d(double x) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_mov_dpp(lo, 0x150 + J, 0xf, 0xf, true);   // every lane receives data: no `old` value to seed
-  hi = __builtin_amdgcn_mov_dpp(hi, 0x150 + J, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-
-// value of x held by lane `src` (per-lane source): ds_bpermute
-__device__ __forceinline__ double bperm_d(double x, int src) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_ds_bpermute(src << 2, lo);
-  hi = __builtin_amdgcn_ds_bpermute(src << 2, hi);
-  return __hiloint2double(hi, lo);
-}
 
 __device__ __forceinline__ double rsqrt_nr(double d) {
   double y = __builtin_amdgcn_rsq(d);
@@ -451,7 +428,10 @@ extern "C" int ffgp_debug_set_diag_trace_row(int row) {
 #define D2_TRACE(slot)                                                                          \
   do {                                                                                          \
     if (lane == 0 && ffgp_diag_trace_buf && (ffgp_diag_trace_row < 0 || ffgp_diag_trace_row == row_base))  \
+    {                                                                                           \
       ffgp_diag_trace_buf[(slot)] = wall_clock64();                                             \
+      if ((slot) == 0 || (slot) == 23) ffgp_diag_trace_buf[120 + ((slot) != 0)] = __builtin_readcyclecounter();   /* shader clock */ \
+    }                                                                                           \
   } while (0)
 #else
 #define D2_TRACE(slot)
@@ -471,7 +451,10 @@ __device__ __forceinline__ int d2_ld(const volatile int* p) {
   int v;
   const unsigned off = (unsigned)(uintptr_t)p;          // low half of a generic LDS address = the LDS offset
   asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(off) : "memory");
-  return v;
+  // every lane read the same word: saying so (v_readfirstlane) lets the compiler keep the polling loops, the loop counters compared
+  // with the flags and every branch on them SCALAR -- without it the whole helper section was compiled as divergent control flow
+  // (exec-mask juggling around every task, loop counters in vector registers)
+  return __builtin_amdgcn_readfirstlane(v);
 }
 __device__ __forceinline__ void d2_st(volatile int* p, int v) {
   const unsigned off = (unsigned)(uintptr_t)p;
@@ -492,44 +475,7 @@ __device__ __forceinline__ bool d2_wait_ge(volatile int* p, int target, volatile
   return true;
 }
 
-// one pivot of the pipelined in-register factor (see the header comment).  lane (g = lane>>4, c = lane&15) holds rows
-// g+4r of column c of the symmetric block (v) and of the eliminated identity (w); rowA / rowW = current row J of both.
-template <int J>
-__device__ __forceinline__ void f16_step(double (&v)[4], double (&w)[4], double& rowA, double& rowW, int c, int g) {
-  double preA = 0.0, preW = 0.0;
-  if constexpr (J < 15) {   // row J+1 as it stands BEFORE this pivot's update; patched below
-    constexpr int PR1 = (J + 1) >> 2, G1 = (J + 1) & 3;
-    preA = bperm_d(v[PR1], 16 * G1 + c);
-    preW = bperm_d(w[PR1], 16 * G1 + c);
-  }
-  const double d = row_bcast_d<J>(rowA);                     // A[J][J]  (checked for positivity after the 16 steps)
-  const double y0 = __builtin_amdgcn_rcp(d);
-  const double e = __builtin_fma(-d, y0, 1.0);
-  const double f = __builtin_fma(e, e, e);                   // 1/d = y0 (1 + e + e^2)
-  const double u = rowA * y0;
-  const double t = __builtin_fma(u, f, u);                   // A[J][c] / d
-  const double uw = rowW * y0;
-  const double tw = __builtin_fma(uw, f, uw);                // W[J][c] / d
-  // registers whose four rows (g + 4r, g = 0..3) are all <= J hold finished rows: neither block is updated there
-  constexpr int RMIN = (J + 1) >> 2;
-  double colj[4];
-#pragma unroll
-  for (int r = RMIN; r < 4; ++r) colj[r] = row_bcast_d<J>(v[r]);   // A[g+4r][J]
-  if constexpr (J < 15) {
-    const double s = row_bcast_d<(J + 1) & 15>(rowA);        // A[J][J+1] = A[J+1][J]
-    rowA = __builtin_fma(-s, t, preA);
-    rowW = __builtin_fma(-s, tw, preW);
-  }
-  const double tm = (c > J) ? t : 0.0;                       // columns <= J are parked: they keep the unscaled L column
-#pragma unroll
-  for (int r = RMIN; r < 4; ++r) v[r] = __builtin_fma(-colj[r], tm, v[r]);
-  constexpr int PR = J >> 2;
-  if constexpr (PR >= RMIN) colj[PR] = (g == (J & 3)) ? 0.0 : colj[PR];   // the pivot row of W stays
-#pragma unroll
-  for (int r = RMIN; r < 4; ++r) w[r] = __builtin_fma(-colj[r], tw, w[r]);
-}
-
-template <int NW>
+template <int NW, bool DPP64>
 __global__ __launch_bounds__(NW * 64, NW / 2) void ffgp_potrf_diag128_v2(double* __restrict__ A, int lda, int nb, double* __restrict__ Dinv,
                                                                  int* info, int row_base, int prio) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -612,22 +558,20 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void ffgp_potrf_diag128_v2(double*
       for (int r = 0; r < 4; ++r) w[r] = (gg + 4 * r == cc) ? 1.0 : 0.0;
       double rowA = bperm_d(v[0], cc);           // row 0: lanes (0, c)
       double rowW = (cc == 0) ? 1.0 : 0.0;
-      f16_step<0>(v, w, rowA, rowW, cc, gg);
-      f16_step<1>(v, w, rowA, rowW, cc, gg);
-      f16_step<2>(v, w, rowA, rowW, cc, gg);
-      f16_step<3>(v, w, rowA, rowW, cc, gg);
-      f16_step<4>(v, w, rowA, rowW, cc, gg);
-      f16_step<5>(v, w, rowA, rowW, cc, gg);
-      f16_step<6>(v, w, rowA, rowW, cc, gg);
-      f16_step<7>(v, w, rowA, rowW, cc, gg);
-      f16_step<8>(v, w, rowA, rowW, cc, gg);
-      f16_step<9>(v, w, rowA, rowW, cc, gg);
-      f16_step<10>(v, w, rowA, rowW, cc, gg);
-      f16_step<11>(v, w, rowA, rowW, cc, gg);
-      f16_step<12>(v, w, rowA, rowW, cc, gg);
-      f16_step<13>(v, w, rowA, rowW, cc, gg);
-      f16_step<14>(v, w, rowA, rowW, cc, gg);
-      f16_step<15>(v, w, rowA, rowW, cc, gg);
+      if constexpr (DPP64) {
+        double hA = bperm_d(v[0], 16 + cc), hW = (cc == 1) ? 1.0 : 0.0;    // row 1 (lanes (1, c), register 0), one step ahead at the start only
+        double pRow = 0.0, pt = 0.0, ptw = 0.0;
+        double dcur = row_bcast64<0>(rowA), ycur = __builtin_amdgcn_rcp(dcur);
+#define F16_S(JJ) f16_step_dpp<JJ>(v, w, rowA, rowW, hA, hW, pRow, pt, ptw, dcur, ycur, cc, gg);
+        F16_S(0) F16_S(1) F16_S(2) F16_S(3) F16_S(4) F16_S(5) F16_S(6) F16_S(7) F16_S(8) F16_S(9) F16_S(10) F16_S(11) F16_S(12) F16_S(13)
+        F16_S(14) F16_S(15)
+#undef F16_S
+      } else {
+#define F16_S(JJ) f16_step<JJ>(v, w, rowA, rowW, cc, gg);
+        F16_S(0) F16_S(1) F16_S(2) F16_S(3) F16_S(4) F16_S(5) F16_S(6) F16_S(7) F16_S(8) F16_S(9) F16_S(10) F16_S(11) F16_S(12) F16_S(13)
+        F16_S(14) F16_S(15)
+#undef F16_S
+      }
       // operands of G(jj) that do not depend on this block's result are fetched now, under the post-processing below:
       // the helpers' updates of iteration jj-1 must have landed in S[jj+1][jj] and S[jj+1][jj+1]
       double sb[4];
@@ -776,6 +720,440 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void ffgp_potrf_diag128_v2(double*
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// potrf_diag128_v3 (round 4): the same chain, with the helpers reorganised around what tools/native/f16_probe.hip measured.
+//
+//  * fp64 MFMAs and fp64 vector instructions share a SIMD's double-precision pipe: ONE MFMA-streaming wave on wave 0's own SIMD
+//    takes the pivot loop from 148 to 270-280 cycles per pivot (s_setprio does not help: an issued 64-cycle MFMA is not
+//    pre-empted); six streaming waves on the three OTHER SIMDs cost nothing (150).  An 8-wave workgroup puts two waves on each
+//    SIMD, so the wave that shares wave 0's SIMD (found by HW_ID.SIMD_ID, not assumed) takes no part in the arithmetic: it leaves
+//    at once.  Six helpers remain.
+//  * No load phase and no workgroup barrier after the role hand-out: wave 0 reads its first diagonal block straight from global
+//    memory into the factor's register layout and starts; every other 16 x 16 block has an OWNER wave (column-major round
+//    robin) that loads it from global memory, keeps its running value in the block's LDS home as a REGISTER IMAGE of the
+//    transposed block (lane (g, c), register r = S[c][g + 4r]: exactly the B operand of the triangular solve and of wave 0's
+//    G, so no product ever needs a layout change), applies every update of that block itself, in order -- right-looking:
+//    column s of L updates all later columns as soon as it exists -- and finally solves it (or hands it to wave 0).  No two
+//    waves ever write the same block, so there are no barriers: a bit per block says "L[i][k] is final" (rows[k], bit i), two counters
+//    hand wave 0 its next operands (hs, hd).  The round-3 kernel ran left-looking with one column of look-ahead and two
+//    7-wave counter barriers per iteration: its helpers needed 3.0-3.3 us per iteration in the middle of the block, more than
+//    wave 0's 2.6 -- the chain waited for them.
+//  * The inverse's row block s, X[s][j] = -inv(L_s) sum_k L[s][k] X[k][j], overwrites row s of L in place; every helper counts
+//    itself in (cntA[s]) once it has finished reading that row, and a row block is stored only when all six have.
+// Stage s of a helper (s = 0 .. 7), after seqF >= s + 1 (inv(L_s) is in LDS):
+//    (1) L[i][s]^T = inv(L_s) S[i][s]^T for its blocks of column s, i >= s + 2 (row s + 1 is wave 0's G)            -> rows[s] bit i
+//    (2) S[i][k]^T -= L[k][s] L[i][s]^T for its blocks with k > s (column s + 1 first); a block whose updates are complete and
+//        that wave 0 needs next is announced: (s + 2, s + 1) -> hs, the diagonal block (s + 2, s + 2) -> hd
+//    (3) its columns of the inverse's row block s
+// ------------------------------------------------------------------------------------------------------------
+struct D3Flags {      // ints in LDS, behind the block image
+  int seqF, h2, hs, hd, abort, roles, pad0[2];
+  int simd[8];
+  int cntA[8];
+  int rows[8];        // rows[s]: bit i = L[i][s] is final and in LDS (bit s + 1 is set by wave 0's G(s), the others by the blocks' owners)
+};
+
+#define D3_NH 6
+// The helpers' work as a STATIC task list per helper (the block structure is fixed, so is the schedule).  A first version walked
+// nested loops over (stage, pass, owned block) with the ownership tests inline: on this machine a not-taken scalar branch costs as
+// much as four vector instructions, and a stage with nothing to do took 2.5 us of pure control flow.  Now lane t of a helper holds
+// descriptor t of its list (one load at the start), v_readlane fetches the next one, and one switch dispatches it.
+//   descriptor: bits 1:0 type, 4:2 i, 7:5 k, 9:8 flag to raise (0 none, 1 hs, 2 hd, 3 h2), 12:10 stage s, 15:13 first column p0 of an
+//   update (it applies columns p0 .. s); 0xffff ends the list
+// Ownership: block t of the column-major enumeration (k = 0..7, i = k..7, without (0, 0)) belongs to helper t % 6.
+// WHEN a block receives column p.  Right-looking (at stage p, the moment column p exists) puts 28 + 21 + 15 of the 77 updates into the
+// first three stages, where the helpers then lag behind wave 0; left-looking (everything at stage k - 1) starves them early and
+// makes the last stages long.  In between: block (i, k) takes column p at stage max(p, k - 3) -- the two columns wave 0 needs next
+// stay current, column s + 3 catches up on columns 0 .. s in ONE task (one read and one write of the image, 4 (s + 1) products),
+// later columns wait: 18, 19, 18, 15, 10, 3, 1 block visits per stage instead of 28, 21, 15, 10, 6, 3, 1.
+// Order inside a stage s (what wave 0's G(s + 1) waits for comes first -- it needs (s + 2, s + 1), (s + 2, s + 2) and (s + 3, s + 1)
+// with column s applied): STAGE (wait for inv(L_s)); the solve of (s + 3, s), the one operand of those three that wave 0 does not
+// produce itself; those three updates; the other solves of column s; the other updates, next column first; the inverse's row s.
+enum { D3_STAGE = 0, D3_TRSM = 1, D3_UPDATE = 2, D3_INVERSE = 3, D3_END = 0xffff, D3_MAXTASKS = 64 };
+struct D3TaskTable { unsigned short t[D3_NH][D3_MAXTASKS]; };
+constexpr int d3_owner(int i, int k) { return (k == 0 ? i - 1 : 8 * k - 1 - k * (k - 1) / 2 + (i - k)) % D3_NH; }
+constexpr unsigned short d3_desc(int type, int i, int k, int flag, int s, int p0 = 0) {
+  return (unsigned short)(type | (i << 2) | (k << 5) | (flag << 8) | (s << 10) | (p0 << 13));
+}
+constexpr int d3_flag_of(int i, int k, int s) {      // which of wave 0's next operands block (i, k) is once column s is applied
+  return (k == s + 1 && i == s + 2) ? 1 : (k == s + 2 && i == k) ? 2 : (k == s + 1 && i == s + 3) ? 3 : 0;
+}
+constexpr D3TaskTable d3_make_tasks() {
+  D3TaskTable T{};
+  for (int h = 0; h < D3_NH; ++h) {
+    int n = 0;
+    for (int s = 0; s < 8; ++s) {
+      T.t[h][n++] = d3_desc(D3_STAGE, 0, 0, 0, s);
+      if (s + 3 < 8 && d3_owner(s + 3, s) == h) T.t[h][n++] = d3_desc(D3_TRSM, s + 3, s, 0, s);
+      for (int pass = 0; pass < 2; ++pass) {            // pass 0: the three urgent updates; pass 1: the other solves, the other updates
+        if (pass == 1)
+          for (int i = s + 4; i < 8; ++i)
+            if (d3_owner(i, s) == h) T.t[h][n++] = d3_desc(D3_TRSM, i, s, 0, s);
+        for (int k = s + 1; k < 8 && k <= s + 3; ++k)
+          for (int i = k; i < 8; ++i) {
+            if (d3_owner(i, k) != h || (i == k && k == s + 1)) continue;      // (the diagonal block of column s + 1 is wave 0's)
+            const int fl = d3_flag_of(i, k, s);
+            if ((fl != 0) == (pass == 0)) T.t[h][n++] = d3_desc(D3_UPDATE, i, k, fl, s, (k == s + 3) ? 0 : s);
+          }
+      }
+      if (s >= 1) T.t[h][n++] = d3_desc(D3_INVERSE, 0, 0, 0, s);
+    }
+    for (; n < D3_MAXTASKS; ++n) T.t[h][n] = (unsigned short)D3_END;
+  }
+  return T;
+}
+__device__ const D3TaskTable D3_TASKS = d3_make_tasks();
+
+// LDS read-modify-write on a flag word, as explicit DS instructions (a generic-pointer atomic compiles to flat_atomic_*)
+__device__ __forceinline__ void d3_or(volatile int* p, int v) {
+  const unsigned off = (unsigned)(uintptr_t)p;
+  asm volatile("ds_or_b32 %0, %1" : : "v"(off), "v"(v) : "memory");
+}
+__device__ __forceinline__ void d3_add(volatile int* p, int v) {
+  const unsigned off = (unsigned)(uintptr_t)p;
+  asm volatile("ds_add_u32 %0, %1" : : "v"(off), "v"(v) : "memory");
+}
+
+#define D3_IMG(bi, bj) (S + blk_off(bi, bj))     /* the block's home: register image [r][lane] while it accumulates, [16][17] once it is L */
+
+__device__ __forceinline__ int d3_simd_id() {
+  return (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3;     // HW_REG_HW_ID (4), SIMD_ID = bits 5:4
+}
+
+// element (r, cc) of the symmetric block (bi, bj) of A as the factor sees it: lower triangle of A, identity beyond nb
+__device__ __forceinline__ double d3_elem(const double* __restrict__ A, int lda, int nb, int r, int cc) {
+  const int hi = max(r, cc), lo = min(r, cc);
+  if (hi >= nb) return (r == cc) ? 1.0 : 0.0;
+  return A[(size_t)hi * lda + lo];
+}
+
+// stores acc = L[i][s]^T (lane (g, c), register r = L[i][s][c][g + 4r]) into the block's LDS home as L[i][s] and into A
+__device__ __forceinline__ void d3_store_LT(double* home, double* __restrict__ A, int lda, int nb, int i, int s, const d4_t& acc, int g, int c) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) home[c * BLD + g + 4 * r] = acc[r];
+  const int gr = i * 16 + c;
+  if (gr < nb) {
+    double* dst = A + (size_t)gr * lda + s * 16 + g;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[4 * r] = acc[r];
+  }
+}
+
+// the transposed register image of block (i, k) of A straight from global memory: lane (g, c), register r = S[c][g + 4r]
+__device__ __forceinline__ void d3_load_image(double (&x)[4], const double* __restrict__ A, int lda, int nb, int i, int k, int g, int c) {
+  const int rr = i * 16 + c;
+  if (i == k) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = d3_elem(A, lda, nb, rr, k * 16 + g + 4 * r);      // mirrored from the lower triangle
+  } else {
+    const double* src = A + (size_t)min(rr, nb - 1) * lda + k * 16 + g;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = (rr < nb) ? src[4 * r] : 0.0;
+  }
+}
+
+// row block s of the inverse, columns hidx and hidx + 6, from registers into the LDS homes of row s of L and into the Dinv store
+__device__ __forceinline__ void d3_store_inverse_rows(double* S, double* __restrict__ Dinv, const double (&Xn)[2][4], int s, int hidx, int g, int c) {
+#pragma unroll
+  for (int q2 = 0; q2 < 2; ++q2) {
+    const int j = hidx + q2 * D3_NH;
+    if (j >= s) continue;
+    double* dst = S + blk_off(s, j);
+    double* gd = Dinv + (size_t)(s * 16 + g) * NB + j * 16 + c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      dst[(g + 4 * r) * BLD + c] = Xn[q2][r];
+      gd[(size_t)4 * r * NB] = Xn[q2][r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 4) void ffgp_potrf_diag128_v3(double* __restrict__ A, int lda, int nb, double* __restrict__ Dinv,
+                                                                int* info, int row_base, int prio) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* S = lds;
+  volatile D3Flags* fl = reinterpret_cast<volatile D3Flags*>(lds + NBLK_LOWER * BLKSZ);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (uniform: scalar control flow)
+  const int g = lane >> 4, c = lane & 15;
+  if (wave == 0) D2_TRACE(0);
+  // wave 0's first operands need no update: it fetches them itself, straight into the registers of F(0) and G(0), and the loads fly
+  // while the roles are handed out
+  double v[4], sb[4], sb2[4];
+  d4_t D;
+  if (wave == 0) {
+    double x[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = d3_elem(A, lda, nb, g + 4 * r, c);
+    d3_load_image(sb, A, lda, nb, 1, 0, g, c);
+    d3_load_image(sb2, A, lda, nb, 2, 0, g, c);
+    d3_load_image(x, A, lda, nb, 1, 1, g, c);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) D[r] = x[r];
+  }
+  // ---- roles: every wave publishes its SIMD; one barrier; the wave that shares wave 0's SIMD steps aside
+  if (tid < (int)(sizeof(D3Flags) / sizeof(int))) d2_st(reinterpret_cast<volatile int*>(fl) + tid, 0);
+  __syncthreads();
+  if (lane == 0) d2_st(&fl->simd[wave], d3_simd_id());
+  __syncthreads();
+  int partner = 4;
+  {
+    int mine;      // lane l < 8 looks at wave l's SIMD: one LDS read for the whole search
+    const unsigned off = (unsigned)(uintptr_t)&fl->simd[lane & 7];
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(mine) : "v"(off) : "memory");
+    const int s0 = __builtin_amdgcn_readfirstlane(mine);
+    const unsigned long long same = __ballot(mine == s0 && lane >= 1 && lane < 8);
+    if (same) partner = __ffsll((long long)same) - 1;
+  }
+  volatile int* ab = &fl->abort;
+  if (wave != 0 && wave == partner) return;      // (its SIMD now belongs to the pivot chain alone)
+  const int hidx = (wave < partner) ? wave - 1 : wave - 2;
+
+  if (wave == 0) {
+    // ================================ the serial chain ================================
+    if (prio) __builtin_amdgcn_s_setprio(3);
+    double w[4];
+    D2_TRACE(1);
+    for (int jj = 0; jj < 8; ++jj) {
+      // ---- F(jj)
+      int cc = c, gg = g;
+      asm volatile("" : "+v"(cc), "+v"(gg));      // (opaque per iteration: see v2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w[r] = (gg + 4 * r == cc) ? 1.0 : 0.0;
+      double rowA = bperm_d(v[0], cc);
+      double rowW = (cc == 0) ? 1.0 : 0.0;
+      {
+        double hA = bperm_d(v[0], 16 + cc), hW = (cc == 1) ? 1.0 : 0.0;
+        double pRow = 0.0, pt = 0.0, ptw = 0.0;
+        double dcur = row_bcast64<0>(rowA), ycur = __builtin_amdgcn_rcp(dcur);
+#define F16_S(JJ) f16_step_dpp<JJ>(v, w, rowA, rowW, hA, hW, pRow, pt, ptw, dcur, ycur, cc, gg);
+        F16_S(0) F16_S(1) F16_S(2) F16_S(3) F16_S(4) F16_S(5) F16_S(6) F16_S(7) F16_S(8) F16_S(9) F16_S(10) F16_S(11) F16_S(12) F16_S(13)
+        F16_S(14) F16_S(15)
+#undef F16_S
+      }
+      D2_TRACE(64 + jj);     // the 16 pivots are done
+      // operands of G(jj), register images left by their owners: requested now, under the post-processing below
+      if (jj >= 1 && jj < 7) {
+        if (!d2_wait_ge(&fl->hs, jj + 1, ab, info) || !d2_wait_ge(&fl->hd, jj + 1, ab, info)) break;
+        if (jj < 6 && !d2_wait_ge(&fl->h2, jj + 1, ab, info)) break;
+        const double* Sb = D3_IMG(jj + 1, jj);
+        const double* Sd = D3_IMG(jj + 1, jj + 1);
+        const double* Sb2 = D3_IMG(min(jj + 2, 7), jj);
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) sb[kq] = Sb[kq * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) D[r] = Sd[r * 64 + lane];
+        if (jj < 6) {
+#pragma unroll
+          for (int kq = 0; kq < 4; ++kq) sb2[kq] = Sb2[kq * 64 + lane];
+        }
+      }
+      D2_TRACE(3 + 3 * jj);
+      const int q = c >> 2;
+      const double dsel = (q == 0) ? v[0] : (q == 1) ? v[1] : (q == 2) ? v[2] : v[3];
+      const double dcol = bperm_d(dsel, 16 * (c & 3) + c);
+      const double rs = rsqrt_nr(dcol);          // 1 / sqrt(pivot of column c)
+      const unsigned long long nonpos = __ballot(!(dcol > 0.0)) & 0xffffull;
+      const int bad = nonpos ? __ffsll((long long)nonpos) : 0;
+      double* Dj = S + blk_off(jj, jj);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = g + 4 * r;
+        const double rsi = bperm_d(rs, i);       // 1 / sqrt(pivot of column i): the row scaling of the inverse
+        const double x = (i >= c) ? w[r] * rsi : 0.0;
+        Dj[i * BLD + c] = x;                                              // inv(L_jj) for the helpers and for G
+        const int gr = jj * 16 + i, gc = jj * 16 + c;
+        if (i >= c) {
+          Dinv[(size_t)gr * NB + gc] = x;
+          if (gr < nb) A[(size_t)gr * lda + gc] = v[r] * rs;              // L_jj
+        }
+      }
+      if (bad && lane == 0 && (jj * 16 + bad) <= nb) atomicCAS(info, 0, row_base + jj * 16 + bad);
+      D2_LDS_FENCE();
+      if (lane == 0) d2_st(&fl->seqF, jj + 1);
+      D2_TRACE(2 + 3 * jj);
+      if (jj == 7) break;
+      // ---- G(jj): the solves of block rows jj + 1 and jj + 2 (both feed the blocks wave 0 needs next, one flag hop away), then
+      // the next diagonal block
+      d4_t Y = {0.0, 0.0, 0.0, 0.0}, Y2 = {0.0, 0.0, 0.0, 0.0};
+      double wa[4];
+      D2_TRACE(72 + jj);
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) wa[kq] = Dj[c * BLD + kq * 4 + g];
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[kq], sb[kq], Y, 0, 0, 0);
+      if (jj < 6) {
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) Y2 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[kq], sb2[kq], Y2, 0, 0, 0);
+      }
+      {   // L[jj+1][jj] = Y^T (its image sits in sb), L[jj+2][jj] = Y2^T: to LDS and announced first -- the helpers' next hop
+        double* h1 = S + blk_off(jj + 1, jj);
+        double* h2 = S + blk_off(min(jj + 2, 7), jj);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h1[c * BLD + g + 4 * r] = Y[r];
+        if (jj < 6) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h2[c * BLD + g + 4 * r] = Y2[r];
+        }
+      }
+      D2_LDS_FENCE();
+      if (lane == 0) d3_or(&fl->rows[jj], (jj < 6) ? (3 << (jj + 1)) : (1 << (jj + 1)));
+      D2_TRACE(80 + jj);     // rows jj + 1, jj + 2 of column jj announced
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) D = __builtin_amdgcn_mfma_f64_16x16x4f64(Y[kq], Y[kq], D, 0, 0, 1);   // D -= Y^T Y
+      {   // ... and to global memory while those products run
+        const int gr = (jj + 1) * 16 + c;
+        if (gr < nb) {
+          double* dst = A + (size_t)gr * lda + jj * 16 + g;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[4 * r] = Y[r];
+        }
+        if (jj < 6 && gr + 16 < nb) {
+          double* dst = A + (size_t)(gr + 16) * lda + jj * 16 + g;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[4 * r] = Y2[r];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = D[r];
+      D2_TRACE(4 + 3 * jj);
+    }
+    return;
+  }
+
+  // ================================ helpers ================================
+  // ---- prologue: the owned blocks come from global memory as transposed register images, all loads in flight at once
+  // (one block after the other was one memory round trip each: 6.5 us before the first stage).  (1, 0), (1, 1), (2, 0) are wave 0's.
+  {
+    double x[6][4];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int t = hidx + u * D3_NH;                  // enumeration index -> (i, k)
+      int k = 0, i = t + 1;
+#pragma unroll
+      for (int kk = 1; kk < 8; ++kk) {
+        const int t0 = 8 * kk - 1 - kk * (kk - 1) / 2;
+        if (t >= t0) { k = kk; i = kk + (t - t0); }
+      }
+      if (t > 34 || (k == 0 && i <= 2) || (k == 1 && i == 1)) continue;
+      d3_load_image(x[u], A, lda, nb, i, k, g, c);
+    }
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      const int t = hidx + u * D3_NH;
+      int k = 0, i = t + 1;
+#pragma unroll
+      for (int kk = 1; kk < 8; ++kk) {
+        const int t0 = 8 * kk - 1 - kk * (kk - 1) / 2;
+        if (t >= t0) { k = kk; i = kk + (t - t0); }
+      }
+      if (t > 34 || (k == 0 && i <= 2) || (k == 1 && i == 1)) continue;
+      double* img = D3_IMG(i, k);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) img[r * 64 + lane] = x[u][r];
+    }
+    D2_LDS_FENCE();
+  }
+  if (hidx == 0) D2_TRACE(31);
+  const int my_desc = D3_TASKS.t[hidx][lane];  // lane t holds descriptor t of this helper's list
+  double Xn[2][4];                             // the row block of the inverse computed in a stage, stored once row s of L is dead
+  const double* Ws = S;                        // inv(L_s)
+  volatile int* rows = &fl->rows[0];           // rows[s], bit i: L[i][s] is final and in LDS
+  int seen = 0;                                // lane p: the bits of rows[p] this wave has seen set (one poll serves every later task)
+#pragma unroll 1
+  for (int t = 0; t < D3_MAXTASKS; ++t) {
+    const int desc = __builtin_amdgcn_readlane(my_desc, t);
+    if (desc == D3_END) break;
+    const int type = desc & 3, i = (desc >> 2) & 7, k = (desc >> 5) & 7, flag = (desc >> 8) & 3, s = (desc >> 10) & 7;
+    if (type == D3_STAGE) {
+      if (hidx == 0 && s >= 1) D2_TRACE(31 + 4 * s);          // (slot 35 + 4 (s - 1): the previous stage is complete)
+      if (!d2_wait_ge(&fl->seqF, s + 1, ab, info)) return;
+      if (hidx == 0) D2_TRACE(32 + 4 * s);
+      Ws = S + blk_off(s, s);
+      rows = &fl->rows[s];
+    } else if (type == D3_TRSM) {
+      // ---- triangular solve of an owned block of column s (its updates were completed in the earlier stages)
+      double* home = D3_IMG(i, s);
+      double b[4];
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) b[kq] = home[kq * 64 + lane];
+      d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[c * BLD + kq * 4 + g], b[kq], acc, 0, 0, 0);
+      d3_store_LT(home, A, lda, nb, i, s, acc, g, c);
+      D2_LDS_FENCE();
+      if (lane == 0) d3_or(rows, 1 << i);
+    } else if (type == D3_UPDATE) {
+      // ---- columns p0 .. s of L update a later block this wave owns:  image -= L[k][p] L[i][p]^T  (the transposed update)
+      const int p0 = (desc >> 13) & 7;
+      const int need = (1 << i) | (1 << k);
+      double* img = D3_IMG(i, k);
+      d4_t acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = img[r * 64 + lane];
+#pragma unroll 1
+      for (int p = p0; p <= s; ++p) {
+        // rows i and k of column p must be final: lane p of `seen` remembers what this wave saw of rows[p] (bits only ever get set)
+        int have = __builtin_amdgcn_readlane(seen, p);
+        if ((have & need) != need) {
+          int spins = 0;
+          while (((have = d2_ld(&fl->rows[p])) & need) != need) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 63) == 0 && (spins > (1 << 21) || d2_ld(ab))) {
+              if (!d2_ld(ab)) atomicExch(info, FFGP_DIAG_WATCHDOG);
+              d2_st(ab, 1);
+              return;
+            }
+          }
+          D2_COMPILER_FENCE();
+          seen = (lane == p) ? have : seen;
+        }
+        const double* Lk = S + blk_off(k, p);
+        const double* Li = S + blk_off(i, p);
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lk[c * BLD + kq * 4 + g], Li[c * BLD + kq * 4 + g], acc, 0, 0, 1);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) img[r * 64 + lane] = acc[r];
+      if (flag) {                              // complete as far as its owner is concerned: an operand of G(s + 1)
+        D2_LDS_FENCE();
+        if (lane == 0) d2_st((flag == 1) ? &fl->hs : (flag == 2) ? &fl->hd : &fl->h2, s + 2);
+      }
+    } else {
+      // ---- row block s of the inverse, columns j = hidx and hidx + 6:  X[s][j] = -inv(L_s) T_j,  T_j = sum_{k=j}^{s-1} L[s][k] X[k][j].
+      // It overwrites row s of L in place, so it may only be stored once all six helpers have finished reading that row (cntA[s]):
+      // the values stay in registers for one stage and are stored at the START of the next stage's inverse task -- a helper that
+      // waited here for the slowest one was late for the next column's urgent updates.
+      if (hidx == 0) D2_TRACE(34 + 4 * s);
+      if (s >= 2) {
+        if (!d2_wait_ge(&fl->cntA[s - 1], D3_NH, ab, info)) return;
+        d3_store_inverse_rows(S, Dinv, Xn, s - 1, hidx, g, c);
+        D2_LDS_FENCE();
+      }
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        const int j = hidx + q2 * D3_NH;
+        if (j >= s) continue;
+        d4_t T = {0.0, 0.0, 0.0, 0.0};
+        for (int kk = j; kk < s; ++kk) mma16<false>(T, S + blk_off(s, kk), BLD, S + blk_off(kk, j), BLD, lane);
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[c * BLD + kq * 4 + g], T[kq], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xn[q2][r] = -acc[r];
+      }
+      // every read of row s of L by this wave is behind it (the updates of column s's blocks ran in earlier stages)
+      D2_LDS_FENCE();
+      if (lane == 0) d3_add(&fl->cntA[s], 1);
+      if (s == 7) {                            // the last row block: nothing follows, store it now
+        if (!d2_wait_ge(&fl->cntA[7], D3_NH, ab, info)) return;
+        d3_store_inverse_rows(S, Dinv, Xn, 7, hidx, g, c);
+      }
+    }
+  }
+  if (hidx == 0) D2_TRACE(63);
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // naive reference kernels (debug / on-device cross-check only; selected with option "naive")
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ffgp_potrf_naive(double* A, int lda, int n, int* info) {
@@ -849,12 +1227,26 @@ static int launch_diag(ffgp_handle* h, double* Ablk, int lda, int nb, double* Di
   }
   if (do_factor && h->diag_v2 && !h->diag_dbg) {   // the pipelined kernel (the barrier version keeps the inverse-only entry)
     if (!(h->diag_attr_set & 2)) {
-      FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v2<8>),
+      FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v2<8, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+      FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v2<8, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
       h->diag_attr_set |= 2;
     }
-    hipLaunchKernelGGL(ffgp_potrf_diag128_v2<8>, dim3(1), dim3(512), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk, h->d_info,
-                       row_base, h->aux_prio);
+    if (h->diag_v2 == 4) {   // round 4: owner-computes helpers, wave 0's SIMD partner steps aside
+      if (!(h->diag_attr_set & 4)) {
+        FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v3), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     DIAG_LDS_BYTES));
+        h->diag_attr_set |= 4;
+      }
+      hipLaunchKernelGGL(ffgp_potrf_diag128_v3, dim3(1), dim3(512), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk, h->d_info,
+                         row_base, h->aux_prio);
+    } else if (h->diag_v2 == 3)   // the round-3 pivot step (32-bit DPP moves), kept for A/B runs
+      hipLaunchKernelGGL((ffgp_potrf_diag128_v2<8, false>), dim3(1), dim3(512), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk,
+                         h->d_info, row_base, h->aux_prio);
+    else
+      hipLaunchKernelGGL((ffgp_potrf_diag128_v2<8, true>), dim3(1), dim3(512), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk,
+                         h->d_info, row_base, h->aux_prio);
     return FFGP_OK;
   }
   hipLaunchKernelGGL(ffgp_potrf_diag128, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk,

@@ -260,6 +260,42 @@ def test_potrf_matches_lapack(ff, tile, n):
     assert (up == 777.0).all(), "strictly-upper triangle was written"
 
 
+@pytest.mark.noisy
+@pytest.mark.parametrize("mode", [0, 1, 3, 4])
+def test_potrf_diag_kernel_variants(ff, mode):
+    """the diagonal-block kernel in its four forms -- 0: barrier version, 3: round-3 pipeline, 1: the same with the DP-ALU DPP pivot
+    step (v_mov_b64_dpp / v_fmac_f64_dpp), 4: round-4 kernel (owner-computes helpers, static task lists; the default) -- against
+    LAPACK at sizes with full, partial and single blocks; the factor and the cached block inverses must be bit-stable over repeated
+    calls while a background load shares the GPU (LDS flag protocols, no barrier after the role hand-out)"""
+    import ctypes as C
+    from fidelityfusion_amd import _lib
+    h = _lib.handle(0)
+    assert _lib.lib.ffgp_set_option(h, b"diag_v2", C.c_double(mode)) == 0
+    try:
+        for n in (128, 100, 16, 129, 640, 1000, 1537):
+            rng = np.random.default_rng(10 * n + mode)
+            S = spd(n, rng)
+            ref = np.linalg.cholesky(S)
+            first = None
+            for rep in range(3):
+                rc, out, _, _ = potrf(ff, S)
+                assert rc == 0
+                got = np.tril(out[:n, :n])
+                assert relerr(got, ref) < 1e-11, (mode, n)
+                assert (out[:n, :n][np.triu_indices(n, 1)] == 777.0).all(), "strictly-upper triangle was written"
+                if first is None:
+                    first = got
+                else:
+                    assert (got == first).all(), "factor changed between identical calls (mode %d, n %d)" % (mode, n)
+        # a non-positive pivot inside a diagonal block is reported with its 1-based index by every variant
+        S = spd(300, np.random.default_rng(7))
+        S[200, 200] = -5.0
+        rc, _, _, _ = potrf(ff, S)
+        assert rc == 201, (mode, rc)
+    finally:
+        assert _lib.lib.ffgp_set_option(h, b"diag_v2", C.c_double(4)) == 0
+
+
 @pytest.mark.parametrize("n", [4000, 6200])
 def test_potrf_large_matches_lapack(ff, n):
     """many workgroups per launch, look-ahead stream active: catches cross-workgroup races the small cases cannot"""

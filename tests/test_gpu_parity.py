@@ -803,15 +803,19 @@ def test_small_problems_batched_call():
         Y = T(rng.standard_normal((n, d)), grad=True)
         ys.append([Y, T(np.diag(rng.uniform(0.01, 0.1, n)))] if i % 3 == 1 else Y)
     calls = []
-    real = F.lib.ffgp_nlml_fused_small_batch_async
+    real, real_async = F.lib.ffgp_nlml_fused_small_batch, F.lib.ffgp_nlml_fused_small_batch_async
 
     class _Spy:
         def __getattr__(self, name):
             return getattr(F._lib.lib, name)
 
-        def ffgp_nlml_fused_small_batch_async(self, h, nF, *a):
+        def ffgp_nlml_fused_small_batch(self, h, nF, *a):       # (the default: status at the call)
             calls.append(nF)
             return real(h, nF, *a)
+
+        def ffgp_nlml_fused_small_batch_async(self, h, nF, *a):  # (with functional.DEFER_RAW_ERRORS)
+            calls.append(nF)
+            return real_async(h, nF, *a)
     F.lib, keep = _Spy(), F.lib
     try:
         vals = negative_log_likelihood_many(models, xs, ys)
@@ -832,11 +836,17 @@ def test_small_problems_batched_call():
         for a, b in zip(got[i][1], [p_.grad for p_ in m.parameters()]):
             assert rel(a, b) < 1e-10, i
         assert rel(got[i][2], Yt.grad) < 1e-10, i
-    # a member whose Sigma is not positive definite: reported (from backward, like the single deferred call)
+    # a member whose Sigma is not positive definite: reported at the call (the default), or from backward with DEFER_RAW_ERRORS
     bad_y = [ys[0].detach(), -3.0 * torch.eye(20, device=DEV, dtype=torch.float64)]
-    out = negative_log_likelihood_many(models[:3], xs[:3], [bad_y, ys[1], ys[2]])
     with pytest.raises(torch.linalg.LinAlgError):
-        out.sum().backward()
+        negative_log_likelihood_many(models[:3], xs[:3], [bad_y, ys[1], ys[2]])
+    F.DEFER_RAW_ERRORS = True
+    try:
+        out = negative_log_likelihood_many(models[:3], xs[:3], [bad_y, ys[1], ys[2]])
+        with pytest.raises(torch.linalg.LinAlgError):
+            out.sum().backward()
+    finally:
+        F.DEFER_RAW_ERRORS = False
     # a member that is too large: the individual calls
     big = cigp(kernel.ARDKernel(2), 0.5).double().to(DEV)
     xb, yb = T(rng.uniform(0, 1, (200, 2))), T(rng.standard_normal((200, 1)))

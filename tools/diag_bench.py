@@ -23,6 +23,9 @@ def spd(n, seed=0):
     return torch.exp(-0.5 * d2) + 0.37 * torch.eye(n, device=dev, dtype=torch.float64)
 
 
+FACTORS = {}
+
+
 def run(n, mode, reps):
     _lib.set_option("diag_v2", mode, 0)
     A = spd(n)
@@ -30,6 +33,7 @@ def run(n, mode, reps):
     rc = lib.ffgp_potrf(h, C.c_void_p(W.data_ptr()), n, n)
     assert rc == 0, rc
     L = torch.tril(W)
+    FACTORS[(n, mode)] = L.clone()
     err = float((L @ L.T - A).abs().max())
     best = 1e9
     for _ in range(reps):
@@ -43,8 +47,10 @@ def run(n, mode, reps):
 
 for n in (128, 256, 1024, 4096, 8192, 16384):
     out = []
-    for mode in (0, 1):
+    for mode in (0, 3, 1, 4):   # 0: barrier version, 3: round-3 pipelined kernel, 1: the same with the DP-ALU DPP pivot step, 4: round-4 kernel (default)
         us, err = run(n, mode, 20 if n <= 4096 else 5)
         out.append("v2=%d: %9.1f us (|LL^T-A| %.1e)" % (mode, us, err))
-    print("potrf n=%5d  " % n + "   ".join(out), flush=True)
-_lib.set_option("diag_v2", 1, 0)
+    dmax = float((FACTORS[(n, 4)] - FACTORS[(n, 3)]).abs().max())
+    print("potrf n=%5d  " % n + "   ".join(out) + "   max |L(4) - L(3)| = %.1e" % dmax, flush=True)
+    FACTORS.clear()
+_lib.set_option("diag_v2", 4, 0)

@@ -13,9 +13,11 @@ SO = os.path.join(ROOT, "fidelityfusion_amd", "libffgp_dtrace.so")
 
 
 def build():
-    srcs = [os.path.join(CSRC, f) for f in "gemm.hip potrf.hip assemble.hip pair.hip solve.hip grad.hip join.hip eig.hip api.hip".split()]
+    import re
+    names = re.search(r"^SRCS = (.*)$", open(os.path.join(CSRC, "Makefile")).read(), re.M).group(1).split()   # the library's own list
+    srcs = [os.path.join(CSRC, f) for f in names]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DFFGP_DIAG_TRACE", "-shared",
-                           "-Wno-unused-value", "-Wno-unused-result", "-o", SO] + srcs)
+                           "-Wno-unused-value", "-Wno-unused-result", "-o", SO] + srcs + ["-ldl"])
 
 
 if __name__ == "__main__":
@@ -45,11 +47,26 @@ if __name__ == "__main__":
         torch.cuda.synchronize()
         t = buf.cpu().numpy().astype("float64") / 100.0     # us
     t0 = t[0]
+    raw = buf.cpu().numpy()
+    if raw[121] > raw[120] and t[23] > t[0]:
+        print("shader clock during the kernel: %.0f MHz" % ((raw[121] - raw[120]) / (t[23] - t[0])))
     print("wave 0 : start 0.00 | load+roles %.2f" % (t[1] - t0))
     for jj in range(8):
         f, w_, g_ = t[2 + 3 * jj] - t0, t[3 + 3 * jj] - t0, t[4 + 3 * jj] - t0
         print("  jj=%d  F done %.2f   doneU seen %.2f   G done %.2f" % (jj, f, w_ if jj < 7 else float("nan"), g_ if jj < 7 else float("nan")))
+    if mode == 4:
+        print("helper0: prologue (blocks loaded) %.2f" % (t[31] - t0))
+    if mode == 4:
+        print("wave 0, round-4 stamps: pivots done | operands seen | seqF set | G starts | rows announced | G done")
+        for jj in range(8):
+            print("  jj=%d  %6.2f %6.2f %6.2f %6.2f %6.2f %6.2f" % (jj, t[64 + jj] - t0, t[3 + 3 * jj] - t0, t[2 + 3 * jj] - t0, t[72 + jj] - t0 if jj < 7 else float("nan"),
+                                                                  t[80 + jj] - t0 if jj < 7 else float("nan"), t[4 + 3 * jj] - t0 if jj < 7 else float("nan")))
     print("helper0:")
+    if mode == 4:        # round-4 kernel: stage entered, (urgent work ...) inverse row started, stage complete
+        for jj in range(8):
+            a, c_, d = t[32 + 4 * jj] - t0, t[34 + 4 * jj] - t0, t[35 + 4 * jj] - t0
+            print("  s=%d  inv(L_s) seen %.2f   solves + updates done %.2f   inverse row done %.2f" % (jj, a, c_ if jj >= 1 else float("nan"), d))
+        sys.exit(0)
     for jj in range(8):
         a, b, c_, d = (t[32 + 4 * jj + k] - t0 for k in range(4))
         print("  jj=%d  seqF seen %.2f   A1/A2 done %.2f   B1/B2 done %.2f   B3 done %.2f" % (jj, a, b, c_ if jj < 7 else float("nan"), d if jj < 7 else float("nan")))
