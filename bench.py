@@ -76,6 +76,8 @@ def parse_args(argv=None):
     ap.add_argument("--dry", action="store_true", help="CPU plumbing run (needs --backend gloo): no GPU work")
     ap.add_argument("--slots", type=int, default=2, help="blocks of one rank that overlap on its GPU (fixed-F workloads)")
     ap.add_argument("--slot-lookahead", action="store_true", help="keep every overlapped block's own look-ahead side stream")
+    ap.add_argument("--no-chain-batch", action="store_true", help="fixed-F workloads: overlap a rank's blocks through streams "
+                    "(functional.concurrent_blocks) instead of sharing ONE factorisation chain (functional.nlml_many)")
     ap.add_argument("--hogp-slots", type=int, default=4, help="host threads that drive the HOGP blocks of one rank (gar8_hogp): "
                     "1 = one block after another (2.46 s/step), 2: 1.87, 3: 1.66, 4: 1.54, 8: 1.58 s/step on one MI355X (sweep taken with 8 hardware queues; the default of 6 measures the same)")
     ap.add_argument("--opt", action="append", default=[], help="library option key=value (development A/B runs)")
@@ -494,6 +496,13 @@ def run_rank(args):
             if len(mine) == 1:
                 f = mine[0]
                 vals[f] = F.nlml(data[f][0], data[f][1], w, amp, diag_add=dadd, clamp=1e-30)
+            elif mine and not args.no_chain_batch:   # the rank's blocks have one shape: ONE factorisation chain for all of them
+                ctx = torch.enable_grad() if args.with_grad else torch.no_grad()
+                with ctx:
+                    out = F.nlml_many([data[f][0] for f in mine], [data[f][1] for f in mine], [w] * len(mine), [amp] * len(mine),
+                                      [dadd] * len(mine), clamp=1e-30)
+                for i, f in enumerate(mine):
+                    vals[f] = out[i]
             elif mine:   # several owned blocks overlap on this GPU
                 ctx = torch.enable_grad() if args.with_grad else torch.no_grad()
                 with ctx, F.concurrent_blocks(nslots=nslots, device_index=local_rank, lookahead=args.slot_lookahead) as cb:

@@ -125,6 +125,7 @@ EXPORTS = {
     "ffgp_nlml_fused_raw_async": (C.c_int, [C.c_void_p, C.POINTER(Problem), C.POINTER(Links), _dp, C.POINTER(Grads)]),
     "ffgp_nlml_fused_small_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Problem), C.POINTER(Links), _dp, C.POINTER(Grads)]),
     "ffgp_nlml_fused_small_batch_async": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Problem), C.POINTER(Links), _dp, C.POINTER(Grads)]),
+    "ffgp_nlml_fused_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Problem), C.POINTER(Links), _dp, C.POINTER(Grads), C.POINTER(C.c_int)]),
     "ffgp_nlml_fused_async": (C.c_int, [C.c_void_p, C.POINTER(Problem), _dp, C.POINTER(Grads)]),
     "ffgp_wait": (C.c_int, [C.c_void_p]),
     "ffgp_predict": (C.c_int, [C.c_void_p, C.POINTER(Problem), _dp, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int]),

@@ -28,18 +28,25 @@ def _split(y_train):
 
 
 def negative_log_likelihood_many(models, xs, ys):
-    """[m.negative_log_likelihood(x, y) for m, x, y in zip(models, xs, ys)] as one tensor [F], evaluated by ONE library call when
-    every model is small (N <= 128, D <= 16, d <= 16) and lives on the GPU in fp64 -- the per-fidelity / per-seed loops of the
-    reference's experiments (Experiments/GAR_Aligned/exp_aligned.py:58-126) train such models one after the other, each step a
-    separate call; independent models can take their steps together.  Anything else falls back to the individual calls."""
+    """[m.negative_log_likelihood(x, y) for m, x, y in zip(models, xs, ys)] as one tensor [F] -- the per-fidelity / per-seed loops of
+    the reference's experiments (Experiments/GAR_Aligned/exp_aligned.py:58-126, FidelityFusion_Models/ResGP.py:78-112) train
+    independent models one after the other, each step a separate call; independent models can take their steps together.
+    ONE library call serves the batch when every model lives on the GPU in fp64 and either
+      * every model is small (N <= 128, D <= 16, d <= 16): one workgroup per model (`ffgp_nlml_fused_small_batch`), or
+      * the models are at least two blocks of one shape (the same N > 128 and d): they share ONE factorisation chain
+        (`ffgp_nlml_fused_batch`) -- eight N = 4096 blocks then cost what three cost one after the other;
+    anything else falls back to the individual calls.  Values and gradients are those of the individual calls, bit for bit."""
     items = []
     for m, x, y in zip(models, xs, ys):
         y, y_var = _split(y)
         lk = F.raw_many_ok(m.kernel, x, y, m.log_beta) if (y_var is None or F.raw_ok(y_var)) else None
         if lk is None or (len(items) and x.device != items[0]["X"].device):
-            return torch.stack([mm.negative_log_likelihood(xx, yy).reshape(()) for mm, xx, yy in zip(models, xs, ys)])
+            items = None
+            break
         items.append({"X": x, "Y": y, "lk": lk, "rdadd": m.log_beta, "dadd_link": F._lib.LINK_EXP_NEG, "dadd_c": JITTER, "diag_vec": y_var,
                       "variant": F.FFGP_LL_V1, "pi_const": PI, "sign": -1.0})
+    if items is None or not F.many_batchable([(it["X"].shape[0], it["Y"].shape[1]) for it in items]):
+        return torch.stack([mm.negative_log_likelihood(xx, yy).reshape(()) for mm, xx, yy in zip(models, xs, ys)])
     return F.nlml_raw_many(items)
 
 

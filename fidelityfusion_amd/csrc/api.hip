@@ -233,6 +233,8 @@ int ffgp_destroy(ffgp_handle* h) {
   for (int i = 0; i < 12; ++i)
     if (h->eig_ev[i]) hipEventDestroy(h->eig_ev[i]);
   if (h->d_info) hipFree(h->d_info);
+  if (h->bt_info) hipFree(h->bt_info);
+  if (h->bt_info_host) hipHostFree(h->bt_info_host);
   if (h->d_scal) hipFree(h->d_scal);
   if (h->d_asm) hipFree(h->d_asm);
   if (h->rawg) {
@@ -699,6 +701,173 @@ int ffgp_nlml_fused_small_batch_async(ffgp_handle* h, int F, const ffgp_problem*
 int ffgp_nlml_fused_small_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g) {
   FFGP_CHECK(ffgp_nlml_fused_small_batch_async(h, F, p, l, nll_dev, g));
   return ffgp_wait(h);
+}
+
+// ---- F blocks of ONE shape in one chain of launches ----------------------------------------------------------------------------
+// The reference's per-fidelity / per-seed loops evaluate independent blocks of equal size one after the other
+// (Experiments/GAR_Aligned/exp_aligned.py:58-126, FidelityFusion_Models/ResGP.py:78-112).  Below N ~ 6000 a block's
+// factorisation is a dependency chain of a few hundred short launches (32 diagonal blocks x (factor 32 us + solve 11 + update 8) at
+// N = 4096: 1.9 of the 2.0 ms); overlapping blocks through streams gives each block its own chain on a shared chip (eight C2 blocks:
+// 1.5 ms each).  Here the F blocks sit at a fixed stride in one workspace and every launch of the chain covers all of them -- the
+// diagonal-block kernel runs one workgroup per block, the GEMMs carry the block index in gridDim.y -- so F blocks share ONE chain
+// and fill its gaps with F times the matrix-core work.  The per-block arithmetic is the single call's, instruction for instruction
+// (same kernels, same k order): the values are bit-identical to F separate calls.
+// Conditions (else FFGP_ERR_ARG, and the caller falls back to separate calls): F >= 2 blocks with the same n > 128 and d, V1
+// likelihood, one radial-profile kernel each (no pair / tree / caller-built covariance), the round-4 diagonal-block kernel.
+// Gradients: the factorisation is shared, the inverse / gradient stages run block after block on the shared scratch.
+int ffgp_nlml_fused_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g,
+                          int* status) {
+  if (!h || !p || !nll_dev || F < 2 || F > 256) return FFGP_ERR_ARG;
+  const int n = p[0].n, d = p[0].d;
+  if (n <= FFGP_NB || d <= 0 || h->use_naive || h->diag_v2 != 4 || h->diag_dbg) return FFGP_ERR_ARG;
+  bool want_grad = false;
+  for (int f = 0; f < F; ++f) {
+    const ffgp_problem& q = p[f];
+    if (q.n != n || q.d != d || q.cov_dev || q.pair || q.tree || !q.X_dev || !q.Y_dev || !q.w_dev || !q.amp_dev || q.D <= 0 || q.D > 128 ||
+        q.ll_variant != FFGP_LL_V1 || q.kfun < FFGP_KFUN_SE || q.kfun > FFGP_KFUN_RQ)
+      return FFGP_ERR_ARG;
+    if (g) {
+      const ffgp_grads& gg = g[f];
+      if (gg.g_cov_dev || gg.g_pair) return FFGP_ERR_ARG;
+      want_grad = want_grad || gg.g_w_dev || gg.g_amp_dev || gg.g_diag_add_dev || gg.g_Y_dev || gg.g_diag_vec_dev || gg.g_kparam_dev;
+    }
+  }
+  FFGP_HIP(hipSetDevice(h->device));
+  const size_t ld = ffgp_round_up(n, 16);
+  const size_t blk = (size_t)(n + d) * ld;                 // Sigma | Y^T  ->  L | Gamma^T   of one block
+  const size_t n1 = ffgp_round_up((n + 1) / 2, FFGP_NB);
+  int Dmax = 0;
+  for (int f = 0; f < F; ++f) Dmax = p[f].D > Dmax ? p[f].D : Dmax;
+  size_t total = blk * F;
+  const size_t o_link = total; total += (size_t)F * 512;   // effective parameters / their gradients, 256 + 256 doubles per block
+  size_t o_X = 0, o_S = 0, o_T = 0, o_At = 0, o_P = 0;
+  if (want_grad) {
+    o_X = total; total += (size_t)n * ld;
+    o_S = total; total += (size_t)n * ld;
+    o_T = total; total += 2 * (n1 * n1 + 16);
+    o_At = total; total += (size_t)d * ld;
+    o_P = total; total += ffgp_grad_partial_doubles(n, Dmax) + 16;
+  }
+  FFGP_CHECK(ffgp_ensure_ws(h, total * sizeof(double)));
+  if (!h->bt_info) {
+    FFGP_HIP(hipMalloc(&h->bt_info, 256 * sizeof(int)));
+    FFGP_HIP(hipHostMalloc(&h->bt_info_host, 256 * sizeof(int)));
+  }
+  const int nblk = (n + FFGP_NB - 1) / FFGP_NB;
+  FFGP_CHECK(ffgp_ensure_dinv(h, F * nblk * FFGP_NB));
+  FFGP_CHECK(ffgp_zero_async(h, h->bt_info, (size_t)F * sizeof(int)));
+  h->n_stages = 0;
+  stage_mark(h, 0);
+  // ---- links, assembly, passenger rows: block after block (each a few launches that fill the chip by themselves)
+  ffgp_problem* q = (ffgp_problem*)alloca(sizeof(ffgp_problem) * F);
+  for (int f = 0; f < F; ++f) {
+    q[f] = p[f];
+    double* eff = h->ws + o_link + (size_t)f * 512;
+    if (l) {
+      hipLaunchKernelGGL(ffgp_link_fwd, dim3(1), dim3(128), 0, h->stream, l[f], p[f].D, p[f].w_dev, p[f].amp_dev, p[f].diag_add_dev, eff);
+      q[f].w_dev = eff;
+      q[f].amp_dev = eff + p[f].D;
+      if (p[f].diag_add_dev) q[f].diag_add_dev = eff + p[f].D + 1;
+    }
+    double* W0 = h->ws + blk * f;
+    FFGP_CHECK(ffgp_assemble_impl(h, q[f].X_dev, n, q[f].X_dev, n, q[f].D, q[f].w_dev, q[f].amp_dev, q[f].clamp_min, q[f].diag_add_dev,
+                                  q[f].diag_vec_dev, q[f].diag_stride, q[f].add_mat_dev, q[f].ld_add, q[f].add_all, q[f].mean_jitter, W0,
+                                  (int)ld, 1, q[f].kfun, q[f].kparam));
+    FFGP_CHECK(ffgp_transpose(h, q[f].Y_dev, n, d, d, W0 + (size_t)n * ld, (int)ld, 1.0));
+  }
+  stage_mark(h, 1);
+  // ---- ONE factorisation chain for all F blocks
+  h->tri_hook_col = 0;
+  h->tri_hook_fired = 0;
+  h->bt_F = F;
+  h->bt_sA = (long)blk;
+  h->bt_sD = (long)nblk * FFGP_NB * FFGP_NB;
+  const int prc = ffgp_potrf_impl(h, h->ws, n, n + d, (int)ld, 0);
+  h->bt_F = 0;
+  h->dinv_L = nullptr;          // (the store holds F factors' inverses: it belongs to none of them as far as the cache is concerned)
+  h->sinv_L = nullptr;
+  FFGP_CHECK(prc);
+  stage_mark(h, 2);
+  double* const dinv0 = h->dinv;
+  int rc_stage = FFGP_OK;
+  for (int f = 0; f < F && rc_stage == FFGP_OK; ++f) {
+    double* W0 = h->ws + blk * f;
+    double* Gt = W0 + (size_t)n * ld;
+    rc_stage = ffgp_nll_reduce_impl(h, FFGP_LL_V1, W0, n, (int)ld, Gt, d, n, (int)ld, d, q[f].pi_const, nll_dev + f);
+    if (rc_stage != FFGP_OK || !want_grad || !g) continue;
+    const ffgp_grads& gg = g[f];
+    if (!(gg.g_w_dev || gg.g_amp_dev || gg.g_diag_add_dev || gg.g_Y_dev || gg.g_diag_vec_dev || gg.g_kparam_dev)) continue;
+    // the block's own slice of the Dinv store, presented as "the" store of this factor while its inverse is formed
+    h->dinv = dinv0 + (size_t)f * nblk * FFGP_NB * FFGP_NB;
+    h->dinv_L = W0; h->dinv_n = n; h->dinv_ld = (int)ld;
+    double* X = h->ws + o_X;
+    double* S = h->ws + o_S;
+    double* T = h->ws + o_T;
+    double* At = h->ws + o_At;
+    double* P = h->ws + o_P;
+    double* geff = h->ws + o_link + (size_t)f * 512 + 256;
+    const int D = q[f].D;
+    ffgp_grads gq = gg;
+    bool chain = false;
+    if (l) {
+      if (gg.g_w_dev) gq.g_w_dev = geff;
+      if (gg.g_amp_dev) gq.g_amp_dev = geff + D;
+      if (gg.g_diag_add_dev) gq.g_diag_add_dev = geff + D + 1;
+      chain = gg.g_w_dev || gg.g_amp_dev || gg.g_diag_add_dev;
+    }
+    if ((rc_stage = ffgp_trtri_impl(h, W0, n, (int)ld, X, (int)ld, T)) != FFGP_OK) break;
+    if ((rc_stage = ffgp_lauum_impl(h, X, n, (int)ld, S, (int)ld)) != FFGP_OK) break;
+    if ((rc_stage = ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Gt, (int)ld, X, (int)ld, At, (int)ld, d, n, n, 1.0, 0.0,
+                                     TRI_LO_J)) != FFGP_OK) break;
+    if ((rc_stage = ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_LOWER, 0, At, (int)ld, At, (int)ld, S, (int)ld, n, n, d, -0.5,
+                                     0.5 * (double)d)) != FFGP_OK) break;
+    if ((rc_stage = ffgp_grad_impl(h, q[f].X_dev, n, D, q[f].w_dev, q[f].amp_dev, q[f].clamp_min, S, (int)ld, q[f].mean_jitter, gq.g_w_dev,
+                                   gq.g_amp_dev, gq.g_diag_add_dev, gq.g_diag_vec_dev, P, q[f].kfun, q[f].kparam, gq.g_kparam_dev)) != FFGP_OK) break;
+    if (gg.g_Y_dev && (rc_stage = ffgp_transpose(h, At, d, n, (int)ld, gg.g_Y_dev, d, 1.0)) != FFGP_OK) break;
+    if (l) {
+      const double sc = (l[f].out_scale == 0.0) ? 1.0 : l[f].out_scale;
+      if (chain)
+        hipLaunchKernelGGL(ffgp_link_bwd, dim3(1), dim3(128), 0, h->stream, l[f], D, p[f].w_dev, p[f].amp_dev, p[f].diag_add_dev, geff,
+                           gg.g_w_dev, gg.g_amp_dev, gg.g_diag_add_dev, sc);
+      if (sc != 1.0) {
+        const long nY = gg.g_Y_dev ? (long)n * d : 0, nv = gg.g_diag_vec_dev ? n : 0;
+        const long tot = nY > nv ? nY : nv;
+        hipLaunchKernelGGL(ffgp_scale_outputs, dim3((unsigned)((tot > 0 ? tot : 1) + 255) / 256), dim3(256), 0, h->stream, sc, nll_dev + f,
+                           gg.g_Y_dev, nY, gg.g_diag_vec_dev, nv, gg.g_kparam_dev);
+      }
+    }
+  }
+  h->dinv = dinv0;
+  h->dinv_L = nullptr;
+  FFGP_CHECK(rc_stage);
+  if (l && !(want_grad && g)) {      // forward only: the output scale (the sign of the reference's +LL) still applies
+    for (int f = 0; f < F; ++f) {
+      const double sc = (l[f].out_scale == 0.0) ? 1.0 : l[f].out_scale;
+      if (sc != 1.0)
+        hipLaunchKernelGGL(ffgp_scale_outputs, dim3(1), dim3(256), 0, h->stream, sc, nll_dev + f, (double*)nullptr, 0L, (double*)nullptr, 0L,
+                           (double*)nullptr);
+    }
+  } else if (l) {                   // blocks without gradients of their own inside a gradient batch
+    for (int f = 0; f < F; ++f) {
+      const ffgp_grads& gg = g[f];
+      const double sc = (l[f].out_scale == 0.0) ? 1.0 : l[f].out_scale;
+      if (!(gg.g_w_dev || gg.g_amp_dev || gg.g_diag_add_dev || gg.g_Y_dev || gg.g_diag_vec_dev || gg.g_kparam_dev) && sc != 1.0)
+        hipLaunchKernelGGL(ffgp_scale_outputs, dim3(1), dim3(256), 0, h->stream, sc, nll_dev + f, (double*)nullptr, 0L, (double*)nullptr, 0L,
+                           (double*)nullptr);
+    }
+  }
+  stage_mark(h, 3);
+  if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
+  FFGP_HIP(hipMemcpyAsync(h->bt_info_host, h->bt_info, (size_t)F * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  FFGP_HIP(hipStreamSynchronize(h->stream));
+  if (h->timing) stage_collect(h);
+  int first = FFGP_OK;
+  for (int f = 0; f < F; ++f) {
+    const int v = ffgp_map_info(h->bt_info_host[f]);
+    if (status) status[f] = v;
+    if (v != 0 && first == FFGP_OK) first = v;
+  }
+  return first;
 }
 
 // ---- launch-bound sizes: the whole call as one captured graph ---------------------------------------------------------------

@@ -162,6 +162,12 @@ struct ffgp_handle {
   hipStream_t aux2;     // third stream: the head of the triangular inverse under the factorisation's tail (nlml_fused_enqueue)
   hipEvent_t tri_ev[2]; // [0] factor columns < tri_hook_col are final (recorded by ffgp_potrf_impl on the side stream); [1] head done
   int tri_hook_col, tri_hook_fired;
+  // batched factorisation (ffgp_nlml_fused_batch): F identical-shape blocks at fixed strides share ONE chain of launches -- every
+  // kernel of ffgp_potrf_impl then covers all F blocks (diagonal-block kernel: one workgroup per block; GEMMs: gridDim.y = F)
+  int bt_F;             // 0 / 1 = not batched
+  long bt_sA, bt_sD;    // element strides between the blocks' workspaces / between their Dinv stores
+  int* bt_info;         // [F] device status words (first non-positive pivot of each block)
+  int* bt_info_host;    // pinned mirror
   int trtri_overlap;    // option (default 1)
   int trtri_fill;       // option "trtri_fill" (default 0): 1 = zero the whole inverse buffer before the head of the triangular inverse; 0 = only the diagonal blocks' upper parts; 2 = NaN-fill it (test)
   hipEvent_t ev_switch; // ffgp_set_stream: recorded on the stream the handle leaves, waited for by the one it moves to

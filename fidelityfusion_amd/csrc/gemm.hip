@@ -718,7 +718,7 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   // few output ROWS (single-output GPs: A^T = Gamma^T L^-1, 1 x n): the transposed matrix-vector product -- C^T = op(B)^T op(A)^T
   // reads B once with the rows of C^T across the lanes; on the 64 x 64 tile the launch above cost 0.21 ms at n = k = 4096
   // (0.6 TB/s of B) inside every training step of a d = 1 model
-  if (h->skinny_max_n > 0 && m <= h->skinny_max_n && m <= 8 && n > 8 && alias == 0 && batch <= 1 && (tri == 0 || tri == TRI_LO_J) &&
+  if (h->skinny_max_n > 0 && m <= h->skinny_max_n && m <= 8 && n > 8 && alias == 0 && (batch == 0 || batch == 1) && (tri == 0 || tri == TRI_LO_J) &&
       mode == TILES_FULL && !syrk_tag && h->stream != h->aux) {
     SkinnyArgs sk = {};
     sk.A = B; sk.B = A; sk.C = C;
@@ -757,7 +757,7 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
     }
     return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
   }
-  if (h->splitk_min_k > 0 && alias == 0 && batch <= 1 && tri == 0 && mode == TILES_FULL && !syrk_tag && k >= h->splitk_min_k &&
+  if (h->splitk_min_k > 0 && alias == 0 && (batch == 0 || batch == 1) && tri == 0 && mode == TILES_FULL && !syrk_tag && k >= h->splitk_min_k &&
       h->stream != h->aux) {
     const int t64 = ((m + 63) / 64) * ((n + 63) / 64);
     if (t64 <= 64) {
@@ -787,7 +787,7 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
       }
     }
   }
-  if (h->skinny_max_n > 0 && n <= h->skinny_max_n && n <= 8 && alias == 0 && batch <= 1 && tri == 0 && mode == TILES_FULL && !syrk_tag &&
+  if (h->skinny_max_n > 0 && n <= h->skinny_max_n && n <= 8 && alias == 0 && (batch == 0 || batch == 1) && tri == 0 && mode == TILES_FULL && !syrk_tag &&
       h->stream != h->aux) {
     SkinnyArgs sk;
     sk.A = A; sk.B = B; sk.C = C;
@@ -812,6 +812,11 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.alpha = alpha; a.beta = beta;
   a.prio = (h->stream == h->aux && h->aux_prio) ? 1 : 0;
+  // batch < 0: |batch| members, with every shape decision below taken as ONE member's launch would take it -- the batched
+  // factorisation (ffgp_nlml_fused_batch) promises the single call's values bit for bit, and the forms differ in rounding (the fast
+  // 128-tile accumulates onto C, the general tiles add alpha * (sum) to beta * C once)
+  const int dec_batch = (batch < 0) ? 1 : (batch > 1 ? batch : 1);
+  if (batch < 0) batch = -batch;
   a.batch = batch > 1 ? batch : 1;
   a.sA = sA; a.sB = sB; a.sC = sC;
   if ((sA & 1) || (sB & 1)) a.avec = a.bvec = 0;  // odd strides break the 16-byte alignment of later batch members
@@ -828,7 +833,7 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   int level = 0;
   if (h->force_ts == 64) level = 1;
   else if (h->force_ts == 32) level = 2;
-  else if (h->force_ts == 0 && a.total_tiles * a.batch < h->small_tile_threshold) level = 1;
+  else if (h->force_ts == 0 && a.total_tiles * dec_batch < h->small_tile_threshold) level = 1;
   const bool kk = (opa == OP_KMAJOR && opb == OP_KMAJOR);
   if (level >= 1) {
     if (alias == 0 || (alias == ALIAS_A && n <= 64) || (alias == ALIAS_B && m <= 64)) {
@@ -837,11 +842,11 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
       tsm = 64;  // 64 x 128: the whole panel-block width in one column tile
     }
     a.total_tiles = count_tiles(mode, m, n, tsm, tsn, a.tiles_m, a.tiles_n);
-    if (h->force_ts == 0 && level == 1 && kk && a.batch == 1 && tsm == 64 && a.total_tiles < h->tile32_threshold) level = 2;
+    if (h->force_ts == 0 && level == 1 && kk && dec_batch == 1 && tsm == 64 && a.total_tiles < h->tile32_threshold) level = 2;
     // 32-row tiles: 32 x 32 for products that alias nothing; an in-place product must keep ONE column tile (C = A's
     // buffer: a second column tile would overwrite columns the first still reads as its k range), so it takes
     // 32 x 128 whatever its width; C = B's buffer (one ROW tile needed) stays on the 64-tile
-    if (level == 2 && kk && tsm == 64 && a.batch == 1 && alias != ALIAS_B) {
+    if (level == 2 && kk && tsm == 64 && dec_batch == 1 && alias != ALIAS_B) {
       tsm = 32;
       tsn = (alias == ALIAS_A) ? 128 : 32;
       a.total_tiles = count_tiles(mode, m, n, tsm, tsn, a.tiles_m, a.tiles_n);
@@ -879,7 +884,7 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   // Split tail (see ffgp_gemm_f64): with T equal tiles on 256 CUs the last (T mod 256) tiles run on otherwise idle CUs for a
   // whole tile time; when that remainder is small, hand it out as 64 x 64 quarters -- 4x the workgroups, a quarter of the
   // chain each -- which start under the last full round.  (An in-place or batched launch never splits.)
-  if (tsm == 128 && tsn == 128 && alias == 0 && a.batch == 1 && h->force_ts == 0 && h->split_rem_max > 0 && a.total_tiles > 256) {
+  if (tsm == 128 && tsn == 128 && alias == 0 && dec_batch == 1 && h->force_ts == 0 && h->split_rem_max > 0 && a.total_tiles > 256) {
     const int rem = a.total_tiles % 256;
     if (rem > 0 && rem <= h->split_rem_max) {
       a.split_at = a.total_tiles - rem;

@@ -868,7 +868,11 @@ __device__ __forceinline__ void d3_store_inverse_rows(double* S, double* __restr
 }
 
 __global__ __launch_bounds__(512, 4) void ffgp_potrf_diag128_v3(double* __restrict__ A, int lda, int nb, double* __restrict__ Dinv,
-                                                                int* info, int row_base, int prio) {
+                                                                int* info, int row_base, int prio, long sA, long sD, int sInfo) {
+  // (batched factorisation: workgroup b factors block b -- its own matrix, Dinv store and status word)
+  A += (size_t)blockIdx.x * sA;
+  Dinv += (size_t)blockIdx.x * sD;
+  info += blockIdx.x * sInfo;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* S = lds;
   volatile D3Flags* fl = reinterpret_cast<volatile D3Flags*>(lds + NBLK_LOWER * BLKSZ);
@@ -1220,6 +1224,7 @@ __global__ __launch_bounds__(128) void ffgp_dinv_naive(const double* L, int ldl,
 // host side
 // ------------------------------------------------------------------------------------------------------------
 static int launch_diag(ffgp_handle* h, double* Ablk, int lda, int nb, double* Dinv_blk, int row_base, int do_factor) {
+  if (h->bt_F > 1 && !(do_factor && h->diag_v2 == 4 && !h->diag_dbg)) return FFGP_ERR_ARG;   // only the round-4 kernel is batched
   if (!(h->diag_attr_set & 1)) {   // per handle = per device (the attribute lives in the device's context)
     FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
@@ -1239,8 +1244,12 @@ static int launch_diag(ffgp_handle* h, double* Ablk, int lda, int nb, double* Di
                                      DIAG_LDS_BYTES));
         h->diag_attr_set |= 4;
       }
-      hipLaunchKernelGGL(ffgp_potrf_diag128_v3, dim3(1), dim3(512), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk, h->d_info,
-                         row_base, h->aux_prio);
+      if (h->bt_F > 1)
+        hipLaunchKernelGGL(ffgp_potrf_diag128_v3, dim3(h->bt_F), dim3(512), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk,
+                           h->bt_info, row_base, h->aux_prio, h->bt_sA, h->bt_sD, 1);
+      else
+        hipLaunchKernelGGL(ffgp_potrf_diag128_v3, dim3(1), dim3(512), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk, h->d_info,
+                           row_base, h->aux_prio, 0L, 0L, 0);
     } else if (h->diag_v2 == 3)   // the round-3 pivot step (32-bit DPP moves), kept for A/B runs
       hipLaunchKernelGGL((ffgp_potrf_diag128_v2<8, false>), dim3(1), dim3(512), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk,
                          h->d_info, row_base, h->aux_prio);
@@ -1316,6 +1325,16 @@ int ffgp_refresh_dinv(ffgp_handle* h, const double* L, int n, int ldl) {
 // panel -- so that block is complete the moment this panel is and no strip update sits between two panels on the
 // dependency chain; `gate2` (nullable) is waited for together with `gate` (the main stream's earlier contribution to
 // those columns must have landed first)
+// the factorisation's GEMMs: in a batched factorisation (h->bt_F blocks at fixed strides) every launch covers all blocks
+static int potrf_gemm(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, const double* A, int lda, const double* B, int ldb,
+                      double* C, int ldc, int m, int n, int k, double alpha, double beta, int tri = 0, int alias = ALIAS_NONE,
+                      bool b_is_dinv = false) {
+  if (h->bt_F > 1)
+    return ffgp_gemm_launch(h, opa, opb, mode, syrk_tag, A, lda, B, ldb, C, ldc, m, n, k, alpha, beta, tri, alias, -h->bt_F, h->bt_sA,
+                            b_is_dinv ? h->bt_sD : h->bt_sA, h->bt_sA);     // (-F: one member's tile shapes, see ffgp_gemm_launch)
+  return ffgp_gemm_launch(h, opa, opb, mode, syrk_tag, A, lda, B, ldb, C, ldc, m, n, k, alpha, beta, tri, alias);
+}
+
 static int factor_panel(ffgp_handle* h, double* A, int n, int mtot, int lda, int k0, int w1, hipEvent_t gate = nullptr, int carry = 0,
                         hipEvent_t gate2 = nullptr) {
   const int pend = k0 + w1;
@@ -1328,14 +1347,14 @@ static int factor_panel(ffgp_handle* h, double* A, int n, int mtot, int lda, int
     if (mrows > 0) {
       double* A21 = A + (size_t)(j0 + jb) * lda + j0;
       // TRSM as GEMM: A21 <- A21 * Dj^T (in place: one column tile, each workgroup rewrites only rows it read)
-      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, A21, lda, Dj, NB, A21, lda, mrows, jb, jb, 1.0, 0.0, 0,
-                                  ALIAS_A));
+      FFGP_CHECK(potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, A21, lda, Dj, NB, A21, lda, mrows, jb, jb, 1.0, 0.0, 0,
+                            ALIAS_A, true));
       const int wrem = pend - (j0 + jb) + carry;
       if (wrem > 0) {
         if (gate && j0 == k0) FFGP_HIP(hipStreamWaitEvent(h->stream, gate, 0));
         if (gate2 && j0 == k0) FFGP_HIP(hipStreamWaitEvent(h->stream, gate2, 0));
         double* C = A + (size_t)(j0 + jb) * lda + (j0 + jb);
-        FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 0, A21, lda, A21, lda, C, lda, mrows, wrem, jb, -1.0,
+        FFGP_CHECK(potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 0, A21, lda, A21, lda, C, lda, mrows, wrem, jb, -1.0,
                                     1.0));
       }
     }
@@ -1377,7 +1396,7 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
         if (mt > 0) {
           double* P = A + (size_t)pend * lda + k0;
           double* C = A + (size_t)pend * lda + pend;
-          FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P, lda, P, lda, C, lda, mtot - pend, mt, w1,
+          FFGP_CHECK(potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P, lda, P, lda, C, lda, mtot - pend, mt, w1,
                                       -1.0, 1.0));
         }
       }
@@ -1412,7 +1431,7 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
         if (wn - wa + wz > 0) {
           double* Pb = A + (size_t)(pend + wa) * lda + k0;
           double* Cb = A + (size_t)(pend + wa) * lda + (pend + wa);
-          FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, Pb, lda, Pb, lda, Cb, lda, mtot - pend - wa,
+          FFGP_CHECK(potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, Pb, lda, Pb, lda, Cb, lda, mtot - pend - wa,
                                       wn - wa + wz, w1, -1.0, 1.0));
           FFGP_HIP(hipEventRecord(eg, main_s));
           gate = eg;
@@ -1433,7 +1452,7 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
         if (mt2 > 0) {
           double* P2 = A + (size_t)(q + wz) * lda + k0;
           double* C2 = A + (size_t)(q + wz) * lda + (q + wz);
-          FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P2, lda, P2, lda, C2, lda, mtot - q - wz, mt2, w1, -1.0,
+          FFGP_CHECK(potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P2, lda, P2, lda, C2, lda, mtot - q - wz, mt2, w1, -1.0,
                                       1.0));
         }
       }
@@ -1466,7 +1485,7 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
         // side stream: S_a(k) (after S_ii(k-1), which carried panel k-1 into these columns)
         if (ei_prev) FFGP_HIP(hipStreamWaitEvent(h->aux, ei_prev, 0));
         h->stream = h->aux;
-        int rc = ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P, lda, P, lda, C, lda, mtot - pend, wa, w1, -1.0, 1.0);
+        int rc = potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P, lda, P, lda, C, lda, mtot - pend, wa, w1, -1.0, 1.0);
         h->stream = main_s;
         FFGP_CHECK(rc);
         // main stream: S_b(k) once panel k is complete
@@ -1475,7 +1494,7 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
         if (wn > wa) {
           double* Pb = A + (size_t)(pend + wa) * lda + k0;
           double* Cb = A + (size_t)(pend + wa) * lda + (pend + wa);
-          FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, Pb, lda, Pb, lda, Cb, lda, mtot - pend - wa, wn - wa,
+          FFGP_CHECK(potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, Pb, lda, Pb, lda, Cb, lda, mtot - pend - wa, wn - wa,
                                       w1, -1.0, 1.0));
           FFGP_HIP(hipEventRecord(eg, main_s));
           gate = eg;
@@ -1497,7 +1516,7 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
         if (mt2 > 0) {
           double* P2 = A + (size_t)(pend + wn) * lda + k0;
           double* C2 = A + (size_t)(pend + wn) * lda + (pend + wn);
-          FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P2, lda, P2, lda, C2, lda, mtot - pend - wn, mt2,
+          FFGP_CHECK(potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P2, lda, P2, lda, C2, lda, mtot - pend - wn, mt2,
                                       w1, -1.0, 1.0));
           FFGP_HIP(hipEventRecord(ei, main_s));
           ei_prev = ei;

@@ -336,6 +336,7 @@ class _NLMLRawMany(torch.autograd.Function):
             _settle_raw(dev.index)
         h = _lib.handle(dev.index, 0)
         _lib.bind_stream(h, dev.index)
+        chain_batch = tensors[0].shape[0] > SMALL_BATCH_MAX_N     # (nlml_raw_many only builds homogeneous batches of either kind)
         P = (Problem * nF)()
         L = (_lib.Links * nF)()
         G = (Grads * nF)()
@@ -383,7 +384,18 @@ class _NLMLRawMany(torch.autograd.Function):
                     g.g_Y_dev = b + 8 * (Dw + 3)
                 if nv:
                     g.g_diag_vec_dev = b + 8 * (Dw + 3 + n * d)
-        if buf is not None and DEFER_RAW_ERRORS:
+        if chain_batch:
+            # equal-shape blocks beyond the one-workgroup sizes: ONE factorisation chain for all of them (ffgp_nlml_fused_batch);
+            # the status is per block, and the FIRST block that is not positive definite raises -- the reference's loop over models
+            # would have stopped there (FidelityFusion_Models/ResGP.py:82-88)
+            status = (C.c_int * nF)()
+            rc = check(lib.ffgp_nlml_fused_batch(h, nF, P, L, out.data_ptr(), G if buf is not None else None, status),
+                       "ffgp_nlml_fused_batch")
+            if rc > 0:
+                bad = next(f for f in range(nF) if status[f] > 0)
+                _raise_not_pd(status[bad], "linalg.cholesky (block %d of the batch)" % bad)
+            ctx.dev_index = None
+        elif buf is not None and DEFER_RAW_ERRORS:
             check(lib.ffgp_nlml_fused_small_batch_async(h, nF, P, L, out.data_ptr(), G), "ffgp_nlml_fused_small_batch_async")
             with _raw_pending_lock:
                 _raw_pending[dev.index] = h
@@ -445,14 +457,42 @@ def nlml_raw_many(items):
     return _NLMLRawMany.apply(tuple(metas), torch.is_grad_enabled(), *tensors)
 
 
+def nlml_many(Xs, Ys, ws, amps, diag_adds, clamp=NEG_INF, pi_const=PI_TRUNC):
+    """[nlml(X, Y, w, amp, diag_add=dadd, clamp=clamp) for ...] as one tensor [F] through ONE factorisation chain
+    (ffgp_nlml_fused_batch): F >= 2 blocks of one shape (the same n > 128 and d), everything on one GPU in fp64, effective
+    parameters (w [D], amp [1], diag_add [1] per block; squared-exponential profile).  Gradients flow to Y, w, amp and diag_add.
+    The per-fidelity blocks of one rank in the sharded workloads (bench.py `cigar4`, `gar8`) are such a batch."""
+    items = []
+    for X, Y, w, amp, dadd in zip(Xs, Ys, ws, amps, diag_adds):
+        if not raw_ok(X, Y, w, amp, dadd) or w.numel() != X.shape[1]:
+            raise ValueError("nlml_many: every tensor must live on one GPU in fp64, contiguous, with w of length D")
+        lk = {"w": w, "w_link": _lib.LINK_ID, "w_c": 0.0, "amp": amp, "amp_link": _lib.LINK_ID, "clamp": clamp, "kfun": 0}
+        items.append({"X": X, "Y": Y, "lk": lk, "rdadd": dadd, "dadd_link": _lib.LINK_ID, "dadd_c": 0.0, "pi_const": pi_const})
+    if not many_batchable([(it["X"].shape[0], it["Y"].shape[1]) for it in items]):
+        raise ValueError("nlml_many: the blocks must share one shape (n, d) with n > %d" % SMALL_BATCH_MAX_N)
+    return nlml_raw_many(items)
+
+
 def raw_many_ok(kernel, x_train, y_train, *others):
-    """`raw_path` + the size limits of the batched small-problem call"""
+    """`raw_path` + the limits of the batched calls: up to SMALL_BATCH_MAX_N points the one-workgroup batch (any mix of shapes,
+    D, d <= 16); beyond that the shared-chain batch, which needs every member to have the SAME (n, d) -- checked by the caller
+    (`many_batchable`) -- and D <= 128"""
     lk = raw_path(kernel, x_train, y_train, *others)
     if lk is None or isinstance(lk.get("kparam"), torch.Tensor):
         return None
-    if x_train.shape[0] > SMALL_BATCH_MAX_N or x_train.shape[1] > SMALL_BATCH_MAX_D or y_train.shape[1] > SMALL_BATCH_MAX_d:
+    if x_train.shape[0] > SMALL_BATCH_MAX_N:
+        return lk if x_train.shape[1] <= 128 else None
+    if x_train.shape[1] > SMALL_BATCH_MAX_D or y_train.shape[1] > SMALL_BATCH_MAX_d:
         return None
     return lk
+
+
+def many_batchable(shapes):
+    """shapes: [(n, d)] of the members.  One library call serves them when they are all small (n <= SMALL_BATCH_MAX_N: one
+    workgroup each), or at least two blocks of ONE larger shape (ffgp_nlml_fused_batch: they share one factorisation chain)."""
+    if all(n <= SMALL_BATCH_MAX_N for n, _ in shapes):
+        return True
+    return len(shapes) >= 2 and len(set(shapes)) == 1 and shapes[0][0] > SMALL_BATCH_MAX_N
 
 
 def raw_ok(*tensors):

@@ -407,6 +407,18 @@ int ffgp_nlml_fused_raw_async(ffgp_handle* h, const ffgp_problem* p, const ffgp_
    ANY member is reported (as that member's leading minor).  The _async form only enqueues (status: next ffgp_wait).             */
 int ffgp_nlml_fused_small_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_links* links, double* nll_dev,
                                 const ffgp_grads* g);
+
+/* F independent blocks of ONE shape (the same n > 128 and d; V1 likelihood; one radial-profile kernel each) in one chain of
+   launches: the per-fidelity / per-seed loops of the reference evaluate equal-size blocks one after the other
+   (Experiments/GAR_Aligned/exp_aligned.py:58-126, FidelityFusion_Models/ResGP.py:78-112), and below N ~ 6000 one block's
+   factorisation is a latency-bound chain of short launches.  Here every launch of that chain covers all F blocks (diagonal-block
+   kernel: one workgroup per block; GEMMs: the block index in gridDim.y), so the blocks share ONE chain; the arithmetic per block is
+   the single call's, and the values are bit-identical to F separate calls.  p, g (may be NULL), links (NULL = effective
+   parameters): arrays of F; nll_dev[f] receives block f's value; status[f] (host, may be NULL) its own factorisation status
+   (0, or the 1-based index of the first non-positive pivot of THAT block).  Returns the first non-zero status, FFGP_ERR_ARG when
+   the blocks do not meet the conditions (call them one by one then).  Synchronous.                                            */
+int ffgp_nlml_fused_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_links* links, double* nll_dev,
+                          const ffgp_grads* g, int* status);
 int ffgp_nlml_fused_small_batch_async(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_links* links, double* nll_dev,
                                       const ffgp_grads* g);
 

@@ -854,6 +854,68 @@ def test_small_problems_batched_call():
     assert rel(mixed[1], big.negative_log_likelihood(xb, yb)) < 1e-13 and rel(mixed[0], got[0][0]) < 1e-13
 
 
+@pytest.mark.noisy
+@pytest.mark.parametrize("n,d,F_", [(300, 2, 3), (700, 1, 4), (1537, 3, 2), (4096, 1, 3)])
+def test_equal_shape_blocks_share_one_chain(n, d, F_):
+    """cigp_v10.negative_log_likelihood_many on blocks of ONE shape beyond the one-workgroup sizes: every launch of the
+    factorisation chain covers all F blocks (ffgp_nlml_fused_batch) -- values and every gradient must be those of the individual
+    calls BIT FOR BIT (same kernels, same k order), for sizes on either side of the look-ahead threshold and with a ragged last
+    diagonal block; D may differ between the members"""
+    from fidelityfusion_amd import functional as F
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp, negative_log_likelihood_many
+    rng = np.random.default_rng(n + d)
+    models, xs, ys = [], [], []
+    for f in range(F_):
+        D = 2 + f
+        k = kernel.ARDKernel(D) if f % 2 == 0 else kernel.MaternKernel(D, nu=2.5)
+        with torch.no_grad():
+            k.length_scales.copy_(torch.tensor(rng.uniform(0.5, 1.5, D) * rng.choice([-1.0, 1.0], D)))
+        models.append(cigp(k, 0.5 + 0.2 * f).double().to(DEV))
+        xs.append(T(rng.uniform(0, 1, (n, D))))
+        ys.append(T(rng.standard_normal((n, d)), grad=True))
+    calls = []
+    real = F.lib.ffgp_nlml_fused_batch
+
+    class _Spy:
+        def __getattr__(self, name):
+            return getattr(F._lib.lib, name)
+
+        def ffgp_nlml_fused_batch(self, h, nF, *a):
+            calls.append(nF)
+            return real(h, nF, *a)
+    F.lib, keep = _Spy(), F.lib
+    try:
+        vals = negative_log_likelihood_many(models, xs, ys)
+        (vals * T(np.linspace(0.5, 1.5, F_))).sum().backward()
+        with torch.no_grad():
+            vals_ng = negative_log_likelihood_many(models, xs, ys)      # forward only: no gradient stages, same values
+    finally:
+        F.lib = keep
+    assert calls == [F_, F_] and vals.shape == (F_,)
+    assert torch.equal(vals_ng, vals.detach())
+    got = [(v.detach().clone(), [p_.grad.clone() for p_ in m.parameters()], y.grad.clone()) for v, m, y in zip(vals, models, ys)]
+    for i, (m, x, y) in enumerate(zip(models, xs, ys)):
+        for p_ in m.parameters():
+            p_.grad = None
+        y.grad = None
+        v = m.negative_log_likelihood(x, y)
+        (v * (0.5 + i / (F_ - 1.0))).backward()
+        assert torch.equal(got[i][0], v.detach()), (i, float(got[i][0]), float(v))
+        for a, b in zip(got[i][1], [p_.grad for p_ in m.parameters()]):
+            assert torch.equal(a, b), i
+        assert torch.equal(got[i][2], y.grad), i
+    # a member that is not positive definite: the batch reports THAT block, as the reference's loop would stop at that model
+    if n <= 700:
+        bad_y = [ys[1].detach(), -3.0 * torch.eye(n, device=DEV, dtype=torch.float64)]
+        with pytest.raises(torch.linalg.LinAlgError, match="block 1"):
+            negative_log_likelihood_many(models, xs, [ys[0], bad_y] + ys[2:])
+        assert torch.isfinite(negative_log_likelihood_many(models, xs, ys)).all()
+    # different shapes: the individual calls
+    mixed = negative_log_likelihood_many(models[:2], [xs[0], xs[1][: n - 7]], [ys[0], ys[1][: n - 7]])
+    assert torch.equal(mixed[0].detach(), got[0][0])
+
+
 def test_small_finish_reports_not_pd():
     """the finishing-kernel path keeps the factorisation's status: a Sigma that is not positive definite raises"""
     from fidelityfusion_amd import kernel
