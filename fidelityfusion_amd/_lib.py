@@ -78,6 +78,7 @@ class Grads(C.Structure):
 EXPORTS = {
     # name: (restype, argtypes)
     "ffgp_version": (C.c_char_p, []),
+    "ffgp_has_dev_options": (C.c_int, []),
     "ffgp_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "ffgp_destroy": (C.c_int, [C.c_void_p]),
     "ffgp_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -157,6 +158,12 @@ def _load():
 
 
 lib = _load()
+
+
+def has_dev_options():
+    """True for the development build (`make -C fidelityfusion_amd/csrc dev`, loaded through FFGP_LIB): the switches of
+    measured-and-rejected experiments are compiled in; the shipped library refuses their keys"""
+    return bool(lib.ffgp_has_dev_options())
 
 _handles = {}
 _lock = threading.Lock()

@@ -116,7 +116,13 @@ static void stage_collect(ffgp_handle* h) {
 
 extern "C" {
 
-const char* ffgp_version(void) { return "ffgp 0.1 (gfx950, fp64 MFMA)"; }
+#ifdef FFGP_DEV_OPTIONS
+const char* ffgp_version(void) { return "ffgp 0.2-dev (gfx950, fp64 MFMA; development build: the options of measured-and-rejected experiments are compiled in)"; }
+int ffgp_has_dev_options(void) { return 1; }
+#else
+const char* ffgp_version(void) { return "ffgp 0.2 (gfx950, fp64 MFMA)"; }
+int ffgp_has_dev_options(void) { return 0; }
+#endif
 
 struct RawGraph {
   ffgp_problem p;
@@ -278,6 +284,15 @@ int ffgp_set_stream(ffgp_handle* h, void* s) {
 int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
   if (!h || !key) return FFGP_ERR_ARG;
   rawg_drop(h);      // a captured call baked the old options in
+#ifndef FFGP_DEV_OPTIONS
+  // The shipped library keeps the switches a binding or a deployment tunes (thresholds, block sizes, the on-device cross-check,
+  // timing).  The switches of experiments that were measured and lost (docs/experiments.md) exist in the development build only
+  // (`make dev` -> libffgp_dev.so, ffgp_has_dev_options() == 1); here their keys are refused like any unknown key.
+  static const char* const dev_only[] = {"raw_graph_max_n", "diag_dbg", "la_split", "nb_big", "nb_big_until", "sb_lookahead", "sb_av_gemm", "sb_qr4", "q2_wave4", "eig_overlap", "chase_pack", "band_log2", "polite_pad_kb"};
+  for (const char* k : dev_only)
+    if (!strcmp(key, k)) return FFGP_ERR_ARG;
+  if (!strcmp(key, "diag_v2") && value != 4.0 && value != 0.0) return FFGP_ERR_ARG;   // (the round-3 pipelines: development build)
+#endif
   if (!strcmp(key, "raw_graph_max_n")) {
     h->raw_graph_max_n = (int)value;
     return FFGP_OK;

@@ -475,6 +475,7 @@ __device__ __forceinline__ bool d2_wait_ge(volatile int* p, int target, volatile
   return true;
 }
 
+#ifdef FFGP_DEV_OPTIONS   // the round-3 pipelines (diag_v2 = 1, 3): development build only
 template <int NW, bool DPP64>
 __global__ __launch_bounds__(NW * 64, NW / 2) void ffgp_potrf_diag128_v2(double* __restrict__ A, int lda, int nb, double* __restrict__ Dinv,
                                                                  int* info, int row_base, int prio) {
@@ -718,6 +719,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void ffgp_potrf_diag128_v2(double*
     if (!helper_barrier()) return;             // row block jj+1 of L is dead now: A2 of the next iteration overwrites it
   }
 }
+
+#endif   // FFGP_DEV_OPTIONS
 
 // ------------------------------------------------------------------------------------------------------------
 // potrf_diag128_v3 (round 4): the same chain, with the helpers reorganised around what tools/native/f16_probe.hip measured.
@@ -1231,6 +1234,7 @@ static int launch_diag(ffgp_handle* h, double* Ablk, int lda, int nb, double* Di
     h->diag_attr_set |= 1;
   }
   if (do_factor && h->diag_v2 && !h->diag_dbg) {   // the pipelined kernel (the barrier version keeps the inverse-only entry)
+#ifdef FFGP_DEV_OPTIONS
     if (!(h->diag_attr_set & 2)) {
       FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v2<8, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
@@ -1238,6 +1242,7 @@ static int launch_diag(ffgp_handle* h, double* Ablk, int lda, int nb, double* Di
                                    hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
       h->diag_attr_set |= 2;
     }
+#endif
     if (h->diag_v2 == 4) {   // round 4: owner-computes helpers, wave 0's SIMD partner steps aside
       if (!(h->diag_attr_set & 4)) {
         FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v3), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1250,12 +1255,15 @@ static int launch_diag(ffgp_handle* h, double* Ablk, int lda, int nb, double* Di
       else
         hipLaunchKernelGGL(ffgp_potrf_diag128_v3, dim3(1), dim3(512), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk, h->d_info,
                            row_base, h->aux_prio, 0L, 0L, 0);
-    } else if (h->diag_v2 == 3)   // the round-3 pivot step (32-bit DPP moves), kept for A/B runs
+    }
+#ifdef FFGP_DEV_OPTIONS
+    else if (h->diag_v2 == 3)   // the round-3 pivot step (32-bit DPP moves), kept for A/B runs
       hipLaunchKernelGGL((ffgp_potrf_diag128_v2<8, false>), dim3(1), dim3(512), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk,
                          h->d_info, row_base, h->aux_prio);
     else
       hipLaunchKernelGGL((ffgp_potrf_diag128_v2<8, true>), dim3(1), dim3(512), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk,
                          h->d_info, row_base, h->aux_prio);
+#endif
     return FFGP_OK;
   }
   hipLaunchKernelGGL(ffgp_potrf_diag128, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk,

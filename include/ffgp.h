@@ -214,6 +214,9 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
                         switches)                                                                  */
 int ffgp_set_option(ffgp_handle* h, const char* key, double value);
 const char* ffgp_version(void);
+/* 1 in the development build (`make dev`: the switches of measured-and-rejected experiments are accepted by ffgp_set_option), 0 in
+   the shipped library */
+int ffgp_has_dev_options(void);
 
 /* ---- building blocks ------------------------------------------------------------------------------------ */
 /* K(x1,x2) [+ Sigma extras when the matrix is square and symmetric].  Replaces kernel.forward

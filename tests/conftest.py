@@ -22,6 +22,14 @@ def pytest_configure(config):
         __graft_entry__.build()
 
 
+def need_dev_options():
+    """skip unless the loaded library is the development build (FFGP_LIB=fidelityfusion_amd/libffgp_dev.so): the switches of
+    measured-and-rejected experiments are not in the shipped libffgp.so"""
+    from fidelityfusion_amd import _lib
+    if not _lib.has_dev_options():
+        pytest.skip("option of a rejected experiment: development build only (FFGP_LIB=fidelityfusion_amd/libffgp_dev.so)")
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np

@@ -46,6 +46,34 @@ def _install_tensorly_stub():
         core, factors = tucker
         return multi_mode_dot(core, factors)
 
+    # The stub is asserted, not trusted: the published definition of the mode-n product, written out as an
+    # einsum per mode -- (T x_n M)[..., j, ...] = sum_i T[..., i, ...] M[j, i] -- must reproduce it on random tensors of orders 2-4,
+    # for every mode, with rectangular factors; multi_mode_dot (all modes, a subset, transposed factors) and the Tucker
+    # reconstruction (core x_0 U_0 x_1 U_1 ...) against their own einsums.
+    def _self_check():
+        g = torch.Generator().manual_seed(20240607)
+        letters = "abcd"
+        for order in (2, 3, 4):
+            shape = [3, 4, 5, 2][:order]
+            T_ = torch.randn(shape, generator=g, dtype=torch.float64)
+            Ms = [torch.randn((shape[m] + 1 + m, shape[m]), generator=g, dtype=torch.float64) for m in range(order)]
+            for m in range(order):
+                sub = letters[:order]
+                out = sub.replace(sub[m], "z")
+                want = torch.einsum("%s,z%s->%s" % (sub, sub[m], out), T_, Ms[m])
+                assert torch.allclose(mode_dot(T_, Ms[m], m), want, rtol=0, atol=1e-13), ("mode_dot", order, m)
+            sub = letters[:order]
+            expr = sub + "," + ",".join(letters[m].upper() + letters[m] for m in range(order)) + "->" + sub.upper()
+            want = torch.einsum(expr, T_, *Ms)
+            assert torch.allclose(multi_mode_dot(T_, Ms), want, rtol=0, atol=1e-12), ("multi_mode_dot", order)
+            assert torch.allclose(tucker_to_tensor((T_, Ms)), want, rtol=0, atol=1e-12), ("tucker_to_tensor", order)
+            if order >= 3:      # a subset of the modes, and transposed factors
+                want = torch.einsum("%s,%s->%s" % (sub, "z" + sub[1], sub.replace(sub[1], "z")), T_, Ms[1])
+                assert torch.allclose(multi_mode_dot(T_, [Ms[1]], modes=[1]), want, rtol=0, atol=1e-13)
+                assert torch.allclose(multi_mode_dot(T_, [M.T.contiguous() for M in Ms], transpose=True), torch.einsum(expr, T_, *Ms),
+                                      rtol=0, atol=1e-12)
+    _self_check()
+
     tl.set_backend = lambda name: None
     tl.tenalg = tenalg
     tl.ones = lambda shape, **kw: torch.ones(shape)

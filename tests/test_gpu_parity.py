@@ -466,8 +466,7 @@ def test_composed_kernel_posterior_is_cached(golden):
         def ffgp_potrf_rows(self, *a):
             calls.append(1)
             return real(*a)
-    F.lib, keep = _Spy(), F.lib
-    try:
+    with F.patched_lib(_Spy()):
         with torch.no_grad():
             m1, v1 = m(X, Y, Xs)                  # factorises (K_s^T rides along)
             m2, v2 = m(X, Y, Xs[:7])              # cached factor
@@ -483,8 +482,6 @@ def test_composed_kernel_posterior_is_cached(golden):
         mean, var = m(X, Y, xq)
         gx, = torch.autograd.grad(mean.sum() + var.diagonal().sum(), xq)
         assert rel(gx, g["g_Xs"]) < 1e-7 and len(calls) == 1      # (freezing bumps no version counter: still the first factor)
-    finally:
-        F.lib = keep
     # appended points: the extended factor answers like a fresh one
     post = F.Posterior(X[:80], Y[:80], None, None, torch.tensor([0.3]), tree=m.kernel.pair())
     post.append(X[80:], Y[80:])
@@ -816,13 +813,10 @@ def test_small_problems_batched_call():
         def ffgp_nlml_fused_small_batch_async(self, h, nF, *a):  # (with functional.DEFER_RAW_ERRORS)
             calls.append(nF)
             return real_async(h, nF, *a)
-    F.lib, keep = _Spy(), F.lib
-    try:
+    with F.patched_lib(_Spy()):
         vals = negative_log_likelihood_many(models, xs, ys)
         assert calls == [len(specs)] and vals.shape == (len(specs),)
         (vals * T(np.linspace(0.5, 1.5, len(specs)))).sum().backward()
-    finally:
-        F.lib = keep
     got = [(v.detach().clone(), [p_.grad.clone() for p_ in m.parameters()], (y[0] if isinstance(y, list) else y).grad.clone())
            for v, m, y in zip(vals, models, ys)]
     for i, (m, x, y) in enumerate(zip(models, xs, ys)):
@@ -840,13 +834,13 @@ def test_small_problems_batched_call():
     bad_y = [ys[0].detach(), -3.0 * torch.eye(20, device=DEV, dtype=torch.float64)]
     with pytest.raises(torch.linalg.LinAlgError):
         negative_log_likelihood_many(models[:3], xs[:3], [bad_y, ys[1], ys[2]])
-    F.DEFER_RAW_ERRORS = True
+    F.defer_raw_errors(True)
     try:
         out = negative_log_likelihood_many(models[:3], xs[:3], [bad_y, ys[1], ys[2]])
         with pytest.raises(torch.linalg.LinAlgError):
             out.sum().backward()
     finally:
-        F.DEFER_RAW_ERRORS = False
+        F.defer_raw_errors(False)
     # a member that is too large: the individual calls
     big = cigp(kernel.ARDKernel(2), 0.5).double().to(DEV)
     xb, yb = T(rng.uniform(0, 1, (200, 2))), T(rng.standard_normal((200, 1)))
@@ -884,14 +878,11 @@ def test_equal_shape_blocks_share_one_chain(n, d, F_):
         def ffgp_nlml_fused_batch(self, h, nF, *a):
             calls.append(nF)
             return real(h, nF, *a)
-    F.lib, keep = _Spy(), F.lib
-    try:
+    with F.patched_lib(_Spy()):
         vals = negative_log_likelihood_many(models, xs, ys)
         (vals * T(np.linspace(0.5, 1.5, F_))).sum().backward()
         with torch.no_grad():
             vals_ng = negative_log_likelihood_many(models, xs, ys)      # forward only: no gradient stages, same values
-    finally:
-        F.lib = keep
     assert calls == [F_, F_] and vals.shape == (F_,)
     assert torch.equal(vals_ng, vals.detach())
     got = [(v.detach().clone(), [p_.grad.clone() for p_ in m.parameters()], y.grad.clone()) for v, m, y in zip(vals, models, ys)]
@@ -946,13 +937,13 @@ def test_raw_path_defers_not_pd_to_backward():
     yv = -3.0 * torch.eye(70, device=DEV, dtype=torch.float64)
     m = cigp(kernel.ARDKernel(2), 0.5).double().to(DEV)
     assert F.raw_path(m.kernel, X, Y, m.log_beta) is not None
-    assert F.DEFER_RAW_ERRORS is False
+    assert F.nlml.DEFER_RAW_ERRORS is False
     with pytest.raises(torch.linalg.LinAlgError):
         m.negative_log_likelihood(X, [Y, yv])               # the reference's semantics: at the call
     ok = m.negative_log_likelihood(X, Y)
     ok.backward()
     assert torch.isfinite(ok) and torch.isfinite(m.log_beta.grad).all()
-    F.DEFER_RAW_ERRORS = True
+    F.defer_raw_errors(True)
     try:
         loss = m.negative_log_likelihood(X, [Y, yv])            # enqueued: no error yet
         with pytest.raises(torch.linalg.LinAlgError):
@@ -966,13 +957,15 @@ def test_raw_path_defers_not_pd_to_backward():
         with torch.no_grad(), pytest.raises(torch.linalg.LinAlgError):
             m.negative_log_likelihood(X, [Y, yv])
     finally:
-        F.DEFER_RAW_ERRORS = False
+        F.defer_raw_errors(False)
     assert torch.isfinite(m.negative_log_likelihood(X, Y))
 
 
 def test_raw_graph_replay():
     """option raw_graph_max_n: the third identical raw-parameter call replays a captured graph (off by default -- no faster on this
     runtime); values and gradients are bit-identical, a changed input or option drops the graph"""
+    from conftest import need_dev_options
+    need_dev_options()
     from fidelityfusion_amd import _lib, kernel
     from fidelityfusion_amd.cigp_v10 import cigp
     rng = np.random.default_rng(6)
@@ -2342,7 +2335,9 @@ def test_no_grad_evaluation_skips_the_gradient_pipeline(monkeypatch):
             note(g)
             return real_raw_async(h, p, l, out, g)
     real_raw, real_raw_async = F.lib.ffgp_nlml_fused_raw, F.lib.ffgp_nlml_fused_raw_async
-    monkeypatch.setattr(F, "lib", _Spy())
+    spy = _Spy()
+    for mod in (F.nlml, F.linalg, F.posterior, F.blocks):      # (every submodule calls the library through its own `lib`)
+        monkeypatch.setattr(mod, "lib", spy)
     gen = torch.Generator().manual_seed(3)
     X = torch.rand((200, 3), generator=gen, dtype=torch.float64).to(DEV)
     Y = torch.randn((200, 2), generator=gen, dtype=torch.float64).to(DEV)

@@ -54,6 +54,8 @@ def test_stage1_band_reduction(n, kind):
 @pytest.mark.parametrize("opts", [{"sb_av_gemm": 1}, {"sb_qr4": 1}, {"sb_lookahead": 1}, {"sb_qr4": 1, "sb_lookahead": 1}],
                          ids=lambda o: "+".join(sorted(o)))
 def test_stage1_band_reduction_alternative_kernels(opts):
+    from conftest import need_dev_options
+    need_dev_options()
     """the band reduction's off-by-default forms (A Y on the general GEMM; leaf QRs on 256-thread workgroups; the next panel's QR
     chain on the side stream) meet the same properties -- four leaves per panel at first, the last one ragged"""
     from fidelityfusion_amd import _lib
@@ -173,11 +175,15 @@ def test_syevd_three_level_tsqr_above_8192(qr4):
     d = torch.cdist(X, X)
     K = torch.exp(-0.5 * d * d)
     del d
-    _lib.set_option("sb_qr4", qr4)
+    if qr4:
+        from conftest import need_dev_options
+        need_dev_options()
+        _lib.set_option("sb_qr4", qr4)
     try:
         W, Z = E.eigh(K)
     finally:
-        _lib.set_option("sb_qr4", 0)
+        if qr4:
+            _lib.set_option("sb_qr4", 0)
     ref = torch.linalg.eigvalsh(K)
     scale = float(ref.abs().max())
     assert float((W - ref).abs().max()) <= 1e-13 * scale

@@ -4,6 +4,8 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _devlib  # noqa: F401,E402  (development build: these switches are not in the shipped library)
 import torch
 
 from fidelityfusion_amd import _lib

@@ -1,5 +1,7 @@
 import os, sys, time
 sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _devlib  # noqa: F401,E402  (development build: these switches are not in the shipped library)
 import torch
 from fidelityfusion_amd import _lib, kernel
 from fidelityfusion_amd.cigp_v10 import cigp
