@@ -11,9 +11,10 @@ Round 4 split the former 1 600-line module by subject; this file re-exports ever
     posterior.py  the kept factor (`Posterior`, `PosteriorCache`)
     blocks.py     several blocks in flight on one GPU (`concurrent_blocks`, `threaded_blocks`)
     kdesc.py, _common.py   descriptor packing, shared plumbing
-Module state lives where it is used: set `nlml.DEFER_RAW_ERRORS` through `defer_raw_errors(True / False)`.
+Module state lives where it is used: set `nlml_module.DEFER_RAW_ERRORS` through `defer_raw_errors(True / False)`.
 """
-from . import _lib, blocks, kdesc, linalg, nlml, posterior
+from . import _lib, blocks, kdesc, linalg, posterior
+from . import nlml as nlml_module     # (the name `nlml` is the likelihood FUNCTION below, as it always was)
 from ._common import NEG_INF, _check_same_D, _check_xy, _dev, _device_of, _ptr, _raise_not_pd, _split_kfun, _weights
 from ._lib import FFGP_LL_V1, FFGP_LL_V2, FFGP_VAR_DIAG, FFGP_VAR_FULL, PI_TRUNC, Grads, KDesc, KDescGrads, Problem, check, lib
 from .blocks import (_mark_used_on, _pending, _slot_args, _threaded_blocks_run, concurrent_blocks, configure_queues, reserve_block_streams,
@@ -28,11 +29,14 @@ from .nlml import (SMALL_BATCH_MAX_d, SMALL_BATCH_MAX_D, SMALL_BATCH_MAX_N, _NLM
                    raw_ok, raw_path)
 from .posterior import Posterior, PosteriorCache, PosteriorCacheMixin, _PosteriorQuery
 
+SUBMODULES = (nlml_module, linalg, posterior, blocks)     # every module that calls the library through its own `lib` name
+
 
 def defer_raw_errors(on):
-    """Opt in to / out of the deferred status of GPU-resident training steps (see nlml.DEFER_RAW_ERRORS); returns the previous setting."""
-    prev = nlml.DEFER_RAW_ERRORS
-    nlml.DEFER_RAW_ERRORS = bool(on)
+    """Opt in to / out of the deferred status of GPU-resident training steps (see nlml.py, DEFER_RAW_ERRORS); returns the previous
+    setting."""
+    prev = nlml_module.DEFER_RAW_ERRORS
+    nlml_module.DEFER_RAW_ERRORS = bool(on)
     return prev
 
 
@@ -44,7 +48,7 @@ class patched_lib:
         self.obj = obj
 
     def __enter__(self):
-        self.saved = [(m, m.lib) for m in (nlml, linalg, posterior, blocks)]
+        self.saved = [(m, m.lib) for m in SUBMODULES]
         for m, _ in self.saved:
             m.lib = self.obj
         return self.obj

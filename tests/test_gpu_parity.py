@@ -937,7 +937,7 @@ def test_raw_path_defers_not_pd_to_backward():
     yv = -3.0 * torch.eye(70, device=DEV, dtype=torch.float64)
     m = cigp(kernel.ARDKernel(2), 0.5).double().to(DEV)
     assert F.raw_path(m.kernel, X, Y, m.log_beta) is not None
-    assert F.nlml.DEFER_RAW_ERRORS is False
+    assert F.nlml_module.DEFER_RAW_ERRORS is False
     with pytest.raises(torch.linalg.LinAlgError):
         m.negative_log_likelihood(X, [Y, yv])               # the reference's semantics: at the call
     ok = m.negative_log_likelihood(X, Y)
@@ -2336,7 +2336,7 @@ def test_no_grad_evaluation_skips_the_gradient_pipeline(monkeypatch):
             return real_raw_async(h, p, l, out, g)
     real_raw, real_raw_async = F.lib.ffgp_nlml_fused_raw, F.lib.ffgp_nlml_fused_raw_async
     spy = _Spy()
-    for mod in (F.nlml, F.linalg, F.posterior, F.blocks):      # (every submodule calls the library through its own `lib`)
+    for mod in F.SUBMODULES:      # (every submodule calls the library through its own `lib`)
         monkeypatch.setattr(mod, "lib", spy)
     gen = torch.Generator().manual_seed(3)
     X = torch.rand((200, 3), generator=gen, dtype=torch.float64).to(DEV)
