@@ -230,7 +230,7 @@ def gpu_parity_values(dev, names):
         ll.backward()
         with torch.no_grad():
             mean, var = m(Xt, Yt.detach(), Xs)
-        out[name] = {"ll": float(ll),
+        out[name] = {"ll": float(ll.detach()),
                      "grads": {"length_scales": m.kernel.length_scales.grad.cpu().numpy(),
                                "signal_variance": m.kernel.signal_variance.grad.cpu().numpy(),
                                "log_beta": m.log_beta.grad.cpu().numpy(), "Y": Yt.grad.cpu().numpy()},
