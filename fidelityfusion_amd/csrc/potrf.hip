@@ -461,12 +461,12 @@ __device__ __forceinline__ void d2_st(volatile int* p, int v) {
   asm volatile("ds_write_b32 %0, %1" : : "v"(off), "v"(v) : "memory");
 }
 
-__device__ __forceinline__ bool d2_wait_ge(volatile int* p, int target, volatile int* abort_flag, int* info) {
+__device__ __forceinline__ bool d2_wait_ge(volatile int* p, int target, volatile int* abort_flag, int* info, int site = 0) {
   int spins = 0;
   while (d2_ld(p) < target) {
     __builtin_amdgcn_s_sleep(1);
     if ((++spins & 63) == 0 && (spins > (1 << 21) || d2_ld(abort_flag))) {   // ~1 s of polling: something upstream died
-      if (!d2_ld(abort_flag)) atomicExch(info, FFGP_DIAG_WATCHDOG);
+      if (!d2_ld(abort_flag)) atomicExch(info, FFGP_DIAG_WATCHDOG + site);    // (site: which hand-off; ffgp_map_info prints it)
       d2_st(abort_flag, 1);
       return false;
     }
@@ -753,6 +753,7 @@ struct D3Flags {      // ints in LDS, behind the block image
   int simd[8];
   int cntA[8];
   int rows[8];        // rows[s]: bit i = L[i][s] is final and in LDS (bit s + 1 is set by wave 0's G(s), the others by the blocks' owners)
+  int prog[8];        // [0] wave 0: 16 jj + phase; [1 + hidx]: the helper's current task index (post-mortem of a timed-out hand-off)
 };
 
 #define D3_NH 6
@@ -870,6 +871,8 @@ __device__ __forceinline__ void d3_store_inverse_rows(double* S, double* __restr
   }
 }
 
+__device__ int ffgp_d3_dbg[32];     // state of the flags when a hand-off timed out (development aid)
+
 __global__ __launch_bounds__(512, 4) void ffgp_potrf_diag128_v3(double* __restrict__ A, int lda, int nb, double* __restrict__ Dinv,
                                                                 int* info, int row_base, int prio, long sA, long sD, int sInfo) {
   // (batched factorisation: workgroup b factors block b -- its own matrix, Dinv store and status word)
@@ -897,9 +900,16 @@ __global__ __launch_bounds__(512, 4) void ffgp_potrf_diag128_v3(double* __restri
     for (int r = 0; r < 4; ++r) D[r] = x[r];
   }
   // ---- roles: every wave publishes its SIMD; one barrier; the wave that shares wave 0's SIMD steps aside
+  // d2_st is inline asm: the compiler's wait-count pass does not see the LDS store inside it and puts NO s_waitcnt in front of the
+  // barrier -- a wave could pass the barrier with its store still in flight.  Under load that happened: a wave read simd[w] before
+  // wave w's store had landed (0, which matched wave 0's SIMD 0), the waves disagreed about who the partner is, one helper role stayed
+  // empty and the others waited for it until the watchdog fired (found by the co-running test leg; only ever seen beside two
+  // eigensolvers).  Every flag store that a barrier is meant to publish is therefore drained explicitly.
   if (tid < (int)(sizeof(D3Flags) / sizeof(int))) d2_st(reinterpret_cast<volatile int*>(fl) + tid, 0);
+  D2_LDS_FENCE();
   __syncthreads();
   if (lane == 0) d2_st(&fl->simd[wave], d3_simd_id());
+  D2_LDS_FENCE();
   __syncthreads();
   int partner = 4;
   {
@@ -937,10 +947,11 @@ __global__ __launch_bounds__(512, 4) void ffgp_potrf_diag128_v3(double* __restri
 #undef F16_S
       }
       D2_TRACE(64 + jj);     // the 16 pivots are done
+      if (lane == 0) d2_st(&fl->prog[0], 16 * jj + 1);
       // operands of G(jj), register images left by their owners: requested now, under the post-processing below
       if (jj >= 1 && jj < 7) {
-        if (!d2_wait_ge(&fl->hs, jj + 1, ab, info) || !d2_wait_ge(&fl->hd, jj + 1, ab, info)) break;
-        if (jj < 6 && !d2_wait_ge(&fl->h2, jj + 1, ab, info)) break;
+        if (!d2_wait_ge(&fl->hs, jj + 1, ab, info, 1) || !d2_wait_ge(&fl->hd, jj + 1, ab, info, 2)) break;
+        if (jj < 6 && !d2_wait_ge(&fl->h2, jj + 1, ab, info, 3)) break;
         const double* Sb = D3_IMG(jj + 1, jj);
         const double* Sd = D3_IMG(jj + 1, jj + 1);
         const double* Sb2 = D3_IMG(min(jj + 2, 7), jj);
@@ -1068,11 +1079,12 @@ __global__ __launch_bounds__(512, 4) void ffgp_potrf_diag128_v3(double* __restri
 #pragma unroll 1
   for (int t = 0; t < D3_MAXTASKS; ++t) {
     const int desc = __builtin_amdgcn_readlane(my_desc, t);
+    if (lane == 0) d2_st(&fl->prog[1 + hidx], 1 + t);      // (post-mortem of a timed-out hand-off: where every helper stood)
     if (desc == D3_END) break;
     const int type = desc & 3, i = (desc >> 2) & 7, k = (desc >> 5) & 7, flag = (desc >> 8) & 3, s = (desc >> 10) & 7;
     if (type == D3_STAGE) {
       if (hidx == 0 && s >= 1) D2_TRACE(31 + 4 * s);          // (slot 35 + 4 (s - 1): the previous stage is complete)
-      if (!d2_wait_ge(&fl->seqF, s + 1, ab, info)) return;
+      if (!d2_wait_ge(&fl->seqF, s + 1, ab, info, 4)) return;
       if (hidx == 0) D2_TRACE(32 + 4 * s);
       Ws = S + blk_off(s, s);
       rows = &fl->rows[s];
@@ -1105,7 +1117,17 @@ __global__ __launch_bounds__(512, 4) void ffgp_potrf_diag128_v3(double* __restri
           while (((have = d2_ld(&fl->rows[p])) & need) != need) {
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 63) == 0 && (spins > (1 << 21) || d2_ld(ab))) {
-              if (!d2_ld(ab)) atomicExch(info, FFGP_DIAG_WATCHDOG);
+              if (!d2_ld(ab)) {
+                atomicExch(info, FFGP_DIAG_WATCHDOG + 5);
+                if (lane == 0) {     // post-mortem: which hand-off never came (printed by ffgp_map_info)
+                  ffgp_d3_dbg[0] = hidx; ffgp_d3_dbg[1] = s; ffgp_d3_dbg[2] = p; ffgp_d3_dbg[3] = i; ffgp_d3_dbg[4] = k; ffgp_d3_dbg[5] = have;
+                  ffgp_d3_dbg[6] = d2_ld(&fl->seqF); ffgp_d3_dbg[7] = d2_ld(&fl->hs); ffgp_d3_dbg[8] = d2_ld(&fl->hd); ffgp_d3_dbg[9] = d2_ld(&fl->h2);
+                  for (int z = 0; z < 8; ++z) ffgp_d3_dbg[10 + z] = d2_ld(&fl->rows[z]);
+                  for (int z = 0; z < 8; ++z) ffgp_d3_dbg[18 + z] = d2_ld(&fl->cntA[z]);
+                  ffgp_d3_dbg[26] = t;
+                  for (int z = 0; z < 5; ++z) ffgp_d3_dbg[27 + z] = d2_ld(&fl->prog[z]) | (d2_ld(&fl->prog[z + (z < 3 ? 5 : 0)]) << 16);
+                }
+              }
               d2_st(ab, 1);
               return;
             }
@@ -1132,7 +1154,7 @@ __global__ __launch_bounds__(512, 4) void ffgp_potrf_diag128_v3(double* __restri
       // waited here for the slowest one was late for the next column's urgent updates.
       if (hidx == 0) D2_TRACE(34 + 4 * s);
       if (s >= 2) {
-        if (!d2_wait_ge(&fl->cntA[s - 1], D3_NH, ab, info)) return;
+        if (!d2_wait_ge(&fl->cntA[s - 1], D3_NH, ab, info, 6)) return;
         d3_store_inverse_rows(S, Dinv, Xn, s - 1, hidx, g, c);
         D2_LDS_FENCE();
       }
@@ -1152,7 +1174,7 @@ __global__ __launch_bounds__(512, 4) void ffgp_potrf_diag128_v3(double* __restri
       D2_LDS_FENCE();
       if (lane == 0) d3_add(&fl->cntA[s], 1);
       if (s == 7) {                            // the last row block: nothing follows, store it now
-        if (!d2_wait_ge(&fl->cntA[7], D3_NH, ab, info)) return;
+        if (!d2_wait_ge(&fl->cntA[7], D3_NH, ab, info, 7)) return;
         d3_store_inverse_rows(S, Dinv, Xn, 7, hidx, g, c);
       }
     }
@@ -1545,7 +1567,18 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
 // status word -> return code: a pivot index passes through; the diagonal-block kernel's watchdog is a library error
 int ffgp_map_info(int v) {
   if (v >= FFGP_DIAG_WATCHDOG) {
-    fprintf(stderr, "[ffgp] potrf_diag128: a wave waited ~1 s for a hand-off inside the kernel and gave up (internal error)\n");
+    fprintf(stderr, "[ffgp] potrf_diag128: a wave waited ~1 s for a hand-off inside the kernel and gave up (internal error; hand-off %d)\n",
+            v - FFGP_DIAG_WATCHDOG);
+    int dbg[32];
+    if (hipMemcpyFromSymbol(dbg, HIP_SYMBOL(ffgp_d3_dbg), sizeof(dbg)) == hipSuccess) {
+      fprintf(stderr, "[ffgp]   helper %d stage %d column %d block (%d, %d) have 0x%x task %d | seqF %d hs %d hd %d h2 %d | rows", dbg[0], dbg[1], dbg[2],
+              dbg[3], dbg[4], dbg[5], dbg[26], dbg[6], dbg[7], dbg[8], dbg[9]);
+      for (int z = 0; z < 8; ++z) fprintf(stderr, " %x", dbg[10 + z]);
+      fprintf(stderr, " | cntA");
+      for (int z = 0; z < 8; ++z) fprintf(stderr, " %d", dbg[18 + z]);
+      fprintf(stderr, " | prog w0 %d h0..5 %d %d %d %d %d %d\n", dbg[27] & 0xffff, dbg[28] & 0xffff, dbg[29] & 0xffff, dbg[30] & 0xffff, dbg[31] & 0xffff,
+              dbg[27] >> 16, dbg[28] >> 16);
+    }
     return FFGP_ERR_HIP;
   }
   return v;

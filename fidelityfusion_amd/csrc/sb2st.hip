@@ -131,6 +131,15 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
   double* AB = p.AB;
   double* vs = vsA;
   double* v2s = vsB;
+  // per-lane byte offsets of the interior step's entries from AB + c0 * SB_LDB (lane (i, h) holds row i, columns cc = 16 h + q):
+  // diagonal block entry (i, cc) lives at min(i, cc) * (SB_LDB - 1) + max(i, cc), the block below's (32 + i, cc) at cc * (SB_LDB - 1) + 32 + i
+  unsigned offD[16], offB[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int cc = h * 16 + q;
+    offD[q] = (unsigned)(min(i, cc) * (SB_LDB - 1) + max(i, cc)) * 8u;
+    offB[q] = (unsigned)(cc * (SB_LDB - 1) + 32 + i) * 8u;
+  }
   for (int s = p.s_begin + wg; s < p.s_end; s += nwg) {
     int c0 = s + 1;
     int len = min(32, n - c0);
@@ -157,6 +166,89 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
       const bool more = (r0 <= n - 1);
       const int nrow = more ? min(32, n - r0) : 0;
       CH_STAMP(0, 0, k);    // the predecessor's counter has been seen
+      if (len == 32 && nrow == 32) {
+        // ---- INTERIOR step (both blocks full: every step but the last one or two of a sweep).  Round 4: the general body below
+        // spends ~85 % of its ~1500 instructions on per-entry bounds predicates (exec-mask juggling around every load and store) and
+        // 64-bit address arithmetic; one wave issues an instruction every ~5 cycles, so the step was issue-bound at ~4 us.  Here
+        // every entry exists: the loads and stores are unconditional with per-lane byte offsets computed once per kernel (scalar
+        // base + 32-bit offset addressing), and the diagonal block's mirrored lanes compute bit-identical values (t1 + t2 with plain
+        // multiplies and one add: the two products only swap places), so BOTH triangles store -- to the same address, the same bits.
+        const char* base = reinterpret_cast<const char*>(AB + (size_t)c0 * SB_LDB);
+        char* wbase = reinterpret_cast<char*>(AB + (size_t)c0 * SB_LDB);
+        double D[16], B[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) D[q] = ldb(reinterpret_cast<const double*>(base + offD[q]));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) B[q] = ldb(reinterpret_cast<const double*>(base + offB[q]));
+        CH_STAMP(1, 1, k);
+        __syncthreads();   // vs complete
+        double vq[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) vq[q] = vs[h * 16 + q];
+        const double vi = vs[i];
+        double pr = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) pr = __builtin_fma(D[q], vq[q], pr);
+        pr = halves_sum(pr);
+        const double a2 = wsum32(vi * pr, lane);
+        const double w = tau * pr - 0.5 * tau * tau * a2 * vi;
+        if (h == 0) wsh[i] = w;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const double t1 = __dmul_rn(vi, wsh[h * 16 + q]), t2 = __dmul_rn(w, vq[q]);      // (no contraction: see above)
+          D[q] = __dsub_rn(D[q], __dadd_rn(t1, t2));
+          stb(reinterpret_cast<double*>(wbase + offD[q]), D[q]);
+        }
+        CH_STAMP(2, 0, k);
+        double sb = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sb = __builtin_fma(B[q], vq[q], sb);
+        sb = halves_sum(sb);
+        const double ts = tau * sb;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) B[q] = __builtin_fma(-ts, vq[q], B[q]);
+        double tau_n, beta_n;
+        const double x0 = __shfl(B[0], i);           // first column: lane i of half 0
+        const double v2i = house32(x0, i, lane, 32, tau_n, beta_n);
+        if (h == 0) {
+          B[0] = (i == 0) ? beta_n : 0.0;
+          v2s[i] = v2i;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Mt[i][h * 16 + q] = (h * 16 + q == 0) ? 0.0 : v2i * B[q];
+        __syncthreads();
+        {
+          double u = 0.0;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) u += Mt[h * 16 + r][i];
+          u = halves_sum(u);
+          if (h == 0) ush[i] = u;
+        }
+        __syncthreads();
+        const double tv = tau_n * v2i;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          B[q] = __builtin_fma(-tv, ush[h * 16 + q], B[q]);
+          stb(reinterpret_cast<double*>(wbase + offB[q]), B[q]);
+        }
+        CH_STAMP(3, 0, k);
+        ++k;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the publish protocol of the general body, below)
+        CH_STAMP(4, 0, k - 1);
+        if (lane == 0) __hip_atomic_store(p.prog + s, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (h == 0) p.V2[((size_t)s * p.K + k) * 32 + i] = v2i;
+        if (lane == 0) p.tau2[(size_t)s * p.K + k] = tau_n;
+        c0 = r0;
+        tau = tau_n;
+        double* t_ = vs;
+        vs = v2s;
+        v2s = t_;
+        CH_STAMP(5, 0, k - 1);
+        if (seen < k + 2) seen = chase_wait(p.prog + s - 1, k + 2, p.err);
+        continue;
+      }
       // ---- both blocks of the step are requested up front
       double D[16], B[16];
 #pragma unroll
@@ -446,7 +538,7 @@ template <bool FWD>
 __global__ __launch_bounds__(256, 4) void q2_apply(ApplyArgs p) {
   __shared__ double Zs[2][32 * XLD];      // physical halves of the window
   __shared__ double Xs[2][32 * XLD];      // the two k-halves of X
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = p.n;
   int slab = blockIdx.x;
   if (p.skip8) {
@@ -587,7 +679,7 @@ __global__ __launch_bounds__(256, NC == 1 ? 2 : 1) void q2_apply_wave4(ApplyArgs
   extern __shared__ double q2w_sm[];
   constexpr int TILE = 32 * XLD;                            // one band of one column tile
   double* ring = q2w_sm;                                    // [Q2W_RING][NC][32][XLD]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   double* xs = q2w_sm + Q2W_RING * NC * TILE + wave * NC * TILE;   // this wave's X tiles [NC][32][XLD]
   const int n = p.n;
   const int col0 = blockIdx.x * 16 * NC;

@@ -58,7 +58,7 @@ struct QrShared {
 // reflector travels through LDS, one workgroup barrier per column.  On exit a[] holds V below the diagonal and R on / above it
 // (a[0] of lane i <= c), sh.T the compact-WY T, sh.tau the scalar factors.  Ends with a barrier.
 __device__ __forceinline__ void qr512(double (&a)[16], QrShared& sh, const int tid) {
-  const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, i = lane & 31;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, i = lane & 31;
   const int c = wave * 2 + half;
   for (int j = 0; j < 32; ++j) {
     const int buf = j & 1;
@@ -181,7 +181,7 @@ struct Qr4Shared {
 };
 
 __device__ __forceinline__ void qr512x4(double (&a)[4][16], Qr4Shared& sh, const int tid) {
-  const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, i = lane & 31;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, i = lane & 31;
   const int hw = wave * 2 + half;
   if (hw == 0) {
     sh.x[0][i] = (i > 0) ? a[0][0] : 0.0;
@@ -591,7 +591,7 @@ struct AvArgs {
 __global__ __launch_bounds__(256, 4) void sy2sb_av(AvArgs p) {
   __shared__ double As[128][17];
   __shared__ double Ys[16][33];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
   const int r0 = blockIdx.x * 128;
   const int k0 = blockIdx.y * p.kc, k1 = min(p.m, k0 + p.kc);
   if (k0 >= k1) return;

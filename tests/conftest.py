@@ -60,6 +60,7 @@ class _Noise:
         self.count = 0
         self.patched = []
         self.thread = None
+        self.error = None
 
     def start(self):
         import functools
@@ -82,6 +83,14 @@ class _Noise:
         self.thread.start()
 
     def _loop(self):
+        try:
+            self._loop_body()
+        except BaseException as e:   # noqa: BLE001  (a dead load must fail the run, not silently stop disturbing it)
+            import traceback
+            self.error = "".join(traceback.format_exception(type(e), e, e.__traceback__))
+            self.parked.set()
+
+    def _loop_body(self):
         import time
         import torch
         from fidelityfusion_amd import _lib
@@ -128,7 +137,9 @@ class _Noise:
 
     def off(self):
         self.run.clear()
-        self.parked.wait(30)
+        self.parked.wait(60)
+        if self.error:
+            raise RuntimeError("the background load of the GPU tests died:\n" + self.error)
 
     def end(self):
         import torch

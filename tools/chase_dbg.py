@@ -1,6 +1,8 @@
 """placement sweep of the bulge chase at N = 8192: option chase_pack (every pack-th workgroup works)"""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _devlib  # noqa: F401,E402  (development build: these switches are not in the shipped library)
 import torch
 from fidelityfusion_amd import eigh as E, _lib
 n = 8192

@@ -49,5 +49,20 @@ def check_chase_publish(asm=None):
     return found
 
 
+def check_diag_barriers(asm=None):
+    """In `ffgp_potrf_diag128_v3` the role hand-out publishes flag words with inline-asm LDS stores and then meets a workgroup barrier:
+    the compiler's wait-count pass does not see inside inline asm, so every `s_barrier` must be preceded by an explicit
+    `s_waitcnt lgkmcnt(0)` (round 4: without it a wave passed the barrier with its store in flight, the waves disagreed about their
+    roles under load and a hand-off timed out)."""
+    body = function_body(asm or device_asm("potrf.hip"), "ffgp_potrf_diag128_v3")
+    bars = [i for i, l in enumerate(body) if l.strip() == "s_barrier"]
+    assert len(bars) == 2, "expected the two barriers of the role hand-out, found %d" % len(bars)
+    for b in bars:
+        prev = [l.strip() for l in body[max(0, b - 4):b] if l.strip() and not l.strip().startswith(";")]
+        assert any(re.match(r"s_waitcnt .*lgkmcnt\(0\)", l) for l in prev[-2:]), "no lgkmcnt(0) drain right before s_barrier: %r" % prev
+    return bars
+
+
 if __name__ == "__main__":
+    print("ffgp_potrf_diag128_v3: barriers behind an LDS drain:", check_diag_barriers())
     print("sb2st_chase: counter stores behind an explicit vmcnt(0):", check_chase_publish())

@@ -4,6 +4,8 @@ import os
 import sys
 import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _devlib  # noqa: F401,E402  (development build: these switches are not in the shipped library)
 import torch
 from fidelityfusion_amd import eigh as E
 from fidelityfusion_amd import _lib
