@@ -58,8 +58,11 @@ def check_diag_barriers(asm=None):
     bars = [i for i, l in enumerate(body) if l.strip() == "s_barrier"]
     assert len(bars) == 2, "expected the two barriers of the role hand-out, found %d" % len(bars)
     for b in bars:
-        prev = [l.strip() for l in body[max(0, b - 4):b] if l.strip() and not l.strip().startswith(";")]
-        assert any(re.match(r"s_waitcnt .*lgkmcnt\(0\)", l) for l in prev[-2:]), "no lgkmcnt(0) drain right before s_barrier: %r" % prev
+        prev = [l.strip() for l in body[max(0, b - 16):b] if l.strip() and not l.strip().startswith(";")]
+        drains = [j for j, l in enumerate(prev) if re.match(r"s_waitcnt .*lgkmcnt\(0\)", l)]
+        assert drains, "no lgkmcnt(0) drain in front of s_barrier: %r" % prev
+        after = prev[drains[-1] + 1:]
+        assert not any(l.startswith("ds_") for l in after), "an LDS instruction between the drain and the barrier: %r" % after
     return bars
 
 
