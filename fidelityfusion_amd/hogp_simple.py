@@ -19,11 +19,13 @@ Kept quirks: ONE kernel module is shared by the input space and every output mod
 0..d-1 as float columns; `forward` needs `log_likelihood` to have been called (it reads the cached `K`, `K_eigen`,
 `A`, `g`); the "variance" is diag(K) + (A-weighted squared eigenvector products) (:60-75).
 
-`variance_mode` (constructor keyword, attribute): "reference" (default) evaluates `K_star @ K_x.inverse() @ U_x` in the
-reference's order of operations (:68) with an EXPLICIT inverse of the jitter-free kernel matrix followed by two GEMMs; the
-inverse is formed from the eigenpairs the likelihood call already produced, K_x^-1 = (U / lambda) U^T on the fp64 GEMM (the
-reference's `.inverse()` is LAPACK's LU; on these numerically singular matrices -- cond 5e6 ... 1e13 on the fixtures -- any
-two inverses agree to ~cond * eps, which is also what the fixtures of the reference's own LU hold this to).  "eigen"
+`variance_mode` (constructor keyword, attribute): "explicit_inverse" (default; "reference" is accepted as its old name) evaluates
+`K_star @ K_x.inverse() @ U_x` in the reference's order of operations (:68) with an EXPLICIT inverse of the jitter-free kernel
+matrix followed by two GEMMs -- but the inverse is NOT the reference's LU inverse: it is formed from the eigenpairs the likelihood
+call already produced, K_x^-1 = (U / lambda) U^T on the fp64 GEMM (the reference's `.inverse()` is LAPACK's LU; on these
+numerically singular matrices -- cond 5e6 ... 1e13 on the fixtures -- any two inverses agree to ~cond * eps, which is also what
+the fixtures of the reference's own LU hold this to; tiny or negative computed eigenvalues are amplified by 1 / lambda exactly as
+they are by any other inverse of such a matrix).  "eigen"
 evaluates the same matrix as `K_star @ (U_x / lambda_x)` without forming the inverse.  Which one is "right" is moot (the
 expression is not a variance); the default keeps the reference's arithmetic shape.
 """
@@ -189,10 +191,12 @@ def kron_nll(y, tau, Ks):
 
 class HOGP_simple(nn.Module):
     def __init__(self, kernel, noise_variance, output_shape, learnable_grid=False, learnable_map=False,
-                 variance_mode="reference"):
+                 variance_mode="explicit_inverse"):
         super().__init__()
-        if variance_mode not in ("reference", "eigen"):
-            raise ValueError("variance_mode must be 'reference' or 'eigen', got %r" % (variance_mode,))
+        if variance_mode == "reference":          # (the mode's name until round 4: it never was the reference's LU inverse)
+            variance_mode = "explicit_inverse"
+        if variance_mode not in ("explicit_inverse", "eigen"):
+            raise ValueError("variance_mode must be 'explicit_inverse' or 'eigen', got %r" % (variance_mode,))
         self.variance_mode = variance_mode
         self.noise_variance = nn.Parameter(torch.tensor([noise_variance]))
         self.K = []
@@ -249,7 +253,7 @@ class HOGP_simple(nn.Module):
         diag_K = diag_K_x * diag_K_dims
         S_2 = (self.A * self.A.pow(-1 / 2)).pow(2)
         e0 = self.K_eigen[0]
-        if self.variance_mode == "reference":   # K_star @ K_x.inverse() @ U_x, the reference's own order of operations (:68)
+        if self.variance_mode in ("explicit_inverse", "reference"):   # K_star @ K_x^-1 @ U_x in the reference's order of operations (:68)
             if torch.is_grad_enabled() and self.K[0].requires_grad:
                 K_inv = _InvFromEigen.apply(self.K[0], e0.value.detach(), e0.vector.detach())
             else:

@@ -1516,9 +1516,9 @@ def test_hogp_block_golden(golden, where):
         mean, var = m.forward(tt(g["X"]), tt(g["Xt"]))
     assert tuple(mean.shape) == g["mean"].shape
     assert rel(mean, g["mean"]) < 1e-7
-    # variance_mode "reference" (default): K_star @ K_x.inverse() @ U_x as hogp_simple.py:68 writes it; cond(K_x) = 5e6 here, so
+    # variance_mode "explicit_inverse" (default; "reference" was its name until round 4): K_star @ K_x.inverse() @ U_x as hogp_simple.py:68 writes it; cond(K_x) = 5e6 here, so
     # two explicit inverses (LAPACK's LU in the fixture, (U / lambda) U^T from the library's eigenpairs here) agree to ~cond * eps
-    assert m.variance_mode == "reference"
+    assert m.variance_mode == "explicit_inverse"
     assert rel(var, g["var"]) < 1e-6
     m.variance_mode = "eigen"            # the opt-in: the same matrix from the cached eigenpairs, U_x / lambda_x
     with torch.no_grad():
@@ -1549,7 +1549,7 @@ def test_gar_chain_golden(golden):
     # this build divides by the eigenvalues; agreement is at the level of that noise
     # 2e-2 holds for both variance modes: the fixture's own LAPACK inverse is only good to that (north_star's 1e-4 is met by
     # the mean and by the block fixture above, whose K_x has cond 5e6)
-    assert all(b.variance_mode == "reference" for b in model.hogp_list)
+    assert all(b.variance_mode == "explicit_inverse" for b in model.hogp_list)
     assert rel(vp, g["var_pred"]) < 2e-2
     for b in model.hogp_list:
         b.variance_mode = "eigen"
