@@ -15,6 +15,11 @@ from fidelityfusion_amd.cigp_v10 import cigp, negative_log_likelihood_many
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 nF = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+for kv in sys.argv[3:]:                      # further arguments: key=value library options (e.g. batch_refine=0)
+    from fidelityfusion_amd import _lib
+    k, v = kv.split("=")
+    _lib.set_option(k, float(v), 0)
+    print("option", k, "=", v)
 D, d = 8, 1
 dev = torch.device("cuda", 0)
 torch.set_default_dtype(torch.float64)
