@@ -10,6 +10,8 @@ int ffgp_assemble_impl(ffgp_handle* h, const double* X1, int n1, const double* X
 int ffgp_transpose(ffgp_handle* h, const double* src, int rows, int cols, int ld_src, double* dst, int ld_dst, double scale);
 int ffgp_trtri_impl(ffgp_handle* h, const double* L, int n, int ldl, double* X, int ldx, double* T);
 int ffgp_lauum_impl(ffgp_handle* h, const double* X, int n, int ldx, double* S, int lds_);
+int ffgp_trtri_lauum_ob(ffgp_handle* h, int F, const double* L0, long sL, int n, int ldl, double* X0, long sX, int ldx, double* T0, long sT,
+                        double* S0, long sS, int lds_, const double* dinv0, long sD);
 int ffgp_nll_reduce_impl(ffgp_handle* h, int variant, const double* L, int n, int ldl, const double* M, int rows, int cols,
                          int ldm, int d, double pi_const, double* out_dev);
 int ffgp_grad_impl(ffgp_handle* h, const double* X, int n, int D, const double* w, const double* amp, double clamp,
@@ -185,6 +187,7 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->device = device;
   h->lookahead = 1;
   h->small_tile_threshold = 640;
+  h->batch_grad_ob = 1;
   h->tile32_threshold = 1024;
   h->polite_m = 6144;
   h->polite_pad_kb = 40;
@@ -311,6 +314,8 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     const int v = (int)value;
     if (v != 0 && v != 32 && v != 64 && v != 128) return FFGP_ERR_ARG;
     h->force_ts = v;
+  } else if (!strcmp(key, "batch_grad_ob")) {
+    h->batch_grad_ob = value != 0.0 ? 1 : 0;
   } else if (!strcmp(key, "small_tile_threshold")) {
     h->small_tile_threshold = (int)value;
   } else if (!strcmp(key, "tile32_threshold")) {
@@ -756,10 +761,21 @@ int ffgp_nlml_fused_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ff
   size_t total = blk * F;
   const size_t o_link = total; total += (size_t)F * 512;   // effective parameters / their gradients, 256 + 256 doubles per block
   size_t o_X = 0, o_S = 0, o_T = 0, o_At = 0, o_P = 0;
+  // gradient stage: when EVERY block wants gradients (and the inverses fit), Sigma_f^-1 of all blocks come out of one sequence of
+  // launches with an outer batch index (ffgp_trtri_lauum_ob) -- a lone N = 4096 inverse underfills the chip at its lower levels;
+  // otherwise block after block through one set of buffers
+  bool all_grad = want_grad && g && h->batch_grad_ob;
+  for (int f = 0; f < F && all_grad; ++f) {
+    const ffgp_grads& gg = g[f];
+    all_grad = gg.g_w_dev || gg.g_amp_dev || gg.g_diag_add_dev || gg.g_Y_dev || gg.g_diag_vec_dev || gg.g_kparam_dev;
+  }
+  const size_t sX = (size_t)n * ld, sT = 2 * (n1 * n1 + 16);
+  if (all_grad && (size_t)F * (2 * sX + sT) * sizeof(double) > ((size_t)48 << 30)) all_grad = false;
+  const size_t copies = all_grad ? (size_t)F : 1;
   if (want_grad) {
-    o_X = total; total += (size_t)n * ld;
-    o_S = total; total += (size_t)n * ld;
-    o_T = total; total += 2 * (n1 * n1 + 16);
+    o_X = total; total += copies * sX;
+    o_S = total; total += copies * sX;
+    o_T = total; total += copies * sT;
     o_At = total; total += (size_t)d * ld;
     o_P = total; total += ffgp_grad_partial_doubles(n, Dmax) + 16;
   }
@@ -805,6 +821,9 @@ int ffgp_nlml_fused_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ff
   stage_mark(h, 2);
   double* const dinv0 = h->dinv;
   int rc_stage = FFGP_OK;
+  if (all_grad)
+    rc_stage = ffgp_trtri_lauum_ob(h, F, h->ws, (long)blk, n, (int)ld, h->ws + o_X, (long)sX, (int)ld, h->ws + o_T, (long)sT, h->ws + o_S,
+                                   (long)sX, (int)ld, dinv0, (long)nblk * FFGP_NB * FFGP_NB);
   for (int f = 0; f < F && rc_stage == FFGP_OK; ++f) {
     double* W0 = h->ws + blk * f;
     double* Gt = W0 + (size_t)n * ld;
@@ -815,8 +834,8 @@ int ffgp_nlml_fused_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ff
     // the block's own slice of the Dinv store, presented as "the" store of this factor while its inverse is formed
     h->dinv = dinv0 + (size_t)f * nblk * FFGP_NB * FFGP_NB;
     h->dinv_L = W0; h->dinv_n = n; h->dinv_ld = (int)ld;
-    double* X = h->ws + o_X;
-    double* S = h->ws + o_S;
+    double* X = h->ws + o_X + (all_grad ? (size_t)f * sX : 0);
+    double* S = h->ws + o_S + (all_grad ? (size_t)f * sX : 0);
     double* T = h->ws + o_T;
     double* At = h->ws + o_At;
     double* P = h->ws + o_P;
@@ -830,8 +849,10 @@ int ffgp_nlml_fused_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ff
       if (gg.g_diag_add_dev) gq.g_diag_add_dev = geff + D + 1;
       chain = gg.g_w_dev || gg.g_amp_dev || gg.g_diag_add_dev;
     }
-    if ((rc_stage = ffgp_trtri_impl(h, W0, n, (int)ld, X, (int)ld, T)) != FFGP_OK) break;
-    if ((rc_stage = ffgp_lauum_impl(h, X, n, (int)ld, S, (int)ld)) != FFGP_OK) break;
+    if (!all_grad) {
+      if ((rc_stage = ffgp_trtri_impl(h, W0, n, (int)ld, X, (int)ld, T)) != FFGP_OK) break;
+      if ((rc_stage = ffgp_lauum_impl(h, X, n, (int)ld, S, (int)ld)) != FFGP_OK) break;
+    }
     if ((rc_stage = ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Gt, (int)ld, X, (int)ld, At, (int)ld, d, n, n, 1.0, 0.0,
                                      TRI_LO_J)) != FFGP_OK) break;
     if ((rc_stage = ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_LOWER, 0, At, (int)ld, At, (int)ld, S, (int)ld, n, n, d, -0.5,

@@ -113,6 +113,9 @@ struct GemmArgs {
   long sA, sB, sC;
   // triangular operands: restrict the k range of tile (ti, tj) to [max(lo_i*ti, lo_j*tj)*128, min(K, hi_i*(ti+1)*128, ...))
   int lo_i, lo_j, hi_i, hi_j;
+  // outer batch (gridDim.z): the same launch for every block of a shared gradient stage, at per-operand element strides
+  int batch2;
+  long sA2, sB2, sC2;
 };
 
 struct ffgp_handle {
@@ -166,6 +169,12 @@ struct ffgp_handle {
   // kernel of ffgp_potrf_impl then covers all F blocks (diagonal-block kernel: one workgroup per block; GEMMs: gridDim.y = F)
   int bt_F;             // 0 / 1 = not batched
   long bt_sA, bt_sD;    // element strides between the blocks' workspaces / between their Dinv stores
+  // outer batch of the shared chain's gradient stage: while ob_F > 1 EVERY ffgp_gemm_launch covers ob_F blocks (gridDim.z), the stride
+  // of each operand looked up from the address range it points into; tile shapes are decided as for one block (same bits)
+  int batch_grad_ob;    // option (default 1): the shared chain's gradient stage inverts all blocks in one outer-batched sequence of launches
+  int ob_F;
+  int ob_n;
+  struct { const double* lo; const double* hi; long stride; } ob_rng[6];
   int* bt_info;         // [F] device status words (first non-positive pivot of each block)
   int* bt_info_host;    // pinned mirror
   int trtri_overlap;    // option (default 1)

@@ -480,9 +480,9 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
   const int tid = threadIdx.x;
   if (p.prio) __builtin_amdgcn_s_setprio(2);  // panel GEMMs of the look-ahead chain outrank the trailing update
   // batched launches (gridDim.y > 1): identical problems at fixed strides (the levels of the blocked TRTRI)
-  const double* __restrict__ Ag = p.A + (size_t)blockIdx.y * p.sA;
-  const double* __restrict__ Bg = p.B + (size_t)blockIdx.y * p.sB;
-  double* __restrict__ Cg = p.C + (size_t)blockIdx.y * p.sC;
+  const double* __restrict__ Ag = p.A + (size_t)blockIdx.y * p.sA + (size_t)blockIdx.z * p.sA2;
+  const double* __restrict__ Bg = p.B + (size_t)blockIdx.y * p.sB + (size_t)blockIdx.z * p.sB2;
+  double* __restrict__ Cg = p.C + (size_t)blockIdx.y * p.sC + (size_t)blockIdx.z * p.sC2;
 
   // One workgroup per tile.  (A persistent 2-per-CU grid was measured and dropped: it keeps the two workgroups of
   // a CU in lock-step, so their prologues and epilogues coincide instead of hiding under each other's k loop.)
@@ -531,7 +531,7 @@ static int launch_t(ffgp_handle* h, const GemmArgs& a) {
   if (a.pad_lds > 0)   // (set per launch: the attribute is per device context, and this path runs ~10 times per factorisation)
     FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffgp_gemm_f64<OPA, OPB, MODE, TAG, TM, TN>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-  hipLaunchKernelGGL((ffgp_gemm_f64<OPA, OPB, MODE, TAG, TM, TN>), dim3(a.grid, a.batch), dim3(256), a.pad_lds, h->stream, a);
+  hipLaunchKernelGGL((ffgp_gemm_f64<OPA, OPB, MODE, TAG, TM, TN>), dim3(a.grid, a.batch, a.batch2), dim3(256), a.pad_lds, h->stream, a);
   return FFGP_OK;
 }
 
@@ -715,6 +715,31 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   if (mode == TILES_LOWER && m < n) return FFGP_ERR_ARG;
   if (alias == ALIAS_A && (n > 128 || mode != TILES_FULL)) return FFGP_ERR_ARG;
   if (alias == ALIAS_B && (m > 128 || mode != TILES_FULL)) return FFGP_ERR_ARG;
+  // outer batch (ffgp_handle::ob_F): only the triangular products of the inverse's levels and the LAUUM go through it -- none of
+  // which may take one of the special paths below (their single-block launches never do either)
+  const bool ob = h->ob_F > 1;
+  long ob_sA = 0, ob_sB = 0, ob_sC = 0;
+  if (ob) {
+    auto stride_of = [&](const double* ptr, long& st) {
+      for (int i = 0; i < h->ob_n; ++i)
+        if (ptr >= h->ob_rng[i].lo && ptr < h->ob_rng[i].hi) { st = h->ob_rng[i].stride; return true; }
+      return false;
+    };
+    if (!stride_of(A, ob_sA) || !stride_of(B, ob_sB) || !stride_of(C, ob_sC) || ((ob_sA | ob_sB | ob_sC) & 1) || alias != 0 || syrk_tag) {
+      fprintf(stderr, "[ffgp] gemm: outer-batch launch with an operand outside the registered ranges\n");
+      return FFGP_ERR_ARG;
+    }
+    if (tri == 0 || m <= 8 || n <= 8) {   // (a ragged last pair of a level can be a one-row product: the single block's own path, block by block)
+      const int F = h->ob_F;
+      h->ob_F = 0;
+      int rc = FFGP_OK;
+      for (int f = 0; f < F && rc == FFGP_OK; ++f)
+        rc = ffgp_gemm_launch(h, opa, opb, mode, syrk_tag, A + (size_t)f * ob_sA, lda, B + (size_t)f * ob_sB, ldb, C + (size_t)f * ob_sC, ldc,
+                              m, n, k, alpha, beta, tri, alias, batch, sA, sB, sC);
+      h->ob_F = F;
+      return rc;
+    }
+  }
   // few output ROWS (single-output GPs: A^T = Gamma^T L^-1, 1 x n): the transposed matrix-vector product -- C^T = op(B)^T op(A)^T
   // reads B once with the rows of C^T across the lanes; on the 64 x 64 tile the launch above cost 0.21 ms at n = k = 4096
   // (0.6 TB/s of B) inside every training step of a d = 1 model
@@ -812,6 +837,12 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.alpha = alpha; a.beta = beta;
   a.prio = (h->stream == h->aux && h->aux_prio) ? 1 : 0;
+  a.batch2 = 1;
+  a.sA2 = a.sB2 = a.sC2 = 0;
+  if (ob) {
+    a.batch2 = h->ob_F;
+    a.sA2 = ob_sA; a.sB2 = ob_sB; a.sC2 = ob_sC;
+  }
   // batch < 0: |batch| members, with every shape decision below taken as ONE member's launch would take it -- the batched
   // factorisation (ffgp_nlml_fused_batch) promises the single call's values bit for bit, and the forms differ in rounding (the fast
   // 128-tile accumulates onto C, the general tiles add alpha * (sum) to beta * C once)

@@ -234,6 +234,7 @@ __global__ void ffgp_copy_dinv_kernel(const double* __restrict__ dinv, double* _
 // Bottom-up by doubling: at level s every aligned pair of inverted s x s diagonal blocks is merged,
 //   inv([[L11,0],[L21,L22]]) = [[X11,0],[-X22 (L21 X11), X22]],
 // all full pairs of a level in ONE batched launch per product (2 launches per level instead of 2 per pair).
+int ffgp_lauum_impl(ffgp_handle* h, const double* X, int n, int ldx, double* S, int lds_);
 static int trtri_levels(ffgp_handle* h, const double* L, int n, int ldl, double* X, int ldx, double* T) {
   for (long s = NB; s < n; s *= 2) {
     const int full = (int)(n / (2 * s));          // pairs with both halves complete
@@ -271,6 +272,28 @@ int ffgp_trtri_impl(ffgp_handle* h, const double* L, int n, int ldl, double* X, 
   const int nblk = (n + NB - 1) / NB;
   hipLaunchKernelGGL(ffgp_copy_dinv_kernel, dim3(NB * NB / 256, nblk), dim3(256), 0, h->stream, h->dinv, X, ldx, n, 0);
   return trtri_levels(h, L, n, ldl, X, ldx, T);
+}
+
+// X_f <- L_f^-1 and S_f <- X_f^T X_f for the F blocks of a shared chain in ONE sequence of launches (outer batch, gridDim.z = F;
+// ffgp_handle::ob_*): every launch decides its tile shapes as the single block's launch does, so each block's bits are those of
+// ffgp_trtri_impl + ffgp_lauum_impl on it alone.  dinv0 / sD: the F stores of inverted diagonal blocks the batched factorisation left.
+int ffgp_trtri_lauum_ob(ffgp_handle* h, int F, const double* L0, long sL, int n, int ldl, double* X0, long sX, int ldx, double* T0, long sT,
+                        double* S0, long sS, int lds_, const double* dinv0, long sD) {
+  FFGP_CHECK(ffgp_zero_async(h, X0, (size_t)F * sX * sizeof(double)));
+  const int nblk = (n + NB - 1) / NB;
+  for (int f = 0; f < F; ++f)
+    hipLaunchKernelGGL(ffgp_copy_dinv_kernel, dim3(NB * NB / 256, nblk), dim3(256), 0, h->stream, dinv0 + (size_t)f * sD, X0 + (size_t)f * sX,
+                       ldx, n, 0);
+  h->ob_n = 4;
+  h->ob_rng[0] = {L0, L0 + (size_t)F * sL, sL};
+  h->ob_rng[1] = {X0, X0 + (size_t)F * sX, sX};
+  h->ob_rng[2] = {T0, T0 + (size_t)F * sT, sT};
+  h->ob_rng[3] = {S0, S0 + (size_t)F * sS, sS};
+  h->ob_F = F;
+  int rc = trtri_levels(h, L0, n, ldl, X0, ldx, T0);
+  if (rc == FFGP_OK) rc = ffgp_lauum_impl(h, X0, n, ldx, S0, lds_);
+  h->ob_F = 0;
+  return rc;
 }
 
 // The same inverse in two parts, split at column n1 (a power-of-two multiple of 128, n1 < n <= 2 n1 -- the top level's own split):
