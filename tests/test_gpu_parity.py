@@ -907,6 +907,60 @@ def test_equal_shape_blocks_share_one_chain(n, d, F_):
     assert torch.equal(mixed[0].detach(), got[0][0])
 
 
+@pytest.mark.noisy
+def test_shared_chain_gradient_stage_paths_agree():
+    """the gradient stage of the shared chain has two routes -- every block's inverse in one outer-batched sequence of launches
+    (all blocks want gradients), or block after block through one set of buffers (a member without gradients, or the option
+    batch_grad_ob = 0): same bits either way"""
+    from fidelityfusion_amd import _lib
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp, negative_log_likelihood_many
+    rng = np.random.default_rng(77)
+    n, d, F_ = 900, 2, 3
+    models, xs, ys = [], [], []
+    for f in range(F_):
+        models.append(cigp(kernel.ARDKernel(3), 0.7 + 0.1 * f).double().to(DEV))
+        xs.append(T(rng.uniform(0, 1, (n, 3))))
+        ys.append(T(rng.standard_normal((n, d)), grad=True))
+
+    def grads(freeze=None):
+        for m, y in zip(models, ys):
+            for p_ in m.parameters():
+                p_.grad = None
+                p_.requires_grad_(True)
+            y.grad = None
+        yy = list(ys)
+        if freeze is not None:
+            for p_ in models[freeze].parameters():
+                p_.requires_grad_(False)
+            yy[freeze] = ys[freeze].detach()
+        vals = negative_log_likelihood_many(models, xs, yy)
+        vals.sum().backward()
+        out = [(v.detach().clone(), [None if p_.grad is None else p_.grad.clone() for p_ in m.parameters()],
+                None if y.grad is None else y.grad.clone()) for v, m, y in zip(vals, models, ys)]
+        for p_ in models[freeze or 0].parameters():
+            p_.requires_grad_(True)
+        return out
+    ref = grads()
+    _lib.set_option("batch_grad_ob", 0.0, 0)
+    try:
+        serial = grads()
+    finally:
+        _lib.set_option("batch_grad_ob", 1.0, 0)
+    frozen = grads(freeze=1)
+    for i in range(F_):
+        assert torch.equal(ref[i][0], serial[i][0]) and torch.equal(ref[i][0], frozen[i][0])
+        for a, b in zip(ref[i][1], serial[i][1]):
+            assert torch.equal(a, b), i
+        assert torch.equal(ref[i][2], serial[i][2]), i
+        if i != 1:
+            for a, b in zip(ref[i][1], frozen[i][1]):
+                assert torch.equal(a, b), i
+            assert torch.equal(ref[i][2], frozen[i][2]), i
+        else:
+            assert all(g_ is None for g_ in frozen[i][1]) and frozen[i][2] is None
+
+
 def test_small_finish_reports_not_pd():
     """the finishing-kernel path keeps the factorisation's status: a Sigma that is not positive definite raises"""
     from fidelityfusion_amd import kernel
