@@ -2209,6 +2209,36 @@ def test_n8192_d32_block_vs_torch_cpu_reference():
     assert all(v < 1e-8 for v in errs.values()), errs
 
 
+@pytest.mark.timeout(900)
+def test_c3_full_size_gradients_vs_torch_cpu_reference():
+    """BASELINE configs[2] -- the headline, N = 16384, D = 16, d = 1 -- +LL and EVERY gradient of one training step against the
+    reference's own torch-CPU operator sequence and its autograd backward (oracle/torch_cpu_ref.py; FidelityFusion_Models/ResGP.py:84-88):
+    the one BASELINE size bench.py checks the value and the posterior at but not the gradients (the CPU backward takes ~25 s)."""
+    from oracle import gp_oracle as O
+    from oracle import torch_cpu_ref as R
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp
+    n, D, d = 16384, 16, 1
+    X, Y = O.synthetic_xy(n, D, d, seed=0)
+    one = lambda k_: torch.ones(k_, dtype=torch.float64)
+    ls = torch.tensor(np.linspace(0.8, 1.7, D) * np.where(np.arange(D) % 3 == 0, -1.0, 1.0))
+    torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    ll_c, g_c = R.cigp_ll_and_grads(torch.tensor(X), torch.tensor(Y), ls, 1.1 * one(1), 1.0 * one(1))
+    k = kernel.ARDKernel(D)
+    with torch.no_grad():
+        k.length_scales.copy_(ls)
+        k.signal_variance.copy_(torch.tensor([1.1]))
+    m = cigp(k, 1.0).to(DEV)
+    Yt = T(Y, grad=True)
+    ll = m.negative_log_likelihood(T(X), Yt)
+    ll.backward()
+    errs = {"ll": rel(ll, ll_c), "Y": rel(Yt.grad, g_c["Y"]), "length_scales": rel(k.length_scales.grad, g_c["length_scales"]),
+            "signal_variance": rel(k.signal_variance.grad, g_c["signal_variance"]), "log_beta": rel(m.log_beta.grad, g_c["log_beta"])}
+    print("C3 (N=16384) vs torch-CPU autograd, relative errors:", errs)
+    assert errs["ll"] < 1e-10, errs
+    assert all(v < 1e-8 for v in errs.values()), errs
+
+
 # ------------------------------------------------------------------------------------------------ full size, properties
 @pytest.mark.noisy
 @pytest.mark.parametrize("n,D", [(4096, 8), (16384, 16)])
