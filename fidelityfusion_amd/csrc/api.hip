@@ -291,7 +291,7 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
   // The shipped library keeps the switches a binding or a deployment tunes (thresholds, block sizes, the on-device cross-check,
   // timing).  The switches of experiments that were measured and lost (docs/experiments.md) exist in the development build only
   // (`make dev` -> libffgp_dev.so, ffgp_has_dev_options() == 1); here their keys are refused like any unknown key.
-  static const char* const dev_only[] = {"raw_graph_max_n", "diag_dbg", "la_split", "nb_big", "nb_big_until", "sb_lookahead", "sb_av_gemm", "sb_qr4", "q2_wave4", "eig_overlap", "chase_pack", "band_log2", "polite_pad_kb"};
+  static const char* const dev_only[] = {"raw_graph_max_n", "diag_dbg", "la_split", "nb_big", "nb_big_until", "sb_lookahead", "sb_av_gemm", "sb_qr4", "q2_wave4", "eig_overlap", "band_log2", "polite_pad_kb"};
   for (const char* k : dev_only)
     if (!strcmp(key, k)) return FFGP_ERR_ARG;
   if (!strcmp(key, "diag_v2") && value != 4.0 && value != 0.0) return FFGP_ERR_ARG;   // (the round-3 pipelines: development build)

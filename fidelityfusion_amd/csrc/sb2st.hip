@@ -67,6 +67,22 @@ __device__ __forceinline__ double halves_sum(double x) {
 __device__ __forceinline__ double ldb(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void stb(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// the same device-scope accesses as buffer instructions: (SGPR resource of the whole band) + (SGPR byte offset of the step's first
+// column) + (one 32-bit per-lane byte offset).  `__hip_atomic_load(base + off)` compiles to flat-style global loads with a 64-bit
+// address pair per entry -- two VALU adds per access and, for the block below, 32 more live registers: with the interior-step fast
+// path the kernel needed 364 registers, one wave per SIMD, which made it a bad neighbour (config 5's eight blocks: 1.46 -> 1.58 s).
+typedef int ch_v2i __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double ldb_buf(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const ch_v2i v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 16);     // aux 16: sc1
+  return __hiloint2double(v.y, v.x);
+}
+__device__ __forceinline__ void stb_buf(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double x) {
+  ch_v2i v;
+  v.x = __double2loint(x);
+  v.y = __double2hiint(x);
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)voff, (int)soff, 16);
+}
+
 __device__ __forceinline__ int chase_wait(const int* p, int need, int* err) {
   int it = 0, v;
   while ((v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
@@ -131,15 +147,8 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
   double* AB = p.AB;
   double* vs = vsA;
   double* v2s = vsB;
-  // per-lane byte offsets of the interior step's entries from AB + c0 * SB_LDB (lane (i, h) holds row i, columns cc = 16 h + q):
-  // diagonal block entry (i, cc) lives at min(i, cc) * (SB_LDB - 1) + max(i, cc), the block below's (32 + i, cc) at cc * (SB_LDB - 1) + 32 + i
-  unsigned offD[16], offB[16];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int cc = h * 16 + q;
-    offD[q] = (unsigned)(min(i, cc) * (SB_LDB - 1) + max(i, cc)) * 8u;
-    offB[q] = (unsigned)(cc * (SB_LDB - 1) + 32 + i) * 8u;
-  }
+  // raw buffer over the whole band (stride 0, range check off the table: num_records = 2 GiB - 1; the band is n * SB_LDB doubles)
+  const __amdgpu_buffer_rsrc_t band = __builtin_amdgcn_make_buffer_rsrc(AB, 0, 0x7fffffff, 0x00020000);
   for (int s = p.s_begin + wg; s < p.s_end; s += nwg) {
     int c0 = s + 1;
     int len = min(32, n - c0);
@@ -161,94 +170,117 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
       }
     }
     int k = 0;
+    {
+      // INTERIOR steps first (both blocks full: every step of a sweep but its last one or two), in their own loop: the per-lane byte
+      // offsets below live only here, not across the general body further down (whose own ~240 registers they would add to)
+      // per-lane byte offsets of the interior step's entries from AB + c0 * SB_LDB (lane (i, h) holds row i, columns cc = 16 h + q):
+      // diagonal block entry (i, cc) lives at min(i, cc) * (SB_LDB - 1) + max(i, cc), the block below's (32 + i, cc) at cc * (SB_LDB - 1) + 32 + i
+      unsigned offD[16], offB[16];
+      int io = i;
+      asm volatile("" : "+v"(io));      // (opaque: keeps the 32 offsets from being hoisted out of the sweep loop, where they would be live across the general body)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int cc = h * 16 + q;
+        offD[q] = (unsigned)(min(io, cc) * (SB_LDB - 1) + max(io, cc)) * 8u;
+        offB[q] = (unsigned)(cc * (SB_LDB - 1) + 32 + io) * 8u;
+      }
+      while (len == 32 && n - c0 >= 64) {
+        const int r0 = c0 + 32;
+        CH_STAMP(0, 0, k);    // the predecessor's counter has been seen
+        {
+        // ---- INTERIOR step (both blocks full: every step but the last one or two of a sweep).  Round 4: the general body below
+          // spends ~85 % of its ~1500 instructions on per-entry bounds predicates (exec-mask juggling around every load and store) and
+          // 64-bit address arithmetic; one wave issues an instruction every ~5 cycles, so the step was issue-bound at ~4 us.  Here
+          // every entry exists: the loads and stores are unconditional with per-lane byte offsets computed once per kernel (scalar
+          // base + 32-bit offset addressing), and the diagonal block's mirrored lanes compute bit-identical values (t1 + t2 with plain
+          // multiplies and one add: the two products only swap places), so BOTH triangles store -- to the same address, the same bits.
+          const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(c0) * (unsigned)(SB_LDB * 8);
+          double D[16], B[16];
+  #pragma unroll
+          for (int q = 0; q < 16; ++q) D[q] = ldb_buf(band, offD[q], soff);
+  #pragma unroll
+          for (int q = 0; q < 16; ++q) B[q] = ldb_buf(band, offB[q], soff);
+          CH_STAMP(1, 1, k);
+          __syncthreads();   // vs complete
+          double vq[16];
+  #pragma unroll
+          for (int q = 0; q < 16; ++q) vq[q] = vs[h * 16 + q];
+          const double vi = vs[i];
+          double pr = 0.0;
+  #pragma unroll
+          for (int q = 0; q < 16; ++q) pr = __builtin_fma(D[q], vq[q], pr);
+          pr = halves_sum(pr);
+          const double a2 = wsum32(vi * pr, lane);
+          const double w = tau * pr - 0.5 * tau * tau * a2 * vi;
+          if (h == 0) wsh[i] = w;
+          __syncthreads();
+  #pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const double t1 = __dmul_rn(vi, wsh[h * 16 + q]), t2 = __dmul_rn(w, vq[q]);      // (no contraction: see above)
+            D[q] = __dsub_rn(D[q], __dadd_rn(t1, t2));
+            stb_buf(band, offD[q], soff, D[q]);
+          }
+          CH_STAMP(2, 0, k);
+          double sb = 0.0;
+  #pragma unroll
+          for (int q = 0; q < 16; ++q) sb = __builtin_fma(B[q], vq[q], sb);
+          sb = halves_sum(sb);
+          const double ts = tau * sb;
+  #pragma unroll
+          for (int q = 0; q < 16; ++q) B[q] = __builtin_fma(-ts, vq[q], B[q]);
+          double tau_n, beta_n;
+          const double x0 = __shfl(B[0], i);           // first column: lane i of half 0
+          const double v2i = house32(x0, i, lane, 32, tau_n, beta_n);
+          if (h == 0) {
+            B[0] = (i == 0) ? beta_n : 0.0;
+            v2s[i] = v2i;
+          }
+  #pragma unroll
+          for (int q = 0; q < 16; ++q) Mt[i][h * 16 + q] = (h * 16 + q == 0) ? 0.0 : v2i * B[q];
+          __syncthreads();
+          {
+            double u = 0.0;
+  #pragma unroll
+            for (int r = 0; r < 16; ++r) u += Mt[h * 16 + r][i];
+            u = halves_sum(u);
+            if (h == 0) ush[i] = u;
+          }
+          __syncthreads();
+          const double tv = tau_n * v2i;
+  #pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            B[q] = __builtin_fma(-tv, ush[h * 16 + q], B[q]);
+            stb_buf(band, offB[q], soff, B[q]);
+          }
+          CH_STAMP(3, 0, k);
+          ++k;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the publish protocol of the general body, below)
+          CH_STAMP(4, 0, k - 1);
+          if (lane == 0) __hip_atomic_store(p.prog + s, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (h == 0) p.V2[((size_t)s * p.K + k) * 32 + i] = v2i;
+          if (lane == 0) p.tau2[(size_t)s * p.K + k] = tau_n;
+          c0 = r0;
+          tau = tau_n;
+          double* t_ = vs;
+          vs = v2s;
+          v2s = t_;
+          CH_STAMP(5, 0, k - 1);
+        if (seen < k + 2) seen = chase_wait(p.prog + s - 1, k + 2, p.err);
+        }
+      }
+    }
     while (true) {
+      // (the general body works from opaque copies of the lane coordinates: everything it derives from them -- dozens of per-entry
+      //  predicates and addresses -- is then recomputed per step instead of being hoisted in front of the interior loop, where it
+      //  would sit in registers across every interior step; these steps are the last one or two of a sweep)
+      int i_ = i, h_ = h, lane_ = lane;
+      asm volatile("" : "+v"(i_), "+v"(h_), "+v"(lane_));
+      const int i = i_, h = h_, lane = lane_;
       const int r0 = c0 + len;
       const bool more = (r0 <= n - 1);
       const int nrow = more ? min(32, n - r0) : 0;
       CH_STAMP(0, 0, k);    // the predecessor's counter has been seen
-      if (len == 32 && nrow == 32) {
-        // ---- INTERIOR step (both blocks full: every step but the last one or two of a sweep).  Round 4: the general body below
-        // spends ~85 % of its ~1500 instructions on per-entry bounds predicates (exec-mask juggling around every load and store) and
-        // 64-bit address arithmetic; one wave issues an instruction every ~5 cycles, so the step was issue-bound at ~4 us.  Here
-        // every entry exists: the loads and stores are unconditional with per-lane byte offsets computed once per kernel (scalar
-        // base + 32-bit offset addressing), and the diagonal block's mirrored lanes compute bit-identical values (t1 + t2 with plain
-        // multiplies and one add: the two products only swap places), so BOTH triangles store -- to the same address, the same bits.
-        const char* base = reinterpret_cast<const char*>(AB + (size_t)c0 * SB_LDB);
-        char* wbase = reinterpret_cast<char*>(AB + (size_t)c0 * SB_LDB);
-        double D[16], B[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) D[q] = ldb(reinterpret_cast<const double*>(base + offD[q]));
-#pragma unroll
-        for (int q = 0; q < 16; ++q) B[q] = ldb(reinterpret_cast<const double*>(base + offB[q]));
-        CH_STAMP(1, 1, k);
-        __syncthreads();   // vs complete
-        double vq[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) vq[q] = vs[h * 16 + q];
-        const double vi = vs[i];
-        double pr = 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) pr = __builtin_fma(D[q], vq[q], pr);
-        pr = halves_sum(pr);
-        const double a2 = wsum32(vi * pr, lane);
-        const double w = tau * pr - 0.5 * tau * tau * a2 * vi;
-        if (h == 0) wsh[i] = w;
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const double t1 = __dmul_rn(vi, wsh[h * 16 + q]), t2 = __dmul_rn(w, vq[q]);      // (no contraction: see above)
-          D[q] = __dsub_rn(D[q], __dadd_rn(t1, t2));
-          stb(reinterpret_cast<double*>(wbase + offD[q]), D[q]);
-        }
-        CH_STAMP(2, 0, k);
-        double sb = 0.0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) sb = __builtin_fma(B[q], vq[q], sb);
-        sb = halves_sum(sb);
-        const double ts = tau * sb;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) B[q] = __builtin_fma(-ts, vq[q], B[q]);
-        double tau_n, beta_n;
-        const double x0 = __shfl(B[0], i);           // first column: lane i of half 0
-        const double v2i = house32(x0, i, lane, 32, tau_n, beta_n);
-        if (h == 0) {
-          B[0] = (i == 0) ? beta_n : 0.0;
-          v2s[i] = v2i;
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) Mt[i][h * 16 + q] = (h * 16 + q == 0) ? 0.0 : v2i * B[q];
-        __syncthreads();
-        {
-          double u = 0.0;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) u += Mt[h * 16 + r][i];
-          u = halves_sum(u);
-          if (h == 0) ush[i] = u;
-        }
-        __syncthreads();
-        const double tv = tau_n * v2i;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          B[q] = __builtin_fma(-tv, ush[h * 16 + q], B[q]);
-          stb(reinterpret_cast<double*>(wbase + offB[q]), B[q]);
-        }
-        CH_STAMP(3, 0, k);
-        ++k;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the publish protocol of the general body, below)
-        CH_STAMP(4, 0, k - 1);
-        if (lane == 0) __hip_atomic_store(p.prog + s, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (h == 0) p.V2[((size_t)s * p.K + k) * 32 + i] = v2i;
-        if (lane == 0) p.tau2[(size_t)s * p.K + k] = tau_n;
-        c0 = r0;
-        tau = tau_n;
-        double* t_ = vs;
-        vs = v2s;
-        v2s = t_;
-        CH_STAMP(5, 0, k - 1);
-        if (seen < k + 2) seen = chase_wait(p.prog + s - 1, k + 2, p.err);
-        continue;
-      }
       // ---- both blocks of the step are requested up front
       double D[16], B[16];
 #pragma unroll
@@ -383,9 +415,11 @@ int ffgp_sb2st_chunk(ffgp_handle* h, hipStream_t st, double* AB, int n, double* 
   a.s_begin = s_begin; a.s_end = s_end;
   // placement of the working wavefronts: every pack-th workgroup works (workgroups are dealt round-robin to the 8 XCDs, so pack = 8
   // puts all of them on one XCD and one L2, pack = 1 one wave on every CU of the chip).  Measured at N = 8192 (tools/chase_dbg.py):
-  // pack 8: 119 ms, 4: 88, 2: 80, 1: 82 -- the waves get in each other's way on a shared SIMD more than the memory-side
-  // hand-over between XCDs costs.  Purely a placement: every band access is a device-scope access wherever the wave runs.
-  a.pack = h->chase_pack > 0 ? h->chase_pack : 2;
+  // pack 8: 166 ms, 4: 92, 2: 68-69, 1: 64-65 (round 3, with a kernel of 238 registers: 119 / 88 / 80 / 82) -- the waves get in each
+  // other's way on a shared SIMD more than the memory-side hand-over between XCDs costs.  Purely a placement: every band access is
+  // a device-scope access wherever the wave runs.  Default 1; beside other blocks' kernels (config 5's eight HOGP blocks from four
+  // host threads) 1 and 2 measure the same, 1.43-1.47 s per step.
+  a.pack = h->chase_pack > 0 ? h->chase_pack : 1;
   const int grid = min(s_end - s_begin, 256) * a.pack;
   hipLaunchKernelGGL(sb2st_chase, dim3(grid), dim3(64), 0, st, a);
   return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;

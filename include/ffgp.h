@@ -210,8 +210,12 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
                         panel against 54.4 us on 1024 threads at n = 8192; with "sb_lookahead" the only form whose leaves overlap
                         the trailing update, stage time equal either way),
             "diag_v2" (default 1: pipelined diagonal-block kernel; 0 = the barrier version, 2 = helper waves off wave 0's SIMD),
-            "trtri_overlap", "small_fused", "small_max_n", "chase_pack", "eig_overlap", "sb_lookahead" (round-3 experiment
-                        switches)                                                                  */
+            "chase_pack" (placement of the bulge chase's 256 working wavefronts: every pack-th workgroup works.  Default 1 = one per
+                        compute unit over the whole chip (N = 8192: 64.6 ms; 2 = on every other XCD: 69.4, 4: 92, 8: 166); beside
+                        other blocks' kernels 1 and 2 measure the same (config 5's eight blocks: 1.43-1.47 s per step either way),
+            "batch_grad_ob" (default 1: the shared chain's gradient stage inverts all blocks in one outer-batched sequence of launches),
+            "trtri_overlap", "small_fused", "small_max_n", "eig_overlap", "sb_lookahead" (round-3 experiment
+                        switches; some exist in the development build only: ffgp_has_dev_options)    */
 int ffgp_set_option(ffgp_handle* h, const char* key, double value);
 const char* ffgp_version(void);
 /* 1 in the development build (`make dev`: the switches of measured-and-rejected experiments are accepted by ffgp_set_option), 0 in

@@ -1,8 +1,8 @@
 """Build-time checks on the generated gfx950 ISA (no GPU needed: hipcc cross-compiles).
 
 check_chase_publish(): in `sb2st_chase` every store of a sweep's progress counter must be preceded by an explicit
-`s_waitcnt vmcnt(0)` with no vector-memory instruction in between -- the band stores of the step are write-through (sc1)
-stores of the same wave and have to be complete before the counter a wave on another XCD polls moves (a workgroup-scope
+`s_waitcnt vmcnt(0)` with no band access (any load, any sc1 / buffer store) in between -- the band stores of the step are write-through
+(sc1) stores of the same wave and have to be complete before the counter a wave on another XCD polls moves (a workgroup-scope
 release fence compiles to `lgkmcnt(0)` only).  Used by tests/test_isa_checks.py; `python tools/check_isa.py` prints the result.
 """
 import os
@@ -35,17 +35,40 @@ def function_body(asm, mangled_substr):
 
 def check_chase_publish(asm=None):
     body = function_body(asm or device_asm("sb2st.hip"), "sb2st_chase")
+    labels = {l.split(":")[0].strip(): i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)}
     waits = [i for i, l in enumerate(body) if l.strip() == "s_waitcnt vmcnt(0)" and i > 0 and "ASMSTART" in body[i - 1]]
+    counter = re.compile(r"global_store_dword\s+v\d+, v\d+, s\[\d+:\d+\](?: offset:-?\d+)? sc1")
+
+    def band_access(ins):
+        # band traffic is device-scope (sc1) -- global_* in the general body, buffer_* in the interior-step loop; a plain store to the
+        # reflector / tau arrays (read only after the kernel) may be scheduled in between
+        return bool(re.match(r"(global|buffer|flat)_(load|atomic)", ins) or ins.startswith("buffer_") or
+                    (re.match(r"(global|flat)_store", ins) and " sc1" in ins))
     found = []
     for w in waits:
-        for j in range(w + 1, min(w + 40, len(body))):
+        hit = None
+        for j in range(w + 1, min(w + 60, len(body))):
             ins = body[j].strip()
-            if re.match(r"global_store_dword\s+v\d+, v\d+, s\[\d+:\d+\] sc1", ins):
-                found.append((w, j))
+            if counter.match(ins):
+                hit = j
                 break
-            if re.match(r"(global|buffer|flat)_(load|store|atomic)", ins):
-                raise AssertionError("vector-memory instruction between the drain and the counter store: " + ins)
-    assert len(found) >= 2, "expected a drained counter store per step and one at the end of a sweep, found %d" % len(found)
+            m = re.match(r"s_cbranch_execnz (\.LBB\d+_\d+)", ins)     # `if (lane == 0) store` laid out of line
+            if m and m.group(1) in labels:
+                blk = [l.strip() for l in body[labels[m.group(1)] + 1: labels[m.group(1)] + 14]]
+                for k, b_ in enumerate(blk):
+                    if counter.match(b_):
+                        hit = labels[m.group(1)] + 1 + k
+                        break
+                    if band_access(b_) or b_.startswith("s_branch") or b_.startswith("s_cbranch"):
+                        break
+                if hit is not None:
+                    break
+                continue
+            if band_access(ins):
+                raise AssertionError("band access between the drain and the counter store: " + ins)
+        if hit is not None:
+            found.append((w, hit))
+    assert len(found) >= 3, "expected a drained counter store per interior step, per general step and at the end of a sweep, found %d" % len(found)
     return found
 
 
