@@ -702,9 +702,31 @@ __global__ __launch_bounds__(256, 4) void q2_apply(ApplyArgs p) {
 // wave-private LDS tile), then one band leaves for global memory and one arrives: two barriers per FOUR blocks, a quarter of the
 // HBM traffic.
 // ---------------------------------------------------------------------------------------------------------------------
+#ifdef FFGP_Q2_STAMPS   // development probe (tools/native/q2_phases.hip): shader-clock stamps of two consecutive time steps, wave FFGP_Q2_STAMP_W
+__device__ unsigned long long ffgp_q2_stamp[32];
+#define Q2_STAMP(idx)                                                                                              \
+  do {                                                                                                             \
+    if (blockIdx.x == FFGP_Q2_STAMP_B && Gtop == p.G1 - 1 - 4 * FFGP_Q2_STAMP_PASS && (t == FFGP_Q2_STAMP_T || t == FFGP_Q2_STAMP_T + 1) && \
+        wave == FFGP_Q2_STAMP_W) {                                                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
+      if (lane == 0) ffgp_q2_stamp[(t - FFGP_Q2_STAMP_T) * 16 + (idx)] = __builtin_readcyclecounter();             \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
+    }                                                                                                              \
+  } while (0)
+#else
+#define Q2_STAMP(idx)
+#endif
 #define Q2W_RING 12
 #define Q2W_LDS_DOUBLES(NC) ((NC) * (Q2W_RING * 32 * XLD + 4 * 32 * XLD))
 
+// Round 4, measured with the stamps above (tools/native/q2_phases.hip; one time step of one wave at N = 8192, two workgroups per CU):
+// X = V^T Z 1.3 us, X through LDS 0.5-0.7, Z -= W X 1.0, the two barriers 0.1-0.2 each, band out / in 0.3-1.0 -- 3.5-4.2 us per
+// step where the two waves of a SIMD need 2.8 us of MFMA issue between them.  Built on that and measured: X handed over in registers
+// (the first product's accumulator layout IS the second product's B-operand layout, no LDS trip), the arriving band stored before the
+// operand loads are issued (the in-order counter made it wait for them), V and W requested a whole step ahead in a second register
+// set.  Each shortens the wave's own path and none moves the kernel (46.7-49.4 ms against 46.7; the 32-column form improves 57 -> 48.5
+// because there a SIMD holds one wave): with 2 x 4 waves per CU pulling 26 KB of V / W per block the kernel sits on the L2's
+// bandwidth (~13 TB/s over the chip), as the note on NC below says.  Taken out again.
 // NC = 1: slabs of 16 columns, 64 KB of LDS, two workgroups per CU.  NC = 2: slabs of 32 columns (two 16-column tiles, stored one
 // after the other so that operand reads stay conflict-free), 128 KB, one workgroup per CU -- every block's V and W^T are fetched
 // once per 32 columns instead of once per 16: the operand stream (n^3 / 6 doubles per 16 columns of Z) is what bounds NC = 1.
@@ -808,9 +830,11 @@ __global__ __launch_bounds__(256, NC == 1 ? 2 : 1) void q2_apply_wave4(ApplyArgs
     }
     for (int t = 0; t < T; ++t) {
       const int b0 = Gtop + t;
+      Q2_STAMP(0);
       d2_t znew[NC];
       load_band(b0 + 2, znew);                             // the band that arrives for the next step
       lds_barrier();                                       // window complete
+      Q2_STAMP(1);
       const int k = t - 2 * wave;
       if (k >= 0 && k < nkw) {
         const int bw = b0 - 3 * wave;                      // this wave's bands: bw, bw + 1
@@ -830,6 +854,7 @@ __global__ __launch_bounds__(256, NC == 1 ? 2 : 1) void q2_apply_wave4(ApplyArgs
             if (kq < 12) ax[ct][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[0][kq], zb, ax[ct][0], 0, 0, 0);
             if (kq >= 4) ax[ct][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[1][kq], zb, ax[ct][1], 0, 0, 0);
           }
+        Q2_STAMP(2);
         if (k + 1 < nkw) load_v(k + 1);                    // (V's registers are free: the next block's travel under the second product)
 #pragma unroll
         for (int ct = 0; ct < NC; ++ct)
@@ -843,6 +868,7 @@ __global__ __launch_bounds__(256, NC == 1 ? 2 : 1) void q2_apply_wave4(ApplyArgs
         for (int ct = 0; ct < NC; ++ct)
 #pragma unroll
           for (int kq = 0; kq < 8; ++kq) xb[ct][kq] = xs[ct * TILE + (kq * 4 + lq) * XLD + lr];
+        Q2_STAMP(3);
         // Zw -= W X  (64 x 16 per tile, k = 32 reflectors): two row tiles at a time, so that two accumulator chains interleave
 #pragma unroll
         for (int zp = 0; zp < 2; ++zp)
@@ -866,15 +892,18 @@ __global__ __launch_bounds__(256, NC == 1 ? 2 : 1) void q2_apply_wave4(ApplyArgs
               zh[(16 + 4 * r + lq) * XLD + lr] = acc1[r];
             }
           }
+        Q2_STAMP(4);
         if (k + 1 < nkw) load_w(k + 1);
       }
       lds_barrier();                                       // every wave is done with its bands
+      Q2_STAMP(5);
       // band b0 - 9 is final for this pass; its slot is NOT the arriving band's (the ring has one spare slot), so the arriving
       // rows go to LDS first and the store follows (a wait for the next load must not also wait for this store)
       d2_t fin[NC];
       get_band(b0 - 9, fin);
       put_band(b0 + 2, znew);
       store_band(b0 - 9, fin);
+      Q2_STAMP(6);
     }
     lds_barrier();
     // what is still in the window after the last step: bands (Gtop + T) - 9 .. (Gtop + T) + 1
