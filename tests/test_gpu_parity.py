@@ -2177,15 +2177,16 @@ def test_c2_full_size_vs_oracle():
 
 @pytest.mark.noisy
 @pytest.mark.timeout(600)
-def test_n8192_d32_block_vs_torch_cpu_reference():
-    """one N = 8192, d = 32 block (the block size of BASELINE configs[3] / [4]) against the reference's torch-CPU operator sequence and
+@pytest.mark.parametrize("d", [32, 1024])
+def test_n8192_d32_block_vs_torch_cpu_reference(d):
+    """one N = 8192 block (the block size of BASELINE configs[3] / [4]; d = 32 and configs[3]'s own d = 1024) against the reference's torch-CPU operator sequence and
     its AUTOGRAD backward (oracle/torch_cpu_ref.py): +LL, d/dY (the gradient the residual chain learns through, CIGAR.py:122), the
     hyper-parameter gradients, and a 64-point posterior on the CPU run's own factor"""
     from oracle import gp_oracle as O
     from oracle import torch_cpu_ref as R
     from fidelityfusion_amd import kernel
     from fidelityfusion_amd.cigp_v10 import cigp
-    n, D, d, nt = 8192, 8, 32, 64
+    n, D, nt = 8192, 8, 64
     X, Y = O.synthetic_xy(n, D, d, seed=11)
     one = lambda k_: torch.ones(k_, dtype=torch.float64)
     Xc, Yc = torch.tensor(X), torch.tensor(Y)
@@ -2204,7 +2205,7 @@ def test_n8192_d32_block_vs_torch_cpu_reference():
         mean_c, var_c = R.cigp_forward(Xc, Yc, torch.tensor(Xs), 1.3 * one(D), 0.8 * one(1), 1.0 * one(1), L=keep["L"])
         mean, var = m(T(X), T(Y), T(Xs))
     errs["mean"], errs["var"] = rel(mean, mean_c), rel(var, var_c)
-    print("N=8192 d=32 vs torch-CPU autograd, relative errors:", errs)
+    print("N=8192 d=%d vs torch-CPU autograd, relative errors:" % d, errs)
     assert errs["ll"] < 1e-10, errs
     assert all(v < 1e-8 for v in errs.values()), errs
 
