@@ -83,6 +83,7 @@ EXPORTS = {
     "ffgp_destroy": (C.c_int, [C.c_void_p]),
     "ffgp_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ffgp_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
+    "ffgp_prepare_streams": (C.c_int, [C.c_void_p]),
     "ffgp_assemble": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, C.c_double, _dp, _dp,
                                 C.c_long, _dp, C.c_int, C.c_double, C.c_double, _dp, C.c_int, C.c_int, C.c_int, C.c_double]),
     "ffgp_assemble_pair": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, C.c_int, C.c_int, C.POINTER(KDesc), C.c_int, _dp, _dp, C.c_long,
@@ -198,7 +199,7 @@ class thread_slot:
 
 block_streams = {}   # (device, worker slot) -> the torch stream `functional.threaded_blocks`' worker of that slot always runs on
 _reserving = threading.RLock()
-DEFAULT_HW_QUEUES = 6
+DEFAULT_HW_QUEUES = 8
 
 
 def configure_queues(max_hw_queues=DEFAULT_HW_QUEUES, reserve_worker_streams=4, device_index=None):
@@ -208,12 +209,14 @@ def configure_queues(max_hw_queues=DEFAULT_HW_QUEUES, reserve_worker_streams=4, 
 
     1. Streams that share a hardware queue run their kernels in order.  ROCm maps all streams of a process onto GPU_MAX_HW_QUEUES
        queues, 4 by default; with a handle's own streams next to the workers' that is not enough -- gar8_hogp (four worker streams):
-       1.75 / 1.77 s per step with 4 queues, 1.46 / 1.49 with 6, 1.47 / 1.51 with 8; 16 double cigar4; 6 costs the other workloads
-       nothing measurable (docs/concurrency.md).  The variable is process-wide (every HIP user of the process sees it) and only read
+       1.75 / 1.77 s per step with 4 queues, 1.46 / 1.49 with 6, 1.47 / 1.51 with 8; 16 double cigar4.  Eight since the end of round 4:
+       the main handle's third stream (step 2 below) needs a queue of its own as well, and with six the HOGP workers then share
+       (1.72 s); 8 costs gar8 0.3-0.4 % (docs/concurrency.md).  The variable is process-wide (every HIP user of the process sees it) and only read
        when HIP initialises: an explicit setting in the environment wins, and a process whose HIP is already up gets a warning
        instead of a silent no-op.  `max_hw_queues=None` leaves the environment alone.
-    2. `reserve_worker_streams` > 0 (and a GPU is present): `reserve_block_streams` -- the worker streams claim their hardware
-       queues first.
+    2. `reserve_worker_streams` > 0 (and a GPU is present): the GPU's default handle is created and its side streams are used once
+       (`ffgp_prepare_streams`), THEN `reserve_block_streams` -- the handle's look-ahead chain and the head of its triangular inverse,
+       then the worker streams, claim their hardware queues before anything else of the process does.
     Returns the value of GPU_MAX_HW_QUEUES in effect for this process (None: ROCm's default)."""
     import torch
 
@@ -228,6 +231,10 @@ def configure_queues(max_hw_queues=DEFAULT_HW_QUEUES, reserve_worker_streams=4, 
             os.environ["GPU_MAX_HW_QUEUES"] = str(int(max_hw_queues))
             log.info("GPU_MAX_HW_QUEUES=%d set for this process (several blocks in flight per GPU)", max_hw_queues)
     if reserve_worker_streams and torch.cuda.is_available():
+        # the GPU's default handle first: its side streams (look-ahead chain, head of the triangular inverse) bind their hardware
+        # queues at creation, the workers take theirs after -- reserved the other way round, the handle's third stream shared the
+        # caller's queue (a training step at N = 4096: 3.4-3.5 instead of 3.1 ms, tools/queue_probe.py)
+        check(lib.ffgp_prepare_streams(handle(device_index, 0)), "ffgp_prepare_streams")
         reserve_block_streams(device_index, reserve_worker_streams)
     return os.environ.get("GPU_MAX_HW_QUEUES")
 

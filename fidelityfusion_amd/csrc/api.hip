@@ -175,6 +175,30 @@ static int create_resources(ffgp_handle* h) {
   return FFGP_OK;
 }
 
+static int ensure_aux2(ffgp_handle* h) {
+  if (h->aux2) return FFGP_OK;
+  FFGP_HIP(hipStreamCreateWithFlags(&h->aux2, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) FFGP_HIP(hipEventCreateWithFlags(&h->tri_ev[i], hipEventDisableTiming));
+  return FFGP_OK;
+}
+
+// ROCm binds a stream to one of its hardware queues at the stream's first USE, streams on one queue run in order, and a stream that
+// first appears late shares a queue with whatever is least loaded then.  The handle's third stream (head of the triangular inverse under
+// the factorisation's tail) is created by the first training step of a large block -- in a process that had reserved worker streams
+// before, it landed on the caller's queue and the head ran in line with the trailing updates instead of beside them (N = 4096 training
+// step 3.12 -> 3.40-3.49 ms with GPU_MAX_HW_QUEUES = 6, tools/queue_probe.py).  A process that is going to put several blocks in flight
+// calls this for its main handle BEFORE it creates the worker streams (fidelityfusion_amd._lib.configure_queues does).
+extern "C" int ffgp_prepare_streams(ffgp_handle* h) {
+  if (!h) return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  FFGP_CHECK(ensure_aux2(h));
+  FFGP_HIP(hipMemsetAsync(h->d_info + 8, 0, sizeof(int), h->aux));
+  FFGP_HIP(hipMemsetAsync(h->d_info + 9, 0, sizeof(int), h->aux2));
+  FFGP_HIP(hipStreamSynchronize(h->aux));
+  FFGP_HIP(hipStreamSynchronize(h->aux2));
+  return FFGP_OK;
+}
+
 int ffgp_create(int device, ffgp_handle** out) {
   if (!out) return FFGP_ERR_ARG;
   int count = 0;
@@ -1174,10 +1198,7 @@ static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll
   }
   h->tri_hook_fired = 0;
   h->tri_hook_col = n1s;
-  if (n1s && !h->aux2) {
-    FFGP_HIP(hipStreamCreateWithFlags(&h->aux2, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) FFGP_HIP(hipEventCreateWithFlags(&h->tri_ev[i], hipEventDisableTiming));
-  }
+  if (n1s) FFGP_CHECK(ensure_aux2(h));
   const int prc = ffgp_potrf_impl(h, W0, n, n + d, (int)ld, 0);
   h->tri_hook_col = 0;
   FFGP_CHECK(prc);

@@ -217,6 +217,10 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
             "trtri_overlap", "small_fused", "small_max_n", "eig_overlap", "sb_lookahead" (round-3 experiment
                         switches; some exist in the development build only: ffgp_has_dev_options)    */
 int ffgp_set_option(ffgp_handle* h, const char* key, double value);
+/* Create the handle's side streams now and use each once, so that they bind their hardware queues before streams the process creates
+   later (ROCm binds at first use; a late stream shares a queue with an earlier one and runs in line with it).  For the main handle of
+   a process that puts several blocks in flight on one GPU: call it before creating the worker streams.  No reference counterpart. */
+int ffgp_prepare_streams(ffgp_handle* h);
 const char* ffgp_version(void);
 /* 1 in the development build (`make dev`: the switches of measured-and-rejected experiments are accepted by ffgp_set_option), 0 in
    the shipped library */

@@ -114,8 +114,8 @@ def test_importing_the_package_leaves_the_environment_alone():
             "import fidelityfusion_amd\nfrom fidelityfusion_amd import _lib, functional\n"
             "assert 'GPU_MAX_HW_QUEUES' not in os.environ\n"
             "import logging\nlogging.basicConfig(level=logging.INFO)\n"
-            "assert _lib.configure_queues() == '6' and os.environ['GPU_MAX_HW_QUEUES'] == '6'\n"
-            "os.environ['GPU_MAX_HW_QUEUES'] = '5'\nassert _lib.configure_queues(8) == '5'\nprint('ok')\n" % ROOT)
+            "assert _lib.configure_queues() == '8' and os.environ['GPU_MAX_HW_QUEUES'] == '8'\n"
+            "os.environ['GPU_MAX_HW_QUEUES'] = '5'\nassert _lib.configure_queues(6) == '5'\nprint('ok')\n" % ROOT)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
     assert p.returncode == 0 and "ok" in p.stdout, p.stderr[-1500:]
-    assert "GPU_MAX_HW_QUEUES=6 set for this process" in p.stderr
+    assert "GPU_MAX_HW_QUEUES=8 set for this process" in p.stderr
