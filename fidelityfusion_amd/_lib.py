@@ -26,6 +26,7 @@ FFGP_KFUN_SE, FFGP_KFUN_MATERN12, FFGP_KFUN_MATERN32, FFGP_KFUN_MATERN52, FFGP_K
 PI_TRUNC = 3.1415  # GaussianProcess/cigp_v10.py:15 ; gp_computation_pack.py:17 ; MFGP_ver2023May/base_gp/cigp.py:6
 
 ERRORS = {-1: "FFGP_ERR_ARG", -2: "FFGP_ERR_HIP", -3: "FFGP_ERR_ALLOC", -4: "FFGP_ERR_NODEVICE"}
+FFGP_ERR_ARG, FFGP_ERR_HIP, FFGP_ERR_ALLOC, FFGP_ERR_NODEVICE = -1, -2, -3, -4
 
 _dp = C.c_void_p  # device pointers travel as void*
 
@@ -64,6 +65,11 @@ class Links(C.Structure):
     """ffgp_links: elementwise maps raw parameter -> effective quantity (include/ffgp.h FFGP_LINK_*)"""
     _fields_ = [("w_link", C.c_int), ("w_c", C.c_double), ("w_broadcast", C.c_int), ("amp_link", C.c_int), ("amp_c", C.c_double),
                 ("dadd_link", C.c_int), ("dadd_c", C.c_double), ("out_scale", C.c_double)]
+
+
+class Adam(C.Structure):
+    """ffgp_adam: torch.optim.Adam's hyper-parameters for ffgp_train_raw"""
+    _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double)]
 
 
 LINK_ID, LINK_INV_ABS_EPS, LINK_EXP_NEG, LINK_INV, LINK_ABS, LINK_EXP_SQ, LINK_SQUARE = range(7)
@@ -128,6 +134,8 @@ EXPORTS = {
     "ffgp_nlml_fused_small_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Problem), C.POINTER(Links), _dp, C.POINTER(Grads)]),
     "ffgp_nlml_fused_small_batch_async": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Problem), C.POINTER(Links), _dp, C.POINTER(Grads)]),
     "ffgp_nlml_fused_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Problem), C.POINTER(Links), _dp, C.POINTER(Grads), C.POINTER(C.c_int)]),
+    "ffgp_train_raw": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Problem), C.POINTER(Links), C.c_int, C.POINTER(Adam), _dp, C.c_long, C.c_long,
+                                 _dp, C.c_long]),
     "ffgp_nlml_fused_async": (C.c_int, [C.c_void_p, C.POINTER(Problem), _dp, C.POINTER(Grads)]),
     "ffgp_wait": (C.c_int, [C.c_void_p]),
     "ffgp_predict": (C.c_int, [C.c_void_p, C.POINTER(Problem), _dp, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_int]),
@@ -142,7 +150,8 @@ EXPORTS = {
 
 
 class FFGPError(RuntimeError):
-    pass
+    """a negative library status; `code` is the FFGP_ERR_* value (-1 ARG, -2 HIP, -3 ALLOC, -4 NODEVICE)"""
+    code = None
 
 
 def _load():
@@ -173,7 +182,9 @@ _lock = threading.Lock()
 def check(rc, what):
     """Negative status -> FFGPError; positive (pivot index) is returned to the caller."""
     if rc < 0:
-        raise FFGPError("%s failed: %s (%d)" % (what, ERRORS.get(rc, "?"), rc))
+        e = FFGPError("%s failed: %s (%d)" % (what, ERRORS.get(rc, "?"), rc))
+        e.code = rc
+        raise e
     return rc
 
 

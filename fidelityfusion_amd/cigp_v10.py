@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as F
+from .train import train_many  # noqa: F401  (K Adam steps of independent models per library call: the reference's train loops)
 
 
 def _kfun(k):
@@ -31,10 +32,12 @@ def negative_log_likelihood_many(models, xs, ys):
     """[m.negative_log_likelihood(x, y) for m, x, y in zip(models, xs, ys)] as one tensor [F] -- the per-fidelity / per-seed loops of
     the reference's experiments (Experiments/GAR_Aligned/exp_aligned.py:58-126, FidelityFusion_Models/ResGP.py:78-112) train
     independent models one after the other, each step a separate call; independent models can take their steps together.
-    ONE library call serves the batch when every model lives on the GPU in fp64 and either
-      * every model is small (N <= 128, D <= 16, d <= 16): one workgroup per model (`ffgp_nlml_fused_small_batch`), or
-      * the models are at least two blocks of one shape (the same N > 128 and d): they share ONE factorisation chain
-        (`ffgp_nlml_fused_batch`) -- eight N = 4096 blocks then cost what three cost one after the other;
+    With every model on the GPU in fp64 the batch is served by at most two library calls:
+      * the small models (N <= 128, D <= 16, d <= 16): one workgroup per model (`ffgp_nlml_fused_small_batch`);
+      * the larger ones, when there are at least two: ONE factorisation chain (`ffgp_nlml_fused_batch`) -- eight N = 4096 blocks then
+        cost what three cost one after the other.  Since round 5 the members may have DIFFERENT sizes (the reference's fidelities do:
+        300 / 300 / 250 points in FidelityFusion_Models/ResGP.py:121-136, 100 low against 4..32 high in
+        Experiments/GAR_Aligned/exp_aligned.py:66-74): a member drops out of the chain when its columns are used up;
     anything else falls back to the individual calls.  Values and gradients are those of the individual calls, bit for bit."""
     items = []
     for m, x, y in zip(models, xs, ys):
@@ -45,9 +48,25 @@ def negative_log_likelihood_many(models, xs, ys):
             break
         items.append({"X": x, "Y": y, "lk": lk, "rdadd": m.log_beta, "dadd_link": F._lib.LINK_EXP_NEG, "dadd_c": JITTER, "diag_vec": y_var,
                       "variant": F.FFGP_LL_V1, "pi_const": PI, "sign": -1.0})
-    if items is None or not F.many_batchable([(it["X"].shape[0], it["Y"].shape[1]) for it in items]):
-        return torch.stack([mm.negative_log_likelihood(xx, yy).reshape(()) for mm, xx, yy in zip(models, xs, ys)])
-    return F.nlml_raw_many(items)
+    single = lambda i: models[i].negative_log_likelihood(xs[i], ys[i]).reshape(())
+    if items is None:
+        return torch.stack([single(i) for i in range(len(models))])
+    shapes = [(it["X"].shape[0], it["Y"].shape[1]) for it in items]
+    if F.many_batchable(shapes):
+        return F.nlml_raw_many(items)
+    # a mix of small and larger models: one call per kind, results back in the caller's order
+    out = [None] * len(items)
+    small = [i for i, (n, _) in enumerate(shapes) if n <= F.SMALL_BATCH_MAX_N]
+    large = [i for i, (n, _) in enumerate(shapes) if n > F.SMALL_BATCH_MAX_N]
+    for idx in (small, large):
+        if len(idx) >= 2 and F.many_batchable([shapes[i] for i in idx]):
+            vals = F.nlml_raw_many([items[i] for i in idx])
+            for k, i in enumerate(idx):
+                out[i] = vals[k]
+        else:
+            for i in idx:
+                out[i] = single(i)
+    return torch.stack(out)
 
 
 class cigp(F.PosteriorCacheMixin, nn.Module):

@@ -1,4 +1,5 @@
 // libffgp C ABI: handle lifetime, workspace, fused NLML (+ gradients) and posterior paths.  See include/ffgp.h.
+#include <algorithm>
 #include <cmath>
 
 #include "ffgp_internal.h"
@@ -77,6 +78,8 @@ int ffgp_ensure_ws(ffgp_handle* h, size_t bytes) {
   const size_t want = (bytes + gran - 1) / gran * gran;
   if (hipMalloc(&h->ws, want) != hipSuccess) {
     fprintf(stderr, "[ffgp] workspace allocation of %zu bytes failed\n", want);
+    (void)hipGetLastError();   // (the failed hipMalloc's sticky status must not fail the next, smaller, call's launch checks)
+    h->ws = nullptr;
     return FFGP_ERR_ALLOC;
   }
   h->ws_bytes = want;
@@ -267,6 +270,7 @@ int ffgp_destroy(ffgp_handle* h) {
     if (h->eig_ev[i]) hipEventDestroy(h->eig_ev[i]);
   if (h->d_info) hipFree(h->d_info);
   if (h->bt_info) hipFree(h->bt_info);
+  if (h->train_g) hipFree(h->train_g);
   if (h->bt_info_host) hipHostFree(h->bt_info_host);
   if (h->d_scal) hipFree(h->d_scal);
   if (h->d_asm) hipFree(h->d_asm);
@@ -756,60 +760,82 @@ int ffgp_nlml_fused_small_batch(ffgp_handle* h, int F, const ffgp_problem* p, co
 // diagonal-block kernel runs one workgroup per block, the GEMMs carry the block index in gridDim.y -- so F blocks share ONE chain
 // and fill its gaps with F times the matrix-core work.  The per-block arithmetic is the single call's, instruction for instruction
 // (same kernels, same k order): the values are bit-identical to F separate calls.
-// Conditions (else FFGP_ERR_ARG, and the caller falls back to separate calls): F >= 2 blocks with the same n > 128 and d, V1
+// Conditions (else FFGP_ERR_ARG, and the caller falls back to separate calls): 2 <= F <= 256 blocks with n > 128, V1
 // likelihood, one radial-profile kernel each (no pair / tree / caller-built covariance), the round-4 diagonal-block kernel.
+// Round 5: the blocks may have DIFFERENT n and d (the reference's fidelities are ragged by nature, FidelityFusion_Models/ResGP.py:121-136):
+// every member follows its own single call's launch sequence and launches of the same kind at the same chain step are merged
+// (ffgp_potrf_ragged, ffgp_gemm_launch_rag), members drop out as their columns run out; members above 12288 rows are refused.
 // Gradients: the factorisation is shared, the inverse / gradient stages run block after block on the shared scratch.
 int ffgp_nlml_fused_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g,
                           int* status) {
   if (!h || !p || !nll_dev || F < 2 || F > 256) return FFGP_ERR_ARG;
-  const int n = p[0].n, d = p[0].d;
-  if (n <= FFGP_NB || d <= 0 || h->use_naive || h->diag_v2 != 4 || h->diag_dbg) return FFGP_ERR_ARG;
-  bool want_grad = false;
+  if (h->use_naive || h->diag_v2 != 4 || h->diag_dbg) return FFGP_ERR_ARG;
+  bool want_grad = false, uniform = true;
   for (int f = 0; f < F; ++f) {
     const ffgp_problem& q = p[f];
-    if (q.n != n || q.d != d || q.cov_dev || q.pair || q.tree || !q.X_dev || !q.Y_dev || !q.w_dev || !q.amp_dev || q.D <= 0 || q.D > 128 ||
+    if (q.n <= FFGP_NB || q.d <= 0 || q.cov_dev || q.pair || q.tree || !q.X_dev || !q.Y_dev || !q.w_dev || !q.amp_dev || q.D <= 0 || q.D > 128 ||
         q.ll_variant != FFGP_LL_V1 || q.kfun < FFGP_KFUN_SE || q.kfun > FFGP_KFUN_RQ)
       return FFGP_ERR_ARG;
+    uniform = uniform && q.n == p[0].n && q.d == p[0].d;
     if (g) {
       const ffgp_grads& gg = g[f];
       if (gg.g_cov_dev || gg.g_pair) return FFGP_ERR_ARG;
       want_grad = want_grad || gg.g_w_dev || gg.g_amp_dev || gg.g_diag_add_dev || gg.g_Y_dev || gg.g_diag_vec_dev || gg.g_kparam_dev;
     }
   }
+  if (!uniform) {      // members of different sizes: the ragged chain's own limits (ffgp_potrf_ragged)
+    if (h->nb_big > h->nb_outer) return FFGP_ERR_ARG;
+    for (int f = 0; f < F; ++f)
+      if (h->lookahead && p[f].n > h->nb_outer && p[f].n > h->la_min_n && !(h->la_carry == 1 || (h->la_carry == 2 && p[f].n <= 12288)))
+        return FFGP_ERR_ARG;
+  }
   FFGP_HIP(hipSetDevice(h->device));
-  const size_t ld = ffgp_round_up(n, 16);
-  const size_t blk = (size_t)(n + d) * ld;                 // Sigma | Y^T  ->  L | Gamma^T   of one block
-  const size_t n1 = ffgp_round_up((n + 1) / 2, FFGP_NB);
+  // per-member layout: [Sigma | Y^T] -> [L | Gamma^T] blocks one after the other, each with its own leading dimension
+  std::vector<size_t> ldv(F), offv(F), doffv(F);
+  std::vector<int> nblkv(F);
+  size_t total = 0, dinv_blocks = 0, sX = 0, sT = 0, sAt = 0, sP = 0;
   int Dmax = 0;
-  for (int f = 0; f < F; ++f) Dmax = p[f].D > Dmax ? p[f].D : Dmax;
-  size_t total = blk * F;
+  for (int f = 0; f < F; ++f) {
+    const int n = p[f].n, d = p[f].d;
+    ldv[f] = ffgp_round_up(n, 16);
+    offv[f] = total;
+    total += (size_t)(n + d) * ldv[f];
+    nblkv[f] = (n + FFGP_NB - 1) / FFGP_NB;
+    doffv[f] = dinv_blocks * FFGP_NB * FFGP_NB;
+    dinv_blocks += nblkv[f];
+    const size_t n1 = ffgp_round_up((n + 1) / 2, FFGP_NB);
+    sX = std::max(sX, (size_t)n * ldv[f]);
+    sT = std::max(sT, 2 * (n1 * n1 + 16));
+    sAt = std::max(sAt, (size_t)d * ldv[f]);
+    sP = std::max(sP, (size_t)ffgp_grad_partial_doubles(n, p[f].D) + 16);
+    Dmax = p[f].D > Dmax ? p[f].D : Dmax;
+  }
+  const size_t blk = offv.size() > 1 ? offv[1] - offv[0] : total;     // (uniform batches: the stride between the blocks)
   const size_t o_link = total; total += (size_t)F * 512;   // effective parameters / their gradients, 256 + 256 doubles per block
   size_t o_X = 0, o_S = 0, o_T = 0, o_At = 0, o_P = 0;
-  // gradient stage: when EVERY block wants gradients (and the inverses fit), Sigma_f^-1 of all blocks come out of one sequence of
-  // launches with an outer batch index (ffgp_trtri_lauum_ob) -- a lone N = 4096 inverse underfills the chip at its lower levels;
-  // otherwise block after block through one set of buffers
-  bool all_grad = want_grad && g && h->batch_grad_ob;
+  // gradient stage: when EVERY block of an equal-shape batch wants gradients (and the inverses fit), Sigma_f^-1 of all blocks come out
+  // of one sequence of launches with an outer batch index (ffgp_trtri_lauum_ob) -- a lone N = 4096 inverse underfills the chip at its
+  // lower levels; otherwise block after block through one set of buffers
+  bool all_grad = want_grad && g && h->batch_grad_ob && uniform;
   for (int f = 0; f < F && all_grad; ++f) {
     const ffgp_grads& gg = g[f];
     all_grad = gg.g_w_dev || gg.g_amp_dev || gg.g_diag_add_dev || gg.g_Y_dev || gg.g_diag_vec_dev || gg.g_kparam_dev;
   }
-  const size_t sX = (size_t)n * ld, sT = 2 * (n1 * n1 + 16);
   if (all_grad && (size_t)F * (2 * sX + sT) * sizeof(double) > ((size_t)48 << 30)) all_grad = false;
   const size_t copies = all_grad ? (size_t)F : 1;
   if (want_grad) {
     o_X = total; total += copies * sX;
     o_S = total; total += copies * sX;
     o_T = total; total += copies * sT;
-    o_At = total; total += (size_t)d * ld;
-    o_P = total; total += ffgp_grad_partial_doubles(n, Dmax) + 16;
+    o_At = total; total += sAt;
+    o_P = total; total += sP;
   }
   FFGP_CHECK(ffgp_ensure_ws(h, total * sizeof(double)));
   if (!h->bt_info) {
     FFGP_HIP(hipMalloc(&h->bt_info, 256 * sizeof(int)));
     FFGP_HIP(hipHostMalloc(&h->bt_info_host, 256 * sizeof(int)));
   }
-  const int nblk = (n + FFGP_NB - 1) / FFGP_NB;
-  FFGP_CHECK(ffgp_ensure_dinv(h, F * nblk * FFGP_NB));
+  FFGP_CHECK(ffgp_ensure_dinv(h, (int)(dinv_blocks * FFGP_NB)));
   FFGP_CHECK(ffgp_zero_async(h, h->bt_info, (size_t)F * sizeof(int)));
   h->n_stages = 0;
   stage_mark(h, 0);
@@ -817,6 +843,7 @@ int ffgp_nlml_fused_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ff
   ffgp_problem* q = (ffgp_problem*)alloca(sizeof(ffgp_problem) * F);
   for (int f = 0; f < F; ++f) {
     q[f] = p[f];
+    const int n = p[f].n, d = p[f].d;
     double* eff = h->ws + o_link + (size_t)f * 512;
     if (l) {
       hipLaunchKernelGGL(ffgp_link_fwd, dim3(1), dim3(128), 0, h->stream, l[f], p[f].D, p[f].w_dev, p[f].amp_dev, p[f].diag_add_dev, eff);
@@ -824,21 +851,28 @@ int ffgp_nlml_fused_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ff
       q[f].amp_dev = eff + p[f].D;
       if (p[f].diag_add_dev) q[f].diag_add_dev = eff + p[f].D + 1;
     }
-    double* W0 = h->ws + blk * f;
+    double* W0 = h->ws + offv[f];
     FFGP_CHECK(ffgp_assemble_impl(h, q[f].X_dev, n, q[f].X_dev, n, q[f].D, q[f].w_dev, q[f].amp_dev, q[f].clamp_min, q[f].diag_add_dev,
                                   q[f].diag_vec_dev, q[f].diag_stride, q[f].add_mat_dev, q[f].ld_add, q[f].add_all, q[f].mean_jitter, W0,
-                                  (int)ld, 1, q[f].kfun, q[f].kparam));
-    FFGP_CHECK(ffgp_transpose(h, q[f].Y_dev, n, d, d, W0 + (size_t)n * ld, (int)ld, 1.0));
+                                  (int)ldv[f], 1, q[f].kfun, q[f].kparam));
+    FFGP_CHECK(ffgp_transpose(h, q[f].Y_dev, n, d, d, W0 + (size_t)n * ldv[f], (int)ldv[f], 1.0));
   }
   stage_mark(h, 1);
   // ---- ONE factorisation chain for all F blocks
   h->tri_hook_col = 0;
   h->tri_hook_fired = 0;
-  h->bt_F = F;
-  h->bt_sA = (long)blk;
-  h->bt_sD = (long)nblk * FFGP_NB * FFGP_NB;
-  const int prc = ffgp_potrf_impl(h, h->ws, n, n + d, (int)ld, 0);
-  h->bt_F = 0;
+  int prc;
+  if (uniform) {
+    h->bt_F = F;
+    h->bt_sA = (long)blk;
+    h->bt_sD = (long)nblkv[0] * FFGP_NB * FFGP_NB;
+    prc = ffgp_potrf_impl(h, h->ws, p[0].n, p[0].n + p[0].d, (int)ldv[0], 0);
+    h->bt_F = 0;
+  } else {
+    std::vector<ffgp_rag_block> mem(F);
+    for (int f = 0; f < F; ++f) mem[f] = ffgp_rag_block{h->ws + offv[f], p[f].n, p[f].n + p[f].d, (int)ldv[f], h->dinv + doffv[f], f};
+    prc = ffgp_potrf_ragged(h, F, mem.data());
+  }
   h->dinv_L = nullptr;          // (the store holds F factors' inverses: it belongs to none of them as far as the cache is concerned)
   h->sinv_L = nullptr;
   FFGP_CHECK(prc);
@@ -846,18 +880,20 @@ int ffgp_nlml_fused_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ff
   double* const dinv0 = h->dinv;
   int rc_stage = FFGP_OK;
   if (all_grad)
-    rc_stage = ffgp_trtri_lauum_ob(h, F, h->ws, (long)blk, n, (int)ld, h->ws + o_X, (long)sX, (int)ld, h->ws + o_T, (long)sT, h->ws + o_S,
-                                   (long)sX, (int)ld, dinv0, (long)nblk * FFGP_NB * FFGP_NB);
+    rc_stage = ffgp_trtri_lauum_ob(h, F, h->ws, (long)blk, p[0].n, (int)ldv[0], h->ws + o_X, (long)sX, (int)ldv[0], h->ws + o_T, (long)sT,
+                                   h->ws + o_S, (long)sX, (int)ldv[0], dinv0, (long)nblkv[0] * FFGP_NB * FFGP_NB);
   for (int f = 0; f < F && rc_stage == FFGP_OK; ++f) {
-    double* W0 = h->ws + blk * f;
+    const int n = p[f].n, d = p[f].d;
+    const int ld = (int)ldv[f];
+    double* W0 = h->ws + offv[f];
     double* Gt = W0 + (size_t)n * ld;
-    rc_stage = ffgp_nll_reduce_impl(h, FFGP_LL_V1, W0, n, (int)ld, Gt, d, n, (int)ld, d, q[f].pi_const, nll_dev + f);
+    rc_stage = ffgp_nll_reduce_impl(h, FFGP_LL_V1, W0, n, ld, Gt, d, n, ld, d, q[f].pi_const, nll_dev + f);
     if (rc_stage != FFGP_OK || !want_grad || !g) continue;
     const ffgp_grads& gg = g[f];
     if (!(gg.g_w_dev || gg.g_amp_dev || gg.g_diag_add_dev || gg.g_Y_dev || gg.g_diag_vec_dev || gg.g_kparam_dev)) continue;
     // the block's own slice of the Dinv store, presented as "the" store of this factor while its inverse is formed
-    h->dinv = dinv0 + (size_t)f * nblk * FFGP_NB * FFGP_NB;
-    h->dinv_L = W0; h->dinv_n = n; h->dinv_ld = (int)ld;
+    h->dinv = dinv0 + doffv[f];
+    h->dinv_L = W0; h->dinv_n = n; h->dinv_ld = ld;
     double* X = h->ws + o_X + (all_grad ? (size_t)f * sX : 0);
     double* S = h->ws + o_S + (all_grad ? (size_t)f * sX : 0);
     double* T = h->ws + o_T;
@@ -874,16 +910,16 @@ int ffgp_nlml_fused_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ff
       chain = gg.g_w_dev || gg.g_amp_dev || gg.g_diag_add_dev;
     }
     if (!all_grad) {
-      if ((rc_stage = ffgp_trtri_impl(h, W0, n, (int)ld, X, (int)ld, T)) != FFGP_OK) break;
-      if ((rc_stage = ffgp_lauum_impl(h, X, n, (int)ld, S, (int)ld)) != FFGP_OK) break;
+      if ((rc_stage = ffgp_trtri_impl(h, W0, n, ld, X, ld, T)) != FFGP_OK) break;
+      if ((rc_stage = ffgp_lauum_impl(h, X, n, ld, S, ld)) != FFGP_OK) break;
     }
-    if ((rc_stage = ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Gt, (int)ld, X, (int)ld, At, (int)ld, d, n, n, 1.0, 0.0,
+    if ((rc_stage = ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, Gt, ld, X, ld, At, ld, d, n, n, 1.0, 0.0,
                                      TRI_LO_J)) != FFGP_OK) break;
-    if ((rc_stage = ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_LOWER, 0, At, (int)ld, At, (int)ld, S, (int)ld, n, n, d, -0.5,
+    if ((rc_stage = ffgp_gemm_launch(h, OP_MNMAJOR, OP_MNMAJOR, TILES_LOWER, 0, At, ld, At, ld, S, ld, n, n, d, -0.5,
                                      0.5 * (double)d)) != FFGP_OK) break;
-    if ((rc_stage = ffgp_grad_impl(h, q[f].X_dev, n, D, q[f].w_dev, q[f].amp_dev, q[f].clamp_min, S, (int)ld, q[f].mean_jitter, gq.g_w_dev,
+    if ((rc_stage = ffgp_grad_impl(h, q[f].X_dev, n, D, q[f].w_dev, q[f].amp_dev, q[f].clamp_min, S, ld, q[f].mean_jitter, gq.g_w_dev,
                                    gq.g_amp_dev, gq.g_diag_add_dev, gq.g_diag_vec_dev, P, q[f].kfun, q[f].kparam, gq.g_kparam_dev)) != FFGP_OK) break;
-    if (gg.g_Y_dev && (rc_stage = ffgp_transpose(h, At, d, n, (int)ld, gg.g_Y_dev, d, 1.0)) != FFGP_OK) break;
+    if (gg.g_Y_dev && (rc_stage = ffgp_transpose(h, At, d, n, ld, gg.g_Y_dev, d, 1.0)) != FFGP_OK) break;
     if (l) {
       const double sc = (l[f].out_scale == 0.0) ? 1.0 : l[f].out_scale;
       if (chain)
@@ -928,6 +964,93 @@ int ffgp_nlml_fused_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ff
     if (v != 0 && first == FFGP_OK) first = v;
   }
   return first;
+}
+
+// ---- K training steps in ONE call -------------------------------------------------------------------------------------------
+// The reference's hot loop (FidelityFusion_Models/ResGP.py:78-112: per fidelity 100-1000 iterations of zero_grad / loss =
+// -negative_log_likelihood / backward / Adam step at N = 16 ... 500) costs one Python round trip, one autograd graph and one status
+// read-back per iteration through the drop-in modules -- 0.28-0.32 ms at N <= 128, of which 0.125 ms is GPU work.  Here the whole
+// loop is enqueued by one call: per step the likelihood + closed-form gradients on the raw parameters (the same launches as
+// ffgp_nlml_fused_raw, or ONE launch for all models when they are small: ffgp_nlml_fused_small_batch's kernel) and one Adam
+// kernel that updates the raw parameters IN PLACE on the device (torch.optim.Adam's arithmetic, operation for operation: lerp,
+// mul + addcmul, bias corrections computed on the host with the C library's pow as Python does, sqrt / div / add eps, addcdiv) and
+// stores the step's loss in the trace.  No host synchronisation inside the loop; the factorisation status is sticky and read once
+// at the end (the first step whose Sigma was not positive definite; the parameters stop moving from that step on).
+static int nlml_fused_raw_plain(ffgp_handle* h, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g);
+
+__global__ void ffgp_adam_kernel(int F, ffgp_train_slot sl, const double* __restrict__ gbuf, double* __restrict__ state, long state_stride,
+                                 double lr, double b1, double b2, double eps, double bc1, double bc2_sqrt, const double* __restrict__ loss,
+                                 double* __restrict__ trace, long trace_stride, int step, const int* __restrict__ info) {
+  const int f = blockIdx.x;
+  if (f >= F) return;
+  const int bad = info[0] | info[1];
+  const int nw = sl.nw[f];
+  if (threadIdx.x == 0) trace[(size_t)f * trace_stride + step] = bad ? __builtin_nan("") : loss[f];
+  if (bad) return;
+  const int i = threadIdx.x;
+  if (i >= nw + 2) return;
+  double* par = (i < nw) ? sl.w[f] + i : (i == nw ? sl.amp[f] : sl.dadd[f]);
+  const double g = gbuf[(size_t)f * FFGP_TRAIN_GSTRIDE + i];
+  double* m = state + (size_t)f * state_stride + i;
+  double* v = m + (nw + 2);
+  const double m1 = m[0] + (g - m[0]) * (1.0 - b1);        // exp_avg.lerp_(grad, 1 - beta1)
+  const double v1 = v[0] * b2 + (1.0 - b2) * g * g;        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+  m[0] = m1;
+  v[0] = v1;
+  const double denom = sqrt(v1) / bc2_sqrt + eps;
+  par[0] = par[0] + (-(lr / bc1)) * (m1 / denom);          // param.addcdiv_(exp_avg, denom, value = -step_size)
+}
+
+int ffgp_train_raw(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_links* l, int steps, const ffgp_adam* opt, double* state_dev,
+                   long state_stride, long step0, double* trace_dev, long trace_stride) {
+  if (!h || !p || !l || !opt || !state_dev || !trace_dev || F <= 0 || F > FFGP_TRAIN_MAXF || steps <= 0 || step0 < 0 || trace_stride < steps)
+    return FFGP_ERR_ARG;
+  FFGP_HIP(hipSetDevice(h->device));
+  ffgp_train_slot sl;
+  bool all_small = true;
+  for (int f = 0; f < F; ++f) {
+    const ffgp_problem& q = p[f];
+    if (!q.w_dev || !q.amp_dev || !q.diag_add_dev || q.cov_dev || q.pair || q.tree || q.D <= 0 || q.D > 128 || q.n <= 0 || q.d <= 0) return FFGP_ERR_ARG;
+    const int nw = l[f].w_broadcast ? 1 : q.D;
+    if (state_stride < 2 * (nw + 2)) return FFGP_ERR_ARG;
+    sl.w[f] = const_cast<double*>(q.w_dev);
+    sl.amp[f] = const_cast<double*>(q.amp_dev);
+    sl.dadd[f] = const_cast<double*>(q.diag_add_dev);
+    sl.nw[f] = nw;
+  }
+  if (!h->train_g) {
+    FFGP_HIP(hipMalloc(&h->train_g, (size_t)FFGP_TRAIN_MAXF * (FFGP_TRAIN_GSTRIDE + 1) * sizeof(double)));
+  }
+  double* gbuf = h->train_g;
+  double* loss = h->train_g + (size_t)FFGP_TRAIN_MAXF * FFGP_TRAIN_GSTRIDE;
+  std::vector<ffgp_grads> g(F);
+  std::vector<ffgp_links> lk(l, l + F);
+  for (int f = 0; f < F; ++f) {
+    memset(&g[f], 0, sizeof(ffgp_grads));
+    g[f].g_w_dev = gbuf + (size_t)f * FFGP_TRAIN_GSTRIDE;
+    g[f].g_amp_dev = g[f].g_w_dev + sl.nw[f];
+    g[f].g_diag_add_dev = g[f].g_amp_dev + 1;
+    all_small = all_small && ffgp_small_batch_ok(p + f, &g[f]);
+  }
+  // the sticky status word starts clean: a failure of an EARLIER call on this handle is that call's to report
+  FFGP_CHECK(ffgp_zero_async(h, h->d_info, 2 * sizeof(int)));
+  for (int k = 0; k < steps; ++k) {
+    if (all_small && F > 1) {
+      FFGP_CHECK(ffgp_zero_async(h, h->d_info, sizeof(int)));
+      FFGP_CHECK(ffgp_small_batch_enqueue(h, F, p, lk.data(), loss, g.data()));
+      hipLaunchKernelGGL(ffgp_sticky_info_kernel, dim3(1), dim3(1), 0, h->stream, h->d_info);
+    } else {
+      for (int f = 0; f < F; ++f) FFGP_CHECK(nlml_fused_raw_plain(h, p + f, &lk[f], loss + f, &g[f]));
+    }
+    const double t = (double)(step0 + k + 1);
+    const double bc1 = 1.0 - std::pow(opt->beta1, t), bc2 = 1.0 - std::pow(opt->beta2, t);
+    hipLaunchKernelGGL(ffgp_adam_kernel, dim3(F), dim3(192), 0, h->stream, F, sl, gbuf, state_dev, state_stride, opt->lr, opt->beta1,
+                       opt->beta2, opt->eps, bc1, std::sqrt(bc2), loss, trace_dev, trace_stride, k, h->d_info);
+  }
+  if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
+  FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  ffgp_invalidate(h);
+  return ffgp_wait(h);
 }
 
 // ---- launch-bound sizes: the whole call as one captured graph ---------------------------------------------------------------

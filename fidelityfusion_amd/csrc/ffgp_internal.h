@@ -118,6 +118,29 @@ struct GemmArgs {
   long sA2, sB2, sC2;
 };
 
+// one member of a ragged GEMM launch (ffgp_gemm_f64_rag): everything of GemmArgs that differs between the members
+#define FFGP_RAG_MAX 8
+struct GemmRagMember {
+  const double* A;
+  const double* B;
+  double* C;
+  int m, n, k;
+  int lda, ldb, ldc;
+  int tiles_m, tiles_n, total_tiles, grid, split_at;
+  int fast, avec, bvec;
+};
+struct GemmRag {
+  GemmArgs base;        // what the members share: alpha, beta, prio, band_log2, pad_lds, triangular hints (none)
+  GemmRagMember mem[FFGP_RAG_MAX];
+};
+// one operand set of a ragged launch as the caller describes it
+struct GemmRagIn {
+  const double* A; int lda;
+  const double* B; int ldb;
+  double* C; int ldc;
+  int m, n, k;
+};
+
 struct ffgp_handle {
   int device;
   hipStream_t stream;   // stream work is enqueued on (caller's, or `own`)
@@ -175,6 +198,7 @@ struct ffgp_handle {
   int ob_F;
   int ob_n;
   struct { const double* lo; const double* hi; long stride; } ob_rng[6];
+  double* train_g;      // ffgp_train_raw: gradients of the raw parameters [MAXF x GSTRIDE] + the step's losses [MAXF]
   int* bt_info;         // [F] device status words (first non-positive pivot of each block)
   int* bt_info_host;    // pinned mirror
   int trtri_overlap;    // option (default 1)
@@ -236,6 +260,27 @@ enum { ALIAS_NONE = 0, ALIAS_A = 1, ALIAS_B = 2 };
 int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, const double* A, int lda, const double* B,
                      int ldb, double* C, int ldc, int m, int n, int k, double alpha, double beta, int tri = 0,
                      int alias = ALIAS_NONE, int batch = 1, long sA = 0, long sB = 0, long sC = 0);
+// K-steps-per-call training (ffgp_train_raw): the raw parameter storages of up to FFGP_TRAIN_MAXF models, by value to the Adam kernel
+#define FFGP_TRAIN_MAXF 16
+#define FFGP_TRAIN_GSTRIDE 160       // doubles per model in the gradient buffer: raw w (<= 128) | amp | diag_add
+struct ffgp_train_slot {
+  double* w[FFGP_TRAIN_MAXF];
+  double* amp[FFGP_TRAIN_MAXF];
+  double* dadd[FFGP_TRAIN_MAXF];
+  int nw[FFGP_TRAIN_MAXF];
+};
+
+// one member of a ragged factorisation chain (ffgp_potrf_ragged): its (mtot x n) matrix [Sigma | passenger rows], its slice of the
+// Dinv store (n / 128 blocks of 128 x 128, zero above the diagonal) and the index of its status word in ffgp_handle::bt_info
+struct ffgp_rag_block {
+  double* A;
+  int n, mtot, lda;
+  double* dinv;
+  int info_index;
+};
+int ffgp_potrf_ragged(ffgp_handle* h, int R, const ffgp_rag_block* mem);
+// ragged form of the chain's K-major products: R members of one kind with their own sizes / operands (see gemm.hip)
+int ffgp_gemm_launch_rag(ffgp_handle* h, int mode, int syrk_tag, int R, const GemmRagIn* in, double alpha, double beta, int alias);
 // ---- potrf.hip
 int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int sync_info);
 int ffgp_ensure_dinv(ffgp_handle* h, int n);

@@ -18,6 +18,8 @@
 // Workgroup -> tile map: XCD-aware (blocks b, b+8, ... share an XCD/L2, so each XCD gets a contiguous chunk
 // of the tile order) over 8-tile-row bands walked column-major, so the ~64 tiles resident on one XCD share
 // 8 A panels and ~8 B panels through its L2.
+#include <algorithm>
+
 #include "ffgp_internal.h"
 
 #define BK 16
@@ -474,19 +476,12 @@ __device__ __forceinline__ void gemm_one_tile(const GemmArgs& p, const double* _
   FFGP_TRACE(3);
 }
 
-template <int OPA, int OPB, int MODE, int TAG, int TM, int TN>
-__global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) double smem[2 * (opbuf<OPA, TM>() + opbuf<OPB, TN>())];
-  const int tid = threadIdx.x;
-  if (p.prio) __builtin_amdgcn_s_setprio(2);  // panel GEMMs of the look-ahead chain outrank the trailing update
-  // batched launches (gridDim.y > 1): identical problems at fixed strides (the levels of the blocked TRTRI)
-  const double* __restrict__ Ag = p.A + (size_t)blockIdx.y * p.sA + (size_t)blockIdx.z * p.sA2;
-  const double* __restrict__ Bg = p.B + (size_t)blockIdx.y * p.sB + (size_t)blockIdx.z * p.sB2;
-  double* __restrict__ Cg = p.C + (size_t)blockIdx.y * p.sC + (size_t)blockIdx.z * p.sC2;
-
+// the work of one workgroup of a GEMM launch: block id -> tile (or quarter tile of the split tail) -> gemm_one_tile
+template <int OPA, int OPB, int MODE, int TM, int TN>
+__device__ __forceinline__ void gemm_block(const GemmArgs& p, const double* __restrict__ Ag, const double* __restrict__ Bg,
+                                           double* __restrict__ Cg, double* smem, const int tid, const int bid) {
   // One workgroup per tile.  (A persistent 2-per-CU grid was measured and dropped: it keeps the two workgroups of
   // a CU in lock-step, so their prologues and epilogues coincide instead of hiding under each other's k loop.)
-  const int bid = blockIdx.x;
   FFGP_TRACE(0);
   if constexpr (TM == 128 && TN == 128) {
     // Split tail: equal-sized tiles finish in rounds of (resident workgroups) and the last round is mostly idle CUs.
@@ -519,6 +514,39 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
   ti = __builtin_amdgcn_readfirstlane(ti);
   tj = __builtin_amdgcn_readfirstlane(tj);
   gemm_one_tile<OPA, OPB, MODE, TM, TN>(p, Ag, Bg, Cg, smem, ti, tj, tid, bid);
+}
+
+template <int OPA, int OPB, int MODE, int TAG, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) double smem[2 * (opbuf<OPA, TM>() + opbuf<OPB, TN>())];
+  const int tid = threadIdx.x;
+  if (p.prio) __builtin_amdgcn_s_setprio(2);  // panel GEMMs of the look-ahead chain outrank the trailing update
+  // batched launches (gridDim.y > 1): identical problems at fixed strides (the levels of the blocked TRTRI)
+  const double* __restrict__ Ag = p.A + (size_t)blockIdx.y * p.sA + (size_t)blockIdx.z * p.sA2;
+  const double* __restrict__ Bg = p.B + (size_t)blockIdx.y * p.sB + (size_t)blockIdx.z * p.sB2;
+  double* __restrict__ Cg = p.C + (size_t)blockIdx.y * p.sC + (size_t)blockIdx.z * p.sC2;
+  gemm_block<OPA, OPB, MODE, TM, TN>(p, Ag, Bg, Cg, smem, tid, blockIdx.x);
+}
+
+// Ragged launch (the shared factorisation chain of blocks of DIFFERENT sizes, ffgp_potrf_ragged): gridDim.y members, each with its
+// own operands, sizes, leading dimensions and tile counts -- every member's launch as its own single call would make it (same tile
+// shape: the launcher groups members by that decision), so that its values are the single call's bit for bit.  gridDim.x is the
+// largest member's grid; a member's surplus workgroups leave at once.
+template <int OPA, int OPB, int MODE, int TAG, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void ffgp_gemm_f64_rag(GemmRag q) {
+  __shared__ __attribute__((aligned(16))) double smem[2 * (opbuf<OPA, TM>() + opbuf<OPB, TN>())];
+  const int tid = threadIdx.x;
+  const GemmRagMember& r = q.mem[blockIdx.y];
+  if ((int)blockIdx.x >= r.grid) return;
+  if (q.base.prio) __builtin_amdgcn_s_setprio(2);
+  GemmArgs p = q.base;
+  p.A = r.A; p.B = r.B; p.C = r.C;
+  p.m = r.m; p.n = r.n; p.k = r.k;
+  p.lda = r.lda; p.ldb = r.ldb; p.ldc = r.ldc;
+  p.tiles_m = r.tiles_m; p.tiles_n = r.tiles_n; p.total_tiles = r.total_tiles;
+  p.grid = r.grid; p.split_at = r.split_at;
+  p.fast = r.fast; p.avec = r.avec; p.bvec = r.bvec;
+  gemm_block<OPA, OPB, MODE, TM, TN>(p, p.A, p.B, p.C, smem, tid, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -701,6 +729,105 @@ static void launch_skinny(ffgp_handle* h, int opa, const SkinnyArgs& a, int part
     hipLaunchKernelGGL(ffgp_skinny_mnmajor<NC>, dim3((a.m + 63) / 64, parts), dim3(512), 0, h->stream, a);
 }
 
+// The shape decision of one launch: tile shape (128 / 64 / 32-row, see below), fast form, split tail, polite padding -- everything
+// between ffgp_gemm_launch's special paths and the launch itself, as a function of the operands' sizes alone, so that a ragged
+// launch (ffgp_gemm_launch_rag) can take it member by member exactly as each member's own single launch would.
+struct GemmPlan {
+  GemmArgs a;
+  int tsm, tsn;
+  int syrk_tag;     // 1 only when the launch is the 128-tile trailing update (the roofline kernel's own instantiation)
+};
+
+static int gemm_plan(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, const double* A, int lda, const double* B, int ldb, double* C,
+                     int ldc, int m, int n, int k, double alpha, double beta, int tri, int alias, int batch, long sA, long sB, long sC,
+                     GemmPlan& pl) {
+  GemmArgs& a = pl.a;
+  a = GemmArgs();
+  // vector (16-byte) operand loads need even leading dimensions and 16-byte aligned bases
+  a.avec = (!(lda & 1) && aligned16(A)) ? 1 : 0;
+  a.bvec = (!(ldb & 1) && aligned16(B)) ? 1 : 0;
+  a.A = A; a.B = B; a.C = C;
+  a.m = m; a.n = n; a.k = k;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.alpha = alpha; a.beta = beta;
+  a.prio = (h->stream == h->aux && h->aux_prio) ? 1 : 0;
+  a.batch2 = 1;
+  a.sA2 = a.sB2 = a.sC2 = 0;
+  // batch < 0: |batch| members, with every shape decision below taken as ONE member's launch would take it -- the batched
+  // factorisation (ffgp_nlml_fused_batch) promises the single call's values bit for bit, and the forms differ in rounding (the fast
+  // 128-tile accumulates onto C, the general tiles add alpha * (sum) to beta * C once)
+  const int dec_batch = (batch < 0) ? 1 : (batch > 1 ? batch : 1);
+  if (batch < 0) batch = -batch;
+  a.batch = batch > 1 ? batch : 1;
+  a.sA = sA; a.sB = sB; a.sC = sC;
+  if ((sA & 1) || (sB & 1)) a.avec = a.bvec = 0;  // odd strides break the 16-byte alignment of later batch members
+  a.lo_i = (tri & TRI_LO_I) ? 1 : 0;
+  a.lo_j = (tri & TRI_LO_J) ? 1 : 0;
+  a.hi_i = (tri & TRI_HI_I) ? 1 : 0;
+  a.hi_j = (tri & TRI_HI_J) ? 1 : 0;
+  // tile shape: the 128-tile is the throughput shape; below ~1.5 tiles per CU the launch is latency-bound and
+  // the 64-tile (4x the workgroups, a quarter of the per-tile MFMA chain) finishes sooner; the kernels of the
+  // factorisation's dependency chain (K-major operands) go one step further to 32-row tiles when even the 64-tiles
+  // would leave most CUs with a single 4-16 us MFMA chain
+  int tsm = 128, tsn = 128;
+  a.total_tiles = count_tiles(mode, m, n, 128, 128, a.tiles_m, a.tiles_n);
+  int level = 0;
+  if (h->force_ts == 64) level = 1;
+  else if (h->force_ts == 32) level = 2;
+  else if (h->force_ts == 0 && a.total_tiles * dec_batch < h->small_tile_threshold) level = 1;
+  const bool kk = (opa == OP_KMAJOR && opb == OP_KMAJOR);
+  if (level >= 1) {
+    if (alias == 0 || (alias == ALIAS_A && n <= 64) || (alias == ALIAS_B && m <= 64)) {
+      tsm = tsn = 64;
+    } else if (alias == ALIAS_A && kk) {
+      tsm = 64;  // 64 x 128: the whole panel-block width in one column tile
+    }
+    a.total_tiles = count_tiles(mode, m, n, tsm, tsn, a.tiles_m, a.tiles_n);
+    if (h->force_ts == 0 && level == 1 && kk && dec_batch == 1 && tsm == 64 && a.total_tiles < h->tile32_threshold) level = 2;
+    // 32-row tiles: 32 x 32 for products that alias nothing; an in-place product must keep ONE column tile (C = A's
+    // buffer: a second column tile would overwrite columns the first still reads as its k range), so it takes
+    // 32 x 128 whatever its width; C = B's buffer (one ROW tile needed) stays on the 64-tile
+    if (level == 2 && kk && tsm == 64 && dec_batch == 1 && alias != ALIAS_B) {
+      tsm = 32;
+      tsn = (alias == ALIAS_A) ? 128 : 32;
+      a.total_tiles = count_tiles(mode, m, n, tsm, tsn, a.tiles_m, a.tiles_n);
+    }
+  }
+  // invariant of the in-place products, whatever shape was chosen above: ONE column tile when C is A's buffer, ONE row
+  // tile when C is B's (a violation is a data race between workgroups, not an error the GPU would report)
+  if ((alias == ALIAS_A && a.tiles_n != 1) || (alias == ALIAS_B && a.tiles_m != 1)) {
+    fprintf(stderr, "[ffgp] gemm: in-place launch would be split across %d x %d tiles (alias %d)\n", a.tiles_m, a.tiles_n, alias);
+    return FFGP_ERR_ARG;
+  }
+  // fast form (see gemm_tile_fast): alpha = +-1, beta in {0, 1}; per-lane byte offsets must fit 32 bits
+  a.fast = ((alpha == 1.0 || alpha == -1.0) && (beta == 0.0 || beta == 1.0) && (size_t)lda * 8 * 130 < 0xffffffffull &&
+            (size_t)ldb * 8 * 130 < 0xffffffffull && (size_t)ldc * 8 * 130 < 0xffffffffull)
+               ? 1 : 0;
+  a.grid = a.total_tiles;
+  a.split_at = 0x7fffffff;
+  a.band_log2 = h->band_log2;
+  // Split tail (see ffgp_gemm_f64): with T equal tiles on 256 CUs the last (T mod 256) tiles run on otherwise idle CUs for a
+  // whole tile time; when that remainder is small, hand it out as 64 x 64 quarters -- 4x the workgroups, a quarter of the
+  // chain each -- which start under the last full round.  (An in-place or batched launch never splits.)
+  if (tsm == 128 && tsn == 128 && alias == 0 && dec_batch == 1 && h->force_ts == 0 && h->split_rem_max > 0 && a.total_tiles > 256) {
+    const int rem = a.total_tiles % 256;
+    if (rem > 0 && rem <= h->split_rem_max) {
+      a.split_at = a.total_tiles - rem;
+      a.total_tiles = a.split_at;          // the XCD remap permutes the whole-tile part only
+      a.grid = a.split_at + 4 * rem;
+    }
+  }
+  // "Polite" trailing update: once the factorisation is bound by its dependency chain (trailing matrix below polite_m
+  // rows) the 128-tile SYRK is launched with LDS padding so that only one of its workgroups fits a CU.  Alone it still
+  // runs the MFMA pipe at ~70 %, and the other half of every CU -- VGPRs, LDS, issue slots -- is free for the chain's
+  // kernels at all times instead of only when a SYRK workgroup happens to exit.
+  a.pad_lds = 0;
+  if (syrk_tag && tsm == 128 && h->lookahead && h->polite_m > 0 && m < h->polite_m && h->stream != h->aux) a.pad_lds = h->polite_pad_kb * 1024;
+  if (tsm != 128) syrk_tag = 0;  // only the 128x128 trailing update is the roofline kernel (own instantiation + stats)
+  pl.tsm = tsm; pl.tsn = tsn; pl.syrk_tag = syrk_tag;
+  return FFGP_OK;
+}
+
 // alias: 0 = C aliases neither operand; ALIAS_A = C is A's buffer (row-wise in place: needs ONE column tile so
 // that no other workgroup reads the rows a workgroup re-writes); ALIAS_B = C is B's buffer (needs ONE row tile)
 int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, const double* A, int lda, const double* B,
@@ -828,70 +955,18 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
     else launch_skinny<8>(h, opa, sk);
     return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
   }
-  GemmArgs a;
-  // vector (16-byte) operand loads need even leading dimensions and 16-byte aligned bases
-  a.avec = (!(lda & 1) && aligned16(A)) ? 1 : 0;
-  a.bvec = (!(ldb & 1) && aligned16(B)) ? 1 : 0;
-  a.A = A; a.B = B; a.C = C;
-  a.m = m; a.n = n; a.k = k;
-  a.lda = lda; a.ldb = ldb; a.ldc = ldc;
-  a.alpha = alpha; a.beta = beta;
-  a.prio = (h->stream == h->aux && h->aux_prio) ? 1 : 0;
-  a.batch2 = 1;
-  a.sA2 = a.sB2 = a.sC2 = 0;
+  GemmPlan pl;
+  FFGP_CHECK(gemm_plan(h, opa, opb, mode, syrk_tag, A, lda, B, ldb, C, ldc, m, n, k, alpha, beta, tri, alias, batch, sA, sB, sC, pl));
+  GemmArgs& a = pl.a;
+  const int tsm = pl.tsm, tsn = pl.tsn;
+  syrk_tag = pl.syrk_tag;
   if (ob) {
     a.batch2 = h->ob_F;
     a.sA2 = ob_sA; a.sB2 = ob_sB; a.sC2 = ob_sC;
   }
-  // batch < 0: |batch| members, with every shape decision below taken as ONE member's launch would take it -- the batched
-  // factorisation (ffgp_nlml_fused_batch) promises the single call's values bit for bit, and the forms differ in rounding (the fast
-  // 128-tile accumulates onto C, the general tiles add alpha * (sum) to beta * C once)
-  const int dec_batch = (batch < 0) ? 1 : (batch > 1 ? batch : 1);
-  if (batch < 0) batch = -batch;
-  a.batch = batch > 1 ? batch : 1;
-  a.sA = sA; a.sB = sB; a.sC = sC;
-  if ((sA & 1) || (sB & 1)) a.avec = a.bvec = 0;  // odd strides break the 16-byte alignment of later batch members
-  a.lo_i = (tri & TRI_LO_I) ? 1 : 0;
-  a.lo_j = (tri & TRI_LO_J) ? 1 : 0;
-  a.hi_i = (tri & TRI_HI_I) ? 1 : 0;
-  a.hi_j = (tri & TRI_HI_J) ? 1 : 0;
-  // tile shape: the 128-tile is the throughput shape; below ~1.5 tiles per CU the launch is latency-bound and
-  // the 64-tile (4x the workgroups, a quarter of the per-tile MFMA chain) finishes sooner; the kernels of the
-  // factorisation's dependency chain (K-major operands) go one step further to 32-row tiles when even the 64-tiles
-  // would leave most CUs with a single 4-16 us MFMA chain
-  int tsm = 128, tsn = 128;
-  a.total_tiles = count_tiles(mode, m, n, 128, 128, a.tiles_m, a.tiles_n);
-  int level = 0;
-  if (h->force_ts == 64) level = 1;
-  else if (h->force_ts == 32) level = 2;
-  else if (h->force_ts == 0 && a.total_tiles * dec_batch < h->small_tile_threshold) level = 1;
-  const bool kk = (opa == OP_KMAJOR && opb == OP_KMAJOR);
-  if (level >= 1) {
-    if (alias == 0 || (alias == ALIAS_A && n <= 64) || (alias == ALIAS_B && m <= 64)) {
-      tsm = tsn = 64;
-    } else if (alias == ALIAS_A && kk) {
-      tsm = 64;  // 64 x 128: the whole panel-block width in one column tile
-    }
-    a.total_tiles = count_tiles(mode, m, n, tsm, tsn, a.tiles_m, a.tiles_n);
-    if (h->force_ts == 0 && level == 1 && kk && dec_batch == 1 && tsm == 64 && a.total_tiles < h->tile32_threshold) level = 2;
-    // 32-row tiles: 32 x 32 for products that alias nothing; an in-place product must keep ONE column tile (C = A's
-    // buffer: a second column tile would overwrite columns the first still reads as its k range), so it takes
-    // 32 x 128 whatever its width; C = B's buffer (one ROW tile needed) stays on the 64-tile
-    if (level == 2 && kk && tsm == 64 && dec_batch == 1 && alias != ALIAS_B) {
-      tsm = 32;
-      tsn = (alias == ALIAS_A) ? 128 : 32;
-      a.total_tiles = count_tiles(mode, m, n, tsm, tsn, a.tiles_m, a.tiles_n);
-    }
-  }
-  // invariant of the in-place products, whatever shape was chosen above: ONE column tile when C is A's buffer, ONE row
-  // tile when C is B's (a violation is a data race between workgroups, not an error the GPU would report)
-  if ((alias == ALIAS_A && a.tiles_n != 1) || (alias == ALIAS_B && a.tiles_m != 1)) {
-    fprintf(stderr, "[ffgp] gemm: in-place launch would be split across %d x %d tiles (alias %d)\n", a.tiles_m, a.tiles_n, alias);
-    return FFGP_ERR_ARG;
-  }
   // timing == 2: bracket every trailing-update launch with its own event pair (no host sync inside the timed
   // region; ffgp_syrk_stats drains the pool afterwards)
-  const bool timed = (syrk_tag && tsm == 128 && h->timing == 2);
+  const bool timed = (syrk_tag && h->timing == 2);
   hipEvent_t ev_stop = nullptr;
   if (timed) {
     if (h->syrk_pool_used + 2 > (int)h->syrk_pool.size()) {
@@ -905,31 +980,6 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
     ev_stop = h->syrk_pool[h->syrk_pool_used + 1];
     h->syrk_pool_used += 2;
   }
-  // fast form (see gemm_tile_fast): alpha = +-1, beta in {0, 1}; per-lane byte offsets must fit 32 bits
-  a.fast = ((alpha == 1.0 || alpha == -1.0) && (beta == 0.0 || beta == 1.0) && (size_t)lda * 8 * 130 < 0xffffffffull &&
-            (size_t)ldb * 8 * 130 < 0xffffffffull && (size_t)ldc * 8 * 130 < 0xffffffffull)
-               ? 1 : 0;
-  a.grid = a.total_tiles;
-  a.split_at = 0x7fffffff;
-  a.band_log2 = h->band_log2;
-  // Split tail (see ffgp_gemm_f64): with T equal tiles on 256 CUs the last (T mod 256) tiles run on otherwise idle CUs for a
-  // whole tile time; when that remainder is small, hand it out as 64 x 64 quarters -- 4x the workgroups, a quarter of the
-  // chain each -- which start under the last full round.  (An in-place or batched launch never splits.)
-  if (tsm == 128 && tsn == 128 && alias == 0 && dec_batch == 1 && h->force_ts == 0 && h->split_rem_max > 0 && a.total_tiles > 256) {
-    const int rem = a.total_tiles % 256;
-    if (rem > 0 && rem <= h->split_rem_max) {
-      a.split_at = a.total_tiles - rem;
-      a.total_tiles = a.split_at;          // the XCD remap permutes the whole-tile part only
-      a.grid = a.split_at + 4 * rem;
-    }
-  }
-  // "Polite" trailing update: once the factorisation is bound by its dependency chain (trailing matrix below polite_m
-  // rows) the 128-tile SYRK is launched with LDS padding so that only one of its workgroups fits a CU.  Alone it still
-  // runs the MFMA pipe at ~70 %, and the other half of every CU -- VGPRs, LDS, issue slots -- is free for the chain's
-  // kernels at all times instead of only when a SYRK workgroup happens to exit.
-  a.pad_lds = 0;
-  if (syrk_tag && tsm == 128 && h->lookahead && h->polite_m > 0 && m < h->polite_m && h->stream != h->aux) a.pad_lds = h->polite_pad_kb * 1024;
-  if (tsm != 128) syrk_tag = 0;  // only the 128x128 trailing update is the roofline kernel (own instantiation + stats)
   int rc;
   if (tsm == 64 && tsn == 128)
     rc = launch_t<OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, 64, 128>(h, a);
@@ -947,8 +997,112 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   if (syrk_tag) {
     h->syrk_launches += 1;
     // algorithmic flops: 2k per element of the lower trapezoid (n(n+1)/2 + (m-n)n elements)
-    h->syrk_flops += 2.0 * (double)k * ((double)n * ((double)n + 1.0) * 0.5 + ((double)m - (double)n) * (double)n);
+    // (a launch of the shared chain covers a.batch blocks, one of the outer-batched stages a.batch2 more: the event pair brackets all of them)
+    h->syrk_flops += 2.0 * (double)k * ((double)n * ((double)n + 1.0) * 0.5 + ((double)m - (double)n) * (double)n) * (double)a.batch *
+                     (double)a.batch2;
     if (timed) hipEventRecord(ev_stop, h->stream);
+  }
+  return FFGP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Ragged launch: R independent products of ONE kind (same operand layouts, tile set, alpha / beta, aliasing) whose sizes, operands
+// and leading dimensions differ -- the shared factorisation chain of blocks of different sizes (ffgp_potrf_ragged).  Every member's
+// shape decision is gemm_plan's for that member alone, i.e. what its own ffgp_gemm_launch would decide; members that decide alike
+// share a launch (gridDim.y, at most FFGP_RAG_MAX per launch), so a member's values are its single call's, bit for bit.  Only the
+// K-major products of the chain exist in this form (TRSM by the inverted diagonal block, panel update, trailing update).
+// ------------------------------------------------------------------------------------------------------------
+template <int MODE, int TAG, int TM, int TN>
+static int launch_rag_t(ffgp_handle* h, const GemmRag& q, int gx, int gy) {
+  if (q.base.pad_lds > 0)
+    FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffgp_gemm_f64_rag<OP_KMAJOR, OP_KMAJOR, MODE, TAG, TM, TN>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  hipLaunchKernelGGL((ffgp_gemm_f64_rag<OP_KMAJOR, OP_KMAJOR, MODE, TAG, TM, TN>), dim3(gx, gy), dim3(256), q.base.pad_lds, h->stream, q);
+  return FFGP_OK;
+}
+
+int ffgp_gemm_launch_rag(ffgp_handle* h, int mode, int syrk_tag, int R, const GemmRagIn* in, double alpha, double beta, int alias) {
+  if (R <= 0) return FFGP_OK;
+  if (!in || h->ob_F > 1) return FFGP_ERR_ARG;
+  struct Item { GemmPlan pl; long key; };
+  std::vector<Item> items;
+  items.reserve(R);
+  for (int r = 0; r < R; ++r) {
+    const GemmRagIn& g = in[r];
+    if (g.m <= 0 || g.n <= 0) continue;
+    if (g.k <= 0 || !g.A || !g.B || !g.C) return FFGP_ERR_ARG;
+    if (mode == TILES_LOWER && g.m < g.n) return FFGP_ERR_ARG;
+    if (alias == ALIAS_A && (g.n > 128 || mode != TILES_FULL)) return FFGP_ERR_ARG;
+    if (alias == ALIAS_B) return FFGP_ERR_ARG;
+    Item it;
+    FFGP_CHECK(gemm_plan(h, OP_KMAJOR, OP_KMAJOR, mode, syrk_tag, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, g.m, g.n, g.k, alpha, beta, 0, alias,
+                         0, 0, 0, 0, it.pl));
+    // members share a launch when they chose the same kernel instantiation and launch attributes
+    it.key = ((long)it.pl.tsm << 40) | ((long)it.pl.tsn << 28) | ((long)it.pl.syrk_tag << 24) | (long)(it.pl.a.pad_lds >> 10);
+    items.push_back(it);
+  }
+  std::vector<char> done(items.size(), 0);
+  for (size_t i0 = 0; i0 < items.size(); ++i0) {
+    if (done[i0]) continue;
+    // the members of this group, FFGP_RAG_MAX per launch
+    std::vector<size_t> grp;
+    for (size_t j = i0; j < items.size(); ++j)
+      if (!done[j] && items[j].key == items[i0].key) { grp.push_back(j); done[j] = 1; }
+    for (size_t g0 = 0; g0 < grp.size(); g0 += FFGP_RAG_MAX) {
+      const int cnt = (int)std::min<size_t>(FFGP_RAG_MAX, grp.size() - g0);
+      GemmRag q;
+      q.base = items[grp[g0]].pl.a;
+      int gx = 0;
+      double flops = 0.0;
+      for (int c = 0; c < cnt; ++c) {
+        const GemmArgs& a = items[grp[g0 + c]].pl.a;
+        GemmRagMember& mm = q.mem[c];
+        mm.A = a.A; mm.B = a.B; mm.C = a.C;
+        mm.m = a.m; mm.n = a.n; mm.k = a.k;
+        mm.lda = a.lda; mm.ldb = a.ldb; mm.ldc = a.ldc;
+        mm.tiles_m = a.tiles_m; mm.tiles_n = a.tiles_n; mm.total_tiles = a.total_tiles; mm.grid = a.grid; mm.split_at = a.split_at;
+        mm.fast = a.fast; mm.avec = a.avec; mm.bvec = a.bvec;
+        gx = std::max(gx, a.grid);
+        flops += 2.0 * (double)a.k * ((double)a.n * ((double)a.n + 1.0) * 0.5 + ((double)a.m - (double)a.n) * (double)a.n);
+      }
+      for (int c = cnt; c < FFGP_RAG_MAX; ++c) { q.mem[c] = q.mem[0]; q.mem[c].grid = 0; }
+      const GemmPlan& pl = items[grp[g0]].pl;
+      const int tsm = pl.tsm, tsn = pl.tsn, tag = pl.syrk_tag;
+      const bool timed = (tag && h->timing == 2);
+      hipEvent_t ev_stop = nullptr;
+      if (timed) {
+        if (h->syrk_pool_used + 2 > (int)h->syrk_pool.size()) {
+          hipEvent_t e0, e1;
+          hipEventCreate(&e0);
+          hipEventCreate(&e1);
+          h->syrk_pool.push_back(e0);
+          h->syrk_pool.push_back(e1);
+        }
+        hipEventRecord(h->syrk_pool[h->syrk_pool_used], h->stream);
+        ev_stop = h->syrk_pool[h->syrk_pool_used + 1];
+        h->syrk_pool_used += 2;
+      }
+      int rc = FFGP_ERR_ARG;
+      if (mode == TILES_FULL) {
+        if (tsm == 128 && tsn == 128) rc = launch_rag_t<TILES_FULL, 0, 128, 128>(h, q, gx, cnt);
+        else if (tsm == 64 && tsn == 128) rc = launch_rag_t<TILES_FULL, 0, 64, 128>(h, q, gx, cnt);
+        else if (tsm == 32 && tsn == 128) rc = launch_rag_t<TILES_FULL, 0, 32, 128>(h, q, gx, cnt);
+        else if (tsm == 64 && tsn == 64) rc = launch_rag_t<TILES_FULL, 0, 64, 64>(h, q, gx, cnt);
+        else if (tsm == 32 && tsn == 32) rc = launch_rag_t<TILES_FULL, 0, 32, 32>(h, q, gx, cnt);
+      } else {
+        if (tsm == 128 && tag) rc = launch_rag_t<TILES_LOWER, 1, 128, 128>(h, q, gx, cnt);
+        else if (tsm == 128) rc = launch_rag_t<TILES_LOWER, 0, 128, 128>(h, q, gx, cnt);
+        else if (tsm == 64) rc = launch_rag_t<TILES_LOWER, 0, 64, 64>(h, q, gx, cnt);
+        else if (tsm == 32) rc = launch_rag_t<TILES_LOWER, 0, 32, 32>(h, q, gx, cnt);
+      }
+      if (rc != FFGP_OK) return rc;
+      if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
+      if (tag) {
+        h->syrk_launches += 1;
+        h->syrk_flops += flops;
+        if (timed) hipEventRecord(ev_stop, h->stream);
+      }
+    }
   }
   return FFGP_OK;
 }

@@ -873,12 +873,32 @@ __device__ __forceinline__ void d3_store_inverse_rows(double* S, double* __restr
 
 __device__ int ffgp_d3_dbg[32];     // state of the flags when a hand-off timed out (development aid)
 
+// members of a ragged launch (blocks of different sizes sharing one chain, ffgp_potrf_ragged): each workgroup's own diagonal block
+struct DiagRag {
+  double* A[FFGP_RAG_MAX];
+  double* Dinv[FFGP_RAG_MAX];
+  int lda[FFGP_RAG_MAX];
+  int nb[FFGP_RAG_MAX];
+  int info[FFGP_RAG_MAX];      // index of the member's status word
+};
+
+template <bool RAG>
 __global__ __launch_bounds__(512, 4) void ffgp_potrf_diag128_v3(double* __restrict__ A, int lda, int nb, double* __restrict__ Dinv,
-                                                                int* info, int row_base, int prio, long sA, long sD, int sInfo) {
-  // (batched factorisation: workgroup b factors block b -- its own matrix, Dinv store and status word)
-  A += (size_t)blockIdx.x * sA;
-  Dinv += (size_t)blockIdx.x * sD;
-  info += blockIdx.x * sInfo;
+                                                                int* info, int row_base, int prio, long sA, long sD, int sInfo,
+                                                                DiagRag rag) {
+  if constexpr (RAG) {
+    // (ragged batch: workgroup b factors member b's block -- own matrix, leading dimension, block size, Dinv slot, status word)
+    A = rag.A[blockIdx.x];
+    Dinv = rag.Dinv[blockIdx.x];
+    lda = rag.lda[blockIdx.x];
+    nb = rag.nb[blockIdx.x];
+    info += rag.info[blockIdx.x];
+  } else {
+    // (batched factorisation: workgroup b factors block b -- its own matrix, Dinv store and status word)
+    A += (size_t)blockIdx.x * sA;
+    Dinv += (size_t)blockIdx.x * sD;
+    info += blockIdx.x * sInfo;
+  }
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* S = lds;
   volatile D3Flags* fl = reinterpret_cast<volatile D3Flags*>(lds + NBLK_LOWER * BLKSZ);
@@ -1267,16 +1287,18 @@ static int launch_diag(ffgp_handle* h, double* Ablk, int lda, int nb, double* Di
 #endif
     if (h->diag_v2 == 4) {   // round 4: owner-computes helpers, wave 0's SIMD partner steps aside
       if (!(h->diag_attr_set & 4)) {
-        FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v3), hipFuncAttributeMaxDynamicSharedMemorySize,
+        FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v3<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     DIAG_LDS_BYTES));
+        FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v3<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      DIAG_LDS_BYTES));
         h->diag_attr_set |= 4;
       }
       if (h->bt_F > 1)
-        hipLaunchKernelGGL(ffgp_potrf_diag128_v3, dim3(h->bt_F), dim3(512), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk,
-                           h->bt_info, row_base, h->aux_prio, h->bt_sA, h->bt_sD, 1);
+        hipLaunchKernelGGL(ffgp_potrf_diag128_v3<false>, dim3(h->bt_F), dim3(512), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk,
+                           h->bt_info, row_base, h->aux_prio, h->bt_sA, h->bt_sD, 1, DiagRag());
       else
-        hipLaunchKernelGGL(ffgp_potrf_diag128_v3, dim3(1), dim3(512), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk, h->d_info,
-                           row_base, h->aux_prio, 0L, 0L, 0);
+        hipLaunchKernelGGL(ffgp_potrf_diag128_v3<false>, dim3(1), dim3(512), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk, h->d_info,
+                           row_base, h->aux_prio, 0L, 0L, 0, DiagRag());
     }
 #ifdef FFGP_DEV_OPTIONS
     else if (h->diag_v2 == 3)   // the round-3 pivot step (32-bit DPP moves), kept for A/B runs
@@ -1562,6 +1584,168 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
   FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   FFGP_HIP(hipStreamSynchronize(h->stream));
   return ffgp_map_info(h->h_info[0]);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// ONE factorisation chain for R blocks of DIFFERENT sizes (ffgp_nlml_fused_batch with unequal members; the reference's fidelities are
+// ragged by nature: 300 / 300 / 250 points in FidelityFusion_Models/ResGP.py:121-136, 100 low against 4..32 high in
+// Experiments/GAR_Aligned/exp_aligned.py:66-74).  Every member follows the launch sequence of its OWN single call -- in order for
+// n <= la_min_n, the carry form of the look-ahead above that -- and launches of the same kind at the same chain step are merged:
+// the diagonal blocks of column j0 of all members that still have one are one launch (one workgroup each), their TRSMs one ragged
+// GEMM launch, their panel updates another (ffgp_gemm_launch_rag: each member's own sizes, tile shape and form, so its values are the
+// single call's bit for bit); a member drops out of the launches when its columns are used up.  The chain runs max(n) / 128 steps on
+// the side stream; trailing updates of in-order members follow their panel on the chain's stream (as in their single call), those
+// of look-ahead members run on the main stream behind the same two events per panel as in ffgp_potrf_impl's carry form.
+// Not covered (FFGP_ERR_ARG, the caller evaluates such sets block by block): members above 12288 rows (their single call uses the
+// round-1 look-ahead form), the naive / barrier-kernel modes, wide early panels (nb_big).
+// ------------------------------------------------------------------------------------------------------------
+int ffgp_potrf_ragged(ffgp_handle* h, int R, const ffgp_rag_block* mem) {
+  if (R <= 0) return FFGP_OK;
+  if (!mem || h->use_naive || h->diag_v2 != 4 || h->diag_dbg || h->nb_big > h->nb_outer) return FFGP_ERR_ARG;
+  const int NB1 = h->nb_outer;
+  std::vector<int> form(R);
+  bool any_la = false;
+  int nmax = 0;
+  for (int f = 0; f < R; ++f) {
+    const ffgp_rag_block& b = mem[f];
+    if (!b.A || !b.dinv || b.n <= 0 || b.lda < b.n || b.mtot < b.n || (b.lda & 1) || (reinterpret_cast<uintptr_t>(b.A) & 15)) return FFGP_ERR_ARG;
+    if (!h->lookahead || b.n <= NB1 || b.n <= h->la_min_n) form[f] = 0;
+    else if (h->la_carry == 1 || (h->la_carry == 2 && b.n <= 12288)) form[f] = 1;
+    else return FFGP_ERR_ARG;
+    any_la = any_la || form[f] == 1;
+    nmax = max(nmax, b.n);
+  }
+  if (!(h->diag_attr_set & 4)) {
+    FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v3<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 DIAG_LDS_BYTES));
+    FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v3<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 DIAG_LDS_BYTES));
+    h->diag_attr_set |= 4;
+  }
+  hipStream_t main_s = h->stream;
+  hipStream_t chain_s = any_la ? h->aux : main_s;
+  if (any_la) {
+    FFGP_HIP(hipEventRecord(h->la_ev[6], main_s));
+    FFGP_HIP(hipStreamWaitEvent(chain_s, h->la_ev[6], 0));
+  }
+  std::vector<GemmRagIn> in;
+  in.reserve(R);
+  hipEvent_t eg_prev = nullptr;
+  int it = 0, rc = FFGP_OK;
+  for (int k0 = 0; k0 < nmax && rc == FFGP_OK; k0 += NB1, ++it) {
+    hipEvent_t eb = h->la_ev[(it & 1) * 3], eg = h->la_ev[(it & 1) * 3 + 1];
+    // ---- the chain of this panel, every member that still has columns here
+    h->stream = chain_s;
+    bool gate_pending = eg_prev != nullptr;
+    for (int j0 = k0; j0 < min(k0 + NB1, nmax) && rc == FFGP_OK; j0 += NB) {
+      for (int f0 = 0; f0 < R && rc == FFGP_OK; f0 += FFGP_RAG_MAX) {      // diagonal blocks: one workgroup per member, 8 members per launch
+        DiagRag dr;
+        int cnt = 0;
+        for (int f = f0; f < min(R, f0 + FFGP_RAG_MAX); ++f) {
+          const ffgp_rag_block& b = mem[f];
+          if (j0 >= b.n) continue;
+          dr.A[cnt] = b.A + (size_t)j0 * b.lda + j0;
+          dr.Dinv[cnt] = b.dinv + (size_t)(j0 / NB) * NB * NB;
+          dr.lda[cnt] = b.lda;
+          dr.nb[cnt] = min(NB, b.n - j0);
+          dr.info[cnt] = b.info_index;
+          ++cnt;
+        }
+        if (!cnt) continue;
+        for (int c = cnt; c < FFGP_RAG_MAX; ++c) { dr.A[c] = dr.A[0]; dr.Dinv[c] = dr.Dinv[0]; dr.lda[c] = dr.lda[0]; dr.nb[c] = dr.nb[0]; dr.info[c] = dr.info[0]; }
+        hipLaunchKernelGGL(ffgp_potrf_diag128_v3<true>, dim3(cnt), dim3(512), DIAG_LDS_BYTES, h->stream, (double*)nullptr, 0, 0, (double*)nullptr,
+                           h->bt_info, j0, h->aux_prio, 0L, 0L, 0, dr);
+      }
+      // TRSM of every row below: A21 <- A21 * Dj^T, in place
+      in.clear();
+      for (int f = 0; f < R; ++f) {
+        const ffgp_rag_block& b = mem[f];
+        if (j0 >= b.n) continue;
+        const int jb = min(NB, b.n - j0), mrows = b.mtot - (j0 + jb);
+        if (mrows <= 0) continue;
+        double* A21 = b.A + (size_t)(j0 + jb) * b.lda + j0;
+        double* Dj = b.dinv + (size_t)(j0 / NB) * NB * NB;
+        in.push_back(GemmRagIn{A21, b.lda, Dj, NB, A21, b.lda, mrows, jb, jb});
+      }
+      if (!in.empty()) rc = ffgp_gemm_launch_rag(h, TILES_FULL, 0, (int)in.size(), in.data(), 1.0, 0.0, ALIAS_A);
+      if (rc != FFGP_OK) break;
+      // update of the panel's remaining columns (look-ahead members: and of the next panel's first block, the carry)
+      in.clear();
+      for (int f = 0; f < R; ++f) {
+        const ffgp_rag_block& b = mem[f];
+        if (j0 >= b.n) continue;
+        const int jb = min(NB, b.n - j0), mrows = b.mtot - (j0 + jb);
+        const int pend = min(k0 + NB1, b.n);
+        const int carry = form[f] == 1 ? max(0, min(NB, b.n - pend)) : 0;
+        const int wrem = pend - (j0 + jb) + carry;
+        if (mrows <= 0 || wrem <= 0) continue;
+        double* A21 = b.A + (size_t)(j0 + jb) * b.lda + j0;
+        double* C = b.A + (size_t)(j0 + jb) * b.lda + (j0 + jb);
+        in.push_back(GemmRagIn{A21, b.lda, A21, b.lda, C, b.lda, mrows, wrem, jb});
+      }
+      if (!in.empty()) {
+        if (gate_pending) {      // the main stream's earlier contribution to these columns (S_bz of the previous panel) must have landed
+          FFGP_HIP(hipStreamWaitEvent(h->stream, eg_prev, 0));
+          gate_pending = false;
+        }
+        rc = ffgp_gemm_launch_rag(h, TILES_LOWER, 0, (int)in.size(), in.data(), -1.0, 1.0, ALIAS_NONE);
+      }
+    }
+    if (rc != FFGP_OK) break;
+    // ---- in-order members: the panel's trailing update follows on the chain's stream
+    in.clear();
+    for (int f = 0; f < R; ++f) {
+      const ffgp_rag_block& b = mem[f];
+      if (form[f] != 0 || k0 >= b.n) continue;
+      const int pend = min(k0 + NB1, b.n), mt = b.n - pend;
+      if (mt <= 0) continue;
+      double* P = b.A + (size_t)pend * b.lda + k0;
+      double* C = b.A + (size_t)pend * b.lda + pend;
+      in.push_back(GemmRagIn{P, b.lda, P, b.lda, C, b.lda, b.mtot - pend, mt, pend - k0});
+    }
+    if (!in.empty()) rc = ffgp_gemm_launch_rag(h, TILES_LOWER, 1, (int)in.size(), in.data(), -1.0, 1.0, ALIAS_NONE);
+    h->stream = main_s;
+    if (rc != FFGP_OK || !any_la) continue;
+    FFGP_HIP(hipEventRecord(eb, chain_s));
+    FFGP_HIP(hipStreamWaitEvent(main_s, eb, 0));
+    // ---- look-ahead members, main stream: S_bz (the rest of the next panel's columns and its carry strip), then S_ii
+    in.clear();
+    for (int f = 0; f < R; ++f) {
+      const ffgp_rag_block& b = mem[f];
+      if (form[f] != 1 || k0 >= b.n) continue;
+      const int pend = min(k0 + NB1, b.n), mt = b.n - pend;
+      if (mt <= 0) continue;
+      const int wn = min(NB1, mt), q = pend + wn, wz = max(0, min(NB, b.n - q)), wa = min(NB, wn);
+      if (wn - wa + wz <= 0) continue;
+      double* Pb = b.A + (size_t)(pend + wa) * b.lda + k0;
+      double* Cb = b.A + (size_t)(pend + wa) * b.lda + (pend + wa);
+      in.push_back(GemmRagIn{Pb, b.lda, Pb, b.lda, Cb, b.lda, b.mtot - pend - wa, wn - wa + wz, pend - k0});
+    }
+    eg_prev = nullptr;
+    if (!in.empty()) {
+      rc = ffgp_gemm_launch_rag(h, TILES_LOWER, 1, (int)in.size(), in.data(), -1.0, 1.0, ALIAS_NONE);
+      if (rc != FFGP_OK) break;
+      FFGP_HIP(hipEventRecord(eg, main_s));
+      eg_prev = eg;
+    }
+    in.clear();
+    for (int f = 0; f < R; ++f) {
+      const ffgp_rag_block& b = mem[f];
+      if (form[f] != 1 || k0 >= b.n) continue;
+      const int pend = min(k0 + NB1, b.n), mt = b.n - pend;
+      if (mt <= 0) continue;
+      const int wn = min(NB1, mt), q = pend + wn, wz = max(0, min(NB, b.n - q));
+      const int mt2 = mt - wn - wz;
+      if (mt2 <= 0) continue;
+      double* P2 = b.A + (size_t)(q + wz) * b.lda + k0;
+      double* C2 = b.A + (size_t)(q + wz) * b.lda + (q + wz);
+      in.push_back(GemmRagIn{P2, b.lda, P2, b.lda, C2, b.lda, b.mtot - q - wz, mt2, pend - k0});
+    }
+    if (!in.empty()) rc = ffgp_gemm_launch_rag(h, TILES_LOWER, 1, (int)in.size(), in.data(), -1.0, 1.0, ALIAS_NONE);
+  }
+  h->stream = main_s;
+  if (hipGetLastError() != hipSuccess && rc == FFGP_OK) rc = FFGP_ERR_HIP;
+  return rc;
 }
 
 // status word -> return code: a pivot index passes through; the diagonal-block kernel's watchdog is a library error

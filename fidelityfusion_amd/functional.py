@@ -24,7 +24,7 @@ from .kdesc import (FFGP_KFUN_LINEAR, FFGP_KOP_PRODUCT, FFGP_KOP_SUM, FFGP_TREE_
 from .linalg import (_CondGauss, _EighSmall, _GaussNLLFromCov, _gemm, _KernelMatrix, _KernelPair, _MatmulNT, _pad_ld, _syevj_small,
                      add_diagonal, cholesky, cholesky_with_rows, conditional_gaussian, eigh_small, gaussian_ll_v2,
                      gaussian_nll_from_cov, kernel_matrix, kernel_on_device, kernel_pair, matmul_nt, rows_in)
-from .nlml import (SMALL_BATCH_MAX_d, SMALL_BATCH_MAX_D, SMALL_BATCH_MAX_N, _NLML, _NLMLPair, _NLMLRaw, _NLMLRawMany, _problem, _raw_pending,
+from .nlml import (RAGGED_CHAIN_MAX_N, SMALL_BATCH_MAX_d, SMALL_BATCH_MAX_D, SMALL_BATCH_MAX_N, _NLML, _NLMLPair, _NLMLRaw, _NLMLRawMany, _problem, _raw_pending,
                    _settle_raw, many_batchable, nlml, nlml_many, nlml_pair, nlml_raw, nlml_raw_many, pair_inputs_plain, predict, raw_many_ok,
                    raw_ok, raw_path)
 from .posterior import Posterior, PosteriorCache, PosteriorCacheMixin, _PosteriorQuery

@@ -406,13 +406,49 @@ def nlml_raw_many(items):
         metas.append((L, float(it.get("mean_jitter", 0.0)), lk["clamp"], it.get("variant", FFGP_LL_V1), it.get("pi_const", PI_TRUNC),
                       lk["kfun"], 1.0 if kp is None else float(kp), float(it.get("sign", 1.0))))
         tensors += [it["X"], it["Y"], lk["w"], lk["amp"], it["rdadd"], it.get("diag_vec")]
-    return _NLMLRawMany.apply(tuple(metas), torch.is_grad_enabled(), *tensors)
+    metas = tuple(metas)
+    rec = torch.is_grad_enabled()
+    if items[0]["X"].shape[0] <= SMALL_BATCH_MAX_N:
+        return _NLMLRawMany.apply(metas, rec, *tensors)
+    return _chain_batches(items, metas, tensors, rec, 0, len(items))
+
+
+CHAIN_BATCH_MAX_F = 256      # ffgp_nlml_fused_batch's limit on the members of one chain (include/ffgp.h)
+
+
+def _chain_batches(items, metas, tensors, rec, lo, hi):
+    """members [lo, hi) of a shared-chain batch -> tensor [hi - lo].  include/ffgp.h leaves the fallback to the caller: the library
+    refuses the batch (FFGP_ERR_ARG) in states it otherwise allows -- option `naive` = 1, `diag_v2` = 0, more than 256 members -- and
+    reports FFGP_ERR_ALLOC when the F-fold workspace does not fit.  Here: chunks of at most 256 members; a chunk that does not fit is
+    halved until it does; a chunk the library refuses (or a single leftover member) goes through the individual calls, which work in
+    all of those states and need one block of memory.  Values and gradients are the individual calls' either way."""
+    if hi - lo > CHAIN_BATCH_MAX_F:
+        mid = lo + CHAIN_BATCH_MAX_F
+        return torch.cat([_chain_batches(items, metas, tensors, rec, lo, mid), _chain_batches(items, metas, tensors, rec, mid, hi)])
+    if hi - lo >= 2:
+        try:
+            return _NLMLRawMany.apply(metas[lo:hi], rec, *tensors[6 * lo:6 * hi])
+        except _lib.FFGPError as e:
+            if e.code == _lib.FFGP_ERR_ALLOC and hi - lo >= 4:
+                mid = (lo + hi) // 2
+                return torch.cat([_chain_batches(items, metas, tensors, rec, lo, mid), _chain_batches(items, metas, tensors, rec, mid, hi)])
+            if e.code not in (_lib.FFGP_ERR_ARG, _lib.FFGP_ERR_ALLOC):
+                raise
+    return torch.stack([_single_raw(it) for it in items[lo:hi]])
+
+
+def _single_raw(it):
+    """one member of a batch through the single-problem call (same links, same sign)"""
+    return nlml_raw(it["X"], it["Y"], it["lk"], it["rdadd"], it["dadd_link"], it["dadd_c"], diag_vec=it.get("diag_vec"),
+                    mean_jitter=float(it.get("mean_jitter", 0.0)), variant=it.get("variant", FFGP_LL_V1),
+                    pi_const=it.get("pi_const", PI_TRUNC), sign=float(it.get("sign", 1.0))).reshape(())
 
 
 def nlml_many(Xs, Ys, ws, amps, diag_adds, clamp=NEG_INF, pi_const=PI_TRUNC):
     """[nlml(X, Y, w, amp, diag_add=dadd, clamp=clamp) for ...] as one tensor [F] through ONE factorisation chain
-    (ffgp_nlml_fused_batch): F >= 2 blocks of one shape (the same n > 128 and d), everything on one GPU in fp64, effective
-    parameters (w [D], amp [1], diag_add [1] per block; squared-exponential profile).  Gradients flow to Y, w, amp and diag_add.
+    (ffgp_nlml_fused_batch): F >= 2 blocks with n > 128 (one shape, or different shapes up to 12288 rows each), everything on one
+    GPU in fp64, effective parameters (w [D], amp [1], diag_add [1] per block; squared-exponential profile).  Gradients flow to Y,
+    w, amp and diag_add.
     The per-fidelity blocks of one rank in the sharded workloads (bench.py `cigar4`, `gar8`) are such a batch."""
     items = []
     for X, Y, w, amp, dadd in zip(Xs, Ys, ws, amps, diag_adds):
@@ -421,14 +457,14 @@ def nlml_many(Xs, Ys, ws, amps, diag_adds, clamp=NEG_INF, pi_const=PI_TRUNC):
         lk = {"w": w, "w_link": _lib.LINK_ID, "w_c": 0.0, "amp": amp, "amp_link": _lib.LINK_ID, "clamp": clamp, "kfun": 0}
         items.append({"X": X, "Y": Y, "lk": lk, "rdadd": dadd, "dadd_link": _lib.LINK_ID, "dadd_c": 0.0, "pi_const": pi_const})
     if not many_batchable([(it["X"].shape[0], it["Y"].shape[1]) for it in items]):
-        raise ValueError("nlml_many: the blocks must share one shape (n, d) with n > %d" % SMALL_BATCH_MAX_N)
+        raise ValueError("nlml_many: at least two blocks with n > %d each (of one shape, or of different shapes with n <= %d)"
+                         % (SMALL_BATCH_MAX_N, RAGGED_CHAIN_MAX_N))
     return nlml_raw_many(items)
 
 
 def raw_many_ok(kernel, x_train, y_train, *others):
     """`raw_path` + the limits of the batched calls: up to SMALL_BATCH_MAX_N points the one-workgroup batch (any mix of shapes,
-    D, d <= 16); beyond that the shared-chain batch, which needs every member to have the SAME (n, d) -- checked by the caller
-    (`many_batchable`) -- and D <= 128"""
+    D, d <= 16); beyond that the shared-chain batch (D <= 128; which sets of shapes share a chain: `many_batchable`)"""
     lk = raw_path(kernel, x_train, y_train, *others)
     if lk is None or isinstance(lk.get("kparam"), torch.Tensor):
         return None
@@ -439,12 +475,19 @@ def raw_many_ok(kernel, x_train, y_train, *others):
     return lk
 
 
+RAGGED_CHAIN_MAX_N = 12288     # members of a ragged shared chain (blocks of different sizes): ffgp_potrf_ragged's limit
+
+
 def many_batchable(shapes):
     """shapes: [(n, d)] of the members.  One library call serves them when they are all small (n <= SMALL_BATCH_MAX_N: one
-    workgroup each), or at least two blocks of ONE larger shape (ffgp_nlml_fused_batch: they share one factorisation chain)."""
+    workgroup each), or at least two larger blocks (ffgp_nlml_fused_batch: they share ONE factorisation chain) -- of one shape, or,
+    since round 5, of different shapes up to RAGGED_CHAIN_MAX_N rows each (the ragged chain: a member drops out of the chain's
+    launches when its columns are used up)."""
     if all(n <= SMALL_BATCH_MAX_N for n, _ in shapes):
         return True
-    return len(shapes) >= 2 and len(set(shapes)) == 1 and shapes[0][0] > SMALL_BATCH_MAX_N
+    if len(shapes) < 2 or any(n <= SMALL_BATCH_MAX_N for n, _ in shapes):
+        return False
+    return len(set(shapes)) == 1 or all(n <= RAGGED_CHAIN_MAX_N for n, _ in shapes)
 
 
 def raw_ok(*tensors):

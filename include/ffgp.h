@@ -209,13 +209,19 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
             "sb_qr4" (default 0; 1: the band reduction's leaf QRs on 256-thread workgroups, four columns per half-wave -- 58.9 us per
                         panel against 54.4 us on 1024 threads at n = 8192; with "sb_lookahead" the only form whose leaves overlap
                         the trailing update, stage time equal either way),
-            "diag_v2" (default 1: pipelined diagonal-block kernel; 0 = the barrier version, 2 = helper waves off wave 0's SIMD),
+            "diag_v2" (default 4: the round-4 diagonal-block kernel ffgp_potrf_diag128_v3 -- owner-computes helper waves, no
+                        barrier; 0 = the barrier version (ffgp_nlml_fused_batch then returns FFGP_ERR_ARG: only the default kernel
+                        is batched).  The shipped library accepts 0 and 4 only; 1 and 3, the round-3 pipelines, exist in the
+                        development build),
             "chase_pack" (placement of the bulge chase's 256 working wavefronts: every pack-th workgroup works.  Default 1 = one per
                         compute unit over the whole chip (N = 8192: 64.6 ms; 2 = on every other XCD: 69.4, 4: 92, 8: 166); beside
                         other blocks' kernels 1 and 2 measure the same (config 5's eight blocks: 1.43-1.47 s per step either way),
             "batch_grad_ob" (default 1: the shared chain's gradient stage inverts all blocks in one outer-batched sequence of launches),
-            "trtri_overlap", "small_fused", "small_max_n", "eig_overlap", "sb_lookahead" (round-3 experiment
-                        switches; some exist in the development build only: ffgp_has_dev_options)    */
+            "trtri_overlap", "small_fused", "small_max_n" (round-3 experiment switches).
+   Keys the SHIPPED library refuses with FFGP_ERR_ARG (they are accepted by the development build only, `make dev`,
+   ffgp_has_dev_options() == 1): "raw_graph_max_n", "diag_dbg", "la_split", "nb_big", "nb_big_until", "sb_lookahead", "sb_av_gemm",
+   "sb_qr4", "q2_wave4", "eig_overlap", "band_log2", "polite_pad_kb", and every value of "diag_v2" other than 0 and 4.  An unknown
+   key is FFGP_ERR_ARG in both builds.    */
 int ffgp_set_option(ffgp_handle* h, const char* key, double value);
 /* Create the handle's side streams now and use each once, so that they bind their hardware queues before streams the process creates
    later (ROCm binds at first use; a late stream shares a queue with an earlier one and runs in line with it).  For the main handle of
@@ -419,17 +425,44 @@ int ffgp_nlml_fused_raw_async(ffgp_handle* h, const ffgp_problem* p, const ffgp_
 int ffgp_nlml_fused_small_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_links* links, double* nll_dev,
                                 const ffgp_grads* g);
 
-/* F independent blocks of ONE shape (the same n > 128 and d; V1 likelihood; one radial-profile kernel each) in one chain of
-   launches: the per-fidelity / per-seed loops of the reference evaluate equal-size blocks one after the other
+/* F independent blocks (2 <= F <= 256; n > 128 each; V1 likelihood; one radial-profile kernel each) in one chain of launches: the
+   per-fidelity / per-seed loops of the reference evaluate its blocks one after the other
    (Experiments/GAR_Aligned/exp_aligned.py:58-126, FidelityFusion_Models/ResGP.py:78-112), and below N ~ 6000 one block's
    factorisation is a latency-bound chain of short launches.  Here every launch of that chain covers all F blocks (diagonal-block
    kernel: one workgroup per block; GEMMs: the block index in gridDim.y), so the blocks share ONE chain; the arithmetic per block is
-   the single call's, and the values are bit-identical to F separate calls.  p, g (may be NULL), links (NULL = effective
-   parameters): arrays of F; nll_dev[f] receives block f's value; status[f] (host, may be NULL) its own factorisation status
-   (0, or the 1-based index of the first non-positive pivot of THAT block).  Returns the first non-zero status, FFGP_ERR_ARG when
-   the blocks do not meet the conditions (call them one by one then).  Synchronous.                                            */
+   the single call's, and the values are bit-identical to F separate calls.
+   The blocks may have ONE shape (any n > 128) or DIFFERENT n and d (n <= 12288 each) -- the reference's fidelities are ragged:
+   300 / 300 / 250 points in FidelityFusion_Models/ResGP.py:121-136, 100 low against 4..32 high in
+   Experiments/GAR_Aligned/exp_aligned.py:66-74.  In a ragged batch every member follows the launch sequence of its own single call
+   (in order up to "la_min_n" rows, the look-ahead's carry form above), launches of one kind at one chain step are merged with
+   per-member sizes, and a member leaves the chain's launches when its columns are used up: the chain runs max(n) / 128 steps.
+   p, g (may be NULL), links (NULL = effective parameters): arrays of F; nll_dev[f] receives block f's value; status[f] (host, may
+   be NULL) its own factorisation status (0, or the 1-based index of the first non-positive pivot of THAT block).  Returns the first
+   non-zero status; FFGP_ERR_ARG when the blocks do not meet the conditions -- also with options "naive" = 1 or "diag_v2" = 0, F > 256,
+   a ragged member above 12288 rows -- and FFGP_ERR_ALLOC when the F-fold workspace does not fit: evaluate the blocks one by one
+   (or in smaller batches) then, as fidelityfusion_amd/nlml.py::_chain_batches does.  Synchronous.                               */
 int ffgp_nlml_fused_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_links* links, double* nll_dev,
                           const ffgp_grads* g, int* status);
+
+/* K Adam training steps of F independent models (F <= 16) in ONE call -- the reference's hot loop
+   (FidelityFusion_Models/ResGP.py:78-112; GaussianProcess/cigp_v10.py:92-104: per fidelity 100-1000 iterations of
+   optimizer.zero_grad(); loss = -model.negative_log_likelihood(x, y); loss.backward(); optimizer.step() at N = 16 ... 500).
+   p[f] / links[f] describe model f on its RAW parameters exactly as for ffgp_nlml_fused_raw (w_dev = raw length scales, amp_dev = raw
+   signal variance, diag_add_dev = raw log_beta; links->out_scale = the sign that makes the value the loss to MINIMISE, +1 for
+   loss = -negative_log_likelihood).  Per step: the likelihood and its closed-form gradients on the raw parameters (one launch for all
+   models when every model is small -- the ffgp_nlml_fused_small_batch limits -- otherwise the launches of ffgp_nlml_fused_raw model
+   after model), then one kernel that applies torch.optim.Adam's update (betas, eps, bias corrections as torch computes them; no
+   weight decay, no amsgrad) to the three raw parameter tensors IN PLACE and stores the step's loss.  No host synchronisation inside
+   the loop.  state_dev: per model [exp_avg (nw + 2) | exp_avg_sq (nw + 2)] at stride state_stride doubles (nw = 1 for a broadcast
+   scalar length scale, else D; order: w, amp, diag_add), zero for a fresh optimiser and carried between calls together with step0 =
+   the number of steps already taken; trace_dev[f * trace_stride + k] = loss of model f at step k, evaluated BEFORE that step's
+   update (what the reference prints).  Returns 0, or the pivot status of the first step whose Sigma was not positive definite
+   (torch.linalg.LinAlgError in the reference's loop): from that step on no parameter moves and the trace holds NaN.  Synchronous. */
+typedef struct ffgp_adam {
+  double lr, beta1, beta2, eps;
+} ffgp_adam;
+int ffgp_train_raw(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_links* links, int steps, const ffgp_adam* opt,
+                   double* state_dev, long state_stride, long step0, double* trace_dev, long trace_stride);
 int ffgp_nlml_fused_small_batch_async(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_links* links, double* nll_dev,
                                       const ffgp_grads* g);
 

@@ -1,5 +1,6 @@
 import os
 import sys
+import time
 
 import pytest
 
@@ -58,6 +59,7 @@ class _Noise:
         self.parked = threading.Event()
         self.vendor = threading.Lock()
         self.count = 0
+        self.locked_s = 0.0
         self.patched = []
         self.thread = None
         self.error = None
@@ -73,8 +75,10 @@ class _Noise:
 
             def quiet(*a, _real=real, **kw):
                 with self.vendor:
+                    t0 = time.perf_counter()
                     out = _real(*a, **kw)
                     torch.cuda.synchronize()
+                    self.locked_s += time.perf_counter() - t0    # (time the load was held off by a comparator)
                     return out
             functools.update_wrapper(quiet, real)
             setattr(torch.linalg, name, quiet)
@@ -129,7 +133,15 @@ class _Noise:
                 self.count += 1
                 time.sleep(0.002)              # (outside the lock: a comparator that is waiting gets its turn -- Python's locks are not fair)
 
+    def check(self):
+        """a dead load must fail the run, in every mode"""
+        if self.error:
+            raise RuntimeError("the background load of the GPU tests died:\n" + self.error)
+        if self.thread is not None and not self.thread.is_alive() and not self.stop.is_set():
+            raise RuntimeError("the background load of the GPU tests stopped without an error message")
+
     def on(self):
+        self.check()
         if self.thread is None:
             self.start()
         self.parked.clear()
@@ -138,8 +150,7 @@ class _Noise:
     def off(self):
         self.run.clear()
         self.parked.wait(60)
-        if self.error:
-            raise RuntimeError("the background load of the GPU tests died:\n" + self.error)
+        self.check()
 
     def end(self):
         import torch
@@ -149,6 +160,8 @@ class _Noise:
             self.thread.join(timeout=60)
         for name, real in self.patched:
             setattr(torch.linalg, name, real)
+        if self.error:
+            raise RuntimeError("the background load of the GPU tests died:\n" + self.error)
 
 
 _noise = None
@@ -188,8 +201,15 @@ def _gpu_noise(request):
     if _noise is None:
         _noise = _Noise()
     _noise.on()
+    before, locked0 = _noise.count, _noise.locked_s
+    t0 = time.perf_counter()
     try:
         yield
     finally:
         if mode != "all":
             _noise.off()
+        else:
+            _noise.check()      # (the load keeps running between tests in this mode: look at it after every test all the same)
+        # a test that ran for a while beside a load that never completed a round was not disturbed by anything
+        if time.perf_counter() - t0 - (_noise.locked_s - locked0) > 10.0 and _noise.count == before:
+            pytest.fail("the background load made no progress during this test (%d rounds before and after)" % before)

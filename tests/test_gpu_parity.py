@@ -908,6 +908,112 @@ def test_equal_shape_blocks_share_one_chain(n, d, F_):
 
 
 @pytest.mark.noisy
+@pytest.mark.parametrize("shapes", [
+    [(300, 1), (300, 1), (250, 1)],                       # the reference's own demo (FidelityFusion_Models/ResGP.py:121-136)
+    [(700, 2), (131, 1), (513, 3), (1100, 1)],            # in-order members, ragged last blocks, d differs
+    [(4000, 1), (2048, 2), (1024, 1), (390, 1)],          # a look-ahead member (carry form) beside in-order ones
+    [(4200, 3), (3700, 1), (640, 2)],                     # two look-ahead members of different length
+    [(200 + 37 * i, 1 + i % 2) for i in range(11)],       # more members than one launch holds (FFGP_RAG_MAX = 8)
+])
+def test_ragged_blocks_share_one_chain(shapes):
+    """cigp_v10.negative_log_likelihood_many on blocks of DIFFERENT sizes: one ragged chain (ffgp_nlml_fused_batch -> ffgp_potrf_ragged:
+    every member follows its own single call's launch sequence, launches of a kind at one chain step are merged with per-member
+    sizes, a member drops out when its columns are used up) -- values and every gradient are the individual calls' BIT FOR BIT"""
+    from fidelityfusion_amd import functional as F
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp, negative_log_likelihood_many
+    rng = np.random.default_rng(sum(n for n, _ in shapes))
+    F_ = len(shapes)
+    models, xs, ys = [], [], []
+    for f, (n, d) in enumerate(shapes):
+        D = 2 + f % 4
+        k = kernel.ARDKernel(D) if f % 2 == 0 else kernel.MaternKernel(D, nu=2.5)
+        with torch.no_grad():
+            k.length_scales.copy_(torch.tensor(rng.uniform(0.5, 1.5, D) * rng.choice([-1.0, 1.0], D)))
+        models.append(cigp(k, 0.5 + 0.05 * f).double().to(DEV))
+        xs.append(T(rng.uniform(0, 1, (n, D))))
+        ys.append(T(rng.standard_normal((n, d)), grad=True))
+    calls = []
+    real = F.lib.ffgp_nlml_fused_batch
+
+    class _Spy:
+        def __getattr__(self, name):
+            return getattr(F._lib.lib, name)
+
+        def ffgp_nlml_fused_batch(self, h, nF, *a):
+            calls.append(nF)
+            return real(h, nF, *a)
+    wts = T(np.linspace(0.5, 1.5, F_))
+    with F.patched_lib(_Spy()):
+        vals = negative_log_likelihood_many(models, xs, ys)
+        (vals * wts).sum().backward()
+        with torch.no_grad():
+            vals_ng = negative_log_likelihood_many(models, xs, ys)
+    assert calls == [F_, F_] and vals.shape == (F_,)
+    assert torch.equal(vals_ng, vals.detach())
+    got = [(v.detach().clone(), [p_.grad.clone() for p_ in m.parameters()], y.grad.clone()) for v, m, y in zip(vals, models, ys)]
+    for i, (m, x, y) in enumerate(zip(models, xs, ys)):
+        for p_ in m.parameters():
+            p_.grad = None
+        y.grad = None
+        v = m.negative_log_likelihood(x, y)
+        (v * wts[i]).backward()
+        assert torch.equal(got[i][0], v.detach()), (i, shapes[i], float(got[i][0]), float(v))
+        for a, b in zip(got[i][1], [p_.grad for p_ in m.parameters()]):
+            assert torch.equal(a, b), (i, shapes[i])
+        assert torch.equal(got[i][2], y.grad), (i, shapes[i])
+    # a member that is not positive definite is reported as THAT block
+    if shapes[1][0] <= 700:
+        n1 = shapes[1][0]
+        bad_y = [ys[1].detach(), -3.0 * torch.eye(n1, device=DEV, dtype=torch.float64)]
+        with pytest.raises(torch.linalg.LinAlgError, match="block 1"):
+            negative_log_likelihood_many(models, xs, [ys[0], bad_y] + ys[2:])
+        assert torch.isfinite(negative_log_likelihood_many(models, xs, ys)).all()
+    # small and larger models in one call: one library call per kind, results in the caller's order
+    ks = kernel.ARDKernel(3)
+    small = cigp(ks, 0.4).double().to(DEV)
+    xsm, ysm = T(rng.uniform(0, 1, (60, 3))), T(rng.standard_normal((60, 2)))
+    with torch.no_grad():
+        mixed = negative_log_likelihood_many([models[0], small, models[1]], [xs[0], xsm, xs[1]], [ys[0], ysm, ys[1]])
+        assert torch.equal(mixed[0], got[0][0]) and torch.equal(mixed[2], got[1][0])
+        assert torch.equal(mixed[1], small.negative_log_likelihood(xsm, ysm))
+
+
+def test_shared_chain_falls_back_when_the_library_refuses_the_batch():
+    """include/ffgp.h leaves the fallback to the caller: with option naive = 1 or diag_v2 = 0 ffgp_nlml_fused_batch returns
+    FFGP_ERR_ARG, and more than 256 members do not fit one call -- negative_log_likelihood_many must still return the individual
+    calls' values (and gradients) instead of raising"""
+    from fidelityfusion_amd import _lib
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd import nlml as NL
+    from fidelityfusion_amd.cigp_v10 import cigp, negative_log_likelihood_many
+    rng = np.random.default_rng(5)
+    n, F_ = 300, 3
+    models = [cigp(kernel.ARDKernel(3), 0.6 + 0.1 * f).double().to(DEV) for f in range(F_)]
+    xs = [T(rng.uniform(0, 1, (n, 3))) for _ in range(F_)]
+    ys = [T(rng.standard_normal((n, 2)), grad=True) for _ in range(F_)]
+    for key, val, back in (("naive", 1, 0), ("diag_v2", 0, 4)):
+        _lib.set_option(key, val, 0)
+        try:
+            ref = torch.stack([m.negative_log_likelihood(x, y).reshape(()) for m, x, y in zip(models, xs, ys)])
+            vals = negative_log_likelihood_many(models, xs, ys)
+            assert torch.equal(vals.detach(), ref.detach()), key
+            vals.sum().backward()
+            assert all(y.grad is not None and torch.isfinite(y.grad).all() for y in ys)
+        finally:
+            _lib.set_option(key, back, 0)
+    # chunking: a limit of two members per chain call -> chunks of two plus a single leftover, same values
+    old = NL.CHAIN_BATCH_MAX_F
+    NL.CHAIN_BATCH_MAX_F = 2
+    try:
+        with torch.no_grad():
+            ref = torch.stack([m.negative_log_likelihood(x, y).reshape(()) for m, x, y in zip(models, xs, ys)])
+            assert torch.equal(negative_log_likelihood_many(models, xs, ys), ref)
+    finally:
+        NL.CHAIN_BATCH_MAX_F = old
+
+
+@pytest.mark.noisy
 def test_shared_chain_gradient_stage_paths_agree():
     """the gradient stage of the shared chain has two routes -- every block's inverse in one outer-batched sequence of launches
     (all blocks want gradients), or block after block through one set of buffers (a member without gradients, or the option

@@ -1,0 +1,179 @@
+"""K Adam steps per library call (cigp_v10.train_many -> ffgp_train_raw) against the reference's own loop -- one
+`optimizer.zero_grad(); loss = -gpr.negative_log_likelihood(x, y); loss.backward(); optimizer.step()` per iteration through the
+drop-in modules and torch.optim.Adam (FidelityFusion_Models/ResGP.py:78-112) -- and against the reference-generated fixtures of that
+loop (tests/golden/resgp_chain.npz, train_log_resgp.npz).  The trajectory must be the per-step path's to 1e-12 (relative; the Adam
+arithmetic is torch's operation for operation, the likelihood and gradients are the same launches)."""
+import copy
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(torch.float32)
+
+
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.tensor(np.asarray(a), dtype=torch.float64, device=DEV)
+
+
+def rel(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, dtype=np.float64)
+    return float(np.abs(a.reshape(b.shape) - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def reference_loop(models, xs, ys, steps, lr):
+    """the reference's loop: a fresh Adam per model, the loss recorded before the update"""
+    trace = np.zeros((len(models), steps))
+    for f, (m, x, y) in enumerate(zip(models, xs, ys)):
+        opt = torch.optim.Adam(m.parameters(), lr=lr)
+        for k in range(steps):
+            opt.zero_grad()
+            loss = -m.negative_log_likelihood(x, y)
+            loss.backward()
+            opt.step()
+            trace[f, k] = float(loss.detach())
+    return trace
+
+
+def make_models(shapes, seed, kinds=None):
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp
+    from oracle import gp_oracle as O
+    rng = np.random.default_rng(seed)
+    models, xs, ys = [], [], []
+    for f, (n, D, d) in enumerate(shapes):
+        kind = (kinds or ["ard"] * len(shapes))[f]
+        if kind == "ard":
+            k = kernel.ARDKernel(D)
+            with torch.no_grad():
+                k.length_scales.copy_(torch.tensor(rng.uniform(0.6, 1.6, D) * rng.choice([-1.0, 1.0], D)))
+        elif kind == "se":
+            k = kernel.SquaredExponentialKernel(0.3, 0.2)
+        else:
+            k = kernel.MaternKernel(D, nu=2.5)
+        models.append(cigp(k, 0.7 + 0.1 * f).double().to(DEV))
+        X, Y = O.synthetic_xy(n, D, d, seed=seed + f)
+        xs.append(T(X))
+        ys.append(T(Y))
+    return models, xs, ys
+
+
+def params_of(m):
+    return [p.detach().cpu().numpy().copy() for p in m.parameters()]
+
+
+@pytest.mark.parametrize("shapes,kinds", [
+    ([(24, 3, 2)], None),                                   # the one-kernel path (n <= 40)
+    ([(128, 4, 1)], None),                                  # one diagonal block
+    ([(300, 5, 2)], ["matern"]),                            # the blocked path, in order
+    ([(700, 2, 3)], ["se"]),                                # scalar log length scale (broadcast), blocked path
+    ([(60, 3, 1), (128, 2, 2), (17, 4, 1)], None),          # three small models: ONE launch per step for all
+    ([(60, 3, 1), (400, 2, 2), (90, 16, 1)], ["ard", "se", "ard"]),   # a mix: model after model inside the step
+])
+def test_train_many_follows_the_reference_loop(shapes, kinds):
+    from fidelityfusion_amd.cigp_v10 import train_many
+    steps, lr = 25, 1e-2
+    models, xs, ys = make_models(shapes, 11, kinds)
+    twins = [copy.deepcopy(m) for m in models]
+    trace, state = train_many(models, xs, ys, steps, lr=lr)
+    ref = reference_loop(twins, xs, ys, steps, lr)
+    assert trace.shape == (len(models), steps) and trace.is_cuda
+    assert rel(trace, ref) < 1e-12, rel(trace, ref)
+    for m, t in zip(models, twins):
+        for a, b in zip(params_of(m), params_of(t)):
+            assert rel(a, b) < 1e-12
+    # the optimisers continue where they stopped: 25 + 15 steps in two calls = 40 steps of the loop
+    trace2, state = train_many(models, xs, ys, 15, lr=lr, state=state)
+    twins2 = [copy.deepcopy(m) for m in make_models(shapes, 11, kinds)[0]]
+    ref40 = reference_loop(twins2, xs, ys, 40, lr)
+    assert rel(torch.cat([trace, trace2], dim=1), ref40) < 1e-11
+    for m, t in zip(models, twins2):
+        for a, b in zip(params_of(m), params_of(t)):
+            assert rel(a, b) < 1e-11
+    # parameters were updated in place behind autograd's back: their version counters moved, so a cached posterior is rebuilt
+    with torch.no_grad():
+        mean, _ = models[0](xs[0], ys[0], xs[0][:5])
+        mean_t, _ = twins2[0](xs[0], ys[0], xs[0][:5])
+    assert rel(mean, mean_t) < 1e-9
+
+
+def test_train_many_on_the_reference_fixture(golden):
+    """tests/golden/resgp_chain.npz: the reference's train_ResGP on a seeded two-fidelity problem, 5 Adam steps per fidelity
+    (FidelityFusion_Models/ResGP.py:67-112; the second fidelity's targets come with a y_var matrix) -- both fidelities as ONE
+    train_many call"""
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp, train_many
+    g = golden("resgp_chain")
+    gprs = [cigp(kernel.SquaredExponentialKernel(), 1.0).double().to(DEV) for _ in range(2)]
+    xs = [T(g["x0n"]), T(g["x_res"])]
+    ys = [T(g["y0n"]), [T(g["y_res_mean"]), T(g["y_res_var"])]]
+    trace, _ = train_many(gprs, xs, ys, 5, lr=1e-2)
+    assert rel(-trace.reshape(-1), g["ll_trace"]) < 1e-8
+    for f in range(2):
+        assert rel(gprs[f].log_beta, g[f"gpr_list__{f}__log_beta"]) < 1e-8
+        assert rel(gprs[f].kernel.length_scale, g[f"gpr_list__{f}__kernel__length_scale"]) < 1e-8
+        assert rel(gprs[f].kernel.signal_variance, g[f"gpr_list__{f}__kernel__signal_variance"]) < 1e-8
+
+
+def test_train_many_reaches_the_reference_log(golden):
+    """the reference's own committed log (FidelityFusion_Models/log/ResGP/train.log:201,401): 199 and 200 Adam steps on fidelity 0
+    of the demo land on the logged parameters to the log's reproducibility (+-2e-3, tests/test_gpu_parity.py holds the per-step
+    path to the same bar) -- here as two train_many calls"""
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp, train_many
+    g = golden("train_log_resgp")
+    m = cigp(kernel.SquaredExponentialKernel(), 1.0).double().to(DEV)
+    x, y = T(g["x0n"]), T(g["y0n"])
+    _, state = train_many([m], [x], [y], 199, lr=1e-2)
+    seen199 = [float(m.log_beta), float(m.kernel.length_scale), float(m.kernel.signal_variance)]
+    train_many([m], [x], [y], 1, lr=1e-2, state=state)
+    seen200 = [float(m.log_beta), float(m.kernel.length_scale), float(m.kernel.signal_variance)]
+    assert np.abs(np.array(seen199) - g["line201"]).max() <= 2e-3
+    assert np.abs(np.array(seen200) - g["line401"][:3]).max() <= 2e-3
+
+
+def test_train_many_reports_a_matrix_that_is_not_positive_definite():
+    from fidelityfusion_amd.cigp_v10 import train_many
+    models, xs, ys = make_models([(50, 2, 1), (90, 3, 1)], 3)
+    before = params_of(models[1])
+    bad = [ys[1], -3.0 * torch.eye(90, device=DEV, dtype=torch.float64)]
+    with pytest.raises(torch.linalg.LinAlgError):
+        train_many(models, xs, [ys[0], bad], 4)
+    # no parameter of the failing call moved past the step that failed (here: the first), and the handle is usable again
+    for a, b in zip(params_of(models[1]), before):
+        assert np.array_equal(a, b)
+    trace, _ = train_many(models, xs, ys, 3)
+    assert torch.isfinite(trace).all()
+
+
+def test_train_many_runs_the_reference_loop_for_models_it_cannot_fuse():
+    """CPU-resident fp32 models (the reference's default) are not eligible for the fused call: train_many then IS the reference's
+    loop through the drop-in modules, same return values"""
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp, train_many
+    torch.set_default_dtype(torch.float32)
+    try:
+        rng = np.random.default_rng(0)
+        x = torch.tensor(rng.uniform(0, 1, (40, 2)), dtype=torch.float32)
+        y = torch.tensor(np.sin(4 * rng.uniform(0, 1, (40, 1))), dtype=torch.float32)
+        m = cigp(kernel.ARDKernel(2), 1.0)
+        t = copy.deepcopy(m)
+        trace, state = train_many([m], [x], [y], 6, lr=1e-2)
+        ref = reference_loop([t], [x], [y], 6, 1e-2)
+    finally:
+        torch.set_default_dtype(torch.float64)
+    assert state["fused"] is False and rel(trace, ref) < 1e-5
