@@ -120,6 +120,56 @@ def spawn_ranks(args):
     return rc
 
 
+def gpu_numa_cpus(local_rank):
+    """CPUs of the NUMA node the local_rank-th AMD GPU hangs off, read from sysfs without touching HIP (cards in PCI-address
+    order, which is the order ROCm enumerates them in on one node); None when sysfs does not say."""
+    import glob
+    cards = []
+    for dev in glob.glob("/sys/class/drm/card[0-9]*/device"):
+        try:
+            if open(os.path.join(dev, "vendor")).read().strip() != "0x1002":
+                continue
+            cards.append((os.path.basename(os.path.realpath(dev)), dev))
+        except OSError:
+            continue
+    cards.sort()
+    if local_rank >= len(cards):
+        return None
+    try:
+        node = int(open(os.path.join(cards[local_rank][1], "numa_node")).read().strip())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        return sorted(cpus)
+    except (OSError, ValueError):
+        return None
+
+
+def pin_rank(local_rank, local_world):
+    """Per-rank CPU affinity, set BEFORE the process touches the GPU (the factorisation is a host-driven chain of ~400 launches per
+    29 ms step: a launch thread that migrates, or shares its core with another rank's, arrives late and the GPU idles -- 29 -> 35 ms
+    on a busy host).  The rank gets its own slice of the CPUs of its GPU's NUMA node (an even slice of the allowed
+    CPUs when sysfs does not name the node); FFGP_BENCH_AFFINITY=0 leaves the affinity alone.  Returns the CPUs pinned to, or None."""
+    if os.environ.get("FFGP_BENCH_AFFINITY", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    allowed = sorted(os.sched_getaffinity(0))
+    node = gpu_numa_cpus(local_rank)
+    pool = [c for c in (node or allowed) if c in set(allowed)] or allowed
+    # the ranks whose GPUs share this pool split it evenly (with one NUMA node per GPU pair, two ranks share a pool)
+    sharers = [r for r in range(local_world) if (gpu_numa_cpus(r) or allowed) == (node or allowed)] or [local_rank]
+    k = sharers.index(local_rank) if local_rank in sharers else 0
+    per = max(1, len(pool) // len(sharers))
+    mine = pool[k * per:(k + 1) * per] or pool
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    return mine
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # workload pieces
 # ---------------------------------------------------------------------------------------------------------------
@@ -379,13 +429,17 @@ def cpu_baseline(budget_s, gpu_ref):
 # one rank
 # ---------------------------------------------------------------------------------------------------------------
 def run_rank(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    pinned = None
+    if world > 1:      # before torch is imported (its worker threads inherit the mask) and long before the first GPU call;
+        pinned = pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))   # a lone rank keeps the whole host
+
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N ranks, or drop WORLD_SIZE to let bench.py "
                          "launch them itself)" % (args.gpus, world))
@@ -427,15 +481,18 @@ def run_rank(args):
         if not args.dry:
             torch.cuda.synchronize()
 
-    def params(D):
+    def params(D, with_grad):
         # reference initial hyper-parameters: length_scales = 1 (kernel.py:84), signal_variance = 1, log_beta = 1 (ResGP.py:27)
-        w = torch.ones(D, dtype=torch.float64, device=dev, requires_grad=args.with_grad)
-        amp = torch.ones(1, dtype=torch.float64, device=dev, requires_grad=args.with_grad)
-        dadd = torch.tensor([np.exp(-1.0) + 1e-6], dtype=torch.float64, device=dev, requires_grad=args.with_grad)
+        w = torch.ones(D, dtype=torch.float64, device=dev, requires_grad=with_grad)
+        amp = torch.ones(1, dtype=torch.float64, device=dev, requires_grad=with_grad)
+        dadd = torch.tensor([np.exp(-1.0) + 1e-6], dtype=torch.float64, device=dev, requires_grad=with_grad)
         return w, amp, dadd
 
-    def make_workload(name, n=None, D=None, d=None, blocks=None):
-        """-> (step(), F_total, n, D, d, scaling): step() evaluates this rank's blocks and all-reduces the F-vector."""
+    def make_workload(name, n=None, D=None, d=None, blocks=None, with_grad=None):
+        """-> (step(), F_total, n, D, d, scaling): step() evaluates this rank's blocks and all-reduces the F-vector.
+        with_grad: the step also produces every gradient `loss.backward()` leaves in the reference's training iteration
+        (FidelityFusion_Models/ResGP.py:84-88) -- Y, length scales, amplitude, noise -- by the closed forms of the same fused call."""
+        with_grad = args.with_grad if with_grad is None else with_grad
         F_fixed, n0, D0, d0, _ = WORKLOADS[name]
         n, D, d = n or n0, D or D0, d or d0
         if F_fixed is None:                                   # one block per rank: fidelity f = rank
@@ -486,9 +543,9 @@ def run_rank(args):
                 data[f] = (torch.tensor(X, dtype=torch.float64, device=dev), torch.tensor(Y, dtype=torch.float64, device=dev))
             else:
                 data[f] = synthetic_xy_device(n, D, d, f, dev)
-            if args.with_grad:
+            if with_grad:
                 data[f][1].requires_grad_(True)
-        w, amp, dadd = params(D)
+        w, amp, dadd = params(D, with_grad)
         nslots = max(1, min(args.slots, len(mine)))
 
         def step():
@@ -497,14 +554,14 @@ def run_rank(args):
                 f = mine[0]
                 vals[f] = F.nlml(data[f][0], data[f][1], w, amp, diag_add=dadd, clamp=1e-30)
             elif mine and not args.no_chain_batch:   # the rank's blocks have one shape: ONE factorisation chain for all of them
-                ctx = torch.enable_grad() if args.with_grad else torch.no_grad()
+                ctx = torch.enable_grad() if with_grad else torch.no_grad()
                 with ctx:
                     out = F.nlml_many([data[f][0] for f in mine], [data[f][1] for f in mine], [w] * len(mine), [amp] * len(mine),
                                       [dadd] * len(mine), clamp=1e-30)
                 for i, f in enumerate(mine):
                     vals[f] = out[i]
             elif mine:   # several owned blocks overlap on this GPU
-                ctx = torch.enable_grad() if args.with_grad else torch.no_grad()
+                ctx = torch.enable_grad() if with_grad else torch.no_grad()
                 with ctx, F.concurrent_blocks(nslots=nslots, device_index=local_rank, lookahead=args.slot_lookahead) as cb:
                     for i, f in enumerate(mine):
                         with cb.slot(i):
@@ -555,6 +612,12 @@ def run_rank(args):
             stages = _lib.last_timings(local_rank)
             _lib.set_option("timing", 0, local_rank)
     ms_per_step = dt / args.steps * 1e3
+    ms_no_events = None
+    if not args.dry and args.steps >= 4:
+        # the same steps once more WITHOUT the per-launch event pairs of the live roofline measurement (timing = 0): what the event
+        # pairs cost the timed region is stated, not assumed -- `value` stays the timed region's, events included
+        dt0, _ = timed(step, args.steps, 0)
+        ms_no_events = dt0 / args.steps * 1e3
     flops_step = nlml_flops(n, D, d) * (3.0 if args.with_grad else 1.0) * F_total   # fwd+bwd ~ N^3
     if args.workload == "gar8_hogp":
         flops_step = hogp_flops(n, HOGP_MODES if d == HOGP_MODES[0] * HOGP_MODES[1] else (d, 1)) * F_total
@@ -594,6 +657,22 @@ def run_rank(args):
             if not args.dry:
                 torch.cuda.empty_cache()
 
+    # ---- the reference's training iteration (forward + every gradient) at C2, C3 and configs[3], a few steps each ------------------
+    train_step = {}
+    if args.workload == "headline" and not args.no_sharded and not args.with_grad and stock and not args.dry:
+        for name in ("c2", "headline", "cigar4"):
+            t_step, tF, tn, tD, td, _ = make_workload(name, with_grad=True)
+            tdt, _ = timed(t_step, 4, 2)
+            tfl = 3.0 * nlml_flops(tn, tD, td) * tF          # forward + backward ~ N^3 + ...
+            train_step[name] = {"blocks": tF, "N": tn, "D": tD, "d": td, "ms_per_step": round(tdt / 4 * 1e3, 3),
+                                "value": round(tfl / (tdt / 4) / 1e9, 1), "unit": "GF/s",
+                                "frac_of_mfma_peak": round(tfl / (tdt / 4) / 1e12 / world / FP64_MFMA_PEAK_TFLOPS, 4),
+                                "what": "likelihood + the gradients loss.backward() leaves (Y, length scales, amplitude, noise) in one "
+                                        "fused call; flops = 3 x the forward's (N^3 + 2 N^2 d + 4 N^2 D, SURVEY 8d)",
+                                "config": "BASELINE configs[%d]" % WORKLOADS[name][4]}
+            del t_step
+            torch.cuda.empty_cache()
+
     if not args.dry and not args.no_cpu_baseline and world == 1 and stock and args.workload in ("headline", "c2"):
         # after every timed leg: the GPU side of the parity columns, and the vendor factorisation as a stated side number
         gpu_ref = gpu_parity_values(dev, ("c2", "headline") if args.workload == "headline" else ("c2",))
@@ -612,7 +691,9 @@ def run_rank(args):
         out = {
             "metric": "GP NLML+Cholesky throughput (NxN fp64 GF/s, %%MFMA-roofline) at N=%d" % n,
             "value": round(value, 1), "unit": "GF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3),
+            "ms_per_step_without_launch_events": None if ms_no_events is None else round(ms_no_events, 3),
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %s NLML %s, ARD kernel, %d block%s of N=%d D=%d d=%d%s"
                                    % (args.workload, "single-fidelity cigp" if F_total == world and scaling == "weak" else
@@ -625,6 +706,8 @@ def run_rank(args):
                                                      if scaling == "strong" else 1),
                        "parallelism": "fidelity-shard x%d (LPT partition, one %d-byte all-reduce per step)" % (world, 8 * F_total)},
             "collective": coll,
+            "cpu_affinity": (None if pinned is None else {"rank0_cpus": len(pinned), "first": pinned[0], "last": pinned[-1],
+                                                          "source": "NUMA node of the rank's GPU (sysfs)" if gpu_numa_cpus(local_rank) else "even split"}),
             "rccl_ranks": coll["ranks"] if coll["backend"] == "nccl" else 0,
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
@@ -646,6 +729,8 @@ def run_rank(args):
                                                  * F_total / (dt / args.steps) / 1e9, 1)
         if sharded:
             out["sharded"] = sharded
+        if train_step:
+            out["train_step"] = train_step
         if vendor is not None:
             out["vendor_potrf_ms"] = dict(vendor, note="torch.linalg.cholesky on this GPU (the reference's own .cuda() path, MFGP_ver2023May/"
                                           "mfgp_demo.py:88-94) vs ffgp_potrf on the same matrix; outside the timed region, never on the product path")

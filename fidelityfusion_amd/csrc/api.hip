@@ -271,6 +271,7 @@ int ffgp_destroy(ffgp_handle* h) {
   if (h->d_info) hipFree(h->d_info);
   if (h->bt_info) hipFree(h->bt_info);
   if (h->train_g) hipFree(h->train_g);
+  ffgp_assemble_collect_free(h);
   if (h->bt_info_host) hipHostFree(h->bt_info_host);
   if (h->d_scal) hipFree(h->d_scal);
   if (h->d_asm) hipFree(h->d_asm);
@@ -661,6 +662,25 @@ __global__ void ffgp_link_fwd(ffgp_links l, int D, const double* __restrict__ rw
     if (rdadd) eff[D + 1] = ffgp_link_val(l.dadd_link, rdadd[0], l.dadd_c);
   }
 }
+// the same for up to FFGP_MULTI_MAX models per launch (the members of a shared-chain batch)
+struct ffgp_multi_link {
+  ffgp_links l[FFGP_MULTI_MAX];
+  const double* rw[FFGP_MULTI_MAX];
+  const double* ramp[FFGP_MULTI_MAX];
+  const double* rdadd[FFGP_MULTI_MAX];
+  double* eff[FFGP_MULTI_MAX];
+  int D[FFGP_MULTI_MAX];
+};
+__global__ void ffgp_link_fwd_multi(ffgp_multi_link q) {
+  const int z = blockIdx.x, t = threadIdx.x, D = q.D[z];
+  const ffgp_links& l = q.l[z];
+  double* __restrict__ eff = q.eff[z];
+  if (t < D) eff[t] = ffgp_link_val(l.w_link, q.rw[z][l.w_broadcast ? 0 : t], l.w_c);
+  if (t == 0) {
+    eff[D] = ffgp_link_val(l.amp_link, q.ramp[z][0], l.amp_c);
+    if (q.rdadd[z]) eff[D + 1] = ffgp_link_val(l.dadd_link, q.rdadd[z][0], l.dadd_c);
+  }
+}
 // geff = [g_w (D) | g_amp | g_dadd] -> gradients with respect to the raw parameters (any output pointer may be null)
 __global__ void ffgp_link_bwd(ffgp_links l, int D, const double* __restrict__ rw, const double* __restrict__ ramp,
                               const double* __restrict__ rdadd, const double* __restrict__ geff, double* __restrict__ g_rw,
@@ -742,7 +762,7 @@ int ffgp_nlml_fused_small_batch_async(ffgp_handle* h, int F, const ffgp_problem*
   FFGP_CHECK(ffgp_zero_async(h, h->d_info, sizeof(int)));
   FFGP_CHECK(ffgp_small_batch_enqueue(h, F, p, l, nll_dev, g));
   hipLaunchKernelGGL(ffgp_sticky_info_kernel, dim3(1), dim3(1), 0, h->stream, h->d_info);
-  FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (!h->defer_info_copy) FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   return FFGP_OK;
 }
 
@@ -812,6 +832,7 @@ int ffgp_nlml_fused_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ff
   }
   const size_t blk = offv.size() > 1 ? offv[1] - offv[0] : total;     // (uniform batches: the stride between the blocks)
   const size_t o_link = total; total += (size_t)F * 512;   // effective parameters / their gradients, 256 + 256 doubles per block
+  const size_t o_red = total; total += (size_t)F * 2 * FFGP_RED_BLOCKS;   // partial sums of the members' reductions
   size_t o_X = 0, o_S = 0, o_T = 0, o_At = 0, o_P = 0;
   // gradient stage: when EVERY block of an equal-shape batch wants gradients (and the inverses fit), Sigma_f^-1 of all blocks come out
   // of one sequence of launches with an outer batch index (ffgp_trtri_lauum_ob) -- a lone N = 4096 inverse underfills the chip at its
@@ -840,22 +861,48 @@ int ffgp_nlml_fused_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ff
   h->n_stages = 0;
   stage_mark(h, 0);
   // ---- links, assembly, passenger rows: block after block (each a few launches that fill the chip by themselves)
+  // (the tiny per-member stages -- links, target transposes, the reductions further down -- are issued for eight members per launch:
+  // F x 5 launches of a few microseconds each were a third of a 300 / 300 / 250 batch's time)
   ffgp_problem* q = (ffgp_problem*)alloca(sizeof(ffgp_problem) * F);
   for (int f = 0; f < F; ++f) {
     q[f] = p[f];
-    const int n = p[f].n, d = p[f].d;
     double* eff = h->ws + o_link + (size_t)f * 512;
     if (l) {
-      hipLaunchKernelGGL(ffgp_link_fwd, dim3(1), dim3(128), 0, h->stream, l[f], p[f].D, p[f].w_dev, p[f].amp_dev, p[f].diag_add_dev, eff);
       q[f].w_dev = eff;
       q[f].amp_dev = eff + p[f].D;
       if (p[f].diag_add_dev) q[f].diag_add_dev = eff + p[f].D + 1;
     }
-    double* W0 = h->ws + offv[f];
-    FFGP_CHECK(ffgp_assemble_impl(h, q[f].X_dev, n, q[f].X_dev, n, q[f].D, q[f].w_dev, q[f].amp_dev, q[f].clamp_min, q[f].diag_add_dev,
-                                  q[f].diag_vec_dev, q[f].diag_stride, q[f].add_mat_dev, q[f].ld_add, q[f].add_all, q[f].mean_jitter, W0,
-                                  (int)ldv[f], 1, q[f].kfun, q[f].kparam));
-    FFGP_CHECK(ffgp_transpose(h, q[f].Y_dev, n, d, d, W0 + (size_t)n * ldv[f], (int)ldv[f], 1.0));
+  }
+  if (l) {
+    for (int f0 = 0; f0 < F; f0 += FFGP_MULTI_MAX) {
+      const int cnt = F - f0 < FFGP_MULTI_MAX ? F - f0 : FFGP_MULTI_MAX;
+      ffgp_multi_link ml;
+      for (int z = 0; z < FFGP_MULTI_MAX; ++z) {
+        const int f = f0 + (z < cnt ? z : 0);
+        ml.l[z] = l[f]; ml.rw[z] = p[f].w_dev; ml.ramp[z] = p[f].amp_dev; ml.rdadd[z] = p[f].diag_add_dev;
+        ml.eff[z] = h->ws + o_link + (size_t)f * 512; ml.D[z] = p[f].D;
+      }
+      hipLaunchKernelGGL(ffgp_link_fwd_multi, dim3(cnt), dim3(128), 0, h->stream, ml);
+    }
+  }
+  {
+    std::vector<const double*> tsrc(F);
+    std::vector<double*> tdst(F);
+    std::vector<int> trows(F), tcols(F), tlds(F), tldd(F);
+    ffgp_assemble_collect_begin(h);      // (small members' assemblies: parked, then eight per launch)
+    int arc = FFGP_OK;
+    for (int f = 0; f < F && arc == FFGP_OK; ++f) {
+      const int n = p[f].n, d = p[f].d;
+      double* W0 = h->ws + offv[f];
+      arc = ffgp_assemble_impl(h, q[f].X_dev, n, q[f].X_dev, n, q[f].D, q[f].w_dev, q[f].amp_dev, q[f].clamp_min, q[f].diag_add_dev,
+                               q[f].diag_vec_dev, q[f].diag_stride, q[f].add_mat_dev, q[f].ld_add, q[f].add_all, q[f].mean_jitter, W0,
+                               (int)ldv[f], 1, q[f].kfun, q[f].kparam);
+      tsrc[f] = q[f].Y_dev; tdst[f] = W0 + (size_t)n * ldv[f]; trows[f] = n; tcols[f] = d; tlds[f] = d; tldd[f] = (int)ldv[f];
+    }
+    const int erc = ffgp_assemble_collect_end(h);      // (always: the handle must not stay in collecting mode)
+    FFGP_CHECK(arc);
+    FFGP_CHECK(erc);
+    FFGP_CHECK(ffgp_transpose_multi(h, F, tsrc.data(), trows.data(), tcols.data(), tlds.data(), tdst.data(), tldd.data()));
   }
   stage_mark(h, 1);
   // ---- ONE factorisation chain for all F blocks
@@ -882,13 +929,27 @@ int ffgp_nlml_fused_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ff
   if (all_grad)
     rc_stage = ffgp_trtri_lauum_ob(h, F, h->ws, (long)blk, p[0].n, (int)ldv[0], h->ws + o_X, (long)sX, (int)ldv[0], h->ws + o_T, (long)sT,
                                    h->ws + o_S, (long)sX, (int)ldv[0], dinv0, (long)nblkv[0] * FFGP_NB * FFGP_NB);
+  const bool fwd_only = !(want_grad && g);
+  if (rc_stage == FFGP_OK) {
+    std::vector<const double*> rL(F), rM(F);
+    std::vector<double*> rout(F);
+    std::vector<int> rn(F), rld(F), rd(F);
+    std::vector<double> rpi(F), rsc(F);
+    for (int f = 0; f < F; ++f) {
+      rL[f] = h->ws + offv[f]; rM[f] = h->ws + offv[f] + (size_t)p[f].n * ldv[f]; rout[f] = nll_dev + f;
+      rn[f] = p[f].n; rld[f] = (int)ldv[f]; rd[f] = p[f].d; rpi[f] = q[f].pi_const;
+      // forward only: the output scale (the sign of the reference's +LL) is folded into the reduction's last step
+      rsc[f] = (l && fwd_only && l[f].out_scale != 0.0) ? l[f].out_scale : 1.0;
+    }
+    rc_stage = ffgp_nll_reduce_multi(h, F, rL.data(), rn.data(), rld.data(), rM.data(), rd.data(), rn.data(), rld.data(), rd.data(), rpi.data(),
+                                     rsc.data(), rout.data(), h->ws + o_red);
+  }
   for (int f = 0; f < F && rc_stage == FFGP_OK; ++f) {
     const int n = p[f].n, d = p[f].d;
     const int ld = (int)ldv[f];
     double* W0 = h->ws + offv[f];
     double* Gt = W0 + (size_t)n * ld;
-    rc_stage = ffgp_nll_reduce_impl(h, FFGP_LL_V1, W0, n, ld, Gt, d, n, ld, d, q[f].pi_const, nll_dev + f);
-    if (rc_stage != FFGP_OK || !want_grad || !g) continue;
+    if (!want_grad || !g) continue;
     const ffgp_grads& gg = g[f];
     if (!(gg.g_w_dev || gg.g_amp_dev || gg.g_diag_add_dev || gg.g_Y_dev || gg.g_diag_vec_dev || gg.g_kparam_dev)) continue;
     // the block's own slice of the Dinv store, presented as "the" store of this factor while its inverse is formed
@@ -936,13 +997,7 @@ int ffgp_nlml_fused_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ff
   h->dinv = dinv0;
   h->dinv_L = nullptr;
   FFGP_CHECK(rc_stage);
-  if (l && !(want_grad && g)) {      // forward only: the output scale (the sign of the reference's +LL) still applies
-    for (int f = 0; f < F; ++f) {
-      const double sc = (l[f].out_scale == 0.0) ? 1.0 : l[f].out_scale;
-      if (sc != 1.0)
-        hipLaunchKernelGGL(ffgp_scale_outputs, dim3(1), dim3(256), 0, h->stream, sc, nll_dev + f, (double*)nullptr, 0L, (double*)nullptr, 0L,
-                           (double*)nullptr);
-    }
+  if (l && fwd_only) {      // forward only: the output scale was applied by the reduction
   } else if (l) {                   // blocks without gradients of their own inside a gradient batch
     for (int f = 0; f < F; ++f) {
       const ffgp_grads& gg = g[f];
@@ -1034,18 +1089,26 @@ int ffgp_train_raw(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_link
   }
   // the sticky status word starts clean: a failure of an EARLIER call on this handle is that call's to report
   FFGP_CHECK(ffgp_zero_async(h, h->d_info, 2 * sizeof(int)));
-  for (int k = 0; k < steps; ++k) {
+  h->defer_info_copy = 1;      // (the per-call read-back of the status word: once, after the loop)
+  int lrc = FFGP_OK;
+  for (int k = 0; k < steps && lrc == FFGP_OK; ++k) {
     if (all_small && F > 1) {
-      FFGP_CHECK(ffgp_zero_async(h, h->d_info, sizeof(int)));
-      FFGP_CHECK(ffgp_small_batch_enqueue(h, F, p, lk.data(), loss, g.data()));
+      if ((lrc = ffgp_zero_async(h, h->d_info, sizeof(int))) != FFGP_OK) break;
+      if ((lrc = ffgp_small_batch_enqueue(h, F, p, lk.data(), loss, g.data())) != FFGP_OK) break;
       hipLaunchKernelGGL(ffgp_sticky_info_kernel, dim3(1), dim3(1), 0, h->stream, h->d_info);
     } else {
-      for (int f = 0; f < F; ++f) FFGP_CHECK(nlml_fused_raw_plain(h, p + f, &lk[f], loss + f, &g[f]));
+      for (int f = 0; f < F && lrc == FFGP_OK; ++f) lrc = nlml_fused_raw_plain(h, p + f, &lk[f], loss + f, &g[f]);
+      if (lrc != FFGP_OK) break;
     }
     const double t = (double)(step0 + k + 1);
     const double bc1 = 1.0 - std::pow(opt->beta1, t), bc2 = 1.0 - std::pow(opt->beta2, t);
     hipLaunchKernelGGL(ffgp_adam_kernel, dim3(F), dim3(192), 0, h->stream, F, sl, gbuf, state_dev, state_stride, opt->lr, opt->beta1,
                        opt->beta2, opt->eps, bc1, std::sqrt(bc2), loss, trace_dev, trace_stride, k, h->d_info);
+  }
+  h->defer_info_copy = 0;
+  if (lrc != FFGP_OK) {
+    hipStreamSynchronize(h->stream);
+    return lrc;
   }
   if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
   FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1192,7 +1255,7 @@ static int small2_enqueue(ffgp_handle* h, const ffgp_problem* p, const ffgp_link
   FFGP_CHECK(ffgp_potrf_impl(h, h->ws, n, n, (int)ld, 0));
   FFGP_CHECK(ffgp_small_enqueue(h, p, l, nll_dev, g, h->dinv));
   hipLaunchKernelGGL(ffgp_sticky_info_kernel, dim3(1), dim3(1), 0, h->stream, h->d_info);
-  FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (!h->defer_info_copy) FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   return FFGP_OK;
 }
 
@@ -1205,7 +1268,7 @@ static int nlml_fused_raw_plain(ffgp_handle* h, const ffgp_problem* p, const ffg
     h->n_stages = 0;
     FFGP_CHECK(ffgp_small_enqueue(h, p, l, nll_dev, g));
     hipLaunchKernelGGL(ffgp_sticky_info_kernel, dim3(1), dim3(1), 0, h->stream, h->d_info);
-    FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (!h->defer_info_copy) FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     return FFGP_OK;
   }
   if (ffgp_small2_ok(h, p, g)) return small2_enqueue(h, p, l, nll_dev, g);
@@ -1288,7 +1351,7 @@ static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll
     h->n_stages = 0;
     FFGP_CHECK(ffgp_small_enqueue(h, p, nullptr, nll_dev, g));
     hipLaunchKernelGGL(ffgp_sticky_info_kernel, dim3(1), dim3(1), 0, h->stream, h->d_info);
-    FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (!h->defer_info_copy) FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     return FFGP_OK;
   }
   if (ffgp_small2_ok(h, p, g)) return small2_enqueue(h, p, nullptr, nll_dev, g);
@@ -1399,7 +1462,7 @@ static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll
     stage_mark(h, 6);
   }
   hipLaunchKernelGGL(ffgp_sticky_info_kernel, dim3(1), dim3(1), 0, h->stream, h->d_info);
-  FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (!h->defer_info_copy) FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   return FFGP_OK;
 }
 

@@ -147,6 +147,80 @@ __global__ __launch_bounds__(256) void ffgp_assemble_kernel(AsmArgs a) {
   if (a.ksum) asm_ksum(a, tsum, red, tid);
 }
 
+// up to FFGP_MULTI_MAX independent assemblies per launch (the members of a shared-chain batch of small blocks: one launch of a few
+// tiles each otherwise); gridDim.y = member, a member's surplus workgroups leave at once
+struct AsmMulti {
+  AsmArgs a[FFGP_MULTI_MAX];
+  int tiles[FFGP_MULTI_MAX];
+};
+__global__ __launch_bounds__(256) void ffgp_assemble_kernel_multi(AsmMulti q) {
+  __shared__ double x1s[AT][DC + 1];
+  __shared__ double x2t[DC][AT + 1];
+  const int z = blockIdx.y;
+  if ((int)blockIdx.x >= q.tiles[z]) return;
+  const AsmArgs& a = q.a[z];
+  const int tid = threadIdx.x;
+  int ti, tj;
+  if (a.lower_only) {
+    const int t = blockIdx.x;
+    int r = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((r + 1) * (r + 2) / 2 <= t) ++r;
+    while (r * (r + 1) / 2 > t) --r;
+    ti = r;
+    tj = t - r * (r + 1) / 2;
+  } else {
+    ti = blockIdx.x / a.tiles_n;
+    tj = blockIdx.x % a.tiles_n;
+  }
+  ExpCoef ec;
+  ffgp_exp_load(ec);
+  double tsum = 0.0;
+  asm_tile_diff(a, ti, tj, tid, x1s, x2t, ec, tsum);
+}
+
+struct AsmCollector {
+  std::vector<AsmArgs> a;
+  std::vector<int> tiles;
+};
+
+// launch what ffgp_assemble_impl parked in the handle's collector (ffgp_handle::asm_collect), eight members per launch
+int ffgp_assemble_flush(ffgp_handle* h) {
+  AsmCollector* c = static_cast<AsmCollector*>(h->asm_collect);
+  if (!c) return FFGP_OK;
+  const int F = (int)c->a.size();
+  for (int f0 = 0; f0 < F; f0 += FFGP_MULTI_MAX) {
+    const int cnt = F - f0 < FFGP_MULTI_MAX ? F - f0 : FFGP_MULTI_MAX;
+    AsmMulti q;
+    int gx = 1;
+    for (int z = 0; z < FFGP_MULTI_MAX; ++z) {
+      const int f = f0 + (z < cnt ? z : 0);
+      q.a[z] = c->a[f];
+      q.tiles[z] = c->tiles[f];
+      if (z < cnt) gx = max(gx, c->tiles[f]);
+    }
+    hipLaunchKernelGGL(ffgp_assemble_kernel_multi, dim3(gx, cnt), dim3(256), 0, h->stream, q);
+  }
+  c->a.clear();
+  c->tiles.clear();
+  if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
+  return FFGP_OK;
+}
+int ffgp_assemble_collect_begin(ffgp_handle* h) {
+  if (!h->asm_collect) h->asm_collect = new AsmCollector();
+  static_cast<AsmCollector*>(h->asm_collect)->a.clear();
+  static_cast<AsmCollector*>(h->asm_collect)->tiles.clear();
+  h->asm_collecting = 1;
+  return FFGP_OK;
+}
+void ffgp_assemble_collect_free(ffgp_handle* h) {
+  delete static_cast<AsmCollector*>(h->asm_collect);
+  h->asm_collect = nullptr;
+}
+int ffgp_assemble_collect_end(ffgp_handle* h) {
+  h->asm_collecting = 0;
+  return ffgp_assemble_flush(h);
+}
+
 // ------------------------------------------------------------------------------------------------------------------------------
 // Interior tiles of the squared-exponential profile on the matrix cores (round 3).  The vector pipe is what bounds the
 // difference form (32 fp64 instructions per entry at D = 16 before the exp even starts), so for 64 x 64 tiles that lie wholly
@@ -514,6 +588,47 @@ int ffgp_transpose(ffgp_handle* h, const double* src, int rows, int cols, int ld
   return FFGP_OK;
 }
 
+// up to FFGP_MULTI_MAX independent transposes per launch (the targets of a shared-chain batch's members)
+__global__ __launch_bounds__(256) void ffgp_transpose_multi_kernel(ffgp_multi_tr q) {
+  const int z = blockIdx.z;
+  const int rows = q.rows[z], cols = q.cols[z];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  if (bx >= cols || by >= rows) return;
+  const double* __restrict__ src = q.src[z];
+  double* __restrict__ dst = q.dst[z];
+  const int lds_ = q.lds[z], ldd = q.ldd[z];
+  __shared__ double t[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = by + i, c = bx + tx;
+    t[i][tx] = (r < rows && c < cols) ? src[(size_t)r * lds_ + c] : 0.0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = bx + i, r = by + tx;
+    if (c < cols && r < rows) dst[(size_t)c * ldd + r] = t[tx][i];
+  }
+}
+
+int ffgp_transpose_multi(ffgp_handle* h, int F, const double* const* src, const int* rows, const int* cols, const int* ld_src,
+                         double* const* dst, const int* ld_dst) {
+  for (int f0 = 0; f0 < F; f0 += FFGP_MULTI_MAX) {
+    const int cnt = F - f0 < FFGP_MULTI_MAX ? F - f0 : FFGP_MULTI_MAX;
+    ffgp_multi_tr q;
+    int gx = 1, gy = 1;
+    for (int z = 0; z < FFGP_MULTI_MAX; ++z) {
+      const int f = f0 + (z < cnt ? z : 0);
+      q.src[z] = src[f]; q.dst[z] = dst[f]; q.rows[z] = rows[f]; q.cols[z] = cols[f]; q.lds[z] = ld_src[f]; q.ldd[z] = ld_dst[f];
+      if (z < cnt) {
+        gx = max(gx, (cols[f] + 31) / 32);
+        gy = max(gy, (rows[f] + 31) / 32);
+      }
+    }
+    hipLaunchKernelGGL(ffgp_transpose_multi_kernel, dim3(gx, gy, cnt), dim3(256), 0, h->stream, q);
+  }
+  return FFGP_OK;
+}
+
 int ffgp_assemble_impl(ffgp_handle* h, const double* X1, int n1, const double* X2, int n2, int D, const double* w,
                        const double* amp, double clamp_min, const double* diag_add, const double* diag_vec,
                        long diag_stride, const double* add_mat, int ld_add, double add_all, double mean_jitter, double* K,
@@ -579,6 +694,11 @@ int ffgp_assemble_impl(ffgp_handle* h, const double* X1, int n1, const double* X
     else hipLaunchKernelGGL(ffgp_assemble_mm_kernel<false>, dim3(grid), dim3(256), 0, h->stream, a, m);
     hipLaunchKernelGGL(ffgp_assemble_fix_kernel, dim3(tm * ASM_FIX_S), dim3(256), 0, h->stream, a, m.flags,
                        (n1 % AT != 0 || n2 % AT != 0) ? 1 : 0);
+  } else if (h->asm_collecting && !a.ksum && tiles <= 1024) {
+    // a member of a batch of small blocks: parked, launched together with the other members' (ffgp_assemble_flush)
+    AsmCollector* c = static_cast<AsmCollector*>(h->asm_collect);
+    c->a.push_back(a);
+    c->tiles.push_back(tiles);
   } else {
     hipLaunchKernelGGL(ffgp_assemble_kernel, dim3(tiles), dim3(256), 0, h->stream, a);
   }

@@ -198,6 +198,9 @@ struct ffgp_handle {
   int ob_F;
   int ob_n;
   struct { const double* lo; const double* hi; long stride; } ob_rng[6];
+  void* asm_collect;    // AsmCollector (assemble.hip): assemblies of a batch's small members parked for one multi-member launch
+  int asm_collecting;
+  int defer_info_copy;  // ffgp_train_raw's loop: the enqueue paths skip their per-call read-back of the status word
   double* train_g;      // ffgp_train_raw: gradients of the raw parameters [MAXF x GSTRIDE] + the step's losses [MAXF]
   int* bt_info;         // [F] device status words (first non-positive pivot of each block)
   int* bt_info_host;    // pinned mirror
@@ -260,6 +263,32 @@ enum { ALIAS_NONE = 0, ALIAS_A = 1, ALIAS_B = 2 };
 int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, const double* A, int lda, const double* B,
                      int ldb, double* C, int ldc, int m, int n, int k, double alpha, double beta, int tri = 0,
                      int alias = ALIAS_NONE, int batch = 1, long sA = 0, long sB = 0, long sC = 0);
+// several independent tiny launches of one kind as ONE launch (the per-member stages around a shared-chain batch)
+#define FFGP_MULTI_MAX 8
+struct ffgp_multi_red {
+  const double* M[FFGP_MULTI_MAX];
+  const double* L[FFGP_MULTI_MAX];
+  double* out[FFGP_MULTI_MAX];
+  double pi_const[FFGP_MULTI_MAX], scale[FFGP_MULTI_MAX];
+  int rows[FFGP_MULTI_MAX], cols[FFGP_MULTI_MAX], ldm[FFGP_MULTI_MAX], n[FFGP_MULTI_MAX], ldl[FFGP_MULTI_MAX], d[FFGP_MULTI_MAX],
+      blocks[FFGP_MULTI_MAX];
+  int first;
+};
+struct ffgp_multi_tr {
+  const double* src[FFGP_MULTI_MAX];
+  double* dst[FFGP_MULTI_MAX];
+  int rows[FFGP_MULTI_MAX], cols[FFGP_MULTI_MAX], lds[FFGP_MULTI_MAX], ldd[FFGP_MULTI_MAX];
+};
+#define FFGP_RED_BLOCKS 512
+int ffgp_nll_reduce_multi(ffgp_handle* h, int F, const double* const* L, const int* n, const int* ldl, const double* const* M,
+                          const int* rows, const int* cols, const int* ldm, const int* d, const double* pi_const, const double* scale,
+                          double* const* out, double* partial_ws);
+int ffgp_assemble_collect_begin(ffgp_handle* h);
+int ffgp_assemble_collect_end(ffgp_handle* h);
+void ffgp_assemble_collect_free(ffgp_handle* h);
+int ffgp_transpose_multi(ffgp_handle* h, int F, const double* const* src, const int* rows, const int* cols, const int* ld_src,
+                         double* const* dst, const int* ld_dst);
+
 // K-steps-per-call training (ffgp_train_raw): the raw parameter storages of up to FFGP_TRAIN_MAXF models, by value to the Adam kernel
 #define FFGP_TRAIN_MAXF 16
 #define FFGP_TRAIN_GSTRIDE 160       // doubles per model in the gradient buffer: raw w (<= 128) | amp | diag_add

@@ -396,6 +396,94 @@ __global__ __launch_bounds__(256) void ffgp_reduce_stage2(const double* __restri
   }
 }
 
+// the same two stages for up to FFGP_MULTI_MAX independent problems per launch (the members of a shared-chain batch: F x 2 tiny
+// launches otherwise); every member keeps its own block count, so its sums are grouped exactly as in its single call
+__global__ __launch_bounds__(256) void ffgp_reduce_stage1_multi(ffgp_multi_red q, double* __restrict__ partial_all) {
+  const int z = blockIdx.y, nb = q.blocks[z];
+  if ((int)blockIdx.x >= nb) return;
+  const double* __restrict__ M = q.M[z];
+  const double* __restrict__ L = q.L[z];
+  const int rows = q.rows[z], cols = q.cols[z], ldm = q.ldm[z], n = q.n[z], ldl = q.ldl[z];
+  double* __restrict__ partial = partial_all + (size_t)(q.first + z) * 2 * RED_BLOCKS;
+  __shared__ double r1[4], r2[4];
+  double ss = 0.0, lg = 0.0;
+  const long total = (long)rows * cols;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)nb * 256) {
+    const long r = e / cols, c = e - r * cols;
+    const double v = M[r * ldm + c];
+    ss = __builtin_fma(v, v, ss);
+  }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += nb * 256) lg += log(L[(size_t)i * ldl + i]);
+  for (int o = 32; o > 0; o >>= 1) {
+    ss += __shfl_down(ss, o);
+    lg += __shfl_down(lg, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    r1[threadIdx.x >> 6] = ss;
+    r2[threadIdx.x >> 6] = lg;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = r1[0] + r1[1] + r1[2] + r1[3];
+    partial[RED_BLOCKS + blockIdx.x] = r2[0] + r2[1] + r2[2] + r2[3];
+  }
+}
+
+__global__ __launch_bounds__(256) void ffgp_reduce_stage2_multi(ffgp_multi_red q, const double* __restrict__ partial_all) {
+  const int z = blockIdx.x;
+  const double* __restrict__ partial = partial_all + (size_t)(q.first + z) * 2 * RED_BLOCKS;
+  const int nblocks = q.blocks[z];
+  __shared__ double r1[4], r2[4];
+  double ss = 0.0, lg = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) {
+    ss += partial[i];
+    lg += partial[RED_BLOCKS + i];
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    ss += __shfl_down(ss, o);
+    lg += __shfl_down(lg, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    r1[threadIdx.x >> 6] = ss;
+    r2[threadIdx.x >> 6] = lg;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ss = r1[0] + r1[1] + r1[2] + r1[3];
+    lg = r2[0] + r2[1] + r2[2] + r2[3];
+    double v = 0.5 * ss + (double)q.d[z] * lg + 0.5 * (double)q.n[z] * (double)q.d[z] * log(2.0 * q.pi_const[z]);
+    if (q.scale[z] != 1.0) v *= q.scale[z];      // (the output scale of the raw-parameter calls, a separate launch in the single call)
+    q.out[z][0] = v;
+  }
+}
+
+// partial_ws: F x 2 x RED_BLOCKS doubles; scale[f] multiplies member f's value (1.0: none)
+int ffgp_nll_reduce_multi(ffgp_handle* h, int F, const double* const* L, const int* n, const int* ldl, const double* const* M,
+                          const int* rows, const int* cols, const int* ldm, const int* d, const double* pi_const, const double* scale,
+                          double* const* out, double* partial_ws) {
+  for (int f0 = 0; f0 < F; f0 += FFGP_MULTI_MAX) {
+    const int cnt = F - f0 < FFGP_MULTI_MAX ? F - f0 : FFGP_MULTI_MAX;
+    ffgp_multi_red q;
+    q.first = f0;
+    int maxb = 1;
+    for (int z = 0; z < FFGP_MULTI_MAX; ++z) {
+      const int f = f0 + (z < cnt ? z : 0);
+      long total = (long)rows[f] * cols[f];
+      int blocks = (int)((total + 255) / 256);
+      if (blocks > RED_BLOCKS) blocks = RED_BLOCKS;
+      if (blocks < 1) blocks = 1;
+      q.M[z] = M[f]; q.L[z] = L[f]; q.rows[z] = rows[f]; q.cols[z] = cols[f]; q.ldm[z] = ldm[f]; q.n[z] = n[f]; q.ldl[z] = ldl[f];
+      q.d[z] = d[f]; q.pi_const[z] = pi_const[f]; q.scale[z] = scale ? scale[f] : 1.0; q.out[z] = out[f];
+      q.blocks[z] = blocks;
+      if (z < cnt && blocks > maxb) maxb = blocks;
+    }
+    hipLaunchKernelGGL(ffgp_reduce_stage1_multi, dim3(maxb, cnt), dim3(256), 0, h->stream, q, partial_ws);
+    hipLaunchKernelGGL(ffgp_reduce_stage2_multi, dim3(cnt), dim3(256), 0, h->stream, q, partial_ws);
+  }
+  if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
+  return FFGP_OK;
+}
+
 int ffgp_nll_reduce_impl(ffgp_handle* h, int variant, const double* L, int n, int ldl, const double* M, int rows, int cols,
                          int ldm, int d, double pi_const, double* out_dev) {
   if (!L || !M || !out_dev) return FFGP_ERR_ARG;

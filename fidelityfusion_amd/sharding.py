@@ -82,9 +82,10 @@ def hip_block_evaluator(device=None):
 
 
 def hip_blocks_evaluator_concurrent(device=None, nslots=2):
-    """Evaluates a LIST of owned blocks together: blocks of one shape share ONE factorisation chain
-    (cigp_v10.negative_log_likelihood_many -> ffgp_nlml_fused_batch); blocks of different shapes overlap on the GPU through streams
-    (functional.concurrent_blocks: one block's latency-bound panel chain runs under another block's trailing updates)."""
+    """Evaluates a LIST of owned blocks together: they share ONE factorisation chain (cigp_v10.negative_log_likelihood_many ->
+    ffgp_nlml_fused_batch; blocks of different sizes up to 12288 rows: the ragged chain, a member leaves it when its columns are used
+    up); sets the chain does not take (a member above 12288 rows beside a different one, small and large members mixed) overlap on the
+    GPU through streams (functional.concurrent_blocks: one block's latency-bound panel chain runs under another's trailing updates)."""
     from . import functional as F
     from . import kernel
     from .cigp_v10 import cigp
@@ -166,6 +167,22 @@ class ShardedTrainer:
         vec = torch.zeros(self.F, dtype=torch.float64, device=dev)
         losses = {}
         on_gpu = torch.cuda.is_available() and len(self.models) > 1 and self.concurrent
+        if on_gpu and self._chainable():
+            # the rank's blocks share ONE factorisation chain (cigp_v10.negative_log_likelihood_many -> ffgp_nlml_fused_batch; blocks of
+            # different sizes: the ragged chain) -- forward and the gradient stages; one backward for the independent blocks' sum
+            from .cigp_v10 import negative_log_likelihood_many
+            order = list(self.models)
+            for f in order:
+                self.opts[f].zero_grad()
+            vals = negative_log_likelihood_many([self.models[f] for f in order], [self.data[f][0] for f in order],
+                                                [self.data[f][1] for f in order])
+            (-vals).sum().backward()
+            for i, f in enumerate(order):
+                self.opts[f].step()
+                vec[f] = -vals[i].detach().to(dev)
+            if _has_group():
+                dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.group)
+            return vec
         if on_gpu:   # owned blocks overlap on the GPU; gradients were produced by the same fused calls
             from . import functional as F
             with F.concurrent_blocks(nslots=min(self.nslots, len(self.models)), lookahead=self.slot_lookahead) as cb:
@@ -184,6 +201,20 @@ class ShardedTrainer:
         if _has_group():
             dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.group)
         return vec
+
+    def _chainable(self):
+        """the owned models are `cigp` modules on one GPU in fp64 whose shapes share a factorisation chain"""
+        from . import functional as F
+        ms = list(self.models.values())
+        if not all(hasattr(m, "kernel") and hasattr(m, "log_beta") for m in ms):
+            return False
+        shapes = []
+        for f, m in self.models.items():
+            x, y = self.data[f]
+            if isinstance(y, list) or not isinstance(x, torch.Tensor) or not x.is_cuda or F.raw_many_ok(m.kernel, x, y, m.log_beta) is None:
+                return False
+            shapes.append((x.shape[0], y.shape[1]))
+        return F.many_batchable(shapes) and all(n > F.SMALL_BATCH_MAX_N for n, _ in shapes)
 
     def gather_posteriors(self, x_test):
         """all-gather of the per-fidelity posterior means / variances at x_test (each rank computes its own

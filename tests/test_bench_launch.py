@@ -33,6 +33,9 @@ def test_self_launch_two_ranks_weak_and_sharded_legs():
     out = _run("--gpus", "2", "--n", "96")
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["blocks"] == 2
     assert out["collective"] == {"backend": "gloo", "ranks": 2}
+    # every rank of a multi-rank run pins itself to its own slice of the host's CPUs before it touches the GPU (bench.pin_rank)
+    aff = out["cpu_affinity"]
+    assert aff is None or (aff["rank0_cpus"] >= 1 and aff["first"] <= aff["last"])
     for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data",
                 "roofline"):
         assert key in out
@@ -119,3 +122,51 @@ def test_importing_the_package_leaves_the_environment_alone():
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
     assert p.returncode == 0 and "ok" in p.stdout, p.stderr[-1500:]
     assert "GPU_MAX_HW_QUEUES=8 set for this process" in p.stderr
+
+
+def test_pin_rank_gives_disjoint_slices():
+    """bench.pin_rank: ranks that share a pool of CPUs get disjoint, non-empty slices; FFGP_BENCH_AFFINITY=0 leaves the mask alone"""
+    sys.path.insert(0, ROOT)
+    code = (
+        "import os, sys, json; sys.path.insert(0, %r); import bench\n"
+        "before = sorted(os.sched_getaffinity(0))\n"
+        "mine = bench.pin_rank(int(sys.argv[1]), 2)\n"
+        "print(json.dumps({'before': before, 'mine': mine, 'now': sorted(os.sched_getaffinity(0))}))\n" % ROOT)
+    outs = []
+    for r in (0, 1):
+        p = subprocess.run([sys.executable, "-c", code, str(r)], capture_output=True, text=True, timeout=60)
+        assert p.returncode == 0, p.stderr
+        outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    if len(outs[0]["before"]) >= 2:
+        assert outs[0]["mine"] and outs[1]["mine"] and not set(outs[0]["mine"]) & set(outs[1]["mine"])
+        assert outs[0]["now"] == outs[0]["mine"]
+    env = dict(os.environ, FFGP_BENCH_AFFINITY="0")
+    p = subprocess.run([sys.executable, "-c", code, "0"], capture_output=True, text=True, timeout=60, env=env)
+    o = json.loads(p.stdout.strip().splitlines()[-1])
+    assert o["mine"] is None and o["now"] == o["before"]
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_roofline_flops_count_every_block_of_a_shared_chain():
+    """the trailing-update statistics behind `roofline.achieved` must count all F blocks a shared-chain launch covers: the same
+    workload with one block (single call) and with four (one chain) reports the same launches per step and four times the flops"""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+    def run(blocks):
+        env = dict(os.environ)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cigar4", "--blocks", str(blocks), "--steps", "2",
+                            "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    one, four = run(1), run(4)
+    r1, r4 = one["roofline"], four["roofline"]
+    assert r1["launches"] == r4["launches"] > 0
+    assert abs(r4["avg_launch_gflop"] - 4.0 * r1["avg_launch_gflop"]) <= 1e-3 * r4["avg_launch_gflop"]     # (the line rounds to 3 decimals)
+    assert 0.2 < r4["frac"] < 1.0

@@ -2465,6 +2465,48 @@ def test_c5_block_full_size_properties():
     assert abs(fd_dadd - float(dadd.grad)) <= 1e-6 * abs(float(dadd.grad))
 
 
+@pytest.mark.noisy
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("F_,d,with_grad", [(4, 1024, True), (2, 4096, False)])
+def test_full_size_blocks_share_one_chain(F_, d, with_grad):
+    """the path bench.py runs for BASELINE configs[3] / [4] on one rank -- functional.nlml_many: the rank's blocks of N = 8192
+    (d = 1024: `cigar4`; d = 4096: `gar8`) as ONE factorisation chain -- against the single-block calls the other full-size tests
+    hold to the oracle: values torch.equal, and for the d = 1024 set every gradient (Y, w, amp, diag_add) as well"""
+    from fidelityfusion_amd import functional as F
+    n, D = 8192, 8
+    gen = torch.Generator(device=DEV).manual_seed(77 + d)
+    Xs, Ys, ws, amps, dadds = [], [], [], [], []
+    for f in range(F_):
+        X = torch.rand((n, D), generator=gen, device=DEV, dtype=torch.float64)
+        Wm = torch.rand((D, d), generator=gen, device=DEV, dtype=torch.float64)
+        Y = torch.sin(2.0 * np.pi * (X @ Wm)) + 0.1 * torch.randn((n, d), generator=gen, device=DEV, dtype=torch.float64)
+        Y = (Y - Y.mean()) / Y.std()
+        Xs.append(X)
+        Ys.append(Y.requires_grad_(with_grad))
+        ws.append(T(np.full(D, 0.9 + 0.05 * f), grad=with_grad))
+        amps.append(T([1.0 + 0.1 * f], grad=with_grad))
+        dadds.append(T([np.exp(-1.0) + 1e-6], grad=with_grad))
+    ctx = torch.enable_grad() if with_grad else torch.no_grad()
+    with ctx:
+        vals = F.nlml_many(Xs, Ys, ws, amps, dadds, clamp=1e-30)
+        if with_grad:
+            vals.sum().backward()
+    got = vals.detach().clone()
+    grads = [[t.grad.clone() for t in (Ys[f], ws[f], amps[f], dadds[f])] for f in range(F_)] if with_grad else None
+    assert torch.isfinite(got).all()
+    for f in range(F_):
+        for t in (Ys[f], ws[f], amps[f], dadds[f]):
+            t.grad = None
+        with ctx:
+            v = F.nlml(Xs[f], Ys[f], ws[f], amps[f], diag_add=dadds[f], clamp=1e-30)
+            if with_grad:
+                v.backward()
+        assert torch.equal(got[f], v.detach()), (f, float(got[f]), float(v))
+        if with_grad:
+            for a, t in zip(grads[f], (Ys[f], ws[f], amps[f], dadds[f])):
+                assert torch.equal(a, t.grad), f
+
+
 def test_train_log_resgp_known_answers(golden):
     """The reference's own committed log (FidelityFusion_Models/log/ResGP/train.log:201,401 -- the only known answers it
     ships for this path): fidelity 0 of the ResGP demo (N = 300, SE kernel, fp32 defaults, Adam lr 1e-2), 199 and 200 steps of
