@@ -178,12 +178,14 @@ static int create_resources(ffgp_handle* h) {
   return FFGP_OK;
 }
 
-static int ensure_aux2(ffgp_handle* h) {
+int ffgp_ensure_aux2(ffgp_handle* h) {
   if (h->aux2) return FFGP_OK;
   FFGP_HIP(hipStreamCreateWithFlags(&h->aux2, hipStreamNonBlocking));
+  FFGP_HIP(hipStreamCreateWithFlags(&h->aux3, hipStreamNonBlocking));
   for (int i = 0; i < 2; ++i) FFGP_HIP(hipEventCreateWithFlags(&h->tri_ev[i], hipEventDisableTiming));
   return FFGP_OK;
 }
+static int ensure_aux2(ffgp_handle* h) { return ffgp_ensure_aux2(h); }
 
 // ROCm binds a stream to one of its hardware queues at the stream's first USE, streams on one queue run in order, and a stream that
 // first appears late shares a queue with whatever is least loaded then.  The handle's third stream (head of the triangular inverse under
@@ -197,8 +199,10 @@ extern "C" int ffgp_prepare_streams(ffgp_handle* h) {
   FFGP_CHECK(ensure_aux2(h));
   FFGP_HIP(hipMemsetAsync(h->d_info + 8, 0, sizeof(int), h->aux));
   FFGP_HIP(hipMemsetAsync(h->d_info + 9, 0, sizeof(int), h->aux2));
+  FFGP_HIP(hipMemsetAsync(h->d_info + 10, 0, sizeof(int), h->aux3));
   FFGP_HIP(hipStreamSynchronize(h->aux));
   FFGP_HIP(hipStreamSynchronize(h->aux2));
+  FFGP_HIP(hipStreamSynchronize(h->aux3));
   return FFGP_OK;
 }
 
@@ -227,6 +231,8 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->la_split = 1;
   h->la_carry = 2;
   h->la_min_n = 3584;
+  h->pass_split_min = 0;        // (measured and lost, docs/experiments.md: 0 = the passenger rows ride in the chain's launches)
+  h->tail_mask_cus = 8;
   h->aux_prio = 1;
   h->nb_outer = 512;
   h->diag_v2 = 4;
@@ -261,6 +267,8 @@ int ffgp_destroy(ffgp_handle* h) {
   if (h->ews) hipFree(h->ews);
   if (h->d_link) hipFree(h->d_link);
   if (h->aux2) hipStreamDestroy(h->aux2);
+  if (h->aux3) hipStreamDestroy(h->aux3);
+  if (h->masked) hipStreamDestroy(h->masked);
   if (h->ev_switch) hipEventDestroy(h->ev_switch);
   for (int i = 0; i < 4; ++i)
     if (h->sb_ev[i]) hipEventDestroy(h->sb_ev[i]);
@@ -357,6 +365,20 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->la_split = (int)value;
   } else if (!strcmp(key, "la_min_n")) {
     h->la_min_n = (int)value;
+  } else if (!strcmp(key, "syrk_h64")) {
+    h->syrk_h64 = (int)value;
+  } else if (!strcmp(key, "tail_mask_m")) {
+    h->tail_mask_m = (int)value;
+  } else if (!strcmp(key, "tail_mask_cus")) {
+    if (value < 1 || value > 31) return FFGP_ERR_ARG;
+    if ((int)value != h->tail_mask_cus && h->masked) {      // another mask: the stream is rebuilt at its next use
+      hipStreamSynchronize(h->masked);
+      hipStreamDestroy(h->masked);
+      h->masked = nullptr;
+    }
+    h->tail_mask_cus = (int)value;
+  } else if (!strcmp(key, "pass_split_min")) {
+    h->pass_split_min = (int)value;
   } else if (!strcmp(key, "la_carry")) {
     h->la_carry = (int)value;
   } else if (!strcmp(key, "lookahead")) {

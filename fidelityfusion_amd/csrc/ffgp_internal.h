@@ -185,6 +185,11 @@ struct ffgp_handle {
   double* ews;       // workspace of the symmetric eigensolver (syevd.hip)
   size_t ews_bytes;
   hipEvent_t eig_ev[12];   // hand-offs between the chase (side stream) and the back-transformation (main stream) of ffgp_syevd
+  hipStream_t masked;   // CU-masked stream for the trailing updates of the chain-bound tail (tail_mask_m > 0)
+  int masked_failed, tail_mask_m, tail_mask_cus;
+  int syrk_h64;         // experiment: trailing update on 128 x 64 half tiles, three workgroups per CU
+  hipStream_t aux3;     // fourth stream: the passenger rows of a look-ahead factorisation, one panel behind the chain (ffgp_potrf_impl)
+  int pass_split_min;   // passenger rows (right-hand sides riding in the factorisation) from this many on leave the chain's launches; 0 = never
   hipStream_t aux2;     // third stream: the head of the triangular inverse under the factorisation's tail (nlml_fused_enqueue)
   hipEvent_t tri_ev[2]; // [0] factor columns < tri_hook_col are final (recorded by ffgp_potrf_impl on the side stream); [1] head done
   int tri_hook_col, tri_hook_fired;
@@ -307,6 +312,7 @@ struct ffgp_rag_block {
   double* dinv;
   int info_index;
 };
+extern "C" int ffgp_ensure_aux2(ffgp_handle* h);
 int ffgp_potrf_ragged(ffgp_handle* h, int R, const ffgp_rag_block* mem);
 // ragged form of the chain's K-major products: R members of one kind with their own sizes / operands (see gemm.hip)
 int ffgp_gemm_launch_rag(ffgp_handle* h, int mode, int syrk_tag, int R, const GemmRagIn* in, double alpha, double beta, int alias);

@@ -398,7 +398,7 @@ __device__ __forceinline__ void gemm_one_tile(const GemmArgs& p, const double* _
     const size_t stepB = (OPB == OP_KMAJOR) ? (size_t)BK * 8 : (size_t)BK * p.ldb * 8;
     char* bC = reinterpret_cast<char*>(Cg) + ((size_t)m0 * p.ldc + n0) * 8;
     const size_t row4 = (size_t)p.ldc * 32;   // 4 rows of C
-    constexpr int PD = (TM == 128 && TN == 128) ? 1 : FFGP_PD_SMALL;
+    constexpr int PD = (TM == 128) ? 1 : FFGP_PD_SMALL;      // (128-row tiles are throughput shapes: 128 x 128, and 128 x 64 below)
     unsigned voffA[Geo<TM>::NLD], voffB[Geo<TN>::NLD];   // per-lane byte offsets (a dozen VALU ops per tile)
     lane_byte_offsets<OPA, TM>(p.lda, tid, voffA);
     lane_byte_offsets<OPB, TN>(p.ldb, tid, voffB);
@@ -526,6 +526,33 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
   const double* __restrict__ Bg = p.B + (size_t)blockIdx.y * p.sB + (size_t)blockIdx.z * p.sB2;
   double* __restrict__ Cg = p.C + (size_t)blockIdx.y * p.sC + (size_t)blockIdx.z * p.sC2;
   gemm_block<OPA, OPB, MODE, TM, TN>(p, Ag, Bg, Cg, smem, tid, blockIdx.x);
+}
+
+// Half-width throughput tiles (option syrk_h64; experiment of round 5): every 128 x 128 tile of the trailing update as two 128 x 64
+// workgroups with 64 accumulator registers per lane, so that THREE workgroups fit a CU (the 128 x 128 tile's 232 registers allow
+// two: while one of them is in its prologue -- C tile and first operand tiles in flight, 8 % of a K = 512 tile's life -- the
+// other has the matrix pipe to itself and drives it at ~70 %).  The two halves of a tile are blocks b and b + 8 (one XCD: they
+// share the A panel in that L2); tile order and XCD chunks as in gemm_block, on the index of the 128 x 128 tile.
+template <int OPA, int OPB, int MODE, int TAG>
+__global__ __launch_bounds__(256, 3) void ffgp_gemm_f64_h64(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) double smem[2 * (opbuf<OPA, 128>() + opbuf<OPB, 64>())];
+  const int tid = threadIdx.x;
+  const double* __restrict__ Ag = p.A + (size_t)blockIdx.y * p.sA;
+  const double* __restrict__ Bg = p.B + (size_t)blockIdx.y * p.sB;
+  double* __restrict__ Cg = p.C + (size_t)blockIdx.y * p.sC;
+  const int bid = blockIdx.x;
+  const int half = (bid >> 3) & 1;
+  const int mt = ((bid >> 4) << 3) | (bid & 7);
+  if (mt >= p.total_tiles) return;
+  const int nwg = p.total_tiles;
+  const int q = nwg >> 3, r = nwg & 7, xcd = mt & 7;
+  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (mt >> 3);
+  int ti, tj;
+  decode_tile(t, MODE, p.tiles_m, p.tiles_n, ti, tj, p.band_log2);
+  ti = __builtin_amdgcn_readfirstlane(ti);
+  tj = __builtin_amdgcn_readfirstlane(2 * tj + half);
+  if (tj * 64 >= p.n) return;
+  gemm_one_tile<OPA, OPB, MODE, 128, 64>(p, Ag, Bg, Cg, smem, ti, tj, tid, bid);
 }
 
 // Ragged launch (the shared factorisation chain of blocks of DIFFERENT sizes, ffgp_potrf_ragged): gridDim.y members, each with its
@@ -809,7 +836,8 @@ static int gemm_plan(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   // Split tail (see ffgp_gemm_f64): with T equal tiles on 256 CUs the last (T mod 256) tiles run on otherwise idle CUs for a
   // whole tile time; when that remainder is small, hand it out as 64 x 64 quarters -- 4x the workgroups, a quarter of the
   // chain each -- which start under the last full round.  (An in-place or batched launch never splits.)
-  if (tsm == 128 && tsn == 128 && alias == 0 && dec_batch == 1 && h->force_ts == 0 && h->split_rem_max > 0 && a.total_tiles > 256) {
+  if (tsm == 128 && tsn == 128 && alias == 0 && dec_batch == 1 && h->force_ts == 0 && h->split_rem_max > 0 && a.total_tiles > 256 &&
+      !(syrk_tag && h->syrk_h64)) {
     const int rem = a.total_tiles % 256;
     if (rem > 0 && rem <= h->split_rem_max) {
       a.split_at = a.total_tiles - rem;
@@ -988,7 +1016,12 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   else if (tsm == 32)
     rc = (mode == TILES_LOWER) ? launch_t<OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 0, 32, 32>(h, a)
                                : launch_t<OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, 32, 32>(h, a);
-  else if (tsm == 128)
+  else if (tsm == 128 && syrk_tag && h->syrk_h64 && a.split_at == 0x7fffffff && a.pad_lds == 0 && !ob) {
+    // (experiment: the trailing update on 128 x 64 half tiles, three workgroups per CU)
+    const int gx = ((a.total_tiles + 7) / 8) * 16;
+    hipLaunchKernelGGL((ffgp_gemm_f64_h64<OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1>), dim3(gx, a.batch), dim3(256), 0, h->stream, a);
+    rc = FFGP_OK;
+  } else if (tsm == 128)
     rc = dispatch<128>(h, opa, opb, mode, syrk_tag, a);
   else
     rc = dispatch<64>(h, opa, opb, mode, syrk_tag, a);

@@ -1414,6 +1414,28 @@ static int factor_panel(ffgp_handle* h, double* A, int n, int mtot, int lda, int
   return FFGP_OK;
 }
 
+// the handle's CU-masked stream (tail_mask_m): every CU except the first tail_mask_cus of each XCD.  Mask bit i <-> XCD i % 8, CU
+// i / 8 of that XCD (tools/native/cumask_probe.hip); a mask that leaves an XCD empty is ignored by the runtime.
+int ffgp_ensure_masked(ffgp_handle* h) {
+  if (h->masked) return FFGP_OK;
+  if (h->masked_failed) return FFGP_ERR_HIP;
+  uint32_t mask[8];
+  for (int i = 0; i < 8; ++i) mask[i] = 0xffffffffu;
+  const int cut = h->tail_mask_cus > 0 && h->tail_mask_cus < 32 ? h->tail_mask_cus : 8;
+  for (int x = 0; x < 8; ++x)
+    for (int c = 0; c < cut; ++c) {
+      const int bit = c * 8 + x;
+      mask[bit / 32] &= ~(1u << (bit % 32));
+    }
+  if (hipExtStreamCreateWithCUMask(&h->masked, 8, mask) != hipSuccess) {
+    (void)hipGetLastError();
+    h->masked = nullptr;
+    h->masked_failed = 1;
+    return FFGP_ERR_HIP;
+  }
+  return FFGP_OK;
+}
+
 // Factor the leading n x n block of A in place; rows n..mtot-1 (if any) are "passenger" rows that receive the
 // same right-hand transformations and come out as  A[n:, :] * L^-T  -- i.e. (L^-1 B)^T for B^T stored below
 // Sigma.  The fused NLML/predict paths put Y^T and K_*^T there, so the triangular solves ride inside the
@@ -1439,7 +1461,49 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
     // panel width at column k0: the wide block while more than nb_big_until columns remain (the SYRK's fixed per-tile
     // cost is amortised over a longer k loop where the chain still hides under it), nb_outer after that
     auto pw = [&](int k0) { return (h->nb_big > NB1 && n - k0 > h->nb_big_until) ? h->nb_big : NB1; };
-    if (!h->lookahead || n <= NB1 || n <= h->la_min_n) {
+    const bool in_order = !h->lookahead || n <= NB1 || n <= h->la_min_n;
+    // Passenger rows off the chain (round 5).  Riding in the chain's own launches, the right-hand sides made every TRSM and
+    // panel update of the dependency chain (n - j) + d rows tall: at N = 8192, d = 4096 a third of the chain's kernel time, on the
+    // latency tiles, while most of the chip idled in the chain-bound tail.  With many of them (>= pass_split_min) and a look-ahead
+    // form, the chain and the trailing updates cover the n x n matrix only, and the passenger rows follow ONE PANEL BEHIND on a
+    // stream of their own: per panel the same operations as before (per 128-column block the product with the inverted diagonal
+    // block and the update of the panel's remaining columns, then the K = panel-width update of the columns to the right), which
+    // read the panel's finished columns of L and write passenger rows only -- they fill the CUs the chain leaves idle.
+    const int npass = mtot - n;
+    const bool split_pass = !in_order && h->pass_split_min > 0 && npass >= h->pass_split_min;
+    const int mch = split_pass ? n : mtot;       // rows the chain's and the trailing updates' launches cover
+    hipEvent_t pass_done = nullptr;
+    if (split_pass) FFGP_CHECK(ffgp_ensure_aux2(h));
+    auto pass_panel = [&](int k0, int w1, hipEvent_t ready) -> int {
+      // `ready`: the panel's columns of L are final.  Runs on h->aux3; h->stream is restored by the caller's bookkeeping.
+      hipStream_t keep = h->stream;
+      FFGP_HIP(hipStreamWaitEvent(h->aux3, ready, 0));
+      h->stream = h->aux3;
+      int rc = FFGP_OK;
+      const int pend = k0 + w1;
+      double* Ap0 = A + (size_t)n * lda;           // first passenger row
+      for (int j0 = k0; j0 < pend && rc == FFGP_OK; j0 += NB) {
+        const int jb = min(NB, n - j0);
+        double* Ap = Ap0 + j0;
+        double* Dj = h->dinv + (size_t)(j0 / NB) * NB * NB;
+        rc = potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, Ap, lda, Dj, NB, Ap, lda, npass, jb, jb, 1.0, 0.0, 0, ALIAS_A, true);
+        const int wrem = pend - (j0 + jb);
+        if (rc == FFGP_OK && wrem > 0)
+          rc = potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, Ap, lda, A + (size_t)(j0 + jb) * lda + j0, lda, Ap0 + (j0 + jb), lda, npass,
+                          wrem, jb, -1.0, 1.0);
+      }
+      const int mt = n - pend;
+      if (rc == FFGP_OK && mt > 0)
+        rc = potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, Ap0 + k0, lda, A + (size_t)pend * lda + k0, lda, Ap0 + pend, lda, npass, mt, w1,
+                        -1.0, 1.0);
+      h->stream = keep;
+      if (rc == FFGP_OK) {
+        FFGP_HIP(hipEventRecord(h->la_ev[9], h->aux3));
+        pass_done = h->la_ev[9];
+      }
+      return rc;
+    };
+    if (in_order) {
       for (int k0 = 0; k0 < n; k0 += pw(k0)) {
         const int w1 = min(pw(k0), n - k0);
         const int pend = k0 + w1;  // end column of this outer panel
@@ -1462,39 +1526,54 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
       // are ordered: Z(k+2) <- S_ii(<= k-1), S_z(k) on the main stream, then chain k+1 (after S_z's event).
       hipStream_t main_s = h->stream;
       auto carry_of = [&](int pend_) { return min(NB, n - pend_); };   // columns of the next panel's first block (0 at the end)
-      FFGP_CHECK(factor_panel(h, A, n, mtot, lda, 0, min(pw(0), n), nullptr, max(0, carry_of(min(pw(0), n)))));
+      FFGP_CHECK(factor_panel(h, A, n, mch, lda, 0, min(pw(0), n), nullptr, max(0, carry_of(min(pw(0), n)))));
       FFGP_HIP(hipEventRecord(h->la_ev[6], main_s));
       FFGP_HIP(hipStreamWaitEvent(h->aux, h->la_ev[6], 0));
+      if (split_pass) FFGP_CHECK(pass_panel(0, min(pw(0), n), h->la_ev[6]));
       int it = 0;
       hipEvent_t eb_prev = nullptr;
+      // Chain-bound tail on a CU-masked stream (option tail_mask_m): once the trailing matrix has fewer rows than that, the trailing
+      // updates are issued to a stream that may not use tail_mask_cus CUs of every XCD -- those CUs stay free of trailing-update
+      // workgroups, so the chain's kernels (unmasked side stream) start at once and run undisturbed instead of waiting for slots and
+      // sharing SIMDs with the update's MFMA stream; the update loses a quarter of the chip where it has slack anyway.
+      hipStream_t syrk_s = main_s;
       for (int k0 = 0; k0 < n; k0 += pw(k0), ++it) {
         const int w1 = min(pw(k0), n - k0);
         const int pend = k0 + w1;
         const int mt = n - pend;
         if (mt <= 0) break;
+        if (h->tail_mask_m > 0 && mch - pend < h->tail_mask_m && syrk_s == main_s && ffgp_ensure_masked(h) == FFGP_OK) {
+          FFGP_HIP(hipEventRecord(h->la_ev[7], main_s));
+          FFGP_HIP(hipStreamWaitEvent(h->masked, h->la_ev[7], 0));
+          syrk_s = h->masked;
+        }
         const int wn = min(pw(pend), mt);  // width of the next panel
         const int q = pend + wn;           // first column of panel k+2
         const int wz = max(0, min(NB, n - q));
         hipEvent_t eb = h->la_ev[(it & 1) * 3], eg = h->la_ev[(it & 1) * 3 + 1];
         const int wa = min(NB, wn);        // Z(k+1): already complete (carried by panel k)
         // main stream, once panel k is complete: S_b(k) and S_z(k) are neighbours (columns pend+wa .. q+wz): one launch, one event
-        if (eb_prev) FFGP_HIP(hipStreamWaitEvent(main_s, eb_prev, 0));
+        if (eb_prev) FFGP_HIP(hipStreamWaitEvent(syrk_s, eb_prev, 0));
         hipEvent_t gate = nullptr, gate2 = nullptr;
         if (wn - wa + wz > 0) {
           double* Pb = A + (size_t)(pend + wa) * lda + k0;
           double* Cb = A + (size_t)(pend + wa) * lda + (pend + wa);
-          FFGP_CHECK(potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, Pb, lda, Pb, lda, Cb, lda, mtot - pend - wa,
-                                      wn - wa + wz, w1, -1.0, 1.0));
-          FFGP_HIP(hipEventRecord(eg, main_s));
+          h->stream = syrk_s;
+          const int brc = potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, Pb, lda, Pb, lda, Cb, lda, mch - pend - wa,
+                                     wn - wa + wz, w1, -1.0, 1.0);
+          h->stream = main_s;
+          FFGP_CHECK(brc);
+          FFGP_HIP(hipEventRecord(eg, syrk_s));
           gate = eg;
         }
         // side stream: panel k+1, carrying Z(k+2)
         h->stream = h->aux;
-        int rc = factor_panel(h, A, n, mtot, lda, pend, wn, gate, wz, gate2);
+        int rc = factor_panel(h, A, n, mch, lda, pend, wn, gate, wz, gate2);
         h->stream = main_s;
         FFGP_CHECK(rc);
         FFGP_HIP(hipEventRecord(eb, h->aux));
         eb_prev = eb;
+        if (split_pass) FFGP_CHECK(pass_panel(pend, wn, eb));
         if (h->tri_hook_col > 0 && pend + wn == h->tri_hook_col) {   // the factor's columns < tri_hook_col are final from here on
           FFGP_HIP(hipEventRecord(h->tri_ev[0], h->aux));
           h->tri_hook_fired = 1;
@@ -1504,11 +1583,18 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
         if (mt2 > 0) {
           double* P2 = A + (size_t)(q + wz) * lda + k0;
           double* C2 = A + (size_t)(q + wz) * lda + (q + wz);
-          FFGP_CHECK(potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P2, lda, P2, lda, C2, lda, mtot - q - wz, mt2, w1, -1.0,
-                                      1.0));
+          h->stream = syrk_s;
+          const int irc = potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P2, lda, P2, lda, C2, lda, mch - q - wz, mt2, w1, -1.0, 1.0);
+          h->stream = main_s;
+          FFGP_CHECK(irc);
         }
       }
+      if (syrk_s != main_s) {
+        FFGP_HIP(hipEventRecord(h->la_ev[8], syrk_s));
+        FFGP_HIP(hipStreamWaitEvent(main_s, h->la_ev[8], 0));
+      }
       if (eb_prev) FFGP_HIP(hipStreamWaitEvent(main_s, eb_prev, 0));
+      if (pass_done) FFGP_HIP(hipStreamWaitEvent(main_s, pass_done, 0));
     } else {
       // Look-ahead.  The trailing update of step k is cut into S_a (the first 128 columns of panel k+1 -- all that its
       // first diagonal factor and TRSM read), S_b (the rest of panel k+1's columns) and S_ii (everything to the right).
@@ -1519,9 +1605,10 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
       // long before (S_ii(k-1), S_b(k)).  Panel k+1 touches only its own columns; S_ii reads panel k and writes the
       // columns to the right of panel k+1, so the two streams never alias.
       hipStream_t main_s = h->stream;
-      FFGP_CHECK(factor_panel(h, A, n, mtot, lda, 0, min(pw(0), n)));
+      FFGP_CHECK(factor_panel(h, A, n, mch, lda, 0, min(pw(0), n)));
       FFGP_HIP(hipEventRecord(h->la_ev[6], main_s));
       FFGP_HIP(hipStreamWaitEvent(h->aux, h->la_ev[6], 0));
+      if (split_pass) FFGP_CHECK(pass_panel(0, min(pw(0), n), h->la_ev[6]));
       int it = 0;
       hipEvent_t eb_prev = nullptr, ei_prev = nullptr;
       for (int k0 = 0; k0 < n; k0 += pw(k0), ++it) {
@@ -1537,7 +1624,7 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
         // side stream: S_a(k) (after S_ii(k-1), which carried panel k-1 into these columns)
         if (ei_prev) FFGP_HIP(hipStreamWaitEvent(h->aux, ei_prev, 0));
         h->stream = h->aux;
-        int rc = potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P, lda, P, lda, C, lda, mtot - pend, wa, w1, -1.0, 1.0);
+        int rc = potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P, lda, P, lda, C, lda, mch - pend, wa, w1, -1.0, 1.0);
         h->stream = main_s;
         FFGP_CHECK(rc);
         // main stream: S_b(k) once panel k is complete
@@ -1546,18 +1633,19 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
         if (wn > wa) {
           double* Pb = A + (size_t)(pend + wa) * lda + k0;
           double* Cb = A + (size_t)(pend + wa) * lda + (pend + wa);
-          FFGP_CHECK(potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, Pb, lda, Pb, lda, Cb, lda, mtot - pend - wa, wn - wa,
+          FFGP_CHECK(potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, Pb, lda, Pb, lda, Cb, lda, mch - pend - wa, wn - wa,
                                       w1, -1.0, 1.0));
           FFGP_HIP(hipEventRecord(eg, main_s));
           gate = eg;
         }
         // side stream: panel k+1
         h->stream = h->aux;
-        rc = factor_panel(h, A, n, mtot, lda, pend, wn, gate);
+        rc = factor_panel(h, A, n, mch, lda, pend, wn, gate);
         h->stream = main_s;
         FFGP_CHECK(rc);
         FFGP_HIP(hipEventRecord(eb, h->aux));
         eb_prev = eb;
+        if (split_pass) FFGP_CHECK(pass_panel(pend, wn, eb));
         if (h->tri_hook_col > 0 && pend + wn == h->tri_hook_col) {   // the factor's columns < tri_hook_col are final from here on
           FFGP_HIP(hipEventRecord(h->tri_ev[0], h->aux));
           h->tri_hook_fired = 1;
@@ -1568,13 +1656,14 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
         if (mt2 > 0) {
           double* P2 = A + (size_t)(pend + wn) * lda + k0;
           double* C2 = A + (size_t)(pend + wn) * lda + (pend + wn);
-          FFGP_CHECK(potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P2, lda, P2, lda, C2, lda, mtot - pend - wn, mt2,
+          FFGP_CHECK(potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P2, lda, P2, lda, C2, lda, mch - pend - wn, mt2,
                                       w1, -1.0, 1.0));
           FFGP_HIP(hipEventRecord(ei, main_s));
           ei_prev = ei;
         }
       }
       if (eb_prev) FFGP_HIP(hipStreamWaitEvent(main_s, eb_prev, 0));
+      if (pass_done) FFGP_HIP(hipStreamWaitEvent(main_s, pass_done, 0));
     }
     h->dinv_L = A;
     h->dinv_n = n;
