@@ -279,6 +279,7 @@ int ffgp_destroy(ffgp_handle* h) {
   if (h->d_info) hipFree(h->d_info);
   if (h->bt_info) hipFree(h->bt_info);
   if (h->train_g) hipFree(h->train_g);
+  if (h->pack_buf) hipFree(h->pack_buf);
   ffgp_assemble_collect_free(h);
   if (h->bt_info_host) hipHostFree(h->bt_info_host);
   if (h->d_scal) hipFree(h->d_scal);
@@ -328,7 +329,7 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
   // The shipped library keeps the switches a binding or a deployment tunes (thresholds, block sizes, the on-device cross-check,
   // timing).  The switches of experiments that were measured and lost (docs/experiments.md) exist in the development build only
   // (`make dev` -> libffgp_dev.so, ffgp_has_dev_options() == 1); here their keys are refused like any unknown key.
-  static const char* const dev_only[] = {"raw_graph_max_n", "diag_dbg", "la_split", "nb_big", "nb_big_until", "sb_lookahead", "sb_av_gemm", "sb_qr4", "q2_wave4", "eig_overlap", "band_log2", "polite_pad_kb"};
+  static const char* const dev_only[] = {"raw_graph_max_n", "diag_dbg", "la_split", "nb_big", "nb_big_until", "sb_lookahead", "sb_av_gemm", "sb_qr4", "q2_wave4", "eig_overlap", "band_log2", "polite_pad_kb", "pass_split_min", "tail_mask_m", "tail_mask_cus", "syrk_h64", "syrk_direct"};
   for (const char* k : dev_only)
     if (!strcmp(key, k)) return FFGP_ERR_ARG;
   if (!strcmp(key, "diag_v2") && value != 4.0 && value != 0.0) return FFGP_ERR_ARG;   // (the round-3 pipelines: development build)
@@ -365,6 +366,8 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->la_split = (int)value;
   } else if (!strcmp(key, "la_min_n")) {
     h->la_min_n = (int)value;
+  } else if (!strcmp(key, "syrk_direct")) {
+    h->syrk_direct = (int)value;
   } else if (!strcmp(key, "syrk_h64")) {
     h->syrk_h64 = (int)value;
   } else if (!strcmp(key, "tail_mask_m")) {

@@ -116,6 +116,7 @@ struct GemmArgs {
   // outer batch (gridDim.z): the same launch for every block of a shared gradient stage, at per-operand element strides
   int batch2;
   long sA2, sB2, sC2;
+  const double* pack;   // the panel in the MFMA operand layout (gemm_tile_direct), or null
 };
 
 // one member of a ragged GEMM launch (ffgp_gemm_f64_rag): everything of GemmArgs that differs between the members
@@ -187,6 +188,9 @@ struct ffgp_handle {
   hipEvent_t eig_ev[12];   // hand-offs between the chase (side stream) and the back-transformation (main stream) of ffgp_syevd
   hipStream_t masked;   // CU-masked stream for the trailing updates of the chain-bound tail (tail_mask_m > 0)
   int masked_failed, tail_mask_m, tail_mask_cus;
+  int syrk_direct;      // trailing update's interior tiles in the direct form (no LDS, no barriers; gemm_tile_direct)
+  double* pack_buf;
+  size_t pack_bytes;
   int syrk_h64;         // experiment: trailing update on 128 x 64 half tiles, three workgroups per CU
   hipStream_t aux3;     // fourth stream: the passenger rows of a look-ahead factorisation, one panel behind the chain (ffgp_potrf_impl)
   int pass_split_min;   // passenger rows (right-hand sides riding in the factorisation) from this many on leave the chain's launches; 0 = never

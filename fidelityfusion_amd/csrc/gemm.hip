@@ -319,6 +319,122 @@ __device__ __forceinline__ void gemm_tile_fast(const char* __restrict__ baseA, c
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Direct form (round 5; option syrk_direct; measured 11 % SLOWER at C3 -- twice the operand traffic from L2 / Infinity Cache per MFMA,
+// docs/experiments.md -- development build only): the trailing update's interior 128 x 128 tiles WITHOUT LDS and WITHOUT barriers.
+// The panel P (rows x K, K-major) is first re-written in the MFMA operand layout -- per 16-row block and per 8 k-columns one
+// 1 KiB record: lane l = 16 kk + r holds { P[16 rb + r][8 kp + kk], P[16 rb + r][8 kp + 4 + kk] } -- which serves as the A operand
+// of one MFMA pair AND, the update being P_r P_c^T, as the B operand.  Every wave then streams its four row-block records and four
+// column-block records per k-pair straight from L2 into registers (one global_load_dwordx4 of 1 KiB contiguous per record, two
+// k-pairs in flight) and is on its own: the LDS form's barrier per k-tile, its LDS stores and reads, and the lock-step of a
+// workgroup's four waves are gone.  Same MFMAs in the same k order on the same accumulators (C loaded into them first, -A by the
+// instruction's modifier): the values are the fast form's bit for bit.  Diagonal and edge tiles keep the LDS forms.
+// ------------------------------------------------------------------------------------------------------------
+#ifdef FFGP_DEV_OPTIONS
+__global__ __launch_bounds__(256) void ffgp_pack_panel_kernel(const double* __restrict__ P, int ld, int rows, int K, d2_t* __restrict__ out) {
+  // workgroup = (row block rb, chunk of 128 k-columns): thread t reads 8 consecutive k of row t >> 4 (a row's 16 threads read 1 KiB)
+  const int rb = blockIdx.x, kc = blockIdx.y, t = threadIdx.x;
+  const int r = t >> 4, c8 = t & 15;
+  const int row = rb * 16 + r, k0 = kc * 128 + c8 * 8;
+  if (k0 >= K) return;
+  d2_t v[4];
+  const bool ok = row < rows;
+  const double* src = P + (size_t)(ok ? row : 0) * ld + k0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = ok ? *reinterpret_cast<const d2_t*>(src + 2 * i) : (d2_t){0.0, 0.0};
+  const double e[8] = {v[0].x, v[0].y, v[1].x, v[1].y, v[2].x, v[2].y, v[3].x, v[3].y};
+  const int KP = K >> 3, kp = k0 >> 3;
+  d2_t* dst = out + ((size_t)rb * KP + kp) * 64 + r;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) dst[kk * 16] = (d2_t){e[kk], e[4 + kk]};
+}
+
+template <bool NEG>
+__device__ __forceinline__ void gemm_tile_direct(const GemmArgs& p, double* __restrict__ Cg, int ti, int tj, int tid) {
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;   // (uniform: scalar bases)
+  const int KP = p.k >> 3;
+  const size_t rec = (size_t)KP * 1024;                        // bytes of one row block's records
+  const char* __restrict__ pk = reinterpret_cast<const char*>(p.pack);
+  const char* baseA = pk + (size_t)(ti * 8 + wm * 4) * rec;    // this wave's four row blocks (A operand) ...
+  const char* baseB = pk + (size_t)(tj * 8 + wn * 4) * rec;    // ... and four column blocks (B operand): wave-uniform
+  const unsigned vo = (unsigned)lane * 16u;
+  // C quadrant straight into the accumulators (layout as in gemm_tile_fast)
+  char* bC = reinterpret_cast<char*>(Cg) + ((size_t)(ti * 128) * p.ldc + tj * 128) * 8;
+  const size_t row4 = (size_t)p.ldc * 32;
+  const unsigned voffC = (unsigned)((wm * 64 + (lane >> 4)) * p.ldc + wn * 64 + (lane & 15)) * 8u;
+  d4_t acc[4][4];
+  d2_t a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a0[i] = *reinterpret_cast<const d2_t*>(baseA + i * rec + vo);
+    b0[i] = *reinterpret_cast<const d2_t*>(baseB + i * rec + vo);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a1[i] = *reinterpret_cast<const d2_t*>(baseA + i * rec + 1024 + vo);
+    b1[i] = *reinterpret_cast<const d2_t*>(baseB + i * rec + 1024 + vo);
+  }
+  if (p.beta != 0.0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const char* rowb = bC + (size_t)(i * 4 + r) * row4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j][r] = *reinterpret_cast<const double*>(rowb + voffC + j * 128);
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+  }
+  baseA += 2048;
+  baseB += 2048;
+  for (int kp = 0; kp < KP; kp += 2) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(h ? a0[i].y : a0[i].x, h ? b0[j].y : b0[j].x, acc[i][j], 0, 0, NEG ? 1 : 0);
+    if (kp + 2 < KP) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a0[i] = *reinterpret_cast<const d2_t*>(baseA + i * rec + vo);
+        b0[i] = *reinterpret_cast<const d2_t*>(baseB + i * rec + vo);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(h ? a1[i].y : a1[i].x, h ? b1[j].y : b1[j].x, acc[i][j], 0, 0, NEG ? 1 : 0);
+    if (kp + 3 < KP) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a1[i] = *reinterpret_cast<const d2_t*>(baseA + i * rec + 1024 + vo);
+        b1[i] = *reinterpret_cast<const d2_t*>(baseB + i * rec + 1024 + vo);
+      }
+    }
+    baseA += 2048;
+    baseB += 2048;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      char* rowb = bC + (size_t)(i * 4 + r) * row4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<double*>(rowb + voffC + j * 128) = acc[i][j][r];
+    }
+}
+
+#endif   // FFGP_DEV_OPTIONS (direct form)
+
 template <int OPA, int OPB, int TM, int TN, bool GUARD>
 __device__ __forceinline__ void gemm_mainloop(const GemmArgs& p, const double* __restrict__ Ag, const double* __restrict__ Bg,
                                               double* smem, int m0, int n0, int kt0, int kt1, int tid,
@@ -388,6 +504,10 @@ __device__ __forceinline__ void gemm_one_tile(const GemmArgs& p, const double* _
   const int kt1 = (kend + BK - 1) / BK;
 
   const bool interior = (m0 + TM <= p.m) && (n0 + TN <= p.n) && (kt1 * BK <= p.k) && p.avec && p.bvec;
+  if constexpr (TM == 128 && TN == 128 && OPA == OP_KMAJOR && OPB == OP_KMAJOR) {
+    // (direct form active: the interior off-diagonal tiles belong to ffgp_gemm_f64_direct's launch)
+    if (p.pack && fast_ab && interior && kt0 == 0 && kt1 * BK == p.k && !(MODE == TILES_LOWER && m0 < n0 + TN)) return;
+  }
   if (fast_ab && interior && kt0 < kt1 && !(MODE == TILES_LOWER && m0 < n0 + TN)) {
     const size_t k0 = (size_t)kt0 * BK;
     const char* bA = reinterpret_cast<const char*>(Ag) +
@@ -516,6 +636,27 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& p, const double* __re
   gemm_one_tile<OPA, OPB, MODE, TM, TN>(p, Ag, Bg, Cg, smem, ti, tj, tid, bid);
 }
 
+#ifdef FFGP_DEV_OPTIONS
+// the direct form's own launch: the same grid and tile order as the LDS kernel's; a workgroup whose tile is interior and off the
+// diagonal computes it (four independent waves, no LDS), every other workgroup leaves -- its tile is the LDS kernel's
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void ffgp_gemm_f64_direct(GemmArgs p) {
+  const int tid = threadIdx.x;
+  const int bid = blockIdx.x;
+  const int nwg = p.total_tiles;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  int ti, tj;
+  decode_tile(t, MODE, p.tiles_m, p.tiles_n, ti, tj, p.band_log2);
+  ti = __builtin_amdgcn_readfirstlane(ti);
+  tj = __builtin_amdgcn_readfirstlane(tj);
+  const int m0 = ti * 128, n0 = tj * 128;
+  if (!((m0 + 128 <= p.m) && (n0 + 128 <= p.n)) || (MODE == TILES_LOWER && m0 < n0 + 128)) return;
+  if (p.alpha < 0.0) gemm_tile_direct<true>(p, p.C, ti, tj, tid);
+  else gemm_tile_direct<false>(p, p.C, ti, tj, tid);
+}
+#endif
+
 template <int OPA, int OPB, int MODE, int TAG, int TM, int TN>
 __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) double smem[2 * (opbuf<OPA, TM>() + opbuf<OPB, TN>())];
@@ -528,11 +669,12 @@ __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
   gemm_block<OPA, OPB, MODE, TM, TN>(p, Ag, Bg, Cg, smem, tid, blockIdx.x);
 }
 
-// Half-width throughput tiles (option syrk_h64; experiment of round 5): every 128 x 128 tile of the trailing update as two 128 x 64
+// Half-width throughput tiles (option syrk_h64; experiment of round 5 -- measured neutral at C3, 28.70 ms either way: development build only): every 128 x 128 tile of the trailing update as two 128 x 64
 // workgroups with 64 accumulator registers per lane, so that THREE workgroups fit a CU (the 128 x 128 tile's 232 registers allow
 // two: while one of them is in its prologue -- C tile and first operand tiles in flight, 8 % of a K = 512 tile's life -- the
 // other has the matrix pipe to itself and drives it at ~70 %).  The two halves of a tile are blocks b and b + 8 (one XCD: they
 // share the A panel in that L2); tile order and XCD chunks as in gemm_block, on the index of the 128 x 128 tile.
+#ifdef FFGP_DEV_OPTIONS
 template <int OPA, int OPB, int MODE, int TAG>
 __global__ __launch_bounds__(256, 3) void ffgp_gemm_f64_h64(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) double smem[2 * (opbuf<OPA, 128>() + opbuf<OPB, 64>())];
@@ -554,6 +696,7 @@ __global__ __launch_bounds__(256, 3) void ffgp_gemm_f64_h64(GemmArgs p) {
   if (tj * 64 >= p.n) return;
   gemm_one_tile<OPA, OPB, MODE, 128, 64>(p, Ag, Bg, Cg, smem, ti, tj, tid, bid);
 }
+#endif
 
 // Ragged launch (the shared factorisation chain of blocks of DIFFERENT sizes, ffgp_potrf_ragged): gridDim.y members, each with its
 // own operands, sizes, leading dimensions and tile counts -- every member's launch as its own single call would make it (same tile
@@ -837,7 +980,7 @@ static int gemm_plan(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   // whole tile time; when that remainder is small, hand it out as 64 x 64 quarters -- 4x the workgroups, a quarter of the
   // chain each -- which start under the last full round.  (An in-place or batched launch never splits.)
   if (tsm == 128 && tsn == 128 && alias == 0 && dec_batch == 1 && h->force_ts == 0 && h->split_rem_max > 0 && a.total_tiles > 256 &&
-      !(syrk_tag && h->syrk_h64)) {
+      !(syrk_tag && (h->syrk_h64 || h->syrk_direct))) {
     const int rem = a.total_tiles % 256;
     if (rem > 0 && rem <= h->split_rem_max) {
       a.split_at = a.total_tiles - rem;
@@ -992,6 +1135,37 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
     a.batch2 = h->ob_F;
     a.sA2 = ob_sA; a.sB2 = ob_sB; a.sC2 = ob_sC;
   }
+  // direct form of the trailing update (see gemm_tile_direct): the panel in the MFMA operand layout, written right before the launch
+  a.pack = nullptr;
+#ifdef FFGP_DEV_OPTIONS
+  if (syrk_tag && h->syrk_direct && A == B && lda == ldb && (k & 15) == 0 && a.batch == 1 && !ob && a.fast && a.avec && a.bvec && tri == 0 &&
+      a.split_at == 0x7fffffff) {
+    const int rbs = (m + 15) / 16;
+    const size_t need = (size_t)rbs * 16 * k * sizeof(double);
+    if (need > h->pack_bytes) {
+      if (h->pack_buf) {
+        hipStreamSynchronize(h->stream);
+        if (h->aux) hipStreamSynchronize(h->aux);
+        hipFree(h->pack_buf);
+        h->pack_buf = nullptr;
+        h->pack_bytes = 0;
+      }
+      if (hipMalloc(&h->pack_buf, need + need / 8) == hipSuccess) h->pack_bytes = need + need / 8;
+      else (void)hipGetLastError();
+    }
+    if (h->pack_buf) {
+      // (one buffer per handle: consecutive trailing updates on DIFFERENT streams would race on it -- the look-ahead forms issue
+      // them on the main stream only, the side stream's S_a keeps the LDS form)
+      if (h->stream != h->aux) {
+        hipLaunchKernelGGL(ffgp_pack_panel_kernel, dim3(rbs, (k + 127) / 128), dim3(256), 0, h->stream, A, lda, m, k,
+                           reinterpret_cast<d2_t*>(h->pack_buf));
+        a.pack = h->pack_buf;
+        if (mode == TILES_LOWER) hipLaunchKernelGGL(ffgp_gemm_f64_direct<TILES_LOWER>, dim3(a.grid), dim3(256), 0, h->stream, a);
+        else hipLaunchKernelGGL(ffgp_gemm_f64_direct<TILES_FULL>, dim3(a.grid), dim3(256), 0, h->stream, a);
+      }
+    }
+  }
+#endif
   // timing == 2: bracket every trailing-update launch with its own event pair (no host sync inside the timed
   // region; ffgp_syrk_stats drains the pool afterwards)
   const bool timed = (syrk_tag && h->timing == 2);
@@ -1016,12 +1190,15 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   else if (tsm == 32)
     rc = (mode == TILES_LOWER) ? launch_t<OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 0, 32, 32>(h, a)
                                : launch_t<OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, 32, 32>(h, a);
+#ifdef FFGP_DEV_OPTIONS
   else if (tsm == 128 && syrk_tag && h->syrk_h64 && a.split_at == 0x7fffffff && a.pad_lds == 0 && !ob) {
     // (experiment: the trailing update on 128 x 64 half tiles, three workgroups per CU)
     const int gx = ((a.total_tiles + 7) / 8) * 16;
     hipLaunchKernelGGL((ffgp_gemm_f64_h64<OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1>), dim3(gx, a.batch), dim3(256), 0, h->stream, a);
     rc = FFGP_OK;
-  } else if (tsm == 128)
+  }
+#endif
+  else if (tsm == 128)
     rc = dispatch<128>(h, opa, opb, mode, syrk_tag, a);
   else
     rc = dispatch<64>(h, opa, opb, mode, syrk_tag, a);

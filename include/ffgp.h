@@ -220,7 +220,8 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
             "trtri_overlap", "small_fused", "small_max_n" (round-3 experiment switches).
    Keys the SHIPPED library refuses with FFGP_ERR_ARG (they are accepted by the development build only, `make dev`,
    ffgp_has_dev_options() == 1): "raw_graph_max_n", "diag_dbg", "la_split", "nb_big", "nb_big_until", "sb_lookahead", "sb_av_gemm",
-   "sb_qr4", "q2_wave4", "eig_overlap", "band_log2", "polite_pad_kb", and every value of "diag_v2" other than 0 and 4.  An unknown
+   "sb_qr4", "q2_wave4", "eig_overlap", "band_log2", "polite_pad_kb", "pass_split_min", "tail_mask_m", "tail_mask_cus", "syrk_h64", "syrk_direct" (the
+   round-5 experiments on the factorisation's chain, docs/experiments.md), and every value of "diag_v2" other than 0 and 4.  An unknown
    key is FFGP_ERR_ARG in both builds.    */
 int ffgp_set_option(ffgp_handle* h, const char* key, double value);
 /* Create the handle's side streams now and use each once, so that they bind their hardware queues before streams the process creates
