@@ -451,7 +451,11 @@ def run_rank(args):
         from fidelityfusion_amd import _lib
         _lib.configure_queues(reserve_worker_streams=0)      # GPU_MAX_HW_QUEUES: before this process first touches the GPU
         ndev = torch.cuda.device_count()                      # (counting devices does not initialise HIP on this image)
-        if ndev < max(args.gpus, local_rank + 1):
+        if os.environ.get("FFGP_BENCH_ONE_GPU") == "1" and args.backend == "gloo" and ndev >= 1:
+            # rehearsal of the multi-rank step on a one-GPU box: every rank drives cuda:0, the F-vector is reduced by gloo on the host
+            # (tests/test_bench_launch.py); never a measurement
+            local_rank = 0
+        elif ndev < max(args.gpus, local_rank + 1):
             raise SystemExit("bench.py: --gpus %d (LOCAL_RANK %d) but only %d GPU%s visible to this process -- check "
                              "HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES or lower --gpus" % (args.gpus, local_rank, ndev, "" if ndev == 1 else "s"))
         assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path; --dry only checks plumbing)"

@@ -786,7 +786,7 @@ int ffgp_nlml_fused_small_batch_async(ffgp_handle* h, int F, const ffgp_problem*
   h->n_stages = 0;
   FFGP_CHECK(ffgp_zero_async(h, h->d_info, sizeof(int)));
   FFGP_CHECK(ffgp_small_batch_enqueue(h, F, p, l, nll_dev, g));
-  hipLaunchKernelGGL(ffgp_sticky_info_kernel, dim3(1), dim3(1), 0, h->stream, h->d_info);
+  if (!h->fold_info) hipLaunchKernelGGL(ffgp_sticky_info_kernel, dim3(1), dim3(1), 0, h->stream, h->d_info);
   if (!h->defer_info_copy) FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   return FFGP_OK;
 }
@@ -1060,10 +1060,18 @@ static int nlml_fused_raw_plain(ffgp_handle* h, const ffgp_problem* p, const ffg
 
 __global__ void ffgp_adam_kernel(int F, ffgp_train_slot sl, const double* __restrict__ gbuf, double* __restrict__ state, long state_stride,
                                  double lr, double b1, double b2, double eps, double bc1, double bc2_sqrt, const double* __restrict__ loss,
-                                 double* __restrict__ trace, long trace_stride, int step, const int* __restrict__ info) {
+                                 double* __restrict__ trace, long trace_stride, int step, int* __restrict__ info, int fold) {
   const int f = blockIdx.x;
   if (f >= F) return;
-  const int bad = info[0] | info[1];
+  const int i0 = info[0], i1 = info[1];
+  const int bad = i0 | i1;
+  if (fold) {      // (one model per call: this kernel also keeps the status words -- sticky first failure, current word cleared for the
+    __syncthreads();   //  next step's factorisation -- two single-thread launches per step otherwise)
+    if (threadIdx.x == 0) {
+      if (i1 == 0 && i0 != 0) info[1] = i0;
+      info[0] = 0;
+    }
+  }
   const int nw = sl.nw[f];
   if (threadIdx.x == 0) trace[(size_t)f * trace_stride + step] = bad ? __builtin_nan("") : loss[f];
   if (bad) return;
@@ -1115,6 +1123,7 @@ int ffgp_train_raw(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_link
   // the sticky status word starts clean: a failure of an EARLIER call on this handle is that call's to report
   FFGP_CHECK(ffgp_zero_async(h, h->d_info, 2 * sizeof(int)));
   h->defer_info_copy = 1;      // (the per-call read-back of the status word: once, after the loop)
+  h->fold_info = (F == 1) ? 1 : 0;   // one model: the Adam kernel clears / accumulates the status words (see ffgp_adam_kernel)
   int lrc = FFGP_OK;
   for (int k = 0; k < steps && lrc == FFGP_OK; ++k) {
     if (all_small && F > 1) {
@@ -1128,9 +1137,10 @@ int ffgp_train_raw(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_link
     const double t = (double)(step0 + k + 1);
     const double bc1 = 1.0 - std::pow(opt->beta1, t), bc2 = 1.0 - std::pow(opt->beta2, t);
     hipLaunchKernelGGL(ffgp_adam_kernel, dim3(F), dim3(192), 0, h->stream, F, sl, gbuf, state_dev, state_stride, opt->lr, opt->beta1,
-                       opt->beta2, opt->eps, bc1, std::sqrt(bc2), loss, trace_dev, trace_stride, k, h->d_info);
+                       opt->beta2, opt->eps, bc1, std::sqrt(bc2), loss, trace_dev, trace_stride, k, h->d_info, h->fold_info);
   }
   h->defer_info_copy = 0;
+  h->fold_info = 0;
   if (lrc != FFGP_OK) {
     hipStreamSynchronize(h->stream);
     return lrc;
@@ -1279,7 +1289,7 @@ static int small2_enqueue(ffgp_handle* h, const ffgp_problem* p, const ffgp_link
                                 p->ld_add, p->add_all, p->mean_jitter, h->ws, (int)ld, 1, p->kfun, p->kparam));
   FFGP_CHECK(ffgp_potrf_impl(h, h->ws, n, n, (int)ld, 0));
   FFGP_CHECK(ffgp_small_enqueue(h, p, l, nll_dev, g, h->dinv));
-  hipLaunchKernelGGL(ffgp_sticky_info_kernel, dim3(1), dim3(1), 0, h->stream, h->d_info);
+  if (!h->fold_info) hipLaunchKernelGGL(ffgp_sticky_info_kernel, dim3(1), dim3(1), 0, h->stream, h->d_info);
   if (!h->defer_info_copy) FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   return FFGP_OK;
 }
@@ -1292,7 +1302,7 @@ static int nlml_fused_raw_plain(ffgp_handle* h, const ffgp_problem* p, const ffg
   if (ffgp_small_ok(h, p, g)) {   // one kernel: links, likelihood, gradients, chain rule, output scale
     h->n_stages = 0;
     FFGP_CHECK(ffgp_small_enqueue(h, p, l, nll_dev, g));
-    hipLaunchKernelGGL(ffgp_sticky_info_kernel, dim3(1), dim3(1), 0, h->stream, h->d_info);
+    if (!h->fold_info) hipLaunchKernelGGL(ffgp_sticky_info_kernel, dim3(1), dim3(1), 0, h->stream, h->d_info);
     if (!h->defer_info_copy) FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     return FFGP_OK;
   }
@@ -1375,7 +1385,7 @@ static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll
   if (ffgp_small_ok(h, p, g)) {   // the sizes of the reference's own demos: one workgroup, one launch (small.hip)
     h->n_stages = 0;
     FFGP_CHECK(ffgp_small_enqueue(h, p, nullptr, nll_dev, g));
-    hipLaunchKernelGGL(ffgp_sticky_info_kernel, dim3(1), dim3(1), 0, h->stream, h->d_info);
+    if (!h->fold_info) hipLaunchKernelGGL(ffgp_sticky_info_kernel, dim3(1), dim3(1), 0, h->stream, h->d_info);
     if (!h->defer_info_copy) FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     return FFGP_OK;
   }
@@ -1486,7 +1496,7 @@ static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll
     if (g->g_Y_dev) FFGP_CHECK(ffgp_transpose(h, gYt, d, n, (int)ld, g->g_Y_dev, d, 1.0));
     stage_mark(h, 6);
   }
-  hipLaunchKernelGGL(ffgp_sticky_info_kernel, dim3(1), dim3(1), 0, h->stream, h->d_info);
+  if (!h->fold_info) hipLaunchKernelGGL(ffgp_sticky_info_kernel, dim3(1), dim3(1), 0, h->stream, h->d_info);
   if (!h->defer_info_copy) FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   return FFGP_OK;
 }

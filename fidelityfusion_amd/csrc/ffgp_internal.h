@@ -209,6 +209,7 @@ struct ffgp_handle {
   struct { const double* lo; const double* hi; long stride; } ob_rng[6];
   void* asm_collect;    // AsmCollector (assemble.hip): assemblies of a batch's small members parked for one multi-member launch
   int asm_collecting;
+  int fold_info;        // ffgp_train_raw with one model: status-word upkeep lives in the Adam kernel
   int defer_info_copy;  // ffgp_train_raw's loop: the enqueue paths skip their per-call read-back of the status word
   double* train_g;      // ffgp_train_raw: gradients of the raw parameters [MAXF x GSTRIDE] + the step's losses [MAXF]
   int* bt_info;         // [F] device status words (first non-positive pivot of each block)

@@ -1448,7 +1448,7 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
     return FFGP_ERR_ARG;
   }
   FFGP_CHECK(ffgp_ensure_dinv(h, n));
-  FFGP_CHECK(ffgp_zero_async(h, h->d_info, sizeof(int)));
+  if (!h->fold_info) FFGP_CHECK(ffgp_zero_async(h, h->d_info, sizeof(int)));   // (ffgp_train_raw's loop: its Adam kernel clears the word)
   h->dinv_L = nullptr;
   h->sinv_L = nullptr;   // super-block inverses belong to the factor that is about to be overwritten
 

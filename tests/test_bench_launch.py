@@ -170,3 +170,27 @@ def test_roofline_flops_count_every_block_of_a_shared_chain():
     assert r1["launches"] == r4["launches"] > 0
     assert abs(r4["avg_launch_gflop"] - 4.0 * r1["avg_launch_gflop"]) <= 1e-3 * r4["avg_launch_gflop"]     # (the line rounds to 3 decimals)
     assert 0.2 < r4["frac"] < 1.0
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_the_one_gpu_real_step_over_gloo():
+    """`--gpus 2 --backend gloo` with the REAL (not dry) step, both ranks on cuda:0 (FFGP_BENCH_ONE_GPU=1): self-launch, per-rank
+    CPU pinning before the first GPU call, LPT partition, the fused HIP blocks, the F-vector all-reduce and the JSON line -- the
+    multi-rank code path end to end on the one-GPU box; the joint value must be the single-rank run's"""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+    def run(gpus):
+        env = dict(os.environ, FFGP_BENCH_ONE_GPU="1")
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--backend", "gloo", "--workload", "cigar4",
+                            "--n", "1536", "--d", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    one, two = run(1), run(2)
+    assert two["n_gpus"] == 2 and two["collective"] == {"backend": "gloo", "ranks": 2} and two["config"]["blocks"] == 4
+    assert two["cpu_affinity"] is None or two["cpu_affinity"]["rank0_cpus"] >= 1
+    assert abs(two["joint_nll"] - one["joint_nll"]) <= 1e-12 * abs(one["joint_nll"])

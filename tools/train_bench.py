@@ -12,6 +12,11 @@ from fidelityfusion_amd import kernel
 from fidelityfusion_amd.cigp_v10 import cigp, train_many
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+for kv in os.environ.get("FFGP_OPTS", "").split(","):      # library options for A/B runs: FFGP_OPTS=small_finish=1
+    if kv:
+        from fidelityfusion_amd import _lib
+        _lib.set_option(kv.split("=")[0], float(kv.split("=")[1]), 0)
+        print("option", kv)
 dev = torch.device("cuda", 0)
 torch.set_default_dtype(torch.float64)
 
