@@ -717,6 +717,9 @@ def run_rank(args):
                          "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "bytes/launch (PMC pass of this command, replayed from the committed profile)",
                          "traffic_source": traffic_src, "traffic_error": traffic_err,
+                         "traffic_calibration": "2 x FETCH_SIZE checked on this kernel's own loads (profiles/r05a_traffic_calibration.txt): a "
+                                                "k = 16 launch at m = 16384 reads 1082 MB of C tiles by construction and reports 2 x FETCH = "
+                                                "1123 MB (TCC_EA0_RDREQ x 128 B, no 32-B requests); WRITE_SIZE exact (1074.0 vs 1073.7 MB)",
                          "algorithmic_bytes_per_launch": round(8.0 * stats["flops"] / max(stats["launches"], 1) / 512.0 * (1.0 + 1.0 / 16.0)),
                          "kernel": ROOFLINE_KERNEL + " (trailing SYRK update of the blocked Cholesky, K = 512)",
                          "launches": stats["launches"], "avg_launch_ms": round(stats["ms"] / max(stats["launches"], 1), 4),

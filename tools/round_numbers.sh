@@ -1,10 +1,12 @@
 #!/bin/bash
 # Every number DESIGN.md quotes for the round, in one GPU call.  Usage: bash tools/round_numbers.sh <tag>
 TAG=${1:-numbers}
+PART=${2:-all}      # bench | tools | all  (a gpurun call is limited to 20 minutes: the two halves fit one call each)
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
+if [ "$PART" != "tools" ]; then
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench.err
 python3 bench.py --workload c2 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_c2.json 2>> $OUT/bench.err
 python3 bench.py --with-grad --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_c3_grad.json 2>> $OUT/bench.err
@@ -16,7 +18,14 @@ python3 bench.py --n 8192 --D 8 --d 1024 --steps 10 --warmup 3 --no-cpu-baseline
 python3 bench.py --n 8192 --D 8 --d 4096 --steps 10 --warmup 3 --no-cpu-baseline --no-sharded > $OUT/bench_c5_block.json 2>> $OUT/bench.err
 python3 bench.py --n 32768 --steps 3 --warmup 1 --no-cpu-baseline --no-sharded > $OUT/bench_n32768.json 2>> $OUT/bench.err
 python3 bench.py --workload gar8_hogp --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_gar8_hogp.json 2>> $OUT/bench.err
+fi
+if [ "$PART" != "bench" ]; then
 {
+echo "## tools/train_bench.py 200"; timeout 300 python3 tools/train_bench.py 200 2>&1 | grep -v amdgpu.ids | tail -8
+for sz in "300,300,250 1" "300,300,250 1 grad" "8192,4096,2048,1024 1" "8192,4096,2048,1024 1 grad" "8192,4096,2048,1024 256"; do
+  echo "## tools/ragged_probe.py $sz"; timeout 300 python3 tools/ragged_probe.py $sz 2>&1 | grep -v amdgpu.ids | tail -7
+done
+echo "## tools/batch_chain_bench.py 4096 8"; timeout 300 python3 tools/batch_chain_bench.py 4096 8 2>&1 | grep -v amdgpu.ids | tail -8
 for t in posterior_bench hogp_bench c4_step small_n_latency small_kernel_bench v2_bench diag_bench assemble_bench chase_dbg step_stages raw_graph_bench; do
   echo "## tools/$t.py"; timeout 300 python3 tools/$t.py 2>&1 | grep -v amdgpu.ids | tail -12
 done
@@ -24,6 +33,7 @@ echo "## tools/eigh_bench.py full big"; timeout 600 python3 tools/eigh_bench.py 
 echo "## tools/pair_bench.py 16384 16"; timeout 300 python3 tools/pair_bench.py 16384 16 2>&1 | grep -v amdgpu.ids | tail -8
 echo "## tools/small_n_breakdown.py 128 400"; timeout 300 python3 tools/small_n_breakdown.py 128 400 2>&1 | grep -v amdgpu.ids | tail -4
 } > $OUT/tools_output.txt
+fi
 for f in $OUT/bench_*.json; do python3 - "$f" <<'P'
 import json, sys
 try:
