@@ -1,5 +1,6 @@
 // libffgp C ABI: handle lifetime, workspace, fused NLML (+ gradients) and posterior paths.  See include/ffgp.h.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 
 #include "ffgp_internal.h"
@@ -233,6 +234,12 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->la_min_n = 3584;
   h->pass_split_min = 0;        // (measured and lost, docs/experiments.md: 0 = the passenger rows ride in the chain's launches)
   h->tail_mask_cus = 8;
+  h->chase_xl = 1;
+  h->chase_xl_max_n = 2048;
+  {   // (handles of one process prefer different XCDs: blocks in flight from several host threads do not crowd one)
+    static std::atomic<int> next_xcc{0};
+    h->chase_xcc = next_xcc.fetch_add(1) & 7;
+  }
   h->aux_prio = 1;
   h->nb_outer = 512;
   h->diag_v2 = 4;
@@ -366,6 +373,10 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->la_split = (int)value;
   } else if (!strcmp(key, "la_min_n")) {
     h->la_min_n = (int)value;
+  } else if (!strcmp(key, "chase_xl")) {
+    h->chase_xl = (int)value;
+  } else if (!strcmp(key, "chase_xl_max_n")) {
+    h->chase_xl_max_n = (int)value;
   } else if (!strcmp(key, "syrk_direct")) {
     h->syrk_direct = (int)value;
   } else if (!strcmp(key, "syrk_h64")) {

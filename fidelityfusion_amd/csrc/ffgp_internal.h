@@ -188,6 +188,9 @@ struct ffgp_handle {
   hipEvent_t eig_ev[12];   // hand-offs between the chase (side stream) and the back-transformation (main stream) of ffgp_syevd
   hipStream_t masked;   // CU-masked stream for the trailing updates of the chain-bound tail (tail_mask_m > 0)
   int masked_failed, tail_mask_m, tail_mask_cus;
+  int chase_xl_max_n;
+  int chase_xcc;        // the XCD this handle's XCD-local chases run on
+  int chase_xl;         // bulge chase with every working wave on one XCD, hand-overs through that XCD's L2 (sb2st.hip)
   int syrk_direct;      // trailing update's interior tiles in the direct form (no LDS, no barriers; gemm_tile_direct)
   double* pack_buf;
   size_t pack_bytes;

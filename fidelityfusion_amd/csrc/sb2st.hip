@@ -76,11 +76,21 @@ __device__ __forceinline__ double ldb_buf(__amdgpu_buffer_rsrc_t r, unsigned vof
   const ch_v2i v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 16);     // aux 16: sc1
   return __hiloint2double(v.y, v.x);
 }
+// XL ("XCD-local", round 5): every working wave of the launch sits on ONE XCD (the kernel checks HW_REG_XCC_ID and the others leave),
+// so that XCD's L2 is the coherence point: band stores are PLAIN stores (written through, and the line STAYS in that L2 -- an sc1
+// store drops it, after which even a same-XCD reader fetches from the memory side), band loads stay sc1 (they bypass this CU's L1 and
+// are served by the L2 the producer just wrote).  Correct by construction: a wave on any other XCD never touches the band.
+template <bool XL>
 __device__ __forceinline__ void stb_buf(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double x) {
   ch_v2i v;
   v.x = __double2loint(x);
   v.y = __double2hiint(x);
-  __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)voff, (int)soff, 16);
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)voff, (int)soff, XL ? 0 : 16);
+}
+template <bool XL>
+__device__ __forceinline__ void stb_x(__amdgpu_buffer_rsrc_t r, const double* AB, double* p, double v) {
+  if (XL) stb_buf<true>(r, (unsigned)((size_t)(p - AB) * 8), 0u, v);
+  else stb(p, v);
 }
 
 __device__ __forceinline__ int chase_wait(const int* p, int need, int* err) {
@@ -134,22 +144,41 @@ struct ChaseArgs {
   int* prog;                         // [n] steps completed per sweep (CH_DONE when the sweep has ended)
   int* err;
   int pack;                          // only workgroups with blockIdx % pack == 0 work (pack = 8: all of them on one XCD, one L2)
+  int* ticket;                       // XL form: the next sweep to hand out (waves take their sweeps in the order they ask)
+  int xcc;                           // XL form: the XCD whose waves work
   int s_begin, s_end;                // sweeps of this launch (the chase may be cut into several launches: prog carries over)
 };
 
+template <bool XL>
 __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
   __shared__ double vsA[32], vsB[32], wsh[32], ush[32];
   __shared__ double Mt[32][33];
-  if (blockIdx.x % p.pack) return;
-  const int wg = blockIdx.x / p.pack, nwg = (gridDim.x + p.pack - 1) / p.pack;
+  int wg = 0, nwg = 1;
+  if (XL) {
+    unsigned xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if ((int)(xcc & 0xfu) != p.xcc) return;        // (placement is observed behaviour, not a contract: so it is CHECKED, wave by wave)
+  } else {
+    if (blockIdx.x % p.pack) return;
+    wg = blockIdx.x / p.pack;
+    nwg = (gridDim.x + p.pack - 1) / p.pack;
+  }
   const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+  // XL: sweeps are handed out by a ticket counter -- a wave that holds sweep s knows every lower sweep has been taken by a wave that is
+  // already running (or done), so it only ever waits for a running wave, however many waves the XCD received
+  auto next_sweep = [&](int cur) -> int {
+    if (!XL) return cur + nwg;
+    int t = 0;
+    if (threadIdx.x == 0) t = atomicAdd(p.ticket, 1);
+    return __builtin_amdgcn_readfirstlane(t);
+  };
   const int n = p.n;
   double* AB = p.AB;
   double* vs = vsA;
   double* v2s = vsB;
   // raw buffer over the whole band (stride 0, range check off the table: num_records = 2 GiB - 1; the band is n * SB_LDB doubles)
   const __amdgpu_buffer_rsrc_t band = __builtin_amdgcn_make_buffer_rsrc(AB, 0, 0x7fffffff, 0x00020000);
-  for (int s = p.s_begin + wg; s < p.s_end; s += nwg) {
+  for (int s = XL ? next_sweep(0) : p.s_begin + wg; s < p.s_end; s = next_sweep(s)) {
     int c0 = s + 1;
     int len = min(32, n - c0);
     int seen = (s > 0) ? 0 : CH_DONE;    // progress of sweep s - 1 as last observed
@@ -160,7 +189,7 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
       const double v = house32(x, i, lane, len, tau, beta);
       if (h == 0) {
         vs[i] = (i < len) ? v : 0.0;
-        if (i < len) stb(AB + (size_t)s * SB_LDB + 1 + i, (i == 0) ? beta : 0.0);
+        if (i < len) stb_x<XL>(band, AB, AB + (size_t)s * SB_LDB + 1 + i, (i == 0) ? beta : 0.0);
         p.V2[((size_t)s * p.K) * 32 + i] = (i < len) ? v : 0.0;
       }
       if (lane == 0) {
@@ -218,7 +247,7 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
           for (int q = 0; q < 16; ++q) {
             const double t1 = __dmul_rn(vi, wsh[h * 16 + q]), t2 = __dmul_rn(w, vq[q]);      // (no contraction: see above)
             D[q] = __dsub_rn(D[q], __dadd_rn(t1, t2));
-            stb_buf(band, offD[q], soff, D[q]);
+            stb_buf<XL>(band, offD[q], soff, D[q]);
           }
           CH_STAMP(2, 0, k);
           double sb = 0.0;
@@ -250,7 +279,7 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
   #pragma unroll
           for (int q = 0; q < 16; ++q) {
             B[q] = __builtin_fma(-tv, ush[h * 16 + q], B[q]);
-            stb_buf(band, offB[q], soff, B[q]);
+            stb_buf<XL>(band, offB[q], soff, B[q]);
           }
           CH_STAMP(3, 0, k);
           ++k;
@@ -315,7 +344,7 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
       for (int q = 0; q < 16; ++q) {
         const int cc = h * 16 + q;
         D[q] -= vi * wsh[cc] + w * vq[q];
-        if (i >= cc && i < len) stb(AB + (size_t)(c0 + cc) * SB_LDB + (i - cc), D[q]);
+        if (i >= cc && i < len) stb_x<XL>(band, AB, AB + (size_t)(c0 + cc) * SB_LDB + (i - cc), D[q]);
       }
       CH_STAMP(2, 0, k);    // diagonal block updated, its stores issued
       if (!more) break;
@@ -354,7 +383,7 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
       for (int q = 0; q < 16; ++q) {
         const int cc = h * 16 + q;
         B[q] = __builtin_fma(-tv, ush[cc], B[q]);
-        if (i < nrow && cc < len) stb(AB + (size_t)(c0 + cc) * SB_LDB + (len + i - cc), B[q]);
+        if (i < nrow && cc < len) stb_x<XL>(band, AB, AB + (size_t)(c0 + cc) * SB_LDB + (len + i - cc), B[q]);
       }
       CH_STAMP(3, 0, k);    // block below updated, its stores issued
       ++k;
@@ -382,6 +411,8 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
     __syncthreads();
   }
 }
+
+__global__ void sb2st_ticket_init(int* ticket, int v) { ticket[0] = v; }
 
 __global__ void sb2st_tail(const double* __restrict__ AB, int n, double* d, double* e) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -420,8 +451,22 @@ int ffgp_sb2st_chunk(ffgp_handle* h, hipStream_t st, double* AB, int n, double* 
   // a device-scope access wherever the wave runs.  Default 1; beside other blocks' kernels (config 5's eight HOGP blocks from four
   // host threads) 1 and 2 measure the same, 1.43-1.47 s per step.
   a.pack = h->chase_pack > 0 ? h->chase_pack : 1;
+  a.ticket = nullptr;
+  a.xcc = h->chase_xcc;
+  // XCD-local form (option chase_xl, default 1; see stb_buf).  A sweep follows its predecessor two steps behind, so (n / 32) / 2 sweeps
+  // are in flight at most: up to n = 2048 that is <= 32 working waves, ONE per CU of one XCD, and the hand-over through that XCD's L2
+  // shortens the step -- sb2st 7.9 -> 6.5 ms at n = 1024, 15.9 -> 13.8 at n = 2048 (same eigenvalues and vectors).  Above that the
+  // waves of one XCD share CUs, which costs more than the memory-side hand-over saves (n = 4096: 32.2 -> 41.9 ms, n = 8192: 64.7 ->
+  // 132.8 with 128 waves on 32 CUs; pack = 8 above is the same lesson), so larger bands keep the chip-wide form.
+  if (h->chase_xl && n <= h->chase_xl_max_n) {
+    a.ticket = h->d_info + 12;
+    hipLaunchKernelGGL(sb2st_ticket_init, dim3(1), dim3(1), 0, st, a.ticket, s_begin);
+    const int grid = min(s_end - s_begin, max(16, n / 64)) * 8;
+    hipLaunchKernelGGL(sb2st_chase<true>, dim3(grid), dim3(64), 0, st, a);
+    return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
+  }
   const int grid = min(s_end - s_begin, 256) * a.pack;
-  hipLaunchKernelGGL(sb2st_chase, dim3(grid), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(sb2st_chase<false>, dim3(grid), dim3(64), 0, st, a);
   return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
 }
 

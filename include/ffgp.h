@@ -216,6 +216,10 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
             "chase_pack" (placement of the bulge chase's 256 working wavefronts: every pack-th workgroup works.  Default 1 = one per
                         compute unit over the whole chip (N = 8192: 64.6 ms; 2 = on every other XCD: 69.4, 4: 92, 8: 166); beside
                         other blocks' kernels 1 and 2 measure the same (config 5's eight blocks: 1.43-1.47 s per step either way),
+            "chase_xl" / "chase_xl_max_n" (default 1 / 2048: bands of up to chase_xl_max_n columns run their bulge chase with every
+                        working wavefront on ONE XCD -- the kernel reads HW_REG_XCC_ID and the others leave -- and hand the band over
+                        through that XCD's L2: plain stores, L1-bypassing loads; sb2st 7.9 -> 6.5 ms at n = 1024, 15.9 -> 13.8 at 2048;
+                        0 = the chip-wide form with device-scope accesses at every size),
             "batch_grad_ob" (default 1: the shared chain's gradient stage inverts all blocks in one outer-batched sequence of launches),
             "trtri_overlap", "small_fused", "small_max_n" (round-3 experiment switches).
    Keys the SHIPPED library refuses with FFGP_ERR_ARG (they are accepted by the development build only, `make dev`,

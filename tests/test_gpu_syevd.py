@@ -269,3 +269,29 @@ def test_eigensolver_and_likelihood_chains_side_by_side():
             assert torch.equal(got_l, ref_l), "repeat %d: likelihood values differ by up to %.2e" % (rep, float((got_l - ref_l).abs().max()))
             for (w0, z0), (w1, z1) in zip(ref_e, got_e):
                 assert torch.equal(w0, w1) and torch.equal(z0, z1), "repeat %d: eigenpairs differ" % rep
+
+
+@pytest.mark.noisy
+@pytest.mark.parametrize("n", [256, 1024, 2048])
+def test_xcd_local_chase_is_the_chip_wide_chase_bit_for_bit(n):
+    """round 5: bands of up to 2048 columns run their bulge chase with every working wave on ONE XCD (the kernel checks HW_REG_XCC_ID,
+    sweeps are handed out by a ticket) and hand the band over through that XCD's L2 (plain stores, L1-bypassing loads).  Only the cache
+    policy differs from the chip-wide form: eigenvalues and eigenvectors must be identical to the last bit, also beside a background load"""
+    from fidelityfusion_amd import _lib
+    from fidelityfusion_amd import eigh as E
+    g = torch.Generator(device=DEV).manual_seed(n)
+    X = torch.rand((n, 5), generator=g, device=DEV, dtype=torch.float64)
+    d = torch.cdist(X, X)
+    K = torch.exp(-0.5 * d * d / 0.36)
+    res = {}
+    for xl in (1, 0, 1):
+        _lib.set_option("chase_xl", xl, 0)
+        try:
+            W, Z = E.eigh(K)
+        finally:
+            _lib.set_option("chase_xl", 1, 0)
+        res.setdefault(xl, []).append((W.clone(), Z.clone()))
+    assert torch.equal(res[1][0][0], res[0][0][0]) and torch.equal(res[1][0][1], res[0][0][1])
+    assert torch.equal(res[1][0][0], res[1][1][0]) and torch.equal(res[1][0][1], res[1][1][1])
+    lam = torch.linalg.eigvalsh(K)
+    assert float((res[1][0][0] - lam).abs().max()) <= 1e-11 * float(lam.abs().max())

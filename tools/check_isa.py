@@ -34,7 +34,13 @@ def function_body(asm, mangled_substr):
 
 
 def check_chase_publish(asm=None):
-    body = function_body(asm or device_asm("sb2st.hip"), "sb2st_chase")
+    """both instantiations: the chip-wide form (ILb0E) and the XCD-local one (ILb1E: plain band stores, same publish protocol)"""
+    asm = asm or device_asm("sb2st.hip")
+    return [_check_chase_publish_one(asm, "sb2st_chaseILb0E"), _check_chase_publish_one(asm, "sb2st_chaseILb1E")]
+
+
+def _check_chase_publish_one(asm, name):
+    body = function_body(asm, name)
     labels = {l.split(":")[0].strip(): i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)}
     waits = [i for i, l in enumerate(body) if l.strip() == "s_waitcnt vmcnt(0)" and i > 0 and "ASMSTART" in body[i - 1]]
     counter = re.compile(r"global_store_dword\s+v\d+, v\d+, s\[\d+:\d+\](?: offset:-?\d+)? sc1")
