@@ -1071,7 +1071,8 @@ static int nlml_fused_raw_plain(ffgp_handle* h, const ffgp_problem* p, const ffg
 
 __global__ void ffgp_adam_kernel(int F, ffgp_train_slot sl, const double* __restrict__ gbuf, double* __restrict__ state, long state_stride,
                                  double lr, double b1, double b2, double eps, double bc1, double bc2_sqrt, const double* __restrict__ loss,
-                                 double* __restrict__ trace, long trace_stride, int step, int* __restrict__ info, int fold) {
+                                 double* __restrict__ trace, long trace_stride, int step, int* __restrict__ info, int fold,
+                                 const double* __restrict__ geff, ffgp_links lk, int lD, double lsc) {
   const int f = blockIdx.x;
   if (f >= F) return;
   const int i0 = info[0], i1 = info[1];
@@ -1089,7 +1090,26 @@ __global__ void ffgp_adam_kernel(int F, ffgp_train_slot sl, const double* __rest
   const int i = threadIdx.x;
   if (i >= nw + 2) return;
   double* par = (i < nw) ? sl.w[f] + i : (i == nw ? sl.amp[f] : sl.dadd[f]);
-  const double g = gbuf[(size_t)f * FFGP_TRAIN_GSTRIDE + i];
+  double g;
+  if (geff) {
+    // (one model, blocked path: the gradients arrive with respect to the EFFECTIVE parameters [w (D) | amp | diag_add]; the links'
+    //  chain rule -- ffgp_link_bwd's arithmetic -- is applied here instead of in a launch of its own)
+    if (i < nw) {
+      if (!lk.w_broadcast) {
+        g = lsc * geff[i] * ffgp_link_der(lk.w_link, par[0], lk.w_c);
+      } else {
+        double sg = 0.0;
+        for (int k = 0; k < lD; ++k) sg += geff[k];
+        g = lsc * sg * ffgp_link_der(lk.w_link, par[0], lk.w_c);
+      }
+    } else if (i == nw) {
+      g = lsc * geff[lD] * ffgp_link_der(lk.amp_link, par[0], lk.amp_c);
+    } else {
+      g = lsc * geff[lD + 1] * ffgp_link_der(lk.dadd_link, par[0], lk.dadd_c);
+    }
+  } else {
+    g = gbuf[(size_t)f * FFGP_TRAIN_GSTRIDE + i];
+  }
   double* m = state + (size_t)f * state_stride + i;
   double* v = m + (nw + 2);
   const double m1 = m[0] + (g - m[0]) * (1.0 - b1);        // exp_avg.lerp_(grad, 1 - beta1)
@@ -1133,6 +1153,8 @@ int ffgp_train_raw(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_link
   }
   // the sticky status word starts clean: a failure of an EARLIER call on this handle is that call's to report
   FFGP_CHECK(ffgp_zero_async(h, h->d_info, 2 * sizeof(int)));
+  // (the one-kernel paths -- n <= 40, or option small_finish -- apply the links inside their kernel and write raw gradients)
+  const bool one_kernel = ffgp_small_ok(h, p, &g[0]) || ffgp_small2_ok(h, p, &g[0]);
   h->defer_info_copy = 1;      // (the per-call read-back of the status word: once, after the loop)
   h->fold_info = (F == 1) ? 1 : 0;   // one model: the Adam kernel clears / accumulates the status words (see ffgp_adam_kernel)
   int lrc = FFGP_OK;
@@ -1148,7 +1170,9 @@ int ffgp_train_raw(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_link
     const double t = (double)(step0 + k + 1);
     const double bc1 = 1.0 - std::pow(opt->beta1, t), bc2 = 1.0 - std::pow(opt->beta2, t);
     hipLaunchKernelGGL(ffgp_adam_kernel, dim3(F), dim3(192), 0, h->stream, F, sl, gbuf, state_dev, state_stride, opt->lr, opt->beta1,
-                       opt->beta2, opt->eps, bc1, std::sqrt(bc2), loss, trace_dev, trace_stride, k, h->d_info, h->fold_info);
+                       opt->beta2, opt->eps, bc1, std::sqrt(bc2), loss, trace_dev, trace_stride, k, h->d_info, h->fold_info,
+                       (h->fold_info && !one_kernel) ? h->d_link + 256 : (const double*)nullptr, lk[0], p[0].D,
+                       (lk[0].out_scale == 0.0) ? 1.0 : lk[0].out_scale);
   }
   h->defer_info_copy = 0;
   h->fold_info = 0;
@@ -1340,7 +1364,7 @@ static int nlml_fused_raw_plain(ffgp_handle* h, const ffgp_problem* p, const ffg
   }
   FFGP_CHECK(nlml_fused_enqueue(h, &q, nll_dev, gp));
   const double sc = (l->out_scale == 0.0) ? 1.0 : l->out_scale;
-  if (chain)
+  if (chain && !h->fold_info)      // (ffgp_train_raw with one model: the Adam kernel applies the links' chain rule itself)
     hipLaunchKernelGGL(ffgp_link_bwd, dim3(1), dim3(128), 0, h->stream, *l, D, p->w_dev, p->amp_dev, p->diag_add_dev, geff, g->g_w_dev,
                        g->g_amp_dev, g->g_diag_add_dev, sc);
   if (sc != 1.0) {

@@ -278,7 +278,8 @@ __global__ __launch_bounds__(256) void ffgp_grad_finish(const double* __restrict
 
 // tr(G) and diag(G)
 __global__ __launch_bounds__(1024) void ffgp_trace_kernel(const double* __restrict__ G, int ldg, int n,
-                                                          double* __restrict__ tr_out, double* __restrict__ diag_out) {
+                                                          double* __restrict__ tr_out, double* __restrict__ diag_out,
+                                                          double* __restrict__ tr_out2) {
   __shared__ double red[16];
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += 1024) {
@@ -293,6 +294,7 @@ __global__ __launch_bounds__(1024) void ffgp_trace_kernel(const double* __restri
     double t = 0.0;
     for (int i = 0; i < 16; ++i) t += red[i];
     tr_out[0] = t;
+    if (tr_out2) tr_out2[0] = t;      // (the noise gradient is tr G: no separate copy launch)
   }
 }
 
@@ -311,8 +313,7 @@ int ffgp_grad_impl(ffgp_handle* h, const double* X, int n, int D, const double* 
                    const double* G, int ldg, double mean_jitter, double* g_w, double* g_amp, double* g_diag_add,
                    double* g_diag_vec, double* partial_ws, int kfun, double kparam, double* g_kparam) {
   double* trG = h->d_scal + 4;
-  hipLaunchKernelGGL(ffgp_trace_kernel, dim3(1), dim3(1024), 0, h->stream, G, ldg, n, trG, g_diag_vec);
-  if (g_diag_add) hipLaunchKernelGGL(ffgp_copy_scalar, dim3(1), dim3(1), 0, h->stream, trG, g_diag_add);
+  hipLaunchKernelGGL(ffgp_trace_kernel, dim3(1), dim3(1024), 0, h->stream, G, ldg, n, trG, g_diag_vec, g_diag_add);
   if (g_w || g_amp || g_kparam) {
     const int tm = (n + AT - 1) / AT;
     const int ntiles = tm * (tm + 1) / 2;

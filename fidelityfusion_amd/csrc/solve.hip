@@ -268,8 +268,12 @@ static int trtri_levels(ffgp_handle* h, const double* L, int n, int ldl, double*
 
 int ffgp_trtri_impl(ffgp_handle* h, const double* L, int n, int ldl, double* X, int ldx, double* T) {
   FFGP_CHECK(ensure_dinv_for(h, L, n, ldl));
-  FFGP_CHECK(ffgp_zero_async(h, X, (size_t)n * ldx * sizeof(double)));
   const int nblk = (n + NB - 1) / NB;
+  if (n <= NB) {      // one diagonal block: the copy writes its zeros above the diagonal itself (a launch less per small-N step)
+    hipLaunchKernelGGL(ffgp_copy_dinv_kernel, dim3(NB * NB / 256, nblk), dim3(256), 0, h->stream, h->dinv, X, ldx, n, 1);
+    return FFGP_OK;
+  }
+  FFGP_CHECK(ffgp_zero_async(h, X, (size_t)n * ldx * sizeof(double)));
   hipLaunchKernelGGL(ffgp_copy_dinv_kernel, dim3(NB * NB / 256, nblk), dim3(256), 0, h->stream, h->dinv, X, ldx, n, 0);
   return trtri_levels(h, L, n, ldl, X, ldx, T);
 }
@@ -338,9 +342,12 @@ int ffgp_lauum_impl(ffgp_handle* h, const double* X, int n, int ldx, double* S, 
 // ------------------------------------------------------------------------------------------------------------
 #define RED_BLOCKS 512
 
+// (fin_out != null and a ONE-block launch: the block finishes the value itself -- stage 2 of a single partial sum is that sum, so the
+//  bits are those of the two-launch form; a launch saved on every small problem, d * n <= 256)
 __global__ __launch_bounds__(256) void ffgp_reduce_stage1(const double* __restrict__ M, int rows, int cols, int ldm,
                                                           const double* __restrict__ L, int n, int ldl,
-                                                          double* __restrict__ partial) {
+                                                          double* __restrict__ partial, double* __restrict__ fin_out, int fin_d,
+                                                          double fin_pi, double* __restrict__ fin_aux) {
   __shared__ double r1[4], r2[4];
   double ss = 0.0, lg = 0.0;
   const long total = (long)rows * cols;
@@ -360,8 +367,18 @@ __global__ __launch_bounds__(256) void ffgp_reduce_stage1(const double* __restri
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    partial[blockIdx.x] = r1[0] + r1[1] + r1[2] + r1[3];
-    partial[RED_BLOCKS + blockIdx.x] = r2[0] + r2[1] + r2[2] + r2[3];
+    const double ssb = r1[0] + r1[1] + r1[2] + r1[3], lgb = r2[0] + r2[1] + r2[2] + r2[3];
+    partial[blockIdx.x] = ssb;
+    partial[RED_BLOCKS + blockIdx.x] = lgb;
+    if (fin_out && gridDim.x == 1) {
+      // what ffgp_reduce_stage2 computes from one partial: the wave sums of (ssb, 0, 0, ...) and the 4-term sum of (ssb, 0, 0, 0)
+      const double ss2 = ((ssb + 0.0) + 0.0) + 0.0, lg2 = ((lgb + 0.0) + 0.0) + 0.0;
+      fin_out[0] = 0.5 * ss2 + (double)fin_d * lg2 + 0.5 * (double)n * (double)fin_d * log(2.0 * fin_pi);
+      if (fin_aux) {
+        fin_aux[0] = ss2;
+        fin_aux[1] = lg2;
+      }
+    }
   }
 }
 
@@ -492,9 +509,15 @@ int ffgp_nll_reduce_impl(ffgp_handle* h, int variant, const double* L, int n, in
   int blocks = (int)((total + 255) / 256);
   if (blocks > RED_BLOCKS) blocks = RED_BLOCKS;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(ffgp_reduce_stage1, dim3(blocks), dim3(256), 0, h->stream, M, rows, cols, ldm, L, n, ldl, partial);
-  hipLaunchKernelGGL(ffgp_reduce_stage2, dim3(1), dim3(256), 0, h->stream, partial, blocks, variant, n, d, pi_const, out_dev,
-                     h->d_scal + 8);
+  if (blocks == 1) {
+    hipLaunchKernelGGL(ffgp_reduce_stage1, dim3(1), dim3(256), 0, h->stream, M, rows, cols, ldm, L, n, ldl, partial, out_dev, d, pi_const,
+                       h->d_scal + 8);
+  } else {
+    hipLaunchKernelGGL(ffgp_reduce_stage1, dim3(blocks), dim3(256), 0, h->stream, M, rows, cols, ldm, L, n, ldl, partial, (double*)nullptr, 0,
+                       0.0, (double*)nullptr);
+    hipLaunchKernelGGL(ffgp_reduce_stage2, dim3(1), dim3(256), 0, h->stream, partial, blocks, variant, n, d, pi_const, out_dev,
+                       h->d_scal + 8);
+  }
   if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
   return FFGP_OK;
 }
