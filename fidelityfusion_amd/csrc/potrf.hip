@@ -1713,6 +1713,10 @@ int ffgp_potrf_ragged(ffgp_handle* h, int R, const ffgp_rag_block* mem) {
   }
   hipStream_t main_s = h->stream;
   hipStream_t chain_s = any_la ? h->aux : main_s;
+  struct StreamGuard {      // whatever path leaves this function (the FFGP_HIP macros return at once), the handle gets its stream back
+    ffgp_handle* h; hipStream_t s;
+    ~StreamGuard() { h->stream = s; }
+  } guard{h, main_s};
   if (any_la) {
     FFGP_HIP(hipEventRecord(h->la_ev[6], main_s));
     FFGP_HIP(hipStreamWaitEvent(chain_s, h->la_ev[6], 0));
