@@ -35,6 +35,13 @@ int main() {
     EXPECT(ffgp_potrf(nullptr, &x, 1, 2) < 0);
     EXPECT(ffgp_nlml_fused(nullptr, &p, &x, nullptr) < 0);
     EXPECT(ffgp_wait(nullptr) < 0);
+    // round 5: the batched / ragged likelihood and the K-steps-per-call training entry refuse a NULL handle before touching anything
+    ffgp_links lk;
+    std::memset(&lk, 0, sizeof lk);
+    ffgp_adam ad = {1e-2, 0.9, 0.999, 1e-8};
+    int st[2] = {0, 0};
+    EXPECT(ffgp_nlml_fused_batch(nullptr, 2, &p, &lk, &x, nullptr, st) < 0);
+    EXPECT(ffgp_train_raw(nullptr, 1, &p, &lk, 3, &ad, &x, 8, 0, &x, 3) < 0);
     ffgp_kdesc kd[2];
     ffgp_kdesc_grads kg[2];
     std::memset(kd, 0, sizeof kd);
