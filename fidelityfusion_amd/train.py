@@ -14,6 +14,7 @@ from ._common import _raise_not_pd
 from ._lib import FFGP_LL_V1, Problem, check, lib
 
 TRAIN_MAX_MODELS = 16      # models per ffgp_train_raw call (include/ffgp.h); longer lists are trained in chunks
+TRAIN_THREADS = 4          # host threads (handle + stream each) that train the larger models of one call side by side
 
 
 class AdamState:
@@ -90,51 +91,84 @@ def train_many(models, xs, ys, steps, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, sta
             raise ValueError("train_many: this state belongs to fused training; the models no longer qualify for it")
         return _reference_loop(models, xs, ys, steps, lr, betas, eps, state["opts"]), state
     JITTER, PI = _jitter_and_pi()
+    from . import functional as F
+    from .blocks import threaded_blocks
     dev = xs[0].device
-    h = _lib.handle(dev.index, 0)
-    _lib.bind_stream(h, dev.index)
     trace = torch.empty((nF, steps), dtype=torch.float64, device=dev)
     opt = _lib.Adam(float(lr), float(betas[0]), float(betas[1]), float(eps))
-    for c0 in range(0, nF, TRAIN_MAX_MODELS):
-        idx = list(range(c0, min(nF, c0 + TRAIN_MAX_MODELS)))
+
+    def describe(f):
+        lk, y, y_var = elig[f]
+        x, m = xs[f], models[f]
+        n, D = x.shape
+        p = Problem()
+        p.n, p.D, p.d = n, D, y.shape[1]
+        p.X_dev, p.Y_dev, p.w_dev, p.amp_dev = x.data_ptr(), y.data_ptr(), lk["w"].data_ptr(), lk["amp"].data_ptr()
+        p.diag_add_dev = m.log_beta.data_ptr()
+        p.clamp_min = lk["clamp"]
+        if y_var is not None:
+            p.diag_stride = y_var.shape[1] + 1 if y_var.dim() == 2 else 1
+            p.diag_vec_dev = y_var.data_ptr()
+        p.ll_variant, p.pi_const = FFGP_LL_V1, PI
+        kp = lk.get("kparam")
+        p.kfun, p.kparam = lk["kfun"], (1.0 if kp is None else float(kp))
+        ll = _lib.Links()
+        ll.w_link, ll.w_c, ll.w_broadcast = lk["w_link"], lk["w_c"], 1 if lk["w"].numel() == 1 and D > 1 else 0
+        ll.amp_link, ll.amp_c = lk["amp_link"], 0.0
+        ll.dadd_link, ll.dadd_c = _lib.LINK_EXP_NEG, JITTER
+        ll.out_scale = 1.0          # the value is the loss the reference minimises: -negative_log_likelihood = +nll
+        return p, ll, lk["w"].numel()
+
+    def run(idx):
+        """one ffgp_train_raw call for the models `idx` (<= 16) on the calling thread's handle and stream; returns the status"""
+        h = _lib.handle(dev.index)
+        _lib.bind_stream(h, dev.index)
         P = (Problem * len(idx))()
         L = (_lib.Links * len(idx))()
         nws = []
         for j, f in enumerate(idx):
-            lk, y, y_var = elig[f]
-            x, m = xs[f], models[f]
-            n, D = x.shape
-            p = P[j]
-            p.n, p.D, p.d = n, D, y.shape[1]
-            p.X_dev, p.Y_dev, p.w_dev, p.amp_dev = x.data_ptr(), y.data_ptr(), lk["w"].data_ptr(), lk["amp"].data_ptr()
-            p.diag_add_dev = m.log_beta.data_ptr()
-            p.clamp_min = lk["clamp"]
-            if y_var is not None:
-                p.diag_stride = y_var.shape[1] + 1 if y_var.dim() == 2 else 1
-                p.diag_vec_dev = y_var.data_ptr()
-            p.ll_variant, p.pi_const = FFGP_LL_V1, PI
-            kp = lk.get("kparam")
-            p.kfun, p.kparam = lk["kfun"], (1.0 if kp is None else float(kp))
-            ll = L[j]
-            ll.w_link, ll.w_c, ll.w_broadcast = lk["w_link"], lk["w_c"], 1 if lk["w"].numel() == 1 and D > 1 else 0
-            ll.amp_link, ll.amp_c = lk["amp_link"], 0.0
-            ll.dadd_link, ll.dadd_c = _lib.LINK_EXP_NEG, JITTER
-            ll.out_scale = 1.0          # the value is the loss the reference minimises: -negative_log_likelihood = +nll
-            nws.append(lk["w"].numel())
+            P[j], L[j], nw = describe(f)
+            nws.append(nw)
         stride = 2 * (max(nws) + 2)
-        st = state["chunks"].get(c0)
-        if st is None or st.stride != stride or st.buf.shape[0] != len(idx) or st.buf.device != dev:
+        key = tuple(idx)
+        st = state["chunks"].get(key)
+        if st is None or st.stride != stride or st.buf.device != dev:
             st = AdamState(torch.zeros((len(idx), stride), dtype=torch.float64, device=dev), stride)
-            state["chunks"][c0] = st
-        tr = trace[c0:c0 + len(idx)]
+            state["chunks"][key] = st
+        # the chunk's rows of the trace: contiguous when the models are consecutive, else through a staging block
+        contiguous = list(idx) == list(range(idx[0], idx[0] + len(idx)))
+        tr = trace[idx[0]:idx[0] + len(idx)] if contiguous else torch.empty((len(idx), steps), dtype=torch.float64, device=dev)
         rc = check(lib.ffgp_train_raw(h, len(idx), P, L, int(steps), C.byref(opt), st.buf.data_ptr(), stride, int(st.step),
-                                      tr.data_ptr(), trace.stride(0)), "ffgp_train_raw")
+                                      tr.data_ptr(), tr.stride(0)), "ffgp_train_raw")
         st.step += steps
-        # the library wrote the parameters behind autograd's back: bump their version counters (cached posteriors key on them)
-        with torch.no_grad():
-            for f in idx:
-                for q in models[f].parameters():
-                    q.add_(0.0)
+        if not contiguous:
+            trace[list(idx)] = tr
+        return rc
+
+    # small models (one workgroup each: ONE launch per step for up to 16 of them) go together; every larger model is a call of its
+    # own -- and, when there are several, they train SIDE BY SIDE from host threads with a handle and a stream each
+    # (blocks.threaded_blocks: the calls only enqueue and wait once, ctypes drops the GIL inside them), so that one model's
+    # latency-bound chain of small kernels runs in the gaps of the others'
+    shapes = [(xs[f].shape[0], xs[f].shape[1], elig[f][1].shape[1]) for f in range(nF)]
+    small = [f for f in range(nF) if shapes[f][0] <= F.SMALL_BATCH_MAX_N and shapes[f][1] <= F.SMALL_BATCH_MAX_D
+             and shapes[f][2] <= F.SMALL_BATCH_MAX_d]
+    large = [f for f in range(nF) if f not in set(small)]
+    if len(small) == 1:      # (a lone small model gains nothing from the batch kernel: its own call folds the tail launches)
+        large, small = sorted(large + small), []
+    rcs = []
+    for c0 in range(0, len(small), TRAIN_MAX_MODELS):
+        rcs.append((small[c0:c0 + TRAIN_MAX_MODELS], run(small[c0:c0 + TRAIN_MAX_MODELS])))
+    if len(large) >= 2 and _lib.current_slot() == 0:
+        outs = threaded_blocks([(lambda f=f: run([f])) for f in large], nslots=min(TRAIN_THREADS, len(large)), device_index=dev.index)
+        rcs += [([f], rc) for f, rc in zip(large, outs)]
+    else:
+        rcs += [([f], run([f])) for f in large]
+    # the library wrote the parameters behind autograd's back: bump their version counters (cached posteriors key on them)
+    with torch.no_grad():
+        for m in models:
+            for q in m.parameters():
+                q.add_(0.0)
+    for idx, rc in rcs:
         if rc > 0:
-            _raise_not_pd(rc, "linalg.cholesky (train_many, models %d..%d)" % (idx[0], idx[-1]))
+            _raise_not_pd(rc, "linalg.cholesky (train_many, model%s %s)" % ("s" if len(idx) > 1 else "", ", ".join(map(str, idx))))
     return trace, state

@@ -82,7 +82,8 @@ def params_of(m):
     ([(300, 5, 2)], ["matern"]),                            # the blocked path, in order
     ([(700, 2, 3)], ["se"]),                                # scalar log length scale (broadcast), blocked path
     ([(60, 3, 1), (128, 2, 2), (17, 4, 1)], None),          # three small models: ONE launch per step for all
-    ([(60, 3, 1), (400, 2, 2), (90, 16, 1)], ["ard", "se", "ard"]),   # a mix: model after model inside the step
+    ([(60, 3, 1), (400, 2, 2), (90, 16, 1)], ["ard", "se", "ard"]),   # a mix: the two small ones in one call, the larger one in its own
+    ([(300, 3, 1), (513, 2, 2), (250, 4, 1)], ["ard", "matern", "se"]),   # three larger models: side by side from host threads
 ])
 def test_train_many_follows_the_reference_loop(shapes, kinds):
     from fidelityfusion_amd.cigp_v10 import train_many

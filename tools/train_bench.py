@@ -41,7 +41,7 @@ def loop(ms, xs, ys, k):
             opt.step()
 
 
-for n, D, d, F in ((32, 5, 1, 1), (128, 5, 1, 1), (256, 5, 1, 1), (512, 5, 1, 1), (1024, 8, 1, 1), (128, 5, 1, 8), (64, 5, 1, 16)):
+for n, D, d, F in ((32, 5, 1, 1), (128, 5, 1, 1), (256, 5, 1, 1), (512, 5, 1, 1), (1024, 8, 1, 1), (128, 5, 1, 8), (64, 5, 1, 16), (300, 5, 1, 3), (512, 5, 1, 4), (1024, 8, 1, 4)):
     ms, xs, ys = make(n, D, d, F)
     train_many(ms, xs, ys, 5)
     torch.cuda.synchronize()
