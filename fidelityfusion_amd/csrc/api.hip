@@ -243,6 +243,8 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->aux_prio = 1;
   h->nb_outer = 512;
   h->diag_v2 = 4;
+  h->trsm128 = 1;
+  h->trsm128_max_m = 8192;
   h->trtri_overlap = 1;
   h->trtri_fill = 0;
   h->raw_graph_max_n = 0;
@@ -365,6 +367,10 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->small_tile_threshold = (int)value;
   } else if (!strcmp(key, "tile32_threshold")) {
     h->tile32_threshold = (int)value;
+  } else if (!strcmp(key, "trsm128")) {
+    h->trsm128 = value != 0.0;
+  } else if (!strcmp(key, "trsm128_max_m")) {
+    h->trsm128_max_m = (int)value;
   } else if (!strcmp(key, "diag_v2")) {
     h->diag_v2 = (int)value;
   } else if (!strcmp(key, "diag_dbg")) {

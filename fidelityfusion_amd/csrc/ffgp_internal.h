@@ -152,6 +152,8 @@ struct ffgp_handle {
   int force_ts;         // 0 = automatic GEMM tile shape, 32 / 64 / 128 = forced (benchmarks, tests)
   int small_tile_threshold;  // launches with fewer 128-tiles than this use the 64-tile
   int tile32_threshold;      // K-major launches with fewer 64-tiles than this use 32-row tiles
+  int trsm128;          // 1 = the chain's full-block TRSM runs on its own kernel (ffgp_trsm128_kernel; same values as the general GEMM)
+  int trsm128_max_m;    // ... for panels of at most this many rows (taller ones stay on the general GEMM)
   int diag_dbg;         // timing-only ablation mask of potrf_diag128 (0 in production)
   int diag_v2;          // diagonal-block kernel: 4 = round-4 kernel (default: owner-computes helpers, wave 0's SIMD partner steps aside), 1 = round-3 pipeline with the DP-ALU DPP pivot step, 3 = round-3 pipeline as it was, 0 = barrier version
   int la_split;         // 1 = issue the look-ahead part of the trailing update in two launches (first 128 columns first)

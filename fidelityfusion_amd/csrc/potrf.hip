@@ -1266,6 +1266,156 @@ __global__ __launch_bounds__(128) void ffgp_dinv_naive(const double* L, int ldl,
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The chain's TRSM as its own kernel (round 5): X = A21 * Dinv^T in place for one full 128-column block.
+// The general GEMM spends 128 MFMAs per wave on a 32 x 128 tile of this product -- half of them on Dinv's zero upper triangle -- behind
+// eight k-tile barriers and a 40 KiB LDS stage.  Here a workgroup owns 16 rows: they go to LDS once (one barrier) and from there into
+// registers as MFMA operands in one batch; wave w owns the 16-column blocks w and 7 - w of the output (4 (w + 1) + 4 (8 - w) = 36 MFMA
+// k-steps for every wave: the triangle is balanced across the four waves) and fetches those blocks' rows of Dinv straight from L2 into
+// registers (no LDS image of Dinv: the kernel must fit beside a resident trailing-update workgroup; 17 KiB of LDS does).
+// The values are the general GEMM's bit for bit: per output element the same v_mfma_f64_16x16x4 chain over k = 0, 4, 8, ... from a zero
+// accumulator, minus the k-steps in which every Dinv operand is a structural zero (adding 0 * a changes nothing) -- so this kernel and
+// the general one are interchangeable launch by launch and member by member: partial last blocks, odd leading dimensions and very tall
+// panels stay on the general GEMM, and a shared chain (ffgp_nlml_fused_batch) still equals the single call whichever kernel each took.
+// Measured (profiles/r05e_*): 7.7 us per launch against 11.0 (an empty dependent launch with the same stores: 5.0); forward at
+// N = 1024 / 2048 / 4096 / 8192: -5.6 / -5.4 / -4.8 / -1.6 %.
+// ------------------------------------------------------------------------------------------------------------
+#define TRSM_LDS_LD 130   // doubles per LDS row: 2 mod 32 -> the 16 rows x 2 k-values a 32-lane half reads hit 32 distinct 8-byte banks
+
+// One 16-byte load per lane fetches the k-pair {8p + 2kk, 8p + 2kk + 1} of the lane's row (kk = lane / 16: 64 contiguous bytes per row and
+// instruction -- half the cache-line requests of one 8-byte load per MFMA k-step); the MFMA operand of k-step 2p wants k = 8p + kk in lane
+// group kk, that of k-step 2p + 1 wants 8p + 4 + kk.  Two of gfx950's row swaps per 32-bit half re-deal the four 16-lane rows:
+// v_permlane16_swap (x.row1 <-> y.row0, x.row3 <-> y.row2), then v_permlane32_swap (x.rows23 <-> y.rows01).
+__device__ __forceinline__ void kpair_to_ksteps(d2_t in, double& u, double& v) {
+  const unsigned long long xb = __builtin_bit_cast(unsigned long long, (double)in.x), yb = __builtin_bit_cast(unsigned long long, (double)in.y);
+  auto l1 = __builtin_amdgcn_permlane16_swap((unsigned)xb, (unsigned)yb, false, false);
+  auto l2 = __builtin_amdgcn_permlane32_swap(l1[0], l1[1], false, false);
+  auto h1 = __builtin_amdgcn_permlane16_swap((unsigned)(xb >> 32), (unsigned)(yb >> 32), false, false);
+  auto h2 = __builtin_amdgcn_permlane32_swap(h1[0], h1[1], false, false);
+  u = __builtin_bit_cast(double, ((unsigned long long)h2[0] << 32) | l2[0]);
+  v = __builtin_bit_cast(double, ((unsigned long long)h2[1] << 32) | l2[1]);
+}
+
+// members of one launch (blockIdx.y): MEMB = 0 one matrix or a batch at fixed strides (ffgp_nlml_fused_batch's uniform chain), MEMB = 1 up
+// to FFGP_RAG_MAX matrices of different sizes from a by-value table (the ragged chain; a member's surplus workgroups exit at once)
+struct TrsmSet {
+  double* A[FFGP_RAG_MAX];
+  const double* D[FFGP_RAG_MAX];
+  int lda[FFGP_RAG_MAX];
+  int mrows[FFGP_RAG_MAX];
+};
+
+template <int MEMB>
+__global__ __launch_bounds__(256) void ffgp_trsm128_kernel(double* __restrict__ A, int lda, int mrows, const double* __restrict__ Dinv,
+                                                           int prio, long sA_, long sD_, TrsmSet set) {
+  __shared__ __attribute__((aligned(16))) double sA[16 * TRSM_LDS_LD];
+  if (prio) __builtin_amdgcn_s_setprio(2);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r0 = blockIdx.x * 16;
+  if (MEMB) {
+    const int f = blockIdx.y;
+    A = set.A[f];
+    Dinv = set.D[f];
+    lda = set.lda[f];
+    mrows = set.mrows[f];
+    if (r0 >= mrows) return;
+  } else {
+    A += (size_t)blockIdx.y * sA_;
+    Dinv += (size_t)blockIdx.y * sD_;
+  }
+  d2_t va[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i, row = idx >> 6, c2 = idx & 63;
+    const int gr = r0 + row;
+    va[i] = (d2_t){0.0, 0.0};
+    if (gr < mrows) va[i] = *reinterpret_cast<const d2_t*>(A + (size_t)gr * lda + 2 * c2);
+  }
+  const int bL = wave, bH = 7 - wave;
+  const int j = lane & 15, kk = lane >> 4;
+  const double* dH = Dinv + (size_t)(16 * bH + j) * NB + 2 * kk;
+  const double* dL = Dinv + (size_t)(16 * bL + j) * NB + 2 * kk;
+  d2_t rh[16], rl[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    if (c <= bH) {
+      rh[2 * c] = *reinterpret_cast<const d2_t*>(dH + 16 * c);
+      rh[2 * c + 1] = *reinterpret_cast<const d2_t*>(dH + 16 * c + 8);
+    }
+    if (c < 4 && c <= bL) {
+      rl[2 * c] = *reinterpret_cast<const d2_t*>(dL + 16 * c);
+      rl[2 * c + 1] = *reinterpret_cast<const d2_t*>(dL + 16 * c + 8);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i, row = idx >> 6, c2 = idx & 63;
+    *reinterpret_cast<d2_t*>(sA + row * TRSM_LDS_LD + 2 * c2) = va[i];
+  }
+  __syncthreads();
+  // every A operand of the wave's k range into registers in one batch (an LDS round trip per MFMA would double the chain)
+  const double* aP = sA + j * TRSM_LDS_LD + kk;
+  double a[32];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    if (c <= bH) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a[4 * c + q] = aP[16 * c + 4 * q];
+    }
+  }
+  d4_t accL = {0.0, 0.0, 0.0, 0.0}, accH = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    if (c <= bH) {
+      double bh[4], bl[4];
+      kpair_to_ksteps(rh[2 * c], bh[0], bh[1]);
+      kpair_to_ksteps(rh[2 * c + 1], bh[2], bh[3]);
+      const bool low = (c < 4 && c <= bL);
+      if (low) {
+        kpair_to_ksteps(rl[(2 * c) & 7], bl[0], bl[1]);
+        kpair_to_ksteps(rl[(2 * c + 1) & 7], bl[2], bl[3]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        accH = __builtin_amdgcn_mfma_f64_16x16x4f64(a[4 * c + q], bh[q], accH, 0, 0, 0);
+        if (low) accL = __builtin_amdgcn_mfma_f64_16x16x4f64(a[4 * c + q], bl[q], accL, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = r0 + kk + 4 * r;
+    if (row < mrows) {
+      double* out = A + (size_t)row * lda + j;
+      out[16 * bL] = accL[r];
+      out[16 * bH] = accH[r];
+    }
+  }
+}
+
+// the dedicated kernel takes full 128-column blocks with 16-byte aligned rows; very tall panels stay on the general GEMM (from ~8000 rows
+// -- of all members of a shared chain's launch together -- the 16-row workgroups outnumber the chip's slots twice over and the launch is
+// no longer latency-bound: measured 0.5 % slower at C3, 1.1 % slower on 8 chained blocks of N = 8192)
+static bool trsm128_fits(const ffgp_handle* h, const double* A21, int lda, int jb, int mrows) {
+  return h->trsm128 && jb == NB && mrows <= h->trsm128_max_m && !(lda & 1) && ((uintptr_t)A21 & 15) == 0;
+}
+
+static int launch_trsm128(ffgp_handle* h, double* A21, int lda, int mrows, const double* Dj) {
+  const int prio = (h->stream == h->aux && h->aux_prio) ? 1 : 0;
+  const int F = h->bt_F > 1 ? h->bt_F : 1;
+  hipLaunchKernelGGL(ffgp_trsm128_kernel<0>, dim3((mrows + 15) / 16, F), dim3(256), 0, h->stream, A21, lda, mrows, Dj, prio,
+                     F > 1 ? h->bt_sA : 0L, F > 1 ? h->bt_sD : 0L, TrsmSet());
+  return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
+}
+
+static int launch_trsm128_set(ffgp_handle* h, const TrsmSet& set, int cnt, int max_rows) {
+  const int prio = (h->stream == h->aux && h->aux_prio) ? 1 : 0;
+  hipLaunchKernelGGL(ffgp_trsm128_kernel<1>, dim3((max_rows + 15) / 16, cnt), dim3(256), 0, h->stream, (double*)nullptr, 0, 0,
+                     (const double*)nullptr, prio, 0L, 0L, set);
+  return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
 static int launch_diag(ffgp_handle* h, double* Ablk, int lda, int nb, double* Dinv_blk, int row_base, int do_factor) {
@@ -1399,8 +1549,11 @@ static int factor_panel(ffgp_handle* h, double* A, int n, int mtot, int lda, int
     if (mrows > 0) {
       double* A21 = A + (size_t)(j0 + jb) * lda + j0;
       // TRSM as GEMM: A21 <- A21 * Dj^T (in place: one column tile, each workgroup rewrites only rows it read)
-      FFGP_CHECK(potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, A21, lda, Dj, NB, A21, lda, mrows, jb, jb, 1.0, 0.0, 0,
-                            ALIAS_A, true));
+      if (trsm128_fits(h, A21, lda, jb, mrows * max(1, h->bt_F)) && (h->bt_F <= 1 || !(h->bt_sA & 1)))
+        FFGP_CHECK(launch_trsm128(h, A21, lda, mrows, Dj));
+      else
+        FFGP_CHECK(potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, A21, lda, Dj, NB, A21, lda, mrows, jb, jb, 1.0, 0.0, 0,
+                              ALIAS_A, true));
       const int wrem = pend - (j0 + jb) + carry;
       if (wrem > 0) {
         if (gate && j0 == k0) FFGP_HIP(hipStreamWaitEvent(h->stream, gate, 0));
@@ -1751,6 +1904,12 @@ int ffgp_potrf_ragged(ffgp_handle* h, int R, const ffgp_rag_block* mem) {
       }
       // TRSM of every row below: A21 <- A21 * Dj^T, in place
       in.clear();
+      TrsmSet ts = TrsmSet();
+      int tcnt = 0, tmax = 0;
+      long rows_all = 0;
+      for (int f = 0; f < R; ++f)
+        if (j0 < mem[f].n) rows_all += max(0, mem[f].mtot - (j0 + min(NB, mem[f].n - j0)));
+      const bool own_kernel = rows_all <= h->trsm128_max_m;
       for (int f = 0; f < R; ++f) {
         const ffgp_rag_block& b = mem[f];
         if (j0 >= b.n) continue;
@@ -1758,9 +1917,20 @@ int ffgp_potrf_ragged(ffgp_handle* h, int R, const ffgp_rag_block* mem) {
         if (mrows <= 0) continue;
         double* A21 = b.A + (size_t)(j0 + jb) * b.lda + j0;
         double* Dj = b.dinv + (size_t)(j0 / NB) * NB * NB;
-        in.push_back(GemmRagIn{A21, b.lda, Dj, NB, A21, b.lda, mrows, jb, jb});
+        if (own_kernel && trsm128_fits(h, A21, b.lda, jb, mrows)) {      // (same values as the general GEMM: members may take either, one by one)
+          ts.A[tcnt] = A21; ts.D[tcnt] = Dj; ts.lda[tcnt] = b.lda; ts.mrows[tcnt] = mrows;
+          tmax = max(tmax, mrows);
+          if (++tcnt == FFGP_RAG_MAX) {
+            rc = launch_trsm128_set(h, ts, tcnt, tmax);
+            tcnt = tmax = 0;
+            if (rc != FFGP_OK) break;
+          }
+        } else {
+          in.push_back(GemmRagIn{A21, b.lda, Dj, NB, A21, b.lda, mrows, jb, jb});
+        }
       }
-      if (!in.empty()) rc = ffgp_gemm_launch_rag(h, TILES_FULL, 0, (int)in.size(), in.data(), 1.0, 0.0, ALIAS_A);
+      if (rc == FFGP_OK && tcnt) rc = launch_trsm128_set(h, ts, tcnt, tmax);
+      if (rc == FFGP_OK && !in.empty()) rc = ffgp_gemm_launch_rag(h, TILES_FULL, 0, (int)in.size(), in.data(), 1.0, 0.0, ALIAS_A);
       if (rc != FFGP_OK) break;
       // update of the panel's remaining columns (look-ahead members: and of the next panel's first block, the carry)
       in.clear();

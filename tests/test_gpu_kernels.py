@@ -362,6 +362,31 @@ def test_potrf_around_the_lookahead_threshold(ff, n):
     assert relerr(np.tril(out[:n, :n]), np.linalg.cholesky(S)) < 1e-11
 
 
+@pytest.mark.parametrize("n,m", [(129, 0), (300, 0), (700, 45), (1537, 3), (4000, 130)])
+def test_potrf_block_trsm_kernel_is_the_general_gemm_bit_for_bit(ff, n, m):
+    """the chain's own TRSM kernel (ffgp_trsm128_kernel: the triangle's zero k-steps skipped, operands re-dealt across lanes) against the
+    same factorisation with the TRSM on the general GEMM (option trsm128 = 0): every element of the factor and of the passenger rows
+    identical, ragged row tails and a partial last block (which stays on the general GEMM) included"""
+    _lib, h = ff
+    rng = np.random.default_rng(n + m)
+    B = rng.standard_normal((n, 56))
+    S = B @ B.T + np.diag(rng.random(n) + 0.5)
+    R = rng.standard_normal((m, n)) if m else None
+    outs = {}
+    try:
+        for on in (1, 0):
+            assert _lib.lib.ffgp_set_option(h, b"trsm128", float(on)) == 0
+            rc, out, _, _ = potrf(ff, S, R)
+            assert rc == 0
+            outs[on] = out
+    finally:
+        _lib.lib.ffgp_set_option(h, b"trsm128", 1.0)
+    low = np.tril_indices(n)
+    assert np.array_equal(outs[1][:n, :n][low], outs[0][:n, :n][low])
+    assert np.array_equal(outs[1][n:, :n], outs[0][n:, :n])
+    assert relerr(np.tril(outs[1][:n, :n]), np.linalg.cholesky(S)) < 1e-11
+
+
 def test_potrf_naive_kernels_agree(ff):
     rng = np.random.default_rng(2)
     S = spd(200, rng)
