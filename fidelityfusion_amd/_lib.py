@@ -85,6 +85,7 @@ EXPORTS = {
     # name: (restype, argtypes)
     "ffgp_version": (C.c_char_p, []),
     "ffgp_has_dev_options": (C.c_int, []),
+    "ffgp_graph_replays": (C.c_long, [C.c_void_p]),
     "ffgp_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "ffgp_destroy": (C.c_int, [C.c_void_p]),
     "ffgp_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),

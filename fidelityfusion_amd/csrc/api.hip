@@ -130,6 +130,8 @@ const char* ffgp_version(void) { return "ffgp 0.2 (gfx950, fp64 MFMA)"; }
 int ffgp_has_dev_options(void) { return 0; }
 #endif
 
+long ffgp_graph_replays(const ffgp_handle* h) { return h ? h->graph_replays : -1; }
+
 struct RawGraph {
   ffgp_problem p;
   ffgp_links l;
@@ -144,8 +146,7 @@ struct RawGraph {
   long stage_len;
 };
 
-static void rawg_drop(ffgp_handle* h) {
-  RawGraph* r = h->rawg;
+static void rawg_drop_one(RawGraph* r) {
   if (!r) return;
   if (r->valid) {
     hipGraphExecDestroy(r->exec);
@@ -153,6 +154,11 @@ static void rawg_drop(ffgp_handle* h) {
   }
   r->valid = false;
   r->seen = 0;
+}
+
+static void rawg_drop(ffgp_handle* h) {
+  rawg_drop_one(h->rawg);
+  rawg_drop_one(h->fwdg);
 }
 
 static int create_resources(ffgp_handle* h) {
@@ -248,6 +254,9 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->trtri_overlap = 1;
   h->trtri_fill = 0;
   h->raw_graph_max_n = 0;
+  h->fwd_graph = 0;
+  h->graph_replays = 0;
+  h->fwdg = nullptr;
   h->small2_off = 1;
   h->q2_wave4 = 1;
   h->sb_qr4 = 0;
@@ -293,8 +302,13 @@ int ffgp_destroy(ffgp_handle* h) {
   if (h->bt_info_host) hipHostFree(h->bt_info_host);
   if (h->d_scal) hipFree(h->d_scal);
   if (h->d_asm) hipFree(h->d_asm);
+  rawg_drop(h);
+  if (h->fwdg) {
+    if (h->fwdg->stage) hipFree(h->fwdg->stage);
+    delete h->fwdg;
+    h->fwdg = nullptr;
+  }
   if (h->rawg) {
-    rawg_drop(h);
     if (h->rawg->stage) hipFree(h->rawg->stage);
     delete h->rawg;
     h->rawg = nullptr;
@@ -367,6 +381,8 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->small_tile_threshold = (int)value;
   } else if (!strcmp(key, "tile32_threshold")) {
     h->tile32_threshold = (int)value;
+  } else if (!strcmp(key, "fwd_graph")) {
+    h->fwd_graph = value != 0.0;
   } else if (!strcmp(key, "trsm128")) {
     h->trsm128 = value != 0.0;
   } else if (!strcmp(key, "trsm128_max_m")) {
@@ -1383,7 +1399,80 @@ static int nlml_fused_raw_plain(ffgp_handle* h, const ffgp_problem* p, const ffg
   return FFGP_OK;
 }
 
+// ---- the forward call as one captured graph (option "fwd_graph", default 0) ---------------------------------------------------
+// A likelihood at N = 16384 is ~400 launches on two streams, issued by ONE host thread a few microseconds ahead of the GPU: on a busy
+// host the step stretches (29 -> 35 ms was seen).  With the option on, the second identical forward-only call (same
+// problem struct: same device buffers, sizes, options) is captured -- both streams: the side stream forks from and joins the capturing
+// stream through the look-ahead's own events -- into a hipGraph that writes its value to a handle-owned slot, and from then on every
+// such call is ONE hipGraphLaunch plus a one-word copy into the caller's output.  Same kernels, same order per stream, same values
+// (test_forward_graph_replay); dropped with any option or buffer change.  Calls with gradients, with stage timing, or on the small-N
+// paths are never captured.
+// MEASURED (tools/host_load_probe.py, ROCm 7.2): idle host 28.65-29.02 ms launch by launch, 28.83-29.12 ms as a graph at N = 16384;
+// 1.84 against 2.25-2.32 ms at N = 4096; with the pod's CPU quota exhausted by spinning processes both take exactly one cgroup period
+// (100.0 ms) per step.  The runtime walks the graph's nodes on a host thread and issues them one by one: a graph does not take the host
+// out of the step here.  What does help a multi-rank run is bench.py's per-rank CPU affinity.  Default off.
+static int nlml_fused_plain(ffgp_handle* h, const ffgp_problem* p, double* nll_dev, const ffgp_grads* g);
+
 static int nlml_fused_enqueue(ffgp_handle* h, const ffgp_problem* p, double* nll_dev, const ffgp_grads* g) {
+  if (!h || !p || !nll_dev) return FFGP_ERR_ARG;
+  const bool wants_grad = g && (g->g_w_dev || g->g_amp_dev || g->g_diag_add_dev || g->g_Y_dev || g->g_diag_vec_dev || g->g_cov_dev ||
+                                g->g_kparam_dev || g->g_pair);
+  const bool eligible = h->fwd_graph && !wants_grad && h->timing == 0 && p->n > FFGP_NB && !h->use_naive;
+  if (!eligible) return nlml_fused_plain(h, p, nll_dev, g);
+  if (!h->fwdg) {
+    h->fwdg = new RawGraph();
+    memset(h->fwdg, 0, sizeof(RawGraph));
+  }
+  RawGraph* r = h->fwdg;
+  const bool same = (r->seen || r->valid) && !memcmp(&r->p, p, sizeof(ffgp_problem)) && r->epoch == h->alloc_epoch;
+  FFGP_HIP(hipSetDevice(h->device));
+  auto replay = [&]() -> int {
+    FFGP_HIP(hipGraphLaunch(r->exec, h->stream));
+    hipLaunchKernelGGL(ffgp_rawg_copy_out, dim3(1), dim3(256), 0, h->stream, r->stage, 0L, nll_dev, (double*)nullptr);
+    ffgp_invalidate(h);     // the replay rewrote the handle's factor on the device; the host-side keys do not know
+    h->graph_replays += 1;
+    return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
+  };
+  if (same && r->valid) return replay();
+  if (!same) {              // first sight of this call: run it plainly (sizes every buffer, sets every kernel attribute), remember it
+    rawg_drop_one(r);
+    const int rc = nlml_fused_plain(h, p, nll_dev, g);
+    r->p = *p;
+    r->epoch = h->alloc_epoch;
+    r->seen = (rc == FFGP_OK) ? 1 : 0;
+    return rc;
+  }
+  if (!r->stage) {
+    FFGP_HIP(hipMalloc(&r->stage, 2 * sizeof(double)));
+    r->stage_len = 2;
+  }
+  r->seen = 0;
+  if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    return nlml_fused_plain(h, p, nll_dev, g);
+  }
+  const int rc = nlml_fused_plain(h, p, r->stage, nullptr);
+  hipGraph_t graph = nullptr;
+  const hipError_t ec = hipStreamEndCapture(h->stream, &graph);
+  if (rc != FFGP_OK || ec != hipSuccess || !graph || r->epoch != h->alloc_epoch) {
+    (void)hipGetLastError();
+    if (graph) hipGraphDestroy(graph);
+    if (getenv("FFGP_GRAPH_DEBUG")) fprintf(stderr, "[ffgp] forward graph: capture failed (rc %d, hip %d)\n", rc, (int)ec);
+    return nlml_fused_plain(h, p, nll_dev, g);
+  }
+  hipGraphExec_t exec = nullptr;
+  if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    hipGraphDestroy(graph);
+    return nlml_fused_plain(h, p, nll_dev, g);
+  }
+  r->graph = graph;
+  r->exec = exec;
+  r->valid = true;
+  return replay();
+}
+
+static int nlml_fused_plain(ffgp_handle* h, const ffgp_problem* p, double* nll_dev, const ffgp_grads* g) {
   if (!h || !p || !nll_dev) return FFGP_ERR_ARG;
   const bool given_cov = (p->cov_dev != nullptr);
   if (p->n <= 0 || p->d <= 0 || !p->Y_dev) return FFGP_ERR_ARG;

@@ -245,6 +245,9 @@ struct ffgp_handle {
   unsigned long alloc_epoch;   // bumped whenever one of the handle's device buffers is re-allocated (captured pointers go stale)
   int raw_graph_max_n;         // option "raw_graph_max_n" (default 0 = never capture: measured no faster, see api.hip)
   struct RawGraph* rawg;
+  int fwd_graph;               // option "fwd_graph" (default 0): forward-only calls replay a captured hipGraph (api.hip)
+  struct RawGraph* fwdg;
+  long graph_replays;
   double* d_asm;     // assembly on the matrix cores: shifted + scaled inputs and their squared norms (n (D + 1) doubles)
   size_t asm_bytes;
   int asm_mm;        // option "asm_mm" (default 1): interior squared-exponential tiles through the MFMA chain

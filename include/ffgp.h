@@ -216,6 +216,8 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
             "chase_pack" (placement of the bulge chase's 256 working wavefronts: every pack-th workgroup works.  Default 1 = one per
                         compute unit over the whole chip (N = 8192: 64.6 ms; 2 = on every other XCD: 69.4, 4: 92, 8: 166); beside
                         other blocks' kernels 1 and 2 measure the same (config 5's eight blocks: 1.43-1.47 s per step either way),
+            "fwd_graph" (default 0; 1 = forward-only likelihood calls of more than one diagonal block replay a captured hipGraph from
+                        their second identical occurrence on: see ffgp_graph_replays -- measured, no gain on this runtime),
             "trsm128" / "trsm128_max_m" (default 1 / 8192: the factorisation chain's full-block TRSM runs on its own latency-shaped
                         kernel for panels of at most trsm128_max_m rows; the values are the general GEMM's bit for bit),
             "chase_xl" / "chase_xl_max_n" (default 1 / 2048: bands of up to chase_xl_max_n columns run their bulge chase with every
@@ -238,6 +240,14 @@ const char* ffgp_version(void);
 /* 1 in the development build (`make dev`: the switches of measured-and-rejected experiments are accepted by ffgp_set_option), 0 in
    the shipped library */
 int ffgp_has_dev_options(void);
+/* Number of forward calls this handle has served by replaying a captured graph since it was created (option "fwd_graph" of
+   ffgp_set_option: the second identical forward-only call -- same problem struct, so the same device buffers; their CONTENTS may
+   change -- is captured with both of its streams, later ones are one hipGraphLaunch and a one-word copy: same kernels, same values,
+   the status of a failing pivot reported as by the plain call).  Measured on ROCm 7.2 (tools/host_load_probe.py): no gain -- this
+   runtime executes a graph's nodes from a host thread one by one, so the step is 0.2-1 % slower at N = 16384, 22 % slower at
+   N = 4096, and as exposed to a starved host as the plain launches; the option is off by default.  -1 for a NULL handle.  No reference
+   counterpart. */
+long ffgp_graph_replays(const ffgp_handle* h);
 
 /* ---- building blocks ------------------------------------------------------------------------------------ */
 /* K(x1,x2) [+ Sigma extras when the matrix is square and symmetric].  Replaces kernel.forward

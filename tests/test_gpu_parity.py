@@ -1157,6 +1157,64 @@ def test_raw_graph_replay():
         _lib.lib.ffgp_set_option(h, b"raw_graph_max_n", 0.0)
 
 
+@pytest.mark.parametrize("n,d", [(1536, 3), (4000, 1)])
+def test_forward_graph_replay(n, d):
+    """option fwd_graph: from its third identical occurrence a forward-only likelihood call is ONE hipGraphLaunch (both streams of the
+    look-ahead captured; n = 1536 is factored in order on one stream, n = 4000 with the side stream).  Same value bit for bit; new
+    CONTENTS of the same buffers are seen by the replay; other buffers drop the graph; a matrix that is not positive definite is
+    reported by the replayed call like by the plain one"""
+    from fidelityfusion_amd import _lib
+    from fidelityfusion_amd import functional as F
+    rng = np.random.default_rng(n)
+    X = T(rng.uniform(0, 1, (n, 4)))
+    Y = T(rng.standard_normal((n, d)))
+    w = T(rng.uniform(0.5, 2.0, 4))
+    amp = T([1.3])
+    dadd = T([0.05])
+    h = _lib.handle(0)
+
+    def value(y, da=dadd):
+        with torch.no_grad():
+            return F.nlml(X, y, w, amp, diag_add=da, clamp=1e-30).clone()
+
+    ref = value(Y)
+    Y2 = Y * 1.5
+    ref2 = value(Y2)
+    before = _lib.lib.ffgp_graph_replays(h)
+    assert _lib.lib.ffgp_set_option(h, b"fwd_graph", 1.0) == 0
+    try:
+        for i in range(5):                       # plain, capture + replay, replay, replay, replay
+            assert torch.equal(value(Y), ref), i
+        assert _lib.lib.ffgp_graph_replays(h) - before == 4
+        Y.mul_(1.5)                              # same buffer, new contents: the replay reads them
+        assert torch.equal(value(Y), ref2)
+        assert _lib.lib.ffgp_graph_replays(h) - before == 5
+        assert torch.equal(value(Y2), ref2)      # another buffer: run plainly (and remembered), not replayed on the old one
+        assert _lib.lib.ffgp_graph_replays(h) - before == 5
+        for i in range(3):
+            assert torch.equal(value(Y2), ref2), i
+        assert _lib.lib.ffgp_graph_replays(h) - before == 8
+        # the replayed call reports a failing pivot: the diagonal shift lives in a device scalar the graph reads
+        neg = T([-5.0])
+        shift = dadd.clone()
+        for i in range(3):
+            assert torch.equal(value(Y2, shift), ref2)
+        shift.copy_(neg)
+        with pytest.raises(torch.linalg.LinAlgError):
+            value(Y2, shift)
+        shift.copy_(dadd)
+        assert torch.equal(value(Y2, shift), ref2)
+        # a call that wants gradients is never replayed
+        Yg = Y2.clone().requires_grad_(True)
+        count = _lib.lib.ffgp_graph_replays(h)
+        v = F.nlml(X, Yg, w, amp, diag_add=dadd, clamp=1e-30)
+        v.backward()
+        assert _lib.lib.ffgp_graph_replays(h) == count and torch.equal(v.detach(), ref2) and torch.isfinite(Yg.grad).all()
+    finally:
+        _lib.lib.ffgp_set_option(h, b"fwd_graph", 0.0)
+    assert torch.equal(value(Y2), ref2)
+
+
 def test_pair_under_no_grad_and_bad_descriptor():
     """no_grad: no gradient pipeline; a descriptor outside the enum is refused by the library (FFGP_ERR_ARG), not run"""
     from fidelityfusion_amd import _lib, kernel
