@@ -259,6 +259,7 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->fwdg = nullptr;
   h->small2_off = 1;
   h->q2_wave4 = 1;
+  h->q2_split_min_cols = 8192;
   h->sb_qr4 = 0;
   h->asm_mm = 1;
   h->asm_mm_min = 6144;
@@ -456,6 +457,8 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->sb_av_gemm = (int)value;
   } else if (!strcmp(key, "sb_qr4")) {
     h->sb_qr4 = (int)value;
+  } else if (!strcmp(key, "q2_split_min_cols")) {
+    h->q2_split_min_cols = (int)value;
   } else if (!strcmp(key, "q2_wave4")) {
     h->q2_wave4 = (int)value;
   } else if (!strcmp(key, "small_finish")) {

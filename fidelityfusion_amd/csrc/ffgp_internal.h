@@ -239,6 +239,7 @@ struct ffgp_handle {
   int sb_av_gemm;              // option "sb_av_gemm" (default 0): 1 = the band reduction's A Y product on the general GEMM again
   int q2_blocks_lanes;         // how the last q2_prep wrote its blocks (1: lane order for q2_apply_wave4)
   int sb_qr4;                  // option "sb_qr4" (default 0): 1 = the band reduction's leaf QRs on 256 threads, four columns per half-wave (sy2sb_leaf_qr4)
+  int q2_split_min_cols;       // option "q2_split_min_cols" (default 8192): from this many columns of Z on, Z <- Q2 Z runs 32-column slabs on eight waves
   int q2_wave4;                // option "q2_wave4" (default 1): Z <- Q2 Z with four sweep groups per pass over Z (sb2st.hip)
   int small2_off;              // option "small_finish" (default 0 = off): 1 = 40 < n <= 128 runs assembly + the blocked diagonal-block
                                // factorisation + ONE finishing kernel (7 launches instead of 21); measured +-5-10 % per training step

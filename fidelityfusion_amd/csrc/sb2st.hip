@@ -775,55 +775,64 @@ __device__ unsigned long long ffgp_q2_stamp[32];
 // NC = 1: slabs of 16 columns, 64 KB of LDS, two workgroups per CU.  NC = 2: slabs of 32 columns (two 16-column tiles, stored one
 // after the other so that operand reads stay conflict-free), 128 KB, one workgroup per CU -- every block's V and W^T are fetched
 // once per 32 columns instead of once per 16: the operand stream (n^3 / 6 doubles per 16 columns of Z) is what bounds NC = 1.
-template <int NC>
-__global__ __launch_bounds__(256, NC == 1 ? 2 : 1) void q2_apply_wave4(ApplyArgs p) {
+// SPLIT (round 5; NC = 2 only): eight waves -- waves 0-3 own the slab's first 16-column tile, waves 4-7 the second -- so the 32-column slab's
+// LDS (one workgroup per CU) no longer means one wave per SIMD: wave w and wave w + 4 apply the SAME block in the same time step to different
+// columns and ask for the same V / W^T at the same moment (one L2 request between them when the second hits the first's line in flight).
+template <int NC, bool SPLIT = false>
+__global__ __launch_bounds__(SPLIT ? 512 : 256, (NC == 1 && !SPLIT) ? 2 : 1) void q2_apply_wave4(ApplyArgs p) {
+  static_assert(!SPLIT || NC == 2, "the split form is the 32-column slab on eight waves");
   extern __shared__ double q2w_sm[];
   constexpr int TILE = 32 * XLD;                            // one band of one column tile
   double* ring = q2w_sm;                                    // [Q2W_RING][NC][32][XLD]
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  double* xs = q2w_sm + Q2W_RING * NC * TILE + wave * NC * TILE;   // this wave's X tiles [NC][32][XLD]
+  const int tid = threadIdx.x, lane = tid & 63, wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = SPLIT ? (wave_all & 3) : wave_all;       // the wave's place in the wavefront of four sweep groups
+  constexpr int NM = SPLIT ? 1 : NC;                        // column tiles a wave applies its block to ...
+  const int c0 = SPLIT ? (wave_all >> 2) : 0;               // ... starting at this one
+  constexpr int NBT = SPLIT ? 1 : NC;                       // column tiles a thread moves per band row ...
+  const int bt0 = SPLIT ? ((tid >> 3) & 1) : 0;             // ... starting at this one
+  double* xs = q2w_sm + Q2W_RING * NC * TILE + wave_all * NM * TILE;   // this wave's X tiles [NM][32][XLD]
   const int n = p.n;
   const int col0 = blockIdx.x * 16 * NC;
   if (col0 >= p.ncols) return;
   double* __restrict__ Zg = p.Z + col0;
   const int lr = lane & 15, lq = lane >> 4;
-  const int trow = tid >> 3, tc2 = (tid & 7) * 2;          // band <-> global map: 256 threads, 32 rows x 8 column pairs (per tile)
-  bool cok0[NC], cok1[NC];
+  const int trow = SPLIT ? (tid >> 4) : (tid >> 3), tc2 = (tid & 7) * 2;   // band <-> global map: 32 rows x 8 column pairs per tile
+  bool cok0[NBT], cok1[NBT];
 #pragma unroll
-  for (int ct = 0; ct < NC; ++ct) {
-    cok0[ct] = col0 + 16 * ct + tc2 < p.ncols;
-    cok1[ct] = col0 + 16 * ct + tc2 + 1 < p.ncols;
+  for (int ct = 0; ct < NBT; ++ct) {
+    cok0[ct] = col0 + 16 * (bt0 + ct) + tc2 < p.ncols;
+    cok1[ct] = col0 + 16 * (bt0 + ct) + tc2 + 1 < p.ncols;
   }
-  auto load_band = [&](int b, d2_t (&v)[NC]) {             // two doubles per tile of one row of band b (rows 32 b + 1 .. 32 b + 32)
+  auto load_band = [&](int b, d2_t (&v)[NBT]) {             // two doubles per tile of one row of band b (rows 32 b + 1 .. 32 b + 32)
     const int grow = 32 * b + 1 + trow;
 #pragma unroll
-    for (int ct = 0; ct < NC; ++ct) {
+    for (int ct = 0; ct < NBT; ++ct) {
       v[ct] = d2_t{0.0, 0.0};
       if (b >= 0 && grow < n) {
-        const double* src = Zg + (size_t)grow * p.ldz + 16 * ct + tc2;
+        const double* src = Zg + (size_t)grow * p.ldz + 16 * (bt0 + ct) + tc2;
         if (cok1[ct]) v[ct] = *reinterpret_cast<const d2_t*>(src);
         else if (cok0[ct]) v[ct].x = src[0];
       }
     }
   };
-  auto store_band = [&](int b, const d2_t (&v)[NC]) {
+  auto store_band = [&](int b, const d2_t (&v)[NBT]) {
     const int grow = 32 * b + 1 + trow;
     if (b < 0 || grow >= n) return;
 #pragma unroll
-    for (int ct = 0; ct < NC; ++ct) {
-      double* dst = Zg + (size_t)grow * p.ldz + 16 * ct + tc2;
+    for (int ct = 0; ct < NBT; ++ct) {
+      double* dst = Zg + (size_t)grow * p.ldz + 16 * (bt0 + ct) + tc2;
       if (cok1[ct]) *reinterpret_cast<d2_t*>(dst) = v[ct];
       else if (cok0[ct]) dst[0] = v[ct].x;
     }
   };
   auto slot = [&](int b) { return ring + (((b % Q2W_RING) + Q2W_RING) % Q2W_RING) * NC * TILE; };
-  auto put_band = [&](int b, const d2_t (&v)[NC]) {
+  auto put_band = [&](int b, const d2_t (&v)[NBT]) {
 #pragma unroll
-    for (int ct = 0; ct < NC; ++ct) *reinterpret_cast<d2_t*>(slot(b) + ct * TILE + trow * XLD + tc2) = v[ct];
+    for (int ct = 0; ct < NBT; ++ct) *reinterpret_cast<d2_t*>(slot(b) + (bt0 + ct) * TILE + trow * XLD + tc2) = v[ct];
   };
-  auto get_band = [&](int b, d2_t (&v)[NC]) {
+  auto get_band = [&](int b, d2_t (&v)[NBT]) {
 #pragma unroll
-    for (int ct = 0; ct < NC; ++ct) v[ct] = *reinterpret_cast<const d2_t*>(slot(b) + ct * TILE + trow * XLD + tc2);
+    for (int ct = 0; ct < NBT; ++ct) v[ct] = *reinterpret_cast<const d2_t*>(slot(b) + (bt0 + ct) * TILE + trow * XLD + tc2);
   };
 
   for (int Gtop = p.G1 - 1; Gtop >= p.G0; Gtop -= 4) {
@@ -839,7 +848,7 @@ __global__ __launch_bounds__(256, NC == 1 ? 2 : 1) void q2_apply_wave4(ApplyArgs
     __syncthreads();       // the previous pass's stores are visible to the whole workgroup, its LDS reads are done
     // the window at t = 0: bands Gtop - 9 .. Gtop + 1
     for (int b = Gtop - 9; b <= Gtop + 1; ++b) {
-      d2_t v[NC];
+      d2_t v[NBT];
       load_band(b, v);
       put_band(b, v);
     }
@@ -876,25 +885,25 @@ __global__ __launch_bounds__(256, NC == 1 ? 2 : 1) void q2_apply_wave4(ApplyArgs
     for (int t = 0; t < T; ++t) {
       const int b0 = Gtop + t;
       Q2_STAMP(0);
-      d2_t znew[NC];
+      d2_t znew[NBT];
       load_band(b0 + 2, znew);                             // the band that arrives for the next step
       lds_barrier();                                       // window complete
       Q2_STAMP(1);
       const int k = t - 2 * wave;
       if (k >= 0 && k < nkw) {
         const int bw = b0 - 3 * wave;                      // this wave's bands: bw, bw + 1
-        double* z0 = slot(bw);
-        double* z1 = slot(bw + 1);
+        double* z0 = slot(bw) + c0 * TILE;
+        double* z1 = slot(bw + 1) + c0 * TILE;
         // X = V^T Zw  (32 x 16 per tile, k = 64 window rows)
-        d4_t ax[NC][2];
+        d4_t ax[NM][2];
 #pragma unroll
-        for (int ct = 0; ct < NC; ++ct) ax[ct][0] = ax[ct][1] = d4_t{0.0, 0.0, 0.0, 0.0};
+        for (int ct = 0; ct < NM; ++ct) ax[ct][0] = ax[ct][1] = d4_t{0.0, 0.0, 0.0, 0.0};
         // (V is a staircase: reflector j lives on window rows j .. j + 31, so reflectors 0-15 never see rows 48-63 and
         // reflectors 16-31 never see rows 0-15: 12 of the 16 k-steps each)
 #pragma unroll
         for (int kq = 0; kq < 16; ++kq)
 #pragma unroll
-          for (int ct = 0; ct < NC; ++ct) {
+          for (int ct = 0; ct < NM; ++ct) {
             const double zb = (kq < 8 ? z0 : z1)[ct * TILE + ((kq & 7) * 4 + lq) * XLD + lr];
             if (kq < 12) ax[ct][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[0][kq], zb, ax[ct][0], 0, 0, 0);
             if (kq >= 4) ax[ct][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[1][kq], zb, ax[ct][1], 0, 0, 0);
@@ -902,15 +911,15 @@ __global__ __launch_bounds__(256, NC == 1 ? 2 : 1) void q2_apply_wave4(ApplyArgs
         Q2_STAMP(2);
         if (k + 1 < nkw) load_v(k + 1);                    // (V's registers are free: the next block's travel under the second product)
 #pragma unroll
-        for (int ct = 0; ct < NC; ++ct)
+        for (int ct = 0; ct < NM; ++ct)
 #pragma unroll
           for (int xa = 0; xa < 2; ++xa)
 #pragma unroll
             for (int r = 0; r < 4; ++r) xs[ct * TILE + (xa * 16 + 4 * r + lq) * XLD + lr] = ax[ct][xa][r];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private tiles: written and read by this wave only
-        double xb[NC][8];
+        double xb[NM][8];
 #pragma unroll
-        for (int ct = 0; ct < NC; ++ct)
+        for (int ct = 0; ct < NM; ++ct)
 #pragma unroll
           for (int kq = 0; kq < 8; ++kq) xb[ct][kq] = xs[ct * TILE + (kq * 4 + lq) * XLD + lr];
         Q2_STAMP(3);
@@ -918,7 +927,7 @@ __global__ __launch_bounds__(256, NC == 1 ? 2 : 1) void q2_apply_wave4(ApplyArgs
 #pragma unroll
         for (int zp = 0; zp < 2; ++zp)
 #pragma unroll
-          for (int ct = 0; ct < NC; ++ct) {
+          for (int ct = 0; ct < NM; ++ct) {
             double* zh = (zp == 0 ? z0 : z1) + ct * TILE;
             d4_t acc0, acc1;
 #pragma unroll
@@ -944,7 +953,7 @@ __global__ __launch_bounds__(256, NC == 1 ? 2 : 1) void q2_apply_wave4(ApplyArgs
       Q2_STAMP(5);
       // band b0 - 9 is final for this pass; its slot is NOT the arriving band's (the ring has one spare slot), so the arriving
       // rows go to LDS first and the store follows (a wait for the next load must not also wait for this store)
-      d2_t fin[NC];
+      d2_t fin[NBT];
       get_band(b0 - 9, fin);
       put_band(b0 + 2, znew);
       store_band(b0 - 9, fin);
@@ -953,7 +962,7 @@ __global__ __launch_bounds__(256, NC == 1 ? 2 : 1) void q2_apply_wave4(ApplyArgs
     lds_barrier();
     // what is still in the window after the last step: bands (Gtop + T) - 9 .. (Gtop + T) + 1
     for (int b = Gtop + T - 9; b <= Gtop + T + 1; ++b) {
-      d2_t v[NC];
+      d2_t v[NBT];
       get_band(b, v);
       store_band(b, v);
     }
@@ -981,7 +990,17 @@ int ffgp_q2_apply_impl(ffgp_handle* h, const double* blocks, int n, double* Z, i
     // 16-column slabs (two workgroups per CU) measured faster than 32-column ones at every size: N = 8192 51.9 / 57.4 ms,
     // N = 16384 401 / 424 ms (the old kernel: 80.4 / 712); option value 2 selects the wide form
     const bool wide = (h->q2_wave4 == 2);
-    if (wide) hipLaunchKernelGGL(q2_apply_wave4<2>, dim3((ncols + 31) / 32), dim3(256), Q2W_LDS_DOUBLES(2) * sizeof(double), h->stream, a);
+    // 32-column slabs on eight waves (the SPLIT form) once there are enough of them to fill the chip: N = 8192 45.4 -> 38.9 ms (256 slabs:
+    // one per CU); at N = 4096 its 128 workgroups leave half the CUs empty (7.2 -> 10.2 ms), so smaller matrices keep the 16-column form
+    if (h->q2_wave4 == 3 || (h->q2_wave4 == 1 && ncols >= h->q2_split_min_cols)) {
+      static bool attr3[64] = {false};
+      if (h->device >= 0 && h->device < 64 && !attr3[h->device]) {
+        FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(q2_apply_wave4<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     Q2W_LDS_DOUBLES(2) * (int)sizeof(double)));
+        attr3[h->device] = true;
+      }
+      hipLaunchKernelGGL((q2_apply_wave4<2, true>), dim3((ncols + 31) / 32), dim3(512), Q2W_LDS_DOUBLES(2) * sizeof(double), h->stream, a);
+    } else if (wide) hipLaunchKernelGGL(q2_apply_wave4<2>, dim3((ncols + 31) / 32), dim3(256), Q2W_LDS_DOUBLES(2) * sizeof(double), h->stream, a);
     else hipLaunchKernelGGL(q2_apply_wave4<1>, dim3(nslab), dim3(256), Q2W_LDS_DOUBLES(1) * sizeof(double), h->stream, a);
     return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
   }

@@ -295,3 +295,32 @@ def test_xcd_local_chase_is_the_chip_wide_chase_bit_for_bit(n):
     assert torch.equal(res[1][0][0], res[1][1][0]) and torch.equal(res[1][0][1], res[1][1][1])
     lam = torch.linalg.eigvalsh(K)
     assert float((res[1][0][0] - lam).abs().max()) <= 1e-11 * float(lam.abs().max())
+
+
+@pytest.mark.noisy
+@pytest.mark.parametrize("n", [300, 1024, 1500])
+def test_back_transformation_on_eight_waves_is_the_four_wave_form_bit_for_bit(n):
+    """round 5: from 8192 columns on, Z <- Q2 Z runs 32-column slabs on EIGHT waves (waves 0-3 the first 16-column tile, waves 4-7 the second:
+    q2_apply_wave4<2, true>); per tile the arithmetic is the four-wave kernel's, so eigenvalues and eigenvectors must be identical to the last
+    bit -- forced here at small sizes (ragged last slab, matrices that are not a multiple of 32 columns) through option q2_split_min_cols"""
+    from fidelityfusion_amd import _lib
+    from fidelityfusion_amd import eigh as E
+    g = torch.Generator(device=DEV).manual_seed(n + 1)
+    X = torch.rand((n, 4), generator=g, device=DEV, dtype=torch.float64)
+    d = torch.cdist(X, X)
+    K = torch.exp(-0.5 * d * d / 0.25)
+    res = {}
+    for split_from in (0, 1 << 30, 0):
+        _lib.set_option("q2_split_min_cols", split_from, 0)
+        try:
+            W, Z = E.eigh(K)
+        finally:
+            _lib.set_option("q2_split_min_cols", 8192, 0)
+        res.setdefault(split_from, []).append((W.clone(), Z.clone()))
+    assert torch.equal(res[0][0][0], res[1 << 30][0][0]) and torch.equal(res[0][0][1], res[1 << 30][0][1])
+    assert torch.equal(res[0][0][0], res[0][1][0]) and torch.equal(res[0][0][1], res[0][1][1])
+    lam = torch.linalg.eigvalsh(K)
+    assert float((res[0][0][0] - lam).abs().max()) <= 1e-11 * float(lam.abs().max())
+    Z = res[0][0][1]
+    assert float((Z.T @ Z - torch.eye(n, device=DEV, dtype=torch.float64)).abs().max()) < 1e-11
+

@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+timeout -k 10 600 python3 -m pytest tests/test_gpu_syevd.py tests/test_gpu_eigh.py -q -x 2>&1 | tail -3
+python3 tools/eigh_bench.py full big 2>&1 | grep -v amdgpu.ids | tail -4
+python3 tools/hogp_bench.py 2>&1 | grep -v amdgpu.ids | tail -2
