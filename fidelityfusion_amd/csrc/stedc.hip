@@ -147,10 +147,12 @@ __global__ __launch_bounds__(64) void dc_deflate(DcLevel p) {
           continue;
         }
         if (prev >= 0) {
-          const double tau = hypot(zj, zprev);
-          const double cc = zj / tau, ss = -zprev / tau;
+          // close pair?  |t c s| <= tol with c = z_j / tau, s = -z_prev / tau, tau = hypot(z_j, z_prev)  <=>  |t z_j z_prev| <= tol tau^2:
+          // the test without the square root and the two divisions -- this lane walks the whole list alone, and nearly every pair fails it
           const double tt = dj - dprev;
-          if (fabs(tt * cc * ss) <= tol) {   // close pair: rotate z[prev] into z[j], position prev deflates
+          if (fabs(tt * zj * zprev) <= tol * __builtin_fma(zj, zj, zprev * zprev)) {   // rotate z[prev] into z[j], position prev deflates
+            const double tau = hypot(zj, zprev);
+            const double cc = zj / tau, ss = -zprev / tau;
             zj = tau;
             const double dp = dprev * cc * cc + dj * ss * ss;
             dj = dprev * ss * ss + dj * cc * cc;
