@@ -218,6 +218,9 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
                         other blocks' kernels 1 and 2 measure the same (config 5's eight blocks: 1.43-1.47 s per step either way),
             "fwd_graph" (default 0; 1 = forward-only likelihood calls of more than one diagonal block replay a captured hipGraph from
                         their second identical occurrence on: see ffgp_graph_replays -- measured, no gain on this runtime),
+            "q2_split_min_cols" (default 8192: from this many columns of Z on, the eigensolver's back-transformation Z <- Q2 Z runs 32-column
+                        slabs on eight waves -- ormq2 45.4 -> 38.9 ms at n = 8192, 434 -> 297 at 16384, values identical; below, the
+                        slabs would not fill the chip),
             "trsm128" / "trsm128_max_m" (default 1 / 8192: the factorisation chain's full-block TRSM runs on its own latency-shaped
                         kernel for panels of at most trsm128_max_m rows; the values are the general GEMM's bit for bit),
             "chase_xl" / "chase_xl_max_n" (default 1 / 2048: bands of up to chase_xl_max_n columns run their bulge chase with every
