@@ -41,7 +41,7 @@ for it in range(150):
     history.append(float(nll.detach()))
 elapsed = time.perf_counter() - clock
 print("150 likelihood + gradient steps on %s: %.2f s;  nll %.3f -> %.3f" % (where, elapsed, history[0], history[-1]))
-print("length scales", [round(float(v), 3) for v in gp.kernel.length_scales.abs()], " noise sd %.3f" % math.exp(-0.5 * float(gp.log_beta)))
+print("length scales", [round(float(v), 3) for v in gp.kernel.length_scales.detach().abs()], " noise sd %.3f" % math.exp(-0.5 * float(gp.log_beta.detach())))
 
 with torch.no_grad():
     mean, cov = gp.forward(x_fit, y_fit, x_new)

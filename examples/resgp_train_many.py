@@ -66,4 +66,4 @@ print("  largest relative difference of the loss traces: %.1e" % float(((trace.c
 for f, (m, t) in enumerate(zip(models, twins)):
     d = max(float((a.detach() - b.detach()).abs().max()) for a, b in zip(m.parameters(), t.parameters()))
     print("  fidelity %d: noise 1/beta = %.4f, length scales %s, largest parameter difference %.1e"
-          % (f, math.exp(-float(m.log_beta)), ["%.3f" % abs(float(v)) for v in m.kernel.length_scales], d))
+          % (f, math.exp(-float(m.log_beta.detach())), ["%.3f" % abs(float(v)) for v in m.kernel.length_scales.detach()], d))
