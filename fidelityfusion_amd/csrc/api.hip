@@ -250,6 +250,8 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->nb_outer = 512;
   h->diag_v2 = 4;
   h->trsm128 = 1;
+  h->polite64_pad_kb = 60;
+  h->polite64_active = 0;
   h->trsm128_max_m = 8192;
   h->trtri_overlap = 1;
   h->trtri_fill = 0;
@@ -384,6 +386,9 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->tile32_threshold = (int)value;
   } else if (!strcmp(key, "fwd_graph")) {
     h->fwd_graph = value != 0.0;
+  } else if (!strcmp(key, "polite64_pad_kb")) {
+    if (value < 0 || value > 64) return FFGP_ERR_ARG;
+    h->polite64_pad_kb = (int)value;
   } else if (!strcmp(key, "trsm128")) {
     h->trsm128 = value != 0.0;
   } else if (!strcmp(key, "trsm128_max_m")) {

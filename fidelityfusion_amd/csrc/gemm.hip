@@ -994,6 +994,15 @@ static int gemm_plan(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   // kernels at all times instead of only when a SYRK workgroup happens to exit.
   a.pad_lds = 0;
   if (syrk_tag && tsm == 128 && h->lookahead && h->polite_m > 0 && m < h->polite_m && h->stream != h->aux) a.pad_lds = h->polite_pad_kb * 1024;
+  // ... and so are its 64-tile launches (trailing matrices below ~4 600 rows: always the chain-bound regime): 20 KiB of LDS let four of
+  // their workgroups sit on a CU, and the chain's first kernels of a panel then run at a third of their speed beside them (the first
+  // panel update 60 us instead of 14, the first diagonal block 50 instead of 28: profiles/r05g_c2_chain_timeline.txt).  With 60 KiB of
+  // unused LDS two fit: N = 4096 -1.7 %, N = 6144 -3.3 %, N = 8192 -2.0 % (same tiles, same values).  Only in the carry form of a single
+  // block's look-ahead (polite64_active, set by ffgp_potrf_impl): the round-1 form above 12 288 rows lost 0.7 % with it at C3, and a
+  // shared chain's launches (batched or ragged: throughput-bound) are left alone.
+  if (syrk_tag && tsm == 64 && tsn == 64 && h->polite64_active && h->polite64_pad_kb > 0 && h->stream != h->aux && dec_batch == 1 &&
+      m - n <= 1024)      // (many passenger rows below the matrix: their updates are throughput work -- d = 4096 lost 1 % with it)
+    a.pad_lds = h->polite64_pad_kb * 1024;
   if (tsm != 128) syrk_tag = 0;  // only the 128x128 trailing update is the roofline kernel (own instantiation + stats)
   pl.tsm = tsm; pl.tsn = tsn; pl.syrk_tag = syrk_tag;
   return FFGP_OK;

@@ -1678,6 +1678,11 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
       // into -- its right-hand neighbour, so the two are one launch) and S_ii (everything right of Z(k+2)).  Writers of any one column range
       // are ordered: Z(k+2) <- S_ii(<= k-1), S_z(k) on the main stream, then chain k+1 (after S_z's event).
       hipStream_t main_s = h->stream;
+      struct Polite64 {        // this form's 64-tile trailing updates leave half of every CU to the chain (gemm_plan); reset on every exit path
+        int& f;
+        explicit Polite64(int& f_) : f(f_) { f = 1; }
+        ~Polite64() { f = 0; }
+      } polite64(h->polite64_active);
       auto carry_of = [&](int pend_) { return min(NB, n - pend_); };   // columns of the next panel's first block (0 at the end)
       FFGP_CHECK(factor_panel(h, A, n, mch, lda, 0, min(pw(0), n), nullptr, max(0, carry_of(min(pw(0), n)))));
       FFGP_HIP(hipEventRecord(h->la_ev[6], main_s));

@@ -221,6 +221,9 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
             "q2_split_min_cols" (default 8192: from this many columns of Z on, the eigensolver's back-transformation Z <- Q2 Z runs 32-column
                         slabs on eight waves -- ormq2 45.4 -> 38.9 ms at n = 8192, 434 -> 297 at 16384, values identical; below, the
                         slabs would not fill the chip),
+            "polite64_pad_kb" (default 60, at most 64: unused dynamic LDS requested by the 64-tile trailing updates of ONE block's carry-form
+                        look-ahead -- two of their workgroups per CU instead of four, so the chain's kernels are not slowed to a third
+                        beside them; N = 4096 / 6144 / 8192 / 12288: -1.2 / -3.0 / -2.0 / -1.0 %, values unchanged; 0 = off),
             "trsm128" / "trsm128_max_m" (default 1 / 8192: the factorisation chain's full-block TRSM runs on its own latency-shaped
                         kernel for panels of at most trsm128_max_m rows; the values are the general GEMM's bit for bit),
             "chase_xl" / "chase_xl_max_n" (default 1 / 2048: bands of up to chase_xl_max_n columns run their bulge chase with every

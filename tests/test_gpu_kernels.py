@@ -387,6 +387,32 @@ def test_potrf_block_trsm_kernel_is_the_general_gemm_bit_for_bit(ff, n, m):
     assert relerr(np.tril(outs[1][:n, :n]), np.linalg.cholesky(S)) < 1e-11
 
 
+def test_potrf_polite_64_tile_updates_change_nothing_but_the_occupancy(ff):
+    """the carry-form look-ahead launches its 64-tile trailing updates with 60 KiB of unused LDS (two workgroups per CU instead of four, so
+    the chain's kernels find room: option polite64_pad_kb): same tiles, same arithmetic -- the factor and the passenger rows must be
+    identical to the last bit with and without it"""
+    _lib, h = ff
+    n, m = 4700, 40
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, 48))
+    S = B @ B.T + np.diag(rng.random(n) + 0.5)
+    R = rng.standard_normal((m, n))
+    outs = {}
+    try:
+        for pad in (60, 0):
+            assert _lib.lib.ffgp_set_option(h, b"polite64_pad_kb", float(pad)) == 0
+            rc, out, _, _ = potrf(ff, S, R)
+            assert rc == 0
+            outs[pad] = out
+    finally:
+        _lib.lib.ffgp_set_option(h, b"polite64_pad_kb", 60.0)
+    low = np.tril_indices(n)
+    assert np.array_equal(outs[60][:n, :n][low], outs[0][:n, :n][low])
+    assert np.array_equal(outs[60][n:, :n], outs[0][n:, :n])
+    assert relerr(np.tril(outs[60][:n, :n]), np.linalg.cholesky(S)) < 1e-11
+    assert _lib.lib.ffgp_set_option(h, b"polite64_pad_kb", 65.0) != 0      # (more than 64 KiB of dynamic LDS is not requested)
+
+
 def test_potrf_naive_kernels_agree(ff):
     rng = np.random.default_rng(2)
     S = spd(200, rng)
