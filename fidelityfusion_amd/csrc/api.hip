@@ -174,6 +174,8 @@ static int create_resources(ffgp_handle* h) {
   for (int i = 0; i < 10; ++i) FFGP_HIP(hipEventCreateWithFlags(&h->la_ev[i], evflags));
   FFGP_HIP(hipMalloc(&h->d_info, 16 * sizeof(int)));
   FFGP_HIP(hipMemset(h->d_info, 0, 16 * sizeof(int)));
+  FFGP_HIP(hipMalloc(&h->ho_mem, 10 * 16 * sizeof(unsigned)));
+  FFGP_HIP(hipMemset(h->ho_mem, 0, 10 * 16 * sizeof(unsigned)));
   FFGP_HIP(hipDeviceSynchronize());   // NULL-stream memset: make it visible before any (non-blocking) stream touches it
   FFGP_HIP(hipMalloc(&h->d_scal, SCAL_DOUBLES * sizeof(double)));
   FFGP_HIP(hipHostMalloc(&h->h_info, 16 * sizeof(int)));
@@ -251,6 +253,10 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->diag_v2 = 4;
   h->trsm128 = 1;
   h->polite64_pad_kb = 60;
+  h->polite32_pad_kb = 34;
+  h->ho_values = 1;
+  h->ho_defer = 1;
+  h->ho_defer_slot = -1;
   h->polite64_active = 0;
   h->trsm128_max_m = 8192;
   h->trtri_overlap = 1;
@@ -298,6 +304,7 @@ int ffgp_destroy(ffgp_handle* h) {
   for (int i = 0; i < 12; ++i)
     if (h->eig_ev[i]) hipEventDestroy(h->eig_ev[i]);
   if (h->d_info) hipFree(h->d_info);
+  if (h->ho_mem) hipFree(h->ho_mem);
   if (h->bt_info) hipFree(h->bt_info);
   if (h->train_g) hipFree(h->train_g);
   if (h->pack_buf) hipFree(h->pack_buf);
@@ -386,6 +393,13 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->tile32_threshold = (int)value;
   } else if (!strcmp(key, "fwd_graph")) {
     h->fwd_graph = value != 0.0;
+  } else if (!strcmp(key, "ho_values")) {
+    h->ho_values = value != 0.0;
+  } else if (!strcmp(key, "ho_defer")) {
+    h->ho_defer = value != 0.0;
+  } else if (!strcmp(key, "polite32_pad_kb")) {
+    if (value < 0 || value > 64) return FFGP_ERR_ARG;
+    h->polite32_pad_kb = (int)value;
   } else if (!strcmp(key, "polite64_pad_kb")) {
     if (value < 0 || value > 64) return FFGP_ERR_ARG;
     h->polite64_pad_kb = (int)value;

@@ -148,11 +148,19 @@ struct ffgp_handle {
   hipStream_t own;      // the handle's own stream
   hipStream_t aux;      // high-priority side stream for the look-ahead panel factorisation
   hipEvent_t la_ev[10]; // look-ahead hand-off events ([7], [8]: carry mode's "strip Z(k) has run", main -> side stream)
+  unsigned* ho_mem;     // one word (64 bytes apart) per look-ahead event: the hand-off as hipStreamWriteValue32 / hipStreamWaitValue32 (potrf.hip)
+  unsigned ho_seq[10];  // ... the number its latest "record" wrote
+  int ho_values;        // option "ho_values" (default 1): value hand-offs; 0 = the event pairs
+  int ho_active;        // set per factorisation (la_begin): value hand-offs in use (not while a stream is being captured)
+  int ho_defer;         // option "ho_defer" (default 1): the chain's "panel complete" word is written by the next diagonal-block kernel
+  int ho_defer_slot;    // pending publication (-1 none) ...
+  hipStream_t ho_defer_stream;  // ... for the next diagonal-block kernel launched on this stream
   int aux_prio;         // 1 = look-ahead chain kernels run at raised wave priority
   int force_ts;         // 0 = automatic GEMM tile shape, 32 / 64 / 128 = forced (benchmarks, tests)
   int small_tile_threshold;  // launches with fewer 128-tiles than this use the 64-tile
   int tile32_threshold;      // K-major launches with fewer 64-tiles than this use 32-row tiles
   int polite64_active;  // set while ffgp_potrf_impl's carry-form look-ahead of ONE block issues its launches
+  int polite32_pad_kb;  // ... and by its 32-tile ones (default 34: three workgroups per CU)
   int polite64_pad_kb;  // unused LDS (KiB) requested by the look-ahead's 64-tile trailing updates (default 60: two workgroups per CU instead of four)
   int trsm128;          // 1 = the chain's full-block TRSM runs on its own kernel (ffgp_trsm128_kernel; same values as the general GEMM)
   int trsm128_max_m;    // ... for panels of at most this many rows (taller ones stay on the general GEMM)

@@ -1003,6 +1003,8 @@ static int gemm_plan(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   if (syrk_tag && tsm == 64 && tsn == 64 && h->polite64_active && h->polite64_pad_kb > 0 && h->stream != h->aux && dec_batch == 1 &&
       m - n <= 1024)      // (many passenger rows below the matrix: their updates are throughput work -- d = 4096 lost 1 % with it)
     a.pad_lds = h->polite64_pad_kb * 1024;
+  if (syrk_tag && tsm == 32 && tsn == 32 && h->polite64_active && h->polite32_pad_kb > 0 && h->stream != h->aux && dec_batch == 1 && m - n <= 1024)
+    a.pad_lds = h->polite32_pad_kb * 1024;
   if (tsm != 128) syrk_tag = 0;  // only the 128x128 trailing update is the roofline kernel (own instantiation + stats)
   pl.tsm = tsm; pl.tsn = tsn; pl.syrk_tag = syrk_tag;
   return FFGP_OK;

@@ -880,6 +880,8 @@ struct DiagRag {
   int lda[FFGP_RAG_MAX];
   int nb[FFGP_RAG_MAX];
   int info[FFGP_RAG_MAX];      // index of the member's status word
+  unsigned* pub;               // (every launch, ragged or not) a look-ahead hand-off this kernel publishes as it starts: everything
+  unsigned pub_val;            // enqueued before it on its stream is complete then (la_record_deferred); nullptr = none
 };
 
 template <bool RAG>
@@ -904,6 +906,8 @@ __global__ __launch_bounds__(512, 4) void ffgp_potrf_diag128_v3(double* __restri
   volatile D3Flags* fl = reinterpret_cast<volatile D3Flags*>(lds + NBLK_LOWER * BLKSZ);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (uniform: scalar control flow)
   const int g = lane >> 4, c = lane & 15;
+  // the previous panel is complete the moment this kernel runs (stream order): publish that to the update stream's waiting gate
+  if (rag.pub && blockIdx.x == 0 && tid == 64) __hip_atomic_store(rag.pub, rag.pub_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (wave == 0) D2_TRACE(0);
   // wave 0's first operands need no update: it fetches them itself, straight into the registers of F(0) and G(0), and the loads fly
   // while the roles are handed out
@@ -1418,6 +1422,7 @@ static int launch_trsm128_set(ffgp_handle* h, const TrsmSet& set, int cnt, int m
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
+static inline void la_take_deferred(ffgp_handle* h, DiagRag& dr);
 static int launch_diag(ffgp_handle* h, double* Ablk, int lda, int nb, double* Dinv_blk, int row_base, int do_factor) {
   if (h->bt_F > 1 && !(do_factor && h->diag_v2 == 4 && !h->diag_dbg)) return FFGP_ERR_ARG;   // only the round-4 kernel is batched
   if (!(h->diag_attr_set & 1)) {   // per handle = per device (the attribute lives in the device's context)
@@ -1443,12 +1448,14 @@ static int launch_diag(ffgp_handle* h, double* Ablk, int lda, int nb, double* Di
                                      DIAG_LDS_BYTES));
         h->diag_attr_set |= 4;
       }
+      DiagRag dr = DiagRag();
+      la_take_deferred(h, dr);
       if (h->bt_F > 1)
         hipLaunchKernelGGL(ffgp_potrf_diag128_v3<false>, dim3(h->bt_F), dim3(512), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk,
-                           h->bt_info, row_base, h->aux_prio, h->bt_sA, h->bt_sD, 1, DiagRag());
+                           h->bt_info, row_base, h->aux_prio, h->bt_sA, h->bt_sD, 1, dr);
       else
         hipLaunchKernelGGL(ffgp_potrf_diag128_v3<false>, dim3(1), dim3(512), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk, h->d_info,
-                           row_base, h->aux_prio, 0L, 0L, 0, DiagRag());
+                           row_base, h->aux_prio, 0L, 0L, 0, dr);
     }
 #ifdef FFGP_DEV_OPTIONS
     else if (h->diag_v2 == 3)   // the round-3 pivot step (32-bit DPP moves), kept for A/B runs
@@ -1519,6 +1526,103 @@ int ffgp_refresh_dinv(ffgp_handle* h, const double* L, int n, int ldl) {
   return FFGP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Cross-stream hand-offs of the look-ahead (round 5).  hipEventRecord + hipStreamWaitEvent between two hardware queues costs
+// 10.7-11.1 us over the in-stream kernel boundary on this runtime; hipStreamWriteValue32 behind the producer + hipStreamWaitValue32
+// in front of the consumer -- two command-processor packets on a word of device memory -- cost 2.9-4.7 us, with the producer's
+// stores visible to a consumer on another XCD (tools/native/handoff_probe.hip: 200 alternating kernels, every value checked).
+// Each of the handle's ten look-ahead events has a word and a host-side sequence number: "record" writes the next number behind the
+// producer's work, "wait" waits for the number of the latest record (>=: the numbers only grow) -- the semantics the event pair had.
+// A never-recorded hand-off waits for 0 and passes.  Events are kept while a stream is being captured into a graph (the value
+// operations are not capturable), with option ho_values = 0, and for every event that is not one of the ten.
+// ------------------------------------------------------------------------------------------------------------
+static inline int la_slot(const ffgp_handle* h, hipEvent_t ev) {
+  if (!h->ho_active) return -1;
+  for (int i = 0; i < 10; ++i)
+    if (h->la_ev[i] == ev) return i;
+  return -1;
+}
+static int la_record(ffgp_handle* h, hipEvent_t ev, hipStream_t s) {
+  const int slot = la_slot(h, ev);
+  if (slot < 0) {
+    FFGP_HIP(hipEventRecord(ev, s));
+    return FFGP_OK;
+  }
+  h->ho_seq[slot] += 1;
+  FFGP_HIP(hipStreamWriteValue32(s, h->ho_mem + slot * 16, h->ho_seq[slot], 0));
+  return FFGP_OK;
+}
+static int la_wait(ffgp_handle* h, hipStream_t s, hipEvent_t ev) {
+  const int slot = la_slot(h, ev);
+  if (slot < 0) {
+    FFGP_HIP(hipStreamWaitEvent(s, ev, 0));
+    return FFGP_OK;
+  }
+  FFGP_HIP(hipStreamWaitValue32(s, h->ho_mem + slot * 16, h->ho_seq[slot], hipStreamWaitValueGte, 0xffffffffu));
+  return FFGP_OK;
+}
+// "record" whose word is written by the NEXT diagonal-block kernel launched on `s` as it starts (launch_diag / the ragged chain pick the
+// pending publication up): on the chain's stream the hipStreamWriteValue32 is a 5 us kernel of its own between a panel's last update and
+// the next panel's first diagonal block.  la_flush writes a publication nobody picked up (end of the factorisation, error paths: a gate
+// already enqueued on another stream must never be left waiting).
+static int la_flush(ffgp_handle* h) {
+  if (h->ho_defer_slot < 0) return FFGP_OK;
+  const int slot = h->ho_defer_slot;
+  h->ho_defer_slot = -1;
+  FFGP_HIP(hipStreamWriteValue32(h->ho_defer_stream, h->ho_mem + slot * 16, h->ho_seq[slot], 0));
+  return FFGP_OK;
+}
+static int la_record_deferred(ffgp_handle* h, hipEvent_t ev, hipStream_t s) {
+  const int slot = la_slot(h, ev);
+  if (slot < 0 || !h->ho_defer) return la_record(h, ev, s);
+  FFGP_CHECK(la_flush(h));
+  h->ho_seq[slot] += 1;
+  h->ho_defer_slot = slot;
+  h->ho_defer_stream = s;
+  return FFGP_OK;
+}
+static inline void la_take_deferred(ffgp_handle* h, DiagRag& dr) {
+  dr.pub = nullptr;
+  dr.pub_val = 0;
+  if (h->ho_defer_slot >= 0 && h->ho_defer_stream == h->stream) {
+    dr.pub = h->ho_mem + h->ho_defer_slot * 16;
+    dr.pub_val = h->ho_seq[h->ho_defer_slot];
+    h->ho_defer_slot = -1;
+  }
+}
+struct LaFlushGuard {      // whatever path leaves the factorisation, a pending publication is written
+  ffgp_handle* h;
+  ~LaFlushGuard() { (void)la_flush(h); }
+};
+
+// called once per factorisation, before its first hand-off: value hand-offs unless the stream is being captured; the sequence
+// numbers start over (all of the handle's streams drained first) long before they could wrap
+static int la_begin(ffgp_handle* h) {
+  h->ho_active = 0;
+  h->ho_defer_slot = -1;
+  if (!h->ho_values || !h->ho_mem) return FFGP_OK;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(h->stream, &st) != hipSuccess) {
+    (void)hipGetLastError();
+    return FFGP_OK;
+  }
+  if (st != hipStreamCaptureStatusNone) return FFGP_OK;
+  unsigned top = 0;
+  for (int i = 0; i < 10; ++i) top = max(top, h->ho_seq[i]);
+  if (top > 0x3fffffffu) {
+    FFGP_HIP(hipStreamSynchronize(h->stream));
+    FFGP_HIP(hipStreamSynchronize(h->aux));
+    if (h->aux2) FFGP_HIP(hipStreamSynchronize(h->aux2));
+    if (h->aux3) FFGP_HIP(hipStreamSynchronize(h->aux3));
+    if (h->masked) FFGP_HIP(hipStreamSynchronize(h->masked));
+    FFGP_HIP(hipMemsetAsync(h->ho_mem, 0, 10 * 16 * sizeof(unsigned), h->stream));
+    FFGP_HIP(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 10; ++i) h->ho_seq[i] = 0;
+  }
+  h->ho_active = 1;
+  return FFGP_OK;
+}
+
 // factor one outer panel (columns k0 .. k0+w1) of the (mtot x n) matrix on h->stream: per 128-column block a
 // diagonal factor+inverse, the TRSM of every row below as one GEMM, and the update of the panel's remaining columns
 // `gate` (nullable): event the stream waits on before the panel's first update GEMM -- the look-ahead driver lets
@@ -1556,8 +1660,8 @@ static int factor_panel(ffgp_handle* h, double* A, int n, int mtot, int lda, int
                               ALIAS_A, true));
       const int wrem = pend - (j0 + jb) + carry;
       if (wrem > 0) {
-        if (gate && j0 == k0) FFGP_HIP(hipStreamWaitEvent(h->stream, gate, 0));
-        if (gate2 && j0 == k0) FFGP_HIP(hipStreamWaitEvent(h->stream, gate2, 0));
+        if (gate && j0 == k0) FFGP_CHECK(la_wait(h, h->stream, gate));
+        if (gate2 && j0 == k0) FFGP_CHECK(la_wait(h, h->stream, gate2));
         double* C = A + (size_t)(j0 + jb) * lda + (j0 + jb);
         FFGP_CHECK(potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 0, A21, lda, A21, lda, C, lda, mrows, wrem, jb, -1.0,
                                     1.0));
@@ -1601,6 +1705,7 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
     return FFGP_ERR_ARG;
   }
   FFGP_CHECK(ffgp_ensure_dinv(h, n));
+  FFGP_CHECK(la_begin(h));
   if (!h->fold_info) FFGP_CHECK(ffgp_zero_async(h, h->d_info, sizeof(int)));   // (ffgp_train_raw's loop: its Adam kernel clears the word)
   h->dinv_L = nullptr;
   h->sinv_L = nullptr;   // super-block inverses belong to the factor that is about to be overwritten
@@ -1630,7 +1735,7 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
     auto pass_panel = [&](int k0, int w1, hipEvent_t ready) -> int {
       // `ready`: the panel's columns of L are final.  Runs on h->aux3; h->stream is restored by the caller's bookkeeping.
       hipStream_t keep = h->stream;
-      FFGP_HIP(hipStreamWaitEvent(h->aux3, ready, 0));
+      FFGP_CHECK(la_wait(h, h->aux3, ready));
       h->stream = h->aux3;
       int rc = FFGP_OK;
       const int pend = k0 + w1;
@@ -1651,7 +1756,7 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
                         -1.0, 1.0);
       h->stream = keep;
       if (rc == FFGP_OK) {
-        FFGP_HIP(hipEventRecord(h->la_ev[9], h->aux3));
+        FFGP_CHECK(la_record(h, h->la_ev[9], h->aux3));
         pass_done = h->la_ev[9];
       }
       return rc;
@@ -1678,6 +1783,7 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
       // into -- its right-hand neighbour, so the two are one launch) and S_ii (everything right of Z(k+2)).  Writers of any one column range
       // are ordered: Z(k+2) <- S_ii(<= k-1), S_z(k) on the main stream, then chain k+1 (after S_z's event).
       hipStream_t main_s = h->stream;
+      LaFlushGuard flush_guard{h};
       struct Polite64 {        // this form's 64-tile trailing updates leave half of every CU to the chain (gemm_plan); reset on every exit path
         int& f;
         explicit Polite64(int& f_) : f(f_) { f = 1; }
@@ -1685,8 +1791,8 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
       } polite64(h->polite64_active);
       auto carry_of = [&](int pend_) { return min(NB, n - pend_); };   // columns of the next panel's first block (0 at the end)
       FFGP_CHECK(factor_panel(h, A, n, mch, lda, 0, min(pw(0), n), nullptr, max(0, carry_of(min(pw(0), n)))));
-      FFGP_HIP(hipEventRecord(h->la_ev[6], main_s));
-      FFGP_HIP(hipStreamWaitEvent(h->aux, h->la_ev[6], 0));
+      FFGP_CHECK(la_record(h, h->la_ev[6], main_s));
+      FFGP_CHECK(la_wait(h, h->aux, h->la_ev[6]));
       if (split_pass) FFGP_CHECK(pass_panel(0, min(pw(0), n), h->la_ev[6]));
       int it = 0;
       hipEvent_t eb_prev = nullptr;
@@ -1701,8 +1807,8 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
         const int mt = n - pend;
         if (mt <= 0) break;
         if (h->tail_mask_m > 0 && mch - pend < h->tail_mask_m && syrk_s == main_s && ffgp_ensure_masked(h) == FFGP_OK) {
-          FFGP_HIP(hipEventRecord(h->la_ev[7], main_s));
-          FFGP_HIP(hipStreamWaitEvent(h->masked, h->la_ev[7], 0));
+          FFGP_CHECK(la_record(h, h->la_ev[7], main_s));
+          FFGP_CHECK(la_wait(h, h->masked, h->la_ev[7]));
           syrk_s = h->masked;
         }
         const int wn = min(pw(pend), mt);  // width of the next panel
@@ -1711,7 +1817,7 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
         hipEvent_t eb = h->la_ev[(it & 1) * 3], eg = h->la_ev[(it & 1) * 3 + 1];
         const int wa = min(NB, wn);        // Z(k+1): already complete (carried by panel k)
         // main stream, once panel k is complete: S_b(k) and S_z(k) are neighbours (columns pend+wa .. q+wz): one launch, one event
-        if (eb_prev) FFGP_HIP(hipStreamWaitEvent(syrk_s, eb_prev, 0));
+        if (eb_prev) FFGP_CHECK(la_wait(h, syrk_s, eb_prev));
         hipEvent_t gate = nullptr, gate2 = nullptr;
         if (wn - wa + wz > 0) {
           double* Pb = A + (size_t)(pend + wa) * lda + k0;
@@ -1721,7 +1827,7 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
                                      wn - wa + wz, w1, -1.0, 1.0);
           h->stream = main_s;
           FFGP_CHECK(brc);
-          FFGP_HIP(hipEventRecord(eg, syrk_s));
+          FFGP_CHECK(la_record(h, eg, syrk_s));
           gate = eg;
         }
         // side stream: panel k+1, carrying Z(k+2)
@@ -1729,11 +1835,11 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
         int rc = factor_panel(h, A, n, mch, lda, pend, wn, gate, wz, gate2);
         h->stream = main_s;
         FFGP_CHECK(rc);
-        FFGP_HIP(hipEventRecord(eb, h->aux));
+        FFGP_CHECK(la_record_deferred(h, eb, h->aux));     // (published by the next panel's first diagonal-block kernel)
         eb_prev = eb;
         if (split_pass) FFGP_CHECK(pass_panel(pend, wn, eb));
         if (h->tri_hook_col > 0 && pend + wn == h->tri_hook_col) {   // the factor's columns < tri_hook_col are final from here on
-          FFGP_HIP(hipEventRecord(h->tri_ev[0], h->aux));
+          FFGP_CHECK(la_record(h, h->tri_ev[0], h->aux));
           h->tri_hook_fired = 1;
         }
         // main stream: S_ii(k), everything right of Z(k+2)
@@ -1747,12 +1853,13 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
           FFGP_CHECK(irc);
         }
       }
+      FFGP_CHECK(la_flush(h));
       if (syrk_s != main_s) {
-        FFGP_HIP(hipEventRecord(h->la_ev[8], syrk_s));
-        FFGP_HIP(hipStreamWaitEvent(main_s, h->la_ev[8], 0));
+        FFGP_CHECK(la_record(h, h->la_ev[8], syrk_s));
+        FFGP_CHECK(la_wait(h, main_s, h->la_ev[8]));
       }
-      if (eb_prev) FFGP_HIP(hipStreamWaitEvent(main_s, eb_prev, 0));
-      if (pass_done) FFGP_HIP(hipStreamWaitEvent(main_s, pass_done, 0));
+      if (eb_prev) FFGP_CHECK(la_wait(h, main_s, eb_prev));
+      if (pass_done) FFGP_CHECK(la_wait(h, main_s, pass_done));
     } else {
       // Look-ahead.  The trailing update of step k is cut into S_a (the first 128 columns of panel k+1 -- all that its
       // first diagonal factor and TRSM read), S_b (the rest of panel k+1's columns) and S_ii (everything to the right).
@@ -1764,8 +1871,8 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
       // columns to the right of panel k+1, so the two streams never alias.
       hipStream_t main_s = h->stream;
       FFGP_CHECK(factor_panel(h, A, n, mch, lda, 0, min(pw(0), n)));
-      FFGP_HIP(hipEventRecord(h->la_ev[6], main_s));
-      FFGP_HIP(hipStreamWaitEvent(h->aux, h->la_ev[6], 0));
+      FFGP_CHECK(la_record(h, h->la_ev[6], main_s));
+      FFGP_CHECK(la_wait(h, h->aux, h->la_ev[6]));
       if (split_pass) FFGP_CHECK(pass_panel(0, min(pw(0), n), h->la_ev[6]));
       int it = 0;
       hipEvent_t eb_prev = nullptr, ei_prev = nullptr;
@@ -1780,20 +1887,20 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
         hipEvent_t eb = h->la_ev[(it & 1) * 3], eg = h->la_ev[(it & 1) * 3 + 1], ei = h->la_ev[(it & 1) * 3 + 2];
         const int wa = h->la_split ? min(NB, wn) : wn;
         // side stream: S_a(k) (after S_ii(k-1), which carried panel k-1 into these columns)
-        if (ei_prev) FFGP_HIP(hipStreamWaitEvent(h->aux, ei_prev, 0));
+        if (ei_prev) FFGP_CHECK(la_wait(h, h->aux, ei_prev));
         h->stream = h->aux;
         int rc = potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P, lda, P, lda, C, lda, mch - pend, wa, w1, -1.0, 1.0);
         h->stream = main_s;
         FFGP_CHECK(rc);
         // main stream: S_b(k) once panel k is complete
-        if (eb_prev) FFGP_HIP(hipStreamWaitEvent(main_s, eb_prev, 0));
+        if (eb_prev) FFGP_CHECK(la_wait(h, main_s, eb_prev));
         hipEvent_t gate = nullptr;
         if (wn > wa) {
           double* Pb = A + (size_t)(pend + wa) * lda + k0;
           double* Cb = A + (size_t)(pend + wa) * lda + (pend + wa);
           FFGP_CHECK(potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, Pb, lda, Pb, lda, Cb, lda, mch - pend - wa, wn - wa,
                                       w1, -1.0, 1.0));
-          FFGP_HIP(hipEventRecord(eg, main_s));
+          FFGP_CHECK(la_record(h, eg, main_s));
           gate = eg;
         }
         // side stream: panel k+1
@@ -1801,11 +1908,11 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
         rc = factor_panel(h, A, n, mch, lda, pend, wn, gate);
         h->stream = main_s;
         FFGP_CHECK(rc);
-        FFGP_HIP(hipEventRecord(eb, h->aux));
+        FFGP_CHECK(la_record(h, eb, h->aux));
         eb_prev = eb;
         if (split_pass) FFGP_CHECK(pass_panel(pend, wn, eb));
         if (h->tri_hook_col > 0 && pend + wn == h->tri_hook_col) {   // the factor's columns < tri_hook_col are final from here on
-          FFGP_HIP(hipEventRecord(h->tri_ev[0], h->aux));
+          FFGP_CHECK(la_record(h, h->tri_ev[0], h->aux));
           h->tri_hook_fired = 1;
         }
         // main stream: S_ii(k), the rest of the trailing matrix
@@ -1816,12 +1923,12 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
           double* C2 = A + (size_t)(pend + wn) * lda + (pend + wn);
           FFGP_CHECK(potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P2, lda, P2, lda, C2, lda, mch - pend - wn, mt2,
                                       w1, -1.0, 1.0));
-          FFGP_HIP(hipEventRecord(ei, main_s));
+          FFGP_CHECK(la_record(h, ei, main_s));
           ei_prev = ei;
         }
       }
-      if (eb_prev) FFGP_HIP(hipStreamWaitEvent(main_s, eb_prev, 0));
-      if (pass_done) FFGP_HIP(hipStreamWaitEvent(main_s, pass_done, 0));
+      if (eb_prev) FFGP_CHECK(la_wait(h, main_s, eb_prev));
+      if (pass_done) FFGP_CHECK(la_wait(h, main_s, pass_done));
     }
     h->dinv_L = A;
     h->dinv_n = n;
@@ -1869,15 +1976,17 @@ int ffgp_potrf_ragged(ffgp_handle* h, int R, const ffgp_rag_block* mem) {
                                  DIAG_LDS_BYTES));
     h->diag_attr_set |= 4;
   }
+  FFGP_CHECK(la_begin(h));
   hipStream_t main_s = h->stream;
   hipStream_t chain_s = any_la ? h->aux : main_s;
   struct StreamGuard {      // whatever path leaves this function (the FFGP_HIP macros return at once), the handle gets its stream back
     ffgp_handle* h; hipStream_t s;
     ~StreamGuard() { h->stream = s; }
   } guard{h, main_s};
+  LaFlushGuard flush_guard{h};
   if (any_la) {
-    FFGP_HIP(hipEventRecord(h->la_ev[6], main_s));
-    FFGP_HIP(hipStreamWaitEvent(chain_s, h->la_ev[6], 0));
+    FFGP_CHECK(la_record(h, h->la_ev[6], main_s));
+    FFGP_CHECK(la_wait(h, chain_s, h->la_ev[6]));
   }
   std::vector<GemmRagIn> in;
   in.reserve(R);
@@ -1903,6 +2012,7 @@ int ffgp_potrf_ragged(ffgp_handle* h, int R, const ffgp_rag_block* mem) {
           ++cnt;
         }
         if (!cnt) continue;
+        la_take_deferred(h, dr);
         for (int c = cnt; c < FFGP_RAG_MAX; ++c) { dr.A[c] = dr.A[0]; dr.Dinv[c] = dr.Dinv[0]; dr.lda[c] = dr.lda[0]; dr.nb[c] = dr.nb[0]; dr.info[c] = dr.info[0]; }
         hipLaunchKernelGGL(ffgp_potrf_diag128_v3<true>, dim3(cnt), dim3(512), DIAG_LDS_BYTES, h->stream, (double*)nullptr, 0, 0, (double*)nullptr,
                            h->bt_info, j0, h->aux_prio, 0L, 0L, 0, dr);
@@ -1953,7 +2063,7 @@ int ffgp_potrf_ragged(ffgp_handle* h, int R, const ffgp_rag_block* mem) {
       }
       if (!in.empty()) {
         if (gate_pending) {      // the main stream's earlier contribution to these columns (S_bz of the previous panel) must have landed
-          FFGP_HIP(hipStreamWaitEvent(h->stream, eg_prev, 0));
+          FFGP_CHECK(la_wait(h, h->stream, eg_prev));
           gate_pending = false;
         }
         rc = ffgp_gemm_launch_rag(h, TILES_LOWER, 0, (int)in.size(), in.data(), -1.0, 1.0, ALIAS_NONE);
@@ -1974,8 +2084,8 @@ int ffgp_potrf_ragged(ffgp_handle* h, int R, const ffgp_rag_block* mem) {
     if (!in.empty()) rc = ffgp_gemm_launch_rag(h, TILES_LOWER, 1, (int)in.size(), in.data(), -1.0, 1.0, ALIAS_NONE);
     h->stream = main_s;
     if (rc != FFGP_OK || !any_la) continue;
-    FFGP_HIP(hipEventRecord(eb, chain_s));
-    FFGP_HIP(hipStreamWaitEvent(main_s, eb, 0));
+    FFGP_CHECK(la_record_deferred(h, eb, chain_s));     // (published by the next panel's first diagonal-block kernel)
+    FFGP_CHECK(la_wait(h, main_s, eb));
     // ---- look-ahead members, main stream: S_bz (the rest of the next panel's columns and its carry strip), then S_ii
     in.clear();
     for (int f = 0; f < R; ++f) {
@@ -1993,7 +2103,7 @@ int ffgp_potrf_ragged(ffgp_handle* h, int R, const ffgp_rag_block* mem) {
     if (!in.empty()) {
       rc = ffgp_gemm_launch_rag(h, TILES_LOWER, 1, (int)in.size(), in.data(), -1.0, 1.0, ALIAS_NONE);
       if (rc != FFGP_OK) break;
-      FFGP_HIP(hipEventRecord(eg, main_s));
+      FFGP_CHECK(la_record(h, eg, main_s));
       eg_prev = eg;
     }
     in.clear();
@@ -2012,6 +2122,7 @@ int ffgp_potrf_ragged(ffgp_handle* h, int R, const ffgp_rag_block* mem) {
     if (!in.empty()) rc = ffgp_gemm_launch_rag(h, TILES_LOWER, 1, (int)in.size(), in.data(), -1.0, 1.0, ALIAS_NONE);
   }
   h->stream = main_s;
+  if (la_flush(h) != FFGP_OK && rc == FFGP_OK) rc = FFGP_ERR_HIP;
   if (hipGetLastError() != hipSuccess && rc == FFGP_OK) rc = FFGP_ERR_HIP;
   return rc;
 }
