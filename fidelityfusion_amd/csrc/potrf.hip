@@ -1774,28 +1774,42 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
                                       -1.0, 1.0));
         }
       }
-    } else if (h->la_carry == 1 || (h->la_carry == 2 && n <= 12288)) {
-      // Look-ahead, "carry" form.  Panel k's own update kernels (one per 128-column block, K = 128) also cover Z(k+1) = the
-      // first 128 columns of panel k+1, so the chain goes from the last TRSM of panel k straight into the first diagonal
-      // block of panel k+1 -- no K = 512 strip update (S_a of the form below) and no event wait between two panels.
-      // The main stream's trailing update of step k is cut into S_b (the rest of panel k+1's columns: gates the chain's
-      // first update, as below) together with S_z (Z(k+2): panel k's contribution to the strip that chain k+1 will carry
-      // into -- its right-hand neighbour, so the two are one launch) and S_ii (everything right of Z(k+2)).  Writers of any one column range
-      // are ordered: Z(k+2) <- S_ii(<= k-1), S_z(k) on the main stream, then chain k+1 (after S_z's event).
+    } else {
+      // Look-ahead.  A high-priority side stream runs the dependency chain (per 128-column block: diagonal factor, TRSM, update of the
+      // panel's remaining columns), the main stream the trailing updates.  Two forms of an iteration (panel k complete, panel k+1 next):
+      //
+      // ROUND-1 form (while the trailing matrix has more than la_carry_rows rows).  The trailing update of step k is cut into S_a (the
+      // first 128 columns of panel k+1 -- all that its first diagonal factor and TRSM read), S_b (the rest of panel k+1's columns) and
+      // S_ii (everything to the right).  The side stream runs  S_a(k) -> panel k+1  back to back; the main stream runs S_b(k), S_ii(k).
+      // S_a sits on the chain's own stream: the only waits left on the chain are for hand-offs that fired long before (S_ii(k-1), S_b(k)).
+      //
+      // CARRY form (from there on; the whole factorisation for n <= la_carry_rows).  Panel k's own update kernels (one per 128-column
+      // block, K = 128) also cover Z(k+1) = the first 128 columns of panel k+1, so the chain goes from the last TRSM of panel k straight
+      // into the first diagonal block of panel k+1 -- no K = 512 strip update and no wait between two panels.  The main stream's update of
+      // step k is S_b(k) together with S_z(k) (Z(k+2): panel k's contribution to the strip that chain k+1 will carry into -- its
+      // right-hand neighbour, so the two are one launch, S_bz) and S_ii(k) (everything right of Z(k+2)).  Writers of any one column range
+      // are ordered: Z(k+2) <- S_ii(<= k-1), S_z(k) on the main stream, then chain k+1 (after S_bz's hand-off).
+      //
+      // The carry form wins where the chain is (nearly) the critical path, the round-1 form where the chain hides under the update: the
+      // carry makes the panel's K = 128 launches 128 columns wider.  Whole factorisations: carry -1.25 % at N = 14336, equal at 16384 /
+      // 20480, +0.6 ... +0.9 % at 24576 / 32768 (profiles/r05i_*).  So the form is chosen per ITERATION: the first carry iteration finds
+      // a panel that did not carry Z(k+1) and runs S_a(k) once more; from then on every panel carries.
       hipStream_t main_s = h->stream;
       LaFlushGuard flush_guard{h};
-      struct Polite64 {        // this form's 64-tile trailing updates leave half of every CU to the chain (gemm_plan); reset on every exit path
+      struct Polite64 {        // the carry iterations' 64-tile trailing updates leave half of every CU to the chain (gemm_plan); reset on every exit path
         int& f;
-        explicit Polite64(int& f_) : f(f_) { f = 1; }
+        explicit Polite64(int& f_) : f(f_) { f = 0; }
         ~Polite64() { f = 0; }
       } polite64(h->polite64_active);
-      auto carry_of = [&](int pend_) { return min(NB, n - pend_); };   // columns of the next panel's first block (0 at the end)
-      FFGP_CHECK(factor_panel(h, A, n, mch, lda, 0, min(pw(0), n), nullptr, max(0, carry_of(min(pw(0), n)))));
+      auto carry_of = [&](int pend_) { return max(0, min(NB, n - pend_)); };   // columns of the next panel's first block (0 at the end)
+      const int w0 = min(pw(0), n);
+      bool carried = (h->la_carry == 1) || (h->la_carry == 2 && n <= h->la_carry_rows);      // does the complete panel carry Z(k+1)?
+      FFGP_CHECK(factor_panel(h, A, n, mch, lda, 0, w0, nullptr, carried ? carry_of(w0) : 0));
       FFGP_CHECK(la_record(h, h->la_ev[6], main_s));
       FFGP_CHECK(la_wait(h, h->aux, h->la_ev[6]));
-      if (split_pass) FFGP_CHECK(pass_panel(0, min(pw(0), n), h->la_ev[6]));
+      if (split_pass) FFGP_CHECK(pass_panel(0, w0, h->la_ev[6]));
       int it = 0;
-      hipEvent_t eb_prev = nullptr;
+      hipEvent_t eb_prev = nullptr, ei_prev = nullptr;
       // Chain-bound tail on a CU-masked stream (option tail_mask_m): once the trailing matrix has fewer rows than that, the trailing
       // updates are issued to a stream that may not use tail_mask_cus CUs of every XCD -- those CUs stay free of trailing-update
       // workgroups, so the chain's kernels (unmasked side stream) start at once and run undisturbed instead of waiting for slots and
@@ -1806,19 +1820,32 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
         const int pend = k0 + w1;
         const int mt = n - pend;
         if (mt <= 0) break;
-        if (h->tail_mask_m > 0 && mch - pend < h->tail_mask_m && syrk_s == main_s && ffgp_ensure_masked(h) == FFGP_OK) {
+        // carry iteration: panel k+1 is factored carrying Z(k+2) (every later iteration is one too: the trailing matrix only shrinks)
+        const bool cm = (h->la_carry == 1) || (h->la_carry == 2 && (carried || mt <= h->la_carry_rows));
+        h->polite64_active = cm ? 1 : 0;
+        if (cm && h->tail_mask_m > 0 && mch - pend < h->tail_mask_m && syrk_s == main_s && ffgp_ensure_masked(h) == FFGP_OK) {
           FFGP_CHECK(la_record(h, h->la_ev[7], main_s));
           FFGP_CHECK(la_wait(h, h->masked, h->la_ev[7]));
           syrk_s = h->masked;
         }
         const int wn = min(pw(pend), mt);  // width of the next panel
         const int q = pend + wn;           // first column of panel k+2
-        const int wz = max(0, min(NB, n - q));
-        hipEvent_t eb = h->la_ev[(it & 1) * 3], eg = h->la_ev[(it & 1) * 3 + 1];
-        const int wa = min(NB, wn);        // Z(k+1): already complete (carried by panel k)
-        // main stream, once panel k is complete: S_b(k) and S_z(k) are neighbours (columns pend+wa .. q+wz): one launch, one event
+        const int wz = cm ? carry_of(q) : 0;
+        hipEvent_t eb = h->la_ev[(it & 1) * 3], eg = h->la_ev[(it & 1) * 3 + 1], ei = h->la_ev[(it & 1) * 3 + 2];
+        const int wa = (cm || h->la_split) ? min(NB, wn) : wn;     // Z(k+1)
+        // side stream: S_a(k) unless panel k carried it (after S_ii(k-1), which carried panel k-1 into these columns)
+        if (!carried) {
+          if (ei_prev) FFGP_CHECK(la_wait(h, h->aux, ei_prev));
+          double* P = A + (size_t)pend * lda + k0;
+          double* C = A + (size_t)pend * lda + pend;
+          h->stream = h->aux;
+          const int arc = potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P, lda, P, lda, C, lda, mch - pend, wa, w1, -1.0, 1.0);
+          h->stream = main_s;
+          FFGP_CHECK(arc);
+        }
+        // main stream, once panel k is complete: S_b(k) (and S_z(k), its right-hand neighbour: columns pend+wa .. q+wz, one launch)
         if (eb_prev) FFGP_CHECK(la_wait(h, syrk_s, eb_prev));
-        hipEvent_t gate = nullptr, gate2 = nullptr;
+        hipEvent_t gate = nullptr;
         if (wn - wa + wz > 0) {
           double* Pb = A + (size_t)(pend + wa) * lda + k0;
           double* Cb = A + (size_t)(pend + wa) * lda + (pend + wa);
@@ -1830,20 +1857,24 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
           FFGP_CHECK(la_record(h, eg, syrk_s));
           gate = eg;
         }
-        // side stream: panel k+1, carrying Z(k+2)
+        // side stream: panel k+1 (carrying Z(k+2) in a carry iteration)
         h->stream = h->aux;
-        int rc = factor_panel(h, A, n, mch, lda, pend, wn, gate, wz, gate2);
+        const int rc = factor_panel(h, A, n, mch, lda, pend, wn, gate, wz);
         h->stream = main_s;
         FFGP_CHECK(rc);
-        FFGP_CHECK(la_record_deferred(h, eb, h->aux));     // (published by the next panel's first diagonal-block kernel)
+        if (cm)
+          FFGP_CHECK(la_record_deferred(h, eb, h->aux));     // (published by the next panel's first diagonal-block kernel)
+        else
+          FFGP_CHECK(la_record(h, eb, h->aux));              // (the next kernel on the side stream is S_a(k+1))
         eb_prev = eb;
         if (split_pass) FFGP_CHECK(pass_panel(pend, wn, eb));
         if (h->tri_hook_col > 0 && pend + wn == h->tri_hook_col) {   // the factor's columns < tri_hook_col are final from here on
           FFGP_CHECK(la_record(h, h->tri_ev[0], h->aux));
           h->tri_hook_fired = 1;
         }
-        // main stream: S_ii(k), everything right of Z(k+2)
+        // main stream: S_ii(k), everything right of panel k+1 and of Z(k+2)
         const int mt2 = mt - wn - wz;
+        ei_prev = nullptr;
         if (mt2 > 0) {
           double* P2 = A + (size_t)(q + wz) * lda + k0;
           double* C2 = A + (size_t)(q + wz) * lda + (q + wz);
@@ -1851,81 +1882,17 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
           const int irc = potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P2, lda, P2, lda, C2, lda, mch - q - wz, mt2, w1, -1.0, 1.0);
           h->stream = main_s;
           FFGP_CHECK(irc);
+          if (!cm) {                                          // (the next iteration's S_a waits for it)
+            FFGP_CHECK(la_record(h, ei, syrk_s));
+            ei_prev = ei;
+          }
         }
+        carried = cm;
       }
       FFGP_CHECK(la_flush(h));
       if (syrk_s != main_s) {
         FFGP_CHECK(la_record(h, h->la_ev[8], syrk_s));
         FFGP_CHECK(la_wait(h, main_s, h->la_ev[8]));
-      }
-      if (eb_prev) FFGP_CHECK(la_wait(h, main_s, eb_prev));
-      if (pass_done) FFGP_CHECK(la_wait(h, main_s, pass_done));
-    } else {
-      // Look-ahead.  The trailing update of step k is cut into S_a (the first 128 columns of panel k+1 -- all that its
-      // first diagonal factor and TRSM read), S_b (the rest of panel k+1's columns) and S_ii (everything to the right).
-      // The side stream (high priority) runs the dependency chain  S_a(k) -> panel k+1 (diag -> TRSM -> update, x4)
-      // back to back; the main stream runs S_b(k), S_ii(k).  While the trailing matrix is large the chain hides under
-      // S_ii; once it is small the chain IS the critical path -- which is why S_a sits on the chain's own stream:
-      // a cross-stream event hand-off costs ~13 us, and the only waits left on the chain are for events that fired
-      // long before (S_ii(k-1), S_b(k)).  Panel k+1 touches only its own columns; S_ii reads panel k and writes the
-      // columns to the right of panel k+1, so the two streams never alias.
-      hipStream_t main_s = h->stream;
-      FFGP_CHECK(factor_panel(h, A, n, mch, lda, 0, min(pw(0), n)));
-      FFGP_CHECK(la_record(h, h->la_ev[6], main_s));
-      FFGP_CHECK(la_wait(h, h->aux, h->la_ev[6]));
-      if (split_pass) FFGP_CHECK(pass_panel(0, min(pw(0), n), h->la_ev[6]));
-      int it = 0;
-      hipEvent_t eb_prev = nullptr, ei_prev = nullptr;
-      for (int k0 = 0; k0 < n; k0 += pw(k0), ++it) {
-        const int w1 = min(pw(k0), n - k0);
-        const int pend = k0 + w1;
-        const int mt = n - pend;
-        if (mt <= 0) break;
-        const int wn = min(pw(pend), mt);  // width of the next panel
-        double* P = A + (size_t)pend * lda + k0;
-        double* C = A + (size_t)pend * lda + pend;
-        hipEvent_t eb = h->la_ev[(it & 1) * 3], eg = h->la_ev[(it & 1) * 3 + 1], ei = h->la_ev[(it & 1) * 3 + 2];
-        const int wa = h->la_split ? min(NB, wn) : wn;
-        // side stream: S_a(k) (after S_ii(k-1), which carried panel k-1 into these columns)
-        if (ei_prev) FFGP_CHECK(la_wait(h, h->aux, ei_prev));
-        h->stream = h->aux;
-        int rc = potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P, lda, P, lda, C, lda, mch - pend, wa, w1, -1.0, 1.0);
-        h->stream = main_s;
-        FFGP_CHECK(rc);
-        // main stream: S_b(k) once panel k is complete
-        if (eb_prev) FFGP_CHECK(la_wait(h, main_s, eb_prev));
-        hipEvent_t gate = nullptr;
-        if (wn > wa) {
-          double* Pb = A + (size_t)(pend + wa) * lda + k0;
-          double* Cb = A + (size_t)(pend + wa) * lda + (pend + wa);
-          FFGP_CHECK(potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, Pb, lda, Pb, lda, Cb, lda, mch - pend - wa, wn - wa,
-                                      w1, -1.0, 1.0));
-          FFGP_CHECK(la_record(h, eg, main_s));
-          gate = eg;
-        }
-        // side stream: panel k+1
-        h->stream = h->aux;
-        rc = factor_panel(h, A, n, mch, lda, pend, wn, gate);
-        h->stream = main_s;
-        FFGP_CHECK(rc);
-        FFGP_CHECK(la_record(h, eb, h->aux));
-        eb_prev = eb;
-        if (split_pass) FFGP_CHECK(pass_panel(pend, wn, eb));
-        if (h->tri_hook_col > 0 && pend + wn == h->tri_hook_col) {   // the factor's columns < tri_hook_col are final from here on
-          FFGP_CHECK(la_record(h, h->tri_ev[0], h->aux));
-          h->tri_hook_fired = 1;
-        }
-        // main stream: S_ii(k), the rest of the trailing matrix
-        const int mt2 = mt - wn;
-        ei_prev = nullptr;
-        if (mt2 > 0) {
-          double* P2 = A + (size_t)(pend + wn) * lda + k0;
-          double* C2 = A + (size_t)(pend + wn) * lda + (pend + wn);
-          FFGP_CHECK(potrf_gemm(h, OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1, P2, lda, P2, lda, C2, lda, mch - pend - wn, mt2,
-                                      w1, -1.0, 1.0));
-          FFGP_CHECK(la_record(h, ei, main_s));
-          ei_prev = ei;
-        }
       }
       if (eb_prev) FFGP_CHECK(la_wait(h, main_s, eb_prev));
       if (pass_done) FFGP_CHECK(la_wait(h, main_s, pass_done));
@@ -1964,7 +1931,7 @@ int ffgp_potrf_ragged(ffgp_handle* h, int R, const ffgp_rag_block* mem) {
     const ffgp_rag_block& b = mem[f];
     if (!b.A || !b.dinv || b.n <= 0 || b.lda < b.n || b.mtot < b.n || (b.lda & 1) || (reinterpret_cast<uintptr_t>(b.A) & 15)) return FFGP_ERR_ARG;
     if (!h->lookahead || b.n <= NB1 || b.n <= h->la_min_n) form[f] = 0;
-    else if (h->la_carry == 1 || (h->la_carry == 2 && b.n <= 12288)) form[f] = 1;
+    else if (h->la_carry == 1 || (h->la_carry == 2 && b.n <= h->la_carry_rows)) form[f] = 1;
     else return FFGP_ERR_ARG;
     any_la = any_la || form[f] == 1;
     nmax = max(nmax, b.n);
