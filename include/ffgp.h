@@ -169,10 +169,17 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
             "la_min_n" (default 3584: smaller blocks are factored in order on one stream -- every cross-stream event wait costs
                         ~6 us of queue barrier, more than the overlap returns below that size; 0 = look ahead at every size),
             "la_split" (default 1: the look-ahead column update covers the next panel's first 128 columns only),
-            "la_carry" (a panel's own update kernels also cover the next panel's first 128 columns, so no strip update sits
-                        between two panels on the dependency chain: 1 = always, 0 = never (the S_a / S_b / S_ii form),
-                        default 2 = for n <= 12288 -- the chain-bound sizes gain 2-5 %, at n = 16384 the trailing update's
-                        in-situ rate drops 4 % for no gain in total),
+            "la_carry" / "la_carry_rows" (a panel's own update kernels also cover the next panel's first 128 columns, so no strip update
+                        sits between two panels on the dependency chain: 1 = always, 0 = never (the S_a / S_b / S_ii form),
+                        default 2 = in the ITERATIONS whose trailing matrix has at most la_carry_rows rows (default 12288; blocks up to that
+                        size are carry form throughout; a larger block starts in the S_a / S_b / S_ii form -- there the chain hides under
+                        the update and the carry only widens its launches -- and changes over: N = 16384 28.55 -> 28.23 ms),
+            "ho_values" / "ho_defer" (default 1 / 1: the look-ahead's hand-offs between its two streams are values in device memory --
+                        hipStreamWriteValue32 behind the producer, hipStreamWaitValue32 in front of the consumer, 2.9-4.7 us per hop
+                        against 10.7-11.1 for hipEventRecord + hipStreamWaitEvent on this runtime -- and the word that says "panel k is
+                        complete" is written by the next panel's first diagonal-block kernel as it starts instead of by a 5 us write
+                        kernel on the chain: N = 4096 / 8192 / 12288 -5.3 / -2.4 / -1.7 %, values unchanged; ho_values = 0: the event
+                        pairs, which are also what a stream under graph capture gets),
             "aux_prio" (default 1: raised wave priority for the side stream's kernels),
             "gemm_tile" (0 = automatic; 32 / 64 / 128 force the GEMM tile shape -- tests and benchmarks),
             "small_tile_threshold" (default 640: launches with fewer 128-tiles use 64-tiles),
@@ -224,6 +231,8 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
             "polite64_pad_kb" (default 60, at most 64: unused dynamic LDS requested by the 64-tile trailing updates of ONE block's carry-form
                         look-ahead -- two of their workgroups per CU instead of four, so the chain's kernels are not slowed to a third
                         beside them; N = 4096 / 6144 / 8192 / 12288: -1.2 / -3.0 / -2.0 / -1.0 %, values unchanged; 0 = off),
+            "polite32_pad_kb" (default 34: the same for that form's 32-tile trailing updates -- three workgroups per CU; N = 4096 / 5120
+                        -0.8 ... -1.5 %; 0 = off),
             "trsm128" / "trsm128_max_m" (default 1 / 8192: the factorisation chain's full-block TRSM runs on its own latency-shaped
                         kernel for panels of at most trsm128_max_m rows; the values are the general GEMM's bit for bit),
             "chase_xl" / "chase_xl_max_n" (default 1 / 2048: bands of up to chase_xl_max_n columns run their bulge chase with every
