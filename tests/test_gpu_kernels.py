@@ -413,6 +413,62 @@ def test_potrf_polite_64_tile_updates_change_nothing_but_the_occupancy(ff):
     assert _lib.lib.ffgp_set_option(h, b"polite64_pad_kb", 65.0) != 0      # (more than 64 KiB of dynamic LDS is not requested)
 
 
+def test_potrf_value_handoffs_are_the_event_handoffs_bit_for_bit(ff):
+    """the look-ahead's cross-stream hand-offs as values in device memory (hipStreamWriteValue32 / hipStreamWaitValue32, option ho_values),
+    the "panel complete" word written by the next diagonal-block kernel (ho_defer), and the event pairs they replace: the same launches in
+    the same order on the same data -- only the waiting differs -- so the factor and the passenger rows are identical to the last bit;
+    repeated calls reuse the words with growing sequence numbers"""
+    _lib, h = ff
+    n, m = 4700, 40
+    rng = np.random.default_rng(n + 1)
+    B = rng.standard_normal((n, 48))
+    S = B @ B.T + np.diag(rng.random(n) + 0.5)
+    R = rng.standard_normal((m, n))
+    outs = {}
+    try:
+        for key, (hv, hd) in {"events": (0, 0), "values": (1, 0), "deferred": (1, 1), "deferred again": (1, 1)}.items():
+            assert _lib.lib.ffgp_set_option(h, b"ho_values", float(hv)) == 0
+            assert _lib.lib.ffgp_set_option(h, b"ho_defer", float(hd)) == 0
+            rc, out, _, _ = potrf(ff, S, R)
+            assert rc == 0
+            outs[key] = out
+    finally:
+        _lib.lib.ffgp_set_option(h, b"ho_values", 1.0)
+        _lib.lib.ffgp_set_option(h, b"ho_defer", 1.0)
+    low = np.tril_indices(n)
+    for key in ("values", "deferred", "deferred again"):
+        assert np.array_equal(outs[key][:n, :n][low], outs["events"][:n, :n][low]), key
+        assert np.array_equal(outs[key][n:, :n], outs["events"][n:, :n]), key
+    assert relerr(np.tril(outs["deferred"][:n, :n]), np.linalg.cholesky(S)) < 1e-11
+
+
+def test_potrf_lookahead_form_changes_over_inside_one_factorisation(ff):
+    """la_carry_rows: a block larger than that starts with round-1 iterations (S_a on the chain's stream) and changes over to carry
+    iterations once its trailing matrix is small enough; the first carry iteration meets a panel that carried nothing.  Exercised at a
+    small size by lowering the threshold: every choice of the change-over point (none, first iteration, in the middle, always carry) gives
+    LAPACK's factor, and the same passenger rows to rounding"""
+    _lib, h = ff
+    n, m = 5000, 24
+    rng = np.random.default_rng(n + 2)
+    B = rng.standard_normal((n, 40))
+    S = B @ B.T + np.diag(rng.random(n) + 0.5)
+    R = rng.standard_normal((m, n))
+    L = np.linalg.cholesky(S)
+    want_rows = np.linalg.solve(L, R.T).T
+    outs = {}
+    try:
+        for rows_ in (0, 2048, 3000, 4488, 12288):
+            assert _lib.lib.ffgp_set_option(h, b"la_carry_rows", float(rows_)) == 0
+            rc, out, _, _ = potrf(ff, S, R)
+            assert rc == 0, rows_
+            outs[rows_] = out
+            assert relerr(np.tril(out[:n, :n]), L) < 1e-11, rows_
+            assert relerr(out[n:, :n], want_rows) < 1e-9, rows_
+    finally:
+        _lib.lib.ffgp_set_option(h, b"la_carry_rows", 12288.0)
+    assert _lib.lib.ffgp_set_option(h, b"la_carry_rows", -1.0) != 0
+
+
 def test_potrf_naive_kernels_agree(ff):
     rng = np.random.default_rng(2)
     S = spd(200, rng)
