@@ -239,7 +239,8 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->super_min_n = 2048;
   h->la_split = 1;
   h->la_carry = 2;
-  h->la_carry_rows = 12288;
+  h->la_carry_n = 12288;
+  h->la_carry_rows = 8192;
   h->la_min_n = 3584;
   h->pass_split_min = 0;        // (measured and lost, docs/experiments.md: 0 = the passenger rows ride in the chain's launches)
   h->tail_mask_cus = 8;
@@ -438,6 +439,9 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->pass_split_min = (int)value;
   } else if (!strcmp(key, "la_carry")) {
     h->la_carry = (int)value;
+  } else if (!strcmp(key, "la_carry_n")) {
+    if (value < 0) return FFGP_ERR_ARG;
+    h->la_carry_n = (int)value;
   } else if (!strcmp(key, "la_carry_rows")) {
     if (value < 0) return FFGP_ERR_ARG;
     h->la_carry_rows = (int)value;
@@ -890,7 +894,7 @@ int ffgp_nlml_fused_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ff
   if (!uniform) {      // members of different sizes: the ragged chain's own limits (ffgp_potrf_ragged)
     if (h->nb_big > h->nb_outer) return FFGP_ERR_ARG;
     for (int f = 0; f < F; ++f)
-      if (h->lookahead && p[f].n > h->nb_outer && p[f].n > h->la_min_n && !(h->la_carry == 1 || (h->la_carry == 2 && p[f].n <= h->la_carry_rows)))
+      if (h->lookahead && p[f].n > h->nb_outer && p[f].n > h->la_min_n && !(h->la_carry == 1 || (h->la_carry == 2 && p[f].n <= h->la_carry_n)))
         return FFGP_ERR_ARG;
   }
   FFGP_HIP(hipSetDevice(h->device));

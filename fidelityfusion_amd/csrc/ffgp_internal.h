@@ -171,8 +171,10 @@ struct ffgp_handle {
   int la_min_n;         // blocks up to this size are factored in order (no side stream): below ~3500 the event hand-offs of the
                         // look-ahead cost more than the overlap returns
   int la_carry;         // the panel's own update kernels also carry the next panel's first 128 columns (no S_a on the chain):
-                        // 0 = never, 1 = always, 2 = in the iterations whose trailing matrix has at most la_carry_rows rows (default)
-  int la_carry_rows;    // ... (default 12288; blocks up to this size are carry-form throughout, the members a ragged chain accepts)
+                        // 0 = never, 1 = always, 2 (default) = throughout for blocks of at most la_carry_n rows, and for larger blocks in
+                        // the iterations whose trailing matrix has at most la_carry_rows rows
+  int la_carry_n;       // ... (default 12288; also the largest member a ragged chain accepts)
+  int la_carry_rows;    // ... (default 8192)
   int diag_attr_set;    // dynamic-LDS attribute of potrf_diag128 set on this handle's device
   int band_log2;        // GEMM tile order: band height 2^band_log2 tile rows (default 3)
   int split_rem_max;    // split tail of the 128-tile launches: quarter the last (tiles mod 256) tiles when that is <= this (0 = off)

@@ -1778,12 +1778,12 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
       // Look-ahead.  A high-priority side stream runs the dependency chain (per 128-column block: diagonal factor, TRSM, update of the
       // panel's remaining columns), the main stream the trailing updates.  Two forms of an iteration (panel k complete, panel k+1 next):
       //
-      // ROUND-1 form (while the trailing matrix has more than la_carry_rows rows).  The trailing update of step k is cut into S_a (the
+      // ROUND-1 form (blocks of more than la_carry_n rows, while their trailing matrix has more than la_carry_rows rows).  The trailing update of step k is cut into S_a (the
       // first 128 columns of panel k+1 -- all that its first diagonal factor and TRSM read), S_b (the rest of panel k+1's columns) and
       // S_ii (everything to the right).  The side stream runs  S_a(k) -> panel k+1  back to back; the main stream runs S_b(k), S_ii(k).
       // S_a sits on the chain's own stream: the only waits left on the chain are for hand-offs that fired long before (S_ii(k-1), S_b(k)).
       //
-      // CARRY form (from there on; the whole factorisation for n <= la_carry_rows).  Panel k's own update kernels (one per 128-column
+      // CARRY form (from there on; the whole factorisation for n <= la_carry_n).  Panel k's own update kernels (one per 128-column
       // block, K = 128) also cover Z(k+1) = the first 128 columns of panel k+1, so the chain goes from the last TRSM of panel k straight
       // into the first diagonal block of panel k+1 -- no K = 512 strip update and no wait between two panels.  The main stream's update of
       // step k is S_b(k) together with S_z(k) (Z(k+2): panel k's contribution to the strip that chain k+1 will carry into -- its
@@ -1803,7 +1803,7 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
       } polite64(h->polite64_active);
       auto carry_of = [&](int pend_) { return max(0, min(NB, n - pend_)); };   // columns of the next panel's first block (0 at the end)
       const int w0 = min(pw(0), n);
-      bool carried = (h->la_carry == 1) || (h->la_carry == 2 && n <= h->la_carry_rows);      // does the complete panel carry Z(k+1)?
+      bool carried = (h->la_carry == 1) || (h->la_carry == 2 && n <= h->la_carry_n);      // does the complete panel carry Z(k+1)?  (blocks up to la_carry_n rows: carry form throughout)
       FFGP_CHECK(factor_panel(h, A, n, mch, lda, 0, w0, nullptr, carried ? carry_of(w0) : 0));
       FFGP_CHECK(la_record(h, h->la_ev[6], main_s));
       FFGP_CHECK(la_wait(h, h->aux, h->la_ev[6]));
@@ -1931,7 +1931,7 @@ int ffgp_potrf_ragged(ffgp_handle* h, int R, const ffgp_rag_block* mem) {
     const ffgp_rag_block& b = mem[f];
     if (!b.A || !b.dinv || b.n <= 0 || b.lda < b.n || b.mtot < b.n || (b.lda & 1) || (reinterpret_cast<uintptr_t>(b.A) & 15)) return FFGP_ERR_ARG;
     if (!h->lookahead || b.n <= NB1 || b.n <= h->la_min_n) form[f] = 0;
-    else if (h->la_carry == 1 || (h->la_carry == 2 && b.n <= h->la_carry_rows)) form[f] = 1;
+    else if (h->la_carry == 1 || (h->la_carry == 2 && b.n <= h->la_carry_n)) form[f] = 1;
     else return FFGP_ERR_ARG;
     any_la = any_la || form[f] == 1;
     nmax = max(nmax, b.n);

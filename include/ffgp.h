@@ -169,11 +169,13 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
             "la_min_n" (default 3584: smaller blocks are factored in order on one stream -- every cross-stream event wait costs
                         ~6 us of queue barrier, more than the overlap returns below that size; 0 = look ahead at every size),
             "la_split" (default 1: the look-ahead column update covers the next panel's first 128 columns only),
-            "la_carry" / "la_carry_rows" (a panel's own update kernels also cover the next panel's first 128 columns, so no strip update
-                        sits between two panels on the dependency chain: 1 = always, 0 = never (the S_a / S_b / S_ii form),
-                        default 2 = in the ITERATIONS whose trailing matrix has at most la_carry_rows rows (default 12288; blocks up to that
-                        size are carry form throughout; a larger block starts in the S_a / S_b / S_ii form -- there the chain hides under
-                        the update and the carry only widens its launches -- and changes over: N = 16384 28.55 -> 28.23 ms),
+            "la_carry" / "la_carry_n" / "la_carry_rows" (a panel's own update kernels also cover the next panel's first 128 columns, so
+                        no strip update sits between two panels on the dependency chain: 1 = always, 0 = never (the S_a / S_b / S_ii
+                        form), default 2 = throughout for blocks of at most la_carry_n rows (default 12288), and for larger blocks in
+                        the ITERATIONS whose trailing matrix has at most la_carry_rows rows (default 8192): such a block starts in the
+                        S_a / S_b / S_ii form -- there the chain hides under the update and the carry only widens its launches -- and
+                        changes over.  Headline bench line, la_carry_rows = 0 / 6144 / 8192 / 10240 / 12288: 28.83 / 28.61 / 28.51 / 28.47 /
+                        28.43 ms with the roofline kernel at 0.697 / 0.697 / 0.693 / 0.690 / 0.685 of peak beside the heavier chain),
             "ho_values" / "ho_defer" (default 1 / 1: the look-ahead's hand-offs between its two streams are values in device memory --
                         hipStreamWriteValue32 behind the producer, hipStreamWaitValue32 in front of the consumer, 2.9-4.7 us per hop
                         against 10.7-11.1 for hipEventRecord + hipStreamWaitEvent on this runtime -- and the word that says "panel k is

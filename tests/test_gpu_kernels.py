@@ -443,7 +443,7 @@ def test_potrf_value_handoffs_are_the_event_handoffs_bit_for_bit(ff):
 
 
 def test_potrf_lookahead_form_changes_over_inside_one_factorisation(ff):
-    """la_carry_rows: a block larger than that starts with round-1 iterations (S_a on the chain's stream) and changes over to carry
+    """la_carry_n / la_carry_rows: a block of more than la_carry_n rows starts with round-1 iterations (S_a on the chain's stream) and changes over to carry
     iterations once its trailing matrix is small enough; the first carry iteration meets a panel that carried nothing.  Exercised at a
     small size by lowering the threshold: every choice of the change-over point (none, first iteration, in the middle, always carry) gives
     LAPACK's factor, and the same passenger rows to rounding"""
@@ -457,6 +457,7 @@ def test_potrf_lookahead_form_changes_over_inside_one_factorisation(ff):
     want_rows = np.linalg.solve(L, R.T).T
     outs = {}
     try:
+        assert _lib.lib.ffgp_set_option(h, b"la_carry_n", 0.0) == 0          # (no block is small enough to be carry form throughout)
         for rows_ in (0, 2048, 3000, 4488, 12288):
             assert _lib.lib.ffgp_set_option(h, b"la_carry_rows", float(rows_)) == 0
             rc, out, _, _ = potrf(ff, S, R)
@@ -465,7 +466,8 @@ def test_potrf_lookahead_form_changes_over_inside_one_factorisation(ff):
             assert relerr(np.tril(out[:n, :n]), L) < 1e-11, rows_
             assert relerr(out[n:, :n], want_rows) < 1e-9, rows_
     finally:
-        _lib.lib.ffgp_set_option(h, b"la_carry_rows", 12288.0)
+        _lib.lib.ffgp_set_option(h, b"la_carry_rows", 8192.0)
+        _lib.lib.ffgp_set_option(h, b"la_carry_n", 12288.0)
     assert _lib.lib.ffgp_set_option(h, b"la_carry_rows", -1.0) != 0
 
 
