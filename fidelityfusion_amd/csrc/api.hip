@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <strings.h>
 
 #include "ffgp_internal.h"
 
@@ -215,6 +216,30 @@ extern "C" int ffgp_prepare_streams(ffgp_handle* h) {
   return FFGP_OK;
 }
 
+// Value hand-offs (potrf.hip) make a stream WAIT inside a one-workgroup kernel for a word another queue's kernel will write.  Anything
+// that runs the process's kernels strictly one at a time -- rocprofv3's counter collection (--pmc / counter groups: it serialises the
+// dispatches of all queues; seen as a hang of the PMC passes of tools/profile_round.sh), thread trace, the rocprofiler v1 / v2 tools,
+// HIP_LAUNCH_BLOCKING, AMD_SERIALIZE_KERNEL -- would leave that kernel spinning for a producer that can never start.  In such a
+// process the handle keeps the event pairs (the command processor waits for those, no kernel does).  FFGP_HANDOFF=events / values
+// overrides the detection.
+static bool env_on(const char* key) {
+  const char* v = getenv(key);
+  return v && *v && strcmp(v, "0") && strcasecmp(v, "false") && strcasecmp(v, "off");
+}
+static int default_ho_values() {
+  const char* f = getenv("FFGP_HANDOFF");
+  if (f && !strcmp(f, "events")) return 0;
+  if (f && !strcmp(f, "values")) return 1;
+  static const char* const serialising[] = {"ROCPROF_COUNTER_COLLECTION", "ROCPROF_COUNTERS", "ROCPROF_COUNTER_GROUPS", "ROCPROF_ADVANCED_THREAD_TRACE",
+                                            "ROCP_METRICS", "ROCPROFILER_METRICS_PATH", "HIP_LAUNCH_BLOCKING", "CUDA_LAUNCH_BLOCKING",
+                                            "AMD_SERIALIZE_KERNEL", "AMD_SERIALIZE_COPY"};
+  for (const char* k : serialising)
+    if (env_on(k)) return 0;
+  const char* tools = getenv("HSA_TOOLS_LIB");
+  if (tools && (strstr(tools, "rocprofiler64") || strstr(tools, "libroctracer"))) return 0;
+  return 1;
+}
+
 int ffgp_create(int device, ffgp_handle** out) {
   if (!out) return FFGP_ERR_ARG;
   int count = 0;
@@ -256,7 +281,7 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->trsm128 = 1;
   h->polite64_pad_kb = 60;
   h->polite32_pad_kb = 34;
-  h->ho_values = 1;
+  h->ho_values = default_ho_values();
   h->ho_defer = 1;
   h->ho_defer_slot = -1;
   h->polite64_active = 0;

@@ -181,7 +181,11 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
                         against 10.7-11.1 for hipEventRecord + hipStreamWaitEvent on this runtime -- and the word that says "panel k is
                         complete" is written by the next panel's first diagonal-block kernel as it starts instead of by a 5 us write
                         kernel on the chain: N = 4096 / 8192 / 12288 -5.3 / -2.4 / -1.7 %, values unchanged; ho_values = 0: the event
-                        pairs, which are also what a stream under graph capture gets),
+                        pairs, which are also what a stream under graph capture gets.  A value wait is a one-workgroup KERNEL that
+                        polls the word, so a process whose kernels run strictly one at a time must not use it: ffgp_create starts a
+                        handle with ho_values = 0 when it sees rocprofv3's counter collection (ROCPROF_COUNTER_COLLECTION: --pmc
+                        serialises the dispatches of all queues), thread trace, the rocprofiler v1 / v2 tool libraries,
+                        HIP_LAUNCH_BLOCKING or AMD_SERIALIZE_KERNEL in the environment; FFGP_HANDOFF=events / values overrides),
             "aux_prio" (default 1: raised wave priority for the side stream's kernels),
             "gemm_tile" (0 = automatic; 32 / 64 / 128 force the GEMM tile shape -- tests and benchmarks),
             "small_tile_threshold" (default 640: launches with fewer 128-tiles use 64-tiles),
