@@ -1607,6 +1607,15 @@ static int la_begin(ffgp_handle* h) {
     return FFGP_OK;
   }
   if (st != hipStreamCaptureStatusNone) return FFGP_OK;
+  // A value wait is a polling kernel: it must never sit in the same hardware queue in front of its producer.  The runtime keeps queues per
+  // priority, and the side stream is created at the greatest one -- a caller's stream of that same priority (ffgp_set_stream) could share
+  // its queue, so such a binding keeps the event pairs.
+  int pm = 0, pa = 0;
+  if (hipStreamGetPriority(h->stream, &pm) != hipSuccess || hipStreamGetPriority(h->aux, &pa) != hipSuccess) {
+    (void)hipGetLastError();
+    return FFGP_OK;
+  }
+  if (pm == pa) return FFGP_OK;
   unsigned top = 0;
   for (int i = 0; i < 10; ++i) top = max(top, h->ho_seq[i]);
   if (top > 0x3fffffffu) {

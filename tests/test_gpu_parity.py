@@ -2762,3 +2762,30 @@ def test_triangular_inverse_head_never_reads_above_the_diagonal():
         for mode in (2, 0):
             for a, b in zip(outs[1], outs[mode]):
                 assert bool(torch.isfinite(b).all()) and torch.equal(a, b), (n, mode)
+
+
+def test_lookahead_on_a_caller_stream_of_the_side_streams_priority():
+    """the look-ahead's value hand-offs are polling kernels and rely on the caller's stream and the library's side stream sitting in different
+    hardware queues (different priorities); a caller's stream of the side stream's own priority keeps the event pairs -- same launches, same
+    value bit for bit, no hang"""
+    from fidelityfusion_amd import functional as F
+    n = 4200
+    rng = np.random.default_rng(n)
+    X = T(rng.uniform(0, 1, (n, 4)))
+    Y = T(rng.standard_normal((n, 2)))
+    w = T(rng.uniform(0.5, 2.0, 4))
+    amp = T([1.3])
+    dadd = T([0.05])
+    with torch.no_grad():
+        ref = F.nlml(X, Y, w, amp, diag_add=dadd, clamp=1e-30).clone()
+    torch.cuda.synchronize()
+    lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+    for prio in sorted({hi, lo, 0}):
+        st = torch.cuda.Stream(priority=prio)
+        with torch.cuda.stream(st), torch.no_grad():
+            for _ in range(3):
+                got = F.nlml(X, Y, w, amp, diag_add=dadd, clamp=1e-30).clone()
+        st.synchronize()
+        assert torch.equal(got, ref), prio
+    with torch.no_grad():
+        assert torch.equal(F.nlml(X, Y, w, amp, diag_add=dadd, clamp=1e-30), ref)
