@@ -282,8 +282,9 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->polite64_pad_kb = 60;
   h->polite32_pad_kb = 34;
   h->ho_values = default_ho_values();
-  h->ho_defer = 1;
+  h->ho_defer = 2;
   h->ho_defer_slot = -1;
+  h->ho_gdefer_slot = -1;
   h->polite64_active = 0;
   h->trsm128_max_m = 8192;
   h->trtri_overlap = 1;
@@ -423,7 +424,8 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "ho_values")) {
     h->ho_values = value != 0.0;
   } else if (!strcmp(key, "ho_defer")) {
-    h->ho_defer = value != 0.0;
+    if (value < 0 || value > 2) return FFGP_ERR_ARG;
+    h->ho_defer = (int)value;
   } else if (!strcmp(key, "polite32_pad_kb")) {
     if (value < 0 || value > 64) return FFGP_ERR_ARG;
     h->polite32_pad_kb = (int)value;

@@ -117,6 +117,8 @@ struct GemmArgs {
   int batch2;
   long sA2, sB2, sC2;
   const double* pack;   // the panel in the MFMA operand layout (gemm_tile_direct), or null
+  unsigned* pub_word;   // a look-ahead hand-off this launch publishes as it starts (everything before it on its stream is complete then:
+  unsigned pub_val;     // potrf.hip, la_record_on_next_gemm), or null
 };
 
 // one member of a ragged GEMM launch (ffgp_gemm_f64_rag): everything of GemmArgs that differs between the members
@@ -154,6 +156,8 @@ struct ffgp_handle {
   int ho_active;        // set per factorisation (la_begin): value hand-offs in use (not while a stream is being captured)
   int ho_defer;         // option "ho_defer" (default 1): the chain's "panel complete" word is written by the next diagonal-block kernel
   int ho_defer_slot;    // pending publication (-1 none) ...
+  int ho_gdefer_slot;   // the same for the next GEMM launched on ho_gdefer_stream (the trailing update that follows S_bz on the main stream)
+  hipStream_t ho_gdefer_stream;
   hipStream_t ho_defer_stream;  // ... for the next diagonal-block kernel launched on this stream
   int aux_prio;         // 1 = look-ahead chain kernels run at raised wave priority
   int force_ts;         // 0 = automatic GEMM tile shape, 32 / 64 / 128 = forced (benchmarks, tests)

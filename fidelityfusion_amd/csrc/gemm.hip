@@ -661,6 +661,9 @@ template <int OPA, int OPB, int MODE, int TAG, int TM, int TN>
 __global__ __launch_bounds__(256, 2) void ffgp_gemm_f64(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) double smem[2 * (opbuf<OPA, TM>() + opbuf<OPB, TN>())];
   const int tid = threadIdx.x;
+  // (look-ahead hand-off published by this launch's first workgroup: the launches before it on this stream have completed)
+  if (p.pub_word && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+    __hip_atomic_store(p.pub_word, p.pub_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (p.prio) __builtin_amdgcn_s_setprio(2);  // panel GEMMs of the look-ahead chain outrank the trailing update
   // batched launches (gridDim.y > 1): identical problems at fixed strides (the levels of the blocked TRTRI)
   const double* __restrict__ Ag = p.A + (size_t)blockIdx.y * p.sA + (size_t)blockIdx.z * p.sA2;
@@ -1005,6 +1008,13 @@ static int gemm_plan(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
     a.pad_lds = h->polite64_pad_kb * 1024;
   if (syrk_tag && tsm == 32 && tsn == 32 && h->polite64_active && h->polite32_pad_kb > 0 && h->stream != h->aux && dec_batch == 1 && m - n <= 1024)
     a.pad_lds = h->polite32_pad_kb * 1024;
+  a.pub_word = nullptr;
+  a.pub_val = 0;
+  if (h->ho_gdefer_slot >= 0 && h->ho_gdefer_stream == h->stream && h->ob_F <= 1) {      // a pending hand-off rides on this launch
+    a.pub_word = h->ho_mem + h->ho_gdefer_slot * 16;
+    a.pub_val = h->ho_seq[h->ho_gdefer_slot];
+    h->ho_gdefer_slot = -1;
+  }
   if (tsm != 128) syrk_tag = 0;  // only the 128x128 trailing update is the roofline kernel (own instantiation + stats)
   pl.tsm = tsm; pl.tsn = tsn; pl.syrk_tag = syrk_tag;
   return FFGP_OK;

@@ -1565,11 +1565,30 @@ static int la_wait(ffgp_handle* h, hipStream_t s, hipEvent_t ev) {
 // pending publication up): on the chain's stream the hipStreamWriteValue32 is a 5 us kernel of its own between a panel's last update and
 // the next panel's first diagonal block.  la_flush writes a publication nobody picked up (end of the factorisation, error paths: a gate
 // already enqueued on another stream must never be left waiting).
+static int la_flush_gemm(ffgp_handle* h) {
+  if (h->ho_gdefer_slot < 0) return FFGP_OK;
+  const int slot = h->ho_gdefer_slot;
+  h->ho_gdefer_slot = -1;
+  FFGP_HIP(hipStreamWriteValue32(h->ho_gdefer_stream, h->ho_mem + slot * 16, h->ho_seq[slot], 0));
+  return FFGP_OK;
+}
 static int la_flush(ffgp_handle* h) {
-  if (h->ho_defer_slot < 0) return FFGP_OK;
+  const int grc = la_flush_gemm(h);
+  if (h->ho_defer_slot < 0) return grc;
   const int slot = h->ho_defer_slot;
   h->ho_defer_slot = -1;
   FFGP_HIP(hipStreamWriteValue32(h->ho_defer_stream, h->ho_mem + slot * 16, h->ho_seq[slot], 0));
+  return grc;
+}
+// "record" on the update stream whose word is written by the next GEMM launched there as it starts (gemm_plan picks it up): S_bz's
+// hand-off rides on the S_ii launch behind it instead of on a 5 us write kernel between the two
+static int la_record_on_next_gemm(ffgp_handle* h, hipEvent_t ev, hipStream_t s) {
+  const int slot = la_slot(h, ev);
+  if (slot < 0 || h->ho_defer < 2) return la_record(h, ev, s);
+  FFGP_CHECK(la_flush_gemm(h));
+  h->ho_seq[slot] += 1;
+  h->ho_gdefer_slot = slot;
+  h->ho_gdefer_stream = s;
   return FFGP_OK;
 }
 static int la_record_deferred(ffgp_handle* h, hipEvent_t ev, hipStream_t s) {
@@ -1600,6 +1619,7 @@ struct LaFlushGuard {      // whatever path leaves the factorisation, a pending 
 static int la_begin(ffgp_handle* h) {
   h->ho_active = 0;
   h->ho_defer_slot = -1;
+  h->ho_gdefer_slot = -1;
   if (!h->ho_values || !h->ho_mem) return FFGP_OK;
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(h->stream, &st) != hipSuccess) {
@@ -1863,7 +1883,7 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
                                      wn - wa + wz, w1, -1.0, 1.0);
           h->stream = main_s;
           FFGP_CHECK(brc);
-          FFGP_CHECK(la_record(h, eg, syrk_s));
+          FFGP_CHECK(la_record_on_next_gemm(h, eg, syrk_s));     // (published by S_ii(k), the next launch on that stream)
           gate = eg;
         }
         // side stream: panel k+1 (carrying Z(k+2) in a carry iteration)
@@ -1896,6 +1916,7 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
             ei_prev = ei;
           }
         }
+        FFGP_CHECK(la_flush_gemm(h));                         // (no S_ii: the hand-off of S_bz is written plainly)
         carried = cm;
       }
       FFGP_CHECK(la_flush(h));

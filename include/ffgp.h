@@ -176,11 +176,12 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
                         S_a / S_b / S_ii form -- there the chain hides under the update and the carry only widens its launches -- and
                         changes over.  Headline bench line, la_carry_rows = 0 / 6144 / 8192 / 10240 / 12288: 28.83 / 28.61 / 28.51 / 28.47 /
                         28.43 ms with the roofline kernel at 0.697 / 0.697 / 0.693 / 0.690 / 0.685 of peak beside the heavier chain),
-            "ho_values" / "ho_defer" (default 1 / 1: the look-ahead's hand-offs between its two streams are values in device memory --
+            "ho_values" / "ho_defer" (default 1 / 2: the look-ahead's hand-offs between its two streams are values in device memory --
                         hipStreamWriteValue32 behind the producer, hipStreamWaitValue32 in front of the consumer, 2.9-4.7 us per hop
                         against 10.7-11.1 for hipEventRecord + hipStreamWaitEvent on this runtime -- and the word that says "panel k is
                         complete" is written by the next panel's first diagonal-block kernel as it starts instead of by a 5 us write
-                        kernel on the chain: N = 4096 / 8192 / 12288 -5.3 / -2.4 / -1.7 %, values unchanged; ho_values = 0: the event
+                        kernel on the chain: N = 4096 / 8192 / 12288 -5.3 / -2.4 / -1.7 %, values unchanged (ho_defer >= 1); with 2 the
+                        hand-off of S_bz is likewise written by the S_ii launch behind it on the update stream: N = 16384 -0.4 %; ho_values = 0: the event
                         pairs, which are also what a stream under graph capture gets.  A value wait is a one-workgroup KERNEL that
                         polls the word, so a process whose kernels run strictly one at a time must not use it: ffgp_create starts a
                         handle with ho_values = 0 when it sees rocprofv3's counter collection (ROCPROF_COUNTER_COLLECTION: --pmc

@@ -426,7 +426,7 @@ def test_potrf_value_handoffs_are_the_event_handoffs_bit_for_bit(ff):
     R = rng.standard_normal((m, n))
     outs = {}
     try:
-        for key, (hv, hd) in {"events": (0, 0), "values": (1, 0), "deferred": (1, 1), "deferred again": (1, 1)}.items():
+        for key, (hv, hd) in {"events": (0, 0), "values": (1, 0), "deferred by the diagonal block": (1, 1), "deferred": (1, 2), "deferred again": (1, 2)}.items():
             assert _lib.lib.ffgp_set_option(h, b"ho_values", float(hv)) == 0
             assert _lib.lib.ffgp_set_option(h, b"ho_defer", float(hd)) == 0
             rc, out, _, _ = potrf(ff, S, R)
@@ -434,9 +434,9 @@ def test_potrf_value_handoffs_are_the_event_handoffs_bit_for_bit(ff):
             outs[key] = out
     finally:
         _lib.lib.ffgp_set_option(h, b"ho_values", 1.0)
-        _lib.lib.ffgp_set_option(h, b"ho_defer", 1.0)
+        _lib.lib.ffgp_set_option(h, b"ho_defer", 2.0)
     low = np.tril_indices(n)
-    for key in ("values", "deferred", "deferred again"):
+    for key in ("values", "deferred by the diagonal block", "deferred", "deferred again"):
         assert np.array_equal(outs[key][:n, :n][low], outs["events"][:n, :n][low]), key
         assert np.array_equal(outs[key][n:, :n], outs["events"][n:, :n]), key
     assert relerr(np.tril(outs["deferred"][:n, :n]), np.linalg.cholesky(S)) < 1e-11
