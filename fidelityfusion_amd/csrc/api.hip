@@ -266,7 +266,7 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->la_carry = 2;
   h->la_carry_n = 12288;
   h->la_carry_rows = 8192;
-  h->la_min_n = 3584;
+  h->la_min_n = 1024;
   h->pass_split_min = 0;        // (measured and lost, docs/experiments.md: 0 = the passenger rows ride in the chain's launches)
   h->tail_mask_cus = 8;
   h->chase_xl = 1;

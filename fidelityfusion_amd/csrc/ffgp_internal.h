@@ -172,8 +172,8 @@ struct ffgp_handle {
   int diag_v2;          // diagonal-block kernel: 4 = round-4 kernel (default: owner-computes helpers, wave 0's SIMD partner steps aside), 1 = round-3 pipeline with the DP-ALU DPP pivot step, 3 = round-3 pipeline as it was, 0 = barrier version
   int la_split;         // 1 = issue the look-ahead part of the trailing update in two launches (first 128 columns first)
   int lookahead;        // 1 = overlap panel k+1 with the trailing update of step k
-  int la_min_n;         // blocks up to this size are factored in order (no side stream): below ~3500 the event hand-offs of the
-                        // look-ahead cost more than the overlap returns
+  int la_min_n;         // blocks up to this size are factored in order (no side stream): default 1024 since the look-ahead's hand-offs are values
+                        // (2 - 6 % at 1280 ... 3584 rows; 3584 while they were event pairs)
   int la_carry;         // the panel's own update kernels also carry the next panel's first 128 columns (no S_a on the chain):
                         // 0 = never, 1 = always, 2 (default) = throughout for blocks of at most la_carry_n rows, and for larger blocks in
                         // the iterations whose trailing matrix has at most la_carry_rows rows

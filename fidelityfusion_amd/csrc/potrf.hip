@@ -1593,7 +1593,9 @@ static int la_record_on_next_gemm(ffgp_handle* h, hipEvent_t ev, hipStream_t s) 
 }
 static int la_record_deferred(ffgp_handle* h, hipEvent_t ev, hipStream_t s) {
   const int slot = la_slot(h, ev);
-  if (slot < 0 || !h->ho_defer) return la_record(h, ev, s);
+  // (only ffgp_potrf_diag128_v3 publishes: with another diagonal-block kernel selected -- option diag_v2 -- nobody would pick the word up, and
+  //  the plain write at the end of the factorisation would sit behind kernels that wait for it; found by the suite's barrier-kernel case)
+  if (slot < 0 || !h->ho_defer || h->diag_v2 != 4 || h->diag_dbg || h->use_naive) return la_record(h, ev, s);
   FFGP_CHECK(la_flush(h));
   h->ho_seq[slot] += 1;
   h->ho_defer_slot = slot;

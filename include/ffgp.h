@@ -166,8 +166,10 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
             "nb_outer" (trailing-update block, multiple of 128; default 512),
             "naive" (1: route factor kernels through the slow reference kernels; debugging only),
             "lookahead" (default 1: factor panel k+1 on a high-priority side stream under the trailing update of step k),
-            "la_min_n" (default 3584: smaller blocks are factored in order on one stream -- every cross-stream event wait costs
-                        ~6 us of queue barrier, more than the overlap returns below that size; 0 = look ahead at every size),
+            "la_min_n" (default 1024: smaller blocks are factored in order on one stream.  With event pairs between the two streams the
+                        overlap did not pay for its hand-offs below ~3500 rows; with value hand-offs -- "ho_values" -- it does from two
+                        panels on: N = 1280 / 1536 / 2048 / 2560 / 3072 / 3584 -3.4 / -2.1 / -4.3 / -4.2 / -5.0 / -6.1 %; 0 = look ahead at
+                        every size),
             "la_split" (default 1: the look-ahead column update covers the next panel's first 128 columns only),
             "la_carry" / "la_carry_n" / "la_carry_rows" (a panel's own update kernels also cover the next panel's first 128 columns, so
                         no strip update sits between two panels on the dependency chain: 1 = always, 0 = never (the S_a / S_b / S_ii

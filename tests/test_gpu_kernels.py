@@ -276,7 +276,7 @@ def test_potrf_diag_kernel_variants(ff, mode):
         need_dev_options()
     assert _lib.lib.ffgp_set_option(h, b"diag_v2", C.c_double(mode)) == 0
     try:
-        for n in (128, 100, 16, 129, 640, 1000, 1537):
+        for n in (128, 100, 16, 129, 640, 1000, 1537, 4300):      # (1537, 4300: with the look-ahead's side stream and its hand-offs)
             rng = np.random.default_rng(10 * n + mode)
             S = spd(n, rng)
             ref = np.linalg.cholesky(S)
@@ -348,12 +348,13 @@ def test_potrf_lookahead_forms(ff, n, m, nb, carry, lookahead):
     finally:
         _lib.lib.ffgp_set_option(h, b"la_carry", 2.0)
         _lib.lib.ffgp_set_option(h, b"lookahead", 1.0)
-        _lib.lib.ffgp_set_option(h, b"la_min_n", 3584.0)
+        _lib.lib.ffgp_set_option(h, b"la_min_n", 1024.0)
 
 
-@pytest.mark.parametrize("n", [3584, 3585])
+@pytest.mark.parametrize("n", [1024, 1025, 1100, 3585])
 def test_potrf_around_the_lookahead_threshold(ff, n):
-    """default options on both sides of la_min_n: 3584 is factored in order on one stream, 3585 with the side stream"""
+    """default options on both sides of la_min_n: 1024 rows are factored in order on one stream, more with the side stream (1025: a one-row
+    second panel; 1100: a partial one)"""
     rng = np.random.default_rng(n)
     B = rng.standard_normal((n, 40))
     S = B @ B.T + np.diag(rng.random(n) + 0.5)

@@ -25,7 +25,10 @@ for t in range(trials):
     carry = int(rng.choice([0, 1, 2]))
     la = int(rng.choice([0, 1, 1, 1]))
     nb = int(rng.choice([256, 512, 512, 768]))
-    for k, v in (("la_carry", carry), ("lookahead", la), ("nb_outer", nb), ("la_min_n", int(rng.choice([0, 3584])))):
+    hv, hd = int(rng.choice([0, 1, 1])), int(rng.choice([0, 1, 2, 2]))      # hand-offs: event pairs / values; publication deferred to the next kernels or not
+    rows_co, n_co = int(rng.choice([0, 1500, 3000, 8192])), int(rng.choice([0, 2000, 12288]))      # change-over of the look-ahead form
+    for k, v in (("la_carry", carry), ("lookahead", la), ("nb_outer", nb), ("la_min_n", int(rng.choice([0, 1024, 3584]))), ("ho_values", hv),
+                 ("ho_defer", hd), ("la_carry_rows", rows_co), ("la_carry_n", n_co)):
         _lib.set_option(k, v, 0)
     g = torch.Generator(device=dev).manual_seed(int(rng.integers(1 << 30)))
     X = torch.rand((n, 6), generator=g, device=dev, dtype=torch.float64)
@@ -43,7 +46,10 @@ for t in range(trials):
         err = max(err, float((W[n:, :n] - want).abs().max() / (1.0 + want.abs().max())))
     worst = max(worst, err)
     if err > 1e-9:
-        print("MISMATCH trial %d n=%d rows=%d carry=%d lookahead=%d nb_outer=%d: %.3e" % (t, n, rows, carry, la, nb, err))
-for k, v in (("la_carry", 2), ("lookahead", 1), ("nb_outer", 512), ("la_min_n", 3584)):
+        print("MISMATCH trial %d n=%d rows=%d carry=%d lookahead=%d nb_outer=%d ho=%d/%d co=%d/%d: %.3e" % (t, n, rows, carry, la, nb, hv, hd, rows_co, n_co, err))
+    if t % 50 == 49:
+        print("  ... %d trials, worst %.3e" % (t + 1, worst), flush=True)
+for k, v in (("la_carry", 2), ("lookahead", 1), ("nb_outer", 512), ("la_min_n", 1024), ("ho_values", 1), ("ho_defer", 2), ("la_carry_rows", 8192),
+             ("la_carry_n", 12288)):
     _lib.set_option(k, v, 0)
 print("potrf_fuzz: %d trials, n < %d, worst |L - L_torch| = %.3e" % (trials, nmax, worst))
