@@ -1672,14 +1672,15 @@ static int potrf_gemm(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, 
   return ffgp_gemm_launch(h, opa, opb, mode, syrk_tag, A, lda, B, ldb, C, ldc, m, n, k, alpha, beta, tri, alias);
 }
 
+// `first_diag_done`: the caller has already launched the panel's first diagonal block on this stream (factor_panel_first_diag below)
 static int factor_panel(ffgp_handle* h, double* A, int n, int mtot, int lda, int k0, int w1, hipEvent_t gate = nullptr, int carry = 0,
-                        hipEvent_t gate2 = nullptr) {
+                        hipEvent_t gate2 = nullptr, bool first_diag_done = false) {
   const int pend = k0 + w1;
   for (int j0 = k0; j0 < pend; j0 += NB) {
     const int jb = min(NB, n - j0);
     double* Ajj = A + (size_t)j0 * lda + j0;
     double* Dj = h->dinv + (size_t)(j0 / NB) * NB * NB;
-    FFGP_CHECK(launch_diag(h, Ajj, lda, jb, Dj, j0, 1));
+    if (!(first_diag_done && j0 == k0)) FFGP_CHECK(launch_diag(h, Ajj, lda, jb, Dj, j0, 1));
     const int mrows = mtot - (j0 + jb);
     if (mrows > 0) {
       double* A21 = A + (size_t)(j0 + jb) * lda + j0;
@@ -1700,6 +1701,12 @@ static int factor_panel(ffgp_handle* h, double* A, int n, int mtot, int lda, int
     }
   }
   return FFGP_OK;
+}
+
+// the first launch of factor_panel on its own: the look-ahead enqueues it before the update stream's wait for the previous panel, because
+// that kernel is what publishes "the previous panel is complete" (la_record_deferred) -- see the ordering rule in ffgp_potrf_impl
+static int factor_panel_first_diag(ffgp_handle* h, double* A, int n, int lda, int k0) {
+  return launch_diag(h, A + (size_t)k0 * lda + k0, lda, min(NB, n - k0), h->dinv + (size_t)(k0 / NB) * NB * NB, k0, 1);
 }
 
 // the handle's CU-masked stream (tail_mask_m): every CU except the first tail_mask_cus of each XCD.  Mask bit i <-> XCD i % 8, CU
@@ -1874,6 +1881,18 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
           h->stream = main_s;
           FFGP_CHECK(arc);
         }
+        // ORDER OF SUBMISSION.  Every wait below is enqueued AFTER the launch that will satisfy it.  A value wait is a kernel at the head of
+        // its hardware queue, and streams of different handles (or the application's own) may share a queue: if a wait could be
+        // enqueued before its producer, two handles could each sit in front of the other's producer and wait for ever (seen once the
+        // suite ran beside its background load with the "panel complete" word left to the NEXT diagonal-block kernel: that kernel used
+        // to be enqueued after the update stream's wait for it).  With producers first, dependencies only point backwards in submission
+        // order -- the property event pairs have by construction -- and shared in-order queues cannot form a cycle.  Hence: the next
+        // panel's first diagonal block (publishes "panel k complete"), then the update stream's wait for it, S_bz and S_ii (whose first
+        // workgroup publishes S_bz's hand-off), and only then the rest of the panel with its gate.
+        h->stream = h->aux;
+        const int drc = factor_panel_first_diag(h, A, n, lda, pend);
+        h->stream = main_s;
+        FFGP_CHECK(drc);
         // main stream, once panel k is complete: S_b(k) (and S_z(k), its right-hand neighbour: columns pend+wa .. q+wz, one launch)
         if (eb_prev) FFGP_CHECK(la_wait(h, syrk_s, eb_prev));
         hipEvent_t gate = nullptr;
@@ -1887,21 +1906,6 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
           FFGP_CHECK(brc);
           FFGP_CHECK(la_record_on_next_gemm(h, eg, syrk_s));     // (published by S_ii(k), the next launch on that stream)
           gate = eg;
-        }
-        // side stream: panel k+1 (carrying Z(k+2) in a carry iteration)
-        h->stream = h->aux;
-        const int rc = factor_panel(h, A, n, mch, lda, pend, wn, gate, wz);
-        h->stream = main_s;
-        FFGP_CHECK(rc);
-        if (cm)
-          FFGP_CHECK(la_record_deferred(h, eb, h->aux));     // (published by the next panel's first diagonal-block kernel)
-        else
-          FFGP_CHECK(la_record(h, eb, h->aux));              // (the next kernel on the side stream is S_a(k+1))
-        eb_prev = eb;
-        if (split_pass) FFGP_CHECK(pass_panel(pend, wn, eb));
-        if (h->tri_hook_col > 0 && pend + wn == h->tri_hook_col) {   // the factor's columns < tri_hook_col are final from here on
-          FFGP_CHECK(la_record(h, h->tri_ev[0], h->aux));
-          h->tri_hook_fired = 1;
         }
         // main stream: S_ii(k), everything right of panel k+1 and of Z(k+2)
         const int mt2 = mt - wn - wz;
@@ -1919,6 +1923,21 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
           }
         }
         FFGP_CHECK(la_flush_gemm(h));                         // (no S_ii: the hand-off of S_bz is written plainly)
+        // side stream: the rest of panel k+1 (carrying Z(k+2) in a carry iteration)
+        h->stream = h->aux;
+        const int rc = factor_panel(h, A, n, mch, lda, pend, wn, gate, wz, nullptr, true);
+        h->stream = main_s;
+        FFGP_CHECK(rc);
+        if (cm && !split_pass)
+          FFGP_CHECK(la_record_deferred(h, eb, h->aux));     // (published by the next panel's first diagonal-block kernel)
+        else
+          FFGP_CHECK(la_record(h, eb, h->aux));              // (the next kernel on the side stream is S_a(k+1); pass_panel waits at once)
+        eb_prev = eb;
+        if (split_pass) FFGP_CHECK(pass_panel(pend, wn, eb));
+        if (h->tri_hook_col > 0 && pend + wn == h->tri_hook_col) {   // the factor's columns < tri_hook_col are final from here on
+          FFGP_CHECK(la_record(h, h->tri_ev[0], h->aux));
+          h->tri_hook_fired = 1;
+        }
         carried = cm;
       }
       FFGP_CHECK(la_flush(h));
@@ -2083,7 +2102,7 @@ int ffgp_potrf_ragged(ffgp_handle* h, int R, const ffgp_rag_block* mem) {
     if (!in.empty()) rc = ffgp_gemm_launch_rag(h, TILES_LOWER, 1, (int)in.size(), in.data(), -1.0, 1.0, ALIAS_NONE);
     h->stream = main_s;
     if (rc != FFGP_OK || !any_la) continue;
-    FFGP_CHECK(la_record_deferred(h, eb, chain_s));     // (published by the next panel's first diagonal-block kernel)
+    FFGP_CHECK(la_record(h, eb, chain_s));     // (a plain write: the wait right below must not be enqueued before its producer)
     FFGP_CHECK(la_wait(h, main_s, eb));
     // ---- look-ahead members, main stream: S_bz (the rest of the next panel's columns and its carry strip), then S_ii
     in.clear();

@@ -194,3 +194,21 @@ def test_two_ranks_share_the_one_gpu_real_step_over_gloo():
     assert two["n_gpus"] == 2 and two["collective"] == {"backend": "gloo", "ranks": 2} and two["config"]["blocks"] == 4
     assert two["cpu_affinity"] is None or two["cpu_affinity"]["rank0_cpus"] >= 1
     assert abs(two["joint_nll"] - one["joint_nll"]) <= 1e-12 * abs(one["joint_nll"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("queues", [1, 2])
+def test_handles_with_lookahead_side_by_side_on_shared_hardware_queues(queues):
+    """the look-ahead's value waits are kernels at the head of their hardware queue, and the streams of several handles share queues
+    once a process has more streams than queues: every wait must be enqueued after the launch that satisfies it (ffgp_potrf_impl's
+    ordering rule), or two handles end up in front of each other's producers.  Three host threads with a handle each factor blocks that
+    all use the side stream, with ONE (and two) hardware queues per priority for the whole process -- tools/handoff_stress.py hangs
+    within seconds when that rule is broken, and checks every value against the block's value alone"""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, FFGP_STRESS_DEADLINE_S="100")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "handoff_stress.py"), "3", "25", str(queues), str(queues)], env=env,
+                       capture_output=True, text=True, timeout=240)
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("handoff_stress")]
+    assert p.returncode == 0 and line and "HUNG" not in line[0], (p.stdout[-1500:], p.stderr[-1500:])
