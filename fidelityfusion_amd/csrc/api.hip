@@ -280,7 +280,7 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->diag_v2 = 4;
   h->trsm128 = 1;
   h->polite64_pad_kb = 60;
-  h->polite32_pad_kb = 34;
+  h->polite32_pad_kb = 46;
   h->ho_values = default_ho_values();
   h->ho_defer = 2;
   h->ho_defer_slot = -1;

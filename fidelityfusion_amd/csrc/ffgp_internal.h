@@ -164,7 +164,7 @@ struct ffgp_handle {
   int small_tile_threshold;  // launches with fewer 128-tiles than this use the 64-tile
   int tile32_threshold;      // K-major launches with fewer 64-tiles than this use 32-row tiles
   int polite64_active;  // set while ffgp_potrf_impl's carry-form look-ahead of ONE block issues its launches
-  int polite32_pad_kb;  // ... and by its 32-tile ones (default 34: three workgroups per CU)
+  int polite32_pad_kb;  // ... and by its 32-tile ones (default 46: two workgroups per CU and 36 KiB left for the chain's kernels)
   int polite64_pad_kb;  // unused LDS (KiB) requested by the look-ahead's 64-tile trailing updates (default 60: two workgroups per CU instead of four)
   int trsm128;          // 1 = the chain's full-block TRSM runs on its own kernel (ffgp_trsm128_kernel; same values as the general GEMM)
   int trsm128_max_m;    // ... for panels of at most this many rows (taller ones stay on the general GEMM)

@@ -240,8 +240,9 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
             "polite64_pad_kb" (default 60, at most 64: unused dynamic LDS requested by the 64-tile trailing updates of ONE block's carry-form
                         look-ahead -- two of their workgroups per CU instead of four, so the chain's kernels are not slowed to a third
                         beside them; N = 4096 / 6144 / 8192 / 12288: -1.2 / -3.0 / -2.0 / -1.0 %, values unchanged; 0 = off),
-            "polite32_pad_kb" (default 34: the same for that form's 32-tile trailing updates -- three workgroups per CU; N = 4096 / 5120
-                        -0.8 ... -1.5 %; 0 = off),
+            "polite32_pad_kb" (default 46: the same for that form's 32-tile trailing updates -- two workgroups per CU and room for the
+                        chain's TRSM beside them: N = 3072 / 4096 / 5120 -1.0 / -0.8 / -0.5 % against 34 (three per CU), which had
+                        been -0.8 ... -1.5 % against none; 0 = off),
             "trsm128" / "trsm128_max_m" (default 1 / 8192: the factorisation chain's full-block TRSM runs on its own latency-shaped
                         kernel for panels of at most trsm128_max_m rows; the values are the general GEMM's bit for bit),
             "chase_xl" / "chase_xl_max_n" (default 1 / 2048: bands of up to chase_xl_max_n columns run their bulge chase with every
