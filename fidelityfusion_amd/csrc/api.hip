@@ -177,7 +177,20 @@ static int create_resources(ffgp_handle* h) {
   FFGP_HIP(hipMemset(h->d_info, 0, 16 * sizeof(int)));
   FFGP_HIP(hipMalloc(&h->ho_mem, 10 * 16 * sizeof(unsigned)));
   FFGP_HIP(hipMemset(h->ho_mem, 0, 10 * 16 * sizeof(unsigned)));
+  h->ho_selftest_pending = 1;      // (the value operations are tried once on the side stream, below, after the NULL-stream memsets are visible)
   FFGP_HIP(hipDeviceSynchronize());   // NULL-stream memset: make it visible before any (non-blocking) stream touches it
+  if (h->ho_values && h->ho_selftest_pending) {
+    // a runtime / driver without the stream value operations keeps the event pairs: one write + wait on an unused word of the hand-off store
+    h->ho_selftest_pending = 0;
+    unsigned* probe = h->ho_mem + 15;
+    const bool ok = hipStreamWriteValue32(h->aux, probe, 1u, 0) == hipSuccess &&
+                    hipStreamWaitValue32(h->aux, probe, 1u, hipStreamWaitValueGte, 0xffffffffu) == hipSuccess &&
+                    hipStreamSynchronize(h->aux) == hipSuccess;
+    if (!ok) {
+      (void)hipGetLastError();
+      h->ho_values = 0;
+    }
+  }
   FFGP_HIP(hipMalloc(&h->d_scal, SCAL_DOUBLES * sizeof(double)));
   FFGP_HIP(hipHostMalloc(&h->h_info, 16 * sizeof(int)));
   memset(h->h_info, 0, 16 * sizeof(int));

@@ -154,6 +154,7 @@ struct ffgp_handle {
   unsigned ho_seq[10];  // ... the number its latest "record" wrote
   int ho_values;        // option "ho_values" (default 1): value hand-offs; 0 = the event pairs
   int ho_active;        // set per factorisation (la_begin): value hand-offs in use (not while a stream is being captured)
+  int ho_selftest_pending;  // create_resources tries the stream value operations once; a runtime without them keeps the event pairs
   int ho_defer;         // option "ho_defer" (default 1): the chain's "panel complete" word is written by the next diagonal-block kernel
   int ho_defer_slot;    // pending publication (-1 none) ...
   int ho_gdefer_slot;   // the same for the next GEMM launched on ho_gdefer_stream (the trailing update that follows S_bz on the main stream)
