@@ -235,6 +235,10 @@ extern "C" int ffgp_prepare_streams(ffgp_handle* h) {
 // HIP_LAUNCH_BLOCKING, AMD_SERIALIZE_KERNEL -- would leave that kernel spinning for a producer that can never start.  In such a
 // process the handle keeps the event pairs (the command processor waits for those, no kernel does).  FFGP_HANDOFF=events / values
 // overrides the detection.
+// handles alive in this process (ffgp_live_handles): a lone handle may assume the chip is its own between its kernels
+static std::atomic<int> g_live_handles{0};
+extern "C++" int ffgp_live_handles() { return g_live_handles.load(std::memory_order_relaxed); }
+
 static bool env_on(const char* key) {
   const char* v = getenv(key);
   return v && *v && strcmp(v, "0") && strcasecmp(v, "false") && strcasecmp(v, "off");
@@ -298,6 +302,7 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->ho_defer = 2;
   h->ho_defer_slot = -1;
   h->ho_gdefer_slot = -1;
+  h->diag_excl_rows = 4096;
   h->polite64_active = 0;
   h->trsm128_max_m = 8192;
   h->trtri_overlap = 1;
@@ -318,12 +323,18 @@ int ffgp_create(int device, ffgp_handle** out) {
     ffgp_destroy(h);
     return rc;
   }
+  g_live_handles.fetch_add(1, std::memory_order_relaxed);
+  h->counted_live = 1;
   *out = h;
   return FFGP_OK;
 }
 
 int ffgp_destroy(ffgp_handle* h) {
   if (!h) return FFGP_OK;
+  if (h->counted_live) {
+    g_live_handles.fetch_sub(1, std::memory_order_relaxed);
+    h->counted_live = 0;
+  }
   hipSetDevice(h->device);
   if (h->own) hipStreamSynchronize(h->own);
   if (h->aux) hipStreamSynchronize(h->aux);
@@ -436,6 +447,8 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->fwd_graph = value != 0.0;
   } else if (!strcmp(key, "ho_values")) {
     h->ho_values = value != 0.0;
+  } else if (!strcmp(key, "diag_excl_rows")) {
+    h->diag_excl_rows = (int)value;
   } else if (!strcmp(key, "ho_defer")) {
     if (value < 0 || value > 2) return FFGP_ERR_ARG;
     h->ho_defer = (int)value;

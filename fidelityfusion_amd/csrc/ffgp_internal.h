@@ -144,6 +144,8 @@ struct GemmRagIn {
   int m, n, k;
 };
 
+int ffgp_live_handles();      // handles alive in this process (api.hip)
+
 struct ffgp_handle {
   int device;
   hipStream_t stream;   // stream work is enqueued on (caller's, or `own`)
@@ -156,6 +158,10 @@ struct ffgp_handle {
   int ho_active;        // set per factorisation (la_begin): value hand-offs in use (not while a stream is being captured)
   int ho_selftest_pending;  // create_resources tries the stream value operations once; a runtime without them keeps the event pairs
   int ho_defer;         // option "ho_defer" (default 1): the chain's "panel complete" word is written by the next diagonal-block kernel
+  int diag_excl_rows;   // option "diag_excl_rows" (default 4096): carry iterations with at most this many trailing rows launch the panel's first diagonal block
+                        // with a whole CU's LDS -- when this is the process's only handle (0 = never)
+  int diag_excl_now;    // ... set around that launch
+  int counted_live;     // this handle is counted in ffgp_live_handles()
   int ho_defer_slot;    // pending publication (-1 none) ...
   int ho_gdefer_slot;   // the same for the next GEMM launched on ho_gdefer_stream (the trailing update that follows S_bz on the main stream)
   hipStream_t ho_gdefer_stream;

@@ -1450,11 +1450,19 @@ static int launch_diag(ffgp_handle* h, double* Ablk, int lda, int nb, double* Di
       }
       DiagRag dr = DiagRag();
       la_take_deferred(h, dr);
+      // (diag_excl: the panel's FIRST diagonal block of a chain-bound carry iteration asks for a whole CU's LDS, so the S_bz workgroups that
+      //  start the moment it publishes cannot land beside it -- see ffgp_potrf_impl)
+      const int lds_bytes = (h->diag_excl_now && h->bt_F <= 1) ? 160 * 1024 : DIAG_LDS_BYTES;
+      if (lds_bytes != DIAG_LDS_BYTES && !(h->diag_attr_set & 8)) {
+        FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v3<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024));
+        h->diag_attr_set |= 8;
+      }
       if (h->bt_F > 1)
         hipLaunchKernelGGL(ffgp_potrf_diag128_v3<false>, dim3(h->bt_F), dim3(512), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk,
                            h->bt_info, row_base, h->aux_prio, h->bt_sA, h->bt_sD, 1, dr);
       else
-        hipLaunchKernelGGL(ffgp_potrf_diag128_v3<false>, dim3(1), dim3(512), DIAG_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk, h->d_info,
+        hipLaunchKernelGGL(ffgp_potrf_diag128_v3<false>, dim3(1), dim3(512), lds_bytes, h->stream, Ablk, lda, nb, Dinv_blk, h->d_info,
                            row_base, h->aux_prio, 0L, 0L, 0, dr);
     }
 #ifdef FFGP_DEV_OPTIONS
@@ -1890,7 +1898,14 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
         // panel's first diagonal block (publishes "panel k complete"), then the update stream's wait for it, S_bz and S_ii (whose first
         // workgroup publishes S_bz's hand-off), and only then the rest of the panel with its gate.
         h->stream = h->aux;
+        // The panel's first diagonal block runs while S_bz -- released by that very kernel's first instruction -- floods the chip, and the
+        // S_bz workgroups that land beside it cost its pivot wave a third of its speed (39 us instead of 28 on the C2 timeline).  In the
+        // chain-bound iterations the chip is idle when it is launched (the update of the step before is long done), so it can ask for
+        // a whole CU's LDS and keep that CU to itself: N = 2048 / 4096 / 8192 -1.7 / -0.8 / -0.8 %.  Only for the process's only handle:
+        // beside other handles' kernels an empty CU may be a long time coming.
+        h->diag_excl_now = (cm && mt <= h->diag_excl_rows && ffgp_live_handles() == 1) ? 1 : 0;
         const int drc = factor_panel_first_diag(h, A, n, lda, pend);
+        h->diag_excl_now = 0;
         h->stream = main_s;
         FFGP_CHECK(drc);
         // main stream, once panel k is complete: S_b(k) (and S_z(k), its right-hand neighbour: columns pend+wa .. q+wz, one launch)

@@ -243,6 +243,10 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
             "polite32_pad_kb" (default 46: the same for that form's 32-tile trailing updates -- two workgroups per CU and room for the
                         chain's TRSM beside them: N = 3072 / 4096 / 5120 -1.0 / -0.8 / -0.5 % against 34 (three per CU), which had
                         been -0.8 ... -1.5 % against none; 0 = off),
+            "diag_excl_rows" (default 4096: in the look-ahead's chain-bound iterations -- at most this many trailing rows -- a panel's first
+                        diagonal-block kernel asks for a whole CU's LDS, so that the trailing-update workgroups it releases cannot land
+                        beside it: N = 2048 / 4096 / 8192 -1.7 / -0.8 / -0.8 %, values unchanged; only while the handle is the process's
+                        only one -- beside other handles' kernels an empty CU may be long in coming; 0 = never),
             "trsm128" / "trsm128_max_m" (default 1 / 8192: the factorisation chain's full-block TRSM runs on its own latency-shaped
                         kernel for panels of at most trsm128_max_m rows; the values are the general GEMM's bit for bit),
             "chase_xl" / "chase_xl_max_n" (default 1 / 2048: bands of up to chase_xl_max_n columns run their bulge chase with every

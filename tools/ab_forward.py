@@ -24,7 +24,7 @@ dadd = torch.tensor([np.exp(-1.0) + 1e-6], dtype=torch.float64, device=dev)
 configs = [dict(kv.split("=") for kv in c.split(",") if kv) for c in sys.argv[1:]]
 keys = sorted({k for c in configs for k in c})
 defaults = {"nb_big": 0, "nb_big_until": 0, "polite_m": 6144, "split_rem_max": 180, "band_log2": 3, "nb_outer": 512,
-            "tile32_threshold": 1024, "polite_pad_kb": 40, "small_tile_threshold": 640, "la_split": 1, "aux_prio": 1, "diag_v2": 4, "la_carry": 2, "lookahead": 1, "la_min_n": 1024, "tail_mask_m": 0, "tail_mask_cus": 8, "pass_split_min": 0, "syrk_h64": 0, "syrk_direct": 0, "trsm128": 1, "polite64_pad_kb": 60, "polite32_pad_kb": 46, "ho_values": 1, "ho_defer": 2, "la_carry_rows": 8192, "la_carry_n": 12288}
+            "tile32_threshold": 1024, "polite_pad_kb": 40, "small_tile_threshold": 640, "la_split": 1, "aux_prio": 1, "diag_v2": 4, "la_carry": 2, "lookahead": 1, "la_min_n": 1024, "tail_mask_m": 0, "tail_mask_cus": 8, "pass_split_min": 0, "syrk_h64": 0, "syrk_direct": 0, "trsm128": 1, "polite64_pad_kb": 60, "polite32_pad_kb": 46, "ho_values": 1, "ho_defer": 2, "la_carry_rows": 8192, "diag_excl_rows": 4096, "la_carry_n": 12288}
 res = {i: [] for i in range(len(configs))}
 for rnd in range(4):
     for i, c in enumerate(configs):
