@@ -120,12 +120,14 @@ def spawn_ranks(args):
     return rc
 
 
-def gpu_numa_cpus(local_rank):
+def gpu_numa_cpus(local_rank, sysfs=None):
     """CPUs of the NUMA node the local_rank-th AMD GPU hangs off, read from sysfs without touching HIP (cards in PCI-address
-    order, which is the order ROCm enumerates them in on one node); None when sysfs does not say."""
+    order, which is the order ROCm enumerates them in on one node); None when sysfs does not say.  `sysfs` (or FFGP_BENCH_SYSFS)
+    points the lookup at another tree: the CPU pre-flight test of an 8-GPU, 2-socket node (tests/test_bench_launch.py)."""
     import glob
+    sysfs = sysfs or os.environ.get("FFGP_BENCH_SYSFS", "/sys")
     cards = []
-    for dev in glob.glob("/sys/class/drm/card[0-9]*/device"):
+    for dev in glob.glob(os.path.join(sysfs, "class/drm/card[0-9]*/device")):
         try:
             if open(os.path.join(dev, "vendor")).read().strip() != "0x1002":
                 continue
@@ -140,12 +142,35 @@ def gpu_numa_cpus(local_rank):
         if node < 0:
             return None
         cpus = set()
-        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+        for part in open(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % node)).read().strip().split(","):
             lo, _, hi = part.partition("-")
             cpus.update(range(int(lo), int(hi or lo) + 1))
         return sorted(cpus)
     except (OSError, ValueError):
         return None
+
+
+def rank_cpu_slice(local_rank, local_world, allowed, sysfs=None):
+    """The CPUs rank `local_rank` of `local_world` pins itself to (pure: nothing is applied): its own slice of the CPUs of its GPU's
+    NUMA node, shared evenly with the other ranks whose GPUs hang off the same node; an even slice of `allowed` when sysfs is silent."""
+    node = gpu_numa_cpus(local_rank, sysfs)
+    pool = [c for c in (node or allowed) if c in set(allowed)] or allowed
+    # the ranks whose GPUs share this pool split it evenly (with one NUMA node per GPU pair, two ranks share a pool)
+    sharers = [r for r in range(local_world) if (gpu_numa_cpus(r, sysfs) or allowed) == (node or allowed)] or [local_rank]
+    k = sharers.index(local_rank) if local_rank in sharers else 0
+    per = max(1, len(pool) // len(sharers))
+    return pool[k * per:(k + 1) * per] or pool
+
+
+def block_path(n_mine, no_chain_batch=False):
+    """Which evaluation a rank's step takes for its `n_mine` blocks of one fixed-F workload: "single" = the one-block fused call
+    (F.nlml -- what every GPU runs when the blocks are dealt one per GPU), "chain" = ONE shared factorisation chain for the rank's
+    blocks (F.nlml_many), "streams" = the blocks overlapped through streams, "idle" = the rank owns no block."""
+    if n_mine <= 0:
+        return "idle"
+    if n_mine == 1:
+        return "single"
+    return "streams" if no_chain_batch else "chain"
 
 
 def pin_rank(local_rank, local_world):
@@ -155,14 +180,7 @@ def pin_rank(local_rank, local_world):
     CPUs when sysfs does not name the node); FFGP_BENCH_AFFINITY=0 leaves the affinity alone.  Returns the CPUs pinned to, or None."""
     if os.environ.get("FFGP_BENCH_AFFINITY", "1") == "0" or not hasattr(os, "sched_setaffinity"):
         return None
-    allowed = sorted(os.sched_getaffinity(0))
-    node = gpu_numa_cpus(local_rank)
-    pool = [c for c in (node or allowed) if c in set(allowed)] or allowed
-    # the ranks whose GPUs share this pool split it evenly (with one NUMA node per GPU pair, two ranks share a pool)
-    sharers = [r for r in range(local_world) if (gpu_numa_cpus(r) or allowed) == (node or allowed)] or [local_rank]
-    k = sharers.index(local_rank) if local_rank in sharers else 0
-    per = max(1, len(pool) // len(sharers))
-    mine = pool[k * per:(k + 1) * per] or pool
+    mine = rank_cpu_slice(local_rank, local_world, sorted(os.sched_getaffinity(0)))
     try:
         os.sched_setaffinity(0, mine)
     except OSError:
@@ -492,6 +510,8 @@ def run_rank(args):
         dadd = torch.tensor([np.exp(-1.0) + 1e-6], dtype=torch.float64, device=dev, requires_grad=with_grad)
         return w, amp, dadd
 
+    deal = {}     # workload name -> how its blocks were dealt (owner of every block, the evaluation path of every rank)
+
     def make_workload(name, n=None, D=None, d=None, blocks=None, with_grad=None):
         """-> (step(), F_total, n, D, d, scaling): step() evaluates this rank's blocks and all-reduces the F-vector.
         with_grad: the step also produces every gradient `loss.backward()` leaves in the reference's training iteration
@@ -501,10 +521,13 @@ def run_rank(args):
         n, D, d = n or n0, D or D0, d or d0
         if F_fixed is None:                                   # one block per rank: fidelity f = rank
             F_total, mine, scaling = world, [rank], "weak"
+            owner = list(range(world))
         else:
             F_total = blocks or F_fixed
             owner = partition_lpt([block_cost(n, d)] * F_total, world)
             mine, scaling = [f for f in range(F_total) if owner[f] == rank], "strong"
+        deal[name] = {"owner": [int(o) for o in owner],
+                      "rank_paths": [block_path(sum(1 for o in owner if o == r), args.no_chain_batch) for r in range(world)]}
         joint = torch.zeros(F_total, dtype=torch.float64, device=red_dev)
         if args.dry:
             data = {f: synthetic_xy(n, D, d, seed=f) for f in mine}
@@ -552,19 +575,21 @@ def run_rank(args):
         w, amp, dadd = params(D, with_grad)
         nslots = max(1, min(args.slots, len(mine)))
 
+        path = block_path(len(mine), args.no_chain_batch)
+
         def step():
             vals = {}
-            if len(mine) == 1:
+            if path == "single":
                 f = mine[0]
                 vals[f] = F.nlml(data[f][0], data[f][1], w, amp, diag_add=dadd, clamp=1e-30)
-            elif mine and not args.no_chain_batch:   # the rank's blocks have one shape: ONE factorisation chain for all of them
+            elif path == "chain":   # the rank's blocks have one shape: ONE factorisation chain for all of them
                 ctx = torch.enable_grad() if with_grad else torch.no_grad()
                 with ctx:
                     out = F.nlml_many([data[f][0] for f in mine], [data[f][1] for f in mine], [w] * len(mine), [amp] * len(mine),
                                       [dadd] * len(mine), clamp=1e-30)
                 for i, f in enumerate(mine):
                     vals[f] = out[i]
-            elif mine:   # several owned blocks overlap on this GPU
+            elif path == "streams":   # several owned blocks overlap on this GPU
                 ctx = torch.enable_grad() if with_grad else torch.no_grad()
                 with ctx, F.concurrent_blocks(nslots=nslots, device_index=local_rank, lookahead=args.slot_lookahead) as cb:
                     for i, f in enumerate(mine):
@@ -644,7 +669,8 @@ def run_rank(args):
             sfl = hogp_flops(sn, HOGP_MODES if sd == HOGP_MODES[0] * HOGP_MODES[1] else (sd, 1)) if hog else nlml_flops(sn, sD, sd)
             sharded[name] = {"blocks": sF, "N": sn, "D": sD, "d": sd, "ms_per_step": round(sdt / ssteps * 1e3, 3),
                              "value": round(sfl * sF / (sdt / ssteps) / 1e9, 1), "unit": "GF/s", "scaling": "strong",
-                             "blocks_per_rank": -(-sF // world),
+                             "blocks_per_rank": -(-sF // world), "owner": deal[name]["owner"],
+                             "rank_paths": ["threads" if hog and p_ in ("chain", "streams") else p_ for p_ in deal[name]["rank_paths"]],
                              "blocks_in_flight_per_rank": min(args.hogp_slots if hog else args.slots, -(-sF // world)),
                              "config": "BASELINE configs[%d]" % WORKLOADS[name][4] + (
                                  " as HOGP blocks (d = %d x %d): eigh of the N x N input kernel on ffgp_syevd + mode products; PRIMARY "
@@ -677,6 +703,24 @@ def run_rank(args):
             del t_step
             torch.cuda.empty_cache()
 
+    # ---- the per-GPU unit of the sharded configs and C2, forward, one block per rank (what one GPU of an 8-GPU gar8 / 4-GPU cigar4
+    #      run executes per step: the single-block F.nlml path) --------------------------------------------------------------------
+    blocks_leg = {}
+    if args.workload == "headline" and not args.no_sharded and not args.with_grad and stock and not args.dry:
+        for key, (bn, bD, bd, cfg) in (("c2", (4096, 8, 1, 1)), ("n8192_d1", (8192, 8, 1, None)), ("n8192_d1024", (8192, 8, 1024, 3)),
+                                       ("n8192_d4096", (8192, 8, 4096, 4))):
+            b_step, bF, _, _, _, _ = make_workload("c2", n=bn, D=bD, d=bd, with_grad=False)
+            bdt, _ = timed(b_step, 10, 3)
+            bfl = nlml_flops(bn, bD, bd) * bF
+            blocks_leg[key] = {"N": bn, "D": bD, "d": bd, "blocks_per_rank": 1, "ms_per_step": round(bdt / 10 * 1e3, 3),
+                               "value": round(bfl / (bdt / 10) / 1e9, 1), "unit": "GF/s",
+                               "frac_of_mfma_peak": round(bfl / (bdt / 10) / 1e12 / world / FP64_MFMA_PEAK_TFLOPS, 4),
+                               "what": "forward NLML of ONE block per rank (10 steps after 3 warm-ups)" + (
+                                   "; BASELINE configs[%d]%s" % (cfg, "" if cfg == 1 else ": the unit each GPU runs when the F blocks are "
+                                                                "dealt one per GPU") if cfg is not None else "")}
+            del b_step
+            torch.cuda.empty_cache()
+
     if not args.dry and not args.no_cpu_baseline and world == 1 and stock and args.workload in ("headline", "c2"):
         # after every timed leg: the GPU side of the parity columns, and the vendor factorisation as a stated side number
         gpu_ref = gpu_parity_values(dev, ("c2", "headline") if args.workload == "headline" else ("c2",))
@@ -705,7 +749,8 @@ def run_rank(args):
                                        else "per-fidelity cigp blocks,"),
                                       "forward+gradients" if args.with_grad else "forward", F_total, "" if F_total == 1 else "s", n, D, d,
                                       " (BASELINE configs[%d])" % cfg_idx if cfg_idx is not None else ""),
-                       "N": n, "D": D, "d": d, "blocks": F_total,
+                       "N": n, "D": D, "d": d, "blocks": F_total, "owner": deal[args.workload]["owner"],
+                       "rank_paths": deal[args.workload]["rank_paths"],
                        "blocks_in_flight_per_rank": (min(args.hogp_slots if args.workload == "gar8_hogp" else args.slots, -(-F_total // world))
                                                      if scaling == "strong" else 1),
                        "parallelism": "fidelity-shard x%d (LPT partition, one %d-byte all-reduce per step)" % (world, 8 * F_total)},
@@ -738,6 +783,8 @@ def run_rank(args):
             out["sharded"] = sharded
         if train_step:
             out["train_step"] = train_step
+        if blocks_leg:
+            out["blocks"] = blocks_leg
         if vendor is not None:
             out["vendor_potrf_ms"] = dict(vendor, note="torch.linalg.cholesky on this GPU (the reference's own .cuda() path, MFGP_ver2023May/"
                                           "mfgp_demo.py:88-94) vs ffgp_potrf on the same matrix; outside the timed region, never on the product path")

@@ -146,6 +146,78 @@ def test_pin_rank_gives_disjoint_slices():
     assert o["mine"] is None and o["now"] == o["before"]
 
 
+def _fake_sysfs(root, ncards=8, nodes=2, cpus_per_node=64):
+    """a sysfs tree of a 2-socket node with eight AMD GPUs, four per socket (what bench.gpu_numa_cpus reads)"""
+    for c in range(ncards):
+        pci = os.path.join(root, "devices", "pci0000:%02x" % (0x10 * c), "0000:%02x:00.0" % (0x10 * c + 1))
+        os.makedirs(pci)
+        open(os.path.join(pci, "vendor"), "w").write("0x1002\n")
+        open(os.path.join(pci, "numa_node"), "w").write("%d\n" % (c * nodes // ncards))
+        card = os.path.join(root, "class", "drm", "card%d" % c)
+        os.makedirs(card)
+        os.symlink(pci, os.path.join(card, "device"))
+    for nd in range(nodes):     # socket 0: CPUs 0-63 and their SMT siblings 128-191; socket 1: 64-127, 192-255
+        d = os.path.join(root, "devices", "system", "node", "node%d" % nd)
+        os.makedirs(d)
+        lo = nd * cpus_per_node
+        open(os.path.join(d, "cpulist"), "w").write("%d-%d,%d-%d\n" % (lo, lo + cpus_per_node - 1, lo + nodes * cpus_per_node,
+                                                                       lo + nodes * cpus_per_node + cpus_per_node - 1))
+
+
+def test_eight_rank_cpu_slices_are_disjoint_on_a_two_socket_node(tmp_path):
+    """pre-flight of the 8-GPU run that needs no GPU: on a 2-socket host with four GPUs per socket every rank's slice lies inside its
+    GPU's NUMA node, the eight slices are pairwise disjoint and together cover both sockets"""
+    sys.path.insert(0, ROOT)
+    import bench
+    root = str(tmp_path / "sys")
+    _fake_sysfs(root)
+    allowed = list(range(256))
+    node_of = lambda c: (c % 128) // 64
+    slices = [bench.rank_cpu_slice(r, 8, allowed, sysfs=root) for r in range(8)]
+    for r, sl in enumerate(slices):
+        assert len(sl) == 32 and {node_of(c) for c in sl} == {r // 4}, (r, sl)
+    flat = [c for sl in slices for c in sl]
+    assert len(flat) == len(set(flat)) == 256
+    # a cgroup that only allows half of each socket: still disjoint, still on the right socket
+    allowed = [c for c in range(256) if c % 2 == 0]
+    slices = [bench.rank_cpu_slice(r, 8, allowed, sysfs=root) for r in range(8)]
+    flat = [c for sl in slices for c in sl]
+    assert len(flat) == len(set(flat)) == 128 and all({node_of(c) for c in sl} == {r // 4} for r, sl in enumerate(slices))
+    # sysfs silent (no cards): an even split of the allowed CPUs
+    empty = str(tmp_path / "none")
+    os.makedirs(empty)
+    slices = [bench.rank_cpu_slice(r, 8, list(range(16)), sysfs=empty) for r in range(8)]
+    assert slices == [[2 * r, 2 * r + 1] for r in range(8)]
+
+
+def test_eight_rank_dry_run_deals_one_block_per_gpu():
+    """`bench.py --gpus 8 --dry --backend gloo`: the launch the driver makes on an 8-GPU node, on CPU.  gar8 (BASELINE configs[4]) puts
+    exactly ONE block on every rank and every rank takes the single-block path (F.nlml -- the `blocks` leg of the 1-GPU line prices
+    that unit); cigar4 (configs[3]) gives four ranks one block each and leaves four idle; the joint values are the 1-rank values"""
+    out = _run("--gpus", "8", "--n", "64")
+    assert out["n_gpus"] == 8 and out["collective"] == {"backend": "gloo", "ranks": 8}
+    assert out["config"]["owner"] == list(range(8)) and out["config"]["rank_paths"] == ["single"] * 8
+    g8, c4, hg = out["sharded"]["gar8"], out["sharded"]["cigar4"], out["sharded"]["gar8_hogp"]
+    assert sorted(g8["owner"]) == list(range(8)) and g8["rank_paths"] == ["single"] * 8 and g8["blocks_per_rank"] == 1
+    assert sorted(hg["owner"]) == list(range(8)) and hg["rank_paths"] == ["single"] * 8
+    assert len(set(c4["owner"])) == 4 and sorted(c4["rank_paths"]) == ["idle"] * 4 + ["single"] * 4
+    assert abs(g8["joint_nll"] - _expected_joint(8, 64, 8, 8)) < 1e-9 * abs(g8["joint_nll"])
+    assert abs(c4["joint_nll"] - _expected_joint(4, 64, 8, 8)) < 1e-9 * abs(c4["joint_nll"])
+    # four ranks: cigar4 one block per GPU, gar8 two per GPU through ONE shared chain
+    out = _run("--gpus", "4", "--n", "64")
+    assert out["sharded"]["cigar4"]["rank_paths"] == ["single"] * 4
+    assert out["sharded"]["gar8"]["rank_paths"] == ["chain"] * 4 and out["sharded"]["gar8_hogp"]["rank_paths"] == ["threads"] * 4
+
+
+def test_block_path_is_what_the_step_runs():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert [bench.block_path(k) for k in (0, 1, 2, 8)] == ["idle", "single", "chain", "chain"]
+    assert bench.block_path(3, no_chain_batch=True) == "streams" and bench.block_path(1, no_chain_batch=True) == "single"
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'if path == "single":' in src and 'elif path == "chain":' in src and 'elif path == "streams":' in src
+
+
 import pytest  # noqa: E402
 
 

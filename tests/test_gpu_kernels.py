@@ -510,6 +510,49 @@ def test_potrf_reports_first_bad_pivot(ff, n, bad):
     assert rc == bad, (rc, bad)
 
 
+def _device_spd(n, seed):
+    """a well-conditioned SPD matrix built on the device (R R^T / 64 + 2 I: every pivot is >= 2)"""
+    g = torch.Generator(device="cuda:0").manual_seed(seed)
+    R = torch.randn(n, 64, dtype=torch.float64, device="cuda:0", generator=g)
+    S = R @ R.T / 64.0
+    S.diagonal().add_(2.0)
+    return S
+
+
+def _potrf_inplace(ff, S):
+    """ffgp_potrf_rows on a copy of S (default options: look-ahead with value hand-offs from 1024 rows on) -> (rc, factor)"""
+    _lib, h = ff
+    n = S.shape[0]
+    W = S.clone()
+    rc = _lib.lib.ffgp_potrf_rows(h, ptr(W), n, n, n)
+    torch.cuda.synchronize()
+    return rc, W
+
+
+@pytest.mark.noisy
+@pytest.mark.parametrize("n", [1536, 4700, 9000])
+def test_potrf_reports_first_bad_pivot_on_the_lookahead_path(ff, n):
+    """the reference's `torch.linalg.cholesky` raises on the first non-positive pivot (GaussianProcess/cigp_v10.py:61); above la_min_n = 1024
+    rows the factorisation is the look-ahead form with value hand-offs between its streams -- a failing pivot in the FIRST, a MIDDLE and
+    the LAST outer panel must come back as its 1-based index, the call must return (no gate left waiting), and the handle must factor the
+    next matrix correctly.  The pivot is made to fail by the UPDATED value (diagonal entry lowered by the pivot's own square + 1/2), so the
+    trailing updates that feed it are part of what is tested"""
+    _lib, h = ff
+    S = _device_spd(n, n)
+    rc, L = _potrf_inplace(ff, S)
+    assert rc == 0
+    piv = L.diagonal().clone()
+    npan = (n + 511) // 512
+    cases = sorted({7, 300, 512 * (npan // 2) + 129, 512 * (npan // 2) + 512, 512 * (npan - 1) + 1, n - 1, n})
+    for bad in cases:
+        S2 = S.clone()
+        S2[bad - 1, bad - 1] -= float(piv[bad - 1]) ** 2 + 0.5
+        rc, _ = _potrf_inplace(ff, S2)
+        assert rc == bad, (n, bad, rc)
+        rc, L2 = _potrf_inplace(ff, S)            # the handle is as good as new: same factor, bit for bit
+        assert rc == 0 and torch.equal(L2.tril(), L.tril()), (n, bad)
+
+
 def test_trsm_and_potrs(ff):
     import scipy.linalg as sla
     _lib, h = ff

@@ -1157,10 +1157,11 @@ def test_raw_graph_replay():
         _lib.lib.ffgp_set_option(h, b"raw_graph_max_n", 0.0)
 
 
-@pytest.mark.parametrize("n,d", [(1536, 3), (4000, 1)])
+@pytest.mark.parametrize("n,d", [(900, 2), (1536, 3), (4000, 1)])
 def test_forward_graph_replay(n, d):
     """option fwd_graph: from its third identical occurrence a forward-only likelihood call is ONE hipGraphLaunch (both streams of the
-    look-ahead captured; n = 1536 is factored in order on one stream, n = 4000 with the side stream).  Same value bit for bit; new
+    look-ahead captured; n = 900 is factored in order on one stream, n = 1536 and n = 4000 -- more than la_min_n = 1024 rows -- with the
+    side stream, whose hand-offs are event pairs under capture).  Same value bit for bit; new
     CONTENTS of the same buffers are seen by the replay; other buffers drop the graph; a matrix that is not positive definite is
     reported by the replayed call like by the plain one"""
     from fidelityfusion_amd import _lib
@@ -2058,6 +2059,60 @@ def test_not_positive_definite_raises():
     bad = -torch.eye(40, device=DEV)
     with pytest.raises(torch.linalg.LinAlgError):
         gp_pack.Gaussian_log_likelihood(torch.ones(40, 1, device=DEV), bad)
+
+
+@pytest.mark.noisy
+@pytest.mark.parametrize("n,bad", [(1536, 3), (1536, 1301), (4700, 2200), (4700, 4700)])
+def test_not_positive_definite_on_the_lookahead_path_through_the_modules(n, bad):
+    """`torch.linalg.cholesky` raises at GaussianProcess/cigp_v10.py:61; here blocks of more than 1024 rows are factored by the look-ahead
+    form whose streams hand over through polled device words -- a failing pivot in the first / a middle / the last panel must surface as
+    LinAlgError with THAT index from `cigp.negative_log_likelihood` (forward, and with gradients wanted), the call must return, and the
+    model must evaluate normally afterwards.  Runs beside the background load (marker `noisy`)"""
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp
+    rng = np.random.default_rng(n + bad)
+    D = 3
+    k = kernel.ARDKernel(D)
+    m = cigp(k, 0.5).double().to(DEV)
+    x, y = T(rng.uniform(0, 1, (n, D))), T(rng.standard_normal((n, 2)))
+    with torch.no_grad():
+        good = m.negative_log_likelihood(x, y).clone()
+    y_var = torch.zeros(n, n, device=DEV, dtype=torch.float64)
+    y_var[bad - 1, bad - 1] = -10.0                      # Sigma[bad, bad] = amp + noise + jitter - 10 < 0: minors < bad stay PD
+    with torch.no_grad(), pytest.raises(torch.linalg.LinAlgError, match="order %d is" % bad):
+        m.negative_log_likelihood(x, [y, y_var])
+    yg = y.clone().requires_grad_(True)
+    with pytest.raises(torch.linalg.LinAlgError, match="order %d is" % bad):
+        m.negative_log_likelihood(x, [yg, y_var]).backward()
+    with torch.no_grad():
+        assert torch.equal(m.negative_log_likelihood(x, y), good)
+
+
+@pytest.mark.noisy
+def test_one_bad_member_of_a_ragged_set_above_1024_rows():
+    """negative_log_likelihood_many on members of different sizes, two of them on the look-ahead form: the member that is not positive
+    definite is reported as THAT block (the reference's loop would stop at that model, FidelityFusion_Models/ResGP.py:78-112), whichever
+    panel its pivot fails in; the same set evaluates normally before and after"""
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp, negative_log_likelihood_many
+    rng = np.random.default_rng(77)
+    shapes = [(1536, 1), (2600, 2), (300, 1)]
+    models, xs, ys = [], [], []
+    for f, (n, d) in enumerate(shapes):
+        models.append(cigp(kernel.ARDKernel(3), 0.5 + 0.1 * f).double().to(DEV))
+        xs.append(T(rng.uniform(0, 1, (n, 3))))
+        ys.append(T(rng.standard_normal((n, d))))
+    with torch.no_grad():
+        good = negative_log_likelihood_many(models, xs, ys).clone()
+        for which, bad in ((1, 5), (1, 1400), (1, 2600), (0, 1100)):
+            n = shapes[which][0]
+            y_var = torch.zeros(n, n, device=DEV, dtype=torch.float64)
+            y_var[bad - 1, bad - 1] = -10.0
+            ys_bad = list(ys)
+            ys_bad[which] = [ys[which], y_var]
+            with pytest.raises(torch.linalg.LinAlgError, match="block %d" % which):
+                negative_log_likelihood_many(models, xs, ys_bad)
+            assert torch.equal(negative_log_likelihood_many(models, xs, ys), good), (which, bad)
 
 
 # ------------------------------------------------------------------------------------------------ callers (X1)
