@@ -39,6 +39,12 @@
 extern "C" {
 #endif
 
+/* libffgp.so is linked with -fvisibility=hidden: exactly the functions declared in this header are exported
+   (tests/test_abi_exports.py holds `nm -D` to this list, in both directions). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
+
 typedef struct ffgp_handle ffgp_handle;
 
 enum {
@@ -546,6 +552,9 @@ int ffgp_syrk_stats(ffgp_handle* h, double* flops, double* ms, long* launches, i
 /* peak probe: runs a register-resident v_mfma_f64_16x16x4_f64 loop on every CU, returns measured TFLOP/s */
 int ffgp_mfma_f64_peak(ffgp_handle* h, double* tflops_out);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

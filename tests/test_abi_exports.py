@@ -38,6 +38,15 @@ def test_so_exports_every_declared_symbol(built):
     assert not missing, missing
 
 
+def test_so_exports_nothing_but_the_declared_symbols(built):
+    """the dynamic symbol table of libffgp.so IS the header (-fvisibility=hidden, the header's visibility pragma and the version
+    script generated from the header): no internal C++ function, kernel handle, device stub or std:: instantiation leaks"""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", SO], capture_output=True, text=True, check=True).stdout
+    exported = sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+    assert exported == declared_functions(), sorted(set(exported) ^ set(declared_functions()))
+
+
 def test_python_binding_covers_the_header(built):
     from fidelityfusion_amd import _lib
     assert sorted(_lib.EXPORTS) == declared_functions()
