@@ -474,6 +474,9 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->chase_xl = (int)value;
   } else if (!strcmp(key, "chase_xl_max_n")) {
     h->chase_xl_max_n = (int)value;
+  } else if (!strcmp(key, "chase_xcc")) {
+    if (value < 0 || value > 15) return FFGP_ERR_ARG;
+    h->chase_xcc = (int)value;
   } else if (!strcmp(key, "syrk_direct")) {
     h->syrk_direct = (int)value;
   } else if (!strcmp(key, "syrk_h64")) {

@@ -1178,6 +1178,10 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
       // (one buffer per handle: consecutive trailing updates on DIFFERENT streams would race on it -- the look-ahead forms issue
       // them on the main stream only, the side stream's S_a keeps the LDS form)
       if (h->stream != h->aux) {
+        if (a.pub_word) {   // (published before the direct kernel, not by the LDS kernel behind it)
+          FFGP_HIP(hipStreamWriteValue32(h->stream, a.pub_word, a.pub_val, 0));
+          a.pub_word = nullptr;
+        }
         hipLaunchKernelGGL(ffgp_pack_panel_kernel, dim3(rbs, (k + 127) / 128), dim3(256), 0, h->stream, A, lda, m, k,
                            reinterpret_cast<d2_t*>(h->pack_buf));
         a.pack = h->pack_buf;
@@ -1215,6 +1219,10 @@ int ffgp_gemm_launch(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   else if (tsm == 128 && syrk_tag && h->syrk_h64 && a.split_at == 0x7fffffff && a.pad_lds == 0 && !ob) {
     // (experiment: the trailing update on 128 x 64 half tiles, three workgroups per CU)
     const int gx = ((a.total_tiles + 7) / 8) * 16;
+    if (a.pub_word) {   // only ffgp_gemm_f64 stores the word itself: a hand-off the plan picked up is written plainly before any other kernel
+      FFGP_HIP(hipStreamWriteValue32(h->stream, a.pub_word, a.pub_val, 0));
+      a.pub_word = nullptr;
+    }
     hipLaunchKernelGGL((ffgp_gemm_f64_h64<OP_KMAJOR, OP_KMAJOR, TILES_LOWER, 1>), dim3(gx, a.batch), dim3(256), 0, h->stream, a);
     rc = FFGP_OK;
   }
@@ -1268,6 +1276,10 @@ int ffgp_gemm_launch_rag(ffgp_handle* h, int mode, int syrk_tag, int R, const Ge
     Item it;
     FFGP_CHECK(gemm_plan(h, OP_KMAJOR, OP_KMAJOR, mode, syrk_tag, g.A, g.lda, g.B, g.ldb, g.C, g.ldc, g.m, g.n, g.k, alpha, beta, 0, alias,
                          0, 0, 0, 0, it.pl));
+    if (it.pl.a.pub_word) {   // (the ragged kernel does not publish: a hand-off the plan picked up is written plainly, never dropped)
+      FFGP_HIP(hipStreamWriteValue32(h->stream, it.pl.a.pub_word, it.pl.a.pub_val, 0));
+      it.pl.a.pub_word = nullptr;
+    }
     // members share a launch when they chose the same kernel instantiation and launch attributes
     it.key = ((long)it.pl.tsm << 40) | ((long)it.pl.tsn << 28) | ((long)it.pl.syrk_tag << 24) | (long)(it.pl.a.pad_lds >> 10);
     items.push_back(it);

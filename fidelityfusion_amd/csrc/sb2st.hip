@@ -147,6 +147,7 @@ struct ChaseArgs {
   int* ticket;                       // XL form: the next sweep to hand out (waves take their sweeps in the order they ask)
   int xcc;                           // XL form: the XCD whose waves work
   int s_begin, s_end;                // sweeps of this launch (the chase may be cut into several launches: prog carries over)
+  const int* begin_from;             // chip-wide form behind an XL launch: the first sweep NOT yet handed out is read here (the XL ticket)
 };
 
 template <bool XL>
@@ -163,6 +164,16 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
     wg = blockIdx.x / p.pack;
     nwg = (gridDim.x + p.pack - 1) / p.pack;
   }
+  // The chip-wide launch that follows every XL launch: where a wave runs is observed behaviour, not a contract (partition modes, a
+  // CU-masked stream, a part with fewer XCDs: possibly NO wave saw p.xcc and the ticket never moved), so whatever the XL launch did
+  // not hand out is chased here.  Every sweep below the ticket was taken by a wave that ran it to its end (stream order: that launch
+  // is complete), so the normal case is ticket >= s_end and every workgroup leaves at once.
+  int s_first = p.s_begin;
+  if (!XL && p.begin_from) {
+    s_first = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p.begin_from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (s_first < p.s_begin) s_first = p.s_begin;
+    if (s_first >= p.s_end) return;
+  }
   const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
   // XL: sweeps are handed out by a ticket counter -- a wave that holds sweep s knows every lower sweep has been taken by a wave that is
   // already running (or done), so it only ever waits for a running wave, however many waves the XCD received
@@ -178,7 +189,7 @@ __global__ __launch_bounds__(64) void sb2st_chase(ChaseArgs p) {
   double* v2s = vsB;
   // raw buffer over the whole band (stride 0, range check off the table: num_records = 2 GiB - 1; the band is n * SB_LDB doubles)
   const __amdgpu_buffer_rsrc_t band = __builtin_amdgcn_make_buffer_rsrc(AB, 0, 0x7fffffff, 0x00020000);
-  for (int s = XL ? next_sweep(0) : p.s_begin + wg; s < p.s_end; s = next_sweep(s)) {
+  for (int s = XL ? next_sweep(0) : s_first + wg; s < p.s_end; s = next_sweep(s)) {
     int c0 = s + 1;
     int len = min(32, n - c0);
     int seen = (s > 0) ? 0 : CH_DONE;    // progress of sweep s - 1 as last observed
@@ -452,6 +463,7 @@ int ffgp_sb2st_chunk(ffgp_handle* h, hipStream_t st, double* AB, int n, double* 
   // host threads) 1 and 2 measure the same, 1.43-1.47 s per step.
   a.pack = h->chase_pack > 0 ? h->chase_pack : 1;
   a.ticket = nullptr;
+  a.begin_from = nullptr;
   a.xcc = h->chase_xcc;
   // XCD-local form (option chase_xl, default 1; see stb_buf).  A sweep follows its predecessor two steps behind, so (n / 32) / 2 sweeps
   // are in flight at most: up to n = 2048 that is <= 32 working waves, ONE per CU of one XCD, and the hand-over through that XCD's L2
@@ -463,6 +475,11 @@ int ffgp_sb2st_chunk(ffgp_handle* h, hipStream_t st, double* AB, int n, double* 
     hipLaunchKernelGGL(sb2st_ticket_init, dim3(1), dim3(1), 0, st, a.ticket, s_begin);
     const int grid = min(s_end - s_begin, max(16, n / 64)) * 8;
     hipLaunchKernelGGL(sb2st_chase<true>, dim3(grid), dim3(64), 0, st, a);
+    // ... and the sweeps the ticket did not reach (none, unless no wave landed on XCD `xcc`) on the chip-wide form: the chase is
+    // complete when this returns, wherever the runtime placed the XL launch's waves
+    a.begin_from = a.ticket;
+    a.ticket = nullptr;
+    hipLaunchKernelGGL(sb2st_chase<false>, dim3(min(s_end - s_begin, 256) * a.pack), dim3(64), 0, st, a);
     return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
   }
   const int grid = min(s_end - s_begin, 256) * a.pack;

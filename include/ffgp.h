@@ -258,7 +258,12 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
             "chase_xl" / "chase_xl_max_n" (default 1 / 2048: bands of up to chase_xl_max_n columns run their bulge chase with every
                         working wavefront on ONE XCD -- the kernel reads HW_REG_XCC_ID and the others leave -- and hand the band over
                         through that XCD's L2: plain stores, L1-bypassing loads; sb2st 7.9 -> 6.5 ms at n = 1024, 15.9 -> 13.8 at 2048;
-                        0 = the chip-wide form with device-scope accesses at every size),
+                        0 = the chip-wide form with device-scope accesses at every size.  Where the runtime places a wave is observed
+                        behaviour, not a contract: every XCD-local launch is followed by a chip-wide launch that chases whatever sweeps
+                        the first did not hand out -- none on a full MI355X; all of them when no wave landed on the chosen XCD, as in a
+                        partition mode or on a CU-masked stream),
+            "chase_xcc" (0..15; default: handles of one process take XCDs 0..7 in turn -- the XCD whose wavefronts run the XCD-local
+                        chase; a value no wave of the launch reports leaves the whole chase to the chip-wide launch behind it: a test mode),
             "batch_grad_ob" (default 1: the shared chain's gradient stage inverts all blocks in one outer-batched sequence of launches),
             "trtri_overlap", "small_fused", "small_max_n" (round-3 experiment switches).
    Keys the SHIPPED library refuses with FFGP_ERR_ARG (they are accepted by the development build only, `make dev`,

@@ -295,6 +295,15 @@ def test_xcd_local_chase_is_the_chip_wide_chase_bit_for_bit(n):
     assert torch.equal(res[1][0][0], res[1][1][0]) and torch.equal(res[1][0][1], res[1][1][1])
     lam = torch.linalg.eigvalsh(K)
     assert float((res[1][0][0] - lam).abs().max()) <= 1e-11 * float(lam.abs().max())
+    # no wave of the XCD-local launch lands on the chosen XCD (partition modes, a CU-masked stream, a part with fewer XCDs; here: an id
+    # the chip does not have): the ticket never moves and the chip-wide launch behind it chases every sweep -- same eigenpairs, not an
+    # un-reduced band returned with FFGP_OK
+    _lib.set_option("chase_xcc", 12, 0)
+    try:
+        W, Z = E.eigh(K)
+    finally:
+        _lib.set_option("chase_xcc", 0, 0)
+    assert torch.equal(W, res[0][0][0]) and torch.equal(Z, res[0][0][1])
 
 
 @pytest.mark.noisy
