@@ -359,6 +359,7 @@ int ffgp_destroy(ffgp_handle* h) {
   if (h->ho_mem) hipFree(h->ho_mem);
   if (h->bt_info) hipFree(h->bt_info);
   if (h->train_g) hipFree(h->train_g);
+  if (h->train_tab) hipFree(h->train_tab);
   if (h->pack_buf) hipFree(h->pack_buf);
   ffgp_assemble_collect_free(h);
   if (h->bt_info_host) hipHostFree(h->bt_info_host);
@@ -474,6 +475,8 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->chase_xl = (int)value;
   } else if (!strcmp(key, "chase_xl_max_n")) {
     h->chase_xl_max_n = (int)value;
+  } else if (!strcmp(key, "train_persist")) {
+    h->train_persist_off = (value == 0.0) ? 1 : 0;
   } else if (!strcmp(key, "chase_xcc")) {
     if (value < 0 || value > 15) return FFGP_ERR_ARG;
     h->chase_xcc = (int)value;
@@ -1244,6 +1247,11 @@ int ffgp_train_raw(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_link
     sl.amp[f] = const_cast<double*>(q.amp_dev);
     sl.dadd[f] = const_cast<double*>(q.diag_add_dev);
     sl.nw[f] = nw;
+  }
+  {   // every model small enough for one workgroup: the whole loop is ONE launch (train.hip)
+    bool persist = true;
+    for (int f = 0; f < F && persist; ++f) persist = ffgp_train_persist_ok(h, p + f, l + f);
+    if (persist) return ffgp_train_persist(h, F, p, l, steps, opt, state_dev, state_stride, step0, trace_dev, trace_stride);
   }
   if (!h->train_g) {
     FFGP_HIP(hipMalloc(&h->train_g, (size_t)FFGP_TRAIN_MAXF * (FFGP_TRAIN_GSTRIDE + 1) * sizeof(double)));

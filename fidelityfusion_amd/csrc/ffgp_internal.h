@@ -241,6 +241,9 @@ struct ffgp_handle {
   int fold_info;        // ffgp_train_raw with one model: status-word upkeep lives in the Adam kernel
   int defer_info_copy;  // ffgp_train_raw's loop: the enqueue paths skip their per-call read-back of the status word
   double* train_g;      // ffgp_train_raw: gradients of the raw parameters [MAXF x GSTRIDE] + the step's losses [MAXF]
+  void* train_tab;      // ffgp_train_persist (train.hip): [models | bias corrections | status words] of the current call
+  size_t train_tab_bytes;
+  int train_persist_off;  // option "train_persist" = 0: ffgp_train_raw never takes the one-launch trainer
   int* bt_info;         // [F] device status words (first non-positive pivot of each block)
   int* bt_info_host;    // pinned mirror
   int trtri_overlap;    // option (default 1)
@@ -370,6 +373,10 @@ int ffgp_small_enqueue(ffgp_handle* h, const ffgp_problem* p, const ffgp_links* 
                        const double* dinv = nullptr);
 bool ffgp_small2_ok(const ffgp_handle* h, const ffgp_problem* p, const ffgp_grads* g);
 bool ffgp_small_batch_ok(const ffgp_problem* p, const ffgp_grads* g);
+// train.hip: K Adam steps of F small models in ONE launch (one persistent workgroup per model)
+bool ffgp_train_persist_ok(const ffgp_handle* h, const ffgp_problem* p, const ffgp_links* l);
+int ffgp_train_persist(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_links* l, int steps, const ffgp_adam* opt, double* state_dev,
+                       long state_stride, long step0, double* trace_dev, long trace_stride);
 int ffgp_small_batch_enqueue(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g);
 // ---- workspace
 int ffgp_ensure_ws(ffgp_handle* h, size_t bytes);

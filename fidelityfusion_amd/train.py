@@ -140,7 +140,8 @@ def train_many(models, xs, ys, steps, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, sta
         tr = trace[idx[0]:idx[0] + len(idx)] if contiguous else torch.empty((len(idx), steps), dtype=torch.float64, device=dev)
         rc = check(lib.ffgp_train_raw(h, len(idx), P, L, int(steps), C.byref(opt), st.buf.data_ptr(), stride, int(st.step),
                                       tr.data_ptr(), tr.stride(0)), "ffgp_train_raw")
-        st.step += steps
+        if rc == 0:      # (a call that failed leaves its optimisers where they were: the caller sees LinAlgError)
+            st.step += steps
         if not contiguous:
             trace[list(idx)] = tr
         return rc

@@ -112,6 +112,57 @@ def test_train_many_follows_the_reference_loop(shapes, kinds):
     assert rel(mean, mean_t) < 1e-9
 
 
+@pytest.mark.parametrize("shapes,kinds,yvar", [
+    ([(16, 2, 1)], None, False), ([(32, 5, 1)], None, False), ([(47, 3, 2)], ["matern"], False), ([(64, 16, 1)], None, True),
+    ([(100, 5, 16)], ["se"], False), ([(128, 5, 1)], None, True), ([(113, 7, 3)], ["matern"], False),
+    ([(64, 5, 1)] * 16, None, False), ([(128, 4, 2), (20, 3, 1), (77, 2, 5)], ["ard", "se", "matern"], True),
+])
+def test_one_launch_trainer_is_the_launch_per_stage_trainer(shapes, kinds, yvar):
+    """round 6: models of up to 128 points train inside ONE persistent kernel launch (csrc/train.hip: one workgroup per model, every Adam
+    step inside the kernel -- Sigma in LDS, blocked Cholesky + inverse + Sigma^-1 on the matrix cores, gradient sums, links, Adam).  The
+    launch-per-stage path it replaces (option train_persist = 0; itself held to torch.optim.Adam's loop above) must give the same
+    trajectory: losses and final parameters to 1e-11, Adam moments carried over a second call"""
+    from fidelityfusion_amd import _lib
+    from fidelityfusion_amd.cigp_v10 import train_many
+    steps, lr = 30, 2e-2
+    runs = {}
+    for persist in (1, 0):
+        models, xs, ys = make_models(shapes, 23, kinds)
+        if yvar:
+            rng = np.random.default_rng(5)
+            ys = [[y, torch.diag(T(rng.uniform(0.01, 0.3, y.shape[0])))] for y in ys]
+        _lib.set_option("train_persist", persist, 0)
+        try:
+            tr1, state = train_many(models, xs, ys, steps, lr=lr)
+            tr2, _ = train_many(models, xs, ys, 7, lr=lr, state=state)
+        finally:
+            _lib.set_option("train_persist", 1, 0)
+        runs[persist] = (torch.cat([tr1, tr2], dim=1).clone(), [params_of(m) for m in models])
+    assert torch.isfinite(runs[1][0]).all()
+    assert rel(runs[1][0], runs[0][0]) < 1e-11, rel(runs[1][0], runs[0][0])
+    for pa, pb in zip(runs[1][1], runs[0][1]):
+        for a, b in zip(pa, pb):
+            assert rel(a, b) < 1e-10, (a, b)
+
+
+def test_one_launch_trainer_stops_only_the_model_that_failed():
+    """a Sigma that is not positive definite stops THAT model (LinAlgError from the call, its parameters as they were); the other
+    models of the launch have trained on: their parameters are those of training them alone"""
+    from fidelityfusion_amd.cigp_v10 import train_many
+    models, xs, ys = make_models([(50, 2, 1), (90, 3, 1), (128, 2, 2)], 3)
+    solo, sx, sy = make_models([(50, 2, 1), (90, 3, 1), (128, 2, 2)], 3)
+    before = params_of(models[1])
+    bad = [ys[1], -3.0 * torch.eye(90, device=DEV, dtype=torch.float64)]
+    with pytest.raises(torch.linalg.LinAlgError):
+        train_many(models, xs, [ys[0], bad, ys[2]], 6)
+    for a, b in zip(params_of(models[1]), before):
+        assert np.array_equal(a, b)
+    for f in (0, 2):
+        train_many([solo[f]], [sx[f]], [sy[f]], 6)
+        for a, b in zip(params_of(models[f]), params_of(solo[f])):
+            assert rel(a, b) < 1e-12
+
+
 def test_train_many_on_the_reference_fixture(golden):
     """tests/golden/resgp_chain.npz: the reference's train_ResGP on a seeded two-fidelity problem, 5 Adam steps per fidelity
     (FidelityFusion_Models/ResGP.py:67-112; the second fidelity's targets come with a y_var matrix) -- both fidelities as ONE
