@@ -360,6 +360,7 @@ int ffgp_destroy(ffgp_handle* h) {
   if (h->bt_info) hipFree(h->bt_info);
   if (h->train_g) hipFree(h->train_g);
   if (h->train_tab) hipFree(h->train_tab);
+  if (h->train_host) hipHostFree(h->train_host);
   if (h->pack_buf) hipFree(h->pack_buf);
   ffgp_assemble_collect_free(h);
   if (h->bt_info_host) hipHostFree(h->bt_info_host);

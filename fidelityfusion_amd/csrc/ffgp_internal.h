@@ -243,6 +243,7 @@ struct ffgp_handle {
   double* train_g;      // ffgp_train_raw: gradients of the raw parameters [MAXF x GSTRIDE] + the step's losses [MAXF]
   void* train_tab;      // ffgp_train_persist (train.hip): [models | bias corrections | status words] of the current call
   size_t train_tab_bytes;
+  void* train_host;     // its pinned host mirror (staging of the table, read-back of the status words)
   int train_persist_off;  // option "train_persist" = 0: ffgp_train_raw never takes the one-launch trainer
   int* bt_info;         // [F] device status words (first non-positive pivot of each block)
   int* bt_info_host;    // pinned mirror

@@ -27,7 +27,7 @@
 #define TR_N 128
 #define TR_D 16
 #define TR_Y 16
-#define TR_NRED 20        // values of the step's one workgroup reduction: ss, s_amp, tr, tot[16], spare
+#define TR_NRED 20        // values of the step's one workgroup reduction: ss, s_amp, tr G, log-det, tot[16]
 
 typedef double tr_d4 __attribute__((ext_vector_type(4)));
 
@@ -41,6 +41,8 @@ struct TrainModel {
   int kfun;
   double* state;                         // [exp_avg (nw + 2) | exp_avg_sq (nw + 2)]
   double* trace;                         // [steps]
+  double* kbuf;                          // [36][4][64] this model's kernel values K / amp, written by the assembly and read back by the
+                                         // gradient pass of the same step (same lane, same slot: the exp is evaluated once per entry and step)
 };
 struct TrainCommon {
   int steps;
@@ -48,7 +50,16 @@ struct TrainCommon {
   const double* bc;                      // [steps][2]: 1 - beta1^t, sqrt(1 - beta2^t) -- computed on the host with the C library's pow, as Python does
   int* info;                             // [models] status: 0, or the 1-based index of the first non-positive pivot of the step that failed
   int* fail_step;                        // [models] the step at which it happened
+  long* prof;                            // development (FFGP_TRAIN_TRACE=1): [12] wall_clock64 ticks per phase, summed over model 0's steps
 };
+#define TR_PROF(k)                                                   \
+  do {                                                               \
+    if (cm.prof && tid == 0 && blockIdx.x == 0) {                    \
+      const long now_ = wall_clock64();                              \
+      cm.prof[k] += now_ - t_prof;                                   \
+      t_prof = now_;                                                 \
+    }                                                                \
+  } while (0)
 
 __device__ __forceinline__ double tr_link_val(int kind, double p, double c) {
   switch (kind) {
@@ -71,6 +82,32 @@ __device__ __forceinline__ double tr_link_der(int kind, double p, double c) {
     case FFGP_LINK_SQUARE: return 2.0 * p;
     default: return 1.0;
   }
+}
+
+// sum over the 64 lanes of the wave, in all of them: four DPP steps inside the rows of 16 lanes, then the rows exchanged by gfx950's
+// row swaps (the shuffle form, ds_bpermute, is an LDS crossbar round trip per step: 6 dependent trips per value)
+template <int CTRL>
+__device__ __forceinline__ double tr_dpp_add(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+  return x + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double tr_wsum(double x) {
+  x = tr_dpp_add<0xB1>(x);
+  x = tr_dpp_add<0x4E>(x);
+  x = tr_dpp_add<0x141>(x);
+  x = tr_dpp_add<0x140>(x);
+  {
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    x = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+  }
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
 }
 
 __device__ __forceinline__ int tr_blk(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * TR_BLK; }
@@ -120,44 +157,6 @@ __device__ __forceinline__ void tr_store(double* dst, const tr_d4& acc, int g, i
   for (int r = 0; r < 4; ++r) dst[(g + 4 * r) * TR_BLD + c] = sign * acc[r];
 }
 
-// one level of the in-place inversion by recursive doubling (as inv_merge_level of potrf.hip): pairs of inverted diagonal super-blocks
-// of S_ blocks are merged, X21 = -X22 (L21 X11).  One (pair, block column) item per wave (4 items per level); a wave keeps its
-// column of T = L21 X11 in registers across the barrier that protects L21 from being overwritten while other waves still read it.
-template <int S_>
-__device__ __forceinline__ void tr_inv_level(double* S, int wave, int lane) {
-  const bool act = wave < 4;
-  const int pair = wave / S_, jl = wave % S_;
-  const int b0 = pair * 2 * S_;
-  const int j = b0 + jl;
-  const int g = lane >> 4, c = lane & 15;
-  tr_d4 T[S_];
-  if (act) {
-#pragma unroll
-    for (int ii = 0; ii < S_; ++ii) {
-      const int i = b0 + S_ + ii;
-      tr_d4 acc = {0.0, 0.0, 0.0, 0.0};
-      for (int k = j; k < b0 + S_; ++k) tr_mma_nn(acc, S + tr_blk(i, k), S + tr_blk(k, j), lane);
-      T[ii] = acc;
-    }
-  }
-  __syncthreads();
-  if (act) {
-#pragma unroll
-    for (int ii = 0; ii < S_; ++ii) tr_store(S + tr_blk(b0 + S_ + ii, j), T[ii], g, c, 1.0);
-    tr_d4 R[S_];
-#pragma unroll
-    for (int ii = 0; ii < S_; ++ii) {      // (reads column j of the rows the same wave just wrote: its own LDS stores, in order)
-      const int i = b0 + S_ + ii;
-      tr_d4 acc = {0.0, 0.0, 0.0, 0.0};
-      for (int k = b0 + S_; k <= i; ++k) tr_mma_nn(acc, S + tr_blk(i, k), S + tr_blk(k, j), lane);
-      R[ii] = acc;
-    }
-#pragma unroll
-    for (int ii = 0; ii < S_; ++ii) tr_store(S + tr_blk(b0 + S_ + ii, j), R[ii], g, c, -1.0);
-  }
-  __syncthreads();
-}
-
 // LDS (doubles): S 36 * 272 | Xs [128][17] | Ym, Gam, Am [128][16] each | piv [128] | dvec [128] | small
 #define TR_OFF_XS (TR_NBLK * TR_BLK)
 #define TR_OFF_YM (TR_OFF_XS + TR_N * (TR_D + 1))
@@ -166,9 +165,11 @@ __device__ __forceinline__ void tr_inv_level(double* S, int wave, int lane) {
 #define TR_OFF_PIV (TR_OFF_AM + TR_N * TR_Y)
 #define TR_OFF_DVEC (TR_OFF_PIV + TR_N)
 #define TR_OFF_SMALL (TR_OFF_DVEC + TR_N)
-#define TR_SMALL_DOUBLES (16 + 3 * 20 + 8 + 8 * TR_NRED + TR_NRED + 8)
+#define TR_SMALL_DOUBLES (16 + 3 * 20 + 8 + 8 * TR_NRED + TR_NRED + 16)
 #define TR_LDS_DOUBLES (TR_OFF_SMALL + TR_SMALL_DOUBLES)
 
+// DM: the input dimensions the per-entry loops are unrolled for (8 or 16: every model of the launch has D <= DM)
+template <int DM>
 __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainModel* __restrict__ tab, TrainCommon cm) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const TrainModel M = tab[blockIdx.x];
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
 
   // ---- once: targets, the diagonal extra, parameters and moments into LDS; identity padding of the blocks the factorisation never touches
   for (int idx = tid; idx < n * d; idx += TR_T) Ym[idx] = M.Y[idx];
+  for (int idx = tid; idx < TR_N * (TR_D + 1); idx += TR_T) Xs[idx] = 0.0;      // (columns >= D and rows >= n stay zero: the unrolled loops read them)
   for (int i = tid; i < TR_N; i += TR_T) dvec[i] = (M.diag_vec && i < n) ? M.diag_vec[(size_t)i * M.diag_stride] : 0.0;
   if (tid < npar) {
     raw[tid] = (tid < nw) ? M.w[tid] : (tid == nw ? M.amp[0] : M.dadd[0]);
@@ -212,21 +214,40 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
     for (int r = 0; r < 4; ++r) S[tr_blk(bi, bj) + (g + 4 * r) * TR_BLD + c] = (bi == bj && g + 4 * r == c) ? 1.0 : 0.0;
   }
   if (tid == 0) flags[0] = 0;
+  if (lane == 0) flags[8 + wave] = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3;      // HW_REG_HW_ID, SIMD_ID (bits 5:4)
+  __syncthreads();
+  // helpers of the factorisation's stage [A]: the waves that do NOT share wave 0's SIMD (six, with two waves per SIMD)
+  int hidx = -1, nh = 0;
+  {
+    const int s0 = flags[8];
+    for (int w_ = 1; w_ < 8; ++w_) {
+      const bool is_h = flags[8 + w_] != s0;
+      if (is_h && w_ == wave) hidx = nh;
+      nh += is_h ? 1 : 0;
+    }
+    if (nh == 0) {      // (every wave on one SIMD cannot happen with 8 waves on 4 SIMDs; keep the kernel correct anyway)
+      nh = 7;
+      hidx = wave - 1;
+    }
+    hidx = __builtin_amdgcn_readfirstlane(hidx);
+    nh = __builtin_amdgcn_readfirstlane(nh);
+  }
+  if (tid < D) wv[tid] = tr_link_val(M.l.w_link, raw[M.l.w_broadcast ? 0 : tid], M.l.w_c);
+  if (tid == 64) sc[0] = tr_link_val(M.l.amp_link, raw[nw], M.l.amp_c);
+  if (tid == 65) sc[1] = tr_link_val(M.l.dadd_link, raw[nw + 1], M.l.dadd_c);
   __syncthreads();
 
   int failed = 0;
+  long t_prof = cm.prof ? wall_clock64() : 0;
   for (int step = 0; step < cm.steps; ++step) {
-    // ---- P0: effective parameters, scaled inputs
-    if (tid < D) wv[tid] = tr_link_val(M.l.w_link, raw[M.l.w_broadcast ? 0 : tid], M.l.w_c);
-    if (tid == 64) sc[0] = tr_link_val(M.l.amp_link, raw[nw], M.l.amp_c);
-    if (tid == 65) sc[1] = tr_link_val(M.l.dadd_link, raw[nw + 1], M.l.dadd_c);
-    __syncthreads();
+    // ---- P0: scaled inputs (the effective parameters were refreshed by the threads that updated the raw ones)
     for (int idx = tid; idx < n * D; idx += TR_T) {
       const int i = idx / D, k = idx - i * D;
       Xs[i * (TR_D + 1) + k] = M.X[idx] * wv[k];
     }
     __syncthreads();
     const double amp = sc[0], dadd = sc[1];
+    TR_PROF(0);
 
     // ---- P1: Sigma, lower block triangle (diagonal blocks symmetric-full: the in-register factor wants both halves); rows / columns
     //      beyond n are identity
@@ -235,29 +256,50 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
       tr_unblk(t, bi, bj);
       double* dst = S + tr_blk(bi, bj);
       const int j = bj * 16 + c;
+      double xj[DM], sq[4];
+#pragma unroll
+      for (int k = 0; k < DM; ++k) xj[k] = Xs[j * (TR_D + 1) + k];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double* xi = Xs + (bi * 16 + g + 4 * r) * (TR_D + 1);
+        sq[r] = 0.0;
+#pragma unroll
+        for (int k = 0; k < DM; ++k) {
+          const double df = xi[k] - xj[k];
+          sq[r] = __builtin_fma(df, df, sq[r]);
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = bi * 16 + g + 4 * r;
-        double kv = (i == j) ? 1.0 : 0.0;
-        if (i < n && j < n) {
-          double sq = 0.0;
-          for (int k = 0; k < D; ++k) {
-            const double df = Xs[i * (TR_D + 1) + k] - Xs[j * (TR_D + 1) + k];
-            sq = __builtin_fma(df, df, sq);
-          }
-          const double s_ = fmax(sq, M.clamp);
-          kv = amp * ((M.kfun == FFGP_KFUN_SE) ? ffgp_exp_fast(-0.5 * s_, ec) : ffgp_kfun_val(M.kfun, M.rinv, s_));
-          if (i == j) kv += dadd + dvec[i];
-        }
+        const double s_ = fmax(sq[r], M.clamp);
+        const double ev = (M.kfun == FFGP_KFUN_SE) ? ffgp_exp_fast(-0.5 * s_, ec) : ffgp_kfun_val(M.kfun, M.rinv, s_);
+        M.kbuf[(t * 4 + r) * 64 + lane] = ev;
+        double kv = amp * ev;
+        if (i == j) kv += dadd + dvec[i];
+        if (i >= n || j >= n) kv = (i == j) ? 1.0 : 0.0;
         dst[(g + 4 * r) * TR_BLD + c] = kv;
       }
     }
     __syncthreads();
+    TR_PROF(1);
 
-    // ---- P2: blocked Cholesky over 16-column stages; the diagonal block's slot receives inv(L_jj), the pivots go to piv[]
+    // ---- P2: blocked Cholesky over 16-column stages AND the inverse, two barriers per stage.
+    //   [A] wave 0 applies column jj - 1 to its diagonal block (jj, jj) and factors + inverts it in registers (F: the slot receives
+    //       inv(L_jj), the pivots go to piv[]); in its shadow the helper waves -- every wave that does not share wave 0's SIMD: fp64
+    //       MFMAs and the pivot loop's fp64 vector instructions use the same pipe -- apply column jj - 1 to all the other blocks and
+    //       compute row block jj - 1 of the inverse, X[s][j] = -inv(L_s) sum_{k=j}^{s-1} L[s][k] X[k][j], into registers;
+    //   [B] the inverse's row is stored over row jj - 1 of L (nobody reads it any more) and column jj is solved by all waves.
     for (int jj = 0; jj < nst; ++jj) {
+      tr_d4 Xn[2];
       if (wave == 0) {
         double* Dj = S + tr_blk(jj, jj);
+        if (jj > 0) {      // the one update still missing from this block
+          tr_d4 acc = {0.0, 0.0, 0.0, 0.0};
+          tr_mma_nt(acc, S + tr_blk(jj, jj - 1), S + tr_blk(jj, jj - 1), lane);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Dj[(g + 4 * r) * TR_BLD + c] -= acc[r];
+        }
         int cc = c, gg = g;
         asm volatile("" : "+v"(cc), "+v"(gg));      // (opaque per iteration: the stage loop must not be specialised per jj)
         double v[4], w[4];
@@ -291,9 +333,43 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
           Dj[i * TR_BLD + c] = (i >= c) ? w[r] * rsi : 0.0;       // inv(L_jj)
         }
         if (bad && lane == 0 && jj * 16 + bad <= n && flags[0] == 0) flags[0] = jj * 16 + bad;
+      } else if (hidx >= 0 && jj > 0) {
+        // column jj - 1 reaches every block (i, k), jj <= k <= i, but (jj, jj)
+        const int m = nst - jj;
+        for (int t = 1 + hidx; t < m * (m + 1) / 2; t += nh) {
+          int a, b;
+          tr_unblk(t, a, b);
+          const int i = jj + a, k = jj + b;
+          tr_d4 acc = {0.0, 0.0, 0.0, 0.0};
+          tr_mma_nt(acc, S + tr_blk(i, jj - 1), S + tr_blk(k, jj - 1), lane);
+          double* dst = S + tr_blk(i, k);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[(g + 4 * r) * TR_BLD + c] -= acc[r];
+        }
+        // row block s = jj - 1 of the inverse, columns hidx and hidx + nh, kept in registers until row s of L is dead
+        const int s_ = jj - 1;
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {
+          const int j = hidx + q2 * nh;
+          if (j >= s_) continue;
+          tr_d4 T = {0.0, 0.0, 0.0, 0.0};
+          for (int k = j; k < s_; ++k) tr_mma_nn(T, S + tr_blk(s_, k), S + tr_blk(k, j), lane);
+          tr_d4 acc = {0.0, 0.0, 0.0, 0.0};
+          const double* Ws = S + tr_blk(s_, s_);
+#pragma unroll
+          for (int kq = 0; kq < 4; ++kq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[c * TR_BLD + kq * 4 + g], T[kq], acc, 0, 0, 0);
+          Xn[q2] = acc;
+        }
       }
       __syncthreads();
-      if (jj + 1 >= nst) break;
+      TR_PROF(2);
+      if (hidx >= 0 && jj > 0) {
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {
+          const int j = hidx + q2 * nh;
+          if (j < jj - 1) tr_store(S + tr_blk(jj - 1, j), Xn[q2], g, c, -1.0);
+        }
+      }
       // solve: L[i][jj] = S[i][jj] inv(L_jj)^T for the block rows below
       for (int i = jj + 1 + wave; i < nst; i += 8) {
         tr_d4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -301,19 +377,7 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
         tr_store(S + tr_blk(i, jj), acc, g, c, 1.0);
       }
       __syncthreads();
-      // update: S[i][k] -= L[i][jj] L[k][jj]^T for jj < k <= i
-      const int m = nst - 1 - jj;
-      for (int t = wave; t < m * (m + 1) / 2; t += 8) {
-        int a, b;
-        tr_unblk(t, a, b);
-        const int i = jj + 1 + a, k = jj + 1 + b;
-        tr_d4 acc = {0.0, 0.0, 0.0, 0.0};
-        tr_mma_nt(acc, S + tr_blk(i, jj), S + tr_blk(k, jj), lane);
-        double* dst = S + tr_blk(i, k);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dst[(g + 4 * r) * TR_BLD + c] -= acc[r];
-      }
-      __syncthreads();
+      TR_PROF(3);
     }
     if (flags[0] != 0) {       // (uniform: every thread reads the same word behind the barrier)
       failed = flags[0];
@@ -324,10 +388,22 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
       for (int k = step + tid; k < cm.steps; k += TR_T) M.trace[k] = __builtin_nan("");
       break;
     }
-    // ---- L^-1 in place
-    if (nst > 1) tr_inv_level<1>(S, wave, lane);
-    if (nst > 2) tr_inv_level<2>(S, wave, lane);
-    if (nst > 4) tr_inv_level<4>(S, wave, lane);
+    // ---- the last row block of the inverse (s = nst - 1), one column per wave
+    if (nst > 1) {
+      const int s_ = nst - 1, j = wave;
+      tr_d4 X = {0.0, 0.0, 0.0, 0.0};
+      if (j < s_) {
+        tr_d4 T = {0.0, 0.0, 0.0, 0.0};
+        for (int k = j; k < s_; ++k) tr_mma_nn(T, S + tr_blk(s_, k), S + tr_blk(k, j), lane);
+        const double* Ws = S + tr_blk(s_, s_);
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) X = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[c * TR_BLD + kq * 4 + g], T[kq], X, 0, 0, 0);
+      }
+      __syncthreads();
+      if (j < s_) tr_store(S + tr_blk(s_, j), X, g, c, -1.0);
+      __syncthreads();
+    }
+    TR_PROF(5);
 
     // ---- P3: Gamma = W Y, A = W^T Gamma (W = L^-1, lower; four lanes share an output, block columns dealt round robin)
     {
@@ -361,91 +437,90 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
       }
       __syncthreads();
     }
+    TR_PROF(6);
 
     // ---- P5: per lane partial sums -- ss (value), s_amp, tr G, tot[k] (length scales); Sigma^-1 block by block on the matrix cores
-    double ss = 0.0, s_amp = 0.0, trg = 0.0, tk[TR_D];
+    double ss = 0.0, s_amp = 0.0, trg = 0.0, tk[DM];
 #pragma unroll
-    for (int k = 0; k < TR_D; ++k) tk[k] = 0.0;
+    for (int k = 0; k < DM; ++k) tk[k] = 0.0;
     for (int idx = tid; idx < n * d; idx += TR_T) ss = __builtin_fma(Gam[idx], Gam[idx], ss);
     for (int t = wave; t < nblk; t += 8) {
       int bi, bj;
       tr_unblk(t, bi, bj);
+      double evs[4];      // (requested before the block's products: the loads fly under the MFMA chain)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) evs[r] = M.kbuf[(t * 4 + r) * 64 + lane];
       tr_d4 acc = {0.0, 0.0, 0.0, 0.0};
       for (int kb = bi; kb < nst; ++kb) tr_mma_tn(acc, S + tr_blk(kb, bi), S + tr_blk(kb, bj), lane);
       const int j = bj * 16 + c;
+      double xj[DM];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int k = 0; k < DM; ++k) xj[k] = Xs[j * (TR_D + 1) + k];
+#pragma unroll 1
+      for (int r = 0; r < 4; ++r) {      // (one row at a time: four rows' differences in flight at once cost more registers than the chip has)
         const int i = bi * 16 + g + 4 * r;
-        if (i < n && j <= i) {
-          double aa = 0.0;
-          for (int q = 0; q < d; ++q) aa = __builtin_fma(Am[i * d + q], Am[j * d + q], aa);
-          const double gv = 0.5 * (double)d * acc[r] - 0.5 * aa;
-          const double sym = (i == j) ? 1.0 : 2.0;
-          double df[TR_D], sq = 0.0;
+        const double* xi = Xs + i * (TR_D + 1);
+        const double accr = (r == 0) ? acc[0] : (r == 1) ? acc[1] : (r == 2) ? acc[2] : acc[3];
+        const double ev = (r == 0) ? evs[0] : (r == 1) ? evs[1] : (r == 2) ? evs[2] : evs[3];
+        double dsq[DM], sq = 0.0;
 #pragma unroll
-          for (int k = 0; k < TR_D; ++k) {
-            df[k] = (k < D) ? Xs[i * (TR_D + 1) + k] - Xs[j * (TR_D + 1) + k] : 0.0;
-            sq = __builtin_fma(df[k], df[k], sq);
-          }
-          const double s_ = fmax(sq, M.clamp);
-          double ev, m2;
-          if (M.kfun == FFGP_KFUN_SE) {
-            ev = ffgp_exp_fast(-0.5 * s_, ec);
-            m2 = ev;
-          } else {
-            ev = ffgp_kfun_val(M.kfun, M.rinv, s_);
-            m2 = ffgp_kfun_m2d(M.kfun, M.rinv, s_);
-          }
-          s_amp = __builtin_fma(sym * gv, ev, s_amp);
-          if (i == j) trg += gv;
-          const double wl = (sq >= M.clamp) ? sym * gv * amp * m2 : 0.0;
-#pragma unroll
-          for (int k = 0; k < TR_D; ++k) tk[k] = __builtin_fma(wl * df[k], df[k], tk[k]);
+        for (int k = 0; k < DM; ++k) {
+          const double df = xi[k] - xj[k];
+          dsq[k] = df * df;
+          sq += dsq[k];
         }
+        double aa = 0.0;
+        for (int q = 0; q < d; ++q) aa = __builtin_fma(Am[min(i, n - 1) * d + q], Am[min(j, n - 1) * d + q], aa);
+        const bool live = (i < n && j <= i);
+        const double gv = live ? 0.5 * (double)d * accr - 0.5 * aa : 0.0;
+        const double sym = (i == j) ? 1.0 : 2.0;
+        double m2 = ev;
+        if (M.kfun != FFGP_KFUN_SE) m2 = ffgp_kfun_m2d(M.kfun, M.rinv, fmax(sq, M.clamp));
+        s_amp = __builtin_fma(sym * gv, ev, s_amp);
+        if (i == j) trg += gv;
+        const double wl = (sq >= M.clamp) ? sym * gv * amp * m2 : 0.0;
+#pragma unroll
+        for (int k = 0; k < DM; ++k) tk[k] = __builtin_fma(wl, dsq[k], tk[k]);
       }
     }
-    // ---- one workgroup reduction for all of them
+    TR_PROF(7);
+    // ---- one workgroup reduction for all of them (and the log-determinant: one pivot per thread)
     {
-      double vals[TR_NRED];
+      constexpr int NV = 4 + DM;
+      double vals[NV];
       vals[0] = ss; vals[1] = s_amp; vals[2] = trg;
+      vals[3] = (tid < n) ? log(piv[tid]) : 0.0;
 #pragma unroll
-      for (int k = 0; k < TR_D; ++k) vals[3 + k] = tk[k];
-      vals[19] = 0.0;
+      for (int k = 0; k < DM; ++k) vals[4 + k] = tk[k];
 #pragma unroll
-      for (int q = 0; q < 3 + TR_D; ++q) {
-        double x = vals[q];
-        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-        vals[q] = x;
+      for (int q = 0; q < NV; ++q) {
+        vals[q] = tr_wsum(vals[q]);
       }
       if (lane == 0) {
 #pragma unroll
-        for (int q = 0; q < 3 + TR_D; ++q) red[wave * TR_NRED + q] = vals[q];
+        for (int q = 0; q < NV; ++q) red[wave * TR_NRED + q] = vals[q];
       }
       __syncthreads();
-      if (tid < 3 + TR_D) {
+      if (tid < NV) {
         double x = 0.0;
 #pragma unroll
         for (int wv_ = 0; wv_ < 8; ++wv_) x += red[wv_ * TR_NRED + tid];
         tot[tid] = x;
       }
-      if (tid == 64) {
-        double ld = 0.0;
-        for (int i = 0; i < n; ++i) ld += log(piv[i]);
-        sc[2] = 0.5 * ld;                                   // sum_i log L_ii
-      }
       __syncthreads();
     }
+    TR_PROF(8);
     // ---- P6: the loss of this step (before the update), the raw gradients through the links, Adam
     if (tid == 0)
-      M.trace[step] = oscale * (0.5 * tot[0] + (double)d * sc[2] + 0.5 * (double)n * (double)d * log(2.0 * M.pi_const));
+      M.trace[step] = oscale * (0.5 * tot[0] + (double)d * 0.5 * tot[3] + 0.5 * (double)n * (double)d * log(2.0 * M.pi_const));
     if (tid < npar) {
       double gr;
       if (tid < nw) {
         if (!M.l.w_broadcast) {
-          gr = oscale * (-tot[3 + tid] / wv[tid]) * tr_link_der(M.l.w_link, raw[tid], M.l.w_c);
+          gr = oscale * (-tot[4 + tid] / wv[tid]) * tr_link_der(M.l.w_link, raw[tid], M.l.w_c);
         } else {
           double sg = 0.0;
-          for (int k = 0; k < D; ++k) sg += -tot[3 + k] / wv[k];
+          for (int k = 0; k < D; ++k) sg += -tot[4 + k] / wv[k];
           gr = oscale * sg * tr_link_der(M.l.w_link, raw[0], M.l.w_c);
         }
       } else if (tid == nw) {
@@ -459,9 +534,24 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
       mom[tid] = m1;
       mo2[tid] = v1;
       const double denom = sqrt(v1) / bc2s + cm.eps;
-      raw[tid] = raw[tid] + (-(cm.lr / bc1)) * (m1 / denom);                  // param.addcdiv_(exp_avg, denom, value = -step_size)
+      const double pnew = raw[tid] + (-(cm.lr / bc1)) * (m1 / denom);         // param.addcdiv_(exp_avg, denom, value = -step_size)
+      raw[tid] = pnew;
+      // the next step's effective value (nobody reads wv / sc between the reduction's barrier and the one below)
+      if (tid < nw) {
+        if (!M.l.w_broadcast) {
+          wv[tid] = tr_link_val(M.l.w_link, pnew, M.l.w_c);
+        } else {
+          const double e_ = tr_link_val(M.l.w_link, pnew, M.l.w_c);
+          for (int k = 0; k < D; ++k) wv[k] = e_;
+        }
+      } else if (tid == nw) {
+        sc[0] = tr_link_val(M.l.amp_link, pnew, M.l.amp_c);
+      } else {
+        sc[1] = tr_link_val(M.l.dadd_link, pnew, M.l.dadd_c);
+      }
     }
     __syncthreads();
+    TR_PROF(9);
   }
   // ---- parameters and moments back to the caller's tensors (a failed step left them as they were when it began)
   if (tid < npar) {
@@ -491,30 +581,40 @@ int ffgp_train_persist(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_
                        long state_stride, long step0, double* trace_dev, long trace_stride) {
   static bool attr_set[64] = {false};
   if (h->device >= 0 && h->device < 64 && !attr_set[h->device]) {
-    FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_train_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_train_persist_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 TR_LDS_DOUBLES * (int)sizeof(double)));
+    FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_train_persist_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  TR_LDS_DOUBLES * (int)sizeof(double)));
     attr_set[h->device] = true;
   }
-  // one device block: [F models | 2 steps bias corrections | 2 F status ints]
+  // one device block: [F models | 2 steps bias corrections | 2 F status ints | F x 36 x 256 kernel values]; its first three parts are
+  // staged in pinned host memory owned by the handle (an asynchronous copy from a temporary would have to be waited for)
   const size_t tab_bytes = (size_t)F * sizeof(TrainModel);
   const size_t bc_off = (tab_bytes + 255) / 256 * 256;
   const size_t info_off = bc_off + ((size_t)2 * steps * sizeof(double) + 255) / 256 * 256;
-  const size_t need = info_off + (size_t)2 * F * sizeof(int);
+  const size_t head = info_off + (size_t)2 * F * sizeof(int);
+  const size_t k_off = (head + 255) / 256 * 256;
+  const size_t need = k_off + (size_t)F * TR_NBLK * 256 * sizeof(double);
   if (need > h->train_tab_bytes) {
-    if (h->train_tab) {
-      FFGP_HIP(hipStreamSynchronize(h->stream));
-      hipFree(h->train_tab);
-      h->train_tab = nullptr;
-      h->train_tab_bytes = 0;
-    }
-    if (hipMalloc(&h->train_tab, need + need / 2) != hipSuccess) {
+    FFGP_HIP(hipStreamSynchronize(h->stream));
+    if (h->train_tab) hipFree(h->train_tab);
+    if (h->train_host) hipHostFree(h->train_host);
+    h->train_tab = nullptr;
+    h->train_host = nullptr;
+    h->train_tab_bytes = 0;
+    const size_t cap = need + need / 2;
+    if (hipMalloc(&h->train_tab, cap) != hipSuccess || hipHostMalloc(&h->train_host, cap, hipHostMallocDefault) != hipSuccess) {
       (void)hipGetLastError();
+      if (h->train_tab) hipFree(h->train_tab);
+      h->train_tab = nullptr;
       return FFGP_ERR_ALLOC;
     }
-    h->train_tab_bytes = need + need / 2;
+    h->train_tab_bytes = cap;
   }
-  std::vector<char> host(info_off + (size_t)2 * F * sizeof(int), 0);
-  TrainModel* tm = reinterpret_cast<TrainModel*>(host.data());
+  char* host = reinterpret_cast<char*>(h->train_host);      // (the previous call on this handle was synchronous: the buffer is free)
+  memset(host, 0, head);
+  char* dev = reinterpret_cast<char*>(h->train_tab);
+  TrainModel* tm = reinterpret_cast<TrainModel*>(host);
   for (int f = 0; f < F; ++f) {
     const ffgp_problem& q = p[f];
     TrainModel& m = tm[f];
@@ -526,28 +626,52 @@ int ffgp_train_persist(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_
     m.clamp = q.clamp_min; m.rinv = (q.kparam != 0.0) ? 1.0 / q.kparam : 1.0; m.pi_const = q.pi_const; m.kfun = q.kfun;
     m.state = state_dev + (size_t)f * state_stride;
     m.trace = trace_dev + (size_t)f * trace_stride;
+    m.kbuf = reinterpret_cast<double*>(dev + k_off) + (size_t)f * TR_NBLK * 256;
   }
-  double* bc = reinterpret_cast<double*>(host.data() + bc_off);
+  double* bc = reinterpret_cast<double*>(host + bc_off);
   for (int k = 0; k < steps; ++k) {
     const double t = (double)(step0 + k + 1);
     bc[2 * k] = 1.0 - std::pow(opt->beta1, t);
     bc[2 * k + 1] = std::sqrt(1.0 - std::pow(opt->beta2, t));
   }
-  char* dev = reinterpret_cast<char*>(h->train_tab);
-  FFGP_HIP(hipMemcpyAsync(dev, host.data(), host.size(), hipMemcpyHostToDevice, h->stream));
-  FFGP_HIP(hipStreamSynchronize(h->stream));       // (the staging vector goes out of scope; a pageable copy may still be reading it)
+  FFGP_HIP(hipMemcpyAsync(dev, host, head, hipMemcpyHostToDevice, h->stream));
   TrainCommon cm;
   cm.steps = steps; cm.lr = opt->lr; cm.b1 = opt->beta1; cm.b2 = opt->beta2; cm.eps = opt->eps;
   cm.bc = reinterpret_cast<const double*>(dev + bc_off);
   cm.info = reinterpret_cast<int*>(dev + info_off);
   cm.fail_step = cm.info + F;
-  hipLaunchKernelGGL(ffgp_train_persist_kernel, dim3(F), dim3(TR_T), TR_LDS_DOUBLES * sizeof(double), h->stream,
-                     reinterpret_cast<const TrainModel*>(dev), cm);
+  cm.prof = nullptr;
+  static const bool trace_on = getenv("FFGP_TRAIN_TRACE") && atoi(getenv("FFGP_TRAIN_TRACE")) != 0;
+  if (trace_on) {
+    FFGP_HIP(hipMalloc(&cm.prof, 12 * sizeof(long)));
+    FFGP_HIP(hipMemset(cm.prof, 0, 12 * sizeof(long)));
+  }
+  int Dmax = 0;
+  for (int f = 0; f < F; ++f) Dmax = std::max(Dmax, p[f].D);
+  if (Dmax <= 8)
+    hipLaunchKernelGGL(ffgp_train_persist_kernel<8>, dim3(F), dim3(TR_T), TR_LDS_DOUBLES * sizeof(double), h->stream,
+                       reinterpret_cast<const TrainModel*>(dev), cm);
+  else
+    hipLaunchKernelGGL(ffgp_train_persist_kernel<16>, dim3(F), dim3(TR_T), TR_LDS_DOUBLES * sizeof(double), h->stream,
+                       reinterpret_cast<const TrainModel*>(dev), cm);
   if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
-  std::vector<int> st(2 * F);
-  FFGP_HIP(hipMemcpyAsync(st.data(), cm.info, (size_t)2 * F * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  int* st = reinterpret_cast<int*>(host + info_off);
+  FFGP_HIP(hipMemcpyAsync(st, cm.info, (size_t)2 * F * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   FFGP_HIP(hipStreamSynchronize(h->stream));
   ffgp_invalidate(h);
+  if (cm.prof) {
+    long pr[12];
+    hipMemcpy(pr, cm.prof, sizeof(pr), hipMemcpyDeviceToHost);
+    hipFree(cm.prof);
+    static const char* const nm[10] = {"links+Xs", "assemble", "F(jj)", "solve", "update", "inverse", "Gamma/A", "Sigma^-1+grad", "reduce", "adam"};
+    fprintf(stderr, "[ffgp] train_persist n=%d D=%d d=%d steps=%d, us per step:", p[0].n, p[0].D, p[0].d, steps);
+    double tot = 0.0;
+    for (int k = 0; k < 10; ++k) {
+      fprintf(stderr, " %s %.2f", nm[k], pr[k] * 0.01 / steps);
+      tot += pr[k] * 0.01 / steps;
+    }
+    fprintf(stderr, " | sum %.2f\n", tot);
+  }
   for (int f = 0; f < F; ++f)
     if (st[f] != 0) return st[f];
   return FFGP_OK;
