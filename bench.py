@@ -721,6 +721,29 @@ def run_rank(args):
             del b_step
             torch.cuda.empty_cache()
 
+    # ---- the reference's training loop at the sizes its experiments run: K Adam steps per library call, small models in ONE launch ----
+    train_small = {}
+    if args.workload == "headline" and not args.no_sharded and not args.with_grad and stock and not args.dry:
+        from fidelityfusion_amd import kernel as K_
+        from fidelityfusion_amd.cigp_v10 import cigp, train_many
+        for key, (tn, tD, td, tFm) in (("n128", (128, 5, 1, 1)), ("n32", (32, 5, 1, 1)), ("n64_x16", (64, 5, 1, 16))):
+            ms_, xs_, ys_ = [], [], []
+            for f in range(tFm):
+                X, Y = synthetic_xy(tn, tD, td, seed=f)
+                ms_.append(cigp(K_.ARDKernel(tD), 1.0).double().to(dev))
+                xs_.append(torch.tensor(X, dtype=torch.float64, device=dev))
+                ys_.append(torch.tensor(Y, dtype=torch.float64, device=dev))
+            train_many(ms_, xs_, ys_, 5)
+            fence()
+            t0 = time.perf_counter()
+            tr_, _ = train_many(ms_, xs_, ys_, 200)
+            fence()
+            tdt = time.perf_counter() - t0
+            train_small[key] = {"N": tn, "D": tD, "d": td, "models": tFm, "steps": 200, "ms_per_call": round(tdt * 1e3, 3),
+                                "us_per_model_step": round(tdt * 1e6 / 200 / tFm, 2), "final_loss": float(tr_[0, -1]),
+                                "what": "cigp_v10.train_many -> ffgp_train_raw: 200 iterations of zero_grad / loss = -negative_log_likelihood / "
+                                        "backward / Adam step (FidelityFusion_Models/ResGP.py:78-112) as ONE call, wall clock around the call"}
+
     if not args.dry and not args.no_cpu_baseline and world == 1 and stock and args.workload in ("headline", "c2"):
         # after every timed leg: the GPU side of the parity columns, and the vendor factorisation as a stated side number
         gpu_ref = gpu_parity_values(dev, ("c2", "headline") if args.workload == "headline" else ("c2",))
@@ -785,6 +808,8 @@ def run_rank(args):
             out["train_step"] = train_step
         if blocks_leg:
             out["blocks"] = blocks_leg
+        if train_small:
+            out["train_small"] = train_small
         if vendor is not None:
             out["vendor_potrf_ms"] = dict(vendor, note="torch.linalg.cholesky on this GPU (the reference's own .cuda() path, MFGP_ver2023May/"
                                           "mfgp_demo.py:88-94) vs ffgp_potrf on the same matrix; outside the timed region, never on the product path")

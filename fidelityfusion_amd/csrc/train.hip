@@ -52,6 +52,10 @@ struct TrainCommon {
   int* fail_step;                        // [models] the step at which it happened
   long* prof;                            // development (FFGP_TRAIN_TRACE=1): [12] wall_clock64 ticks per phase, summed over model 0's steps
 };
+// workgroup barrier that publishes LDS only: __syncthreads() also drains the wave's GLOBAL stores (the kernel values parked for the
+// gradient pass, the trace), whose round trip to L2 would be exposed at every barrier behind them.  Nothing inside the step loop is
+// handed from thread to thread through global memory.
+#define TR_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define TR_PROF(k)                                                   \
   do {                                                               \
     if (cm.prof && tid == 0 && blockIdx.x == 0) {                    \
@@ -118,6 +122,10 @@ __device__ __forceinline__ void tr_unblk(int t, int& bi, int& bj) {
   for (int q = 1; q < 8; ++q) bi += (t >= q * (q + 1) / 2) ? 1 : 0;
   bj = t - bi * (bi + 1) / 2;
 }
+// block dealt to `wave` in round q of the assembly / the Sigma^-1 pass: the row-major enumeration has the expensive blocks of the Sigma^-1
+// pass first (block (bi, bj) costs nst - bi products), so the rounds run forwards and backwards in turn -- 16 products for the busiest
+// wave at n = 128 instead of 19.  Both passes MUST deal alike: the kernel values travel from one to the other by (block, lane) slot.
+__device__ __forceinline__ int tr_deal(int q, int wave) { return 8 * q + ((q & 1) ? 7 - wave : wave); }
 __device__ __forceinline__ double tr_rsqrt(double d) {
   double y = __builtin_amdgcn_rsq(d);
 #pragma unroll
@@ -149,6 +157,45 @@ __device__ __forceinline__ void tr_mma_tn(tr_d4& acc, const double* pa, const do
   for (int kq = 0; kq < 4; ++kq) {
     const int k = kq * 4 + (lane >> 4);
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k * TR_BLD + (lane & 15)], pb[k * TR_BLD + (lane & 15)], acc, 0, 0, 0);
+  }
+}
+// acc += sum_{kb = k0}^{k1 - 1} op(P_kb) * Q_kb over 16 x 16 blocks, the NEXT block's operands requested before this block's four MFMAs
+// (a runtime loop of load-then-multiply rounds waits one LDS round trip per block).  P_kb at baseA + offA(kb): element (m, k) at
+// [m * lda + k], or (TA) the transposed block: (m, k) at [k * lda + m]; Q_kb at baseB + offB(kb): element (k, n) at [k * ldb + n].
+template <bool TA, class OA, class OB>
+__device__ __forceinline__ void tr_chain(tr_d4& acc, int k0, int k1, const double* baseA, OA offA, int lda, const double* baseB, OB offB,
+                                         int ldb, int lane) {
+  if (k0 >= k1) return;
+  const int m = lane & 15, g = lane >> 4;
+  double a[4], b[4];
+  {
+    const double* pa = baseA + offA(k0);
+    const double* pb = baseB + offB(k0);
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+      const int k = kq * 4 + g;
+      a[kq] = TA ? pa[k * lda + m] : pa[m * lda + k];
+      b[kq] = pb[k * ldb + m];
+    }
+  }
+  for (int kb = k0; kb < k1; ++kb) {
+    double an[4], bn[4];
+    const int kn = min(kb + 1, k1 - 1);      // (the last round re-reads its own block)
+    const double* pa = baseA + offA(kn);
+    const double* pb = baseB + offB(kn);
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+      const int k = kq * 4 + g;
+      an[kq] = TA ? pa[k * lda + m] : pa[m * lda + k];
+      bn[kq] = pb[k * ldb + m];
+    }
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kq], b[kq], acc, 0, 0, 0);
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+      a[kq] = an[kq];
+      b[kq] = bn[kq];
+    }
   }
 }
 // accumulator (lane (g, c), register r = entry (g + 4 r, c)) -> the block's [16][17] home
@@ -198,7 +245,13 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
   ffgp_exp_load(ec);
 
   // ---- once: targets, the diagonal extra, parameters and moments into LDS; identity padding of the blocks the factorisation never touches
-  for (int idx = tid; idx < n * d; idx += TR_T) Ym[idx] = M.Y[idx];
+  // targets, Gamma and A live as [128][16] images, zero beyond (n, d): the matrix-core products read them without guards
+  for (int idx = tid; idx < TR_N * TR_Y; idx += TR_T) {
+    const int i = idx >> 4, q = idx & 15;
+    Ym[idx] = (i < n && q < d) ? M.Y[i * d + q] : 0.0;
+    Gam[idx] = 0.0;
+    Am[idx] = 0.0;
+  }
   for (int idx = tid; idx < TR_N * (TR_D + 1); idx += TR_T) Xs[idx] = 0.0;      // (columns >= D and rows >= n stay zero: the unrolled loops read them)
   for (int i = tid; i < TR_N; i += TR_T) dvec[i] = (M.diag_vec && i < n) ? M.diag_vec[(size_t)i * M.diag_stride] : 0.0;
   if (tid < npar) {
@@ -245,13 +298,15 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
       const int i = idx / D, k = idx - i * D;
       Xs[i * (TR_D + 1) + k] = M.X[idx] * wv[k];
     }
-    __syncthreads();
+    TR_BARRIER();
     const double amp = sc[0], dadd = sc[1];
     TR_PROF(0);
 
     // ---- P1: Sigma, lower block triangle (diagonal blocks symmetric-full: the in-register factor wants both halves); rows / columns
     //      beyond n are identity
-    for (int t = wave; t < nblk; t += 8) {
+    for (int q_ = 0; q_ < 5; ++q_) {
+      const int t = tr_deal(q_, wave);
+      if (t >= nblk) continue;
       int bi, bj;
       tr_unblk(t, bi, bj);
       double* dst = S + tr_blk(bi, bj);
@@ -281,7 +336,7 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
         dst[(g + 4 * r) * TR_BLD + c] = kv;
       }
     }
-    __syncthreads();
+    TR_BARRIER();
     TR_PROF(1);
 
     // ---- P2: blocked Cholesky over 16-column stages AND the inverse, two barriers per stage.
@@ -294,18 +349,14 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
       tr_d4 Xn[2];
       if (wave == 0) {
         double* Dj = S + tr_blk(jj, jj);
-        if (jj > 0) {      // the one update still missing from this block
-          tr_d4 acc = {0.0, 0.0, 0.0, 0.0};
-          tr_mma_nt(acc, S + tr_blk(jj, jj - 1), S + tr_blk(jj, jj - 1), lane);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) Dj[(g + 4 * r) * TR_BLD + c] -= acc[r];
-        }
+        tr_d4 upd = {0.0, 0.0, 0.0, 0.0};      // the one update still missing from this block: applied on the way into the registers
+        if (jj > 0) tr_mma_nt(upd, S + tr_blk(jj, jj - 1), S + tr_blk(jj, jj - 1), lane);
         int cc = c, gg = g;
         asm volatile("" : "+v"(cc), "+v"(gg));      // (opaque per iteration: the stage loop must not be specialised per jj)
         double v[4], w[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          v[r] = Dj[(gg + 4 * r) * TR_BLD + cc];
+          v[r] = Dj[(gg + 4 * r) * TR_BLD + cc] - upd[r];
           w[r] = (gg + 4 * r == cc) ? 1.0 : 0.0;
         }
         double rowA = bperm_d(v[0], cc);
@@ -353,7 +404,7 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
           const int j = hidx + q2 * nh;
           if (j >= s_) continue;
           tr_d4 T = {0.0, 0.0, 0.0, 0.0};
-          for (int k = j; k < s_; ++k) tr_mma_nn(T, S + tr_blk(s_, k), S + tr_blk(k, j), lane);
+          tr_chain<false>(T, j, s_, S + tr_blk(s_, 0), [](int k) { return k * TR_BLK; }, TR_BLD, S, [j](int k) { return tr_blk(k, j); }, TR_BLD, lane);
           tr_d4 acc = {0.0, 0.0, 0.0, 0.0};
           const double* Ws = S + tr_blk(s_, s_);
 #pragma unroll
@@ -361,7 +412,7 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
           Xn[q2] = acc;
         }
       }
-      __syncthreads();
+      TR_BARRIER();
       TR_PROF(2);
       if (hidx >= 0 && jj > 0) {
 #pragma unroll
@@ -376,7 +427,7 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
         tr_mma_nt(acc, S + tr_blk(i, jj), S + tr_blk(jj, jj), lane);
         tr_store(S + tr_blk(i, jj), acc, g, c, 1.0);
       }
-      __syncthreads();
+      TR_BARRIER();
       TR_PROF(3);
     }
     if (flags[0] != 0) {       // (uniform: every thread reads the same word behind the barrier)
@@ -394,64 +445,57 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
       tr_d4 X = {0.0, 0.0, 0.0, 0.0};
       if (j < s_) {
         tr_d4 T = {0.0, 0.0, 0.0, 0.0};
-        for (int k = j; k < s_; ++k) tr_mma_nn(T, S + tr_blk(s_, k), S + tr_blk(k, j), lane);
+        tr_chain<false>(T, j, s_, S + tr_blk(s_, 0), [](int k) { return k * TR_BLK; }, TR_BLD, S, [j](int k) { return tr_blk(k, j); }, TR_BLD, lane);
         const double* Ws = S + tr_blk(s_, s_);
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq) X = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[c * TR_BLD + kq * 4 + g], T[kq], X, 0, 0, 0);
       }
-      __syncthreads();
+      TR_BARRIER();
       if (j < s_) tr_store(S + tr_blk(s_, j), X, g, c, -1.0);
-      __syncthreads();
+      TR_BARRIER();
     }
     TR_PROF(5);
 
-    // ---- P3: Gamma = W Y, A = W^T Gamma (W = L^-1, lower; four lanes share an output, block columns dealt round robin)
+    // ---- P3: Gamma = W Y, A = W^T Gamma on the matrix cores (W = L^-1, lower; the d <= 16 target columns are one block column): wave w
+    //      owns block row w of Gamma (w + 1 products) and block row 7 - w of A (w + 1 products)
     {
-      const int q4 = tid & 3;
-      for (int it = tid >> 2; it < n * d; it += TR_T / 4) {
-        const int i = it / d, cc2 = it - i * d;
-        const int bi = i >> 4;
-        double s = 0.0;
-        for (int kb = q4; kb <= bi; kb += 4) {
-          const double* wr = S + tr_blk(bi, kb) + (i & 15) * TR_BLD;
+      if (wave < nst) {
+        const int bi = wave;
+        tr_d4 acc = {0.0, 0.0, 0.0, 0.0};
+        tr_chain<false>(acc, 0, bi + 1, S + tr_blk(bi, 0), [](int kb) { return kb * TR_BLK; }, TR_BLD, Ym, [](int kb) { return kb * 16 * TR_Y; },
+                        TR_Y, lane);
 #pragma unroll
-          for (int k = 0; k < 16; ++k) s = __builtin_fma(wr[k], (kb * 16 + k < n) ? Ym[(kb * 16 + k) * d + cc2] : 0.0, s);
-        }
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        if (q4 == 0) Gam[it] = s;
+        for (int r = 0; r < 4; ++r) Gam[(bi * 16 + g + 4 * r) * TR_Y + c] = acc[r];
       }
-      __syncthreads();
-      for (int it = tid >> 2; it < n * d; it += TR_T / 4) {
-        const int i = it / d, cc2 = it - i * d;
-        const int bi = i >> 4;
-        double s = 0.0;
-        for (int kb = bi + q4; kb < nst; kb += 4) {
-          const double* wc = S + tr_blk(kb, bi) + (i & 15);
+      TR_BARRIER();
+      if (7 - wave < nst) {
+        const int bi = 7 - wave;
+        tr_d4 acc = {0.0, 0.0, 0.0, 0.0};
+        tr_chain<true>(acc, bi, nst, S, [bi](int kb) { return tr_blk(kb, bi); }, TR_BLD, Gam, [](int kb) { return kb * 16 * TR_Y; }, TR_Y, lane);
 #pragma unroll
-          for (int k = 0; k < 16; ++k) s = __builtin_fma(wc[k * TR_BLD], (kb * 16 + k < n) ? Gam[(kb * 16 + k) * d + cc2] : 0.0, s);
-        }
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        if (q4 == 0) Am[it] = s;
+        for (int r = 0; r < 4; ++r) Am[(bi * 16 + g + 4 * r) * TR_Y + c] = acc[r];
       }
-      __syncthreads();
+      TR_BARRIER();
     }
     TR_PROF(6);
 
     // ---- P5: per lane partial sums -- ss (value), s_amp, tr G, tot[k] (length scales); Sigma^-1 block by block on the matrix cores
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this lane's parked kernel values have landed (long ago)
     double ss = 0.0, s_amp = 0.0, trg = 0.0, tk[DM];
 #pragma unroll
     for (int k = 0; k < DM; ++k) tk[k] = 0.0;
-    for (int idx = tid; idx < n * d; idx += TR_T) ss = __builtin_fma(Gam[idx], Gam[idx], ss);
-    for (int t = wave; t < nblk; t += 8) {
+#pragma unroll
+    for (int q = 0; q < TR_N * TR_Y / TR_T; ++q) ss = __builtin_fma(Gam[tid + TR_T * q], Gam[tid + TR_T * q], ss);
+    for (int q_ = 0; q_ < 5; ++q_) {
+      const int t = tr_deal(q_, wave);
+      if (t >= nblk) continue;
       int bi, bj;
       tr_unblk(t, bi, bj);
-      double evs[4];      // (requested before the block's products: the loads fly under the MFMA chain)
+      double evs[4];      // (requested before the block's products: the loads fly under the MFMA chain; written by this very lane)
 #pragma unroll
       for (int r = 0; r < 4; ++r) evs[r] = M.kbuf[(t * 4 + r) * 64 + lane];
       tr_d4 acc = {0.0, 0.0, 0.0, 0.0};
-      for (int kb = bi; kb < nst; ++kb) tr_mma_tn(acc, S + tr_blk(kb, bi), S + tr_blk(kb, bj), lane);
+      tr_chain<true>(acc, bi, nst, S, [bi](int kb) { return tr_blk(kb, bi); }, TR_BLD, S, [bj](int kb) { return tr_blk(kb, bj); }, TR_BLD, lane);
       const int j = bj * 16 + c;
       double xj[DM];
 #pragma unroll
@@ -470,7 +514,7 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
           sq += dsq[k];
         }
         double aa = 0.0;
-        for (int q = 0; q < d; ++q) aa = __builtin_fma(Am[min(i, n - 1) * d + q], Am[min(j, n - 1) * d + q], aa);
+        for (int q = 0; q < d; ++q) aa = __builtin_fma(Am[i * TR_Y + q], Am[j * TR_Y + q], aa);
         const bool live = (i < n && j <= i);
         const double gv = live ? 0.5 * (double)d * accr - 0.5 * aa : 0.0;
         const double sym = (i == j) ? 1.0 : 2.0;
@@ -500,14 +544,14 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
 #pragma unroll
         for (int q = 0; q < NV; ++q) red[wave * TR_NRED + q] = vals[q];
       }
-      __syncthreads();
+      TR_BARRIER();
       if (tid < NV) {
         double x = 0.0;
 #pragma unroll
         for (int wv_ = 0; wv_ < 8; ++wv_) x += red[wv_ * TR_NRED + tid];
         tot[tid] = x;
       }
-      __syncthreads();
+      TR_BARRIER();
     }
     TR_PROF(8);
     // ---- P6: the loss of this step (before the update), the raw gradients through the links, Adam
@@ -550,7 +594,7 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
         sc[1] = tr_link_val(M.l.dadd_link, pnew, M.l.dadd_c);
       }
     }
-    __syncthreads();
+    TR_BARRIER();
     TR_PROF(9);
   }
   // ---- parameters and moments back to the caller's tensors (a failed step left them as they were when it began)

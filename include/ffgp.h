@@ -262,6 +262,8 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
                         behaviour, not a contract: every XCD-local launch is followed by a chip-wide launch that chases whatever sweeps
                         the first did not hand out -- none on a full MI355X; all of them when no wave landed on the chosen XCD, as in a
                         partition mode or on a CU-masked stream),
+            "train_persist" (default 1: ffgp_train_raw runs sets of small models -- n <= 128, D, d <= 16 -- as ONE persistent kernel launch,
+                        see ffgp_train_raw; 0 = one launch per stage and step, the round-5 form),
             "chase_xcc" (0..15; default: handles of one process take XCDs 0..7 in turn -- the XCD whose wavefronts run the XCD-local
                         chase; a value no wave of the launch reports leaves the whole chase to the chip-wide launch behind it: a test mode),
             "batch_grad_ob" (default 1: the shared chain's gradient stage inverts all blocks in one outer-batched sequence of launches),
@@ -514,7 +516,14 @@ int ffgp_nlml_fused_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ff
    scalar length scale, else D; order: w, amp, diag_add), zero for a fresh optimiser and carried between calls together with step0 =
    the number of steps already taken; trace_dev[f * trace_stride + k] = loss of model f at step k, evaluated BEFORE that step's
    update (what the reference prints).  Returns 0, or the pivot status of the first step whose Sigma was not positive definite
-   (torch.linalg.LinAlgError in the reference's loop): from that step on no parameter moves and the trace holds NaN.  Synchronous. */
+   (torch.linalg.LinAlgError in the reference's loop): from that step on no parameter moves and the trace holds NaN.  Synchronous.
+   ONE LAUNCH FOR THE WHOLE LOOP (round 6, csrc/train.hip): when every model has n <= 128, D <= 16, d <= 16, the V1 likelihood and no
+   Sigma extra but diag_add / diag_vec -- what the reference's experiments run (Experiments/GAR_Aligned/exp_aligned.py:66-74: 100 low-
+   against 4..32 high-fidelity points) -- the call is one kernel launch: a persistent workgroup per model keeps Sigma, its factor, the
+   inverse, the parameters and the Adam moments in LDS and runs all `steps` iterations inside the kernel (option "train_persist" = 0
+   restores the launch-per-stage loop).  There a failing model stops alone -- its trace holds NaN from its failing step on, its
+   parameters are those it had when that step began -- while the other models of the call complete their steps; the return value is
+   the first failing model's pivot status.  200 steps at n = 128: 9.7 ms (19.2 ms launch by launch); n = 32: 16 us per step. */
 typedef struct ffgp_adam {
   double lr, beta1, beta2, eps;
 } ffgp_adam;
