@@ -25,8 +25,10 @@ FFGP_VAR_FULL, FFGP_VAR_DIAG = 0, 1
 FFGP_KFUN_SE, FFGP_KFUN_MATERN12, FFGP_KFUN_MATERN32, FFGP_KFUN_MATERN52, FFGP_KFUN_RQ = 0, 1, 2, 3, 4
 PI_TRUNC = 3.1415  # GaussianProcess/cigp_v10.py:15 ; gp_computation_pack.py:17 ; MFGP_ver2023May/base_gp/cigp.py:6
 
-ERRORS = {-1: "FFGP_ERR_ARG", -2: "FFGP_ERR_HIP", -3: "FFGP_ERR_ALLOC", -4: "FFGP_ERR_NODEVICE"}
-FFGP_ERR_ARG, FFGP_ERR_HIP, FFGP_ERR_ALLOC, FFGP_ERR_NODEVICE = -1, -2, -3, -4
+ERRORS = {-1: "FFGP_ERR_ARG", -2: "FFGP_ERR_HIP", -3: "FFGP_ERR_ALLOC", -4: "FFGP_ERR_NODEVICE",
+          -5: "FFGP_ERR_HANDOFF (a cross-stream hand-off of the look-ahead never arrived: a tool that serialises this process's kernels? "
+              "FFGP_HANDOFF=events keeps the event pairs)"}
+FFGP_ERR_ARG, FFGP_ERR_HIP, FFGP_ERR_ALLOC, FFGP_ERR_NODEVICE, FFGP_ERR_HANDOFF = -1, -2, -3, -4, -5
 
 _dp = C.c_void_p  # device pointers travel as void*
 

@@ -191,6 +191,14 @@ static int create_resources(ffgp_handle* h) {
       h->ho_values = 0;
     }
   }
+  if (h->ho_values && h->own) {      // ... and a wait enqueued BEFORE its producer on another stream must come through (potrf.hip)
+    const int st = ffgp_handoff_selftest(h);
+    if (st != 0) {
+      if (st < 0) (void)hipGetLastError();
+      h->ho_values = 0;
+      h->ho_selftest_failed = 1;
+    }
+  }
   FFGP_HIP(hipMalloc(&h->d_scal, SCAL_DOUBLES * sizeof(double)));
   FFGP_HIP(hipHostMalloc(&h->h_info, 16 * sizeof(int)));
   memset(h->h_info, 0, 16 * sizeof(int));
@@ -300,6 +308,8 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->polite32_pad_kb = 46;
   h->ho_values = default_ho_values();
   h->ho_defer = 2;
+  h->ho_gate = 1;
+  h->ho_timeout_ms = 2000;
   h->ho_defer_slot = -1;
   h->ho_gdefer_slot = -1;
   h->diag_excl_rows = 4096;
@@ -448,7 +458,15 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "fwd_graph")) {
     h->fwd_graph = value != 0.0;
   } else if (!strcmp(key, "ho_values")) {
+    if (value != 0.0 && h->ho_selftest_failed) return FFGP_ERR_ARG;      // (this process runs its kernels one at a time: see ffgp_handoff_selftest)
     h->ho_values = value != 0.0;
+  } else if (!strcmp(key, "ho_gate")) {
+    h->ho_gate = value != 0.0;
+  } else if (!strcmp(key, "ho_timeout_ms")) {
+    if (value < 1.0 || value > 600000.0) return FFGP_ERR_ARG;
+    h->ho_timeout_ms = (int)value;
+  } else if (!strcmp(key, "ho_withhold")) {
+    h->ho_withhold = (int)value;
   } else if (!strcmp(key, "diag_excl_rows")) {
     h->diag_excl_rows = (int)value;
   } else if (!strcmp(key, "ho_defer")) {

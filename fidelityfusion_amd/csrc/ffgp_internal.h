@@ -154,8 +154,15 @@ struct ffgp_handle {
   hipEvent_t la_ev[10]; // look-ahead hand-off events ([7], [8]: carry mode's "strip Z(k) has run", main -> side stream)
   unsigned* ho_mem;     // one word (64 bytes apart) per look-ahead event: the hand-off as hipStreamWriteValue32 / hipStreamWaitValue32 (potrf.hip)
   unsigned ho_seq[10];  // ... the number its latest "record" wrote
+  unsigned ho_launched[10];   // ... the newest number whose producing operation has been ENQUEUED (submission-order rule, la_wait)
+  long ho_order_violations;   // waits enqueued before their producers (must stay 0)
+  int ho_gate;          // option "ho_gate" (default 1): waits are the library's own gate kernel with a watchdog; 0 = hipStreamWaitValue32
+  int ho_timeout_ms;    // option "ho_timeout_ms" (default 2000): the gate gives up after this long (FFGP_ERR_HANDOFF)
+  int* ho_info;         // the status word a gate that gives up writes to (set by the factorisation entry points)
+  int ho_withhold;      // test hook, option "ho_withhold" = k: the k-th publication from now on is never written
   int ho_values;        // option "ho_values" (default 1): value hand-offs; 0 = the event pairs
   int ho_active;        // set per factorisation (la_begin): value hand-offs in use (not while a stream is being captured)
+  int ho_selftest_failed;   // the cross-stream self-test timed out (serialised dispatches): value hand-offs stay off for this handle
   int ho_selftest_pending;  // create_resources tries the stream value operations once; a runtime without them keeps the event pairs
   int ho_defer;         // option "ho_defer" (default 1): the chain's "panel complete" word is written by the next diagonal-block kernel
   int diag_excl_rows;   // option "diag_excl_rows" (default 4096): carry iterations with at most this many trailing rows launch the panel's first diagonal block
@@ -356,6 +363,7 @@ struct ffgp_rag_block {
 };
 extern "C" int ffgp_ensure_aux2(ffgp_handle* h);
 int ffgp_potrf_ragged(ffgp_handle* h, int R, const ffgp_rag_block* mem);
+int ffgp_handoff_selftest(ffgp_handle* h);      // 0: a gate on one stream sees a value written from another; 1: it timed out; < 0: error
 // ragged form of the chain's K-major products: R members of one kind with their own sizes / operands (see gemm.hip)
 int ffgp_gemm_launch_rag(ffgp_handle* h, int mode, int syrk_tag, int R, const GemmRagIn* in, double alpha, double beta, int alias);
 // ---- potrf.hip

@@ -1013,6 +1013,7 @@ static int gemm_plan(ffgp_handle* h, int opa, int opb, int mode, int syrk_tag, c
   if (h->ho_gdefer_slot >= 0 && h->ho_gdefer_stream == h->stream && h->ob_F <= 1) {      // a pending hand-off rides on this launch
     a.pub_word = h->ho_mem + h->ho_gdefer_slot * 16;
     a.pub_val = h->ho_seq[h->ho_gdefer_slot];
+    h->ho_launched[h->ho_gdefer_slot] = h->ho_seq[h->ho_gdefer_slot];      // (the launch being planned publishes: submission-order rule)
     h->ho_gdefer_slot = -1;
   }
   if (tsm != 128) syrk_tag = 0;  // only the 128x128 trailing update is the roofline kernel (own instantiation + stats)

@@ -413,6 +413,7 @@ __global__ __launch_bounds__(DIAG_THREADS) void ffgp_potrf_diag128(double* __res
 // sees FFGP_DIAG_WATCHDOG in the status word instead of a hung queue.
 // ------------------------------------------------------------------------------------------------------------
 #define FFGP_DIAG_WATCHDOG 0x7ffffff0
+#define FFGP_HANDOFF_WATCHDOG 0x7fffffe0     // a look-ahead gate gave up waiting for its hand-off (ffgp_handoff_gate)
 
 // tools/diag_trace.py builds a second library with -DFFGP_DIAG_TRACE: wave 0 and helper 0 stamp the cycle counter at their
 // phase boundaries (never compiled into libffgp.so)
@@ -1550,6 +1551,59 @@ static inline int la_slot(const ffgp_handle* h, hipEvent_t ev) {
     if (h->la_ev[i] == ev) return i;
   return -1;
 }
+// The wait is the library's OWN one-wave kernel (round 6): hipStreamWaitValue32 is a polling kernel of the runtime with no timeout -- in a
+// process whose dispatches are serialised by a tool that is not on default_ho_values()'s list (api.hip) it would spin for a producer
+// that can never start, and the GPU hangs.  This gate polls the same word (measured at the same cost per hop: 3.5-4.0 us against the
+// runtime's 2.9-4.7, tools/native/handoff_probe.hip `kgate` / `vgate`), but watches the 100 MHz wall clock: after `ticks` without the
+// value it writes FFGP_HANDOFF_WATCHDOG into the status word and LEAVES -- the kernels behind it then run on incomplete data and the
+// call returns FFGP_ERR_HANDOFF instead of never returning; the handle goes back to event pairs (ffgp_map_info).
+__global__ void ffgp_handoff_gate(const unsigned* __restrict__ word, unsigned need, int* info, long ticks) {
+  if (threadIdx.x != 0) return;
+  const long t0 = wall_clock64();
+  while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need) {
+    __builtin_amdgcn_s_sleep(1);
+    if (wall_clock64() - t0 > ticks) {
+      atomicCAS(info, 0, FFGP_HANDOFF_WATCHDOG);
+      return;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// Create-time self-test across two streams (api.hip, create_resources): the gate is enqueued on the side stream FIRST, the write that
+// satisfies it on the handle's own stream afterwards.  Where kernels of different queues can run side by side the gate sees the value
+// within microseconds; in a process whose dispatches are serialised it gives up after 50 ms -- the handle then keeps the event pairs for
+// its whole life (ho_selftest_failed: option "ho_values" = 1 is refused).  This is the DETECTION; the list of environment variables in
+// default_ho_values() only spares such a process the 50 ms.
+int ffgp_handoff_selftest(ffgp_handle* h) {
+  unsigned* probe = h->ho_mem + 9 * 16 + 8;
+  int* word = h->d_info + 8;
+  FFGP_HIP(hipMemsetAsync(word, 0, sizeof(int), h->aux));
+  hipLaunchKernelGGL(ffgp_handoff_gate, dim3(1), dim3(64), 0, h->aux, probe, 2u, word, 50L * 100000L);
+  if (hipGetLastError() != hipSuccess) return FFGP_ERR_HIP;
+  if (hipStreamWriteValue32(h->own, probe, 2u, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    FFGP_HIP(hipMemsetAsync(probe, 0xff, sizeof(unsigned), h->own));      // (no value operations: release the gate another way)
+    FFGP_HIP(hipStreamSynchronize(h->own));
+    FFGP_HIP(hipStreamSynchronize(h->aux));
+    return 1;
+  }
+  FFGP_HIP(hipStreamSynchronize(h->aux));
+  FFGP_HIP(hipStreamSynchronize(h->own));
+  int got = 0;
+  FFGP_HIP(hipMemcpy(&got, word, sizeof(int), hipMemcpyDeviceToHost));
+  FFGP_HIP(hipMemset(word, 0, sizeof(int)));
+  FFGP_HIP(hipMemset(probe, 0, sizeof(unsigned)));
+  return got != 0 ? 1 : 0;      // 1: the gate timed out -- kernels of two queues do not overlap here
+}
+// test hook (option "ho_withhold" = k > 0): the k-th publication from now on is never written -- the consumer's gate must time out
+static inline bool la_withheld(ffgp_handle* h) {
+  if (h->ho_withhold <= 0) return false;
+  return --h->ho_withhold == 0;
+}
+// submission-order rule (see ffgp_potrf_impl): a wait is only ever ENQUEUED after the launch that satisfies it, so that polling gates in
+// shared in-order hardware queues cannot form a cycle.  ho_launched[slot] = the newest sequence number whose producing operation has
+// been enqueued; la_wait checks it (development build: an error; product: counted in ho_order_violations).
+static inline void la_mark_launched(ffgp_handle* h, int slot) { h->ho_launched[slot] = h->ho_seq[slot]; }
 static int la_record(ffgp_handle* h, hipEvent_t ev, hipStream_t s) {
   const int slot = la_slot(h, ev);
   if (slot < 0) {
@@ -1557,6 +1611,8 @@ static int la_record(ffgp_handle* h, hipEvent_t ev, hipStream_t s) {
     return FFGP_OK;
   }
   h->ho_seq[slot] += 1;
+  la_mark_launched(h, slot);
+  if (la_withheld(h)) return FFGP_OK;
   FFGP_HIP(hipStreamWriteValue32(s, h->ho_mem + slot * 16, h->ho_seq[slot], 0));
   return FFGP_OK;
 }
@@ -1565,6 +1621,20 @@ static int la_wait(ffgp_handle* h, hipStream_t s, hipEvent_t ev) {
   if (slot < 0) {
     FFGP_HIP(hipStreamWaitEvent(s, ev, 0));
     return FFGP_OK;
+  }
+  if (h->ho_launched[slot] != h->ho_seq[slot]) {      // the producer of this number has not been enqueued yet
+    h->ho_order_violations += 1;
+#ifdef FFGP_DEV_OPTIONS
+    fprintf(stderr, "[ffgp] look-ahead: wait for hand-off %d #%u enqueued before its producer (#%u launched)\n", slot, h->ho_seq[slot],
+            h->ho_launched[slot]);
+    return FFGP_ERR_HIP;
+#endif
+  }
+  if (h->ho_gate) {
+    int* info = h->ho_info ? h->ho_info : h->d_info;
+    hipLaunchKernelGGL(ffgp_handoff_gate, dim3(1), dim3(64), 0, s, h->ho_mem + slot * 16, h->ho_seq[slot], info,
+                       (long)h->ho_timeout_ms * 100000L);
+    return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
   }
   FFGP_HIP(hipStreamWaitValue32(s, h->ho_mem + slot * 16, h->ho_seq[slot], hipStreamWaitValueGte, 0xffffffffu));
   return FFGP_OK;
@@ -1577,6 +1647,7 @@ static int la_flush_gemm(ffgp_handle* h) {
   if (h->ho_gdefer_slot < 0) return FFGP_OK;
   const int slot = h->ho_gdefer_slot;
   h->ho_gdefer_slot = -1;
+  la_mark_launched(h, slot);
   FFGP_HIP(hipStreamWriteValue32(h->ho_gdefer_stream, h->ho_mem + slot * 16, h->ho_seq[slot], 0));
   return FFGP_OK;
 }
@@ -1585,6 +1656,7 @@ static int la_flush(ffgp_handle* h) {
   if (h->ho_defer_slot < 0) return grc;
   const int slot = h->ho_defer_slot;
   h->ho_defer_slot = -1;
+  la_mark_launched(h, slot);
   FFGP_HIP(hipStreamWriteValue32(h->ho_defer_stream, h->ho_mem + slot * 16, h->ho_seq[slot], 0));
   return grc;
 }
@@ -1616,7 +1688,9 @@ static inline void la_take_deferred(ffgp_handle* h, DiagRag& dr) {
   if (h->ho_defer_slot >= 0 && h->ho_defer_stream == h->stream) {
     dr.pub = h->ho_mem + h->ho_defer_slot * 16;
     dr.pub_val = h->ho_seq[h->ho_defer_slot];
+    la_mark_launched(h, h->ho_defer_slot);
     h->ho_defer_slot = -1;
+    if (la_withheld(h)) dr.pub = nullptr;      // (test hook: this publication never happens)
   }
 }
 struct LaFlushGuard {      // whatever path leaves the factorisation, a pending publication is written
@@ -1752,6 +1826,7 @@ int ffgp_potrf_impl(ffgp_handle* h, double* A, int n, int mtot, int lda, int syn
   }
   FFGP_CHECK(ffgp_ensure_dinv(h, n));
   FFGP_CHECK(la_begin(h));
+  h->ho_info = (h->bt_F > 1 && h->bt_info) ? h->bt_info : h->d_info;
   if (!h->fold_info) FFGP_CHECK(ffgp_zero_async(h, h->d_info, sizeof(int)));   // (ffgp_train_raw's loop: its Adam kernel clears the word)
   h->dinv_L = nullptr;
   h->sinv_L = nullptr;   // super-block inverses belong to the factor that is about to be overwritten
@@ -2010,6 +2085,7 @@ int ffgp_potrf_ragged(ffgp_handle* h, int R, const ffgp_rag_block* mem) {
     h->diag_attr_set |= 4;
   }
   FFGP_CHECK(la_begin(h));
+  h->ho_info = h->bt_info + mem[0].info_index;      // (a gate that gives up reports through the first member's status word)
   hipStream_t main_s = h->stream;
   hipStream_t chain_s = any_la ? h->aux : main_s;
   struct StreamGuard {      // whatever path leaves this function (the FFGP_HIP macros return at once), the handle gets its stream back
@@ -2162,6 +2238,11 @@ int ffgp_potrf_ragged(ffgp_handle* h, int R, const ffgp_rag_block* mem) {
 
 // status word -> return code: a pivot index passes through; the diagonal-block kernel's watchdog is a library error
 int ffgp_map_info(int v) {
+  if (v == FFGP_HANDOFF_WATCHDOG) {
+    fprintf(stderr, "[ffgp] look-ahead: a gate waited for a cross-stream hand-off that never came and gave up (a tool that runs this "
+                    "process's kernels one at a time?); the call's results are invalid -- FFGP_HANDOFF=events keeps the event pairs\n");
+    return FFGP_ERR_HANDOFF;
+  }
   if (v >= FFGP_DIAG_WATCHDOG) {
     fprintf(stderr, "[ffgp] potrf_diag128: a wave waited ~1 s for a hand-off inside the kernel and gave up (internal error; hand-off %d)\n",
             v - FFGP_DIAG_WATCHDOG);

@@ -52,7 +52,9 @@ enum {
   FFGP_ERR_ARG = -1,    /* bad argument (null pointer, negative size, misaligned leading dimension) */
   FFGP_ERR_HIP = -2,    /* a HIP runtime call failed (message on stderr) */
   FFGP_ERR_ALLOC = -3,  /* device workspace allocation failed */
-  FFGP_ERR_NODEVICE = -4
+  FFGP_ERR_NODEVICE = -4,
+  FFGP_ERR_HANDOFF = -5 /* a cross-stream hand-off of the factorisation's look-ahead never arrived and its gate gave up after option
+                           "ho_timeout_ms" (a tool that serialises this process's kernels); the call's results are invalid */
 };
 
 /* likelihood formula variants */
@@ -262,6 +264,11 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
                         behaviour, not a contract: every XCD-local launch is followed by a chip-wide launch that chases whatever sweeps
                         the first did not hand out -- none on a full MI355X; all of them when no wave landed on the chosen XCD, as in a
                         partition mode or on a CU-masked stream),
+            "ho_gate" / "ho_timeout_ms" (default 1 / 2000: the look-ahead's cross-stream waits are the library's own one-wave gate kernel,
+                        which gives up after ho_timeout_ms without its value -- the call then returns FFGP_ERR_HANDOFF instead of hanging the
+                        GPU, e.g. under a tool that runs this process's kernels one at a time and is not recognised at create time;
+                        0 = hipStreamWaitValue32, which has no timeout),
+            "ho_withhold" (test hook: k > 0 makes the k-th hand-off publication from now on never happen),
             "train_persist" (default 1: ffgp_train_raw runs sets of small models -- n <= 128, D, d <= 16 -- as ONE persistent kernel launch,
                         see ffgp_train_raw; 0 = one launch per stage and step, the round-5 form),
             "chase_xcc" (0..15; default: handles of one process take XCDs 0..7 in turn -- the XCD whose wavefronts run the XCD-local

@@ -553,6 +553,38 @@ def test_potrf_reports_first_bad_pivot_on_the_lookahead_path(ff, n):
         assert rc == 0 and torch.equal(L2.tril(), L.tril()), (n, bad)
 
 
+def test_a_lost_handoff_is_an_error_within_a_second_not_a_hang(ff):
+    """the look-ahead's streams hand over through words of device memory that a one-wave gate kernel polls (potrf.hip, ffgp_handoff_gate).
+    A publication that never happens -- forced here by the test hook `ho_withhold`; in the field: a tool that serialises this process's
+    kernels and was not recognised when the handle was created -- must end in FFGP_ERR_HANDOFF after `ho_timeout_ms`, never in a hung
+    queue; the handle then factors the next matrix normally"""
+    import time
+    _lib, h = ff
+    n = 3000
+    S = _device_spd(n, 5)
+    rc, L = _potrf_inplace(ff, S)
+    assert rc == 0
+    assert _lib.lib.ffgp_set_option(h, b"ho_timeout_ms", 150.0) == 0
+    seen = set()
+    try:
+        for k in range(1, 7):
+            assert _lib.lib.ffgp_set_option(h, b"ho_withhold", float(k)) == 0
+            t0 = time.perf_counter()
+            rc, L2 = _potrf_inplace(ff, S)
+            dt = time.perf_counter() - t0
+            _lib.lib.ffgp_set_option(h, b"ho_withhold", 0.0)
+            assert rc in (0, -5) and dt < 1.0, (k, rc, dt)
+            seen.add(rc)
+            if rc == 0:      # (a publication nobody was waiting for)
+                assert torch.equal(L2.tril(), L.tril()), k
+            rc, L3 = _potrf_inplace(ff, S)
+            assert rc == 0 and torch.equal(L3.tril(), L.tril()), k
+    finally:
+        _lib.lib.ffgp_set_option(h, b"ho_withhold", 0.0)
+        _lib.lib.ffgp_set_option(h, b"ho_timeout_ms", 2000.0)
+    assert -5 in seen, seen
+
+
 def test_trsm_and_potrs(ff):
     import scipy.linalg as sla
     _lib, h = ff
