@@ -309,6 +309,7 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->ho_values = default_ho_values();
   h->ho_defer = 2;
   h->ho_gate = 1;
+  h->grad_lanes = FFGP_GRAD_LANES;
   h->ho_timeout_ms = 2000;
   h->ho_defer_slot = -1;
   h->ho_gdefer_slot = -1;
@@ -369,6 +370,12 @@ int ffgp_destroy(ffgp_handle* h) {
   if (h->ho_mem) hipFree(h->ho_mem);
   if (h->bt_info) hipFree(h->bt_info);
   if (h->train_g) hipFree(h->train_g);
+  for (int z = 0; z < FFGP_GRAD_LANES; ++z) {
+    if (h->lane_st[z]) { hipStreamSynchronize(h->lane_st[z]); hipStreamDestroy(h->lane_st[z]); }
+    if (h->lane_ev[z]) hipEventDestroy(h->lane_ev[z]);
+    if (z > 0 && h->lane_skw[z]) hipFree(h->lane_skw[z]);
+  }
+  if (h->lane_scal) hipFree(h->lane_scal);
   if (h->train_tab) hipFree(h->train_tab);
   if (h->train_host) hipHostFree(h->train_host);
   if (h->pack_buf) hipFree(h->pack_buf);
@@ -494,6 +501,9 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->chase_xl = (int)value;
   } else if (!strcmp(key, "chase_xl_max_n")) {
     h->chase_xl_max_n = (int)value;
+  } else if (!strcmp(key, "grad_lanes")) {
+    if (value < 1.0 || value > (double)FFGP_GRAD_LANES) return FFGP_ERR_ARG;
+    h->grad_lanes = (int)value;
   } else if (!strcmp(key, "train_persist")) {
     h->train_persist_off = (value == 0.0) ? 1 : 0;
   } else if (!strcmp(key, "chase_xcc")) {
@@ -937,6 +947,19 @@ int ffgp_nlml_fused_small_batch(ffgp_handle* h, int F, const ffgp_problem* p, co
   return ffgp_wait(h);
 }
 
+// streams, events and scalar scratch of the gradient lanes (ffgp_nlml_fused_batch), created at first use
+static int ffgp_grad_lanes_prepare(ffgp_handle* h, int nl) {
+  if (!h->lane_scal) {
+    FFGP_HIP(hipMalloc(&h->lane_scal, (size_t)FFGP_GRAD_LANES * 64 * sizeof(double)));
+    FFGP_HIP(hipMemsetAsync(h->lane_scal, 0, (size_t)FFGP_GRAD_LANES * 64 * sizeof(double), h->stream));
+  }
+  for (int z = 0; z < nl; ++z) {
+    if (!h->lane_ev[z]) FFGP_HIP(hipEventCreateWithFlags(&h->lane_ev[z], hipEventDisableTiming));
+    if (z > 0 && !h->lane_st[z]) FFGP_HIP(hipStreamCreateWithFlags(&h->lane_st[z], hipStreamNonBlocking));
+  }
+  return FFGP_OK;
+}
+
 // ---- F blocks of ONE shape in one chain of launches ----------------------------------------------------------------------------
 // The reference's per-fidelity / per-seed loops evaluate independent blocks of equal size one after the other
 // (Experiments/GAR_Aligned/exp_aligned.py:58-126, FidelityFusion_Models/ResGP.py:78-112).  Below N ~ 6000 a block's
@@ -1009,13 +1032,26 @@ int ffgp_nlml_fused_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ff
     all_grad = gg.g_w_dev || gg.g_amp_dev || gg.g_diag_add_dev || gg.g_Y_dev || gg.g_diag_vec_dev || gg.g_kparam_dev;
   }
   if (all_grad && (size_t)F * (2 * sX + sT) * sizeof(double) > ((size_t)48 << 30)) all_grad = false;
-  const size_t copies = all_grad ? (size_t)F : 1;
+  // Members whose gradient stages cannot share launches (different sizes) run them SIDE BY SIDE instead (round 6): up to four lanes, each
+  // a stream with its own scratch (inverse, Sigma^-1, TRTRI workspace, A^T, partial sums, split-K workspace, trace scalar), every member's
+  // stage sequence exactly its single call's -- so its bits are too.  For three blocks of 300 / 300 / 250 points the three latency-bound
+  // chains of ~12 launches overlap; larger members fill one another's gaps.  Option "grad_lanes" (default 4; 1 = member after member).
+  int n_grad = 0;
+  if (want_grad && g)
+    for (int f = 0; f < F; ++f) {
+      const ffgp_grads& gg = g[f];
+      n_grad += (gg.g_w_dev || gg.g_amp_dev || gg.g_diag_add_dev || gg.g_Y_dev || gg.g_diag_vec_dev || gg.g_kparam_dev) ? 1 : 0;
+    }
+  int nl = (!all_grad && n_grad >= 2 && h->grad_lanes > 1 && h->timing == 0) ? std::min(std::min(n_grad, h->grad_lanes), FFGP_GRAD_LANES) : 1;
+  sT = (sT + 15) / 16 * 16; sAt = (sAt + 15) / 16 * 16; sP = (sP + 15) / 16 * 16;
+  if (nl > 1 && (size_t)nl * (2 * sX + sT) * sizeof(double) > ((size_t)48 << 30)) nl = 1;
+  const size_t copies = all_grad ? (size_t)F : (size_t)nl;
   if (want_grad) {
     o_X = total; total += copies * sX;
     o_S = total; total += copies * sX;
     o_T = total; total += copies * sT;
-    o_At = total; total += sAt;
-    o_P = total; total += sP;
+    o_At = total; total += (size_t)nl * sAt;
+    o_P = total; total += (size_t)nl * sP;
   }
   FFGP_CHECK(ffgp_ensure_ws(h, total * sizeof(double)));
   if (!h->bt_info) {
@@ -1110,7 +1146,46 @@ int ffgp_nlml_fused_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ff
     rc_stage = ffgp_nll_reduce_multi(h, F, rL.data(), rn.data(), rld.data(), rM.data(), rd.data(), rn.data(), rld.data(), rd.data(), rpi.data(),
                                      rsc.data(), rout.data(), h->ws + o_red);
   }
-  for (int f = 0; f < F && rc_stage == FFGP_OK; ++f) {
+  // lanes: members dealt longest-first to the lane with the least work so far; lane 0 is the call's own stream
+  std::vector<int> order(F), lane_of(F, 0);
+  for (int f = 0; f < F; ++f) order[f] = f;
+  hipStream_t const main_stream = h->stream;
+  if (nl > 1 && rc_stage == FFGP_OK) {
+    rc_stage = ffgp_grad_lanes_prepare(h, nl);
+    if (rc_stage == FFGP_OK) {
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return p[a].n > p[b].n; });
+      double load[FFGP_GRAD_LANES] = {0.0, 0.0, 0.0, 0.0};
+      for (int f : order) {
+        int best = 0;
+        for (int z = 1; z < nl; ++z)
+          if (load[z] < load[best]) best = z;
+        lane_of[f] = best;
+        load[best] += (double)p[f].n * p[f].n * p[f].n + 1e6;      // (+ a launch-count term: small members are chains of launches)
+      }
+      if (hipEventRecord(h->lane_ev[0], main_stream) != hipSuccess) rc_stage = FFGP_ERR_HIP;
+      for (int z = 1; z < nl && rc_stage == FFGP_OK; ++z)
+        if (hipStreamWaitEvent(h->lane_st[z], h->lane_ev[0], 0) != hipSuccess) rc_stage = FFGP_ERR_HIP;
+    }
+  }
+  struct LaneGuard {      // the handle's stream and per-lane scratch pointers while one member's stages are enqueued on a lane
+    ffgp_handle* h; int lane; hipStream_t main_s; double* skw0; size_t skwb0; double* scal0;
+    LaneGuard(ffgp_handle* h_, int lane_, hipStream_t m) : h(h_), lane(lane_), main_s(m), skw0(h_->skw), skwb0(h_->skw_bytes), scal0(h_->d_scal) {
+      if (lane > 0) {
+        h->stream = h->lane_st[lane];
+        h->skw = h->lane_skw[lane]; h->skw_bytes = h->lane_skw_bytes[lane];
+        h->d_scal = h->lane_scal + (size_t)lane * 64;
+      }
+    }
+    ~LaneGuard() {
+      if (lane > 0) {
+        h->lane_skw[lane] = h->skw; h->lane_skw_bytes[lane] = h->skw_bytes;      // (it may have grown)
+        h->skw = skw0; h->skw_bytes = skwb0; h->d_scal = scal0;
+        h->stream = main_s;
+      }
+    }
+  };
+  for (int oi = 0; oi < F && rc_stage == FFGP_OK; ++oi) {
+    const int f = order[oi];
     const int n = p[f].n, d = p[f].d;
     const int ld = (int)ldv[f];
     double* W0 = h->ws + offv[f];
@@ -1118,14 +1193,16 @@ int ffgp_nlml_fused_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ff
     if (!want_grad || !g) continue;
     const ffgp_grads& gg = g[f];
     if (!(gg.g_w_dev || gg.g_amp_dev || gg.g_diag_add_dev || gg.g_Y_dev || gg.g_diag_vec_dev || gg.g_kparam_dev)) continue;
+    const int lane = (nl > 1) ? lane_of[f] : 0;
+    LaneGuard lg(h, lane, main_stream);
     // the block's own slice of the Dinv store, presented as "the" store of this factor while its inverse is formed
     h->dinv = dinv0 + doffv[f];
     h->dinv_L = W0; h->dinv_n = n; h->dinv_ld = ld;
-    double* X = h->ws + o_X + (all_grad ? (size_t)f * sX : 0);
-    double* S = h->ws + o_S + (all_grad ? (size_t)f * sX : 0);
-    double* T = h->ws + o_T;
-    double* At = h->ws + o_At;
-    double* P = h->ws + o_P;
+    double* X = h->ws + o_X + (all_grad ? (size_t)f * sX : (size_t)lane * sX);
+    double* S = h->ws + o_S + (all_grad ? (size_t)f * sX : (size_t)lane * sX);
+    double* T = h->ws + o_T + (all_grad ? 0 : (size_t)lane * sT);
+    double* At = h->ws + o_At + (size_t)lane * sAt;
+    double* P = h->ws + o_P + (size_t)lane * sP;
     double* geff = h->ws + o_link + (size_t)f * 512 + 256;
     const int D = q[f].D;
     ffgp_grads gq = gg;
@@ -1162,6 +1239,14 @@ int ffgp_nlml_fused_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ff
   }
   h->dinv = dinv0;
   h->dinv_L = nullptr;
+  if (nl > 1) {      // the call's stream waits for every lane (also on an error path: nothing of this call may still be running on a lane)
+    for (int z = 1; z < nl; ++z) {
+      if (hipEventRecord(h->lane_ev[z], h->lane_st[z]) != hipSuccess || hipStreamWaitEvent(main_stream, h->lane_ev[z], 0) != hipSuccess) {
+        (void)hipGetLastError();
+        hipStreamSynchronize(h->lane_st[z]);
+      }
+    }
+  }
   FFGP_CHECK(rc_stage);
   if (l && fwd_only) {      // forward only: the output scale was applied by the reduction
   } else if (l) {                   // blocks without gradients of their own inside a gradient batch

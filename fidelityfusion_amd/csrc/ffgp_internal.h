@@ -30,6 +30,7 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
     if (s_ != 0) return s_;         \
   } while (0)
 
+#define FFGP_GRAD_LANES 4      // gradient lanes of ffgp_nlml_fused_batch (api.hip)
 static inline int ffgp_round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // radial profiles (include/ffgp.h FFGP_KFUN_*): value phi(s) and  -2 * dphi/ds  (the factor that turns G o K' into the
@@ -248,6 +249,13 @@ struct ffgp_handle {
   int fold_info;        // ffgp_train_raw with one model: status-word upkeep lives in the Adam kernel
   int defer_info_copy;  // ffgp_train_raw's loop: the enqueue paths skip their per-call read-back of the status word
   double* train_g;      // ffgp_train_raw: gradients of the raw parameters [MAXF x GSTRIDE] + the step's losses [MAXF]
+  // gradient lanes of ffgp_nlml_fused_batch: members of different sizes run their inverse / gradient stages side by side
+  int grad_lanes;       // option "grad_lanes" (default 4; 1 = member after member)
+  hipStream_t lane_st[FFGP_GRAD_LANES];   // [0] unused (lane 0 is the call's stream)
+  hipEvent_t lane_ev[FFGP_GRAD_LANES];    // [0] fork, [z] lane z done
+  double* lane_skw[FFGP_GRAD_LANES];      // per-lane split-K workspaces (swapped into h->skw while a member is enqueued on the lane)
+  size_t lane_skw_bytes[FFGP_GRAD_LANES];
+  double* lane_scal;    // per-lane scalar scratch (64 doubles each; swapped into h->d_scal)
   void* train_tab;      // ffgp_train_persist (train.hip): [models | bias corrections | status words] of the current call
   size_t train_tab_bytes;
   void* train_host;     // its pinned host mirror (staging of the table, read-back of the status words)
