@@ -309,7 +309,7 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->ho_values = default_ho_values();
   h->ho_defer = 2;
   h->ho_gate = 1;
-  h->grad_lanes = FFGP_GRAD_LANES;
+  h->grad_lanes = 3;
   h->ho_timeout_ms = 2000;
   h->ho_defer_slot = -1;
   h->ho_gdefer_slot = -1;
@@ -371,7 +371,6 @@ int ffgp_destroy(ffgp_handle* h) {
   if (h->bt_info) hipFree(h->bt_info);
   if (h->train_g) hipFree(h->train_g);
   for (int z = 0; z < FFGP_GRAD_LANES; ++z) {
-    if (h->lane_st[z]) { hipStreamSynchronize(h->lane_st[z]); hipStreamDestroy(h->lane_st[z]); }
     if (h->lane_ev[z]) hipEventDestroy(h->lane_ev[z]);
     if (z > 0 && h->lane_skw[z]) hipFree(h->lane_skw[z]);
   }
@@ -502,7 +501,7 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "chase_xl_max_n")) {
     h->chase_xl_max_n = (int)value;
   } else if (!strcmp(key, "grad_lanes")) {
-    if (value < 1.0 || value > (double)FFGP_GRAD_LANES) return FFGP_ERR_ARG;
+    if (value < 1.0 || value > 3.0) return FFGP_ERR_ARG;
     h->grad_lanes = (int)value;
   } else if (!strcmp(key, "train_persist")) {
     h->train_persist_off = (value == 0.0) ? 1 : 0;
@@ -953,10 +952,13 @@ static int ffgp_grad_lanes_prepare(ffgp_handle* h, int nl) {
     FFGP_HIP(hipMalloc(&h->lane_scal, (size_t)FFGP_GRAD_LANES * 64 * sizeof(double)));
     FFGP_HIP(hipMemsetAsync(h->lane_scal, 0, (size_t)FFGP_GRAD_LANES * 64 * sizeof(double), h->stream));
   }
-  for (int z = 0; z < nl; ++z) {
+  // the lanes are the handle's side streams (idle during the gradient stages): they own hardware queues already -- a stream created
+  // now would be dealt onto one of the few queues round robin, quite possibly the call's own, and run BEHIND it
+  FFGP_CHECK(ffgp_ensure_aux2(h));
+  h->lane_st[1] = h->aux2;
+  h->lane_st[2] = h->aux3;      // (not the chain's stream h->aux: the GEMM launcher treats launches on it specially -- priority, no split-K)
+  for (int z = 0; z < nl; ++z)
     if (!h->lane_ev[z]) FFGP_HIP(hipEventCreateWithFlags(&h->lane_ev[z], hipEventDisableTiming));
-    if (z > 0 && !h->lane_st[z]) FFGP_HIP(hipStreamCreateWithFlags(&h->lane_st[z], hipStreamNonBlocking));
-  }
   return FFGP_OK;
 }
 
@@ -1042,7 +1044,13 @@ int ffgp_nlml_fused_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ff
       const ffgp_grads& gg = g[f];
       n_grad += (gg.g_w_dev || gg.g_amp_dev || gg.g_diag_add_dev || gg.g_Y_dev || gg.g_diag_vec_dev || gg.g_kparam_dev) ? 1 : 0;
     }
-  int nl = (!all_grad && n_grad >= 2 && h->grad_lanes > 1 && h->timing == 0) ? std::min(std::min(n_grad, h->grad_lanes), FFGP_GRAD_LANES) : 1;
+  int nmax_all = 0;
+  for (int f = 0; f < F; ++f) nmax_all = std::max(nmax_all, p[f].n);
+  // measured (tools/ragged_probe.py, FFGP_OPTS=grad_lanes=1 / 3): (300, 300, 250) 0.839 -> 0.789 ms, (4096, 3000, 2000) 5.32 -> 5.02,
+  // (2048, 2048, 1024, 1500) 2.77 -> 2.69; (8192, 4096, 2048, 1024) 16.3 -> 17.0 -- a throughput-bound member gains nothing from
+  // neighbours on its chip, so sets with a member above 6144 rows stay member after member.  Small members are bound by the HOST's
+  // launch rate (15 launches per member), which lanes do not change: the gate of 1.4 x the largest member is not met (1.66 x).
+  int nl = (!all_grad && n_grad >= 2 && h->grad_lanes > 1 && h->timing == 0 && nmax_all <= 6144) ? std::min(std::min(n_grad, h->grad_lanes), 3) : 1;
   sT = (sT + 15) / 16 * 16; sAt = (sAt + 15) / 16 * 16; sP = (sP + 15) / 16 * 16;
   if (nl > 1 && (size_t)nl * (2 * sX + sT) * sizeof(double) > ((size_t)48 << 30)) nl = 1;
   const size_t copies = all_grad ? (size_t)F : (size_t)nl;

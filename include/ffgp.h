@@ -269,6 +269,9 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
                         GPU, e.g. under a tool that runs this process's kernels one at a time and is not recognised at create time;
                         0 = hipStreamWaitValue32, which has no timeout),
             "ho_withhold" (test hook: k > 0 makes the k-th hand-off publication from now on never happen),
+            "grad_lanes" (default 3: in ffgp_nlml_fused_batch, members of DIFFERENT sizes (all <= 6144 rows) run their inverse / gradient
+                        stages side by side on up to three of the handle's streams, each with its own scratch; every member's launch
+                        sequence is its single call's, so are its bits; 1 = member after member.  Measured -3 ... -6 %),
             "train_persist" (default 1: ffgp_train_raw runs sets of small models -- n <= 128, D, d <= 16 -- as ONE persistent kernel launch,
                         see ffgp_train_raw; 0 = one launch per stage and step, the round-5 form),
             "chase_xcc" (0..15; default: handles of one process take XCDs 0..7 in turn -- the XCD whose wavefronts run the XCD-local

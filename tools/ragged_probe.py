@@ -19,6 +19,11 @@ grad = len(sys.argv) > 3 and sys.argv[3] == "grad"
 D = 8
 dev = torch.device("cuda", 0)
 torch.set_default_dtype(torch.float64)
+for kv in os.environ.get("FFGP_OPTS", "").split(","):      # library options for A/B runs: FFGP_OPTS=grad_lanes=1
+    if kv:
+        from fidelityfusion_amd import _lib
+        _lib.set_option(kv.split("=")[0], float(kv.split("=")[1]), 0)
+        print("option", kv)
 models, xs, ys = [], [], []
 for f, n in enumerate(sizes):
     X, Y = synthetic_xy(n, D, d, seed=f)
