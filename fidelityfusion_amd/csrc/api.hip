@@ -309,6 +309,7 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->ho_values = default_ho_values();
   h->ho_defer = 2;
   h->ho_gate = 1;
+  h->diag_v4 = 1;
   h->grad_lanes = 3;
   h->ho_timeout_ms = 2000;
   h->ho_defer_slot = -1;
@@ -466,6 +467,9 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
   } else if (!strcmp(key, "ho_values")) {
     if (value != 0.0 && h->ho_selftest_failed) return FFGP_ERR_ARG;      // (this process runs its kernels one at a time: see ffgp_handoff_selftest)
     h->ho_values = value != 0.0;
+  } else if (!strcmp(key, "diag_v4")) {
+    if (value < 0.0 || value > 2.0) return FFGP_ERR_ARG;
+    h->diag_v4 = (int)value;
   } else if (!strcmp(key, "ho_gate")) {
     h->ho_gate = value != 0.0;
   } else if (!strcmp(key, "ho_timeout_ms")) {

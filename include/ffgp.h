@@ -264,6 +264,10 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
                         behaviour, not a contract: every XCD-local launch is followed by a chip-wide launch that chases whatever sweeps
                         the first did not hand out -- none on a full MI355X; all of them when no wave landed on the chosen XCD, as in a
                         partition mode or on a CU-masked stream),
+            "diag_v4" (default 1: the factorisation's 128 x 128 diagonal blocks on ffgp_potrf_diag128_v4 -- two workgroup barriers per
+                        16-column stage, the inverse's rows formed in the shadow of the next block's pivots: 25.2 us per block against
+                        28.6 for the flag-driven pipeline of round 4 (v3, = 0), forward N = 1024 / 4096 / 8192 -6.9 / -5.7 / -2.0 %;
+                        the factors differ in the last bits (the updates reach a block in another order)),
             "ho_gate" / "ho_timeout_ms" (default 1 / 2000: the look-ahead's cross-stream waits are the library's own one-wave gate kernel,
                         which gives up after ho_timeout_ms without its value -- the call then returns FFGP_ERR_HANDOFF instead of hanging the
                         GPU, e.g. under a tool that runs this process's kernels one at a time and is not recognised at create time;
