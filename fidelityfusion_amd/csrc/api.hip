@@ -468,8 +468,7 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     if (value != 0.0 && h->ho_selftest_failed) return FFGP_ERR_ARG;      // (this process runs its kernels one at a time: see ffgp_handoff_selftest)
     h->ho_values = value != 0.0;
   } else if (!strcmp(key, "diag_v4")) {
-    if (value < 0.0 || value > 2.0) return FFGP_ERR_ARG;
-    h->diag_v4 = (int)value;
+    h->diag_v4 = value != 0.0;
   } else if (!strcmp(key, "ho_gate")) {
     h->ho_gate = value != 0.0;
   } else if (!strcmp(key, "ho_timeout_ms")) {

@@ -1217,7 +1217,9 @@ __global__ __launch_bounds__(512, 4) void ffgp_potrf_diag128_v3(double* __restri
 //       pivot step); in its shadow the helper waves (those that do not share wave 0's SIMD) apply column jj - 1 to every other block and
 //       compute row block jj - 1 of the inverse into registers;
 //   [B] the inverse's row is stored (LDS + Dinv store), all eight waves solve column jj with inv(L_jj) (one block each) and write L.
-// Only ceil(nb / 16) stages run.  Measured alone: see DESIGN 4.2.  The factor differs from v3's in the last bits (the updates reach a
+// Only ceil(nb / 16) stages run.  25.2 us per 128-block alone against v3's 28.6 (rocprofv3 kernel trace, profiles/r06g_*).  A variant with
+// ONE workgroup barrier per stage -- wave 0 solving block row jj itself in v3's way (Y = inv(L) S^T, D -= Y^T Y in registers) and the
+// helpers meeting at an LDS counter that wave 0 only arrives at -- was built and measured equal (docs/experiments.md, round 6).  The factor differs from v3's in the last bits (the updates reach a
 // block in a different order); both are held to LAPACK (1e-11) by the same tests.
 // ------------------------------------------------------------------------------------------------------------
 #define DIAG4_LDS_DOUBLES (NBLK_LOWER * BLKSZ + 128 + 16)
@@ -1419,271 +1421,6 @@ __global__ __launch_bounds__(512, 2) void ffgp_potrf_diag128_v4(double* __restri
       }
     }
     D4_BARRIER();
-  }
-  if (nst > 1 && hidx >= 0) {      // the last row block of the inverse: the helpers' columns, one product left per column
-    const int s_ = nst - 1;
-    const double* Ws = S + blk_off(s_, s_);
-#pragma unroll
-    for (int q2 = 0; q2 < 2; ++q2) {
-      const int j = hidx + q2 * nh;
-      if (j >= s_) continue;
-      d4_t T = Tl[q2];
-      mma16<false>(T, S + blk_off(s_, s_ - 1), BLD, S + blk_off(s_ - 1, j), BLD, lane);      // (block (s - 1, s - 1) holds inv(L_{s-1}) = X[s-1][s-1])
-      d4_t X = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int kq = 0; kq < 4; ++kq) X = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[c * BLD + kq * 4 + g], T[kq], X, 0, 0, 0);
-      double* gd = Dinv + (size_t)(s_ * 16 + g) * NB + j * 16 + c;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) gd[(size_t)4 * r * NB] = -X[r];
-    }
-  }
-}
-
-template <bool RAG>
-__global__ __launch_bounds__(512, 2) void ffgp_potrf_diag128_v5(double* __restrict__ A, int lda, int nb, double* __restrict__ Dinv,
-                                                                int* info, int row_base, int prio, long sA, long sD, int sInfo,
-                                                                DiagRag rag) {
-  if constexpr (RAG) {
-    A = rag.A[blockIdx.x];
-    Dinv = rag.Dinv[blockIdx.x];
-    lda = rag.lda[blockIdx.x];
-    nb = rag.nb[blockIdx.x];
-    info += rag.info[blockIdx.x];
-  } else {
-    A += (size_t)blockIdx.x * sA;
-    Dinv += (size_t)blockIdx.x * sD;
-    info += blockIdx.x * sInfo;
-  }
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* S = lds;
-  int* flags = reinterpret_cast<int*>(lds + NBLK_LOWER * BLKSZ + 128);      // [0..7] SIMD of wave w
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, c = lane & 15;
-  if (rag.pub && blockIdx.x == 0 && tid == 64) __hip_atomic_store(rag.pub, rag.pub_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (prio) __builtin_amdgcn_s_setprio(3);
-  const int nst = (nb + 15) >> 4;
-  if (tid < 16) flags[tid] = 0;
-  D4_BARRIER();
-  if (lane == 0) flags[wave] = d3_simd_id();
-  D4_BARRIER();
-  int hidx = -1, nh = 0;      // helpers: the waves that do not share wave 0's SIMD (fp64 MFMAs and the pivot loop's DP-ALU work share a pipe)
-  {
-    const int s0 = flags[0];
-    for (int w_ = 1; w_ < 8; ++w_) {
-      const bool is_h = flags[w_] != s0;
-      if (is_h && w_ == wave) hidx = nh;
-      nh += is_h ? 1 : 0;
-    }
-    if (nh == 0) { nh = 7; hidx = wave - 1; }
-    hidx = __builtin_amdgcn_readfirstlane(hidx);
-    nh = __builtin_amdgcn_readfirstlane(nh);
-  }
-  // ---- loads: wave 0 takes block (0, 0) straight into the factor's registers; the other waves bring every other lower block of the
-  //      first nst block rows into LDS ([16][17] images; diagonal blocks mirrored to full), all loads of a wave in flight at once
-  double v0[4];
-  if (wave == 0) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v0[r] = d3_elem(A, lda, nb, g + 4 * r, c);
-  } else {
-    const int nblk = nst * (nst + 1) / 2;
-    double x[6][4];
-#pragma unroll
-    for (int u = 0; u < 6; ++u) {
-      const int t = wave + 7 * u;      // blocks 1 .. nblk - 1 of the row-major enumeration over seven waves
-      if (t >= nblk) continue;
-      int bi = 0;
-#pragma unroll
-      for (int q = 1; q < 8; ++q) bi += (t >= q * (q + 1) / 2) ? 1 : 0;
-      const int bj = t - bi * (bi + 1) / 2;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) x[u][r] = d3_elem(A, lda, nb, bi * 16 + g + 4 * r, bj * 16 + c);
-    }
-#pragma unroll
-    for (int u = 0; u < 6; ++u) {
-      const int t = wave + 7 * u;
-      if (t >= nblk) continue;
-      int bi = 0;
-#pragma unroll
-      for (int q = 1; q < 8; ++q) bi += (t >= q * (q + 1) / 2) ? 1 : 0;
-      const int bj = t - bi * (bi + 1) / 2;
-      double* dst = S + blk_off(bi, bj);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dst[(g + 4 * r) * BLD + c] = x[u][r];
-    }
-    // rows beyond the stages that run: identity in the Dinv store (a previous, larger block may have left its inverse there)
-    for (int t = nst * (nst + 1) / 2 + (wave - 1); t < NBLK_LOWER; t += 7) {
-      int bi = 0;
-#pragma unroll
-      for (int q = 1; q < 8; ++q) bi += (t >= q * (q + 1) / 2) ? 1 : 0;
-      const int bj = t - bi * (bi + 1) / 2;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = g + 4 * r;
-        if (bi != bj || i >= c) Dinv[(size_t)(bi * 16 + i) * NB + bj * 16 + c] = (bi == bj && i == c) ? 1.0 : 0.0;
-      }
-    }
-  }
-  d4_t Tl[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-  d4_t Xn[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-  volatile int* hb = reinterpret_cast<volatile int*>(flags + 8);      // arrivals of the stage's solves: nh helpers + wave 0, per stage >= 1
-  volatile int* ab = reinterpret_cast<volatile int*>(flags + 9);
-  // ONE workgroup barrier per stage.  Stage jj >= 1:
-  //   wave 0  : solves block row jj of column jj - 1 itself (Y = inv(L_{jj-1}) S[jj][jj-1]^T: its accumulator is at once the A layout of
-  //             Y^T and the B layout of Y), D = S[jj][jj] - Y^T Y in registers, the 16 pivots, inv(L_jj) -> LDS / Dinv store
-  //   helpers : store row jj - 2 of the inverse (computed in the previous stage), solve the block rows below jj of column jj - 1 (one
-  //             block each), meet at a counter in LDS that wave 0 only ARRIVES at (it never waits), apply column jj - 1 to every block
-  //             but (jj, jj), compute row jj - 1 of the inverse into registers
-  for (int jj = 0; jj < nst; ++jj) {
-    if (wave == 0) {
-      double* Dj = S + blk_off(jj, jj);
-      double v[4], w[4];
-      int cc = c, gg = g;
-      asm volatile("" : "+v"(cc), "+v"(gg));      // (opaque per iteration: see v2)
-      if (jj == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = v0[r];
-      } else {
-        const double* Wp = S + blk_off(jj - 1, jj - 1);
-        const double* Sb = S + blk_off(jj, jj - 1);
-        d4_t Y = {0.0, 0.0, 0.0, 0.0}, D;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) D[r] = Dj[(g + 4 * r) * BLD + c];
-#pragma unroll
-        for (int kq = 0; kq < 4; ++kq)
-          Y = __builtin_amdgcn_mfma_f64_16x16x4f64(Wp[c * BLD + kq * 4 + g], Sb[c * BLD + kq * 4 + g], Y, 0, 0, 0);      // Y = W S^T
-        double* h1 = S + blk_off(jj, jj - 1);      // L[jj][jj-1] = Y^T: to LDS first -- the helpers' updates of column jj wait for it
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h1[c * BLD + g + 4 * r] = Y[r];
-        D2_LDS_FENCE();
-        if (lane == 0) d3_add(hb, 1);
-#pragma unroll
-        for (int kq = 0; kq < 4; ++kq) D = __builtin_amdgcn_mfma_f64_16x16x4f64(Y[kq], Y[kq], D, 0, 0, 1);   // D -= Y^T Y
-        {
-          const int gr = jj * 16 + c;
-          if (gr < nb) {
-            double* dst = A + (size_t)gr * lda + (jj - 1) * 16 + g;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dst[4 * r] = Y[r];
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = D[r];
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) w[r] = (gg + 4 * r == cc) ? 1.0 : 0.0;
-      double rowA = bperm_d(v[0], cc);
-      double rowW = (cc == 0) ? 1.0 : 0.0;
-      {
-        double hA = bperm_d(v[0], 16 + cc), hW = (cc == 1) ? 1.0 : 0.0;
-        double pRow = 0.0, pt = 0.0, ptw = 0.0;
-        double dcur = row_bcast64<0>(rowA), ycur = __builtin_amdgcn_rcp(dcur);
-#define F16_S(JJ) f16_step_dpp<JJ>(v, w, rowA, rowW, hA, hW, pRow, pt, ptw, dcur, ycur, cc, gg);
-        F16_S(0) F16_S(1) F16_S(2) F16_S(3) F16_S(4) F16_S(5) F16_S(6) F16_S(7) F16_S(8) F16_S(9) F16_S(10) F16_S(11) F16_S(12) F16_S(13)
-        F16_S(14) F16_S(15)
-#undef F16_S
-      }
-      const int q = c >> 2;
-      const double dsel = (q == 0) ? v[0] : (q == 1) ? v[1] : (q == 2) ? v[2] : v[3];
-      const double dcol = bperm_d(dsel, 16 * (c & 3) + c);
-      const double rs = rsqrt_nr(dcol);
-      const unsigned long long nonpos = __ballot(!(dcol > 0.0)) & 0xffffull;
-      const int bad = nonpos ? __ffsll((long long)nonpos) : 0;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = g + 4 * r;
-        const double rsi = bperm_d(rs, i);
-        const double x = (i >= c) ? w[r] * rsi : 0.0;
-        Dj[i * BLD + c] = x;                                              // inv(L_jj)
-        const int gr = jj * 16 + i, gc = jj * 16 + c;
-        if (i >= c) {
-          Dinv[(size_t)gr * NB + gc] = x;
-          if (gr < nb) A[(size_t)gr * lda + gc] = v[r] * rs;              // L_jj
-        }
-      }
-      if (bad && lane == 0 && (jj * 16 + bad) <= nb) atomicCAS(info, 0, row_base + jj * 16 + bad);
-    } else if (hidx >= 0 && jj > 0) {
-      const int sc_ = jj - 1;      // the column being solved and applied in this stage
-      if (jj > 1) {                // row jj - 2 of L is dead: the inverse's row (last stage's registers) takes its place
-#pragma unroll
-        for (int q2 = 0; q2 < 2; ++q2) {
-          const int j = hidx + q2 * nh;
-          if (j >= jj - 2) continue;
-          double* dst = S + blk_off(jj - 2, j);
-          double* gd = Dinv + (size_t)((jj - 2) * 16 + g) * NB + j * 16 + c;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            dst[(g + 4 * r) * BLD + c] = -Xn[q2][r];
-            gd[(size_t)4 * r * NB] = -Xn[q2][r];
-          }
-        }
-      }
-      for (int i = jj + 1 + hidx; i < nst; i += nh) {      // solve: L[i][sc] = S[i][sc] inv(L_sc)^T, block rows below jj
-        d4_t acc = {0.0, 0.0, 0.0, 0.0};
-        mma16<true>(acc, S + blk_off(i, sc_), BLD, S + blk_off(sc_, sc_), BLD, lane);
-        double* dst = S + blk_off(i, sc_);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          dst[(g + 4 * r) * BLD + c] = acc[r];
-          const int gr = i * 16 + g + 4 * r;
-          if (gr < nb) A[(size_t)gr * lda + sc_ * 16 + c] = acc[r];
-        }
-      }
-      D2_LDS_FENCE();
-      if (lane == 0) d3_add(hb, 1);
-      if (!d2_wait_ge(hb, (nh + 1) * jj, ab, info, 8)) return;      // every solve of column sc (wave 0's included) is in LDS
-      const int m = nst - jj;
-      for (int t = 1 + hidx; t < m * (m + 1) / 2; t += nh) {      // column sc reaches every block (i, k), jj <= k <= i, but (jj, jj)
-        int a = 0;
-#pragma unroll
-        for (int q = 1; q < 8; ++q) a += (t >= q * (q + 1) / 2) ? 1 : 0;
-        const int b = t - a * (a + 1) / 2;
-        const int i = jj + a, k = jj + b;
-        d4_t acc = {0.0, 0.0, 0.0, 0.0};
-        mma16<true>(acc, S + blk_off(i, sc_), BLD, S + blk_off(k, sc_), BLD, lane);
-        double* dst = S + blk_off(i, k);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dst[(g + 4 * r) * BLD + c] -= acc[r];
-      }
-      // row block sc of the inverse, columns hidx and hidx + nh: X = -inv(L_s) sum_k L[s][k] X[k][j]
-#pragma unroll
-      for (int q2 = 0; q2 < 2; ++q2) {
-        const int j = hidx + q2 * nh;
-        if (j >= sc_) continue;
-        d4_t T = {0.0, 0.0, 0.0, 0.0};
-        for (int k = j; k < sc_; ++k) mma16<false>(T, S + blk_off(sc_, k), BLD, S + blk_off(k, j), BLD, lane);
-        d4_t acc = {0.0, 0.0, 0.0, 0.0};
-        const double* Ws = S + blk_off(sc_, sc_);
-#pragma unroll
-        for (int kq = 0; kq < 4; ++kq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[c * BLD + kq * 4 + g], T[kq], acc, 0, 0, 0);
-        Xn[q2] = acc;
-      }
-      if (jj == nst - 1) {      // last stage: the terms k <= s - 2 of the inverse's LAST row as well (only k = s - 1 is left for the tail)
-#pragma unroll
-        for (int q2 = 0; q2 < 2; ++q2) {
-          const int j = hidx + q2 * nh;
-          d4_t T = {0.0, 0.0, 0.0, 0.0};
-          if (j < jj - 1)
-            for (int k = j; k < jj - 1; ++k) mma16<false>(T, S + blk_off(jj, k), BLD, S + blk_off(k, j), BLD, lane);
-          Tl[q2] = T;
-        }
-      }
-    }
-    D4_BARRIER();
-  }
-  if (nst > 1 && hidx >= 0) {      // row nst - 2 of the inverse (the last stage's registers): stored before the tail reads it
-#pragma unroll
-    for (int q2 = 0; q2 < 2; ++q2) {
-      const int j = hidx + q2 * nh;
-      if (j >= nst - 2) continue;
-      double* dst = S + blk_off(nst - 2, j);
-      double* gd = Dinv + (size_t)((nst - 2) * 16 + g) * NB + j * 16 + c;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        dst[(g + 4 * r) * BLD + c] = -Xn[q2][r];
-        gd[(size_t)4 * r * NB] = -Xn[q2][r];
-      }
-    }
-    D2_LDS_FENCE();      // (the tail below reads exactly the blocks this wave stored: columns hidx, hidx + nh of row nst - 2)
   }
   if (nst > 1 && hidx >= 0) {      // the last row block of the inverse: the helpers' columns, one product left per column
     const int s_ = nst - 1;
@@ -1962,14 +1699,10 @@ static int launch_diag(ffgp_handle* h, double* Ablk, int lda, int nb, double* Di
                                        160 * 1024));
           FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v4<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024));
-          FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v5<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024));
-          FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v5<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024));
           h->diag_attr_set |= 16;
         }
         const int lds4 = (lds_bytes != DIAG_LDS_BYTES) ? lds_bytes : DIAG4_LDS_BYTES;
-        auto kern = (h->diag_v4 == 2) ? ffgp_potrf_diag128_v5<false> : ffgp_potrf_diag128_v4<false>;
+        auto kern = ffgp_potrf_diag128_v4<false>;
         if (h->bt_F > 1)
           hipLaunchKernelGGL(kern, dim3(h->bt_F), dim3(512), DIAG4_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk,
                              h->bt_info, row_base, h->aux_prio, h->bt_sA, h->bt_sD, 1, dr);
@@ -2646,13 +2379,9 @@ int ffgp_potrf_ragged(ffgp_handle* h, int R, const ffgp_rag_block* mem) {
                                          160 * 1024));
             FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v4<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          160 * 1024));
-            FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v5<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         160 * 1024));
-            FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v5<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         160 * 1024));
             h->diag_attr_set |= 16;
           }
-          hipLaunchKernelGGL((h->diag_v4 == 2) ? ffgp_potrf_diag128_v5<true> : ffgp_potrf_diag128_v4<true>, dim3(cnt), dim3(512), DIAG4_LDS_BYTES,
+          hipLaunchKernelGGL(ffgp_potrf_diag128_v4<true>, dim3(cnt), dim3(512), DIAG4_LDS_BYTES,
                              h->stream, (double*)nullptr, 0, 0, (double*)nullptr, h->bt_info, j0, h->aux_prio, 0L, 0L, 0, dr);
         } else
         hipLaunchKernelGGL(ffgp_potrf_diag128_v3<true>, dim3(cnt), dim3(512), DIAG_LDS_BYTES, h->stream, (double*)nullptr, 0, 0, (double*)nullptr,
