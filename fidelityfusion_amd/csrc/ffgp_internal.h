@@ -157,6 +157,7 @@ struct ffgp_handle {
   unsigned ho_seq[10];  // ... the number its latest "record" wrote
   unsigned ho_launched[10];   // ... the newest number whose producing operation has been ENQUEUED (submission-order rule, la_wait)
   long ho_order_violations;   // waits enqueued before their producers (must stay 0)
+  int lds_cap, lds_cap_known;   // hipDeviceAttributeMaxSharedMemoryPerBlock, asked for once (launch_diag)
   int diag_v4;          // option "diag_v4": the diagonal-block kernel with two barriers per stage (ffgp_potrf_diag128_v4) in place of v3
   int ho_gate;          // option "ho_gate" (default 1): waits are the library's own gate kernel with a watchdog; 0 = hipStreamWaitValue32
   int ho_timeout_ms;    // option "ho_timeout_ms" (default 2000): the gate gives up after this long (FFGP_ERR_HANDOFF)

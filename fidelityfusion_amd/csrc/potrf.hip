@@ -1683,25 +1683,36 @@ static int launch_diag(ffgp_handle* h, double* Ablk, int lda, int nb, double* Di
                                      DIAG_LDS_BYTES));
         h->diag_attr_set |= 4;
       }
-      DiagRag dr = DiagRag();
-      la_take_deferred(h, dr);
       // (diag_excl: the panel's FIRST diagonal block of a chain-bound carry iteration asks for a whole CU's LDS, so the S_bz workgroups that
-      //  start the moment it publishes cannot land beside it -- see ffgp_potrf_impl)
-      const int lds_bytes = (h->diag_excl_now && h->bt_F <= 1) ? 160 * 1024 : DIAG_LDS_BYTES;
-      if (lds_bytes != DIAG_LDS_BYTES && !(h->diag_attr_set & 8)) {
+      //  start the moment it publishes cannot land beside it -- see ffgp_potrf_impl.  Only where a workgroup may have that much: the
+      //  limit is asked for once, and a device or runtime that says less simply keeps the ordinary launch)
+      if (!h->lds_cap_known) {
+        int cap = 0;
+        if (hipDeviceGetAttribute(&cap, hipDeviceAttributeMaxSharedMemoryPerBlock, h->device) != hipSuccess) {
+          (void)hipGetLastError();
+          cap = 64 * 1024;
+        }
+        h->lds_cap = cap;
+        h->lds_cap_known = 1;
+      }
+      const bool excl = h->diag_excl_now && h->bt_F <= 1 && h->lds_cap >= 160 * 1024;
+      const int lds_bytes = excl ? 160 * 1024 : DIAG_LDS_BYTES;
+      if (excl && !h->diag_v4 && !(h->diag_attr_set & 8)) {
         FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v3<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      160 * 1024));
         h->diag_attr_set |= 8;
       }
+      if (h->diag_v4 && !(h->diag_attr_set & 16)) {
+        const int want = h->lds_cap >= 160 * 1024 ? 160 * 1024 : DIAG4_LDS_BYTES;
+        FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v4<false>), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v4<true>), hipFuncAttributeMaxDynamicSharedMemorySize, want));
+        h->diag_attr_set |= 16;
+      }
+      // the pending "panel complete" publication is taken only now, when nothing can fail between here and the launch that carries it
+      DiagRag dr = DiagRag();
+      la_take_deferred(h, dr);
       if (h->diag_v4) {      // round 6: two barriers per stage (ffgp_potrf_diag128_v4)
-        if (!(h->diag_attr_set & 16)) {
-          FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v4<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024));
-          FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v4<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024));
-          h->diag_attr_set |= 16;
-        }
-        const int lds4 = (lds_bytes != DIAG_LDS_BYTES) ? lds_bytes : DIAG4_LDS_BYTES;
+        const int lds4 = excl ? lds_bytes : DIAG4_LDS_BYTES;
         auto kern = ffgp_potrf_diag128_v4<false>;
         if (h->bt_F > 1)
           hipLaunchKernelGGL(kern, dim3(h->bt_F), dim3(512), DIAG4_LDS_BYTES, h->stream, Ablk, lda, nb, Dinv_blk,
@@ -1715,6 +1726,10 @@ static int launch_diag(ffgp_handle* h, double* Ablk, int lda, int nb, double* Di
       else
         hipLaunchKernelGGL(ffgp_potrf_diag128_v3<false>, dim3(1), dim3(512), lds_bytes, h->stream, Ablk, lda, nb, Dinv_blk, h->d_info,
                            row_base, h->aux_prio, 0L, 0L, 0, dr);
+      if (hipGetLastError() != hipSuccess) {      // the launch that carried the publication did not happen: write it plainly, report
+        if (dr.pub) (void)hipStreamWriteValue32(h->stream, dr.pub, dr.pub_val, 0);
+        return FFGP_ERR_HIP;
+      }
     }
 #ifdef FFGP_DEV_OPTIONS
     else if (h->diag_v2 == 3)   // the round-3 pivot step (32-bit DPP moves), kept for A/B runs
@@ -2334,6 +2349,13 @@ int ffgp_potrf_ragged(ffgp_handle* h, int R, const ffgp_rag_block* mem) {
                                  DIAG_LDS_BYTES));
     h->diag_attr_set |= 4;
   }
+  if (h->diag_v4 && !(h->diag_attr_set & 32)) {      // (the ragged launches never ask for more than the kernel's own image)
+    if (!(h->diag_attr_set & 16)) {
+      FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v4<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DIAG4_LDS_BYTES));
+      FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v4<false>), hipFuncAttributeMaxDynamicSharedMemorySize, DIAG4_LDS_BYTES));
+    }
+    h->diag_attr_set |= 32;
+  }
   FFGP_CHECK(la_begin(h));
   h->ho_info = h->bt_info + mem[0].info_index;      // (a gate that gives up reports through the first member's status word)
   hipStream_t main_s = h->stream;
@@ -2374,13 +2396,6 @@ int ffgp_potrf_ragged(ffgp_handle* h, int R, const ffgp_rag_block* mem) {
         la_take_deferred(h, dr);
         for (int c = cnt; c < FFGP_RAG_MAX; ++c) { dr.A[c] = dr.A[0]; dr.Dinv[c] = dr.Dinv[0]; dr.lda[c] = dr.lda[0]; dr.nb[c] = dr.nb[0]; dr.info[c] = dr.info[0]; }
         if (h->diag_v4) {
-          if (!(h->diag_attr_set & 16)) {
-            FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v4<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         160 * 1024));
-            FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_potrf_diag128_v4<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         160 * 1024));
-            h->diag_attr_set |= 16;
-          }
           hipLaunchKernelGGL(ffgp_potrf_diag128_v4<true>, dim3(cnt), dim3(512), DIAG4_LDS_BYTES,
                              h->stream, (double*)nullptr, 0, 0, (double*)nullptr, h->bt_info, j0, h->aux_prio, 0L, 0L, 0, dr);
         } else

@@ -261,10 +261,11 @@ def test_potrf_matches_lapack(ff, tile, n):
 
 
 @pytest.mark.noisy
-@pytest.mark.parametrize("mode", [0, 1, 3, 4])
+@pytest.mark.parametrize("mode", [0, 1, 3, 4, 40])
 def test_potrf_diag_kernel_variants(ff, mode):
-    """the diagonal-block kernel in its four forms -- 0: barrier version, 3: round-3 pipeline, 1: the same with the DP-ALU DPP pivot
-    step (v_mov_b64_dpp / v_fmac_f64_dpp), 4: round-4 kernel (owner-computes helpers, static task lists; the default) -- against
+    """the diagonal-block kernel in its forms -- 0: barrier version, 3: round-3 pipeline, 1: the same with the DP-ALU DPP pivot
+    step (v_mov_b64_dpp / v_fmac_f64_dpp), 4: the default, round 6's ffgp_potrf_diag128_v4 (two barriers per 16-column stage, the inverse's
+    rows in the shadow of the next block's pivots), 40: round 4's flag-driven pipeline v3 (option diag_v4 = 0) -- against
     LAPACK at sizes with full, partial and single blocks; the factor and the cached block inverses must be bit-stable over repeated
     calls while a background load shares the GPU (LDS flag protocols, no barrier after the role hand-out)"""
     import ctypes as C
@@ -274,7 +275,8 @@ def test_potrf_diag_kernel_variants(ff, mode):
     if mode in (1, 3):                # the round-3 pipelines live in the development build only
         assert _lib.has_dev_options() or _lib.lib.ffgp_set_option(h, b"diag_v2", C.c_double(mode)) < 0    # (the shipped library refuses the key)
         need_dev_options()
-    assert _lib.lib.ffgp_set_option(h, b"diag_v2", C.c_double(mode)) == 0
+    assert _lib.lib.ffgp_set_option(h, b"diag_v2", C.c_double(4 if mode == 40 else mode)) == 0
+    assert _lib.lib.ffgp_set_option(h, b"diag_v4", C.c_double(0 if mode == 40 else 1)) == 0
     try:
         for n in (128, 100, 16, 129, 640, 1000, 1537, 4300):      # (1537, 4300: with the look-ahead's side stream and its hand-offs)
             rng = np.random.default_rng(10 * n + mode)
@@ -298,6 +300,7 @@ def test_potrf_diag_kernel_variants(ff, mode):
         assert rc == 201, (mode, rc)
     finally:
         assert _lib.lib.ffgp_set_option(h, b"diag_v2", C.c_double(4)) == 0
+        assert _lib.lib.ffgp_set_option(h, b"diag_v4", C.c_double(1)) == 0
 
 
 @pytest.mark.parametrize("n", [4000, 6200])
