@@ -20,6 +20,9 @@ python3 bench.py --n 32768 --steps 3 --warmup 1 --no-cpu-baseline --no-sharded >
 python3 bench.py --workload gar8_hogp --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_gar8_hogp.json 2>> $OUT/bench.err
 fi
 if [ "$PART" != "bench" ]; then
+# (the development library -- switches of rejected experiments that diag_bench / eigh_bench / raw_graph_bench A/B -- does not travel to
+#  the box: built here, ~1 min; tools/_devlib.py picks it up)
+make -C fidelityfusion_amd/csrc -j16 dev > $OUT/make_dev.log 2>&1
 {
 echo "## tools/train_bench.py 200"; timeout 300 python3 tools/train_bench.py 200 2>&1 | grep -v amdgpu.ids | tail -8
 for sz in "300,300,250 1" "300,300,250 1 grad" "8192,4096,2048,1024 1" "8192,4096,2048,1024 1 grad" "8192,4096,2048,1024 256"; do
