@@ -75,9 +75,14 @@ def train_many(models, xs, ys, steps, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, sta
     trace [F, steps] (float64, on the models' device) = the loss of model f at step k BEFORE that step's update -- what the reference
     prints -- and `state`, to be passed back in to continue the same optimisers (`state=None`: fresh optimisers).
     Models on one GPU in fp64 with a library kernel are trained by ffgp_train_raw, up to 16 per call (small models -- N <= 128, D,
-    d <= 16 -- take ONE launch per step for all of them); anything else runs the reference's loop through the drop-in modules.
-    A Sigma that is not positive definite raises torch.linalg.LinAlgError as the reference's loop would; the parameters then hold
-    the values they had when that step began."""
+    d <= 16 -- take ONE kernel launch for ALL their steps: csrc/train.hip, a persistent workgroup per model); anything else runs the
+    reference's loop through the drop-in modules.
+    A Sigma that is not positive definite raises torch.linalg.LinAlgError as the reference's loop would; the failing model's parameters
+    then hold the values they had when that step began (the other small models of the same call have completed their steps; the
+    optimiser state of a failed call is not advanced).
+    Two differences from running the loop yourself: the parameters are updated in place on the device and are left WITHOUT `.grad`
+    (there is no autograd pass), and the Adam moments live in the returned `state`, not in a `torch.optim.Adam` -- there is no
+    `optimizer.state_dict()` to checkpoint; keep `state` (and the step count inside it) instead."""
     models, xs, ys = list(models), list(xs), list(ys)
     nF = len(models)
     if not (nF == len(xs) == len(ys)) or steps <= 0:
