@@ -1223,6 +1223,9 @@ __global__ __launch_bounds__(512, 4) void ffgp_potrf_diag128_v3(double* __restri
 // block in a different order); both are held to LAPACK (1e-11) by the same tests.
 // ------------------------------------------------------------------------------------------------------------
 #define DIAG4_LDS_DOUBLES (NBLK_LOWER * BLKSZ + 128 + 16)
+#ifndef FFGP_D4_DBG
+#define FFGP_D4_DBG 0      // timing-only ablations of v4 (results wrong when non-zero): 1 = helpers idle in [A], 2 = wave 0 skips its pivots
+#endif
 #define DIAG4_LDS_BYTES (DIAG4_LDS_DOUBLES * 8)
 
 // (workgroup barrier that publishes LDS only: the kernel's global stores -- L, the Dinv store -- are read by nobody inside it, and
@@ -1333,8 +1336,10 @@ __global__ __launch_bounds__(512, 2) void ffgp_potrf_diag128_v4(double* __restri
         double pRow = 0.0, pt = 0.0, ptw = 0.0;
         double dcur = row_bcast64<0>(rowA), ycur = __builtin_amdgcn_rcp(dcur);
 #define F16_S(JJ) f16_step_dpp<JJ>(v, w, rowA, rowW, hA, hW, pRow, pt, ptw, dcur, ycur, cc, gg);
+        if (!(FFGP_D4_DBG & 2)) {
         F16_S(0) F16_S(1) F16_S(2) F16_S(3) F16_S(4) F16_S(5) F16_S(6) F16_S(7) F16_S(8) F16_S(9) F16_S(10) F16_S(11) F16_S(12) F16_S(13)
         F16_S(14) F16_S(15)
+        }
 #undef F16_S
       }
       const int q = c >> 2;
@@ -1356,9 +1361,12 @@ __global__ __launch_bounds__(512, 2) void ffgp_potrf_diag128_v4(double* __restri
         }
       }
       if (bad && lane == 0 && (jj * 16 + bad) <= nb) atomicCAS(info, 0, row_base + jj * 16 + bad);
-    } else if (hidx >= 0 && jj > 0) {
+    } else if (hidx >= 0 && jj > 0 && !(FFGP_D4_DBG & 1)) {
+      // column jj - 1 reaches every block (i, k), jj <= k <= i, but (jj, jj).  (Two tasks at a time -- both tasks' operands requested before
+      // either product, the two MFMA chains alternating -- was measured SLOWER: 25.9 against 25.2 us per block.  By ablation
+      // (-DFFGP_D4_DBG) the kernel is co-limited: without wave 0's pivots it takes the same time, with idle helpers 2.9 us less.)
       const int m = nst - jj;
-      for (int t = 1 + hidx; t < m * (m + 1) / 2; t += nh) {      // column jj - 1 reaches every block (i, k), jj <= k <= i, but (jj, jj)
+      for (int t = 1 + hidx; t < m * (m + 1) / 2; t += nh) {
         int a = 0;
 #pragma unroll
         for (int q = 1; q < 8; ++q) a += (t >= q * (q + 1) / 2) ? 1 : 0;
