@@ -124,10 +124,10 @@ static void stage_collect(ffgp_handle* h) {
 extern "C" {
 
 #ifdef FFGP_DEV_OPTIONS
-const char* ffgp_version(void) { return "ffgp 0.2-dev (gfx950, fp64 MFMA; development build: the options of measured-and-rejected experiments are compiled in)"; }
+const char* ffgp_version(void) { return "ffgp 0.6-dev (gfx950, fp64 MFMA; development build: the options of measured-and-rejected experiments are compiled in)"; }
 int ffgp_has_dev_options(void) { return 1; }
 #else
-const char* ffgp_version(void) { return "ffgp 0.2 (gfx950, fp64 MFMA)"; }
+const char* ffgp_version(void) { return "ffgp 0.6 (gfx950, fp64 MFMA)"; }
 int ffgp_has_dev_options(void) { return 0; }
 #endif
 
