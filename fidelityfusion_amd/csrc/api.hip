@@ -376,6 +376,7 @@ int ffgp_destroy(ffgp_handle* h) {
     if (z > 0 && h->lane_skw[z]) hipFree(h->lane_skw[z]);
   }
   if (h->lane_scal) hipFree(h->lane_scal);
+  if (h->small_kbuf) hipFree(h->small_kbuf);
   if (h->train_tab) hipFree(h->train_tab);
   if (h->train_host) hipHostFree(h->train_host);
   if (h->pack_buf) hipFree(h->pack_buf);
@@ -938,7 +939,10 @@ int ffgp_nlml_fused_small_batch_async(ffgp_handle* h, int F, const ffgp_problem*
   FFGP_HIP(hipSetDevice(h->device));
   h->n_stages = 0;
   FFGP_CHECK(ffgp_zero_async(h, h->d_info, sizeof(int)));
-  FFGP_CHECK(ffgp_small_batch_enqueue(h, F, p, l, nll_dev, g));
+  bool mfma = true;      // (round 6: the one-workgroup MFMA kernel of train.hip, when every problem is within its limits)
+  for (int f = 0; f < F && mfma; ++f) mfma = ffgp_small_mfma_ok(h, p + f, g ? g + f : nullptr);
+  if (mfma) FFGP_CHECK(ffgp_small_mfma_enqueue(h, F, p, l, nll_dev, g, 1));
+  else FFGP_CHECK(ffgp_small_batch_enqueue(h, F, p, l, nll_dev, g));
   if (!h->fold_info) hipLaunchKernelGGL(ffgp_sticky_info_kernel, dim3(1), dim3(1), 0, h->stream, h->d_info);
   if (!h->defer_info_copy) FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   return FFGP_OK;
@@ -1565,6 +1569,16 @@ static int nlml_fused_raw_plain(ffgp_handle* h, const ffgp_problem* p, const ffg
   if (p->cov_dev || p->pair || p->tree || !p->w_dev || !p->amp_dev || p->D <= 0 || p->D > 128) return FFGP_ERR_ARG;
   FFGP_HIP(hipSetDevice(h->device));
   if (p->n <= 0 || p->d <= 0 || !p->X_dev || !p->Y_dev || (p->ll_variant != FFGP_LL_V1 && p->ll_variant != FFGP_LL_V2)) return FFGP_ERR_ARG;
+  if (!h->fold_info && ffgp_small_mfma_ok(h, p, g)) {   // n <= 128: ONE launch on the matrix cores (train.hip, evaluate mode) instead of the scalar one-workgroup
+                                                        // kernel (n <= 40) or ~13 launches of the blocked path
+    h->n_stages = 0;
+    FFGP_CHECK(ffgp_zero_async(h, h->d_info, sizeof(int)));
+    FFGP_CHECK(ffgp_small_mfma_enqueue(h, 1, p, l, nll_dev, g, 0));
+    hipLaunchKernelGGL(ffgp_sticky_info_kernel, dim3(1), dim3(1), 0, h->stream, h->d_info);
+    if (!h->defer_info_copy) FFGP_HIP(hipMemcpyAsync(h->h_info, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    ffgp_invalidate(h);
+    return FFGP_OK;
+  }
   if (ffgp_small_ok(h, p, g)) {   // one kernel: links, likelihood, gradients, chain rule, output scale
     h->n_stages = 0;
     FFGP_CHECK(ffgp_small_enqueue(h, p, l, nll_dev, g));

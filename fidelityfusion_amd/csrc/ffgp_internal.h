@@ -260,6 +260,7 @@ struct ffgp_handle {
   double* lane_scal;    // per-lane scalar scratch (64 doubles each; swapped into h->d_scal)
   void* train_tab;      // ffgp_train_persist (train.hip): [models | bias corrections | status words] of the current call
   size_t train_tab_bytes;
+  double* small_kbuf;   // ffgp_small_mfma_enqueue: the evaluate-mode launches' parked kernel values (8 models x 36 x 256 doubles)
   void* train_host;     // its pinned host mirror (staging of the table, read-back of the status words)
   int train_persist_off;  // option "train_persist" = 0: ffgp_train_raw never takes the one-launch trainer
   int* bt_info;         // [F] device status words (first non-positive pivot of each block)
@@ -394,6 +395,8 @@ bool ffgp_small2_ok(const ffgp_handle* h, const ffgp_problem* p, const ffgp_grad
 bool ffgp_small_batch_ok(const ffgp_problem* p, const ffgp_grads* g);
 // train.hip: K Adam steps of F small models in ONE launch (one persistent workgroup per model)
 bool ffgp_train_persist_ok(const ffgp_handle* h, const ffgp_problem* p, const ffgp_links* l);
+bool ffgp_small_mfma_ok(const ffgp_handle* h, const ffgp_problem* p, const ffgp_grads* g);      // one likelihood (+ gradients), n <= 128: same kernel, no Adam
+int ffgp_small_mfma_enqueue(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g, int info_max);
 int ffgp_train_persist(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_links* l, int steps, const ffgp_adam* opt, double* state_dev,
                        long state_stride, long step0, double* trace_dev, long trace_stride);
 int ffgp_small_batch_enqueue(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g);

@@ -41,6 +41,10 @@ struct TrainModel {
   int kfun;
   double* state;                         // [exp_avg (nw + 2) | exp_avg_sq (nw + 2)]
   double* trace;                         // [steps]
+  // evaluate mode (one likelihood + gradient call, no Adam: ffgp_nlml_fused_small_batch / ffgp_nlml_fused_raw at n <= 128)
+  double* nll;                           // [1] value
+  double* g_w; double* g_amp; double* g_dadd; double* g_Y; double* g_dvec;   // gradients (raw parameters, Y, diag_vec); any may be null
+  int want_grad;
   double* kbuf;                          // [36][4][64] this model's kernel values K / amp, written by the assembly and read back by the
                                          // gradient pass of the same step (same lane, same slot: the exp is evaluated once per entry and step)
 };
@@ -50,6 +54,8 @@ struct TrainCommon {
   const double* bc;                      // [steps][2]: 1 - beta1^t, sqrt(1 - beta2^t) -- computed on the host with the C library's pow, as Python does
   int* info;                             // [models] status: 0, or the 1-based index of the first non-positive pivot of the step that failed
   int* fail_step;                        // [models] the step at which it happened
+  int* shared_info;                      // evaluate mode: the handle's status word (batch: atomicMax of the failing pivot; single: plain store)
+  int info_max;
   long* prof;                            // development (FFGP_TRAIN_TRACE=1): [12] wall_clock64 ticks per phase, summed over model 0's steps
 };
 // workgroup barrier that publishes LDS only: __syncthreads() also drains the wave's GLOBAL stores (the kernel values parked for the
@@ -216,10 +222,10 @@ __device__ __forceinline__ void tr_store(double* dst, const tr_d4& acc, int g, i
 #define TR_LDS_DOUBLES (TR_OFF_SMALL + TR_SMALL_DOUBLES)
 
 // DM: the input dimensions the per-entry loops are unrolled for (8 or 16: every model of the launch has D <= DM)
-template <int DM>
-__global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainModel* __restrict__ tab, TrainCommon cm) {
+// TRAIN: every step of the loop with Adam inside; !TRAIN ("evaluate"): ONE pass that writes the value and the gradients out
+template <int DM, bool TRAIN>
+__device__ __forceinline__ void tr_body(const TrainModel& M, const TrainCommon& cm) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const TrainModel M = tab[blockIdx.x];
   double* S = lds;
   double* Xs = lds + TR_OFF_XS;
   double* Ym = lds + TR_OFF_YM;
@@ -255,9 +261,11 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
   for (int idx = tid; idx < TR_N * (TR_D + 1); idx += TR_T) Xs[idx] = 0.0;      // (columns >= D and rows >= n stay zero: the unrolled loops read them)
   for (int i = tid; i < TR_N; i += TR_T) dvec[i] = (M.diag_vec && i < n) ? M.diag_vec[(size_t)i * M.diag_stride] : 0.0;
   if (tid < npar) {
-    raw[tid] = (tid < nw) ? M.w[tid] : (tid == nw ? M.amp[0] : M.dadd[0]);
-    mom[tid] = M.state[tid];
-    mo2[tid] = M.state[npar + tid];
+    raw[tid] = (tid < nw) ? M.w[tid] : (tid == nw ? M.amp[0] : (M.dadd ? M.dadd[0] : 0.0));
+    if (TRAIN) {
+      mom[tid] = M.state[tid];
+      mo2[tid] = M.state[npar + tid];
+    }
   }
   for (int t = wave; t < TR_NBLK; t += 8) {
     int bi, bj;
@@ -287,12 +295,13 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
   }
   if (tid < D) wv[tid] = tr_link_val(M.l.w_link, raw[M.l.w_broadcast ? 0 : tid], M.l.w_c);
   if (tid == 64) sc[0] = tr_link_val(M.l.amp_link, raw[nw], M.l.amp_c);
-  if (tid == 65) sc[1] = tr_link_val(M.l.dadd_link, raw[nw + 1], M.l.dadd_c);
+  if (tid == 65) sc[1] = M.dadd ? tr_link_val(M.l.dadd_link, raw[nw + 1], M.l.dadd_c) : 0.0;
   __syncthreads();
 
   int failed = 0;
   long t_prof = cm.prof ? wall_clock64() : 0;
-  for (int step = 0; step < cm.steps; ++step) {
+  const int nsteps = TRAIN ? cm.steps : 1;
+  for (int step = 0; step < nsteps; ++step) {
     // ---- P0: scaled inputs (the effective parameters were refreshed by the threads that updated the raw ones)
     for (int idx = tid; idx < n * D; idx += TR_T) {
       const int i = idx / D, k = idx - i * D;
@@ -432,11 +441,17 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
     }
     if (flags[0] != 0) {       // (uniform: every thread reads the same word behind the barrier)
       failed = flags[0];
-      if (tid == 0) {
-        cm.info[blockIdx.x] = failed;
-        cm.fail_step[blockIdx.x] = step;
+      if (TRAIN) {
+        if (tid == 0) {
+          cm.info[blockIdx.x] = failed;
+          cm.fail_step[blockIdx.x] = step;
+        }
+        for (int k = step + tid; k < cm.steps; k += TR_T) M.trace[k] = __builtin_nan("");
+      } else if (tid == 0) {      // (the blocked path goes on with a unit pivot and returns garbage; here the value is NaN)
+        if (cm.info_max) atomicMax(cm.shared_info, failed);
+        else cm.shared_info[0] = failed;
+        M.nll[0] = __builtin_nan("");
       }
-      for (int k = step + tid; k < cm.steps; k += TR_T) M.trace[k] = __builtin_nan("");
       break;
     }
     // ---- the last row block of the inverse (s = nst - 1), one column per wave
@@ -486,7 +501,7 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
     for (int k = 0; k < DM; ++k) tk[k] = 0.0;
 #pragma unroll
     for (int q = 0; q < TR_N * TR_Y / TR_T; ++q) ss = __builtin_fma(Gam[tid + TR_T * q], Gam[tid + TR_T * q], ss);
-    for (int q_ = 0; q_ < 5; ++q_) {
+    for (int q_ = 0; q_ < 5 && (TRAIN || M.want_grad); ++q_) {
       const int t = tr_deal(q_, wave);
       if (t >= nblk) continue;
       int bi, bj;
@@ -521,7 +536,10 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
         double m2 = ev;
         if (M.kfun != FFGP_KFUN_SE) m2 = ffgp_kfun_m2d(M.kfun, M.rinv, fmax(sq, M.clamp));
         s_amp = __builtin_fma(sym * gv, ev, s_amp);
-        if (i == j) trg += gv;
+        if (i == j) {
+          trg += gv;
+          if (!TRAIN && live) dvec[i] = gv;      // (evaluate mode: diag G for g_diag_vec; the diagonal extra was consumed by the assembly)
+        }
         const double wl = (sq >= M.clamp) ? sym * gv * amp * m2 : 0.0;
 #pragma unroll
         for (int k = 0; k < DM; ++k) tk[k] = __builtin_fma(wl, dsq[k], tk[k]);
@@ -555,8 +573,35 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
     }
     TR_PROF(8);
     // ---- P6: the loss of this step (before the update), the raw gradients through the links, Adam
-    if (tid == 0)
-      M.trace[step] = oscale * (0.5 * tot[0] + (double)d * 0.5 * tot[3] + 0.5 * (double)n * (double)d * log(2.0 * M.pi_const));
+    const double value = oscale * (0.5 * tot[0] + (double)d * 0.5 * tot[3] + 0.5 * (double)n * (double)d * log(2.0 * M.pi_const));
+    if (!TRAIN) {
+      if (tid == 0) M.nll[0] = value;
+      if (M.want_grad) {
+        if (tid < npar) {
+          double gr;
+          if (tid < nw) {
+            if (!M.l.w_broadcast) {
+              gr = oscale * (-tot[4 + tid] / wv[tid]) * tr_link_der(M.l.w_link, raw[tid], M.l.w_c);
+            } else {
+              double sg = 0.0;
+              for (int k = 0; k < D; ++k) sg += -tot[4 + k] / wv[k];
+              gr = oscale * sg * tr_link_der(M.l.w_link, raw[0], M.l.w_c);
+            }
+            if (M.g_w) M.g_w[tid] = gr;
+          } else if (tid == nw) {
+            if (M.g_amp) M.g_amp[0] = oscale * tot[1] * tr_link_der(M.l.amp_link, raw[nw], M.l.amp_c);
+          } else if (M.g_dadd) {
+            M.g_dadd[0] = oscale * tot[2] * (M.dadd ? tr_link_der(M.l.dadd_link, raw[nw + 1], M.l.dadd_c) : 1.0);
+          }
+        }
+        if (M.g_Y)
+          for (int idx = tid; idx < n * d; idx += TR_T) M.g_Y[idx] = oscale * Am[(idx / d) * TR_Y + (idx % d)];
+        if (M.g_dvec)
+          for (int i = tid; i < n; i += TR_T) M.g_dvec[i] = oscale * dvec[i];
+      }
+      break;
+    }
+    if (tid == 0) M.trace[step] = value;
     if (tid < npar) {
       double gr;
       if (tid < nw) {
@@ -598,7 +643,7 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
     TR_PROF(9);
   }
   // ---- parameters and moments back to the caller's tensors (a failed step left them as they were when it began)
-  if (tid < npar) {
+  if (TRAIN && tid < npar) {
     if (tid < nw) M.w[tid] = raw[tid];
     else if (tid == nw) M.amp[0] = raw[tid];
     else M.dadd[0] = raw[tid];
@@ -606,6 +651,22 @@ __global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainMod
     M.state[npar + tid] = mo2[tid];
   }
   (void)failed;
+}
+
+template <int DM>
+__global__ __launch_bounds__(TR_T) void ffgp_train_persist_kernel(const TrainModel* __restrict__ tab, TrainCommon cm) {
+  const TrainModel M = tab[blockIdx.x];
+  tr_body<DM, true>(M, cm);
+}
+// evaluate mode: up to eight models per launch, their descriptions by value (the enqueue-only entry points must not stage anything in
+// host memory that a later call could overwrite)
+#define TR_EVAL_BATCH 8
+struct TrainEvalBatch {
+  TrainModel m[TR_EVAL_BATCH];
+};
+template <int DM>
+__global__ __launch_bounds__(TR_T) void ffgp_small_mfma_kernel(TrainEvalBatch b, TrainCommon cm) {
+  tr_body<DM, false>(b.m[blockIdx.x], cm);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
@@ -671,6 +732,7 @@ int ffgp_train_persist(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_
     m.state = state_dev + (size_t)f * state_stride;
     m.trace = trace_dev + (size_t)f * trace_stride;
     m.kbuf = reinterpret_cast<double*>(dev + k_off) + (size_t)f * TR_NBLK * 256;
+    m.want_grad = 1;
   }
   double* bc = reinterpret_cast<double*>(host + bc_off);
   for (int k = 0; k < steps; ++k) {
@@ -684,6 +746,8 @@ int ffgp_train_persist(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_
   cm.bc = reinterpret_cast<const double*>(dev + bc_off);
   cm.info = reinterpret_cast<int*>(dev + info_off);
   cm.fail_step = cm.info + F;
+  cm.shared_info = nullptr;
+  cm.info_max = 0;
   cm.prof = nullptr;
   static const bool trace_on = getenv("FFGP_TRAIN_TRACE") && atoi(getenv("FFGP_TRAIN_TRACE")) != 0;
   if (trace_on) {
@@ -719,4 +783,70 @@ int ffgp_train_persist(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_
   for (int f = 0; f < F; ++f)
     if (st[f] != 0) return st[f];
   return FFGP_OK;
+}
+
+// ---- evaluate mode: one likelihood (+ gradients) of F small problems, ONE launch per eight of them ---------------------------------
+// What ffgp_nlml_fused_small_batch and, for 40 < n <= 128, ffgp_nlml_fused_raw run instead of the scalar one-workgroup kernel of
+// small.hip (0.58 ms at n = 128) or ~13 launches of the blocked path (0.098 ms): the trainer's pass without Adam.
+bool ffgp_small_mfma_ok(const ffgp_handle* h, const ffgp_problem* p, const ffgp_grads* g) {
+  if (h->train_persist_off || h->use_naive || h->timing || h->small_off) return false;
+  if (p->n <= 0 || p->n > TR_N || p->D <= 0 || p->D > TR_D || p->d <= 0 || p->d > TR_Y) return false;
+  if (p->cov_dev || p->pair || p->tree || p->add_mat_dev || p->add_all != 0.0 || p->mean_jitter != 0.0) return false;
+  if (!p->X_dev || !p->Y_dev || !p->w_dev || !p->amp_dev) return false;
+  if (p->kfun < FFGP_KFUN_SE || p->kfun > FFGP_KFUN_RQ || p->ll_variant != FFGP_LL_V1) return false;
+  if (g && (g->g_cov_dev || g->g_pair || g->g_kparam_dev)) return false;
+  return true;
+}
+
+int ffgp_small_mfma_enqueue(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_links* l, double* nll_dev, const ffgp_grads* g,
+                            int info_max) {
+  static bool attr_set[64] = {false};
+  if (h->device >= 0 && h->device < 64 && !attr_set[h->device]) {
+    FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_small_mfma_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 TR_LDS_DOUBLES * (int)sizeof(double)));
+    FFGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ffgp_small_mfma_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 TR_LDS_DOUBLES * (int)sizeof(double)));
+    attr_set[h->device] = true;
+  }
+  if (!h->small_kbuf) FFGP_HIP(hipMalloc(&h->small_kbuf, (size_t)TR_EVAL_BATCH * TR_NBLK * 256 * sizeof(double)));
+  TrainCommon cm;
+  memset(&cm, 0, sizeof(cm));
+  cm.steps = 1;
+  cm.shared_info = h->d_info;
+  cm.info_max = info_max;
+  for (int f0 = 0; f0 < F; f0 += TR_EVAL_BATCH) {
+    const int nb = std::min(TR_EVAL_BATCH, F - f0);
+    TrainEvalBatch b;
+    memset(&b, 0, sizeof(b));
+    int Dmax = 0;
+    for (int z = 0; z < nb; ++z) {
+      const ffgp_problem& q = p[f0 + z];
+      const ffgp_grads* gg = g ? g + f0 + z : nullptr;
+      TrainModel& m = b.m[z];
+      m.n = q.n; m.D = q.D; m.d = q.d;
+      m.X = q.X_dev; m.Y = q.Y_dev;
+      m.w = const_cast<double*>(q.w_dev); m.amp = const_cast<double*>(q.amp_dev); m.dadd = const_cast<double*>(q.diag_add_dev);
+      m.diag_vec = q.diag_vec_dev; m.diag_stride = q.diag_stride;
+      if (l) {
+        m.l = l[f0 + z];
+      } else {      // effective parameters: identity links
+        memset(&m.l, 0, sizeof(m.l));
+        m.l.w_link = m.l.amp_link = m.l.dadd_link = FFGP_LINK_ID;
+      }
+      m.nw = m.l.w_broadcast ? 1 : q.D;
+      m.clamp = q.clamp_min; m.rinv = (q.kparam != 0.0) ? 1.0 / q.kparam : 1.0; m.pi_const = q.pi_const; m.kfun = q.kfun;
+      m.nll = nll_dev + f0 + z;
+      if (gg) {
+        m.g_w = gg->g_w_dev; m.g_amp = gg->g_amp_dev; m.g_dadd = gg->g_diag_add_dev; m.g_Y = gg->g_Y_dev; m.g_dvec = gg->g_diag_vec_dev;
+      }
+      m.want_grad = (m.g_w || m.g_amp || m.g_dadd || m.g_Y || m.g_dvec) ? 1 : 0;
+      m.kbuf = h->small_kbuf + (size_t)z * TR_NBLK * 256;
+      Dmax = std::max(Dmax, q.D);
+    }
+    if (Dmax <= 8)
+      hipLaunchKernelGGL(ffgp_small_mfma_kernel<8>, dim3(nb), dim3(TR_T), TR_LDS_DOUBLES * sizeof(double), h->stream, b, cm);
+    else
+      hipLaunchKernelGGL(ffgp_small_mfma_kernel<16>, dim3(nb), dim3(TR_T), TR_LDS_DOUBLES * sizeof(double), h->stream, b, cm);
+  }
+  return hipGetLastError() == hipSuccess ? FFGP_OK : FFGP_ERR_HIP;
 }

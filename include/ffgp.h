@@ -494,7 +494,10 @@ int ffgp_nlml_fused_raw_async(ffgp_handle* h, const ffgp_problem* p, const ffgp_
    experiments (Experiments/GAR_Aligned/exp_aligned.py:58-126; every model there has N = 16 ... 128) call cigp.negative_log_likelihood
    for one such model after the other.  p, g: arrays of F; links: array of F (raw parameters, as ffgp_nlml_fused_raw) or NULL
    (effective parameters); problem f's value lands in nll_dev[f].  The status is shared: a Sigma that is not positive definite in
-   ANY member is reported (as that member's leading minor).  The _async form only enqueues (status: next ffgp_wait).             */
+   ANY member is reported (as that member's leading minor).  The _async form only enqueues (status: next ffgp_wait).
+   Since round 6 problems within the one-launch trainer's limits (V1 likelihood, no add_mat / add_all / mean_jitter, no g_kparam) run on
+   its matrix-core kernel (csrc/train.hip, evaluate mode: eight models per launch), as does ffgp_nlml_fused_raw at n <= 128; the others
+   keep the scalar one-workgroup kernel.  Option "train_persist" = 0 restores the old routing.                                     */
 int ffgp_nlml_fused_small_batch(ffgp_handle* h, int F, const ffgp_problem* p, const ffgp_links* links, double* nll_dev,
                                 const ffgp_grads* g);
 
