@@ -301,11 +301,17 @@ __device__ __forceinline__ void tr_body(const TrainModel& M, const TrainCommon& 
   int failed = 0;
   long t_prof = cm.prof ? wall_clock64() : 0;
   const int nsteps = TRAIN ? cm.steps : 1;
+  const int lane_k = lane, wave_k = wave;
   for (int step = 0; step < nsteps; ++step) {
+    // (the lane coordinates opaque per iteration: otherwise every per-lane offset of every phase is hoisted out of the step loop and kept
+    //  alive across it -- 256 registers and 79 spilled ones, reloaded inside the phases)
+    int lane = lane_k, wave = wave_k;
+    asm volatile("" : "+v"(lane), "+s"(wave));
+    const int g = lane >> 4, c = lane & 15;
     // ---- P0: scaled inputs (the effective parameters were refreshed by the threads that updated the raw ones)
-    for (int idx = tid; idx < n * D; idx += TR_T) {
+    for (int idx = tid; idx < n * D; idx += TR_T) {      // (shifted by the first point: only differences enter the kernel)
       const int i = idx / D, k = idx - i * D;
-      Xs[i * (TR_D + 1) + k] = M.X[idx] * wv[k];
+      Xs[i * (TR_D + 1) + k] = (M.X[idx] - M.X[k]) * wv[k];
     }
     TR_BARRIER();
     const double amp = sc[0], dadd = sc[1];
@@ -494,11 +500,16 @@ __device__ __forceinline__ void tr_body(const TrainModel& M, const TrainCommon& 
     }
     TR_PROF(6);
 
-    // ---- P5: per lane partial sums -- ss (value), s_amp, tr G, tot[k] (length scales); Sigma^-1 block by block on the matrix cores
+    // ---- P5: per lane partial sums -- ss (value), s_amp, tr G, tot[k] (length scales); Sigma^-1 block by block on the matrix cores.
+    // (The length-scale sums through the matrix cores as well -- tot_k = sum_j [V_jk + x_jk^2 c_j - 2 x_jk U_jk] with U | V = W_low^T [X | X^2]
+    //  as one MFMA group per block, the block's weights used as the A operand straight from the accumulator layout, added into an LDS
+    //  image -- was built, passed every test and measured SLOWER: 12.4 against 10.2 us at n = 128, D = 5; four LDS atomics per lane and block
+    //  and two more barriers cost more than the 24 vector instructions per entry they replace.)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this lane's parked kernel values have landed (long ago)
     double ss = 0.0, s_amp = 0.0, trg = 0.0, tk[DM];
 #pragma unroll
     for (int k = 0; k < DM; ++k) tk[k] = 0.0;
+    const double lpiv = (tid < n) ? log(piv[tid]) : 0.0;
 #pragma unroll
     for (int q = 0; q < TR_N * TR_Y / TR_T; ++q) ss = __builtin_fma(Gam[tid + TR_T * q], Gam[tid + TR_T * q], ss);
     for (int q_ = 0; q_ < 5 && (TRAIN || M.want_grad); ++q_) {
@@ -551,7 +562,7 @@ __device__ __forceinline__ void tr_body(const TrainModel& M, const TrainCommon& 
       constexpr int NV = 4 + DM;
       double vals[NV];
       vals[0] = ss; vals[1] = s_amp; vals[2] = trg;
-      vals[3] = (tid < n) ? log(piv[tid]) : 0.0;
+      vals[3] = lpiv;
 #pragma unroll
       for (int k = 0; k < DM; ++k) vals[4 + k] = tk[k];
 #pragma unroll

@@ -170,10 +170,14 @@ def train_many(models, xs, ys, steps, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, sta
     else:
         rcs += [([f], run([f])) for f in large]
     # the library wrote the parameters behind autograd's back: bump their version counters (cached posteriors key on them)
+    bump = getattr(torch.autograd.graph, "increment_version", None)      # (torch >= 2.1: no kernel; else an in-place no-op add)
     with torch.no_grad():
         for m in models:
             for q in m.parameters():
-                q.add_(0.0)
+                if bump is not None:
+                    bump(q)
+                else:
+                    q.add_(0.0)
     for idx, rc in rcs:
         if rc > 0:
             _raise_not_pd(rc, "linalg.cholesky (train_many, model%s %s)" % ("s" if len(idx) > 1 else "", ", ".join(map(str, idx))))
