@@ -1636,6 +1636,42 @@ def test_hogp_block_full_size_properties():
     assert float((mu - Y[:16]).abs().max()) < float(Y.abs().max())     # interpolates towards the data, not garbage
 
 
+@pytest.mark.timeout(300)
+def test_hogp_block_n3000_vs_oracle():
+    """between the N = 64 reference fixtures and the property test at N = 8192: one HOGP block at N = 3000 (not a multiple of the
+    eigensolver's 64-row padding), d = 12 x 10, against the numpy restatement of HOGP_simple.log_likelihood
+    (two_fidelity_models/hogp_simple.py:79-126; LAPACK eigh on the host) -- the loss, the eigenvalue sum A, the cached solve g and the
+    posterior mean at 20 points"""
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.hogp_simple import HOGP_simple
+    from oracle import gp_oracle as O
+    n, d1, d2, D = 3000, 12, 10, 4
+    rng = np.random.default_rng(31)
+    Xn = rng.uniform(0, 1, (n, D))
+    Yn = np.sin(3.0 * Xn @ rng.uniform(0.5, 1.5, (D, d1 * d2))).reshape(n, d1, d2) + 0.05 * rng.standard_normal((n, d1, d2))
+    ls = np.array([0.7, -1.1, 0.9, 1.3])
+    k = kernel.ARDKernel(D)
+    with torch.no_grad():
+        k.length_scales.copy_(torch.tensor(ls))
+        k.signal_variance.copy_(torch.tensor([1.2]))
+    m = HOGP_simple(k, 0.6, [d1, d2]).double().to(DEV)
+    loss = m.log_likelihood(T(Xn), T(Yn))
+    # the oracle on the model's own kernel matrices (the mode kernels are learnable parameters of the module)
+    Ks = [O.ard_kernel(Xn, Xn, ls, [1.2])] + [Km.detach().cpu().numpy() for Km in m.K[1:]]
+    want, A_ref, g_ref, _ = O.hogp_ll(Ks, Yn, m.noise_variance.detach().cpu().numpy())
+    assert abs(float(loss.detach()) - want) <= 1e-9 * abs(want), (float(loss.detach()), want)
+    assert rel(m.A.sum(), A_ref.sum()) < 1e-10
+    assert rel(m.g, g_ref) < 1e-6          # (g solves a system of condition ~ lam_max * noise)
+    with torch.no_grad():
+        mu, _ = m.forward(T(Xn), T(Xn[:20]))
+    mu_ref = g_ref
+    Kstar = O.ard_kernel(Xn[:20], Xn, ls, [1.2])
+    mu_ref = O._mode_dot(g_ref, Kstar, 0)
+    for i, Km in enumerate(Ks[1:]):
+        mu_ref = O._mode_dot(mu_ref, Km, i + 1)
+    assert rel(mu, mu_ref) < 1e-6
+
+
 @pytest.mark.parametrize("where", ["cuda", "cpu"])
 def test_withmean_and_multitask_golden(golden, where):
     """the two hand-written GP modules next to cigp_v10 (GaussianProcess/cigp_withMean.py:29-64, MultiTaskGP_cigp.py:14-50):
