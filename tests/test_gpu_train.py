@@ -163,6 +163,45 @@ def test_one_launch_trainer_stops_only_the_model_that_failed():
             assert rel(a, b) < 1e-12
 
 
+@pytest.mark.parametrize("n,D,d", [(1, 1, 1), (2, 3, 1), (15, 2, 2), (16, 16, 16), (17, 1, 3), (31, 8, 1), (33, 9, 5), (64, 8, 16), (127, 16, 16),
+                                    (128, 16, 16), (128, 1, 1)])
+def test_one_workgroup_kernel_edge_shapes_against_the_oracle(n, D, d):
+    """csrc/train.hip at the corners of what it accepts -- one point, one stage and one row more, the D <= 8 / <= 16 instantiations at
+    their limits, 16 target columns, the full 128 x 128 image -- (i) in evaluate mode through the drop-in module: value and every gradient
+    `loss.backward()` leaves against the numpy oracle of GaussianProcess/cigp_v10.py:50-69; (ii) as the trainer: three Adam steps
+    against the reference's loop"""
+    from fidelityfusion_amd import kernel
+    from fidelityfusion_amd.cigp_v10 import cigp, train_many
+    from oracle import gp_oracle as O
+    rng = np.random.default_rng(1000 * n + 10 * D + d)
+    X = rng.uniform(0, 1, (n, D))
+    Y = rng.standard_normal((n, d))
+    ls = rng.uniform(0.5, 1.5, D) * rng.choice([-1.0, 1.0], D)
+    sv, lb = [-0.9], [0.4]
+    k = kernel.ARDKernel(D)
+    with torch.no_grad():
+        k.length_scales.copy_(torch.tensor(ls))
+        k.signal_variance.copy_(torch.tensor(sv))
+    m = cigp(k, lb[0]).double().to(DEV)
+    Xt, Yt = T(X), T(Y).requires_grad_(True)
+    ll = m.negative_log_likelihood(Xt, Yt)
+    ll.backward()
+    ll_ref, g_ref = O.cigp_ll_and_grads(X, Y, ls, sv, lb)
+    assert rel(ll.detach(), ll_ref) < 1e-10
+    assert rel(k.length_scales.grad, g_ref["length_scales"]) < 1e-8
+    assert rel(k.signal_variance.grad, g_ref["signal_variance"]) < 1e-8
+    assert rel(m.log_beta.grad, g_ref["log_beta"]) < 1e-8
+    assert rel(Yt.grad, g_ref["Y"]) < 1e-8
+    twin = copy.deepcopy(m)
+    for q in list(m.parameters()) + list(twin.parameters()):
+        q.grad = None
+    trace, _ = train_many([m], [Xt], [Yt.detach()], 3, lr=1e-2)
+    ref = reference_loop([twin], [Xt], [Yt.detach()], 3, 1e-2)
+    assert rel(trace, ref) < 1e-11
+    for a, b in zip(params_of(m), params_of(twin)):
+        assert rel(a, b) < 1e-11
+
+
 def test_train_many_on_the_reference_fixture(golden):
     """tests/golden/resgp_chain.npz: the reference's train_ResGP on a seeded two-fidelity problem, 5 Adam steps per fidelity
     (FidelityFusion_Models/ResGP.py:67-112; the second fidelity's targets come with a y_var matrix) -- both fidelities as ONE
