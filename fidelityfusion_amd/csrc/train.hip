@@ -1,22 +1,27 @@
-// K Adam steps of F small models in ONE launch (round 6) -- the reference's hot loop at the sizes its experiments run
-// (FidelityFusion_Models/ResGP.py:78-112, GaussianProcess/cigp_v10.py:92-104: per fidelity 100-1000 iterations of zero_grad / loss =
-// -negative_log_likelihood / backward / Adam step at N = 16 ... 128; Experiments/GAR_Aligned/exp_aligned.py:66-74: 100 low- against 4..32
-// high-fidelity points).  ffgp_train_raw used to enqueue 13 dependent launches per step at n = 128 (0.096 ms per step, two thirds of
-// it launch floors).  Here one PERSISTENT workgroup per model (gridDim.x = models, 512 threads) runs every step inside the kernel:
+// One workgroup, one small GP: K Adam steps of F models in ONE launch, and the per-step likelihood + gradient call (round 6).
+// The reference's hot loop runs at the sizes of its experiments (FidelityFusion_Models/ResGP.py:78-112, GaussianProcess/cigp_v10.py:92-104:
+// per fidelity 100-1000 iterations of zero_grad / loss = -negative_log_likelihood / backward / Adam step at N = 16 ... 128;
+// Experiments/GAR_Aligned/exp_aligned.py:66-74: 100 low- against 4..32 high-fidelity points).  ffgp_train_raw used to enqueue 13 dependent
+// launches per step at n = 128 (0.096 ms per step, two thirds of it launch floors).  Here one PERSISTENT workgroup per model
+// (gridDim.x = models, 512 threads) runs every step inside the kernel:
 //
-//   links (raw -> effective parameters)  ->  Sigma assembled straight into LDS as 16 x 16 blocks [16][17] (lower block triangle, 78 KiB)
-//   ->  blocked Cholesky: the 16 x 16 diagonal block is factored AND inverted in registers by wave 0 on the DP-ALU DPP pivot step of the
-//       diagonal-block kernel (f16_steps.h), the blocks below are solved with that inverse and the trailing blocks updated on the matrix
-//       cores by all eight waves; only ceil(n / 16) stages run, so n = 32 costs a quarter of n = 128
-//   ->  L^-1 in place by recursive doubling on the matrix cores  ->  Gamma = L^-1 Y, A = L^-T Gamma, the value
+//   links (raw -> effective parameters)  ->  Sigma assembled straight into LDS as 16 x 16 blocks [16][17] (lower block triangle, 78 KiB),
+//       the kernel values parked in a global scratch for the gradient pass
+//   ->  blocked Cholesky AND inverse, two workgroup barriers per 16-column stage: wave 0 factors + inverts the diagonal block in
+//       registers on the DP-ALU DPP pivot step of f16_steps.h while the helper waves apply the previous column and form the previous row
+//       of the inverse; then all eight waves solve the column.  Only ceil(n / 16) stages run: n = 32 costs a quarter of n = 128.
+//       (This loop became the factorisation's diagonal-block kernel, ffgp_potrf_diag128_v4 in potrf.hip.)
+//   ->  Gamma = L^-1 Y, A = L^-T Gamma as MFMA block chains on zero-padded [128][16] images, the value
 //   ->  Sigma^-1 = L^-T L^-1 block by block on the matrix cores, each 16 x 16 block consumed in its accumulators: G = d/2 Sigma^-1 - 1/2 A A^T,
-//       the kernel re-evaluated for the entry, the gradient sums of grad.hip (amplitude, length scales, trace) -- Sigma^-1 is never stored
-//   ->  the links' chain rule and torch.optim.Adam's update (operation for operation as ffgp_adam_kernel) on parameters and moments that
-//       live in LDS for the whole call; the step's loss goes to the trace.
+//       the gradient sums of grad.hip (amplitude, length scales, trace) -- Sigma^-1 is never stored
+//   ->  one workgroup reduction, the links' chain rule and torch.optim.Adam's update (operation for operation as ffgp_adam_kernel) on
+//       parameters and moments that live in LDS for the whole call; the step's loss goes to the trace.
 // A Sigma that is not positive definite stops THAT model at that step (its status word, NaN in its trace from there on, parameters as
 // they were when the step began); the other models of the launch train on.
+// EVALUATE mode (tr_body<DM, false>, ffgp_small_mfma_kernel): the same pass once, without Adam -- value, raw-parameter gradients, dL/dY and
+// diag G written out -- for ffgp_nlml_fused_small_batch and ffgp_nlml_fused_raw at n <= 128.
 // Covers: n <= 128, D <= 16, d <= 16, one radial-profile kernel, V1 likelihood, diag_add and diag_vec (no matrix / all-entries /
-// mean(K) extras, no learnable profile parameter): what cigp_v10.train_many produces.  Everything else stays on the launch-per-stage path.
+// mean(K) extras, no learnable profile parameter): what cigp_v10 produces.  Everything else keeps the paths it had.
 #include "ffgp_internal.h"
 #include "f16_steps.h"
 
@@ -147,22 +152,6 @@ __device__ __forceinline__ void tr_mma_nt(tr_d4& acc, const double* pa, const do
   for (int kq = 0; kq < 4; ++kq) {
     const int k = kq * 4 + (lane >> 4);
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[(lane & 15) * TR_BLD + k], pb[(lane & 15) * TR_BLD + k], acc, 0, 0, 0);
-  }
-}
-// acc += P * Q: P[m][k] at pa[m * 17 + k], Q[k][n] at pb[k * 17 + n]
-__device__ __forceinline__ void tr_mma_nn(tr_d4& acc, const double* pa, const double* pb, int lane) {
-#pragma unroll
-  for (int kq = 0; kq < 4; ++kq) {
-    const int k = kq * 4 + (lane >> 4);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[(lane & 15) * TR_BLD + k], pb[k * TR_BLD + (lane & 15)], acc, 0, 0, 0);
-  }
-}
-// acc += P^T * Q: P[k][m] at pa[k * 17 + m], Q[k][n] at pb[k * 17 + n]
-__device__ __forceinline__ void tr_mma_tn(tr_d4& acc, const double* pa, const double* pb, int lane) {
-#pragma unroll
-  for (int kq = 0; kq < 4; ++kq) {
-    const int k = kq * 4 + (lane >> 4);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k * TR_BLD + (lane & 15)], pb[k * TR_BLD + (lane & 15)], acc, 0, 0, 0);
   }
 }
 // acc += sum_{kb = k0}^{k1 - 1} op(P_kb) * Q_kb over 16 x 16 blocks, the NEXT block's operands requested before this block's four MFMAs
