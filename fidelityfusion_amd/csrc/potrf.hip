@@ -1840,7 +1840,7 @@ __global__ void ffgp_handoff_gate(const unsigned* __restrict__ word, unsigned ne
       return;
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // (no fence of its own: the kernels behind the gate acquire at their dispatch, as after any kernel boundary)
 }
 // Create-time self-test across two streams (api.hip, create_resources): the gate is enqueued on the side stream FIRST, the write that
 // satisfies it on the handle's own stream afterwards.  Where kernels of different queues can run side by side the gate sees the value
