@@ -15,6 +15,10 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 dev = torch.device("cuda", 0)
+for kv in os.environ.get("FFGP_OPTS", "").split(","):      # library options, "k=v,k=v"
+    if kv:
+        from fidelityfusion_amd import _lib
+        _lib.set_option(kv.split("=")[0], float(kv.split("=")[1]), 0)
 X, Y = synthetic_xy(n, D, 1, seed=0)
 Xd, Yd = torch.tensor(X, device=dev), torch.tensor(Y, device=dev)
 w = torch.ones(D, dtype=torch.float64, device=dev)
