@@ -327,6 +327,9 @@ int ffgp_create(int device, ffgp_handle** out) {
   h->q2_wave4 = 1;
   h->q2_split_min_cols = 8192;
   h->sb_qr4 = 0;
+  h->sb_lower = 1;
+  h->sb_lower_min_n = 6144;
+  h->sb_sym_wg = 2048;
   h->asm_mm = 1;
   h->asm_mm_min = 6144;
   h->asm_mm_grid = 768;
@@ -571,6 +574,14 @@ int ffgp_set_option(ffgp_handle* h, const char* key, double value) {
     h->trtri_overlap = (int)value;
   } else if (!strcmp(key, "small_max_n")) {
     h->small_max_n = (int)value;
+  } else if (!strcmp(key, "sb_lower")) {
+    h->sb_lower = value != 0.0;
+  } else if (!strcmp(key, "sb_lower_min_n")) {
+    if (value < 0) return FFGP_ERR_ARG;
+    h->sb_lower_min_n = (int)value;
+  } else if (!strcmp(key, "sb_sym_wg")) {
+    if (value < 64 || value > 65536) return FFGP_ERR_ARG;
+    h->sb_sym_wg = (int)value;
   } else if (!strcmp(key, "sb_av_gemm")) {
     h->sb_av_gemm = (int)value;
   } else if (!strcmp(key, "sb_qr4")) {

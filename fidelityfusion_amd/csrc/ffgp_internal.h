@@ -282,6 +282,9 @@ struct ffgp_handle {
   int* d_info;       // device status word(s)
   double* d_scal;    // small device scalar scratch (64 doubles)
   // launch-bound sizes: the raw-parameter likelihood call replayed as a captured graph (api.hip, nlml_fused_raw_enqueue)
+  int sb_lower;                // option "sb_lower" (default 1): the band reduction keeps and reads only the LOWER triangle of the trailing matrix (sy2sb_av_sym) ...
+  int sb_lower_min_n;          // ... for matrices of at least this many rows (option "sb_lower_min_n", default 6144: below, the full form is as fast or faster)
+  int sb_sym_wg;               // option "sb_sym_wg" (default 2048): workgroups the lower-triangle A Y launch aims for (half of them exit: chunks right of the diagonal)
   int sb_av_gemm;              // option "sb_av_gemm" (default 0): 1 = the band reduction's A Y product on the general GEMM again
   int q2_blocks_lanes;         // how the last q2_prep wrote its blocks (1: lane order for q2_apply_wave4)
   int sb_qr4;                  // option "sb_qr4" (default 0): 1 = the band reduction's leaf QRs on 256 threads, four columns per half-wave (sy2sb_leaf_qr4)

@@ -659,8 +659,128 @@ __global__ __launch_bounds__(256, 4) void sy2sb_av(AvArgs p) {
     }
 }
 
+// Yp-partials from the LOWER triangle of A22 alone (round 6, option "sb_lower", default).  The trailing update is bound by HBM (rank 64:
+// 8 flop per byte of C), and A22 Y read the whole matrix once more per panel; A22 is symmetric, so the update now writes only its lower
+// triangle (half the bytes: the GEMM's lower-trapezoid tile set) and this kernel reads only that -- every element A[i][k], k < i, serves
+// both  Yp[i] += A[i][k] Y[k]  and  Yp[k] += A[i][k] Y[i].  A workgroup owns 128 rows x one k chunk as before (chunks right of its rows
+// belong to other workgroups' transposed side and exit at once); per k step (128 x 16 tile through LDS, strictly-upper entries of a
+// tile on the diagonal stored as zeros) waves 0-1 compute the direct product for 64 rows each, waves 2-3 the transposed one (16 columns
+// of A x one half of Y's 32 columns each, summed over all 128 rows: Y's rows of the workgroup sit in registers for the whole launch) --
+// 32 MFMAs per wave and step either way, no reduction across waves.  Direct partials P[chunk][row][32] as before; transposed partials
+// PT[row block][column][32]; sy2sb_red adds, for row j, the chunks left of its row block's end and the row blocks from its own
+// downwards, in that fixed order.
+struct AvSymArgs {
+  const double* A; int lda;      // A22 (lower triangle valid), m x m row-major
+  const double* Y; int ldy;      // Y, m x 32
+  double* P; long sP;            // direct partials [parts][m][32]
+  double* PT; long sPT;          // transposed partials [row blocks][m][32]
+  int m, kc;
+};
+
+// (workgroup barrier that publishes LDS only: __syncthreads() also waits for the wave's global loads -- the next tiles, which are meant to
+//  stay in flight across the step -- and for the transposed partials' stores, which nobody in this launch reads)
+#define AV_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+__global__ __launch_bounds__(256, 3) void sy2sb_av_sym(AvSymArgs p) {
+  __shared__ double As[128][17];
+  __shared__ double Ys[16][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lq = lane >> 4;
+  const int r0 = blockIdx.x * 128;
+  const int k0 = blockIdx.y * p.kc, k1 = min(min(p.m, k0 + p.kc), r0 + 128);
+  if (k0 >= k1) return;
+  const int arow = tid >> 1, acol = (tid & 1) * 8;
+  const double* __restrict__ ap = p.A + (size_t)min(r0 + arow, p.m - 1) * p.lda + acol;
+  const int yk = tid >> 4, yc = (tid & 15) * 2;
+  const double* __restrict__ yp = p.Y + yc;
+  struct Tile { d4_t a0, a1; d2_t y; };
+  auto fetch = [&](int k, Tile& t) {
+    t.a0 = *reinterpret_cast<const d4_t*>(ap + k);
+    t.a1 = *reinterpret_cast<const d4_t*>(ap + k + 4);
+    t.y = *reinterpret_cast<const d2_t*>(yp + (size_t)(k + yk) * p.ldy);
+  };
+  const bool direct = wave < 2;
+  const int ct = wave & 1;                 // transposed waves: their half of Y's columns
+  d4_t acc[4][2];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) acc[rt][c2] = d4_t{0.0, 0.0, 0.0, 0.0};
+  // transposed waves keep Y[r0 + 4 s + lq][16 ct + lr] (zero beyond the matrix), s = 0 .. 31, in the registers the direct waves use as
+  // accumulators: acc[s >> 3][(s >> 2) & 1][s & 3]
+  if (!direct) {
+#pragma unroll
+    for (int s_ = 0; s_ < 32; ++s_) {
+      const int row = r0 + 4 * s_ + lq;
+      acc[s_ >> 3][(s_ >> 2) & 1][s_ & 3] = (row < p.m) ? p.Y[(size_t)row * p.ldy + 16 * ct + lr] : 0.0;
+    }
+  }
+  double* __restrict__ outT = p.PT + (size_t)blockIdx.x * p.sPT;
+  auto step = [&](const Tile& t, const int k) {
+    AV_BARRIER();                          // the previous step's operand reads are done
+    const bool on_diag = k + 15 > r0;      // the tile reaches the diagonal: entries right of it are not part of the lower triangle
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool up0 = on_diag && (k + acol + q > r0 + arow), up1 = on_diag && (k + acol + 4 + q > r0 + arow);
+      As[arow][acol + q] = up0 ? 0.0 : t.a0[q];
+      As[arow][acol + 4 + q] = up1 ? 0.0 : t.a1[q];
+    }
+    Ys[yk][yc] = t.y.x;
+    Ys[yk][yc + 1] = t.y.y;
+    AV_BARRIER();
+    if (direct) {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        double av[4], bv[2];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) av[rt] = As[64 * wave + 16 * rt + lr][4 * s4 + lq];
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) bv[c2] = Ys[4 * s4 + lq][16 * c2 + lr];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2) acc[rt][c2] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[rt], bv[c2], acc[rt][c2], 0, 0, 0);
+      }
+    } else {
+      d4_t at[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};      // even / odd k steps: two independent chains, added at the end
+#pragma unroll
+      for (int s_ = 0; s_ < 32; ++s_) {
+        double a = As[4 * s_ + lq][lr];
+        if (on_diag && (r0 + 4 * s_ + lq == k + lr)) a = 0.0;      // the diagonal entry belongs to the direct side only
+        at[s_ & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[s_ >> 3][(s_ >> 2) & 1][s_ & 3], at[s_ & 1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) outT[(size_t)(k + lq + 4 * r) * 32 + 16 * ct + lr] = at[0][r] + at[1][r];
+    }
+  };
+  Tile ta, tb;
+  fetch(k0, ta);
+  if (k0 + 16 < k1) fetch(k0 + 16, tb);
+  for (int k = k0; k < k1; k += 32) {
+    step(ta, k);
+    if (k + 32 < k1) fetch(k + 32, ta);
+    if (k + 16 < k1) {
+      step(tb, k + 16);
+      if (k + 48 < k1) fetch(k + 48, tb);
+    }
+  }
+  if (direct) {
+    double* __restrict__ out = p.P + (size_t)blockIdx.y * p.sP;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + 64 * wave + 16 * rt + 4 * r + lq;
+        if (row < p.m) {
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2) out[(size_t)row * 32 + 16 * c2 + lr] = acc[rt][c2][r];
+        }
+      }
+  }
+}
+
 struct RedArgs {
   const double* P; long sP; int parts;   // partial products A22[:, chunk] Y[chunk, :], [parts][m][32]
+  const double* PT; long sPT; int kc;    // lower-triangle form (sy2sb_av_sym; null otherwise): transposed partials [row blocks][m][32], chunk length
   const double* Y; int ldy;
   double* Yp;                            // [m][32]  their sum
   double* Gpart;                         // [workgroups][32][32]  Y_blk^T Yp_blk
@@ -675,10 +795,20 @@ __global__ __launch_bounds__(1024) void sy2sb_red(RedArgs p) {
   const int row = blockIdx.x * 128 + lrow;
   double yp[4] = {0.0, 0.0, 0.0, 0.0}, y[4] = {0.0, 0.0, 0.0, 0.0};
   if (row < p.m) {
+    const int rbend = p.PT ? (row & ~127) + 128 : 0x7fffffff;      // (lower-triangle form: chunks right of the row block were never computed)
     for (int s = 0; s < p.parts; ++s) {
+      if (s * p.kc >= rbend) break;
       const d4_t v = *reinterpret_cast<const d4_t*>(p.P + (size_t)s * p.sP + (size_t)row * 32 + c4);
 #pragma unroll
       for (int q = 0; q < 4; ++q) yp[q] += v[q];
+    }
+    if (p.PT) {
+      const int nrb = (p.m + 127) >> 7;
+      for (int rb = row >> 7; rb < nrb; ++rb) {
+        const d4_t v = *reinterpret_cast<const d4_t*>(p.PT + (size_t)rb * p.sPT + (size_t)row * 32 + c4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) yp[q] += v[q];
+      }
     }
     d4_t o;
 #pragma unroll
@@ -781,13 +911,14 @@ __global__ void sy2sb_copy_diag(const double* __restrict__ A, int lda, double* _
   }
 }
 
-#define AV_MAX_PARTS 16
+#define AV_MAX_PARTS 32
 static inline int sy2sb_max_leaves(int n) { return max(16, (n + QR_ROWS - 1) / QR_ROWS); }
 size_t ffgp_sy2sb_ws_doubles(int n) {
   // Rst, Tst (all leaves), Rst2, Tst2 (middle level), Vtst, small (+ Mh), Yp, Gpart, VW, WV, partial products of the k-chunks
   return (size_t)sy2sb_max_leaves(n) * 1024 * 2 + (size_t)16 * 1024 * 2 + 512 * 32 + 4096 + (size_t)n * 32 + (size_t)(n / 128 + 1) * 1024 +
          (size_t)n * 64 * 2 +
-         (size_t)(AV_MAX_PARTS + 1) * n * 32 + 64;
+         (size_t)(AV_MAX_PARTS + 1) * n * 32 + 64 +
+         (size_t)(n / 128 + 1) * n * 32;      // transposed partials of the lower-triangle form (sy2sb_av_sym)
 }
 
 // A [n, n] full symmetric (destroyed), AB [n, 64] band out, Y [n, ldy] reflector store out (zero outside the staircase),
@@ -808,6 +939,9 @@ int ffgp_sy2sb_impl(ffgp_handle* h, double* A, int n, int lda, double* AB, doubl
   double* Mh = small + 3072;   // (small holds Xt | S | U^-1 in its first 2080 doubles)
   double* WV = VW + (size_t)n * 64;
   double* Ppart = WV + (size_t)n * 64;
+  double* PTpart = Ppart + (size_t)(AV_MAX_PARTS + 1) * n * 32 + 64;
+  // lower-triangle form: the trailing matrix is kept in its lower triangle only (the forms that read whole rows keep the full update)
+  const bool lower = h->sb_lower && n >= h->sb_lower_min_n && !h->sb_av_gemm && !h->sb_lookahead;
   FFGP_HIP(hipMemsetAsync(AB, 0, (size_t)n * SB_LDB * sizeof(double), st));
   FFGP_HIP(hipMemsetAsync(Y, 0, (size_t)n * ldy * sizeof(double), st));
   const int npan = n / 32 - 1;
@@ -856,7 +990,7 @@ int ffgp_sy2sb_impl(ffgp_handle* h, double* A, int n, int lda, double* AB, doubl
     // Yp = A22 Y  (m x m times m x 32; A22 K-major, Y stored k x n), cut along k into `parts` chunks that run as ONE batched launch
     // (enough workgroups to fill the chip whatever m is); the chunks are summed in fixed order by sy2sb_red, which also leaves
     // the pieces of G = Y^T Yp
-    int parts = min(AV_MAX_PARTS, max(1, (h->sb_av_gemm ? 1024 : 2048) / ((m + 63) / 64)));
+    int parts = min(lower ? AV_MAX_PARTS : 16, max(1, (h->sb_av_gemm ? 1024 : (lower ? h->sb_sym_wg : 2048)) / ((m + 63) / 64)));
     int kc = ((m + parts - 1) / parts + 31) & ~31;
     parts = m / kc;                       // full chunks; a shorter tail chunk runs as its own launch
     const int tail = m - parts * kc;
@@ -868,6 +1002,10 @@ int ffgp_sy2sb_impl(ffgp_handle* h, double* A, int n, int lda, double* AB, doubl
       if (tail > 0)
         FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_MNMAJOR, TILES_FULL, 0, A22 + (size_t)parts * kc, lda, Ypan + (size_t)parts * kc * ldy, ldy,
                                     Ppart + (size_t)parts * sP, 32, m, 32, tail, 1.0, 0.0));
+    } else if (lower) {
+      AvSymArgs av;
+      av.A = A22; av.lda = lda; av.Y = Ypan; av.ldy = ldy; av.P = Ppart; av.sP = sP; av.PT = PTpart; av.sPT = sP; av.m = m; av.kc = kc;
+      hipLaunchKernelGGL(sy2sb_av_sym, dim3((m + 127) / 128, parts + (tail > 0 ? 1 : 0)), dim3(256), 0, st, av);
     } else {
       AvArgs av;
       av.A = A22; av.lda = lda; av.Y = Ypan; av.ldy = ldy; av.P = Ppart; av.sP = sP; av.m = m; av.kc = kc;
@@ -875,6 +1013,7 @@ int ffgp_sy2sb_impl(ffgp_handle* h, double* A, int n, int lda, double* AB, doubl
     }
     RedArgs ra;
     ra.P = Ppart; ra.sP = sP; ra.parts = parts + (tail > 0 ? 1 : 0); ra.Y = Ypan; ra.ldy = ldy; ra.Yp = Yp; ra.Gpart = Gpart; ra.m = m;
+    ra.PT = lower ? PTpart : nullptr; ra.sPT = sP; ra.kc = kc;
     const int nred = (m + 127) / 128;
     hipLaunchKernelGGL(sy2sb_red, dim3(nred), dim3(1024), 0, st, ra);
     MArgs ma;
@@ -896,7 +1035,7 @@ int ffgp_sy2sb_impl(ffgp_handle* h, double* A, int n, int lda, double* AB, doubl
       FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, VW, 64, WV + 32 * 64, 64, A22 + 32, lda, m, m - 32, 64, -1.0, 1.0));
       FFGP_HIP(hipStreamWaitEvent(st, eq, 0));
     } else {
-      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, TILES_FULL, 0, VW, 64, WV, 64, A22, lda, m, m, 64, -1.0, 1.0));
+      FFGP_CHECK(ffgp_gemm_launch(h, OP_KMAJOR, OP_KMAJOR, lower ? TILES_LOWER : TILES_FULL, 0, VW, 64, WV, 64, A22, lda, m, m, 64, -1.0, 1.0));
       if (next) FFGP_CHECK(panel_qr(p + 1, st));
     }
   }

@@ -230,6 +230,12 @@ int ffgp_set_stream(ffgp_handle* h, void* hip_stream); /* hipStream_t; NULL rest
                         1 = zero-fill the whole buffer first (2 GB per step at N = 16384; +0.2 ms); 2 = fill it with NaN, a test mode),
             "sb_av_gemm" (default 0: the band reduction forms A * Y with its own 128-row kernel; 1 = the general GEMM -- measured
                         sy2sb 104 -> 91 ms at n = 8192, equal below n = 4096),
+            "sb_lower" (default 1) / "sb_lower_min_n" (default 6144): for matrices of at least that many rows ffgp_syevd's band
+                        reduction keeps only the LOWER triangle of the trailing matrix up to date (the rank-64 update is bound by
+                        HBM: half the bytes) and forms A * Y from that triangle alone (every element serves the product and its
+                        transpose); results agree with the full form to rounding.  n = 8192: update 21.8 -> 12.3 ms, A * Y and its
+                        sums 16.1 -> 20.6 ms, eigh 234.3 -> 229.7 ms; below ~6000 rows the full form is as fast.  "sb_sym_wg"
+                        (default 2048): workgroups the lower-triangle A * Y launch aims for,
             "sb_qr4" (default 0; 1: the band reduction's leaf QRs on 256-thread workgroups, four columns per half-wave -- 58.9 us per
                         panel against 54.4 us on 1024 threads at n = 8192; with "sb_lookahead" the only form whose leaves overlap
                         the trailing update, stage time equal either way),

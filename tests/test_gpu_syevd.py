@@ -79,6 +79,54 @@ def test_stage1_band_reduction_alternative_kernels(opts):
     assert np.abs(Q1 @ B @ Q1.T - A.numpy()).max() <= 2e-13 * scale
 
 
+@pytest.mark.parametrize("n,kind", [(64, "rand"), (128, "rand"), (192, "kern"), (576, "kern"), (1088, "rand"), (1600, "kern"), (2304, "rand")])
+def test_stage1_band_reduction_on_the_lower_triangle(n, kind):
+    """the default form for n >= 6144 (`sb_lower`: the trailing update writes, and A22 Y reads, the lower triangle only --
+    sy2sb_av_sym), forced at small sizes: same properties as the full form, its band within rounding of the full form's, the whole
+    solver on it; row blocks of 128 and k chunks at every alignment (n - 32 (p + 1) rows trail panel p: ragged last row blocks, chunks
+    cut by the diagonal, one-chunk and one-block panels)"""
+    from fidelityfusion_amd import _lib
+    from fidelityfusion_amd import eigh as E
+    A = (_random_sym(n, n) if kind == "rand" else _kernel_matrix(n, 3, 0.6, n))
+    AB_full, _ = E.sy2sb(A.to(DEV))
+    _lib.set_option("sb_lower_min_n", 64)
+    try:
+        AB, Y = E.sy2sb(A.to(DEV))
+        Q1 = E.ormq1(Y, torch.eye(n, dtype=torch.float64, device=DEV)).cpu().numpy()
+        lam, U = E.eigh(A.to(DEV))
+    finally:
+        _lib.set_option("sb_lower_min_n", 6144)
+    assert float(AB[:, 33:].abs().max()) == 0.0
+    B = _band_dense(AB)
+    ref = np.linalg.eigvalsh(A.numpy())
+    scale = np.abs(ref).max()
+    assert np.abs(np.linalg.eigvalsh(B) - ref).max() <= 5e-14 * scale
+    assert np.abs(Q1.T @ Q1 - np.eye(n)).max() <= 1e-13
+    assert np.abs(Q1 @ B @ Q1.T - A.numpy()).max() <= 2e-13 * scale
+    assert float((AB - AB_full).abs().max()) <= 1e-12 * scale        # same reflectors up to rounding: the two forms sum in different orders
+    lam, U = lam.cpu().numpy(), U.cpu().numpy()
+    assert np.abs(lam - ref).max() <= 5e-14 * scale
+    assert np.abs(U.T @ U - np.eye(n)).max() <= 2e-13
+    assert np.abs((U * lam) @ U.T - A.numpy()).max() <= 5e-13 * scale
+
+
+def test_syevd_at_the_size_where_the_lower_triangle_form_is_the_default():
+    """n = 6144 with the library's defaults (`sb_lower_min_n`): residual, orthogonality, and the spectrum against rocSOLVER's"""
+    from fidelityfusion_amd import eigh as E
+    n = 6144
+    g = torch.Generator(device=DEV).manual_seed(6144)
+    X = torch.rand((n, 6), generator=g, device=DEV, dtype=torch.float64)
+    d = torch.cdist(X, X)
+    K = torch.exp(-0.5 * d * d / 0.49) + 1e-3 * torch.eye(n, device=DEV, dtype=torch.float64)
+    del d
+    lam, U = E.eigh(K)
+    scale = float(lam.abs().max())
+    assert float((U.T @ U - torch.eye(n, device=DEV, dtype=torch.float64)).abs().max()) <= 2e-13
+    assert float(((U * lam) @ U.T - K).abs().max()) <= 1e-12 * scale
+    ref = torch.linalg.eigvalsh(K)
+    assert float((lam - ref).abs().max()) <= 1e-12 * scale
+
+
 @pytest.mark.parametrize("n", [64, 192, 640, 1216])
 def test_stage2_bulge_chasing(n):
     """sb2st: tridiagonal with the band's eigenvalues; B = Q2 T Q2^T with an orthogonal Q2 (through ormq2)"""

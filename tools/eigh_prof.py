@@ -4,6 +4,10 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from fidelityfusion_amd import eigh as E
+from fidelityfusion_amd import _lib
+for _kv in os.environ.get("FFGP_OPTS", "").split(","):      # library options, "k=v,k=v"
+    if _kv:
+        _lib.set_option(_kv.split("=")[0], float(_kv.split("=")[1]), 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 dev = "cuda:0"
 g = torch.Generator(device=dev).manual_seed(0)
