@@ -116,6 +116,8 @@ __device__ __forceinline__ void qr512(double (&a)[16], QrShared& sh, const int t
   __syncthreads();
   {   // T row by row: T[t][j] = -tau_j sum_{cc = t}^{j-1} T[t][cc] H[cc][j].  The rows are independent recurrences: row t runs on
       // half-wave t with T[t][cc] in lane cc, every step one product per lane and a half-wave sum -- no barrier, no serial inner loop
+      // (one row per LANE of a single wave, the entries in registers -- the form sy2sb_top's triangular solves take -- was measured
+      //  slower here: 49 -> 55 us per leaf; the 32 extra registers spill beside the block's 16 rows per lane)
     const int t = c;
     double trow = (i == t) ? sh.tau[t] : 0.0;
 #pragma unroll 4
@@ -440,23 +442,36 @@ __global__ __launch_bounds__(QR_THREADS) void sy2sb_top(TopArgs p) {
   // U (upper) -> M1;  T = U Y1^-T -> M2 (row i: forward substitution over the columns);  U^-1 -> Q0 (column by column)
   M1[i][c] = (c >= i) ? (((i == c) ? 1.0 : 0.0) - Ssign[c] * Wt[i][c]) : 0.0;
   __syncthreads();
-  {   // both triangular solves as independent half-wave recurrences (value of entry cc in lane cc, one half-wave sum per step):
-      // row c of T = U Y1^-T (forward over the columns) and column c of U^-1 (backward over the rows)
-    const double urow = M1[c][i];
-    const double dii = M1[i][i];
-    double m2 = 0.0, q = 0.0;
-#pragma unroll 4
+  // Both triangular solves, one ROW (of T = U Y1^-T, forward over the columns) or COLUMN (of U^-1, backward over the rows) per LANE with
+  // its 32 entries in registers: every coefficient (Y1[j][i], U[ii][i]) is the same for all lanes -- one broadcast LDS read -- and a step
+  // is a chain of plain multiply-adds.  (They ran as half-wave recurrences, one entry per lane and a half-wave sum per step, on all
+  // sixteen waves: 2 x 32 steps of ~50 instructions of reduction, four waves deep on every SIMD -- 14 us; here wave 0 does T while
+  // wave 1 does U^-1, 496 multiply-adds each.)
+  if (tid < 32) {                    // row c = tid of T:  T[c][j] = U[c][j] - sum_{i<j} T[c][i] Y1[j][i]
+    const int cr = tid;
+    double t[32];
+#pragma unroll
     for (int j = 0; j < 32; ++j) {
-      const int ii = 31 - j;
-      const double yv = V1[j][i];
-      const double uv = M1[ii][i];
-      const double s1 = qr_wsum32((i < j) ? m2 * yv : 0.0, lane);
-      const double s2 = qr_wsum32((i > ii && i <= c) ? uv * q : 0.0, lane);
-      if (i == j) m2 = urow - s1;
-      if (i == ii) q = (ii > c) ? 0.0 : (((ii == c) ? 1.0 : 0.0) - s2) / dii;
+      double acc_ = M1[cr][j];
+#pragma unroll
+      for (int i2 = 0; i2 < j; ++i2) acc_ = __builtin_fma(-t[i2], V1[j][i2], acc_);
+      t[j] = acc_;
     }
-    M2[c][i] = m2;
-    Q0[i][c] = q;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) M2[cr][j] = t[j];
+  } else if (tid >= 64 && tid < 96) {   // column c = tid - 64 of U^-1:  X[ii][c] = (delta - sum_{i>ii} U[ii][i] X[i][c]) / U[ii][ii], zero below the diagonal
+    const int cc_ = tid - 64;
+    double q[32];
+#pragma unroll
+    for (int jj = 0; jj < 32; ++jj) {
+      const int ii = 31 - jj;
+      double acc_ = (ii == cc_) ? 1.0 : 0.0;
+#pragma unroll
+      for (int i2 = ii + 1; i2 < 32; ++i2) acc_ = __builtin_fma(-M1[ii][i2], q[i2], acc_);
+      q[ii] = (ii > cc_) ? 0.0 : acc_ / M1[ii][ii];
+    }
+#pragma unroll
+    for (int ii = 0; ii < 32; ++ii) Q0[ii][cc_] = q[ii];
   }
   __syncthreads();
   QR_STAMP(36);
